@@ -1,0 +1,531 @@
+"""CPU oracle for the SmaAt-UNet forward+backward hot path.
+
+TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py may import this file.  The product package
+(smaat_unet_amd/) never imports it and has no CPU fallback.
+
+It is a plain-numpy restatement (forward AND hand-derived backward) of the
+arithmetic that the reference executes through torch.nn for the path named by
+BASELINE.json:north_star.  The arithmetic itself lives in a third-party
+dependency of the reference (torch==2.6.0, /root/reference/requirements.txt:56);
+every function cites the reference call site it restates.
+
+Pinning: the reference ships no tests or golden vectors, so
+the oracle is pinned against OUTPUTS OF THE REFERENCE ITSELF: oracle/gen_golden.py
+imports /root/reference/models/SmaAt_UNet.py in the build container, runs it on
+seeded inputs and commits activations + gradients under tests/golden/; the
+`-m "not gpu"` tests check every function here against those fixtures.
+
+Layout: NCHW, C-contiguous.  dtype follows the inputs (float32 for parity runs,
+float64 for the noise-floor studies).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# --------------------------------------------------------------------------- #
+# depthwise 3x3  (reference: models/layers.py:38-44, called :48)
+#   nn.Conv2d(Cin, Cin*kpl, 3, padding=1, groups=Cin): out channel o reads input
+#   channel o // kpl, cross-correlation, zero padding 1.
+# --------------------------------------------------------------------------- #
+
+
+def dw3x3_fwd(x, w, b, kpl):
+    n, cin, h, wd = x.shape
+    cdw = cin * kpl
+    assert w.shape == (cdw, 1, 3, 3)
+    xp = np.zeros((n, cin, h + 2, wd + 2), x.dtype)
+    xp[:, :, 1:-1, 1:-1] = x
+    xe = np.repeat(xp, kpl, axis=1)  # channel o <- o // kpl
+    y = np.zeros((n, cdw, h, wd), x.dtype)
+    for i in range(3):
+        for j in range(3):
+            y += w[None, :, 0, i, j, None, None] * xe[:, :, i:i + h, j:j + wd]
+    if b is not None:
+        y += b[None, :, None, None]
+    return y
+
+
+def dw3x3_bwd(x, w, dy, kpl):
+    """returns dx, dw, db"""
+    n, cin, h, wd = x.shape
+    cdw = cin * kpl
+    xp = np.zeros((n, cin, h + 2, wd + 2), x.dtype)
+    xp[:, :, 1:-1, 1:-1] = x
+    xe = np.repeat(xp, kpl, axis=1)
+    dwgt = np.zeros_like(w)
+    dxe = np.zeros_like(xe)
+    for i in range(3):
+        for j in range(3):
+            dwgt[:, 0, i, j] = np.einsum("nchw,nchw->c", dy, xe[:, :, i:i + h, j:j + wd])
+            dxe[:, :, i:i + h, j:j + wd] += w[None, :, 0, i, j, None, None] * dy
+    dxp = dxe.reshape(n, cin, kpl, h + 2, wd + 2).sum(axis=2)
+    dx = dxp[:, :, 1:-1, 1:-1].copy()
+    db = dy.sum(axis=(0, 2, 3))
+    return dx, dwgt, db
+
+
+# --------------------------------------------------------------------------- #
+# pointwise 1x1  (reference: models/layers.py:45, called :49;
+#                 OutConv models/unet_parts.py:67-73)
+# --------------------------------------------------------------------------- #
+
+
+def pw1x1_fwd(y, w, b):
+    w2 = w.reshape(w.shape[0], w.shape[1])
+    z = np.einsum("ok,nkhw->nohw", w2, y)
+    if b is not None:
+        z = z + b[None, :, None, None]
+    return z.astype(y.dtype, copy=False)
+
+
+def pw1x1_bwd(y, w, dz):
+    w2 = w.reshape(w.shape[0], w.shape[1])
+    dy = np.einsum("ok,nohw->nkhw", w2, dz)
+    dwgt = np.einsum("nohw,nkhw->ok", dz, y).reshape(w.shape)
+    db = dz.sum(axis=(0, 2, 3))
+    return dy.astype(y.dtype, copy=False), dwgt.astype(y.dtype, copy=False), db
+
+
+# --------------------------------------------------------------------------- #
+# BatchNorm2d, train mode  (reference: models/unet_parts_depthwise_separable.py:25,34
+#   and models/layers.py:120,127).  Biased variance for normalisation, unbiased
+#   variance into running_var, momentum 0.1, eps 1e-5 (torch.nn defaults).
+# --------------------------------------------------------------------------- #
+
+
+def bn_train_fwd(z, gamma, beta, eps=1e-5):
+    mean = z.mean(axis=(0, 2, 3), dtype=np.float64)
+    var = z.var(axis=(0, 2, 3), dtype=np.float64)
+    invstd = 1.0 / np.sqrt(var + eps)
+    mean32 = mean.astype(z.dtype)
+    invstd32 = invstd.astype(z.dtype)
+    y = (z - mean32[None, :, None, None]) * invstd32[None, :, None, None]
+    y = y * gamma[None, :, None, None] + beta[None, :, None, None]
+    return y.astype(z.dtype, copy=False), mean32, invstd32, var.astype(z.dtype)
+
+
+def bn_running_update(running_mean, running_var, mean, var_biased, count, momentum=0.1):
+    unbiased = var_biased * (count / max(count - 1, 1))
+    rm = (1 - momentum) * running_mean + momentum * mean
+    rv = (1 - momentum) * running_var + momentum * unbiased
+    return rm.astype(running_mean.dtype), rv.astype(running_var.dtype)
+
+
+def bn_eval_fwd(z, gamma, beta, running_mean, running_var, eps=1e-5):
+    invstd = (1.0 / np.sqrt(running_var.astype(np.float64) + eps)).astype(z.dtype)
+    y = (z - running_mean[None, :, None, None]) * invstd[None, :, None, None]
+    return (y * gamma[None, :, None, None] + beta[None, :, None, None]).astype(z.dtype, copy=False)
+
+
+def bn_train_bwd(z, gamma, mean, invstd, dy):
+    """returns dz, dgamma, dbeta"""
+    m = z.shape[0] * z.shape[2] * z.shape[3]
+    xhat = (z - mean[None, :, None, None]) * invstd[None, :, None, None]
+    dbeta = dy.sum(axis=(0, 2, 3), dtype=np.float64)
+    dgamma = (dy * xhat).sum(axis=(0, 2, 3), dtype=np.float64)
+    k1 = (dbeta / m).astype(z.dtype)[None, :, None, None]
+    k2 = (dgamma / m).astype(z.dtype)[None, :, None, None]
+    dz = (gamma * invstd)[None, :, None, None] * (dy - k1 - xhat * k2)
+    return dz.astype(z.dtype, copy=False), dgamma.astype(z.dtype), dbeta.astype(z.dtype)
+
+
+# --------------------------------------------------------------------------- #
+# ReLU (reference: unet_parts_depthwise_separable.py:26,35; layers.py:101)
+# --------------------------------------------------------------------------- #
+
+
+def relu_fwd(x):
+    return np.maximum(x, 0)
+
+
+def relu_bwd(y, dy):
+    return dy * (y > 0)
+
+
+# --------------------------------------------------------------------------- #
+# MaxPool2d(2)  (reference: unet_parts_depthwise_separable.py:48)
+# floor mode: odd trailing row/col is dropped.  First max in window scan order
+# (0,0),(0,1),(1,0),(1,1) receives the gradient.
+# --------------------------------------------------------------------------- #
+
+
+def maxpool2_fwd(x):
+    n, c, h, w = x.shape
+    ho, wo = h // 2, w // 2
+    xw = x[:, :, :ho * 2, :wo * 2].reshape(n, c, ho, 2, wo, 2).transpose(0, 1, 2, 4, 3, 5).reshape(n, c, ho, wo, 4)
+    idx = xw.argmax(axis=-1)  # first occurrence
+    y = np.take_along_axis(xw, idx[..., None], axis=-1)[..., 0]
+    return y, idx.astype(np.int8)
+
+
+def maxpool2_bwd(x_shape, idx, dy):
+    n, c, h, w = x_shape
+    ho, wo = h // 2, w // 2
+    g = np.zeros((n, c, ho, wo, 4), dy.dtype)
+    np.put_along_axis(g, idx[..., None].astype(np.int64), dy[..., None], axis=-1)
+    dx = np.zeros(x_shape, dy.dtype)
+    dx[:, :, :ho * 2, :wo * 2] = g.reshape(n, c, ho, wo, 2, 2).transpose(0, 1, 2, 4, 3, 5).reshape(n, c, ho * 2, wo * 2)
+    return dx
+
+
+# --------------------------------------------------------------------------- #
+# nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+#   (reference: unet_parts_depthwise_separable.py:64): src = dst*(Hin-1)/(Hout-1)
+# --------------------------------------------------------------------------- #
+
+
+def _ac_coeffs(n_in, n_out, dtype):
+    # mirrors ATen area_pixel_compute_scale/source_index for align_corners=True
+    scale = dtype((n_in - 1) / (n_out - 1)) if n_out > 1 else dtype(0)
+    src = (np.arange(n_out, dtype=dtype) * scale).astype(dtype)
+    i0 = np.floor(src).astype(np.int64)
+    i0 = np.minimum(i0, n_in - 1)
+    i1 = np.minimum(i0 + 1, n_in - 1)
+    l1 = (src - i0.astype(dtype)).astype(dtype)
+    l0 = (dtype(1) - l1).astype(dtype)
+    return i0, i1, l0, l1
+
+
+def upsample2x_fwd(x):
+    n, c, h, w = x.shape
+    dt = x.dtype.type
+    r0, r1, a0, a1 = _ac_coeffs(h, 2 * h, dt)
+    c0, c1, b0, b1 = _ac_coeffs(w, 2 * w, dt)
+    top = x[:, :, r0, :]
+    bot = x[:, :, r1, :]
+    tl, tr = top[:, :, :, c0], top[:, :, :, c1]
+    bl, br = bot[:, :, :, c0], bot[:, :, :, c1]
+    a0 = a0[None, None, :, None]
+    a1 = a1[None, None, :, None]
+    b0 = b0[None, None, None, :]
+    b1 = b1[None, None, None, :]
+    return (a0 * (b0 * tl + b1 * tr) + a1 * (b0 * bl + b1 * br)).astype(x.dtype, copy=False)
+
+
+def upsample2x_bwd(x_shape, dy):
+    n, c, h, w = x_shape
+    dt = dy.dtype.type
+    r0, r1, a0, a1 = _ac_coeffs(h, 2 * h, dt)
+    c0, c1, b0, b1 = _ac_coeffs(w, 2 * w, dt)
+    dx = np.zeros(x_shape, dy.dtype)
+    for (ri, ra) in ((r0, a0), (r1, a1)):
+        for (ci, cb) in ((c0, b0), (c1, b1)):
+            contrib = dy * ra[None, None, :, None] * cb[None, None, None, :]
+            # scatter-add rows then cols
+            tmp = np.zeros((n, c, h, 2 * w), dy.dtype)
+            np.add.at(tmp, (slice(None), slice(None), ri, slice(None)), contrib)
+            np.add.at(dx, (slice(None), slice(None), slice(None), ci), tmp)
+    return dx
+
+
+# --------------------------------------------------------------------------- #
+# F.pad + torch.cat([x2, x1], dim=1)  (reference: unet_parts_depthwise_separable.py:76-85)
+# --------------------------------------------------------------------------- #
+
+
+def pad_cat_fwd(x1_up, x2):
+    dy_ = x2.shape[2] - x1_up.shape[2]
+    dx_ = x2.shape[3] - x1_up.shape[3]
+    assert dy_ >= 0 and dx_ >= 0, "negative pad (crop) not restated"
+    x1p = np.pad(x1_up, ((0, 0), (0, 0), (dy_ // 2, dy_ - dy_ // 2), (dx_ // 2, dx_ - dx_ // 2)))
+    return np.concatenate([x2, x1p], axis=1)
+
+
+def pad_cat_bwd(x1_up_shape, x2_shape, dcat):
+    c2 = x2_shape[1]
+    dy_ = x2_shape[2] - x1_up_shape[2]
+    dx_ = x2_shape[3] - x1_up_shape[3]
+    dx2 = dcat[:, :c2]
+    t, l = dy_ // 2, dx_ // 2
+    dx1 = dcat[:, c2:, t:t + x1_up_shape[2], l:l + x1_up_shape[3]]
+    return dx1, dx2
+
+
+# --------------------------------------------------------------------------- #
+# ChannelAttention  (reference: models/layers.py:90-111)
+#   AdaptiveAvgPool2d(1), AdaptiveMaxPool2d(1) -> shared MLP (Linear, ReLU, Linear)
+#   applied to both -> sum -> sigmoid -> broadcast multiply
+# --------------------------------------------------------------------------- #
+
+
+def sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def channel_att_fwd(x, w1, b1, w2, b2):
+    n, c, h, w = x.shape
+    xf = x.reshape(n, c, h * w)
+    avg = xf.mean(axis=2, dtype=np.float64).astype(x.dtype)
+    amax_idx = xf.argmax(axis=2)
+    mx = np.take_along_axis(xf, amax_idx[..., None], axis=2)[..., 0]
+    ha = np.maximum(avg @ w1.T + b1, 0)
+    hm = np.maximum(mx @ w1.T + b1, 0)
+    out = (ha @ w2.T + b2) + (hm @ w2.T + b2)
+    s = sigmoid(out).astype(x.dtype)
+    y = x * s[:, :, None, None]
+    cache = dict(avg=avg, mx=mx, amax_idx=amax_idx, ha=ha, hm=hm, s=s)
+    return y, cache
+
+
+def channel_att_bwd(x, w1, b1, w2, b2, cache, dy):
+    n, c, h, w = x.shape
+    p = h * w
+    s, ha, hm = cache["s"], cache["ha"], cache["hm"]
+    ds = (dy * x).sum(axis=(2, 3), dtype=np.float64).astype(x.dtype)
+    dout = ds * s * (1 - s)
+    dw2 = dout.T @ (ha + hm)
+    db2 = 2 * dout.sum(axis=0)
+    dh = dout @ w2
+    dha = dh * (ha > 0)
+    dhm = dh * (hm > 0)
+    dw1 = dha.T @ cache["avg"] + dhm.T @ cache["mx"]
+    db1 = dha.sum(axis=0) + dhm.sum(axis=0)
+    davg = dha @ w1
+    dmx = dhm @ w1
+    dx = dy * s[:, :, None, None] + (davg / p).astype(x.dtype)[:, :, None, None]
+    dxf = dx.reshape(n, c, p)
+    np.put_along_axis(dxf, cache["amax_idx"][..., None],
+                      np.take_along_axis(dxf, cache["amax_idx"][..., None], axis=2) + dmx[..., None], axis=2)
+    return dxf.reshape(x.shape), dw1.astype(x.dtype), db1.astype(x.dtype), dw2.astype(x.dtype), db2.astype(x.dtype)
+
+
+# --------------------------------------------------------------------------- #
+# SpatialAttention  (reference: models/layers.py:114-129)
+#   mean/max over channels -> cat -> Conv2d(2,1,7,pad 3,no bias) -> BatchNorm2d(1)
+#   -> sigmoid -> multiply
+# --------------------------------------------------------------------------- #
+
+
+def conv2d_same_fwd(x, w):
+    """dense small conv, stride 1, 'same' zero padding (k odd). x [N,Ci,H,W], w [Co,Ci,k,k]"""
+    n, ci, h, wd = x.shape
+    co, _, k, _ = w.shape
+    pd = k // 2
+    xp = np.pad(x, ((0, 0), (0, 0), (pd, pd), (pd, pd)))
+    y = np.zeros((n, co, h, wd), x.dtype)
+    for i in range(k):
+        for j in range(k):
+            y += np.einsum("oc,nchw->nohw", w[:, :, i, j], xp[:, :, i:i + h, j:j + wd])
+    return y
+
+
+def conv2d_same_bwd(x, w, dy):
+    n, ci, h, wd = x.shape
+    co, _, k, _ = w.shape
+    pd = k // 2
+    xp = np.pad(x, ((0, 0), (0, 0), (pd, pd), (pd, pd)))
+    dxp = np.zeros_like(xp)
+    dwgt = np.zeros_like(w)
+    for i in range(k):
+        for j in range(k):
+            dwgt[:, :, i, j] = np.einsum("nohw,nchw->oc", dy, xp[:, :, i:i + h, j:j + wd])
+            dxp[:, :, i:i + h, j:j + wd] += np.einsum("oc,nohw->nchw", w[:, :, i, j], dy)
+    return dxp[:, :, pd:pd + h, pd:pd + wd].copy(), dwgt
+
+
+def spatial_att_fwd(x, wconv, gamma, beta, eps=1e-5):
+    n, c, h, w = x.shape
+    avg = x.mean(axis=1, keepdims=True, dtype=np.float64).astype(x.dtype)
+    cidx = x.argmax(axis=1)  # first occurrence along channel
+    mx = np.take_along_axis(x, cidx[:, None], axis=1)
+    maps = np.concatenate([avg, mx], axis=1)
+    conv = conv2d_same_fwd(maps, wconv)
+    bn, mean, invstd, var = bn_train_fwd(conv, gamma, beta, eps)
+    m = sigmoid(bn).astype(x.dtype)
+    y = x * m
+    cache = dict(maps=maps, cidx=cidx, conv=conv, mean=mean, invstd=invstd, var=var, m=m)
+    return y, cache
+
+
+def spatial_att_bwd(x, wconv, gamma, cache, dy):
+    n, c, h, w = x.shape
+    m = cache["m"]
+    dm = (dy * x).sum(axis=1, keepdims=True, dtype=np.float64).astype(x.dtype)
+    dbn = dm * m * (1 - m)
+    dconv, dgamma, dbeta = bn_train_bwd(cache["conv"], gamma, cache["mean"], cache["invstd"], dbn)
+    dmaps, dwconv = conv2d_same_bwd(cache["maps"], wconv, dconv)
+    dx = dy * m + dmaps[:, 0:1] / x.dtype.type(c)
+    np.put_along_axis(dx, cache["cidx"][:, None],
+                      np.take_along_axis(dx, cache["cidx"][:, None], axis=1) + dmaps[:, 1:2], axis=1)
+    return dx.astype(x.dtype, copy=False), dwconv, dgamma, dbeta
+
+
+# --------------------------------------------------------------------------- #
+# MSE(sum)/N  (reference: models/regression_lightning.py:57-65)
+# --------------------------------------------------------------------------- #
+
+
+def mse_sum_over_batch(pred, target):
+    p = pred[:, 0] if pred.ndim > target.ndim else pred
+    d = (p - target).astype(np.float64)
+    loss = (d * d).sum() / target.shape[0]
+    dpred = (2.0 * d / target.shape[0]).astype(pred.dtype)
+    if pred.ndim > target.ndim:
+        dpred = dpred[:, None]
+    return pred.dtype.type(loss), dpred
+
+
+# --------------------------------------------------------------------------- #
+# Model assembly
+#   DoubleConvDS  unet_parts_depthwise_separable.py:10-39
+#   DownDS        :42-53        UpDS :56-86       CBAM layers.py:132-141
+#   SmaAt_UNet    models/SmaAt_UNet.py:8-57
+# Parameters are a flat dict keyed exactly like the reference state_dict.
+# --------------------------------------------------------------------------- #
+
+
+class Tape:
+    """Records what the backward needs. One per forward call."""
+
+    def __init__(self):
+        self.d = {}
+
+
+def _dsconv_bn_relu_fwd(P, pre, bn_pre, x, kpl, tape, key, eps=1e-5):
+    y = dw3x3_fwd(x, P[pre + ".depthwise.weight"], P[pre + ".depthwise.bias"], kpl)
+    z = pw1x1_fwd(y, P[pre + ".pointwise.weight"], P[pre + ".pointwise.bias"])
+    a, mean, invstd, var = bn_train_fwd(z, P[bn_pre + ".weight"], P[bn_pre + ".bias"], eps)
+    out = relu_fwd(a)
+    tape.d[key] = dict(x=x, y=y, z=z, mean=mean, invstd=invstd, var=var, out=out)
+    return out
+
+
+def _dsconv_bn_relu_bwd(P, G, pre, bn_pre, kpl, tape, key, dout):
+    t = tape.d[key]
+    da = relu_bwd(t["out"], dout)
+    dz, dg, db = bn_train_bwd(t["z"], P[bn_pre + ".weight"], t["mean"], t["invstd"], da)
+    G[bn_pre + ".weight"] = dg
+    G[bn_pre + ".bias"] = db
+    dy, dwp, dbp = pw1x1_bwd(t["y"], P[pre + ".pointwise.weight"], dz)
+    G[pre + ".pointwise.weight"] = dwp
+    G[pre + ".pointwise.bias"] = dbp.astype(dz.dtype)
+    dx, dwd, dbd = dw3x3_bwd(t["x"], P[pre + ".depthwise.weight"], dy, kpl)
+    G[pre + ".depthwise.weight"] = dwd
+    G[pre + ".depthwise.bias"] = dbd.astype(dz.dtype)
+    return dx
+
+
+def double_conv_ds_fwd(P, pre, x, kpl, tape):
+    h = _dsconv_bn_relu_fwd(P, pre + ".double_conv.0", pre + ".double_conv.1", x, kpl, tape, pre + "#0")
+    return _dsconv_bn_relu_fwd(P, pre + ".double_conv.3", pre + ".double_conv.4", h, kpl, tape, pre + "#1")
+
+
+def double_conv_ds_bwd(P, G, pre, kpl, tape, dout):
+    dh = _dsconv_bn_relu_bwd(P, G, pre + ".double_conv.3", pre + ".double_conv.4", kpl, tape, pre + "#1", dout)
+    return _dsconv_bn_relu_bwd(P, G, pre + ".double_conv.0", pre + ".double_conv.1", kpl, tape, pre + "#0", dh)
+
+
+def cbam_fwd(P, pre, x, tape):
+    ca = pre + ".channel_att.MLP"
+    y1, c1 = channel_att_fwd(x, P[ca + ".1.weight"], P[ca + ".1.bias"], P[ca + ".3.weight"], P[ca + ".3.bias"])
+    sp = pre + ".spatial_att"
+    y2, c2 = spatial_att_fwd(y1, P[sp + ".conv.weight"], P[sp + ".bn.weight"], P[sp + ".bn.bias"])
+    tape.d[pre] = dict(x=x, y1=y1, c1=c1, c2=c2)
+    return y2
+
+
+def cbam_bwd(P, G, pre, tape, dout):
+    t = tape.d[pre]
+    sp = pre + ".spatial_att"
+    dy1, dwc, dg, db = spatial_att_bwd(t["y1"], P[sp + ".conv.weight"], P[sp + ".bn.weight"], t["c2"], dout)
+    G[sp + ".conv.weight"] = dwc
+    G[sp + ".bn.weight"] = dg
+    G[sp + ".bn.bias"] = db
+    ca = pre + ".channel_att.MLP"
+    dx, dw1, db1, dw2, db2 = channel_att_bwd(t["x"], P[ca + ".1.weight"], P[ca + ".1.bias"], P[ca + ".3.weight"],
+                                            P[ca + ".3.bias"], t["c1"], dy1)
+    G[ca + ".1.weight"], G[ca + ".1.bias"], G[ca + ".3.weight"], G[ca + ".3.bias"] = dw1, db1, dw2, db2
+    return dx
+
+
+def down_fwd(P, pre, x, kpl, tape):
+    p, idx = maxpool2_fwd(x)
+    tape.d[pre + "#pool"] = dict(shape=x.shape, idx=idx)
+    return double_conv_ds_fwd(P, pre + ".maxpool_conv.1", p, kpl, tape)
+
+
+def down_bwd(P, G, pre, kpl, tape, dout):
+    dp = double_conv_ds_bwd(P, G, pre + ".maxpool_conv.1", kpl, tape, dout)
+    t = tape.d[pre + "#pool"]
+    return maxpool2_bwd(t["shape"], t["idx"], dp)
+
+
+def up_fwd(P, pre, x1, x2, kpl, tape):
+    u = upsample2x_fwd(x1)
+    cat = pad_cat_fwd(u, x2)
+    tape.d[pre + "#up"] = dict(x1_shape=x1.shape, u_shape=u.shape, x2_shape=x2.shape)
+    return double_conv_ds_fwd(P, pre + ".conv", cat, kpl, tape)
+
+
+def up_bwd(P, G, pre, kpl, tape, dout):
+    dcat = double_conv_ds_bwd(P, G, pre + ".conv", kpl, tape, dout)
+    t = tape.d[pre + "#up"]
+    du, dx2 = pad_cat_bwd(t["u_shape"], t["x2_shape"], dcat)
+    return upsample2x_bwd(t["x1_shape"], np.ascontiguousarray(du)), dx2
+
+
+def smaat_unet_fwd(P, x, kpl=2):
+    """models/SmaAt_UNet.py:41-57.  Returns (logits, tape, acts)."""
+    tape = Tape()
+    a = {}
+    a["x1"] = double_conv_ds_fwd(P, "inc", x, kpl, tape)
+    a["x1Att"] = cbam_fwd(P, "cbam1", a["x1"], tape)
+    a["x2"] = down_fwd(P, "down1", a["x1"], kpl, tape)
+    a["x2Att"] = cbam_fwd(P, "cbam2", a["x2"], tape)
+    a["x3"] = down_fwd(P, "down2", a["x2"], kpl, tape)
+    a["x3Att"] = cbam_fwd(P, "cbam3", a["x3"], tape)
+    a["x4"] = down_fwd(P, "down3", a["x3"], kpl, tape)
+    a["x4Att"] = cbam_fwd(P, "cbam4", a["x4"], tape)
+    a["x5"] = down_fwd(P, "down4", a["x4"], kpl, tape)
+    a["x5Att"] = cbam_fwd(P, "cbam5", a["x5"], tape)
+    a["u1"] = up_fwd(P, "up1", a["x5Att"], a["x4Att"], kpl, tape)
+    a["u2"] = up_fwd(P, "up2", a["u1"], a["x3Att"], kpl, tape)
+    a["u3"] = up_fwd(P, "up3", a["u2"], a["x2Att"], kpl, tape)
+    a["u4"] = up_fwd(P, "up4", a["u3"], a["x1Att"], kpl, tape)
+    logits = pw1x1_fwd(a["u4"], P["outc.conv.weight"], P["outc.conv.bias"])
+    tape.d["outc"] = dict(x=a["u4"])
+    a["logits"] = logits
+    return logits, tape, a
+
+
+def smaat_unet_bwd(P, tape, dlogits, kpl=2):
+    """Returns (grads dict keyed like state_dict params, dx)."""
+    G = {}
+    du4, G["outc.conv.weight"], dbo = pw1x1_bwd(tape.d["outc"]["x"], P["outc.conv.weight"], dlogits)
+    G["outc.conv.bias"] = dbo.astype(dlogits.dtype)
+    du3, dx1att = up_bwd(P, G, "up4", kpl, tape, du4)
+    du2, dx2att = up_bwd(P, G, "up3", kpl, tape, du3)
+    du1, dx3att = up_bwd(P, G, "up2", kpl, tape, du2)
+    dx5att, dx4att = up_bwd(P, G, "up1", kpl, tape, du1)
+    dx5 = cbam_bwd(P, G, "cbam5", tape, np.ascontiguousarray(dx5att))
+    dx4 = down_bwd(P, G, "down4", kpl, tape, dx5) + cbam_bwd(P, G, "cbam4", tape, np.ascontiguousarray(dx4att))
+    dx3 = down_bwd(P, G, "down3", kpl, tape, dx4) + cbam_bwd(P, G, "cbam3", tape, np.ascontiguousarray(dx3att))
+    dx2 = down_bwd(P, G, "down2", kpl, tape, dx3) + cbam_bwd(P, G, "cbam2", tape, np.ascontiguousarray(dx2att))
+    dx1 = down_bwd(P, G, "down1", kpl, tape, dx2) + cbam_bwd(P, G, "cbam1", tape, np.ascontiguousarray(dx1att))
+    dx = double_conv_ds_bwd(P, G, "inc", kpl, tape, dx1)
+    return G, dx
+
+
+def train_step_loss_and_grads(P, x, target, kpl=2):
+    """forward + MSE(sum)/N + backward: the unit bench.py's cpu_baseline leg times."""
+    logits, tape, acts = smaat_unet_fwd(P, x, kpl)
+    loss, dlogits = mse_sum_over_batch(logits, target)
+    G, dx = smaat_unet_bwd(P, tape, dlogits, kpl)
+    return loss, G, dx, acts
+
+
+# --------------------------------------------------------------------------- #
+# Deterministic synthetic inputs; numpy-only so that the
+# generator travels to the GPU box.  NOTE: these are NOT bit-identical to the
+# torch.Generator stream named in the survey; the golden fixtures store the exact
+# tensors they were produced from.
+# --------------------------------------------------------------------------- #
+
+
+def synthetic_precip(n, c, h, w, seed=1234, dtype=np.float32):
+    rng = np.random.default_rng(seed)
+    u = rng.random((n, c, h, w), dtype=np.float32)
+    x = np.where(u > 0.7, (u - 0.7) / 0.3 * 0.5, 0.0).astype(dtype)
+    y = (rng.random((n, h, w), dtype=np.float32) * 0.3).astype(dtype)
+    return x, y
