@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""Training-throughput bench for the MI355X-native SmaAt-UNet path.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = forward + MSE(sum)/N loss (reference models/regression_lightning.py:57-65) +
+backward + gradient all-reduce (N > 1) + Adam(lr 1e-3) (reference :48) on a batch of 32
+synthetic 12x288x288 frames per GPU (BASELINE.json configs[1]; weak scaling -> configs[2] at
+N = 8).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-in MFMA = f32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def synthetic_batch(n, h, w, seed, device):
+    """~30 % 'rain' pixels in [0, 0.5], target in [0, 0.3]."""
+    g = torch.Generator().manual_seed(seed)
+    u = torch.rand(n, 12, h, w, generator=g)
+    x = torch.where(u > 0.7, (u - 0.7) / 0.3 * 0.5, torch.zeros(()))
+    y = torch.rand(n, h, w, generator=g) * 0.3
+    return x.to(device), y.to(device)
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The reference's arithmetic on the host cores: oracle/torch_ref.py (the same ATen CPU
+    operators the reference dispatches to), batch 2 at 288x288, full train step."""
+    from oracle import params as oparams
+    from oracle import torch_ref
+    threads = torch.get_num_threads()
+    P = torch_ref.params_from_numpy(oparams.make_smaat_params(12, 1, 2, 16, 0))
+    g = torch.Generator().manual_seed(1)
+    bs = 2
+    x = torch.rand(bs, 12, 288, 288, generator=g)
+    y = torch.rand(bs, 288, 288, generator=g) * 0.3
+    opt = torch.optim.Adam([p for p in P.values() if p.requires_grad], lr=1e-3)
+    torch_ref.train_step(P, x, y)  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        torch_ref.train_step(P, x, y)
+        opt.step()
+        n += 1
+        if time.perf_counter() - t0 > seconds_budget or n >= 16:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(bs * n / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{n} train steps of batch {bs} (12x288x288, fp32) through oracle/torch_ref.py "
+                      f"(torch {torch.__version__} CPU ops, {threads} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="frames per GPU")
+    ap.add_argument("--size", type=int, default=288)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import smaat_unet_amd as S
+    from smaat_unet_amd import _lib
+    from smaat_unet_amd.ddp import FlatGradAllReduce
+    _lib.get()
+
+    torch.manual_seed(0)
+    model = S.SmaAt_UNet(12, 1).to(dev).train()
+    ddp = FlatGradAllReduce(model.parameters(), world_size=world)
+    ddp.broadcast_parameters()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, foreach=True)
+    x, y = synthetic_batch(args.batch, args.size, args.size, 1234 + rank, dev)
+
+    def step():
+        out = model(x)
+        loss = torch.nn.functional.mse_loss(out.squeeze(1), y, reduction="sum") / y.size(0)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if world > 1:
+            ddp.reduce()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    final_loss = loss.item()
+
+    roof = None
+    kernels = None
+    if rank == 0 and not args.no_profile:
+        prof = _lib.Profiler()
+        for _ in range(2):
+            step()
+        summ = prof.summary()
+        prof.close()
+        kernels = {}
+        for name, d in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
+            ms = d["ms"] / 2.0
+            e = {"calls": d["calls"] // 2, "ms_per_step": round(ms, 3)}
+            if d["flop"]:
+                e["tflops"] = round(d["flop"] / 2.0 / (ms * 1e-3) / 1e12, 2)
+                e["alg_gbs"] = round(d["bytes"] / 2.0 / (ms * 1e-3) / 1e9, 1)
+            kernels[name] = e
+        # dominant kernel class = the MFMA pointwise family (fwd fused dsconv, dgrad, wgrad)
+        fam = ["smaat_dsconv_fwd", "smaat_pointwise_fwd", "smaat_dsconv_wgrad", "smaat_pointwise_wgrad"]
+        fl = sum(summ[k]["flop"] for k in fam if k in summ) / 2.0
+        ms = sum(summ[k]["ms"] for k in fam if k in summ) / 2.0
+        calls = sum(summ[k]["calls"] for k in fam if k in summ) // 2
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "kernel": "k_pwgemm/k_wgrad family (v_mfma_f32_32x32x2_f32)", "launches_per_step": calls,
+                "avg_launch_ms": round(ms / max(calls, 1), 4), "ms_per_step": round(ms, 3)}
+        if "smaat_dw3x3_bwd" in summ:
+            d = summ["smaat_dw3x3_bwd"]
+            roof["dw_bwd_hbm"] = {"achieved_GBs": round(d["bytes"] / d["ms"] / 1e6, 1), "peak_GBs": PEAK_HBM_GBS,
+                                  "frac": round(d["bytes"] / d["ms"] / 1e6 / PEAK_HBM_GBS, 4)}
+
+    cpu = None
+    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        frames = args.batch * world * args.steps
+        line = {
+            "metric": "training frames/sec (288x288, 12-ch in)",
+            "value": round(frames / dt, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"SmaAt-UNet 12->1ch, {args.size}x{args.size} synthetic precip, batch={args.batch}/GPU "
+                                   "fp32, fwd+MSE+bwd+Adam (BASELINE.json configs[1])",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "final_loss": round(final_loss, 5)},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "kernels": kernels,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,142 @@
+/* smaat_hip.h -- C ABI of libsmaat_hip.so: the MI355X (gfx950) kernels behind the
+ * SmaAt-UNet forward+backward hot path.
+ *
+ * The reference (HansBambel/SmaAt-UNet) has no FFI: the path sits behind torch.nn
+ * modules.  Each entry point below replaces the torch.nn call(s) cited next to it; the
+ * Python host (smaat_unet_amd/) binds them with ctypes and exposes them as
+ * torch.ops.smaat.* custom ops behind module classes with the reference's constructor
+ * signatures and state_dict keys.
+ *
+ * Conventions
+ *  - all tensors are float32, NCHW, device pointers; "plane" = H*W contiguous floats;
+ *    channel stride = H*W; batch stride is passed explicitly (`*_bs`, in elements) so
+ *    that a tensor may be a channel slice of a larger concatenation buffer.
+ *  - no allocation, no synchronisation, no global state inside: workspaces are passed in,
+ *    kernels are enqueued on `stream` (a hipStream_t).
+ *  - return value: 0 = ok, >0 = hipError_t, -1 = unsupported argument.
+ */
+#ifndef SMAAT_HIP_H
+#define SMAAT_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int smaat_abi_version(void);
+
+/* ---- DepthwiseSeparableConv: depthwise 3x3 (pad 1, groups=Cin, kpl outputs per input
+ *      channel) fused through LDS into the pointwise 1x1 on the f32 MFMA pipe.
+ *      reference: models/layers.py:34-50 (depthwise :38-44, pointwise :45, forward :47-50)
+ *   x        [N][Cin][H][W]            (optional in_scale/in_shift[Cin]: x := relu(x*sc+sh) on load)
+ *   w_dw     [Cin*kpl][9], b_dw [Cin*kpl] (nullable)
+ *   wt_pw    [Cin*kpl][Cout]  = pointwise.weight TRANSPOSED (k-major), b_pw [Cout] (nullable)
+ *   z        [N][Cout][H][W]
+ *   part     nullable; [2][slots][Cout] per-tile sum / sum-of-squares of (z - b_pw) for the
+ *            following train-mode BatchNorm; slots = smaat_pw_num_slots(N,H,W,Cout)
+ */
+int smaat_pw_num_slots(int N, int H, int W, int M);
+int smaat_dsconv_fwd(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                     const float* b_dw, const float* wt_pw, const float* b_pw, float* z, long z_bs, float* part,
+                     int N, int Cin, int kpl, int Cout, int H, int W, void* stream);
+
+/* ---- plain pointwise conv  out[n][m][p] = sum_c wt[c][m] * x[n][c][p] + bias[m]
+ *      reference: OutConv models/unet_parts.py:67-73; also the data gradient of the
+ *      pointwise conv (dY = W^T dZ: pass wt = pointwise.weight in its natural [Cout][K] layout,
+ *      Cin := Cout, M := K).
+ */
+int smaat_pointwise_fwd(const float* x, long x_bs, const float* wt, const float* bias, float* out, long out_bs,
+                        float* part, int N, int Cin, int M, int H, int W, void* stream);
+
+/* ---- pointwise weight gradient  dW[m][k] = sum_{n,p} dz[n][m][p] * Y[n][k][p]
+ *      dsconv variant recomputes Y = depthwise(x) on the fly (the expanded tensor never
+ *      touches HBM).  ws: [smaat_wgrad_num_splits(...)][M][K] floats.  dw_out [M][K].
+ */
+int smaat_wgrad_num_splits(int N, int H, int W, int M, int K);
+int smaat_dsconv_wgrad(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                       const float* b_dw, const float* dz, long dz_bs, float* ws, float* dw_out, int N, int Cin,
+                       int kpl, int Cout, int H, int W, void* stream);
+int smaat_pointwise_wgrad(const float* x, long x_bs, const float* dz, long dz_bs, float* ws, float* dw_out, int N,
+                          int Cin, int M, int H, int W, void* stream);
+
+/* ---- depthwise 3x3 backward (autograd of nn.Conv2d(groups=Cin), models/layers.py:38-44)
+ *   dy [N][Cin*kpl][H][W] -> dx [N][Cin][H][W] (nullable), dw_out [Cin*kpl][9], db_out [Cin*kpl] (nullable)
+ *   ws: [N+1][Cin*kpl][10] floats
+ */
+int smaat_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, const float* w_dw, float* dx, long dx_bs,
+                    float* ws, float* dw_out, float* db_out, int N, int Cin, int kpl, int H, int W, void* stream);
+
+/* ---- BatchNorm2d (train) + ReLU   reference: unet_parts_depthwise_separable.py:25-26,34-35,
+ *      layers.py:120,127.  Statistics arrive as partial sums (from smaat_dsconv_fwd etc.).
+ *   finalize: part [2][T][C], count = N*H*W; bias_shift[C] (nullable) is added to the mean
+ *             (the partials are of z - bias).  Writes mean/invstd/scale/shift [C] and updates
+ *             running_mean/var (nullable) with `momentum` and the unbiased variance.
+ *   affine_act: y = relu?(z*scale[c] + shift[c])
+ *   bwd: g = dy*[y>0]; part [2][slots][C] with slots = smaat_plane_num_slots(N,P);
+ *        finalize -> dgamma, dbeta, coef[3][C]; apply -> dz.
+ */
+int smaat_bn_finalize(const float* part, int T, int C, double count, const float* bias_shift, const float* gamma,
+                      const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                      float* mean, float* invstd, float* scale, float* shift, void* stream);
+int smaat_affine_act(const float* z, long z_bs, const float* scale, const float* shift, float* y, long y_bs, int N,
+                     int C, int P, int relu, void* stream);
+int smaat_plane_num_slots(int N, int P);
+int smaat_bn_bwd_reduce(const float* dy, long dy_bs, const float* z, long z_bs, const float* scale,
+                        const float* shift, const float* mean, const float* invstd, float* part, int N, int C, int P,
+                        int relu, void* stream);
+int smaat_bn_bwd_finalize(const float* part, int slots, int C, double count, const float* gamma, const float* invstd,
+                          float* dgamma, float* dbeta, float* coef, void* stream);
+int smaat_bn_bwd_apply(const float* dy, long dy_bs, const float* z, long z_bs, const float* scale,
+                       const float* shift, const float* mean, const float* invstd, const float* coef, float* dz,
+                       long dz_bs, int N, int C, int P, int relu, void* stream);
+
+/* ---- small helpers */
+int smaat_reduce_rows(const float* part, int rows, long len, float* out, float alpha, void* stream);
+/* out[c] = sum_{n,p} x[n][c][p]; ws: [smaat_plane_num_slots(N,P)][C] */
+int smaat_channel_sum(const float* x, long x_bs, int N, int C, int P, float* ws, float* out, void* stream);
+/* dst[n][0:plane_len] (+)= src[n][0:plane_len] with separate batch strides (torch.cat slices) */
+int smaat_copy_planes(const float* src, long s_bs, float* dst, long d_bs, int N, long plane_len, int accum,
+                      void* stream);
+
+/* ---- MaxPool2d(2)   reference: unet_parts_depthwise_separable.py:48 */
+int smaat_maxpool2_fwd(const float* x, long x_bs, float* y, long y_bs, int N, int C, int H, int W, void* stream);
+int smaat_maxpool2_bwd(const float* x, long x_bs, const float* dy, long dy_bs, float* dx, long dx_bs, int N, int C,
+                       int H, int W, int accum, void* stream);
+
+/* ---- nn.Upsample(x2, bilinear, align_corners=True) + F.pad into an [Ho][Wo] plane of the
+ *      concatenation buffer   reference: unet_parts_depthwise_separable.py:64,76-85 */
+int smaat_upsample2x_fwd(const float* x, long x_bs, float* out, long out_bs, int N, int C, int H, int W, int Ho,
+                         int Wo, int pad_t, int pad_l, void* stream);
+int smaat_upsample2x_bwd(const float* dout, long dout_bs, float* dx, long dx_bs, int N, int C, int H, int W, int Ho,
+                         int Wo, int pad_t, int pad_l, void* stream);
+
+/* ---- CBAM   reference: models/layers.py:90-141 */
+int smaat_cbam_spconv_blocks(int N, int H, int W);
+int smaat_cbam_pix_blocks(int N, int P);
+int smaat_cbam_chpool(const float* x, long x_bs, int N, int C, int P, float* avg, float* mx, int* amax, void* stream);
+int smaat_cbam_mlp(const float* avg, const float* mx, const float* w1, const float* b1, const float* w2,
+                   const float* b2, int N, int C, int Cr, float* ha, float* hm, float* s, void* stream);
+int smaat_cbam_sppool(const float* x, long x_bs, const float* s, int N, int C, int P, float* maps, void* stream);
+int smaat_cbam_spconv(const float* maps, const float* wc, int ks, int N, int H, int W, float* conv, float* part,
+                      void* stream);
+int smaat_cbam_gate(const float* conv, const float* scale, const float* shift, long total, float* gate, void* stream);
+int smaat_cbam_apply(const float* x, long x_bs, const float* s, const float* gate, float* out, long out_bs, int N,
+                     int C, int P, void* stream);
+int smaat_cbam_bwd_gate(const float* dout, long dout_bs, const float* x, long x_bs, const float* s,
+                        const float* gate, const float* conv, const float* mean, const float* invstd, int N, int C,
+                        int P, float* dbn, float* part, void* stream);
+int smaat_cbam_bwd_spconv(const float* dbn, const float* conv, const float* mean, const float* invstd,
+                          const float* coef, const float* maps, const float* wc, int ks, int N, int H, int W,
+                          float* dmaps, float* wpart, void* stream);
+int smaat_cbam_bwd_main(const float* dout, long dout_bs, const float* x, long x_bs, const float* s,
+                        const float* gate, const float* maps, const float* dmaps, int N, int C, int P, float* dx,
+                        long dx_bs, float* dspart, void* stream);
+int smaat_cbam_bwd_mlp(const float* ds, const float* s, const float* avg, const float* mx, const float* ha,
+                       const float* hm, const float* w1, const float* w2, int N, int C, int Cr, float* pg,
+                       float* davg, float* dmx, void* stream);
+int smaat_cbam_bwd_final(float* dx, long dx_bs, const float* davg, const float* dmx, const int* amax, int N, int C,
+                         int P, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMAAT_HIP_H */

@@ -72,17 +72,21 @@ def dw3x3_bwd(x, w, dy, kpl):
 
 
 def pw1x1_fwd(y, w, b):
+    n, k, h, wd = y.shape
     w2 = w.reshape(w.shape[0], w.shape[1])
-    z = np.einsum("ok,nkhw->nohw", w2, y)
+    z = np.matmul(w2[None], y.reshape(n, k, h * wd)).reshape(n, w2.shape[0], h, wd)  # BLAS sgemm per image
     if b is not None:
         z = z + b[None, :, None, None]
     return z.astype(y.dtype, copy=False)
 
 
 def pw1x1_bwd(y, w, dz):
-    w2 = w.reshape(w.shape[0], w.shape[1])
-    dy = np.einsum("ok,nohw->nkhw", w2, dz)
-    dwgt = np.einsum("nohw,nkhw->ok", dz, y).reshape(w.shape)
+    n, k, h, wd = y.shape
+    m = w.shape[0]
+    w2 = w.reshape(m, k)
+    dzf = dz.reshape(n, m, h * wd)
+    dy = np.matmul(w2.T[None], dzf).reshape(n, k, h, wd)
+    dwgt = np.matmul(dzf, y.reshape(n, k, h * wd).transpose(0, 2, 1)).sum(axis=0).reshape(w.shape)
     db = dz.sum(axis=(0, 2, 3))
     return dy.astype(y.dtype, copy=False), dwgt.astype(y.dtype, copy=False), db
 

@@ -1,0 +1,12 @@
+"""smaat_unet_amd -- MI355X (gfx950) native forward+backward path for SmaAt-UNet.
+
+Hand-written HIP kernels (libsmaat_hip.so, C ABI in include/smaat_hip.h) behind module
+classes that mirror the reference's `models/` API.  There is no CPU fallback.
+"""
+from . import _lib  # noqa: F401
+from .SmaAt_UNet import SmaAt_UNet  # noqa: F401
+from .layers import CBAM, ChannelAttention, DepthwiseSeparableConv, SpatialAttention  # noqa: F401
+from .unet_parts_depthwise_separable import DoubleConvDS, DownDS, OutConv, UpDS  # noqa: F401
+
+__all__ = ["SmaAt_UNet", "CBAM", "ChannelAttention", "SpatialAttention", "DepthwiseSeparableConv", "DoubleConvDS",
+           "DownDS", "UpDS", "OutConv"]

@@ -1,0 +1,198 @@
+"""ctypes binding of libsmaat_hip.so (C ABI declared in include/smaat_hip.h).
+
+There is NO CPU fallback: `get()` raises if the HIP library is missing, and the ops
+refuse host tensors.  `build()` compiles the library in-tree with hipcc for gfx950.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsmaat_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_long
+_F = ctypes.c_float
+_D = ctypes.c_double
+
+# name -> argtypes (restype is always int).  Order mirrors include/smaat_hip.h exactly.
+SIGNATURES = {
+    "smaat_abi_version": [],
+    "smaat_pw_num_slots": [_I, _I, _I, _I],
+    "smaat_dsconv_fwd": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P],
+    "smaat_pointwise_fwd": [_P, _L, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P],
+    "smaat_wgrad_num_splits": [_I, _I, _I, _I, _I],
+    "smaat_dsconv_wgrad": [_P, _L, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "smaat_pointwise_wgrad": [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _P],
+    "smaat_dw3x3_bwd": [_P, _L, _P, _L, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "smaat_bn_finalize": [_P, _I, _I, _D, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P],
+    "smaat_affine_act": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "smaat_plane_num_slots": [_I, _I],
+    "smaat_bn_bwd_reduce": [_P, _L, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "smaat_bn_bwd_finalize": [_P, _I, _I, _D, _P, _P, _P, _P, _P, _P],
+    "smaat_bn_bwd_apply": [_P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "smaat_reduce_rows": [_P, _I, _L, _P, _F, _P],
+    "smaat_channel_sum": [_P, _L, _I, _I, _I, _P, _P, _P],
+    "smaat_copy_planes": [_P, _L, _P, _L, _I, _L, _I, _P],
+    "smaat_maxpool2_fwd": [_P, _L, _P, _L, _I, _I, _I, _I, _P],
+    "smaat_maxpool2_bwd": [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P],
+    "smaat_upsample2x_fwd": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "smaat_upsample2x_bwd": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "smaat_cbam_spconv_blocks": [_I, _I, _I],
+    "smaat_cbam_pix_blocks": [_I, _I],
+    "smaat_cbam_chpool": [_P, _L, _I, _I, _I, _P, _P, _P, _P],
+    "smaat_cbam_mlp": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "smaat_cbam_sppool": [_P, _L, _P, _I, _I, _I, _P, _P],
+    "smaat_cbam_spconv": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "smaat_cbam_gate": [_P, _P, _P, _L, _P, _P],
+    "smaat_cbam_apply": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _P],
+    "smaat_cbam_bwd_gate": [_P, _L, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
+    "smaat_cbam_bwd_spconv": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "smaat_cbam_bwd_main": [_P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P, _P],
+    "smaat_cbam_bwd_mlp": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "smaat_cbam_bwd_final": [_P, _L, _P, _P, _P, _I, _I, _I, _P],
+}
+
+_instance = None
+# Set to True ONLY by the CPU test-suite when it injects its emulation backend
+# (tests/emu_backend.py).  Product code never touches it.
+_ALLOW_HOST_POINTERS = False
+
+
+class SmaatHipError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self, path):
+        self._dll = ctypes.CDLL(path)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(self._dll, name)  # AttributeError if the symbol is missing
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+            setattr(self, name, fn)
+        if self.smaat_abi_version() != 1:
+            raise SmaatHipError("libsmaat_hip.so ABI version mismatch")
+
+
+def build(force=False, verbose=False):
+    """Compile every .hip source for gfx950 into smaat_unet_amd/libsmaat_hip.so (in-tree)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=not verbose)
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise SmaatHipError("hipcc build failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    if verbose:
+        print(r.stdout[-2000:])
+    return LIB_PATH
+
+
+def get():
+    """The loaded library; raises loudly if it has not been built (no fallback)."""
+    global _instance
+    if _instance is None:
+        if not os.path.exists(LIB_PATH):
+            raise SmaatHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). smaat_unet_amd has no CPU fallback.")
+        _instance = _Lib(LIB_PATH)
+    return _instance
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SmaatHipError(f"{what} failed with code {rc}")
+
+
+# --------------------------------------------------------------------------------------
+# optional per-entry-point timing (HIP events on the launch stream) used by bench.py
+# --------------------------------------------------------------------------------------
+def _w_dsconv_fwd(a):
+    n, cin, kpl, cout, h, w = a[11:17]
+    return 2.0 * n * cin * kpl * cout * h * w, 4.0 * n * (cin + cout) * h * w
+
+
+def _w_pointwise_fwd(a):
+    n, cin, m, h, w = a[7:12]
+    return 2.0 * n * cin * m * h * w, 4.0 * n * (cin + m) * h * w
+
+
+def _w_dsconv_wgrad(a):
+    n, cin, kpl, cout, h, w = a[10:16]
+    return 2.0 * n * cin * kpl * cout * h * w, 4.0 * n * (cin + cout) * h * w
+
+
+def _w_pointwise_wgrad(a):
+    n, cin, m, h, w = a[6:11]
+    return 2.0 * n * cin * m * h * w, 4.0 * n * (cin + m) * h * w
+
+
+def _w_dw_bwd(a):
+    n, cin, kpl, h, w = a[10:15]
+    return 38.0 * n * cin * kpl * h * w, 4.0 * n * (cin * kpl + 2 * cin) * h * w
+
+
+WORK_MODELS = {
+    "smaat_dsconv_fwd": _w_dsconv_fwd,
+    "smaat_pointwise_fwd": _w_pointwise_fwd,
+    "smaat_dsconv_wgrad": _w_dsconv_wgrad,
+    "smaat_pointwise_wgrad": _w_pointwise_wgrad,
+    "smaat_dw3x3_bwd": _w_dw_bwd,
+    "smaat_affine_act": lambda a: (2.0 * a[6] * a[7] * a[8], 8.0 * a[6] * a[7] * a[8]),
+    "smaat_bn_bwd_reduce": lambda a: (6.0 * a[9] * a[10] * a[11], 8.0 * a[9] * a[10] * a[11]),
+    "smaat_bn_bwd_apply": lambda a: (8.0 * a[11] * a[12] * a[13], 12.0 * a[11] * a[12] * a[13]),
+}
+
+
+class Profiler:
+    """Wraps every entry point of the loaded library with a pair of events on the current
+    stream.  `summary()` synchronises and returns name -> dict(calls, ms, flop, bytes)."""
+
+    def __init__(self):
+        import torch
+        self.torch = torch
+        self.lib = get()
+        self.records = []
+        self._orig = {}
+        for name in SIGNATURES:
+            fn = getattr(self.lib, name)
+            if name.endswith(("_slots", "_splits", "_blocks", "_version")):
+                continue
+            self._orig[name] = fn
+            setattr(self.lib, name, self._wrap(name, fn))
+
+    def _wrap(self, name, fn):
+        torch = self.torch
+
+        def wrapped(*args):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            self.records.append((name, e0, e1, args))
+            return rc
+        return wrapped
+
+    def close(self):
+        for name, fn in self._orig.items():
+            setattr(self.lib, name, fn)
+
+    def summary(self):
+        self.torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1, args in self.records:
+            d = out.setdefault(name, dict(calls=0, ms=0.0, flop=0.0, bytes=0.0))
+            d["calls"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            wm = WORK_MODELS.get(name)
+            if wm is not None:
+                f, b = wm(args)
+                d["flop"] += f
+                d["bytes"] += b
+        self.records = []
+        return out

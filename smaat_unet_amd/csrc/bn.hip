@@ -1,0 +1,373 @@
+// Train-mode BatchNorm2d (+ReLU) forward/backward passes around the pointwise GEMM.
+// Reference: nn.BatchNorm2d in models/unet_parts_depthwise_separable.py:25,34 and
+// models/layers.py:120,127 (biased variance for normalisation, unbiased into
+// running_var, momentum/eps from the module), nn.ReLU(inplace=True) :26,35.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------
+// finalize forward statistics: part[2][T][C] (sum, sumsq of z - shift_bias) -> per channel
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ part, int T, int C, double count,
+                                                     const float* __restrict__ bias_shift,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float eps, float momentum, float* running_mean,
+                                                     float* running_var, float* mean_out, float* invstd_out,
+                                                     float* scale_out, float* shift_out) {
+    const int c = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int t = threadIdx.x; t < T; t += 256) {
+        s += (double)part[(long)t * C + c];
+        q += (double)part[((long)T + t) * C + c];
+    }
+    __shared__ double rs[256], rq[256];
+    rs[threadIdx.x] = s;
+    rq[threadIdx.x] = q;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+            rs[threadIdx.x] += rs[threadIdx.x + st];
+            rq[threadIdx.x] += rq[threadIdx.x + st];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double m0 = rs[0] / count;
+        double var = rq[0] / count - m0 * m0;
+        if (var < 0.0) var = 0.0;
+        const double mean = m0 + (bias_shift ? (double)bias_shift[c] : 0.0);
+        const double invstd = 1.0 / sqrt(var + (double)eps);
+        const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+        const float meanf = (float)mean, invf = (float)invstd;
+        mean_out[c] = meanf;
+        invstd_out[c] = invf;
+        const float sc = g * invf;
+        scale_out[c] = sc;
+        shift_out[c] = bt - meanf * sc;
+        if (running_mean) {
+            const double unb = var * (count / (count > 1.0 ? count - 1.0 : 1.0));
+            running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// y = [relu](z * scale[c] + shift[c]) over [N][C][P] planes with batch strides
+// grid: (N*C planes, segments)
+// ---------------------------------------------------------------------------------
+template <bool RELU>
+__global__ __launch_bounds__(256) void k_affine_act(const float* __restrict__ z, long z_bs,
+                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    float* __restrict__ y, long y_bs, int C, int P, int seg_len) {
+    const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
+    const float sc = scale[c], sh = shift[c];
+    const float* zp = z + (long)n * z_bs + (long)c * P;
+    float* yp = y + (long)n * y_bs + (long)c * P;
+    const int p0 = blockIdx.y * seg_len;
+    int p1 = p0 + seg_len;
+    if (p1 > P) p1 = P;
+    const bool vec = ((P & 3) == 0) && ((z_bs & 3) == 0) && ((y_bs & 3) == 0) && ((seg_len & 3) == 0) &&
+                     ((((uintptr_t)z) & 15) == 0) && ((((uintptr_t)y) & 15) == 0);
+    if (vec) {
+        for (int p = p0 + threadIdx.x * 4; p < p1; p += 1024) {
+            float4 v = *(const float4*)(zp + p);
+            v.x = fmaf(v.x, sc, sh);
+            v.y = fmaf(v.y, sc, sh);
+            v.z = fmaf(v.z, sc, sh);
+            v.w = fmaf(v.w, sc, sh);
+            if (RELU) {
+                v.x = fmaxf(v.x, 0.f);
+                v.y = fmaxf(v.y, 0.f);
+                v.z = fmaxf(v.z, 0.f);
+                v.w = fmaxf(v.w, 0.f);
+            }
+            *(float4*)(yp + p) = v;
+        }
+    } else {
+        for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+            float v = fmaf(zp[p], sc, sh);
+            if (RELU) v = fmaxf(v, 0.f);
+            yp[p] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// backward pass 1: per (plane, segment) partial sums of g and g*xhat,
+//   g = dy * [z*scale+shift > 0] (RELU) or dy;  xhat = (z - mean) * invstd
+// part[2][slots][C], slot = n * nseg + seg
+// ---------------------------------------------------------------------------------
+template <bool RELU>
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__ dy, long dy_bs,
+                                                       const float* __restrict__ z, long z_bs,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, float* __restrict__ part,
+                                                       int C, int P, int seg_len, int slots) {
+    __shared__ float red[8];
+    const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
+    const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+    const float* zp = z + (long)n * z_bs + (long)c * P;
+    const float* gp = dy + (long)n * dy_bs + (long)c * P;
+    const int p0 = blockIdx.y * seg_len;
+    int p1 = p0 + seg_len;
+    if (p1 > P) p1 = P;
+    float s1 = 0.f, s2 = 0.f;
+    const bool vec = ((P & 3) == 0) && ((z_bs & 3) == 0) && ((dy_bs & 3) == 0) && ((seg_len & 3) == 0) &&
+                     ((((uintptr_t)z) & 15) == 0) && ((((uintptr_t)dy) & 15) == 0);
+    if (vec) {
+        for (int p = p0 + threadIdx.x * 4; p < p1; p += 1024) {
+            const float4 zv = *(const float4*)(zp + p);
+            const float4 gv = *(const float4*)(gp + p);
+            const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+            const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float g = gg[j];
+                if (RELU && !(fmaf(zz[j], sc, sh) > 0.f)) g = 0.f;
+                s1 += g;
+                s2 = fmaf(g, (zz[j] - mu) * is, s2);
+            }
+        }
+    } else {
+        for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+            const float zz = zp[p];
+            float g = gp[p];
+            if (RELU && !(fmaf(zz, sc, sh) > 0.f)) g = 0.f;
+            s1 += g;
+            s2 = fmaf(g, (zz - mu) * is, s2);
+        }
+    }
+    const float t1 = block_sum_t0(s1, red);
+    const float t2 = block_sum_t0(s2, red + 4);
+    if (threadIdx.x == 0) {
+        const int slot = n * gridDim.y + blockIdx.y;
+        part[(long)slot * C + c] = t1;
+        part[((long)slots + slot) * C + c] = t2;
+    }
+}
+
+// finalize backward: dgamma = S2, dbeta = S1, coefficients for the apply pass
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ part, int slots, int C,
+                                                         double count, const float* __restrict__ gamma,
+                                                         const float* __restrict__ invstd, float* dgamma,
+                                                         float* dbeta, float* coef /*[3][C]*/) {
+    const int c = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int t = threadIdx.x; t < slots; t += 256) {
+        s += (double)part[(long)t * C + c];
+        q += (double)part[((long)slots + t) * C + c];
+    }
+    __shared__ double rs[256], rq[256];
+    rs[threadIdx.x] = s;
+    rq[threadIdx.x] = q;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+            rs[threadIdx.x] += rs[threadIdx.x + st];
+            rq[threadIdx.x] += rq[threadIdx.x + st];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (dbeta) dbeta[c] = (float)rs[0];
+        if (dgamma) dgamma[c] = (float)rq[0];
+        const float g = gamma ? gamma[c] : 1.f;
+        coef[c] = g * invstd[c];
+        coef[C + c] = (float)(rs[0] / count);
+        coef[2 * C + c] = (float)(rq[0] / count);
+    }
+}
+
+// backward pass 2: dz = c1 * (g - c2 - xhat * c3)
+template <bool RELU>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dy, long dy_bs,
+                                                      const float* __restrict__ z, long z_bs,
+                                                      const float* __restrict__ scale,
+                                                      const float* __restrict__ shift,
+                                                      const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd,
+                                                      const float* __restrict__ coef, float* __restrict__ dz,
+                                                      long dz_bs, int C, int P, int seg_len) {
+    const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
+    const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+    const float c1 = coef[c], c2 = coef[C + c], c3 = coef[2 * C + c];
+    const float* zp = z + (long)n * z_bs + (long)c * P;
+    const float* gp = dy + (long)n * dy_bs + (long)c * P;
+    float* op = dz + (long)n * dz_bs + (long)c * P;
+    const int p0 = blockIdx.y * seg_len;
+    int p1 = p0 + seg_len;
+    if (p1 > P) p1 = P;
+    const bool vec = ((P & 3) == 0) && ((z_bs & 3) == 0) && ((dy_bs & 3) == 0) && ((dz_bs & 3) == 0) &&
+                     ((seg_len & 3) == 0) && ((((uintptr_t)z) & 15) == 0) && ((((uintptr_t)dy) & 15) == 0) &&
+                     ((((uintptr_t)dz) & 15) == 0);
+    if (vec) {
+        for (int p = p0 + threadIdx.x * 4; p < p1; p += 1024) {
+            const float4 zv = *(const float4*)(zp + p);
+            const float4 gv = *(const float4*)(gp + p);
+            const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+            const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float g = gg[j];
+                if (RELU && !(fmaf(zz[j], sc, sh) > 0.f)) g = 0.f;
+                o[j] = c1 * (g - c2 - (zz[j] - mu) * is * c3);
+            }
+            *(float4*)(op + p) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    } else {
+        for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+            const float zz = zp[p];
+            float g = gp[p];
+            if (RELU && !(fmaf(zz, sc, sh) > 0.f)) g = 0.f;
+            op[p] = c1 * (g - c2 - (zz - mu) * is * c3);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// generic helpers
+// ---------------------------------------------------------------------------------
+// out[j] = sum_r part[r][j], fp64 accumulation (deterministic order)
+__global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ part, int rows, long len,
+                                                     float* __restrict__ out, float alpha) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= len) return;
+    double s = 0.0;
+    for (int r = 0; r < rows; ++r) s += (double)part[(long)r * len + j];
+    out[j] = (float)(s * alpha);
+}
+
+// part[slot][c] = sum over one plane segment of x[n][c][:]   (bias gradients; finished by k_reduce_rows)
+__global__ __launch_bounds__(256) void k_plane_sum(const float* __restrict__ x, long x_bs, int C, int P, int seg_len,
+                                                   float* __restrict__ part) {
+    __shared__ float red[4];
+    const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
+    const float* xp = x + (long)n * x_bs + (long)c * P;
+    const int p0 = blockIdx.y * seg_len;
+    int p1 = p0 + seg_len;
+    if (p1 > P) p1 = P;
+    float ls = 0.f;
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) ls += xp[p];
+    const float t = block_sum_t0(ls, red);
+    if (threadIdx.x == 0) part[(long)(n * gridDim.y + blockIdx.y) * C + c] = t;
+}
+
+// strided plane copy: dst[n][c][p] = src[n][c][p] with separate batch strides
+__global__ __launch_bounds__(256) void k_copy_planes(const float* __restrict__ src, long s_bs,
+                                                     float* __restrict__ dst, long d_bs, long plane_len, int accum) {
+    const int n = blockIdx.y;
+    const float* sp = src + (long)n * s_bs;
+    float* dp = dst + (long)n * d_bs;
+    const bool vec = ((plane_len & 3) == 0) && ((s_bs & 3) == 0) && ((d_bs & 3) == 0) &&
+                     ((((uintptr_t)src) & 15) == 0) && ((((uintptr_t)dst) & 15) == 0);
+    if (vec) {
+        for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < plane_len; i += (long)gridDim.x * 1024) {
+            float4 v = *(const float4*)(sp + i);
+            if (accum) {
+                const float4 o = *(const float4*)(dp + i);
+                v.x += o.x;
+                v.y += o.y;
+                v.z += o.z;
+                v.w += o.w;
+            }
+            *(float4*)(dp + i) = v;
+        }
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < plane_len; i += (long)gridDim.x * 256)
+            dp[i] = accum ? dp[i] + sp[i] : sp[i];
+    }
+}
+
+// =====================================================================================
+// launchers
+// =====================================================================================
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// segment length used by the plane-wise kernels: multiple of 1024, <= 8192 elements per block
+static int plane_seg_len(int P) {
+    if (P <= 8192) return ((P + 1023) / 1024) * 1024;
+    return 8192;
+}
+
+int smaat_bn_bwd_num_slots_impl(int N, int P) { return N * cdiv(P, plane_seg_len(P)); }
+
+int launch_bn_finalize(const float* part, int T, int C, double count, const float* bias_shift, const float* gamma,
+                       const float* beta, float eps, float momentum, float* rm, float* rv, float* mean, float* invstd,
+                       float* scale, float* shift, hipStream_t st) {
+    hipLaunchKernelGGL(k_bn_finalize, dim3(C), dim3(256), 0, st, part, T, C, count, bias_shift, gamma, beta, eps,
+                       momentum, rm, rv, mean, invstd, scale, shift);
+    return (int)hipGetLastError();
+}
+
+int launch_affine_act(const float* z, long z_bs, const float* scale, const float* shift, float* y, long y_bs, int N,
+                      int C, int P, int relu, hipStream_t st) {
+    const int seg = plane_seg_len(P);
+    dim3 grid(N * C, cdiv(P, seg));
+    if (relu)
+        hipLaunchKernelGGL(k_affine_act<true>, grid, dim3(256), 0, st, z, z_bs, scale, shift, y, y_bs, C, P, seg);
+    else
+        hipLaunchKernelGGL(k_affine_act<false>, grid, dim3(256), 0, st, z, z_bs, scale, shift, y, y_bs, C, P, seg);
+    return (int)hipGetLastError();
+}
+
+int launch_bn_bwd_reduce(const float* dy, long dy_bs, const float* z, long z_bs, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, float* part, int N, int C, int P,
+                         int relu, hipStream_t st) {
+    const int seg = plane_seg_len(P);
+    dim3 grid(N * C, cdiv(P, seg));
+    const int slots = N * grid.y;
+    if (relu)
+        hipLaunchKernelGGL(k_bn_bwd_reduce<true>, grid, dim3(256), 0, st, dy, dy_bs, z, z_bs, scale, shift, mean,
+                           invstd, part, C, P, seg, slots);
+    else
+        hipLaunchKernelGGL(k_bn_bwd_reduce<false>, grid, dim3(256), 0, st, dy, dy_bs, z, z_bs, scale, shift, mean,
+                           invstd, part, C, P, seg, slots);
+    return (int)hipGetLastError();
+}
+
+int launch_bn_bwd_finalize(const float* part, int slots, int C, double count, const float* gamma,
+                           const float* invstd, float* dgamma, float* dbeta, float* coef, hipStream_t st) {
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(C), dim3(256), 0, st, part, slots, C, count, gamma, invstd, dgamma,
+                       dbeta, coef);
+    return (int)hipGetLastError();
+}
+
+int launch_bn_bwd_apply(const float* dy, long dy_bs, const float* z, long z_bs, const float* scale,
+                        const float* shift, const float* mean, const float* invstd, const float* coef, float* dz,
+                        long dz_bs, int N, int C, int P, int relu, hipStream_t st) {
+    const int seg = plane_seg_len(P);
+    dim3 grid(N * C, cdiv(P, seg));
+    if (relu)
+        hipLaunchKernelGGL(k_bn_bwd_apply<true>, grid, dim3(256), 0, st, dy, dy_bs, z, z_bs, scale, shift, mean,
+                           invstd, coef, dz, dz_bs, C, P, seg);
+    else
+        hipLaunchKernelGGL(k_bn_bwd_apply<false>, grid, dim3(256), 0, st, dy, dy_bs, z, z_bs, scale, shift, mean,
+                           invstd, coef, dz, dz_bs, C, P, seg);
+    return (int)hipGetLastError();
+}
+
+int launch_reduce_rows(const float* part, int rows, long len, float* out, float alpha, hipStream_t st) {
+    hipLaunchKernelGGL(k_reduce_rows, dim3(cdiv(len, 256)), dim3(256), 0, st, part, rows, len, out, alpha);
+    return (int)hipGetLastError();
+}
+
+int launch_channel_sum(const float* x, long x_bs, int N, int C, int P, float* ws, float* out, hipStream_t st) {
+    const int seg = plane_seg_len(P);
+    dim3 grid(N * C, cdiv(P, seg));
+    hipLaunchKernelGGL(k_plane_sum, grid, dim3(256), 0, st, x, x_bs, C, P, seg, ws);
+    const int slots = N * grid.y;
+    hipLaunchKernelGGL(k_reduce_rows, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)ws, slots, (long)C, out, 1.f);
+    return (int)hipGetLastError();
+}
+
+int launch_copy_planes(const float* src, long s_bs, float* dst, long d_bs, int N, long plane_len, int accum,
+                       hipStream_t st) {
+    int gx = cdiv(plane_len, 4096);
+    if (gx > 4096) gx = 4096;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(k_copy_planes, dim3(gx, N), dim3(256), 0, st, src, s_bs, dst, d_bs, plane_len, accum);
+    return (int)hipGetLastError();
+}

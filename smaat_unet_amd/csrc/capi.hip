@@ -1,0 +1,228 @@
+// extern "C" surface of libsmaat_hip.so (declared in include/smaat_hip.h).
+#include "../../include/smaat_hip.h"
+#include "common.h"
+
+// ---- launchers defined in the kernel files -------------------------------------------
+struct PwArgs {
+    const float* x; long x_bs; const float* in_scale; const float* in_shift; const float* w_dw; const float* b_dw;
+    const float* wt; const float* bias; float* out; long out_bs; float* part;
+    int N, Cin, kpl, Kdim, M, nco; TileGeom g;
+};
+struct WgArgs {
+    const float* x; long x_bs; const float* in_scale; const float* in_shift; const float* w_dw; const float* b_dw;
+    const float* dz; long dz_bs; float* dwpart;
+    int N, Cin, kpl, Kdim, M, nco, nkt, nsplit, tiles_per_split; TileGeom g;
+};
+int launch_pwgemm(PwArgs& a, bool dw, hipStream_t st);
+int launch_wgrad(WgArgs& a, bool dw, hipStream_t st);
+int smaat_pw_num_slots_impl(int N, int H, int W, int M);
+int smaat_wgrad_num_splits_impl(int N, int H, int W, int M, int Kdim);
+
+int launch_bn_finalize(const float*, int, int, double, const float*, const float*, const float*, float, float, float*,
+                       float*, float*, float*, float*, float*, hipStream_t);
+int launch_affine_act(const float*, long, const float*, const float*, float*, long, int, int, int, int, hipStream_t);
+int smaat_bn_bwd_num_slots_impl(int N, int P);
+int launch_bn_bwd_reduce(const float*, long, const float*, long, const float*, const float*, const float*, const float*,
+                         float*, int, int, int, int, hipStream_t);
+int launch_bn_bwd_finalize(const float*, int, int, double, const float*, const float*, float*, float*, float*,
+                           hipStream_t);
+int launch_bn_bwd_apply(const float*, long, const float*, long, const float*, const float*, const float*, const float*,
+                        const float*, float*, long, int, int, int, int, hipStream_t);
+int launch_reduce_rows(const float*, int, long, float*, float, hipStream_t);
+int launch_channel_sum(const float*, long, int, int, int, float*, float*, hipStream_t);
+int launch_copy_planes(const float*, long, float*, long, int, long, int, hipStream_t);
+
+int launch_maxpool2_fwd(const float*, long, float*, long, int, int, int, int, hipStream_t);
+int launch_maxpool2_bwd(const float*, long, const float*, long, float*, long, int, int, int, int, int, hipStream_t);
+int launch_upsample2x_fwd(const float*, long, float*, long, int, int, int, int, int, int, int, int, hipStream_t);
+int launch_upsample2x_bwd(const float*, long, float*, long, int, int, int, int, int, int, int, int, hipStream_t);
+int launch_dw3x3_bwd(const float*, long, const float*, long, const float*, float*, long, float*, int, int, int, int,
+                     int, hipStream_t);
+int launch_dw_split(const float*, int, float*, float*, hipStream_t);
+
+int smaat_cbam_spconv_blocks_impl(int N, int H, int W);
+int smaat_cbam_pix_blocks_impl(int N, int P);
+int launch_cbam_chpool(const float*, long, int, int, int, float*, float*, int*, hipStream_t);
+int launch_cbam_mlp(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int,
+                    float*, float*, float*, hipStream_t);
+int launch_cbam_sppool(const float*, long, const float*, int, int, int, float*, hipStream_t);
+int launch_cbam_spconv(const float*, const float*, int, int, int, int, float*, float*, hipStream_t);
+int launch_cbam_gate(const float*, const float*, const float*, long, float*, hipStream_t);
+int launch_cbam_apply(const float*, long, const float*, const float*, float*, long, int, int, int, hipStream_t);
+int launch_cbam_bwd_gate(const float*, long, const float*, long, const float*, const float*, const float*,
+                         const float*, const float*, int, int, int, float*, float*, hipStream_t);
+int launch_cbam_bwd_spconv(const float*, const float*, const float*, const float*, const float*, const float*,
+                           const float*, int, int, int, int, float*, float*, hipStream_t);
+int launch_cbam_bwd_main(const float*, long, const float*, long, const float*, const float*, const float*,
+                         const float*, int, int, int, float*, long, float*, hipStream_t);
+int launch_cbam_bwd_mlp(const float*, const float*, const float*, const float*, const float*, const float*,
+                        const float*, const float*, int, int, int, float*, float*, float*, hipStream_t);
+int launch_cbam_bwd_final(float*, long, const float*, const float*, const int*, int, int, int, hipStream_t);
+
+#define ST ((hipStream_t)stream)
+#define CHK(e)              \
+    do {                    \
+        int _r = (e);       \
+        if (_r) return _r;  \
+    } while (0)
+
+extern "C" {
+
+int smaat_abi_version(void) { return 1; }
+
+int smaat_pw_num_slots(int N, int H, int W, int M) { return smaat_pw_num_slots_impl(N, H, W, M); }
+
+int smaat_dsconv_fwd(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                     const float* b_dw, const float* wt_pw, const float* b_pw, float* z, long z_bs, float* part,
+                     int N, int Cin, int kpl, int Cout, int H, int W, void* stream) {
+    if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return -1;
+    PwArgs a{};
+    a.x = x; a.x_bs = x_bs; a.in_scale = in_scale; a.in_shift = in_shift; a.w_dw = w_dw; a.b_dw = b_dw;
+    a.wt = wt_pw; a.bias = b_pw; a.out = z; a.out_bs = z_bs; a.part = part;
+    a.N = N; a.Cin = Cin; a.kpl = kpl; a.Kdim = Cin * kpl; a.M = Cout; a.g.H = H; a.g.W = W;
+    return launch_pwgemm(a, true, ST);
+}
+
+int smaat_pointwise_fwd(const float* x, long x_bs, const float* wt, const float* bias, float* out, long out_bs,
+                        float* part, int N, int Cin, int M, int H, int W, void* stream) {
+    if (N < 1 || Cin < 1 || M < 1 || H < 1 || W < 1) return -1;
+    PwArgs a{};
+    a.x = x; a.x_bs = x_bs; a.wt = wt; a.bias = bias; a.out = out; a.out_bs = out_bs; a.part = part;
+    a.N = N; a.Cin = Cin; a.kpl = 1; a.Kdim = Cin; a.M = M; a.g.H = H; a.g.W = W;
+    return launch_pwgemm(a, false, ST);
+}
+
+int smaat_wgrad_num_splits(int N, int H, int W, int M, int K) { return smaat_wgrad_num_splits_impl(N, H, W, M, K); }
+
+int smaat_dsconv_wgrad(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                       const float* b_dw, const float* dz, long dz_bs, float* ws, float* dw_out, int N, int Cin,
+                       int kpl, int Cout, int H, int W, void* stream) {
+    if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return -1;
+    WgArgs a{};
+    a.x = x; a.x_bs = x_bs; a.in_scale = in_scale; a.in_shift = in_shift; a.w_dw = w_dw; a.b_dw = b_dw;
+    a.dz = dz; a.dz_bs = dz_bs; a.dwpart = ws;
+    a.N = N; a.Cin = Cin; a.kpl = kpl; a.Kdim = Cin * kpl; a.M = Cout; a.g.H = H; a.g.W = W;
+    CHK(launch_wgrad(a, true, ST));
+    return launch_reduce_rows(ws, a.nsplit, (long)Cout * a.Kdim, dw_out, 1.f, ST);
+}
+
+int smaat_pointwise_wgrad(const float* x, long x_bs, const float* dz, long dz_bs, float* ws, float* dw_out, int N,
+                          int Cin, int M, int H, int W, void* stream) {
+    if (N < 1 || Cin < 1 || M < 1 || H < 1 || W < 1) return -1;
+    WgArgs a{};
+    a.x = x; a.x_bs = x_bs; a.dz = dz; a.dz_bs = dz_bs; a.dwpart = ws;
+    a.N = N; a.Cin = Cin; a.kpl = 1; a.Kdim = Cin; a.M = M; a.g.H = H; a.g.W = W;
+    CHK(launch_wgrad(a, false, ST));
+    return launch_reduce_rows(ws, a.nsplit, (long)M * a.Kdim, dw_out, 1.f, ST);
+}
+
+int smaat_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, const float* w_dw, float* dx, long dx_bs,
+                    float* ws, float* dw_out, float* db_out, int N, int Cin, int kpl, int H, int W, void* stream) {
+    const int Cdw = Cin * kpl;
+    CHK(launch_dw3x3_bwd(x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, ws, N, Cin, kpl, H, W, ST));
+    float* tmp = ws + (long)N * Cdw * 10;
+    CHK(launch_reduce_rows(ws, N, (long)Cdw * 10, tmp, 1.f, ST));
+    return launch_dw_split(tmp, Cdw, dw_out, db_out, ST);
+}
+
+int smaat_bn_finalize(const float* part, int T, int C, double count, const float* bias_shift, const float* gamma,
+                      const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                      float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    return launch_bn_finalize(part, T, C, count, bias_shift, gamma, beta, eps, momentum, running_mean, running_var,
+                              mean, invstd, scale, shift, ST);
+}
+int smaat_affine_act(const float* z, long z_bs, const float* scale, const float* shift, float* y, long y_bs, int N,
+                     int C, int P, int relu, void* stream) {
+    return launch_affine_act(z, z_bs, scale, shift, y, y_bs, N, C, P, relu, ST);
+}
+int smaat_plane_num_slots(int N, int P) { return smaat_bn_bwd_num_slots_impl(N, P); }
+int smaat_bn_bwd_reduce(const float* dy, long dy_bs, const float* z, long z_bs, const float* scale,
+                        const float* shift, const float* mean, const float* invstd, float* part, int N, int C, int P,
+                        int relu, void* stream) {
+    return launch_bn_bwd_reduce(dy, dy_bs, z, z_bs, scale, shift, mean, invstd, part, N, C, P, relu, ST);
+}
+int smaat_bn_bwd_finalize(const float* part, int slots, int C, double count, const float* gamma, const float* invstd,
+                          float* dgamma, float* dbeta, float* coef, void* stream) {
+    return launch_bn_bwd_finalize(part, slots, C, count, gamma, invstd, dgamma, dbeta, coef, ST);
+}
+int smaat_bn_bwd_apply(const float* dy, long dy_bs, const float* z, long z_bs, const float* scale,
+                       const float* shift, const float* mean, const float* invstd, const float* coef, float* dz,
+                       long dz_bs, int N, int C, int P, int relu, void* stream) {
+    return launch_bn_bwd_apply(dy, dy_bs, z, z_bs, scale, shift, mean, invstd, coef, dz, dz_bs, N, C, P, relu, ST);
+}
+int smaat_reduce_rows(const float* part, int rows, long len, float* out, float alpha, void* stream) {
+    return launch_reduce_rows(part, rows, len, out, alpha, ST);
+}
+int smaat_channel_sum(const float* x, long x_bs, int N, int C, int P, float* ws, float* out, void* stream) {
+    return launch_channel_sum(x, x_bs, N, C, P, ws, out, ST);
+}
+int smaat_copy_planes(const float* src, long s_bs, float* dst, long d_bs, int N, long plane_len, int accum,
+                      void* stream) {
+    return launch_copy_planes(src, s_bs, dst, d_bs, N, plane_len, accum, ST);
+}
+int smaat_maxpool2_fwd(const float* x, long x_bs, float* y, long y_bs, int N, int C, int H, int W, void* stream) {
+    return launch_maxpool2_fwd(x, x_bs, y, y_bs, N, C, H, W, ST);
+}
+int smaat_maxpool2_bwd(const float* x, long x_bs, const float* dy, long dy_bs, float* dx, long dx_bs, int N, int C,
+                       int H, int W, int accum, void* stream) {
+    return launch_maxpool2_bwd(x, x_bs, dy, dy_bs, dx, dx_bs, N, C, H, W, accum, ST);
+}
+int smaat_upsample2x_fwd(const float* x, long x_bs, float* out, long out_bs, int N, int C, int H, int W, int Ho,
+                         int Wo, int pad_t, int pad_l, void* stream) {
+    return launch_upsample2x_fwd(x, x_bs, out, out_bs, N, C, H, W, Ho, Wo, pad_t, pad_l, ST);
+}
+int smaat_upsample2x_bwd(const float* dout, long dout_bs, float* dx, long dx_bs, int N, int C, int H, int W, int Ho,
+                         int Wo, int pad_t, int pad_l, void* stream) {
+    return launch_upsample2x_bwd(dout, dout_bs, dx, dx_bs, N, C, H, W, Ho, Wo, pad_t, pad_l, ST);
+}
+int smaat_cbam_spconv_blocks(int N, int H, int W) { return smaat_cbam_spconv_blocks_impl(N, H, W); }
+int smaat_cbam_pix_blocks(int N, int P) { return smaat_cbam_pix_blocks_impl(N, P); }
+int smaat_cbam_chpool(const float* x, long x_bs, int N, int C, int P, float* avg, float* mx, int* amax,
+                      void* stream) {
+    return launch_cbam_chpool(x, x_bs, N, C, P, avg, mx, amax, ST);
+}
+int smaat_cbam_mlp(const float* avg, const float* mx, const float* w1, const float* b1, const float* w2,
+                   const float* b2, int N, int C, int Cr, float* ha, float* hm, float* s, void* stream) {
+    return launch_cbam_mlp(avg, mx, w1, b1, w2, b2, N, C, Cr, ha, hm, s, ST);
+}
+int smaat_cbam_sppool(const float* x, long x_bs, const float* s, int N, int C, int P, float* maps, void* stream) {
+    return launch_cbam_sppool(x, x_bs, s, N, C, P, maps, ST);
+}
+int smaat_cbam_spconv(const float* maps, const float* wc, int ks, int N, int H, int W, float* conv, float* part,
+                      void* stream) {
+    return launch_cbam_spconv(maps, wc, ks, N, H, W, conv, part, ST);
+}
+int smaat_cbam_gate(const float* conv, const float* scale, const float* shift, long total, float* gate,
+                    void* stream) {
+    return launch_cbam_gate(conv, scale, shift, total, gate, ST);
+}
+int smaat_cbam_apply(const float* x, long x_bs, const float* s, const float* gate, float* out, long out_bs, int N,
+                     int C, int P, void* stream) {
+    return launch_cbam_apply(x, x_bs, s, gate, out, out_bs, N, C, P, ST);
+}
+int smaat_cbam_bwd_gate(const float* dout, long dout_bs, const float* x, long x_bs, const float* s,
+                        const float* gate, const float* conv, const float* mean, const float* invstd, int N, int C,
+                        int P, float* dbn, float* part, void* stream) {
+    return launch_cbam_bwd_gate(dout, dout_bs, x, x_bs, s, gate, conv, mean, invstd, N, C, P, dbn, part, ST);
+}
+int smaat_cbam_bwd_spconv(const float* dbn, const float* conv, const float* mean, const float* invstd,
+                          const float* coef, const float* maps, const float* wc, int ks, int N, int H, int W,
+                          float* dmaps, float* wpart, void* stream) {
+    return launch_cbam_bwd_spconv(dbn, conv, mean, invstd, coef, maps, wc, ks, N, H, W, dmaps, wpart, ST);
+}
+int smaat_cbam_bwd_main(const float* dout, long dout_bs, const float* x, long x_bs, const float* s,
+                        const float* gate, const float* maps, const float* dmaps, int N, int C, int P, float* dx,
+                        long dx_bs, float* dspart, void* stream) {
+    return launch_cbam_bwd_main(dout, dout_bs, x, x_bs, s, gate, maps, dmaps, N, C, P, dx, dx_bs, dspart, ST);
+}
+int smaat_cbam_bwd_mlp(const float* ds, const float* s, const float* avg, const float* mx, const float* ha,
+                       const float* hm, const float* w1, const float* w2, int N, int C, int Cr, float* pg,
+                       float* davg, float* dmx, void* stream) {
+    return launch_cbam_bwd_mlp(ds, s, avg, mx, ha, hm, w1, w2, N, C, Cr, pg, davg, dmx, ST);
+}
+int smaat_cbam_bwd_final(float* dx, long dx_bs, const float* davg, const float* dmx, const int* amax, int N, int C,
+                         int P, void* stream) {
+    return launch_cbam_bwd_final(dx, dx_bs, davg, dmx, amax, N, C, P, ST);
+}
+
+}  // extern "C"

@@ -1,0 +1,509 @@
+// CBAM = ChannelAttention -> SpatialAttention  (reference models/layers.py:90-141)
+//
+// forward:
+//   k_cbam_chpool   avg / max (+ first argmax) over H*W per (n,c)            layers.py:107-108
+//   k_cbam_mlp      shared MLP on both pooled vectors, sum, sigmoid -> s[n][c]   :98-103,109-110
+//   k_cbam_sppool   mean / max over channels of x*s -> maps[n][2][p]          :123-125
+//   k_cbam_spconv   Conv2d(2,1,k,pad k/2,no bias) + BN(1) partial stats          :126-127
+//   (bn finalize from bn.hip, C = 1)
+//   k_cbam_apply    out = x * s[n][c] * sigmoid(conv*scale+shift)[n][p]          :110,128
+// backward: see the individual kernels.
+#include "common.h"
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cbam_chpool(const float* __restrict__ x, long x_bs, int C, int P,
+                                                     float* __restrict__ avg, float* __restrict__ mx,
+                                                     int* __restrict__ amax) {
+    __shared__ float rf[8];
+    __shared__ int ri[4];
+    const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
+    const float* xp = x + (long)n * x_bs + (long)c * P;
+    float s = 0.f, m = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int p = threadIdx.x; p < P; p += 256) {
+        const float v = xp[p];
+        s += v;
+        if (v > m) {
+            m = v;
+            mi = p;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float ws = wave_sum_all(s);
+    const float wm = wave_max_all(m);
+    if (lane == 0) {
+        rf[wave] = ws;
+        rf[4 + wave] = wm;
+    }
+    __syncthreads();
+    const float bm = fmaxf(fmaxf(rf[4], rf[5]), fmaxf(rf[6], rf[7]));
+    int cand = (m == bm) ? mi : 0x7fffffff;
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) {
+        const int o = __shfl_xor(cand, k, 64);
+        cand = o < cand ? o : cand;
+    }
+    if (lane == 0) ri[wave] = cand;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = (double)rf[0] + (double)rf[1] + (double)rf[2] + (double)rf[3];
+        avg[plane] = (float)(tot / (double)P);
+        mx[plane] = bm;
+        int a = ri[0];
+        a = ri[1] < a ? ri[1] : a;
+        a = ri[2] < a ? ri[2] : a;
+        a = ri[3] < a ? ri[3] : a;
+        amax[plane] = a;
+    }
+}
+
+// one block per sample.  LDS: avg[C], mx[C], ha[Cr], hm[Cr]
+__global__ __launch_bounds__(256) void k_cbam_mlp(const float* __restrict__ avg, const float* __restrict__ mx,
+                                                  const float* __restrict__ w1, const float* __restrict__ b1,
+                                                  const float* __restrict__ w2, const float* __restrict__ b2, int C,
+                                                  int Cr, float* __restrict__ ha_out, float* __restrict__ hm_out,
+                                                  float* __restrict__ s_out) {
+    extern __shared__ float sm[];
+    float* la = sm;
+    float* lm = la + C;
+    float* ha = lm + C;
+    float* hm = ha + Cr;
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < C; c += 256) {
+        la[c] = avg[(long)n * C + c];
+        lm[c] = mx[(long)n * C + c];
+    }
+    __syncthreads();
+    for (int j = wave; j < Cr; j += 4) {
+        float pa = 0.f, pm = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float w = w1[(long)j * C + c];
+            pa = fmaf(w, la[c], pa);
+            pm = fmaf(w, lm[c], pm);
+        }
+        pa = wave_sum_all(pa);
+        pm = wave_sum_all(pm);
+        if (lane == 0) {
+            const float a = fmaxf(pa + b1[j], 0.f), m = fmaxf(pm + b1[j], 0.f);
+            ha[j] = a;
+            hm[j] = m;
+            ha_out[(long)n * Cr + j] = a;
+            hm_out[(long)n * Cr + j] = m;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float oa = b2[c], om = b2[c];
+        for (int j = 0; j < Cr; ++j) {
+            const float w = w2[(long)c * Cr + j];
+            oa = fmaf(w, ha[j], oa);
+            om = fmaf(w, hm[j], om);
+        }
+        s_out[(long)n * C + c] = sigmoidf_(oa + om);
+    }
+}
+
+// thread per pixel, loop over channels.  maps[n][0][p] = mean_c(x*s), maps[n][1][p] = max_c(x*s)
+__global__ __launch_bounds__(256) void k_cbam_sppool(const float* __restrict__ x, long x_bs,
+                                                     const float* __restrict__ s, int C, int P,
+                                                     float* __restrict__ maps) {
+    const int n = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const float* xp = x + (long)n * x_bs + p;
+    const float* sp = s + (long)n * C;
+    float sum = 0.f, m = -INFINITY;
+    for (int c = 0; c < C; ++c) {
+        const float v = xp[(long)c * P] * sp[c];
+        sum += v;
+        m = fmaxf(m, v);
+    }
+    maps[((long)n * 2 + 0) * P + p] = sum / (float)C;
+    maps[((long)n * 2 + 1) * P + p] = m;
+}
+
+// k x k conv (k = 3 or 7) over the 2-channel maps, 16x16 pixel tiles, + BN(1) partials
+// part[2][nblocks]
+#define SPT 16
+__global__ __launch_bounds__(256) void k_cbam_spconv(const float* __restrict__ maps, const float* __restrict__ wc,
+                                                     int ks, int H, int W, float* __restrict__ conv,
+                                                     float* __restrict__ part, int nblocks) {
+    __shared__ float tile[2][SPT + 6][SPT + 6 + 1];
+    __shared__ float wl[2 * 49];
+    __shared__ float red[8];
+    const int n = blockIdx.z, P = H * W;
+    const int r0 = blockIdx.y * SPT, c0 = blockIdx.x * SPT;
+    const int pd = ks >> 1, R = SPT + 2 * pd;
+    const int tid = threadIdx.x;
+    if (tid < 2 * ks * ks) wl[tid] = wc[tid];
+    for (int e = tid; e < 2 * R * R; e += 256) {
+        const int ch = e / (R * R), rem = e - ch * R * R;
+        const int sr = rem / R, sc = rem - sr * R;
+        const int gr = r0 - pd + sr, gc = c0 - pd + sc;
+        float v = 0.f;
+        if (gr >= 0 && gr < H && gc >= 0 && gc < W) v = maps[((long)n * 2 + ch) * P + gr * W + gc];
+        tile[ch][sr][sc] = v;
+    }
+    __syncthreads();
+    const int tr = tid / SPT, tc = tid - tr * SPT;
+    const int r = r0 + tr, c = c0 + tc;
+    float acc = 0.f;
+    const bool valid = r < H && c < W;
+    if (valid) {
+        for (int ch = 0; ch < 2; ++ch)
+            for (int i = 0; i < ks; ++i)
+                for (int j = 0; j < ks; ++j) acc = fmaf(wl[(ch * ks + i) * ks + j], tile[ch][tr + i][tc + j], acc);
+        conv[(long)n * P + r * W + c] = acc;
+    }
+    const float v = valid ? acc : 0.f;
+    const float t1 = block_sum_t0(v, red);
+    const float t2 = block_sum_t0(v * v, red + 4);
+    if (tid == 0) {
+        const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        part[blk] = t1;
+        part[nblocks + blk] = t2;
+    }
+}
+
+// m[n][p] = sigmoid(conv * scale + shift)   (BN(1) + sigmoid)
+__global__ __launch_bounds__(256) void k_cbam_gate(const float* __restrict__ conv, const float* __restrict__ scale,
+                                                   const float* __restrict__ shift, long total,
+                                                   float* __restrict__ gate) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) gate[i] = sigmoidf_(fmaf(conv[i], scale[0], shift[0]));
+}
+
+// out[n][c][p] = x[n][c][p] * s[n][c] * gate[n][p];  grid (N*C planes, segments)
+__global__ __launch_bounds__(256) void k_cbam_apply(const float* __restrict__ x, long x_bs,
+                                                    const float* __restrict__ s, const float* __restrict__ gate,
+                                                    float* __restrict__ out, long out_bs, int C, int P, int seg_len) {
+    const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
+    const float sv = s[plane];
+    const float* xp = x + (long)n * x_bs + (long)c * P;
+    const float* gp = gate + (long)n * P;
+    float* op = out + (long)n * out_bs + (long)c * P;
+    const int p0 = blockIdx.y * seg_len;
+    int p1 = p0 + seg_len;
+    if (p1 > P) p1 = P;
+    const bool vec = ((P & 3) == 0) && ((x_bs & 3) == 0) && ((out_bs & 3) == 0) && ((seg_len & 3) == 0) &&
+                     ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)out) & 15) == 0) &&
+                     ((((uintptr_t)gate) & 15) == 0);
+    if (vec) {
+        for (int p = p0 + threadIdx.x * 4; p < p1; p += 1024) {
+            float4 v = *(const float4*)(xp + p);
+            const float4 g = *(const float4*)(gp + p);
+            v.x = v.x * sv * g.x;
+            v.y = v.y * sv * g.y;
+            v.z = v.z * sv * g.z;
+            v.w = v.w * sv * g.w;
+            *(float4*)(op + p) = v;
+        }
+    } else {
+        for (int p = p0 + threadIdx.x; p < p1; p += 256) op[p] = xp[p] * sv * gp[p];
+    }
+}
+
+// ===================================== backward ======================================
+// B1: dgate[n][p] = sum_c dout*x*s ; dbn = dgate * m * (1-m); BN(1) backward partials
+//     (sum dbn, sum dbn*xhat), xhat = (conv - mean) * invstd.   part[2][nblocks]
+__global__ __launch_bounds__(256) void k_cbam_bwd_gate(const float* __restrict__ dout, long dout_bs,
+                                                       const float* __restrict__ x, long x_bs,
+                                                       const float* __restrict__ s, const float* __restrict__ gate,
+                                                       const float* __restrict__ conv,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, int C, int P,
+                                                       float* __restrict__ dbn, float* __restrict__ part,
+                                                       int nblocks) {
+    __shared__ float red[8];
+    const int n = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    float d = 0.f, dx = 0.f;
+    if (p < P) {
+        const float* xp = x + (long)n * x_bs + p;
+        const float* gp = dout + (long)n * dout_bs + p;
+        const float* sp = s + (long)n * C;
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc = fmaf(gp[(long)c * P] * xp[(long)c * P], sp[c], acc);
+        const float m = gate[(long)n * P + p];
+        d = acc * m * (1.f - m);
+        dbn[(long)n * P + p] = d;
+        dx = d * (conv[(long)n * P + p] - mean[0]) * invstd[0];
+    }
+    const float t1 = block_sum_t0(d, red);
+    const float t2 = block_sum_t0(dx, red + 4);
+    if (threadIdx.x == 0) {
+        const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+        part[blk] = t1;
+        part[nblocks + blk] = t2;
+    }
+}
+
+// B2: dconv = c1*(dbn - c2 - xhat*c3) on the fly (staged with halo); transposed conv ->
+//     dmaps[n][2][p]; conv-weight gradient partials wpart[nblocks][2*ks*ks]
+__global__ __launch_bounds__(256) void k_cbam_bwd_spconv(const float* __restrict__ dbn,
+                                                         const float* __restrict__ conv,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd,
+                                                         const float* __restrict__ coef,
+                                                         const float* __restrict__ maps,
+                                                         const float* __restrict__ wc, int ks, int H, int W,
+                                                         float* __restrict__ dmaps, float* __restrict__ wpart) {
+    __shared__ float tile[SPT + 6][SPT + 6 + 1];
+    __shared__ float wl[2 * 49];
+    __shared__ float red[4 * 2 * 49];
+    const int n = blockIdx.z, P = H * W;
+    const int r0 = blockIdx.y * SPT, c0 = blockIdx.x * SPT;
+    const int pd = ks >> 1, R = SPT + 2 * pd;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float mu = mean[0], is = invstd[0], c1 = coef[0], c2 = coef[1], c3 = coef[2];
+    if (tid < 2 * ks * ks) wl[tid] = wc[tid];
+    for (int e = tid; e < R * R; e += 256) {
+        const int sr = e / R, sc = e - sr * R;
+        const int gr = r0 - pd + sr, gc = c0 - pd + sc;
+        float v = 0.f;
+        if (gr >= 0 && gr < H && gc >= 0 && gc < W) {
+            const long o = (long)n * P + gr * W + gc;
+            v = c1 * (dbn[o] - c2 - (conv[o] - mu) * is * c3);
+        }
+        tile[sr][sc] = v;
+    }
+    __syncthreads();
+    const int tr = tid / SPT, tc = tid - tr * SPT;
+    const int r = r0 + tr, c = c0 + tc;
+    const bool valid = r < H && c < W;
+    float m0 = 0.f, m1 = 0.f;
+    if (valid) {
+        m0 = maps[((long)n * 2 + 0) * P + r * W + c];
+        m1 = maps[((long)n * 2 + 1) * P + r * W + c];
+    }
+    float d0 = 0.f, d1 = 0.f;
+    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    // tap (i,j): forward read maps at q+(i-pd, j-pd); so dconv at q' - (i-pd, j-pd) pairs with maps[q']
+    for (int i = 0; i < ks; ++i) {
+        for (int j = 0; j < ks; ++j) {
+            const float d = valid ? tile[tr + 2 * pd - i][tc + 2 * pd - j] : 0.f;
+            d0 = fmaf(wl[(0 * ks + i) * ks + j], d, d0);
+            d1 = fmaf(wl[(1 * ks + i) * ks + j], d, d1);
+            const float a0 = wave_sum_l63(m0 * d);
+            const float a1 = wave_sum_l63(m1 * d);
+            if (lane == 63) {
+                red[(wave * 2 + 0) * 49 + i * ks + j] = a0;
+                red[(wave * 2 + 1) * 49 + i * ks + j] = a1;
+            }
+        }
+    }
+    if (valid) {
+        dmaps[((long)n * 2 + 0) * P + r * W + c] = d0;
+        dmaps[((long)n * 2 + 1) * P + r * W + c] = d1;
+    }
+    __syncthreads();
+    if (tid < 2 * ks * ks) {
+        const int ch = tid / (ks * ks), t = tid - ch * ks * ks;
+        const float v = red[(0 * 2 + ch) * 49 + t] + red[(1 * 2 + ch) * 49 + t] + red[(2 * 2 + ch) * 49 + t] +
+                        red[(3 * 2 + ch) * 49 + t];
+        wpart[(long)blk * (2 * ks * ks) + tid] = v;
+    }
+}
+
+// B3: per pixel, loop over channels:
+//     xs = x*s ; dxs = dout*gate + dmaps0/C + [c == first argmax_c xs] * dmaps1
+//     t[n][c][p] = dxs * s         (main part of dx, written to dx)
+//     dspart[blk][n][c] = sum_p dxs * x          (-> ds[n][c] after k_reduce_rows over blk)
+__global__ __launch_bounds__(256) void k_cbam_bwd_main(const float* __restrict__ dout, long dout_bs,
+                                                       const float* __restrict__ x, long x_bs,
+                                                       const float* __restrict__ s, const float* __restrict__ gate,
+                                                       const float* __restrict__ maps,
+                                                       const float* __restrict__ dmaps, int C, int P,
+                                                       float* __restrict__ dx, long dx_bs,
+                                                       float* __restrict__ dspart) {
+    extern __shared__ float red[];  // [4][C]
+    const int n = blockIdx.y, N = gridDim.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool valid = p < P;
+    const int pp = valid ? p : P - 1;
+    const float* xp = x + (long)n * x_bs + pp;
+    const float* gp = dout + (long)n * dout_bs + pp;
+    float* dp = dx + (long)n * dx_bs + pp;
+    const float* sp = s + (long)n * C;
+    const float g = gate[(long)n * P + pp];
+    const float mxv = maps[((long)n * 2 + 1) * P + pp];
+    const float da = dmaps[((long)n * 2 + 0) * P + pp] / (float)C;
+    const float dm = dmaps[((long)n * 2 + 1) * P + pp];
+    bool found = false;
+    for (int c = 0; c < C; ++c) {
+        const float xv = xp[(long)c * P], sv = sp[c];
+        const float xs = xv * sv;
+        float dxs = fmaf(gp[(long)c * P], g, da);
+        if (!found && xs == mxv) {
+            dxs += dm;
+            found = true;
+        }
+        if (valid) dp[(long)c * P] = dxs * sv;
+        const float r = wave_sum_l63(valid ? dxs * xv : 0.f);
+        if (lane == 63) red[wave * C + c] = r;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256)
+        dspart[((long)blockIdx.x * N + n) * C + c] = red[c] + red[C + c] + red[2 * C + c] + red[3 * C + c];
+}
+
+// B4: MLP backward, one block per sample.  Per-sample parameter-gradient partials:
+//   pg[n][ C*Cr (dW2) | C (db2) | Cr*C (dW1) | Cr (db1) ]  -> reduced over n by k_reduce_rows
+//   davg[n][c], dmx[n][c]
+__global__ __launch_bounds__(256) void k_cbam_bwd_mlp(const float* __restrict__ ds, const float* __restrict__ s,
+                                                      const float* __restrict__ avg, const float* __restrict__ mx,
+                                                      const float* __restrict__ ha, const float* __restrict__ hm,
+                                                      const float* __restrict__ w1, const float* __restrict__ w2,
+                                                      int C, int Cr, float* __restrict__ pg,
+                                                      float* __restrict__ davg, float* __restrict__ dmx) {
+    extern __shared__ float sm[];
+    float* dout = sm;        // [C]
+    float* dha = dout + C;   // [Cr]
+    float* dhm = dha + Cr;   // [Cr]
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long pgs = (long)C * Cr + C + (long)Cr * C + Cr;
+    float* pgn = pg + (long)n * pgs;
+    float* dW2 = pgn;
+    float* db2 = dW2 + (long)C * Cr;
+    float* dW1 = db2 + C;
+    float* db1 = dW1 + (long)Cr * C;
+    for (int c = tid; c < C; c += 256) {
+        const float sv = s[(long)n * C + c];
+        const float d = ds[(long)n * C + c] * sv * (1.f - sv);
+        dout[c] = d;
+        db2[c] = 2.f * d;
+        for (int j = 0; j < Cr; ++j) dW2[(long)c * Cr + j] = d * (ha[(long)n * Cr + j] + hm[(long)n * Cr + j]);
+    }
+    __syncthreads();
+    for (int j = wave; j < Cr; j += 4) {
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a = fmaf(dout[c], w2[(long)c * Cr + j], a);
+        a = wave_sum_all(a);
+        if (lane == 0) {
+            const float va = ha[(long)n * Cr + j] > 0.f ? a : 0.f;
+            const float vm = hm[(long)n * Cr + j] > 0.f ? a : 0.f;
+            dha[j] = va;
+            dhm[j] = vm;
+            db1[j] = va + vm;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const float av = avg[(long)n * C + c], mv = mx[(long)n * C + c];
+        float da = 0.f, dm = 0.f;
+        for (int j = 0; j < Cr; ++j) {
+            const float w = w1[(long)j * C + c];
+            da = fmaf(dha[j], w, da);
+            dm = fmaf(dhm[j], w, dm);
+            dW1[(long)j * C + c] = dha[j] * av + dhm[j] * mv;
+        }
+        davg[(long)n * C + c] = da;
+        dmx[(long)n * C + c] = dm;
+    }
+}
+
+// B5: dx[n][c][p] += davg[n][c]/P ; dx[n][c][amax[n][c]] += dmx[n][c]     (in place)
+__global__ __launch_bounds__(256) void k_cbam_bwd_final(float* __restrict__ dx, long dx_bs,
+                                                        const float* __restrict__ davg,
+                                                        const float* __restrict__ dmx, const int* __restrict__ amax,
+                                                        int C, int P, int seg_len) {
+    const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
+    const float add = davg[plane] / (float)P;
+    const float dm = dmx[plane];
+    const int am = amax[plane];
+    float* dp = dx + (long)n * dx_bs + (long)c * P;
+    const int p0 = blockIdx.y * seg_len;
+    int p1 = p0 + seg_len;
+    if (p1 > P) p1 = P;
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+        float v = dp[p] + add;
+        if (p == am) v += dm;
+        dp[p] = v;
+    }
+}
+
+// =====================================================================================
+static inline int cdivc(long a, long b) { return (int)((a + b - 1) / b); }
+static int seg_len_c(int P) { return P <= 8192 ? ((P + 1023) / 1024) * 1024 : 8192; }
+
+int smaat_cbam_spconv_blocks_impl(int N, int H, int W) { return N * cdivc(H, SPT) * cdivc(W, SPT); }
+int smaat_cbam_pix_blocks_impl(int N, int P) { return N * cdivc(P, 256); }
+
+int launch_cbam_chpool(const float* x, long x_bs, int N, int C, int P, float* avg, float* mx, int* amax,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(k_cbam_chpool, dim3(N * C), dim3(256), 0, st, x, x_bs, C, P, avg, mx, amax);
+    return (int)hipGetLastError();
+}
+int launch_cbam_mlp(const float* avg, const float* mx, const float* w1, const float* b1, const float* w2,
+                    const float* b2, int N, int C, int Cr, float* ha, float* hm, float* s, hipStream_t st) {
+    const size_t lds = sizeof(float) * (size_t)(2 * C + 2 * Cr);
+    hipLaunchKernelGGL(k_cbam_mlp, dim3(N), dim3(256), lds, st, avg, mx, w1, b1, w2, b2, C, Cr, ha, hm, s);
+    return (int)hipGetLastError();
+}
+int launch_cbam_sppool(const float* x, long x_bs, const float* s, int N, int C, int P, float* maps, hipStream_t st) {
+    hipLaunchKernelGGL(k_cbam_sppool, dim3(cdivc(P, 256), N), dim3(256), 0, st, x, x_bs, s, C, P, maps);
+    return (int)hipGetLastError();
+}
+int launch_cbam_spconv(const float* maps, const float* wc, int ks, int N, int H, int W, float* conv, float* part,
+                       hipStream_t st) {
+    if (ks != 3 && ks != 7) return -1;
+    dim3 grid(cdivc(W, SPT), cdivc(H, SPT), N);
+    hipLaunchKernelGGL(k_cbam_spconv, grid, dim3(256), 0, st, maps, wc, ks, H, W, conv, part,
+                       (int)(grid.x * grid.y * grid.z));
+    return (int)hipGetLastError();
+}
+int launch_cbam_gate(const float* conv, const float* scale, const float* shift, long total, float* gate,
+                     hipStream_t st) {
+    hipLaunchKernelGGL(k_cbam_gate, dim3(cdivc(total, 256)), dim3(256), 0, st, conv, scale, shift, total, gate);
+    return (int)hipGetLastError();
+}
+int launch_cbam_apply(const float* x, long x_bs, const float* s, const float* gate, float* out, long out_bs, int N,
+                      int C, int P, hipStream_t st) {
+    const int seg = seg_len_c(P);
+    hipLaunchKernelGGL(k_cbam_apply, dim3(N * C, cdivc(P, seg)), dim3(256), 0, st, x, x_bs, s, gate, out, out_bs, C,
+                       P, seg);
+    return (int)hipGetLastError();
+}
+int launch_cbam_bwd_gate(const float* dout, long dout_bs, const float* x, long x_bs, const float* s,
+                         const float* gate, const float* conv, const float* mean, const float* invstd, int N, int C,
+                         int P, float* dbn, float* part, hipStream_t st) {
+    dim3 grid(cdivc(P, 256), N);
+    hipLaunchKernelGGL(k_cbam_bwd_gate, grid, dim3(256), 0, st, dout, dout_bs, x, x_bs, s, gate, conv, mean, invstd,
+                       C, P, dbn, part, (int)(grid.x * grid.y));
+    return (int)hipGetLastError();
+}
+int launch_cbam_bwd_spconv(const float* dbn, const float* conv, const float* mean, const float* invstd,
+                           const float* coef, const float* maps, const float* wc, int ks, int N, int H, int W,
+                           float* dmaps, float* wpart, hipStream_t st) {
+    if (ks != 3 && ks != 7) return -1;
+    dim3 grid(cdivc(W, SPT), cdivc(H, SPT), N);
+    hipLaunchKernelGGL(k_cbam_bwd_spconv, grid, dim3(256), 0, st, dbn, conv, mean, invstd, coef, maps, wc, ks, H, W,
+                       dmaps, wpart);
+    return (int)hipGetLastError();
+}
+int launch_cbam_bwd_main(const float* dout, long dout_bs, const float* x, long x_bs, const float* s,
+                         const float* gate, const float* maps, const float* dmaps, int N, int C, int P, float* dx,
+                         long dx_bs, float* dspart, hipStream_t st) {
+    const size_t lds = sizeof(float) * (size_t)(4 * C);
+    hipLaunchKernelGGL(k_cbam_bwd_main, dim3(cdivc(P, 256), N), dim3(256), lds, st, dout, dout_bs, x, x_bs, s, gate,
+                       maps, dmaps, C, P, dx, dx_bs, dspart);
+    return (int)hipGetLastError();
+}
+int launch_cbam_bwd_mlp(const float* ds, const float* s, const float* avg, const float* mx, const float* ha,
+                        const float* hm, const float* w1, const float* w2, int N, int C, int Cr, float* pg,
+                        float* davg, float* dmx, hipStream_t st) {
+    const size_t lds = sizeof(float) * (size_t)(C + 2 * Cr);
+    hipLaunchKernelGGL(k_cbam_bwd_mlp, dim3(N), dim3(256), lds, st, ds, s, avg, mx, ha, hm, w1, w2, C, Cr, pg, davg,
+                       dmx);
+    return (int)hipGetLastError();
+}
+int launch_cbam_bwd_final(float* dx, long dx_bs, const float* davg, const float* dmx, const int* amax, int N, int C,
+                          int P, hipStream_t st) {
+    const int seg = seg_len_c(P);
+    hipLaunchKernelGGL(k_cbam_bwd_final, dim3(N * C, cdivc(P, seg)), dim3(256), 0, st, dx, dx_bs, davg, dmx, amax, C,
+                       P, seg);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,122 @@
+// Shared device helpers for the SmaAt-UNet gfx950 kernels.
+// Written for CDNA4 only: 64-lane wavefronts, DPP row ops, f32 MFMA 32x32x2.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SMAAT_THREADS 256
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- DPP cross-lane adds (pure VALU, no LDS crossbar) -------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_src(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+// sum over the 16 lanes of a DPP row; every lane of the row ends with the row sum
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_src<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v += dpp_src<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v += dpp_src<0x141, 0xF>(v);  // row_half_mirror
+    v += dpp_src<0x140, 0xF>(v);  // row_mirror
+    return v;
+}
+// sum over each 32-lane half of the wave; valid in lanes 16..31 (half 0) and 48..63 (half 1)
+__device__ __forceinline__ float half32_sum_hi(float v) {
+    v = row16_sum(v);
+    v += dpp_src<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+    return v;
+}
+// full 64-lane sum, valid in lane 63
+__device__ __forceinline__ float wave_sum_l63(float v) {
+    v = half32_sum_hi(v);
+    v += dpp_src<0x143, 0xC>(v);  // row_bcast:31 into rows 2,3
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_src<0xB1, 0xF>(v));
+    v = fmaxf(v, dpp_src<0x4E, 0xF>(v));
+    v = fmaxf(v, dpp_src<0x141, 0xF>(v));
+    v = fmaxf(v, dpp_src<0x140, 0xF>(v));
+    return v;
+}
+// butterfly shuffles for the places where every lane needs the result
+__device__ __forceinline__ float wave_sum_all(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max_all(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+// block-wide sum for 256-thread blocks; result valid in thread 0. `red` = 4 floats of LDS.
+__device__ __forceinline__ float block_sum_t0(float v, float* red) {
+    v = wave_sum_l63(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 63) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// ---- pixel-tile geometry ---------------------------------------------------------
+// A "pixel tile" is PT pixels of ONE image.  mode 0: PT consecutive pixels of the
+// flattened H*W plane (small maps).  mode 1: a TH x TW patch (TH*TW == PT).
+struct TileGeom {
+    int H, W, P;
+    int mode, TH, TW;
+    int tiles_x;        // mode 1: tiles along W
+    int tiles_per_img;  // per image
+    int T;              // N * tiles_per_img
+    int PT;
+};
+
+struct StageRegion {
+    int row_lo, col_lo, nrows, SW;  // region = nrows x SW staged floats per channel
+};
+
+__device__ __forceinline__ StageRegion stage_region(const TileGeom& g, int tl) {
+    StageRegion r;
+    if (g.mode == 0) {
+        const int p0 = tl * g.PT;
+        int p1 = p0 + g.PT;
+        if (p1 > g.P) p1 = g.P;
+        r.row_lo = p0 / g.W - 1;
+        r.nrows = (p1 - 1) / g.W - r.row_lo + 2;
+        r.SW = g.W + 2;
+        r.col_lo = -1;
+    } else {
+        const int ty = tl / g.tiles_x, tx = tl - ty * g.tiles_x;
+        r.row_lo = ty * g.TH - 1;
+        r.nrows = g.TH + 2;
+        r.SW = g.TW + 2;
+        r.col_lo = tx * g.TW - 1;
+    }
+    return r;
+}
+
+// tile pixel i -> (row, col); returns false when the pixel is outside the image
+__device__ __forceinline__ bool tile_pixel(const TileGeom& g, int tl, int i, int& r, int& c) {
+    if (g.mode == 0) {
+        const int p = tl * g.PT + i;
+        r = p / g.W;
+        c = p - r * g.W;
+        return p < g.P;
+    }
+    const int ty = tl / g.tiles_x, tx = tl - ty * g.tiles_x;
+    const int tr = i / g.TW, tc = i - tr * g.TW;
+    r = ty * g.TH + tr;
+    c = tx * g.TW + tc;
+    return (r < g.H) && (c < g.W);
+}
+
+#define HIP_RET(expr)                          \
+    do {                                       \
+        hipError_t _e = (expr);                \
+        if (_e != hipSuccess) return (int)_e;  \
+    } while (0)

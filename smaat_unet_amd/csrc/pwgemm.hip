@@ -1,0 +1,559 @@
+// Pointwise (1x1) convolution family on the f32 MFMA pipe of gfx950, with the
+// depthwise 3x3 stage fused in front of it through LDS.
+//
+//   k_pwgemm<DW=true>   z[n][m][p] = sum_k wt[k][m] * dw3x3(x)[n][k][p] + bias[m]
+//                       (DepthwiseSeparableConv.forward, reference models/layers.py:47-50)
+//                       + per-tile BatchNorm partial statistics of the accumulators.
+//   k_pwgemm<DW=false>  out[n][m][p] = sum_c wt[c][m] * in[n][c][p] + bias[m]
+//                       (OutConv, reference models/unet_parts.py:72; and the data-gradient
+//                        dY = W^T dZ of the pointwise conv, with wt = w_pw in natural layout)
+//   k_wgrad<DW=true>    dW_pw[m][k] = sum_{n,p} dz[n][m][p] * dw3x3(x)[n][k][p]   (Y recomputed)
+//   k_wgrad<DW=false>   dW[m][k]    = sum_{n,p} dz[n][m][p] * in[n][k][p]
+//
+// Mapping: v_mfma_f32_32x32x2_f32, A = weights (rows = output channel), B = pixels
+// (cols), so that for a fixed accumulator register the 32 lanes of a half-wave hold 32
+// consecutive pixels of one output channel -> every global store is a full 128 B row.
+#include "common.h"
+
+#define KC 16       // contraction rows staged per chunk
+#define SMAX 768    // staged floats per input channel (3 per thread)
+#define SMAXW 512   // same for the weight-gradient kernel (64-pixel sub tiles, 2 per thread)
+#define PSW 64      // pixels per sub tile in the weight-gradient kernel
+
+struct PwArgs {
+    const float* x;
+    long x_bs;
+    const float* in_scale;
+    const float* in_shift;
+    const float* w_dw;
+    const float* b_dw;
+    const float* wt;    // [Kdim][M]
+    const float* bias;  // [M] or null
+    float* out;
+    long out_bs;
+    float* part;  // [2][T][M] or null
+    int N, Cin, kpl, Kdim, M, nco;
+    TileGeom g;
+};
+
+template <int WCO, int CT, int WPX, int PXT, bool DW, bool AFF>
+__global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
+    constexpr int COT = WCO * CT * 32;
+    constexpr int PT = WPX * PXT * 32;
+    constexpr int G = SMAAT_THREADS / PT;  // channel sub-groups in the depthwise stage
+    extern __shared__ float smem[];
+    float* Yl = smem;                   // [KC][PT]
+    float* Wl = Yl + KC * PT;           // [KC][COT]
+    float* stat = Wl + KC * COT;        // [WPX][2][COT]
+    int* pixoff = (int*)(stat + WPX * 2 * COT);  // [PT]
+    int* sidx = pixoff + PT;            // [PT]
+    float* S = (float*)(sidx + PT);     // [kci][SMAX]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wco = wave % WCO, wpx = wave / WCO;
+    const int l31 = lane & 31, half = lane >> 5;
+    const TileGeom& g = a.g;
+
+    // XCD-aware block map: the co tiles of one pixel tile run back to back on ONE XCD.
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int cot = idx % a.nco;
+    const int ptg = (idx / a.nco) * 8 + xcd;
+    if (ptg >= g.T) return;
+    const int n = ptg / g.tiles_per_img, tl = ptg - n * g.tiles_per_img;
+    const int co0 = cot * COT;
+    const StageRegion rg = stage_region(g, tl);
+
+    for (int i = tid; i < PT; i += SMAAT_THREADS) {
+        int r, c;
+        const bool v = tile_pixel(g, tl, i, r, c);
+        pixoff[i] = v ? r * g.W + c : -1;
+        sidx[i] = v ? (r - rg.row_lo) * rg.SW + (c - rg.col_lo) : (rg.SW + 1);
+    }
+    // staging slots of this thread (same for every channel)
+    int goff[3];
+    if (DW) {
+        const int rsize = rg.nrows * rg.SW;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int e = tid + SMAAT_THREADS * j;
+            if (e < rsize) {
+                const int sr = e / rg.SW, sc = e - sr * rg.SW;
+                const int gr = rg.row_lo + sr, gc = rg.col_lo + sc;
+                goff[j] = (gr >= 0 && gr < g.H && gc >= 0 && gc < g.W) ? gr * g.W + gc : -1;
+            } else {
+                goff[j] = -2;
+            }
+        }
+    }
+
+    f32x16 acc[CT][PXT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < PXT; ++pt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
+
+    const int kci = KC / a.kpl;
+    const int nchunks = (a.Kdim + KC - 1) / KC;
+    const int pi = tid % PT;
+    const int g0 = __builtin_amdgcn_readfirstlane(tid / PT);
+    __syncthreads();
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int k0 = ch * KC;
+        if (DW) {
+            const int ci0 = k0 / a.kpl;
+            for (int cl = 0; cl < kci; ++cl) {
+                const int ci = ci0 + cl;
+                const bool cv = ci < a.Cin;
+                const float* plane = a.x + (long)n * a.x_bs + (long)ci * g.P;
+                float sc_ = 1.f, sh_ = 0.f;
+                if (AFF && cv) {
+                    sc_ = a.in_scale[ci];
+                    sh_ = a.in_shift[ci];
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (goff[j] != -2) {
+                        float v = 0.f;
+                        if (cv && goff[j] >= 0) {
+                            v = plane[goff[j]];
+                            if (AFF) v = fmaxf(fmaf(v, sc_, sh_), 0.f);
+                        }
+                        S[cl * SMAX + tid + SMAAT_THREADS * j] = v;
+                    }
+                }
+            }
+            __syncthreads();  // also orders the previous chunk's MFMA reads before Yl/Wl are rewritten
+            const int sb = sidx[pi];
+            const int SW = rg.SW;
+            for (int cl = g0; cl < kci; cl += G) {
+                const float* sp = S + cl * SMAX + sb;
+                const float s00 = sp[-SW - 1], s01 = sp[-SW], s02 = sp[-SW + 1];
+                const float s10 = sp[-1], s11 = sp[0], s12 = sp[1];
+                const float s20 = sp[SW - 1], s21 = sp[SW], s22 = sp[SW + 1];
+                for (int j = 0; j < a.kpl; ++j) {
+                    const int k = cl * a.kpl + j, kg = k0 + k;
+                    float y = 0.f;
+                    if (kg < a.Kdim) {
+                        const float* w = a.w_dw + kg * 9;
+                        y = a.b_dw ? a.b_dw[kg] : 0.f;
+                        y = fmaf(w[0], s00, y);
+                        y = fmaf(w[1], s01, y);
+                        y = fmaf(w[2], s02, y);
+                        y = fmaf(w[3], s10, y);
+                        y = fmaf(w[4], s11, y);
+                        y = fmaf(w[5], s12, y);
+                        y = fmaf(w[6], s20, y);
+                        y = fmaf(w[7], s21, y);
+                        y = fmaf(w[8], s22, y);
+                    }
+                    Yl[k * PT + pi] = y;
+                }
+            }
+        } else {
+            if (ch > 0) __syncthreads();  // previous chunk's MFMA reads are done
+            const int po = pixoff[pi];
+            for (int k = g0; k < KC; k += G) {
+                const int kg = k0 + k;
+                float v = 0.f;
+                if (kg < a.Kdim && po >= 0) v = a.x[(long)n * a.x_bs + (long)kg * g.P + po];
+                Yl[k * PT + pi] = v;
+            }
+        }
+        for (int e = tid; e < KC * COT; e += SMAAT_THREADS) {
+            const int k = e / COT, co = e - k * COT;
+            const int kg = k0 + k, m = co0 + co;
+            Wl[e] = (kg < a.Kdim && m < a.M) ? a.wt[(long)kg * a.M + m] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KC / 2; ++kk) {
+            const int krow = 2 * kk + half;
+            float av[CT], bv[PXT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) av[ct] = Wl[krow * COT + (wco * CT + ct) * 32 + l31];
+#pragma unroll
+            for (int pt = 0; pt < PXT; ++pt) bv[pt] = Yl[krow * PT + (wpx * PXT + pt) * 32 + l31];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < PXT; ++pt)
+                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ct], bv[pt], acc[ct][pt], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: bias + coalesced row stores --------------------------------------
+    int off[PXT];
+#pragma unroll
+    for (int pt = 0; pt < PXT; ++pt) off[pt] = pixoff[(wpx * PXT + pt) * 32 + l31];
+    float* obase = a.out + (long)n * a.out_bs;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = co0 + (wco * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m < a.M) {
+                const float bvv = a.bias ? a.bias[m] : 0.f;
+                float* rowp = obase + (long)m * g.P;
+#pragma unroll
+                for (int pt = 0; pt < PXT; ++pt)
+                    if (off[pt] >= 0) rowp[off[pt]] = acc[ct][pt][r] + bvv;
+            }
+        }
+    }
+    // ---- BatchNorm partial statistics of the raw accumulators (z - bias) ---------------
+    if (a.part) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int pt = 0; pt < PXT; ++pt) {
+                    const float v = (off[pt] >= 0) ? acc[ct][pt][r] : 0.f;
+                    s += v;
+                    q = fmaf(v, v, q);
+                }
+                s = half32_sum_hi(s);
+                q = half32_sum_hi(q);
+                if (l31 == 16 + r) {
+                    const int col = (wco * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    stat[(wpx * 2 + 0) * COT + col] = s;
+                    stat[(wpx * 2 + 1) * COT + col] = q;
+                }
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < 2 * COT; t += SMAAT_THREADS) {
+            const int which = t / COT, col = t - which * COT;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < WPX; ++w) v += stat[(w * 2 + which) * COT + col];
+            const int m = co0 + col;
+            if (m < a.M) a.part[((long)which * g.T + ptg) * a.M + m] = v;
+        }
+    }
+}
+
+// =====================================================================================
+// weight gradient
+// =====================================================================================
+struct WgArgs {
+    const float* x;
+    long x_bs;
+    const float* in_scale;
+    const float* in_shift;
+    const float* w_dw;
+    const float* b_dw;
+    const float* dz;
+    long dz_bs;
+    float* dwpart;  // [nsplit][M][Kdim]
+    int N, Cin, kpl, Kdim, M, nco, nkt, nsplit, tiles_per_split;
+    TileGeom g;  // PT == PSW
+};
+
+template <int WCO, int CT, int WK, int KW, bool DW, bool AFF>
+__global__ __launch_bounds__(SMAAT_THREADS) void k_wgrad(const WgArgs a) {
+    constexpr int COT = WCO * CT * 32;
+    constexpr int KT = WK * KW * 32;
+    constexpr int ZS = COT + 1;  // odd strides: conflict-free column reads
+    constexpr int YS = KT + 1;
+    extern __shared__ float smem[];
+    float* Zt = smem;             // [PSW][ZS]   dz tile, pixel-major
+    float* Yt = Zt + PSW * ZS;    // [PSW][YS]   dw output tile, pixel-major
+    float* S = Yt + PSW * YS;     // [KT/kpl][SMAXW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wco = wave % WCO, wk = wave / WCO;
+    const int l31 = lane & 31, half = lane >> 5;
+    const TileGeom& g = a.g;
+
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int ntile = a.nco * a.nkt;
+    const int rest = idx % ntile;
+    const int split = (idx / ntile) * 8 + xcd;
+    if (split >= a.nsplit) return;
+    const int cot = rest % a.nco, kt = rest / a.nco;
+    const int co0 = cot * COT, kt0 = kt * KT;
+    const int kci = KT / a.kpl;
+    const int ci0 = kt0 / a.kpl;
+
+    f32x16 acc[CT][KW];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][kw][r] = 0.f;
+
+    int t_end = (split + 1) * a.tiles_per_split;
+    if (t_end > g.T) t_end = g.T;
+    for (int t = split * a.tiles_per_split; t < t_end; ++t) {
+        const int n = t / g.tiles_per_img, tl = t - n * g.tiles_per_img;
+        const StageRegion rg = stage_region(g, tl);
+        int pr, pc;
+        const bool pv = tile_pixel(g, tl, lane, pr, pc);  // this lane's pixel
+        const int po = pv ? pr * g.W + pc : -1;
+        // dz tile -> Zt (transposed)
+        {
+            const float* zb = a.dz + (long)n * a.dz_bs;
+            for (int co = wave; co < COT; co += 4) {
+                const int m = co0 + co;
+                float v = 0.f;
+                if (pv && m < a.M) v = zb[(long)m * g.P + po];
+                Zt[lane * ZS + co] = v;
+            }
+        }
+        if (DW) {
+            const int rsize = rg.nrows * rg.SW;
+            int goff[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int e = tid + SMAAT_THREADS * j;
+                if (e < rsize) {
+                    const int sr = e / rg.SW, sc = e - sr * rg.SW;
+                    const int gr = rg.row_lo + sr, gc = rg.col_lo + sc;
+                    goff[j] = (gr >= 0 && gr < g.H && gc >= 0 && gc < g.W) ? gr * g.W + gc : -1;
+                } else {
+                    goff[j] = -2;
+                }
+            }
+            for (int cl = 0; cl < kci; ++cl) {
+                const int ci = ci0 + cl;
+                const bool cv = ci < a.Cin;
+                const float* plane = a.x + (long)n * a.x_bs + (long)ci * g.P;
+                float sc_ = 1.f, sh_ = 0.f;
+                if (AFF && cv) {
+                    sc_ = a.in_scale[ci];
+                    sh_ = a.in_shift[ci];
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (goff[j] != -2) {
+                        float v = 0.f;
+                        if (cv && goff[j] >= 0) {
+                            v = plane[goff[j]];
+                            if (AFF) v = fmaxf(fmaf(v, sc_, sh_), 0.f);
+                        }
+                        S[cl * SMAXW + tid + SMAAT_THREADS * j] = v;
+                    }
+                }
+            }
+            __syncthreads();
+            const int SW = rg.SW;
+            const int sb = pv ? (pr - rg.row_lo) * SW + (pc - rg.col_lo) : (SW + 1);
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
+            for (int cl = wv; cl < kci; cl += 4) {
+                const float* sp = S + cl * SMAXW + sb;
+                const float s00 = sp[-SW - 1], s01 = sp[-SW], s02 = sp[-SW + 1];
+                const float s10 = sp[-1], s11 = sp[0], s12 = sp[1];
+                const float s20 = sp[SW - 1], s21 = sp[SW], s22 = sp[SW + 1];
+                for (int j = 0; j < a.kpl; ++j) {
+                    const int k = cl * a.kpl + j, kg = kt0 + k;
+                    float y = 0.f;
+                    if (pv && kg < a.Kdim) {
+                        const float* w = a.w_dw + kg * 9;
+                        y = a.b_dw ? a.b_dw[kg] : 0.f;
+                        y = fmaf(w[0], s00, y);
+                        y = fmaf(w[1], s01, y);
+                        y = fmaf(w[2], s02, y);
+                        y = fmaf(w[3], s10, y);
+                        y = fmaf(w[4], s11, y);
+                        y = fmaf(w[5], s12, y);
+                        y = fmaf(w[6], s20, y);
+                        y = fmaf(w[7], s21, y);
+                        y = fmaf(w[8], s22, y);
+                    }
+                    Yt[lane * YS + k] = y;
+                }
+            }
+        } else {
+            const float* xb = a.x + (long)n * a.x_bs;
+            for (int k = wave; k < KT; k += 4) {
+                const int kg = kt0 + k;
+                float v = 0.f;
+                if (pv && kg < a.Kdim) v = xb[(long)kg * g.P + po];
+                Yt[lane * YS + k] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int s = 0; s < PSW / 2; ++s) {
+            const int px = 2 * s + half;
+            float av[CT], bv[KW];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) av[ct] = Zt[px * ZS + (wco * CT + ct) * 32 + l31];
+#pragma unroll
+            for (int kw = 0; kw < KW; ++kw) bv[kw] = Yt[px * YS + (wk * KW + kw) * 32 + l31];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw)
+                    acc[ct][kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ct], bv[kw], acc[ct][kw], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* ob = a.dwpart + (long)split * a.M * a.Kdim;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = co0 + (wco * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m < a.M) {
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw) {
+                    const int kg = kt0 + (wk * KW + kw) * 32 + l31;
+                    if (kg < a.Kdim) ob[(long)m * a.Kdim + kg] = acc[ct][kw][r];
+                }
+            }
+        }
+}
+
+// =====================================================================================
+// host-side launchers (C ABI wrappers live in capi.cpp)
+// =====================================================================================
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// choose the pixel-tile geometry for a (H, W) plane and PT pixels per tile
+static void choose_geom(int N, int H, int W, int PT, int smax, TileGeom* g) {
+    g->H = H;
+    g->W = W;
+    g->P = H * W;
+    g->PT = PT;
+    g->mode = -1;
+    const int P = H * W;
+    double best = -1.0;
+    // score = tile utilisation, discounted by the halo over-read, with a small bonus for
+    // layouts whose rows are >= 128 B contiguous
+    {   // candidate 0: PT consecutive pixels of the flattened plane
+        const int rows = (PT + W - 2) / W + 2;
+        const int staged = rows * (W + 2);
+        if (staged <= smax) {
+            const int tiles = ceil_div(P, PT);
+            best = (double)P / ((double)tiles * PT) * (1.0 - 0.08 * staged / PT) + 0.02;
+            g->mode = 0;
+            g->TH = 0;
+            g->TW = 0;
+            g->tiles_x = 0;
+            g->tiles_per_img = tiles;
+        }
+    }
+    const int tws[3] = {32, 16, 8};
+    for (int c = 0; c < 3; ++c) {
+        const int TW = tws[c], TH = PT / TW;
+        const int staged = (TH + 2) * (TW + 2);
+        if (TH < 1 || staged > smax) continue;
+        const int tx = ceil_div(W, TW), ty = ceil_div(H, TH);
+        const double sc = (double)P / ((double)tx * ty * PT) * (1.0 - 0.08 * staged / PT) + (TW == 32 ? 0.02 : 0.0);
+        if (sc > best) {
+            best = sc;
+            g->mode = 1;
+            g->TH = TH;
+            g->TW = TW;
+            g->tiles_x = tx;
+            g->tiles_per_img = tx * ty;
+        }
+    }
+    g->T = N * g->tiles_per_img;
+}
+
+template <int WCO, int CT, int WPX, int PXT>
+static int launch_pwgemm_cfg(PwArgs& a, bool dw, bool aff, hipStream_t st) {
+    constexpr int COT = WCO * CT * 32, PT = WPX * PXT * 32;
+    choose_geom(a.N, a.g.H, a.g.W, PT, SMAX, &a.g);
+    a.nco = ceil_div(a.M, COT);
+    const int kci = KC / a.kpl;
+    size_t lds = sizeof(float) * (size_t)(KC * PT + KC * COT + WPX * 2 * COT + 2 * PT + (dw ? kci * SMAX : 0));
+    const int grid = ceil_div(a.g.T, 8) * 8 * a.nco;
+#define LAUNCH(DWF, AFFF)                                                                                 \
+    do {                                                                                                  \
+        auto kern = k_pwgemm<WCO, CT, WPX, PXT, DWF, AFFF>;                                                  \
+        HIP_RET(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(SMAAT_THREADS), lds, st, a);                             \
+    } while (0)
+    if (dw && aff)
+        LAUNCH(true, true);
+    else if (dw)
+        LAUNCH(true, false);
+    else
+        LAUNCH(false, false);
+#undef LAUNCH
+    return (int)hipGetLastError();
+}
+
+int smaat_pw_num_slots_impl(int N, int H, int W, int M) {
+    // must mirror the tile choice of launch_pwgemm()
+    TileGeom g;
+    g.H = H;
+    g.W = W;
+    const int PT = ((long)N * H * W >= 256L * 1024) ? 256 : 128;
+    choose_geom(N, H, W, PT, SMAX, &g);
+    (void)M;
+    return g.T;
+}
+
+int launch_pwgemm(PwArgs& a, bool dw, hipStream_t st) {
+    if (a.kpl != 1 && a.kpl != 2 && a.kpl != 4) return -1;
+    const bool aff = dw && a.in_scale != nullptr;
+    const bool big = ((long)a.N * a.g.H * a.g.W >= 256L * 1024);
+    if (a.M > 64) {
+        if (big) return launch_pwgemm_cfg<2, 2, 2, 4>(a, dw, aff, st);  // 128 x 256
+        return launch_pwgemm_cfg<2, 2, 2, 2>(a, dw, aff, st);           // 128 x 128
+    }
+    if (big) return launch_pwgemm_cfg<1, 2, 4, 2>(a, dw, aff, st);  // 64 x 256
+    return launch_pwgemm_cfg<1, 2, 4, 1>(a, dw, aff, st);           // 64 x 128
+}
+
+template <int WCO, int CT, int WK, int KW>
+static int launch_wgrad_cfg(WgArgs& a, bool dw, bool aff, hipStream_t st) {
+    constexpr int COT = WCO * CT * 32, KT = WK * KW * 32;
+    a.nco = ceil_div(a.M, COT);
+    a.nkt = ceil_div(a.Kdim, KT);
+    const int kci = KT / a.kpl;
+    size_t lds = sizeof(float) * (size_t)(PSW * (COT + 1) + PSW * (KT + 1) + (dw ? kci * SMAXW : 0));
+    const int grid = ceil_div(a.nsplit, 8) * 8 * a.nco * a.nkt;
+#define LAUNCH(DWF, AFFF)                                                                                 \
+    do {                                                                                                  \
+        auto kern = k_wgrad<WCO, CT, WK, KW, DWF, AFFF>;                                                     \
+        HIP_RET(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(SMAAT_THREADS), lds, st, a);                             \
+    } while (0)
+    if (dw && aff)
+        LAUNCH(true, true);
+    else if (dw)
+        LAUNCH(true, false);
+    else
+        LAUNCH(false, false);
+#undef LAUNCH
+    return (int)hipGetLastError();
+}
+
+// number of pixel splits used by the weight-gradient kernel (size of the partial buffer)
+int smaat_wgrad_num_splits_impl(int N, int H, int W, int M, int Kdim) {
+    TileGeom g;
+    g.H = H;
+    g.W = W;
+    choose_geom(N, H, W, PSW, SMAXW, &g);
+    const int cot = (M > 64) ? 128 : 64;
+    const int ntile = ceil_div(M, cot) * ceil_div(Kdim, 64);
+    int ns = ceil_div(2048, ntile);
+    if (ns > g.T) ns = g.T;
+    if (ns < 1) ns = 1;
+    const int tps = ceil_div(g.T, ns);
+    return ceil_div(g.T, tps);
+}
+
+int launch_wgrad(WgArgs& a, bool dw, hipStream_t st) {
+    if (a.kpl != 1 && a.kpl != 2 && a.kpl != 4) return -1;
+    const bool aff = dw && a.in_scale != nullptr;
+    choose_geom(a.N, a.g.H, a.g.W, PSW, SMAXW, &a.g);
+    a.nsplit = smaat_wgrad_num_splits_impl(a.N, a.g.H, a.g.W, a.M, a.Kdim);
+    a.tiles_per_split = ceil_div(a.g.T, a.nsplit);
+    if (a.M > 64) return launch_wgrad_cfg<2, 2, 2, 1>(a, dw, aff, st);  // 128 x 64
+    return launch_wgrad_cfg<2, 1, 2, 1>(a, dw, aff, st);                // 64 x 64
+}
+
+// public wrapper of the geometry chooser (used by spatial.hip)
+void choose_geom_pub(int N, int H, int W, int PT, int smax, TileGeom* g) { choose_geom(N, H, W, PT, smax, g); }

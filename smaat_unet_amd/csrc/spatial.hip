@@ -1,0 +1,343 @@
+// HBM-bound spatial operators of the SmaAt-UNet path:
+//   MaxPool2d(2)            reference models/unet_parts_depthwise_separable.py:48
+//   Upsample(x2, bilinear, align_corners=True) + F.pad + cat slice write   :64, :78-85
+//   depthwise 3x3 backward (dX, dW, db)   (nn.Conv2d groups=Cin, models/layers.py:38-44)
+#include "common.h"
+
+// ---------------------------------------------------------------------------------
+// MaxPool 2x2 (floor mode).  grid: (N*C planes, segments of output pixels)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_maxpool2_fwd(const float* __restrict__ x, long x_bs, float* __restrict__ y,
+                                                      long y_bs, int C, int H, int W) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
+    const float* xp = x + (long)n * x_bs + (long)c * H * W;
+    float* yp = y + (long)n * y_bs + (long)c * Ho * Wo;
+    const int Po = Ho * Wo;
+    for (int o = blockIdx.y * 256 + threadIdx.x; o < Po; o += gridDim.y * 256) {
+        const int i = o / Wo, j = o - i * Wo;
+        const float* p = xp + (long)(2 * i) * W + 2 * j;
+        const float2 a = *(const float2*)p;  // 2*j even; row start parity handled below
+        const float2 b2 = *(const float2*)(p + W);
+        yp[o] = fmaxf(fmaxf(a.x, a.y), fmaxf(b2.x, b2.y));
+    }
+}
+// scalar variant for odd W (float2 loads would be misaligned)
+__global__ __launch_bounds__(256) void k_maxpool2_fwd_s(const float* __restrict__ x, long x_bs, float* __restrict__ y,
+                                                        long y_bs, int C, int H, int W) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
+    const float* xp = x + (long)n * x_bs + (long)c * H * W;
+    float* yp = y + (long)n * y_bs + (long)c * Ho * Wo;
+    const int Po = Ho * Wo;
+    for (int o = blockIdx.y * 256 + threadIdx.x; o < Po; o += gridDim.y * 256) {
+        const int i = o / Wo, j = o - i * Wo;
+        const float* p = xp + (long)(2 * i) * W + 2 * j;
+        yp[o] = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[W], p[W + 1]));
+    }
+}
+
+// dx: gradient goes to the FIRST maximum in scan order (0,0),(0,1),(1,0),(1,1); rows/cols
+// dropped by floor mode get zero.  One thread per INPUT pixel pair row -> full coverage.
+__global__ __launch_bounds__(256) void k_maxpool2_bwd(const float* __restrict__ x, long x_bs,
+                                                      const float* __restrict__ dy, long dy_bs,
+                                                      float* __restrict__ dx, long dx_bs, int C, int H, int W,
+                                                      int accum) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
+    const float* xp = x + (long)n * x_bs + (long)c * H * W;
+    const float* gp = dy + (long)n * dy_bs + (long)c * Ho * Wo;
+    float* dp = dx + (long)n * dx_bs + (long)c * H * W;
+    const int P = H * W;
+    for (int p = blockIdx.y * 256 + threadIdx.x; p < P; p += gridDim.y * 256) {
+        const int r = p / W, cc = p - r * W;
+        const int i = r >> 1, j = cc >> 1;
+        float g = 0.f;
+        if (i < Ho && j < Wo) {
+            const float* q = xp + (long)(2 * i) * W + 2 * j;
+            const float v0 = q[0], v1 = q[1], v2 = q[W], v3 = q[W + 1];
+            int am = 0;
+            float m = v0;
+            if (v1 > m) { m = v1; am = 1; }
+            if (v2 > m) { m = v2; am = 2; }
+            if (v3 > m) { m = v3; am = 3; }
+            const int me = ((r & 1) << 1) | (cc & 1);
+            if (me == am) g = gp[i * Wo + j];
+        }
+        dp[p] = accum ? dp[p] + g : g;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// bilinear x2, align_corners=True, written into a (possibly padded) slice of a cat buffer
+// out plane is Ho x Wo (skip-connection size); the 2H x 2W image sits at (pad_t, pad_l);
+// the rest of the plane is zero (F.pad).
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void ac_coef(int o, float scale, int n_in, int& i0, int& i1, float& l0, float& l1) {
+    const float src = (float)o * scale;
+    i0 = (int)floorf(src);
+    if (i0 > n_in - 1) i0 = n_in - 1;
+    i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
+    l1 = src - (float)i0;
+    l0 = 1.f - l1;
+}
+
+__global__ __launch_bounds__(256) void k_upsample2x_fwd(const float* __restrict__ x, long x_bs,
+                                                        float* __restrict__ out, long out_bs, int C, int H, int W,
+                                                        int Ho, int Wo, int pad_t, int pad_l) {
+    const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
+    const float* xp = x + (long)n * x_bs + (long)c * H * W;
+    float* op = out + (long)n * out_bs + (long)c * Ho * Wo;
+    const int H2 = 2 * H, W2 = 2 * W;
+    const float sh = H2 > 1 ? (float)(H - 1) / (float)(H2 - 1) : 0.f;
+    const float sw = W2 > 1 ? (float)(W - 1) / (float)(W2 - 1) : 0.f;
+    const int Po = Ho * Wo;
+    for (int o = blockIdx.y * 256 + threadIdx.x; o < Po; o += gridDim.y * 256) {
+        const int r = o / Wo, cc = o - r * Wo;
+        const int ur = r - pad_t, uc = cc - pad_l;
+        float v = 0.f;
+        if (ur >= 0 && ur < H2 && uc >= 0 && uc < W2) {
+            int r0, r1, c0, c1;
+            float a0, a1, b0, b1;
+            ac_coef(ur, sh, H, r0, r1, a0, a1);
+            ac_coef(uc, sw, W, c0, c1, b0, b1);
+            const float tl = xp[r0 * W + c0], tr = xp[r0 * W + c1];
+            const float bl = xp[r1 * W + c0], br = xp[r1 * W + c1];
+            v = a0 * (b0 * tl + b1 * tr) + a1 * (b0 * bl + b1 * br);
+        }
+        op[o] = v;
+    }
+}
+
+// gather form of the transpose (deterministic): each input pixel sums the output pixels
+// that referenced it, recomputing the forward coefficients exactly.
+__global__ __launch_bounds__(256) void k_upsample2x_bwd(const float* __restrict__ dout, long dout_bs,
+                                                        float* __restrict__ dx, long dx_bs, int C, int H, int W,
+                                                        int Ho, int Wo, int pad_t, int pad_l) {
+    const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
+    const float* gp = dout + (long)n * dout_bs + (long)c * Ho * Wo;
+    float* dp = dx + (long)n * dx_bs + (long)c * H * W;
+    const int H2 = 2 * H, W2 = 2 * W;
+    const float sh = H2 > 1 ? (float)(H - 1) / (float)(H2 - 1) : 0.f;
+    const float sw = W2 > 1 ? (float)(W - 1) / (float)(W2 - 1) : 0.f;
+    const int P = H * W;
+    for (int p = blockIdx.y * 256 + threadIdx.x; p < P; p += gridDim.y * 256) {
+        const int h = p / W, w = p - h * W;
+        // candidate output rows: src in (h-1, h+1)  ->  o in [2h-2, 2h+3] is a safe superset
+        int olo = 2 * h - 2, ohi = 2 * h + 3;
+        if (olo < 0) olo = 0;
+        if (ohi > H2 - 1) ohi = H2 - 1;
+        int plo = 2 * w - 2, phi = 2 * w + 3;
+        if (plo < 0) plo = 0;
+        if (phi > W2 - 1) phi = W2 - 1;
+        float acc = 0.f;
+        for (int orow = olo; orow <= ohi; ++orow) {
+            int r0, r1;
+            float a0, a1;
+            ac_coef(orow, sh, H, r0, r1, a0, a1);
+            float wr = 0.f;
+            if (r0 == h) wr += a0;
+            if (r1 == h) wr += a1;
+            if (wr == 0.f) continue;
+            const int gr = orow + pad_t;
+            if (gr < 0 || gr >= Ho) continue;
+            float rowacc = 0.f;
+            for (int ocol = plo; ocol <= phi; ++ocol) {
+                int c0, c1;
+                float b0, b1;
+                ac_coef(ocol, sw, W, c0, c1, b0, b1);
+                float wc = 0.f;
+                if (c0 == w) wc += b0;
+                if (c1 == w) wc += b1;
+                const int gc = ocol + pad_l;
+                if (wc != 0.f && gc >= 0 && gc < Wo) rowacc = fmaf(wc, gp[gr * Wo + gc], rowacc);
+            }
+            acc = fmaf(wr, rowacc, acc);
+        }
+        dp[p] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// depthwise 3x3 backward.  One block per (n, input channel); loops over the pixel tiles
+// of the plane.  dY is staged with a halo in LDS; every dY neighbour read feeds BOTH the
+// data gradient (x w) and the 9-tap weight gradient (x x[centre]).
+//   dX[ci][q]      = sum_j sum_tap w[ci*kpl+j][tap] * dY[ci*kpl+j][q - tap]
+//   dW[o][tap]     = sum_q x[ci][q] * dY[o][q - tap]
+//   db[o]          = sum_q dY[o][q]
+// part: [N][Cdw][10]  (9 taps + bias), finished by k_reduce_rows over N.
+// ---------------------------------------------------------------------------------
+#define DWB_SMAX 768
+#define DWB_KPL_MAX 4
+
+__global__ __launch_bounds__(256) void k_dw3x3_bwd(const float* __restrict__ x, long x_bs,
+                                                   const float* __restrict__ dy, long dy_bs,
+                                                   const float* __restrict__ w_dw, float* __restrict__ dx,
+                                                   long dx_bs, float* __restrict__ part, int Cin, int kpl,
+                                                   TileGeom g) {
+    __shared__ float S[DWB_KPL_MAX * DWB_SMAX];
+    __shared__ float red[4 * 10 * DWB_KPL_MAX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int plane = blockIdx.x, n = plane / Cin, ci = plane - n * Cin;
+    const int Cdw = Cin * kpl;
+    const float* xp = x + (long)n * x_bs + (long)ci * g.P;
+    float* dxp = dx ? dx + (long)n * dx_bs + (long)ci * g.P : nullptr;
+
+    float accw[DWB_KPL_MAX][10];
+#pragma unroll
+    for (int j = 0; j < DWB_KPL_MAX; ++j)
+#pragma unroll
+        for (int t = 0; t < 10; ++t) accw[j][t] = 0.f;
+
+    for (int tl = 0; tl < g.tiles_per_img; ++tl) {
+        const StageRegion rg = stage_region(g, tl);
+        const int rsize = rg.nrows * rg.SW;
+        __syncthreads();  // previous tile's reads are done
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+            const int e = tid + 256 * jj;
+            if (e < rsize) {
+                const int sr = e / rg.SW, sc = e - sr * rg.SW;
+                const int gr = rg.row_lo + sr, gc = rg.col_lo + sc;
+                const bool in = (gr >= 0 && gr < g.H && gc >= 0 && gc < g.W);
+                for (int j = 0; j < kpl; ++j) {
+                    float v = 0.f;
+                    if (in) v = dy[(long)n * dy_bs + (long)(ci * kpl + j) * g.P + gr * g.W + gc];
+                    S[j * DWB_SMAX + e] = v;
+                }
+            }
+        }
+        __syncthreads();
+        int r, c;
+        const bool pv = tile_pixel(g, tl, tid, r, c);
+        if (pv) {
+            const int po = r * g.W + c;
+            const int sb = (r - rg.row_lo) * rg.SW + (c - rg.col_lo);
+            const int SW = rg.SW;
+            const float xv = xp[po];
+            float dxa = 0.f;
+#pragma unroll
+            for (int j = 0; j < DWB_KPL_MAX; ++j) {
+                if (j < kpl) {
+                    const float* sp = S + j * DWB_SMAX + sb;
+                    const float* w = w_dw + (ci * kpl + j) * 9;
+                    // tap (dr,dc) pairs with dY at q - (dr,dc)
+                    const float d00 = sp[SW + 1], d01 = sp[SW], d02 = sp[SW - 1];
+                    const float d10 = sp[1], d11 = sp[0], d12 = sp[-1];
+                    const float d20 = sp[-SW + 1], d21 = sp[-SW], d22 = sp[-SW - 1];
+                    dxa = fmaf(w[0], d00, dxa);
+                    dxa = fmaf(w[1], d01, dxa);
+                    dxa = fmaf(w[2], d02, dxa);
+                    dxa = fmaf(w[3], d10, dxa);
+                    dxa = fmaf(w[4], d11, dxa);
+                    dxa = fmaf(w[5], d12, dxa);
+                    dxa = fmaf(w[6], d20, dxa);
+                    dxa = fmaf(w[7], d21, dxa);
+                    dxa = fmaf(w[8], d22, dxa);
+                    accw[j][0] = fmaf(xv, d00, accw[j][0]);
+                    accw[j][1] = fmaf(xv, d01, accw[j][1]);
+                    accw[j][2] = fmaf(xv, d02, accw[j][2]);
+                    accw[j][3] = fmaf(xv, d10, accw[j][3]);
+                    accw[j][4] = fmaf(xv, d11, accw[j][4]);
+                    accw[j][5] = fmaf(xv, d12, accw[j][5]);
+                    accw[j][6] = fmaf(xv, d20, accw[j][6]);
+                    accw[j][7] = fmaf(xv, d21, accw[j][7]);
+                    accw[j][8] = fmaf(xv, d22, accw[j][8]);
+                    accw[j][9] += d11;
+                }
+            }
+            if (dxp) dxp[po] = dxa;
+        }
+    }
+    // block reduction of the (kpl x 10) accumulators
+#pragma unroll
+    for (int j = 0; j < DWB_KPL_MAX; ++j) {
+        if (j < kpl) {
+#pragma unroll
+            for (int t = 0; t < 10; ++t) {
+                const float v = wave_sum_l63(accw[j][t]);
+                if (lane == 63) red[(wave * DWB_KPL_MAX + j) * 10 + t] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < kpl * 10) {
+        const int j = tid / 10, t = tid - j * 10;
+        const float v = red[(0 * DWB_KPL_MAX + j) * 10 + t] + red[(1 * DWB_KPL_MAX + j) * 10 + t] +
+                        red[(2 * DWB_KPL_MAX + j) * 10 + t] + red[(3 * DWB_KPL_MAX + j) * 10 + t];
+        part[((long)n * Cdw + ci * kpl + j) * 10 + t] = v;
+    }
+}
+
+// split part[N][Cdw][10] (already reduced over N into tmp[Cdw][10]) into dW[Cdw][9], db[Cdw]
+__global__ __launch_bounds__(256) void k_dw_split(const float* __restrict__ tmp, int Cdw, float* __restrict__ dw,
+                                                  float* __restrict__ db) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Cdw * 10) return;
+    const int o = i / 10, t = i - o * 10;
+    if (t < 9)
+        dw[o * 9 + t] = tmp[i];
+    else if (db)
+        db[o] = tmp[i];
+}
+
+// =====================================================================================
+static inline int cdivs(long a, long b) { return (int)((a + b - 1) / b); }
+
+int launch_maxpool2_fwd(const float* x, long x_bs, float* y, long y_bs, int N, int C, int H, int W, hipStream_t st) {
+    const int Po = (H / 2) * (W / 2);
+    if (Po == 0) return -1;
+    int gy = cdivs(Po, 1024);
+    if (gy > 64) gy = 64;
+    dim3 grid(N * C, gy);
+    if ((W & 1) == 0 && (x_bs & 1) == 0 && ((((uintptr_t)x) & 7) == 0))
+        hipLaunchKernelGGL(k_maxpool2_fwd, grid, dim3(256), 0, st, x, x_bs, y, y_bs, C, H, W);
+    else
+        hipLaunchKernelGGL(k_maxpool2_fwd_s, grid, dim3(256), 0, st, x, x_bs, y, y_bs, C, H, W);
+    return (int)hipGetLastError();
+}
+
+int launch_maxpool2_bwd(const float* x, long x_bs, const float* dy, long dy_bs, float* dx, long dx_bs, int N, int C,
+                        int H, int W, int accum, hipStream_t st) {
+    int gy = cdivs((long)H * W, 2048);
+    if (gy > 64) gy = 64;
+    dim3 grid(N * C, gy);
+    hipLaunchKernelGGL(k_maxpool2_bwd, grid, dim3(256), 0, st, x, x_bs, dy, dy_bs, dx, dx_bs, C, H, W, accum);
+    return (int)hipGetLastError();
+}
+
+int launch_upsample2x_fwd(const float* x, long x_bs, float* out, long out_bs, int N, int C, int H, int W, int Ho,
+                          int Wo, int pad_t, int pad_l, hipStream_t st) {
+    int gy = cdivs((long)Ho * Wo, 2048);
+    if (gy > 64) gy = 64;
+    dim3 grid(N * C, gy);
+    hipLaunchKernelGGL(k_upsample2x_fwd, grid, dim3(256), 0, st, x, x_bs, out, out_bs, C, H, W, Ho, Wo, pad_t, pad_l);
+    return (int)hipGetLastError();
+}
+
+int launch_upsample2x_bwd(const float* dout, long dout_bs, float* dx, long dx_bs, int N, int C, int H, int W, int Ho,
+                          int Wo, int pad_t, int pad_l, hipStream_t st) {
+    int gy = cdivs((long)H * W, 1024);
+    if (gy > 64) gy = 64;
+    dim3 grid(N * C, gy);
+    hipLaunchKernelGGL(k_upsample2x_bwd, grid, dim3(256), 0, st, dout, dout_bs, dx, dx_bs, C, H, W, Ho, Wo, pad_t,
+                       pad_l);
+    return (int)hipGetLastError();
+}
+
+void choose_geom_pub(int N, int H, int W, int PT, int smax, TileGeom* g);  // pwgemm.hip
+
+int launch_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, const float* w_dw, float* dx, long dx_bs,
+                     float* part, int N, int Cin, int kpl, int H, int W, hipStream_t st) {
+    if (kpl < 1 || kpl > DWB_KPL_MAX) return -1;
+    TileGeom g;
+    choose_geom_pub(N, H, W, 256, DWB_SMAX, &g);
+    hipLaunchKernelGGL(k_dw3x3_bwd, dim3(N * Cin), dim3(256), 0, st, x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, part, Cin,
+                       kpl, g);
+    return (int)hipGetLastError();
+}
+
+int launch_dw_split(const float* tmp, int Cdw, float* dw, float* db, hipStream_t st) {
+    hipLaunchKernelGGL(k_dw_split, dim3(cdivs((long)Cdw * 10, 256)), dim3(256), 0, st, tmp, Cdw, dw, db);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,109 @@
+"""Drop-in module classes for /root/reference/models/layers.py (the four classes on the
+hot path): same constructor signatures, attribute names and state_dict keys; `forward`
+dispatches to the gfx950 kernels (smaat_unet_amd.ops).  No CPU path."""
+from __future__ import annotations
+
+from torch import nn
+
+from . import ops
+
+
+def _bn_args(bn: nn.BatchNorm2d):
+    """(gamma, beta, running_mean, running_var, training, momentum, eps) with torch's
+    exponential_average_factor rule (momentum=None -> cumulative average)."""
+    momentum = bn.momentum
+    if bn.training and bn.track_running_stats:
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+            if bn.momentum is None:
+                momentum = 1.0 / float(bn.num_batches_tracked)
+    training = bn.training or (bn.running_mean is None and bn.running_var is None)
+    return bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps
+
+
+class DepthwiseSeparableConv(nn.Module):
+    """reference: models/layers.py:34-50.  Only the 3x3 / padding=1 configuration used by
+    DoubleConvDS is accelerated; other kernel sizes are rejected."""
+
+    def __init__(self, in_channels, output_channels, kernel_size, padding=0, kernels_per_layer=1):
+        super().__init__()
+        self.depthwise = nn.Conv2d(
+            in_channels,
+            in_channels * kernels_per_layer,
+            kernel_size=kernel_size,
+            padding=padding,
+            groups=in_channels,
+        )
+        self.pointwise = nn.Conv2d(in_channels * kernels_per_layer, output_channels, kernel_size=1)
+        self.kernels_per_layer_ = kernels_per_layer
+
+    def _check_geometry(self):
+        dw = self.depthwise
+        if dw.kernel_size != (3, 3) or dw.padding != (1, 1) or dw.stride != (1, 1) or dw.dilation != (1, 1):
+            raise NotImplementedError("smaat_unet_amd accelerates depthwise 3x3, stride 1, padding 1 only")
+
+    def forward(self, x):
+        self._check_geometry()
+        return ops.dsconv(x, self.depthwise.weight, self.depthwise.bias, self.pointwise.weight, self.pointwise.bias,
+                          self.kernels_per_layer_)
+
+
+class Flatten(nn.Module):
+    """reference: models/layers.py:85-87 (kept so that MLP indices 1 and 3 match)."""
+
+    def forward(self, x):
+        return x.view(x.size(0), -1)
+
+
+class ChannelAttention(nn.Module):
+    """reference: models/layers.py:90-111."""
+
+    def __init__(self, input_channels, reduction_ratio=16):
+        super().__init__()
+        self.input_channels = input_channels
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.max_pool = nn.AdaptiveMaxPool2d(1)
+        self.MLP = nn.Sequential(
+            Flatten(),
+            nn.Linear(input_channels, input_channels // reduction_ratio),
+            nn.ReLU(),
+            nn.Linear(input_channels // reduction_ratio, input_channels),
+        )
+
+    def _mlp_params(self):
+        return self.MLP[1].weight, self.MLP[1].bias, self.MLP[3].weight, self.MLP[3].bias
+
+    def forward(self, x):
+        w1, b1, w2, b2 = self._mlp_params()
+        return ops.cbam(x, w1, b1, w2, b2, None, None, None, None, None, False, None, 0.0, True, False)
+
+
+class SpatialAttention(nn.Module):
+    """reference: models/layers.py:114-129."""
+
+    def __init__(self, kernel_size=7):
+        super().__init__()
+        assert kernel_size in (3, 7), "kernel size must be 3 or 7"
+        padding = 3 if kernel_size == 7 else 1
+        self.conv = nn.Conv2d(2, 1, kernel_size=kernel_size, padding=padding, bias=False)
+        self.bn = nn.BatchNorm2d(1)
+
+    def forward(self, x):
+        g, b, rm, rv, training, momentum, eps = _bn_args(self.bn)
+        return ops.cbam(x, None, None, None, None, self.conv.weight, g, b, rm, rv, training, momentum, eps, False,
+                        True)
+
+
+class CBAM(nn.Module):
+    """reference: models/layers.py:132-141; both halves run as one fused operator."""
+
+    def __init__(self, input_channels, reduction_ratio=16, kernel_size=7):
+        super().__init__()
+        self.channel_att = ChannelAttention(input_channels, reduction_ratio=reduction_ratio)
+        self.spatial_att = SpatialAttention(kernel_size=kernel_size)
+
+    def forward(self, x):
+        w1, b1, w2, b2 = self.channel_att._mlp_params()
+        sp = self.spatial_att
+        g, b, rm, rv, training, momentum, eps = _bn_args(sp.bn)
+        return ops.cbam(x, w1, b1, w2, b2, sp.conv.weight, g, b, rm, rv, training, momentum, eps, True, True)

@@ -1,0 +1,550 @@
+"""PyTorch-ROCm autograd operators over the C ABI of libsmaat_hip.so.
+
+Every forward/backward here only enqueues hand-written HIP kernels on the current
+stream (plus tiny torch ops on [C]-sized vectors).  PyTorch provides device memory,
+streams and autograd bookkeeping only.  No CPU fallback: host tensors are rejected.
+
+Mapping to the reference (HansBambel/SmaAt-UNet):
+  dsconv_bn_relu   DepthwiseSeparableConv -> BatchNorm2d -> ReLU   (models/layers.py:47-50,
+                   models/unet_parts_depthwise_separable.py:17-36)
+  dsconv           DepthwiseSeparableConv alone                    (models/layers.py:34-50)
+  pointwise        OutConv                                          (models/unet_parts.py:67-73)
+  maxpool2         nn.MaxPool2d(2)                                  (unet_parts_depthwise_separable.py:48)
+  upsample_cat     nn.Upsample + F.pad + torch.cat([x2, x1])         (:64, :76-85)
+  cbam             ChannelAttention / SpatialAttention / CBAM        (models/layers.py:90-141)
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+# --------------------------------------------------------------------------------------
+# plumbing
+# --------------------------------------------------------------------------------------
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t):
+    if t.is_cuda:
+        return torch.cuda.current_stream(t.device).cuda_stream
+    return None
+
+
+def _check(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda and not _lib._ALLOW_HOST_POINTERS:
+            raise _lib.SmaatHipError("smaat_unet_amd operators need ROCm (cuda) tensors: there is no CPU fallback")
+        if t.dtype not in (torch.float32, torch.int32):
+            raise TypeError(f"smaat_unet_amd operators are float32-only (got {t.dtype})")
+
+
+def _planes(t):
+    """(tensor usable by the kernels, batch stride): NCHW with dense [C][H][W] planes; the
+    batch stride may be larger than C*H*W (channel slice of a cat buffer)."""
+    n, c, h, w = t.shape
+    st = t.stride()
+    if st[3] == 1 and st[2] == w and (c == 1 or st[1] == h * w) and (n == 1 or st[0] >= c * h * w):
+        return t, (st[0] if n > 1 else c * h * w)
+    t = t.contiguous()
+    return t, c * h * w
+
+
+def _new(ref, *shape, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=ref.device)
+
+
+# --------------------------------------------------------------------------------------
+# raw kernel wrappers (thin; shapes derived from tensors)
+# --------------------------------------------------------------------------------------
+def _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, in_shift=None):
+    L = _lib.get()
+    x, x_bs = _planes(x)
+    n, cin, h, w = x.shape
+    cout = w_pw.shape[0]
+    k = cin * kpl
+    wt = w_pw.reshape(cout, k).t().contiguous()
+    z = _new(x, n, cout, h, w)
+    part = None
+    slots = 0
+    if want_stats:
+        slots = L.smaat_pw_num_slots(n, h, w, cout)
+        part = _new(x, 2, slots, cout)
+    _lib.check(L.smaat_dsconv_fwd(_ptr(x), x_bs, _ptr(in_scale), _ptr(in_shift), _ptr(w_dw), _ptr(b_dw), _ptr(wt),
+                                  _ptr(b_pw), _ptr(z), cout * h * w, _ptr(part), n, cin, kpl, cout, h, w,
+                                  _stream(x)), "smaat_dsconv_fwd")
+    return z, part, slots
+
+
+def _pointwise_raw(x, wt, bias, m):
+    """out[n][m][p] = sum_c wt[c][m] x[n][c][p] + bias[m]; wt is [C][m] contiguous."""
+    L = _lib.get()
+    x, x_bs = _planes(x)
+    n, c, h, w = x.shape
+    out = _new(x, n, m, h, w)
+    _lib.check(L.smaat_pointwise_fwd(_ptr(x), x_bs, _ptr(wt), _ptr(bias), _ptr(out), m * h * w, None, n, c, m, h, w,
+                                     _stream(x)), "smaat_pointwise_fwd")
+    return out
+
+
+def _bn_finalize_raw(part, slots, c, count, bias_shift, gamma, beta, eps, momentum, rm, rv):
+    L = _lib.get()
+    st = _new(part, 4, c)
+    _lib.check(L.smaat_bn_finalize(_ptr(part), slots, c, float(count), _ptr(bias_shift), _ptr(gamma), _ptr(beta),
+                                   float(eps), float(momentum), _ptr(rm), _ptr(rv), _ptr(st[0]), _ptr(st[1]),
+                                   _ptr(st[2]), _ptr(st[3]), _stream(part)), "smaat_bn_finalize")
+    return st  # rows: mean, invstd, scale, shift
+
+
+def _affine_act_raw(z, scale, shift, relu, out=None):
+    L = _lib.get()
+    z, z_bs = _planes(z)
+    n, c, h, w = z.shape
+    if out is None:
+        out = _new(z, n, c, h, w)
+    out_t, o_bs = _planes(out)
+    assert out_t is out
+    _lib.check(L.smaat_affine_act(_ptr(z), z_bs, _ptr(scale), _ptr(shift), _ptr(out), o_bs, n, c, h * w,
+                                  1 if relu else 0, _stream(z)), "smaat_affine_act")
+    return out
+
+
+def _bn_bwd_raw(dy, z, st, gamma, relu, train):
+    """dz, dgamma, dbeta for y = relu?(bn(z)).  st rows: mean, invstd, scale, shift."""
+    L = _lib.get()
+    dy, dy_bs = _planes(dy)
+    z, z_bs = _planes(z)
+    n, c, h, w = z.shape
+    p = h * w
+    slots = L.smaat_plane_num_slots(n, p)
+    part = _new(z, 2, slots, c)
+    s = _stream(z)
+    _lib.check(L.smaat_bn_bwd_reduce(_ptr(dy), dy_bs, _ptr(z), z_bs, _ptr(st[2]), _ptr(st[3]), _ptr(st[0]),
+                                     _ptr(st[1]), _ptr(part), n, c, p, 1 if relu else 0, s), "smaat_bn_bwd_reduce")
+    dgamma = _new(z, c)
+    dbeta = _new(z, c)
+    coef = _new(z, 3, c)
+    _lib.check(L.smaat_bn_bwd_finalize(_ptr(part), slots, c, float(n * p), _ptr(gamma), _ptr(st[1]), _ptr(dgamma),
+                                       _ptr(dbeta), _ptr(coef), s), "smaat_bn_bwd_finalize")
+    if not train:  # eval mode: statistics are constants -> no mean/var terms
+        coef[1:].zero_()
+    dz = _new(z, n, c, h, w)
+    _lib.check(L.smaat_bn_bwd_apply(_ptr(dy), dy_bs, _ptr(z), z_bs, _ptr(st[2]), _ptr(st[3]), _ptr(st[0]),
+                                    _ptr(st[1]), _ptr(coef), _ptr(dz), c * p, n, c, p, 1 if relu else 0, s),
+               "smaat_bn_bwd_apply")
+    return dz, dgamma, dbeta
+
+
+def _channel_sum_raw(x):
+    L = _lib.get()
+    x, x_bs = _planes(x)
+    n, c, h, w = x.shape
+    ws = _new(x, L.smaat_plane_num_slots(n, h * w), c)
+    out = _new(x, c)
+    _lib.check(L.smaat_channel_sum(_ptr(x), x_bs, n, c, h * w, _ptr(ws), _ptr(out), _stream(x)), "smaat_channel_sum")
+    return out
+
+
+def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, in_scale=None, in_shift=None):
+    """gradients of z = pointwise(depthwise(x)) given dz: dx, dw_dw, db_dw, dw_pw."""
+    L = _lib.get()
+    x, x_bs = _planes(x)
+    dz, dz_bs = _planes(dz)
+    n, cin, h, w = x.shape
+    cout = w_pw.shape[0]
+    k = cin * kpl
+    s = _stream(x)
+    # pointwise weight gradient, Y recomputed on the fly
+    ns = L.smaat_wgrad_num_splits(n, h, w, cout, k)
+    ws = _new(x, ns, cout, k)
+    dw_pw = _new(x, cout, k, 1, 1)
+    _lib.check(L.smaat_dsconv_wgrad(_ptr(x), x_bs, _ptr(in_scale), _ptr(in_shift), _ptr(w_dw), _ptr(b_dw), _ptr(dz),
+                                    dz_bs, _ptr(ws), _ptr(dw_pw), n, cin, kpl, cout, h, w, s), "smaat_dsconv_wgrad")
+    del ws
+    # data gradient of the pointwise conv: dY = W^T dZ  (wt := w_pw in its natural [Cout][K] layout)
+    dy = _new(x, n, k, h, w)
+    _lib.check(L.smaat_pointwise_fwd(_ptr(dz), dz_bs, _ptr(w_pw), None, _ptr(dy), k * h * w, None, n, cout, k, h, w,
+                                     s), "smaat_pointwise_fwd(dgrad)")
+    # depthwise backward
+    dx = _new(x, n, cin, h, w) if need_dx else None
+    ws2 = _new(x, n + 1, k, 10)
+    dw_dw = _new(x, k, 1, 3, 3)
+    db_dw = _new(x, k)
+    _lib.check(L.smaat_dw3x3_bwd(_ptr(x), x_bs, _ptr(dy), k * h * w, _ptr(w_dw), _ptr(dx), cin * h * w, _ptr(ws2),
+                                 _ptr(dw_dw), _ptr(db_dw), n, cin, kpl, h, w, s), "smaat_dw3x3_bwd")
+    return dx, dw_dw, db_dw, dw_pw
+
+
+# --------------------------------------------------------------------------------------
+# DepthwiseSeparableConv (+ BatchNorm2d + ReLU)
+# --------------------------------------------------------------------------------------
+class _DSConvBNReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, momentum, eps, kpl):
+        _check(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv)
+        w_dw = w_dw.contiguous()
+        w_pw = w_pw.contiguous()
+        n, cin, h, w = x.shape
+        cout = w_pw.shape[0]
+        use_batch_stats = training or rm is None
+        if use_batch_stats:
+            z, part, slots = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, True)
+            st = _bn_finalize_raw(part, slots, cout, n * h * w, b_pw, gamma, beta, eps,
+                                  momentum if momentum is not None else 0.0, rm if training else None,
+                                  rv if training else None)
+        else:
+            z, _, _ = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, False)
+            invstd = torch.rsqrt(rv + eps)
+            g = gamma if gamma is not None else torch.ones_like(rm)
+            b = beta if beta is not None else torch.zeros_like(rm)
+            scale = g * invstd
+            st = torch.stack([rm, invstd, scale, b - rm * scale]).contiguous()
+        y = _affine_act_raw(z, st[2], st[3], True)
+        ctx.save_for_backward(x, w_dw, b_dw, w_pw, gamma, z, st)
+        ctx.kpl = kpl
+        ctx.train_stats = use_batch_stats
+        ctx.has_bias = (b_dw is not None, b_pw is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_dw, b_dw, w_pw, gamma, z, st = ctx.saved_tensors
+        dz, dgamma, dbeta = _bn_bwd_raw(dy, z, st, gamma, True, ctx.train_stats)
+        need_dx = ctx.needs_input_grad[0]
+        dx, dw_dw, db_dw, dw_pw = _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, ctx.kpl, need_dx)
+        if ctx.train_stats:
+            # a bias in front of a train-mode BatchNorm has an exactly-zero gradient
+            db_pw = torch.zeros_like(dgamma) if ctx.has_bias[1] else None
+        else:
+            db_pw = _channel_sum_raw(dz) if ctx.has_bias[1] else None
+        if not ctx.has_bias[0]:
+            db_dw = None
+        if gamma is None:
+            dgamma = dbeta = None
+        return dx, dw_dw, db_dw, dw_pw, db_pw, dgamma, dbeta, None, None, None, None, None, None
+
+
+def dsconv_bn_relu(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, running_mean, running_var, training, momentum, eps, kpl):
+    return _DSConvBNReLU.apply(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, running_mean, running_var, training,
+                               momentum, eps, kpl)
+
+
+class _DSConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_dw, b_dw, w_pw, b_pw, kpl):
+        _check(x, w_dw, b_dw, w_pw, b_pw)
+        w_dw = w_dw.contiguous()
+        w_pw = w_pw.contiguous()
+        z, _, _ = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, False)
+        ctx.save_for_backward(x, w_dw, b_dw, w_pw)
+        ctx.kpl = kpl
+        ctx.has_bias = (b_dw is not None, b_pw is not None)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w_dw, b_dw, w_pw = ctx.saved_tensors
+        dx, dw_dw, db_dw, dw_pw = _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, ctx.kpl, ctx.needs_input_grad[0])
+        db_pw = _channel_sum_raw(dz) if ctx.has_bias[1] else None
+        if not ctx.has_bias[0]:
+            db_dw = None
+        return dx, dw_dw, db_dw, dw_pw, db_pw, None
+
+
+def dsconv(x, w_dw, b_dw, w_pw, b_pw, kpl):
+    return _DSConv.apply(x, w_dw, b_dw, w_pw, b_pw, kpl)
+
+
+# --------------------------------------------------------------------------------------
+# OutConv (plain 1x1)
+# --------------------------------------------------------------------------------------
+class _Pointwise(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _check(x, w, b)
+        w = w.contiguous()
+        m, c = w.shape[0], w.shape[1]
+        wt = w.reshape(m, c).t().contiguous()
+        out = _pointwise_raw(x, wt, b, m)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dz):
+        L = _lib.get()
+        x, w = ctx.saved_tensors
+        m, c = w.shape[0], w.shape[1]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _pointwise_raw(dz, w.reshape(m, c), None, c)  # wt[c'=m][m'=c] = w natural
+        x_, x_bs = _planes(x)
+        dz_, dz_bs = _planes(dz)
+        n, _, h, wd = x_.shape
+        ns = L.smaat_wgrad_num_splits(n, h, wd, m, c)
+        ws = _new(x_, ns, m, c)
+        dw = _new(x_, m, c, 1, 1)
+        _lib.check(L.smaat_pointwise_wgrad(_ptr(x_), x_bs, _ptr(dz_), dz_bs, _ptr(ws), _ptr(dw), n, c, m, h, wd,
+                                           _stream(x_)), "smaat_pointwise_wgrad")
+        db = _channel_sum_raw(dz) if ctx.has_bias else None
+        return dx, dw, db
+
+
+def pointwise(x, w, b):
+    return _Pointwise.apply(x, w, b)
+
+
+# --------------------------------------------------------------------------------------
+# MaxPool2d(2)
+# --------------------------------------------------------------------------------------
+class _MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _check(x)
+        L = _lib.get()
+        x, x_bs = _planes(x)
+        n, c, h, w = x.shape
+        y = _new(x, n, c, h // 2, w // 2)
+        _lib.check(L.smaat_maxpool2_fwd(_ptr(x), x_bs, _ptr(y), c * (h // 2) * (w // 2), n, c, h, w, _stream(x)),
+                   "smaat_maxpool2_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.get()
+        (x,) = ctx.saved_tensors
+        x, x_bs = _planes(x)
+        dy, dy_bs = _planes(dy)
+        n, c, h, w = x.shape
+        dx = _new(x, n, c, h, w)
+        _lib.check(L.smaat_maxpool2_bwd(_ptr(x), x_bs, _ptr(dy), dy_bs, _ptr(dx), c * h * w, n, c, h, w, 0,
+                                        _stream(x)), "smaat_maxpool2_bwd")
+        return dx
+
+
+def maxpool2(x):
+    return _MaxPool2.apply(x)
+
+
+# --------------------------------------------------------------------------------------
+# Upsample(x2, bilinear, align_corners=True) + F.pad + cat([x2, x1_up], dim=1)
+# --------------------------------------------------------------------------------------
+class _UpsampleCat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2):
+        _check(x1, x2)
+        L = _lib.get()
+        x1, x1_bs = _planes(x1)
+        x2, x2_bs = _planes(x2)
+        n, c1, h, w = x1.shape
+        n2, c2, ho, wo = x2.shape
+        assert n == n2
+        dy_, dx_ = ho - 2 * h, wo - 2 * w
+        if dy_ < 0 or dx_ < 0:
+            raise NotImplementedError("UpDS with a skip connection smaller than the upsampled map (negative pad)")
+        pt, pl = dy_ // 2, dx_ // 2
+        cat = _new(x1, n, c2 + c1, ho, wo)
+        cbs = (c1 + c2) * ho * wo
+        s = _stream(x1)
+        _lib.check(L.smaat_copy_planes(_ptr(x2), x2_bs, _ptr(cat), cbs, n, c2 * ho * wo, 0, s), "smaat_copy_planes")
+        _lib.check(L.smaat_upsample2x_fwd(_ptr(x1), x1_bs, cat.data_ptr() + 4 * c2 * ho * wo, cbs, n, c1, h, w, ho,
+                                          wo, pt, pl, s), "smaat_upsample2x_fwd")
+        ctx.geom = (n, c1, h, w, c2, ho, wo, pt, pl)
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        L = _lib.get()
+        n, c1, h, w, c2, ho, wo, pt, pl = ctx.geom
+        dcat = dcat.contiguous()
+        cbs = (c1 + c2) * ho * wo
+        s = _stream(dcat)
+        dx1 = dx2 = None
+        if ctx.needs_input_grad[1]:
+            dx2 = _new(dcat, n, c2, ho, wo)
+            _lib.check(L.smaat_copy_planes(_ptr(dcat), cbs, _ptr(dx2), c2 * ho * wo, n, c2 * ho * wo, 0, s),
+                       "smaat_copy_planes")
+        if ctx.needs_input_grad[0]:
+            dx1 = _new(dcat, n, c1, h, w)
+            _lib.check(L.smaat_upsample2x_bwd(dcat.data_ptr() + 4 * c2 * ho * wo, cbs, _ptr(dx1), c1 * h * w, n, c1,
+                                              h, w, ho, wo, pt, pl, s), "smaat_upsample2x_bwd")
+        return dx1, dx2
+
+
+def upsample_cat(x1, x2):
+    return _UpsampleCat.apply(x1, x2)
+
+
+# --------------------------------------------------------------------------------------
+# CBAM (channel attention and/or spatial attention)
+# --------------------------------------------------------------------------------------
+class _CBAM(torch.autograd.Function):
+    """out = spatial_att(channel_att(x)); either half can be switched off (standalone
+    ChannelAttention / SpatialAttention modules reuse the same kernels)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, use_ch, use_sp):
+        _check(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv)
+        L = _lib.get()
+        x, x_bs = _planes(x)
+        n, c, h, w = x.shape
+        p = h * w
+        s_ = _stream(x)
+        dev = x
+        if use_ch:
+            cr = w1.shape[0]
+            w1 = w1.contiguous()
+            w2 = w2.contiguous()
+            avg = _new(dev, n, c)
+            mx = _new(dev, n, c)
+            amax = _new(dev, n, c, dtype=torch.int32)
+            _lib.check(L.smaat_cbam_chpool(_ptr(x), x_bs, n, c, p, _ptr(avg), _ptr(mx), _ptr(amax), s_),
+                       "smaat_cbam_chpool")
+            ha = _new(dev, n, cr)
+            hm = _new(dev, n, cr)
+            sc = _new(dev, n, c)
+            _lib.check(L.smaat_cbam_mlp(_ptr(avg), _ptr(mx), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), n, c, cr,
+                                        _ptr(ha), _ptr(hm), _ptr(sc), s_), "smaat_cbam_mlp")
+        else:
+            avg = mx = amax = ha = hm = None
+            sc = torch.ones(n, c, dtype=torch.float32, device=x.device)
+        if use_sp:
+            wconv = wconv.contiguous()
+            ks = wconv.shape[-1]
+            maps = _new(dev, n, 2, h, w)
+            _lib.check(L.smaat_cbam_sppool(_ptr(x), x_bs, _ptr(sc), n, c, p, _ptr(maps), s_), "smaat_cbam_sppool")
+            nb = L.smaat_cbam_spconv_blocks(n, h, w)
+            conv = _new(dev, n, 1, h, w)
+            use_batch_stats = training or rm is None
+            part = _new(dev, 2, nb, 1)
+            _lib.check(L.smaat_cbam_spconv(_ptr(maps), _ptr(wconv), ks, n, h, w, _ptr(conv), _ptr(part), s_),
+                       "smaat_cbam_spconv")
+            if use_batch_stats:
+                st = _bn_finalize_raw(part, nb, 1, n * p, None, gamma, beta, eps,
+                                      momentum if momentum is not None else 0.0, rm if training else None,
+                                      rv if training else None)
+            else:
+                invstd = torch.rsqrt(rv + eps)
+                g = gamma if gamma is not None else torch.ones_like(rm)
+                b = beta if beta is not None else torch.zeros_like(rm)
+                scale = g * invstd
+                st = torch.stack([rm, invstd, scale, b - rm * scale]).contiguous()
+            gate = _new(dev, n, 1, h, w)
+            _lib.check(L.smaat_cbam_gate(_ptr(conv), _ptr(st[2]), _ptr(st[3]), n * p, _ptr(gate), s_),
+                       "smaat_cbam_gate")
+        else:
+            maps = conv = st = None
+            use_batch_stats = False
+            gate = torch.ones(n, 1, h, w, dtype=torch.float32, device=x.device)
+        out = _new(dev, n, c, h, w)
+        _lib.check(L.smaat_cbam_apply(_ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(out), c * p, n, c, p, s_),
+                   "smaat_cbam_apply")
+        ctx.save_for_backward(x, w1, w2, wconv, gamma, avg, mx, amax, ha, hm, sc, maps, conv, st, gate)
+        ctx.flags = (use_ch, use_sp, use_batch_stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.get()
+        x, w1, w2, wconv, gamma, avg, mx, amax, ha, hm, sc, maps, conv, st, gate = ctx.saved_tensors
+        use_ch, use_sp, train_stats = ctx.flags
+        x, x_bs = _planes(x)
+        dout, do_bs = _planes(dout)
+        n, c, h, w = x.shape
+        p = h * w
+        s_ = _stream(x)
+        dev = x
+        dwconv = dgamma = dbeta = None
+        if use_sp:
+            ks = wconv.shape[-1]
+            nbp = L.smaat_cbam_pix_blocks(n, p)
+            dbn = _new(dev, n, p)
+            part = _new(dev, 2, nbp, 1)
+            _lib.check(L.smaat_cbam_bwd_gate(_ptr(dout), do_bs, _ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(conv),
+                                             _ptr(st[0]), _ptr(st[1]), n, c, p, _ptr(dbn), _ptr(part), s_),
+                       "smaat_cbam_bwd_gate")
+            dgamma = _new(dev, 1)
+            dbeta = _new(dev, 1)
+            coef = _new(dev, 3, 1)
+            _lib.check(L.smaat_bn_bwd_finalize(_ptr(part), nbp, 1, float(n * p), _ptr(gamma), _ptr(st[1]),
+                                               _ptr(dgamma), _ptr(dbeta), _ptr(coef), s_), "smaat_bn_bwd_finalize")
+            if not train_stats:
+                coef[1:].zero_()
+            nb = L.smaat_cbam_spconv_blocks(n, h, w)
+            dmaps = _new(dev, n, 2, h, w)
+            wpart = _new(dev, nb, 2 * ks * ks)
+            _lib.check(L.smaat_cbam_bwd_spconv(_ptr(dbn), _ptr(conv), _ptr(st[0]), _ptr(st[1]), _ptr(coef),
+                                               _ptr(maps), _ptr(wconv), ks, n, h, w, _ptr(dmaps), _ptr(wpart), s_),
+                       "smaat_cbam_bwd_spconv")
+            dwconv = _new(dev, 1, 2, ks, ks)
+            _lib.check(L.smaat_reduce_rows(_ptr(wpart), nb, 2 * ks * ks, _ptr(dwconv), 1.0, s_), "smaat_reduce_rows")
+            if gamma is None:
+                dgamma = dbeta = None
+        else:
+            # no spatial half: gate == 1, no pooled-map gradients
+            maps = torch.full((n, 2, h, w), float("inf"), dtype=torch.float32, device=x.device)
+            dmaps = torch.zeros(n, 2, h, w, dtype=torch.float32, device=x.device)
+        nbp = L.smaat_cbam_pix_blocks(n, p)
+        dx = _new(dev, n, c, h, w)
+        dspart = _new(dev, nbp, c)
+        _lib.check(L.smaat_cbam_bwd_main(_ptr(dout), do_bs, _ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(maps),
+                                         _ptr(dmaps), n, c, p, _ptr(dx), c * p, _ptr(dspart), s_),
+                   "smaat_cbam_bwd_main")
+        dw1 = db1 = dw2 = db2 = None
+        if use_ch:
+            cr = w1.shape[0]
+            per = nbp // n
+            ds = _new(dev, n, c)
+            # dspart is [per][n][c]: one deterministic row reduction
+            _lib.check(L.smaat_reduce_rows(_ptr(dspart), per, n * c, _ptr(ds), 1.0, s_), "smaat_reduce_rows")
+            pgs = c * cr + c + cr * c + cr
+            pg = _new(dev, n, pgs)
+            davg = _new(dev, n, c)
+            dmx = _new(dev, n, c)
+            _lib.check(L.smaat_cbam_bwd_mlp(_ptr(ds), _ptr(sc), _ptr(avg), _ptr(mx), _ptr(ha), _ptr(hm), _ptr(w1),
+                                            _ptr(w2), n, c, cr, _ptr(pg), _ptr(davg), _ptr(dmx), s_),
+                       "smaat_cbam_bwd_mlp")
+            pgr = _new(dev, pgs)
+            _lib.check(L.smaat_reduce_rows(_ptr(pg), n, pgs, _ptr(pgr), 1.0, s_), "smaat_reduce_rows")
+            dw2 = pgr[:c * cr].view(c, cr)
+            db2 = pgr[c * cr:c * cr + c]
+            dw1 = pgr[c * cr + c:c * cr + c + cr * c].view(cr, c)
+            db1 = pgr[c * cr + c + cr * c:]
+            _lib.check(L.smaat_cbam_bwd_final(_ptr(dx), c * p, _ptr(davg), _ptr(dmx), _ptr(amax), n, c, p, s_),
+                       "smaat_cbam_bwd_final")
+        return dx, dw1, db1, dw2, db2, dwconv, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def cbam(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, use_ch=True, use_sp=True):
+    return _CBAM.apply(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, use_ch, use_sp)
+
+
+# --------------------------------------------------------------------------------------
+# torch.ops.smaat.* registration (inference-style functional entry points; training goes
+# through the autograd Functions above, which the modules call)
+# --------------------------------------------------------------------------------------
+def _register_torch_ops():
+    try:
+        lib = torch.library.Library("smaat", "DEF")
+    except Exception:  # already defined (module re-import)
+        return
+    lib.define("dsconv(Tensor x, Tensor w_dw, Tensor? b_dw, Tensor w_pw, Tensor? b_pw, int kpl) -> Tensor")
+    lib.define("pointwise(Tensor x, Tensor w, Tensor? b) -> Tensor")
+    lib.define("maxpool2(Tensor x) -> Tensor")
+    lib.define("upsample_cat(Tensor x1, Tensor x2) -> Tensor")
+
+    # CompositeImplicitAutograd: the autograd.Functions inside record their own backward
+    key = "CompositeImplicitAutograd"
+    lib.impl("dsconv", lambda x, wd, bd, wp, bp, kpl: _DSConv.apply(x, wd, bd, wp, bp, kpl), key)
+    lib.impl("pointwise", lambda x, w, b: _Pointwise.apply(x, w, b), key)
+    lib.impl("maxpool2", lambda x: _MaxPool2.apply(x), key)
+    lib.impl("upsample_cat", lambda a, b: _UpsampleCat.apply(a, b), key)
+    globals()["_TORCH_LIB"] = lib
+
+
+_register_torch_ops()

@@ -1,0 +1,101 @@
+"""Drop-in module classes for /root/reference/models/unet_parts_depthwise_separable.py."""
+from __future__ import annotations
+
+from torch import nn
+
+from . import ops
+from .layers import DepthwiseSeparableConv, _bn_args
+
+
+class DoubleConvDS(nn.Module):
+    """(DepthwiseSeparableConv => BN => ReLU) * 2 -- reference :10-39.  Each half runs as the
+    fused dsconv+BN-stats kernel, a finalize and one BN-apply+ReLU pass."""
+
+    def __init__(self, in_channels, out_channels, mid_channels=None, kernels_per_layer=1):
+        super().__init__()
+        if not mid_channels:
+            mid_channels = out_channels
+        self.double_conv = nn.Sequential(
+            DepthwiseSeparableConv(
+                in_channels,
+                mid_channels,
+                kernel_size=3,
+                kernels_per_layer=kernels_per_layer,
+                padding=1,
+            ),
+            nn.BatchNorm2d(mid_channels),
+            nn.ReLU(inplace=True),
+            DepthwiseSeparableConv(
+                mid_channels,
+                out_channels,
+                kernel_size=3,
+                kernels_per_layer=kernels_per_layer,
+                padding=1,
+            ),
+            nn.BatchNorm2d(out_channels),
+            nn.ReLU(inplace=True),
+        )
+
+    @staticmethod
+    def _half(x, conv: DepthwiseSeparableConv, bn: nn.BatchNorm2d):
+        conv._check_geometry()
+        g, b, rm, rv, training, momentum, eps = _bn_args(bn)
+        return ops.dsconv_bn_relu(x, conv.depthwise.weight, conv.depthwise.bias, conv.pointwise.weight,
+                                  conv.pointwise.bias, g, b, rm, rv, training, momentum, eps,
+                                  conv.kernels_per_layer_)
+
+    def forward(self, x):
+        seq = self.double_conv
+        x = self._half(x, seq[0], seq[1])
+        return self._half(x, seq[3], seq[4])
+
+
+class _MaxPool2(nn.MaxPool2d):
+    def forward(self, x):
+        return ops.maxpool2(x)
+
+
+class DownDS(nn.Module):
+    """Downscaling with maxpool then double conv -- reference :42-53."""
+
+    def __init__(self, in_channels, out_channels, kernels_per_layer=1):
+        super().__init__()
+        self.maxpool_conv = nn.Sequential(
+            _MaxPool2(2),
+            DoubleConvDS(in_channels, out_channels, kernels_per_layer=kernels_per_layer),
+        )
+
+    def forward(self, x):
+        return self.maxpool_conv(x)
+
+
+class UpDS(nn.Module):
+    """Upscaling then double conv -- reference :56-86 (bilinear branch; the ConvTranspose2d
+    branch `bilinear=False` is never used by the reference scripts and is not accelerated)."""
+
+    def __init__(self, in_channels, out_channels, bilinear=True, kernels_per_layer=1):
+        super().__init__()
+        if bilinear:
+            self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+            self.conv = DoubleConvDS(
+                in_channels,
+                out_channels,
+                in_channels // 2,
+                kernels_per_layer=kernels_per_layer,
+            )
+        else:
+            raise NotImplementedError("UpDS(bilinear=False) (ConvTranspose2d) is outside the accelerated hot path")
+
+    def forward(self, x1, x2):
+        return self.conv(ops.upsample_cat(x1, x2))
+
+
+class OutConv(nn.Module):
+    """reference :89-95 (duplicate of models/unet_parts.py:67-73)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+
+    def forward(self, x):
+        return ops.pointwise(x, self.conv.weight, self.conv.bias)

@@ -1,0 +1,381 @@
+"""TEST INFRASTRUCTURE ONLY -- numpy emulation of every entry of include/smaat_hip.h on HOST
+pointers, built on the oracle.  Two uses:
+  * CPU suite: injected in place of libsmaat_hip.so so that the Python host logic
+    (autograd wiring, buffer sizes, module API) is checked against the reference-generated
+    goldens without a GPU;
+  * GPU suite: per-kernel reference -- the HIP entry point and the emulated one are run on
+    the same inputs and compared.
+The product package never imports this file.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from oracle import smaat_oracle as O
+
+
+def f32(ptr, count):
+    if ptr is None or ptr == 0:
+        return None
+    return np.ctypeslib.as_array((ctypes.c_float * int(count)).from_address(int(ptr)))
+
+
+def i32(ptr, count):
+    return np.ctypeslib.as_array((ctypes.c_int32 * int(count)).from_address(int(ptr)))
+
+
+def planes(ptr, n, c, p, bs):
+    """[n][c][p] view with batch stride bs (elements)."""
+    if ptr is None or ptr == 0:
+        return None
+    total = (n - 1) * bs + c * p
+    flat = f32(ptr, total)
+    return np.lib.stride_tricks.as_strided(flat, shape=(n, c, p), strides=(bs * 4, p * 4, 4))
+
+
+PW_SLOTS = 3
+PLANE_SLOTS = 2
+WG_SPLITS = 2
+
+
+class EmuLib:
+    # ------------------------------------------------------------------ queries
+    def smaat_abi_version(self):
+        return 1
+
+    def smaat_pw_num_slots(self, N, H, W, M):
+        return PW_SLOTS
+
+    def smaat_wgrad_num_splits(self, N, H, W, M, K):
+        return WG_SPLITS
+
+    def smaat_plane_num_slots(self, N, P):
+        return PLANE_SLOTS * N
+
+    def smaat_cbam_spconv_blocks(self, N, H, W):
+        return 2 * N
+
+    def smaat_cbam_pix_blocks(self, N, P):
+        return 3 * N
+
+    # ------------------------------------------------------------------ pointwise family
+    @staticmethod
+    def _write_part(part, T, M, acc):
+        if part is None:
+            return
+        pp = f32(part, 2 * T * M).reshape(2, T, M)
+        pp[:] = 0
+        a64 = acc.astype(np.float64)
+        pp[0, T - 1] = a64.sum(axis=(0, 2))
+        pp[1, T - 1] = (a64 * a64).sum(axis=(0, 2))
+
+    def smaat_dsconv_fwd(self, x, x_bs, in_scale, in_shift, w_dw, b_dw, wt_pw, b_pw, z, z_bs, part, N, Cin, kpl, Cout,
+                         H, W, stream):
+        P, K = H * W, Cin * kpl
+        xv = np.array(planes(x, N, Cin, P, x_bs)).reshape(N, Cin, H, W)
+        if in_scale:
+            sc, sh = f32(in_scale, Cin), f32(in_shift, Cin)
+            xv = np.maximum(xv * sc[None, :, None, None] + sh[None, :, None, None], 0)
+        y = O.dw3x3_fwd(xv, f32(w_dw, K * 9).reshape(K, 1, 3, 3), f32(b_dw, K) if b_dw else None, kpl)
+        wt = f32(wt_pw, K * Cout).reshape(K, Cout)
+        acc = np.einsum("km,nkp->nmp", wt, y.reshape(N, K, P))
+        zz = planes(z, N, Cout, P, z_bs)
+        zz[:] = acc + (f32(b_pw, Cout)[None, :, None] if b_pw else 0)
+        self._write_part(part, PW_SLOTS, Cout, acc)
+        return 0
+
+    def smaat_pointwise_fwd(self, x, x_bs, wt, bias, out, out_bs, part, N, Cin, M, H, W, stream):
+        P = H * W
+        xv = planes(x, N, Cin, P, x_bs)
+        w = f32(wt, Cin * M).reshape(Cin, M)
+        acc = np.einsum("cm,ncp->nmp", w, xv)
+        planes(out, N, M, P, out_bs)[:] = acc + (f32(bias, M)[None, :, None] if bias else 0)
+        self._write_part(part, PW_SLOTS, M, acc)
+        return 0
+
+    def smaat_dsconv_wgrad(self, x, x_bs, in_scale, in_shift, w_dw, b_dw, dz, dz_bs, ws, dw_out, N, Cin, kpl, Cout, H,
+                           W, stream):
+        P, K = H * W, Cin * kpl
+        xv = np.array(planes(x, N, Cin, P, x_bs)).reshape(N, Cin, H, W)
+        if in_scale:
+            sc, sh = f32(in_scale, Cin), f32(in_shift, Cin)
+            xv = np.maximum(xv * sc[None, :, None, None] + sh[None, :, None, None], 0)
+        y = O.dw3x3_fwd(xv, f32(w_dw, K * 9).reshape(K, 1, 3, 3), f32(b_dw, K) if b_dw else None, kpl)
+        dzv = planes(dz, N, Cout, P, dz_bs)
+        f32(dw_out, Cout * K).reshape(Cout, K)[:] = np.einsum("nmp,nkp->mk", dzv, y.reshape(N, K, P))
+        return 0
+
+    def smaat_pointwise_wgrad(self, x, x_bs, dz, dz_bs, ws, dw_out, N, Cin, M, H, W, stream):
+        P = H * W
+        f32(dw_out, M * Cin).reshape(M, Cin)[:] = np.einsum("nmp,nkp->mk", planes(dz, N, M, P, dz_bs),
+                                                             planes(x, N, Cin, P, x_bs))
+        return 0
+
+    def smaat_dw3x3_bwd(self, x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, ws, dw_out, db_out, N, Cin, kpl, H, W, stream):
+        P, K = H * W, Cin * kpl
+        xv = np.array(planes(x, N, Cin, P, x_bs)).reshape(N, Cin, H, W)
+        dyv = np.array(planes(dy, N, K, P, dy_bs)).reshape(N, K, H, W)
+        gx, gw, gb = O.dw3x3_bwd(xv, f32(w_dw, K * 9).reshape(K, 1, 3, 3), dyv, kpl)
+        if dx:
+            planes(dx, N, Cin, P, dx_bs)[:] = gx.reshape(N, Cin, P)
+        f32(dw_out, K * 9)[:] = gw.reshape(-1)
+        if db_out:
+            f32(db_out, K)[:] = gb
+        return 0
+
+    # ------------------------------------------------------------------ batch norm
+    def smaat_bn_finalize(self, part, T, C, count, bias_shift, gamma, beta, eps, momentum, rm, rv, mean, invstd, scale,
+                          shift, stream):
+        pp = f32(part, 2 * T * C).reshape(2, T, C).astype(np.float64)
+        m0 = pp[0].sum(0) / count
+        var = np.maximum(pp[1].sum(0) / count - m0 * m0, 0)
+        mu = m0 + (f32(bias_shift, C).astype(np.float64) if bias_shift else 0)
+        istd = 1.0 / np.sqrt(var + eps)
+        g = f32(gamma, C) if gamma else np.ones(C, np.float32)
+        b = f32(beta, C) if beta else np.zeros(C, np.float32)
+        muf, isf = mu.astype(np.float32), istd.astype(np.float32)
+        f32(mean, C)[:] = muf
+        f32(invstd, C)[:] = isf
+        sc = g * isf
+        f32(scale, C)[:] = sc
+        f32(shift, C)[:] = b - muf * sc
+        if rm:
+            unb = var * (count / max(count - 1.0, 1.0))
+            r1, r2 = f32(rm, C), f32(rv, C)
+            r1[:] = ((1 - momentum) * r1.astype(np.float64) + momentum * mu).astype(np.float32)
+            r2[:] = ((1 - momentum) * r2.astype(np.float64) + momentum * unb).astype(np.float32)
+        return 0
+
+    def smaat_affine_act(self, z, z_bs, scale, shift, y, y_bs, N, C, P, relu, stream):
+        v = planes(z, N, C, P, z_bs) * f32(scale, C)[None, :, None] + f32(shift, C)[None, :, None]
+        planes(y, N, C, P, y_bs)[:] = np.maximum(v, 0) if relu else v
+        return 0
+
+    @staticmethod
+    def _g_xhat(dy, dy_bs, z, z_bs, scale, shift, mean, invstd, N, C, P, relu):
+        zz = planes(z, N, C, P, z_bs)
+        g = np.array(planes(dy, N, C, P, dy_bs))
+        if relu:
+            a = zz * f32(scale, C)[None, :, None] + f32(shift, C)[None, :, None]
+            g = g * (a > 0)
+        xhat = (zz - f32(mean, C)[None, :, None]) * f32(invstd, C)[None, :, None]
+        return g, xhat
+
+    def smaat_bn_bwd_reduce(self, dy, dy_bs, z, z_bs, scale, shift, mean, invstd, part, N, C, P, relu, stream):
+        g, xhat = self._g_xhat(dy, dy_bs, z, z_bs, scale, shift, mean, invstd, N, C, P, relu)
+        slots = PLANE_SLOTS * N
+        pp = f32(part, 2 * slots * C).reshape(2, slots, C)
+        pp[:] = 0
+        pp[0, 0] = g.astype(np.float64).sum(axis=(0, 2))
+        pp[1, 0] = (g.astype(np.float64) * xhat).sum(axis=(0, 2))
+        return 0
+
+    def smaat_bn_bwd_finalize(self, part, slots, C, count, gamma, invstd, dgamma, dbeta, coef, stream):
+        pp = f32(part, 2 * slots * C).reshape(2, slots, C).astype(np.float64)
+        s1, s2 = pp[0].sum(0), pp[1].sum(0)
+        if dbeta:
+            f32(dbeta, C)[:] = s1
+        if dgamma:
+            f32(dgamma, C)[:] = s2
+        g = f32(gamma, C) if gamma else np.ones(C, np.float32)
+        cf = f32(coef, 3 * C).reshape(3, C)
+        cf[0] = g * f32(invstd, C)
+        cf[1] = s1 / count
+        cf[2] = s2 / count
+        return 0
+
+    def smaat_bn_bwd_apply(self, dy, dy_bs, z, z_bs, scale, shift, mean, invstd, coef, dz, dz_bs, N, C, P, relu,
+                           stream):
+        g, xhat = self._g_xhat(dy, dy_bs, z, z_bs, scale, shift, mean, invstd, N, C, P, relu)
+        cf = f32(coef, 3 * C).reshape(3, C)
+        planes(dz, N, C, P, dz_bs)[:] = cf[0][None, :, None] * (g - cf[1][None, :, None] - xhat * cf[2][None, :, None])
+        return 0
+
+    # ------------------------------------------------------------------ helpers
+    def smaat_reduce_rows(self, part, rows, length, out, alpha, stream):
+        f32(out, length)[:] = f32(part, rows * length).reshape(rows, length).astype(np.float64).sum(0) * alpha
+        return 0
+
+    def smaat_channel_sum(self, x, x_bs, N, C, P, ws, out, stream):
+        f32(out, C)[:] = planes(x, N, C, P, x_bs).astype(np.float64).sum(axis=(0, 2))
+        return 0
+
+    def smaat_copy_planes(self, src, s_bs, dst, d_bs, N, plane_len, accum, stream):
+        s = planes(src, N, 1, plane_len, s_bs)
+        d = planes(dst, N, 1, plane_len, d_bs)
+        if accum:
+            d += s
+        else:
+            d[:] = s
+        return 0
+
+    # ------------------------------------------------------------------ pool / upsample
+    def smaat_maxpool2_fwd(self, x, x_bs, y, y_bs, N, C, H, W, stream):
+        xv = np.array(planes(x, N, C, H * W, x_bs)).reshape(N, C, H, W)
+        yv, _ = O.maxpool2_fwd(xv)
+        planes(y, N, C, (H // 2) * (W // 2), y_bs)[:] = yv.reshape(N, C, -1)
+        return 0
+
+    def smaat_maxpool2_bwd(self, x, x_bs, dy, dy_bs, dx, dx_bs, N, C, H, W, accum, stream):
+        xv = np.array(planes(x, N, C, H * W, x_bs)).reshape(N, C, H, W)
+        _, idx = O.maxpool2_fwd(xv)
+        g = np.array(planes(dy, N, C, (H // 2) * (W // 2), dy_bs)).reshape(N, C, H // 2, W // 2)
+        r = O.maxpool2_bwd((N, C, H, W), idx, g).reshape(N, C, H * W)
+        d = planes(dx, N, C, H * W, dx_bs)
+        if accum:
+            d += r
+        else:
+            d[:] = r
+        return 0
+
+    def smaat_upsample2x_fwd(self, x, x_bs, out, out_bs, N, C, H, W, Ho, Wo, pad_t, pad_l, stream):
+        xv = np.array(planes(x, N, C, H * W, x_bs)).reshape(N, C, H, W)
+        u = O.upsample2x_fwd(xv)
+        full = np.zeros((N, C, Ho, Wo), np.float32)
+        full[:, :, pad_t:pad_t + 2 * H, pad_l:pad_l + 2 * W] = u
+        planes(out, N, C, Ho * Wo, out_bs)[:] = full.reshape(N, C, -1)
+        return 0
+
+    def smaat_upsample2x_bwd(self, dout, dout_bs, dx, dx_bs, N, C, H, W, Ho, Wo, pad_t, pad_l, stream):
+        g = np.array(planes(dout, N, C, Ho * Wo, dout_bs)).reshape(N, C, Ho, Wo)
+        gu = np.ascontiguousarray(g[:, :, pad_t:pad_t + 2 * H, pad_l:pad_l + 2 * W])
+        planes(dx, N, C, H * W, dx_bs)[:] = O.upsample2x_bwd((N, C, H, W), gu).reshape(N, C, -1)
+        return 0
+
+    # ------------------------------------------------------------------ CBAM
+    def smaat_cbam_chpool(self, x, x_bs, N, C, P, avg, mx, amax, stream):
+        xv = planes(x, N, C, P, x_bs)
+        f32(avg, N * C).reshape(N, C)[:] = xv.mean(axis=2, dtype=np.float64)
+        am = xv.argmax(axis=2)
+        i32(amax, N * C).reshape(N, C)[:] = am
+        f32(mx, N * C).reshape(N, C)[:] = np.take_along_axis(xv, am[..., None], axis=2)[..., 0]
+        return 0
+
+    def smaat_cbam_mlp(self, avg, mx, w1, b1, w2, b2, N, C, Cr, ha, hm, s, stream):
+        a, m = f32(avg, N * C).reshape(N, C), f32(mx, N * C).reshape(N, C)
+        W1, B1 = f32(w1, Cr * C).reshape(Cr, C), f32(b1, Cr)
+        W2, B2 = f32(w2, C * Cr).reshape(C, Cr), f32(b2, C)
+        h1 = np.maximum(a @ W1.T + B1, 0)
+        h2 = np.maximum(m @ W1.T + B1, 0)
+        f32(ha, N * Cr).reshape(N, Cr)[:] = h1
+        f32(hm, N * Cr).reshape(N, Cr)[:] = h2
+        f32(s, N * C).reshape(N, C)[:] = O.sigmoid((h1 @ W2.T + B2) + (h2 @ W2.T + B2))
+        return 0
+
+    def smaat_cbam_sppool(self, x, x_bs, s, N, C, P, maps, stream):
+        xs = planes(x, N, C, P, x_bs) * f32(s, N * C).reshape(N, C)[:, :, None]
+        mp = f32(maps, N * 2 * P).reshape(N, 2, P)
+        mp[:, 0] = xs.mean(axis=1, dtype=np.float64)
+        mp[:, 1] = xs.max(axis=1)
+        return 0
+
+    def smaat_cbam_spconv(self, maps, wc, ks, N, H, W, conv, part, stream):
+        mp = f32(maps, N * 2 * H * W).reshape(N, 2, H, W)
+        cv = O.conv2d_same_fwd(mp, f32(wc, 2 * ks * ks).reshape(1, 2, ks, ks))
+        f32(conv, N * H * W)[:] = cv.reshape(-1)
+        nb = 2 * N
+        pp = f32(part, 2 * nb).reshape(2, nb)
+        pp[:] = 0
+        pp[0, 1] = cv.astype(np.float64).sum()
+        pp[1, 1] = (cv.astype(np.float64) ** 2).sum()
+        return 0
+
+    def smaat_cbam_gate(self, conv, scale, shift, total, gate, stream):
+        f32(gate, total)[:] = O.sigmoid(f32(conv, total) * f32(scale, 1)[0] + f32(shift, 1)[0])
+        return 0
+
+    def smaat_cbam_apply(self, x, x_bs, s, gate, out, out_bs, N, C, P, stream):
+        planes(out, N, C, P, out_bs)[:] = (planes(x, N, C, P, x_bs) * f32(s, N * C).reshape(N, C)[:, :, None]) * \
+            f32(gate, N * P).reshape(N, 1, P)
+        return 0
+
+    def smaat_cbam_bwd_gate(self, dout, dout_bs, x, x_bs, s, gate, conv, mean, invstd, N, C, P, dbn, part, stream):
+        xs = planes(x, N, C, P, x_bs) * f32(s, N * C).reshape(N, C)[:, :, None]
+        dg = (planes(dout, N, C, P, dout_bs) * xs).sum(axis=1, dtype=np.float64).astype(np.float32)
+        m = f32(gate, N * P).reshape(N, P)
+        d = dg * m * (1 - m)
+        f32(dbn, N * P).reshape(N, P)[:] = d
+        xhat = (f32(conv, N * P).reshape(N, P) - f32(mean, 1)[0]) * f32(invstd, 1)[0]
+        nb = 3 * N
+        pp = f32(part, 2 * nb).reshape(2, nb)
+        pp[:] = 0
+        pp[0, 2] = d.astype(np.float64).sum()
+        pp[1, 2] = (d.astype(np.float64) * xhat).sum()
+        return 0
+
+    def smaat_cbam_bwd_spconv(self, dbn, conv, mean, invstd, coef, maps, wc, ks, N, H, W, dmaps, wpart, stream):
+        P = H * W
+        cf = f32(coef, 3)
+        xhat = (f32(conv, N * P) - f32(mean, 1)[0]) * f32(invstd, 1)[0]
+        dconv = (cf[0] * (f32(dbn, N * P) - cf[1] - xhat * cf[2])).reshape(N, 1, H, W)
+        mp = f32(maps, N * 2 * P).reshape(N, 2, H, W)
+        w = f32(wc, 2 * ks * ks).reshape(1, 2, ks, ks)
+        dm, dw = O.conv2d_same_bwd(mp, w, dconv)
+        f32(dmaps, N * 2 * P)[:] = dm.reshape(-1)
+        nb = 2 * N
+        wp = f32(wpart, nb * 2 * ks * ks).reshape(nb, 2 * ks * ks)
+        wp[:] = 0
+        wp[0] = dw.reshape(-1)
+        return 0
+
+    def smaat_cbam_bwd_main(self, dout, dout_bs, x, x_bs, s, gate, maps, dmaps, N, C, P, dx, dx_bs, dspart, stream):
+        xv = planes(x, N, C, P, x_bs)
+        sv = f32(s, N * C).reshape(N, C)
+        xs = xv * sv[:, :, None]
+        g = f32(gate, N * P).reshape(N, 1, P)
+        mp = f32(maps, N * 2 * P).reshape(N, 2, P)
+        dmp = f32(dmaps, N * 2 * P).reshape(N, 2, P)
+        dxs = planes(dout, N, C, P, dout_bs) * g + dmp[:, 0:1] / np.float32(C)
+        eq = xs == mp[:, 1:2]
+        first = eq & (np.cumsum(eq, axis=1) == 1)
+        dxs = dxs + first * dmp[:, 1:2]
+        planes(dx, N, C, P, dx_bs)[:] = dxs * sv[:, :, None]
+        per = 3
+        dp = f32(dspart, per * N * C).reshape(per, N, C)
+        dp[:] = 0
+        dp[1] = (dxs.astype(np.float64) * xv).sum(axis=2)
+        return 0
+
+    def smaat_cbam_bwd_mlp(self, ds, s, avg, mx, ha, hm, w1, w2, N, C, Cr, pg, davg, dmx, stream):
+        dsv, sv = f32(ds, N * C).reshape(N, C), f32(s, N * C).reshape(N, C)
+        a, m = f32(avg, N * C).reshape(N, C), f32(mx, N * C).reshape(N, C)
+        h1, h2 = f32(ha, N * Cr).reshape(N, Cr), f32(hm, N * Cr).reshape(N, Cr)
+        W1, W2 = f32(w1, Cr * C).reshape(Cr, C), f32(w2, C * Cr).reshape(C, Cr)
+        do = dsv * sv * (1 - sv)
+        pgs = C * Cr + C + Cr * C + Cr
+        pgv = f32(pg, N * pgs).reshape(N, pgs)
+        dh = do @ W2
+        dha, dhm = dh * (h1 > 0), dh * (h2 > 0)
+        for n in range(N):
+            pgv[n, :C * Cr] = np.outer(do[n], h1[n] + h2[n]).reshape(-1)
+            pgv[n, C * Cr:C * Cr + C] = 2 * do[n]
+            pgv[n, C * Cr + C:C * Cr + C + Cr * C] = (np.outer(dha[n], a[n]) + np.outer(dhm[n], m[n])).reshape(-1)
+            pgv[n, C * Cr + C + Cr * C:] = dha[n] + dhm[n]
+        f32(davg, N * C).reshape(N, C)[:] = dha @ W1
+        f32(dmx, N * C).reshape(N, C)[:] = dhm @ W1
+        return 0
+
+    def smaat_cbam_bwd_final(self, dx, dx_bs, davg, dmx, amax, N, C, P, stream):
+        d = planes(dx, N, C, P, dx_bs)
+        d += (f32(davg, N * C).reshape(N, C) / np.float32(P))[:, :, None]
+        am = i32(amax, N * C).reshape(N, C)
+        dm = f32(dmx, N * C).reshape(N, C)
+        for n in range(N):
+            for c in range(C):
+                d[n, c, am[n, c]] += dm[n, c]
+        return 0
+
+
+def install():
+    """Swap the emulation in for libsmaat_hip.so (CPU tests only)."""
+    from smaat_unet_amd import _lib
+    _lib._instance = EmuLib()
+    _lib._ALLOW_HOST_POINTERS = True
+
+
+def uninstall():
+    from smaat_unet_amd import _lib
+    _lib._instance = None
+    _lib._ALLOW_HOST_POINTERS = False

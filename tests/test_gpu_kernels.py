@@ -1,0 +1,335 @@
+"""GPU: every C-ABI entry point of libsmaat_hip.so against its numpy emulation
+(tests/emu_backend.py, built on the oracle) on identical seeded inputs.
+Tolerance: rel-L2 <= 1e-5 (fp32, north_star asks 1e-4) unless stated."""
+import numpy as np
+import pytest
+import torch
+
+from smaat_unet_amd import _lib
+from tests.emu_backend import EmuLib
+
+pytestmark = pytest.mark.gpu
+
+
+def _backends():
+    return (("emu", EmuLib(), torch.device("cpu")), ("hip", _lib.get(), torch.device("cuda:0")))
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def P(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None
+
+
+def both(case, *args, tol=1e-5, **kw):
+    res = {}
+    for name, L, dev in _backends():
+        out = case(L, dev, *args, **kw)
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        res[name] = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in out.items()}
+    for k in res["emu"]:
+        e = rel(res["hip"][k], res["emu"][k])
+        assert e <= tol, f"{k}: rel err {e:.3e} > {tol}  (max abs {np.abs(res['hip'][k]-res['emu'][k]).max():.3e})"
+    return res
+
+
+def rnd(seed, *shape, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------
+def case_dsconv_fwd(L, dev, N, Cin, kpl, Cout, H, W, aff=False, pad_c=0, bias=True):
+    K = Cin * kpl
+    xfull = T(rnd(1, N, Cin + pad_c, H, W), dev)
+    x = xfull[:, pad_c:]  # channel slice of a bigger buffer -> batch stride > Cin*H*W
+    x_bs = (Cin + pad_c) * H * W
+    w_dw, b_dw = T(rnd(2, K, 9, scale=0.3), dev), T(rnd(3, K, scale=0.3), dev)
+    wt, b_pw = T(rnd(4, K, Cout, scale=0.2), dev), T(rnd(5, Cout), dev)
+    sc = T(np.random.default_rng(6).uniform(0.5, 1.5, Cin).astype(np.float32), dev) if aff else None
+    sh = T(rnd(7, Cin, scale=0.3), dev) if aff else None
+    z = torch.full((N, Cout, H, W), float("nan"), device=dev)
+    slots = L.smaat_pw_num_slots(N, H, W, Cout)
+    part = torch.full((2, slots, Cout), float("nan"), device=dev)
+    xptr = x.data_ptr()
+    rc = L.smaat_dsconv_fwd(xptr, x_bs, P(sc), P(sh), P(w_dw), P(b_dw) if bias else None, P(wt),
+                            P(b_pw) if bias else None, P(z), Cout * H * W, P(part), N, Cin, kpl, Cout, H, W,
+                            stream(dev))
+    assert rc == 0
+    return dict(z=z, psum=part[0].double().sum(0), psq=part[1].double().sum(0))
+
+
+DS_SHAPES = [
+    # N, Cin, kpl, Cout, H, W
+    (2, 12, 2, 64, 32, 32),     # inc.0-like, flattened tiles
+    (2, 6, 2, 10, 9, 11),       # odd everything, partial co tile
+    (1, 3, 4, 8, 6, 10),        # kpl 4
+    (2, 5, 1, 7, 8, 8),         # kpl 1
+    (2, 64, 2, 128, 36, 36),    # flattened mode, 128-wide co tile
+    (3, 16, 2, 130, 18, 18),    # co not a multiple of 64/128
+    (2, 64, 2, 64, 72, 72),     # 72-wide flattened
+    (2, 32, 2, 64, 144, 144),   # 16-wide 2D tiles
+    (4, 12, 2, 64, 288, 288),   # "big" config (256-pixel tiles, 8x32)
+    (4, 8, 2, 128, 288, 288),   # big + 128 co tile
+    (1, 4, 2, 16, 100, 100),    # partial 2D tiles
+    (2, 24, 2, 32, 4, 4),       # tiny maps (64x64 config bottoms out at 4x4)
+    (1, 8, 2, 16, 2, 2),
+]
+
+
+@pytest.mark.parametrize("shape", DS_SHAPES)
+def test_dsconv_fwd(shape):
+    both(case_dsconv_fwd, *shape)
+
+
+def test_dsconv_fwd_affine_slice_nobias():
+    both(case_dsconv_fwd, 2, 12, 2, 64, 32, 32, aff=True, pad_c=4)
+    both(case_dsconv_fwd, 2, 6, 2, 10, 9, 11, bias=False)
+
+
+def case_pointwise(L, dev, N, C, M, H, W, with_part=False):
+    x = T(rnd(1, N, C, H, W), dev)
+    wt, b = T(rnd(2, C, M, scale=0.2), dev), T(rnd(3, M), dev)
+    out = torch.full((N, M, H, W), float("nan"), device=dev)
+    slots = L.smaat_pw_num_slots(N, H, W, M)
+    part = torch.zeros((2, slots, M), device=dev) if with_part else None
+    assert L.smaat_pointwise_fwd(P(x), C * H * W, P(wt), P(b), P(out), M * H * W, P(part), N, C, M, H, W,
+                                 stream(dev)) == 0
+    r = dict(out=out)
+    if with_part:
+        r["psum"] = part[0].double().sum(0)
+    return r
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 1, 32, 32), (2, 64, 21, 16, 16), (2, 16, 3, 6, 7), (2, 128, 256, 36, 36),
+                                   (4, 64, 1, 288, 288), (2, 1, 64, 20, 20), (2, 512, 1024, 18, 18)])
+def test_pointwise_fwd(shape):
+    both(case_pointwise, *shape)
+    both(case_pointwise, *shape, with_part=True)
+
+
+def case_dsconv_wgrad(L, dev, N, Cin, kpl, Cout, H, W):
+    K = Cin * kpl
+    x = T(rnd(1, N, Cin, H, W), dev)
+    w_dw, b_dw = T(rnd(2, K, 9, scale=0.3), dev), T(rnd(3, K, scale=0.3), dev)
+    dz = T(rnd(4, N, Cout, H, W), dev)
+    ns = L.smaat_wgrad_num_splits(N, H, W, Cout, K)
+    ws = torch.empty((ns, Cout, K), device=dev)
+    dw = torch.full((Cout, K), float("nan"), device=dev)
+    assert L.smaat_dsconv_wgrad(P(x), Cin * H * W, None, None, P(w_dw), P(b_dw), P(dz), Cout * H * W, P(ws), P(dw), N,
+                                Cin, kpl, Cout, H, W, stream(dev)) == 0
+    return dict(dw=dw)
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 2, 64, 32, 32), (2, 6, 2, 10, 9, 11), (1, 3, 4, 8, 6, 10),
+                                   (2, 5, 1, 7, 8, 8), (2, 64, 2, 128, 36, 36), (2, 40, 2, 130, 18, 18),
+                                   (2, 16, 2, 64, 144, 144), (2, 12, 2, 64, 288, 288), (1, 4, 2, 16, 100, 100),
+                                   (2, 24, 2, 32, 4, 4)])
+def test_dsconv_wgrad(shape):
+    both(case_dsconv_wgrad, *shape, tol=2e-5)
+
+
+def case_pointwise_wgrad(L, dev, N, C, M, H, W):
+    x, dz = T(rnd(1, N, C, H, W), dev), T(rnd(2, N, M, H, W), dev)
+    ns = L.smaat_wgrad_num_splits(N, H, W, M, C)
+    ws = torch.empty((ns, M, C), device=dev)
+    dw = torch.full((M, C), float("nan"), device=dev)
+    assert L.smaat_pointwise_wgrad(P(x), C * H * W, P(dz), M * H * W, P(ws), P(dw), N, C, M, H, W, stream(dev)) == 0
+    return dict(dw=dw)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 1, 32, 32), (2, 64, 21, 16, 16), (2, 16, 3, 6, 7), (2, 64, 1, 288, 288)])
+def test_pointwise_wgrad(shape):
+    both(case_pointwise_wgrad, *shape, tol=2e-5)
+
+
+def case_dw_bwd(L, dev, N, Cin, kpl, H, W, need_dx=True):
+    K = Cin * kpl
+    x, dy = T(rnd(1, N, Cin, H, W), dev), T(rnd(2, N, K, H, W), dev)
+    w_dw = T(rnd(3, K, 9, scale=0.3), dev)
+    dx = torch.full((N, Cin, H, W), float("nan"), device=dev) if need_dx else None
+    ws = torch.empty((N + 1, K, 10), device=dev)
+    dw, db = torch.full((K, 9), float("nan"), device=dev), torch.full((K,), float("nan"), device=dev)
+    assert L.smaat_dw3x3_bwd(P(x), Cin * H * W, P(dy), K * H * W, P(w_dw), P(dx), Cin * H * W, P(ws), P(dw), P(db), N,
+                             Cin, kpl, H, W, stream(dev)) == 0
+    r = dict(dw=dw, db=db)
+    if need_dx:
+        r["dx"] = dx
+    return r
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 2, 32, 32), (2, 6, 2, 9, 11), (1, 3, 4, 6, 10), (2, 5, 1, 8, 8),
+                                   (2, 8, 2, 36, 36), (2, 4, 2, 144, 144), (2, 3, 2, 288, 288), (1, 4, 2, 100, 100),
+                                   (2, 8, 2, 4, 4), (1, 8, 2, 2, 2)])
+def test_dw3x3_bwd(shape):
+    both(case_dw_bwd, *shape, tol=2e-5)
+    both(case_dw_bwd, *shape, need_dx=False, tol=2e-5)
+
+
+# ----------------------------------------------------------------------------------------
+def case_bn(L, dev, N, C, H, W, relu=1, slice_pad=0):
+    Pn = H * W
+    zfull = T(rnd(1, N, C + slice_pad, H, W) * 1.7 + 0.3, dev)
+    z = zfull[:, slice_pad:]
+    z_bs = (C + slice_pad) * Pn
+    gamma = T(np.random.default_rng(2).uniform(0.5, 1.5, C).astype(np.float32), dev)
+    beta = T(rnd(3, C, scale=0.2), dev)
+    bias = T(rnd(4, C, scale=0.5), dev)
+    # partial sums of (z - bias) spread over 5 slots
+    zz = (z - bias[None, :, None, None]).double()
+    part = torch.zeros((2, 5, C), device=dev)
+    part[0, 1] = zz.sum(dim=(0, 2, 3)).float() * 0.25
+    part[0, 3] = zz.sum(dim=(0, 2, 3)).float() * 0.75
+    part[1, 4] = (zz * zz).sum(dim=(0, 2, 3)).float()
+    rm, rv = T(rnd(5, C, scale=0.1), dev), T(np.random.default_rng(6).uniform(0.5, 2, C).astype(np.float32), dev)
+    st = torch.empty((4, C), device=dev)
+    s = stream(dev)
+    assert L.smaat_bn_finalize(P(part), 5, C, float(N * Pn), P(bias), P(gamma), P(beta), 1e-5, 0.1, P(rm), P(rv),
+                               P(st[0]), P(st[1]), P(st[2]), P(st[3]), s) == 0
+    y = torch.full((N, C, H, W), float("nan"), device=dev)
+    assert L.smaat_affine_act(z.data_ptr(), z_bs, P(st[2]), P(st[3]), P(y), C * Pn, N, C, Pn, relu, s) == 0
+    dy = T(rnd(7, N, C, H, W), dev)
+    slots = L.smaat_plane_num_slots(N, Pn)
+    bpart = torch.empty((2, slots, C), device=dev)
+    assert L.smaat_bn_bwd_reduce(P(dy), C * Pn, z.data_ptr(), z_bs, P(st[2]), P(st[3]), P(st[0]), P(st[1]), P(bpart),
+                                 N, C, Pn, relu, s) == 0
+    dgamma, dbeta, coef = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty((3, C), device=dev)
+    assert L.smaat_bn_bwd_finalize(P(bpart), slots, C, float(N * Pn), P(gamma), P(st[1]), P(dgamma), P(dbeta), P(coef),
+                                   s) == 0
+    dz = torch.full((N, C, H, W), float("nan"), device=dev)
+    assert L.smaat_bn_bwd_apply(P(dy), C * Pn, z.data_ptr(), z_bs, P(st[2]), P(st[3]), P(st[0]), P(st[1]), P(coef),
+                                P(dz), C * Pn, N, C, Pn, relu, s) == 0
+    return dict(st=st, rm=rm, rv=rv, y=y, dgamma=dgamma, dbeta=dbeta, coef=coef, dz=dz)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 12, 10), (3, 5, 9, 7), (2, 64, 72, 72), (2, 4, 288, 288), (4, 1, 36, 36)])
+def test_bn_chain(shape):
+    both(case_bn, *shape, tol=2e-5)
+    both(case_bn, *shape, relu=0, slice_pad=3, tol=2e-5)
+
+
+def case_misc(L, dev, N, C, H, W):
+    Pn = H * W
+    x = T(rnd(1, N, C, H, W), dev)
+    s = stream(dev)
+    ws = torch.empty((L.smaat_plane_num_slots(N, Pn), C), device=dev)
+    cs = torch.empty(C, device=dev)
+    assert L.smaat_channel_sum(P(x), C * Pn, N, C, Pn, P(ws), P(cs), s) == 0
+    rows = T(rnd(2, 7, 1000), dev)
+    rr = torch.empty(1000, device=dev)
+    assert L.smaat_reduce_rows(P(rows), 7, 1000, P(rr), 0.5, s) == 0
+    big = torch.zeros((N, C + 3, H, W), device=dev)
+    assert L.smaat_copy_planes(P(x), C * Pn, big.data_ptr() + 4 * 2 * Pn, (C + 3) * Pn, N, C * Pn, 0, s) == 0
+    assert L.smaat_copy_planes(P(x), C * Pn, big.data_ptr() + 4 * 2 * Pn, (C + 3) * Pn, N, C * Pn, 1, s) == 0
+    return dict(cs=cs, rr=rr, big=big)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 5, 7), (2, 16, 64, 64), (1, 1, 288, 288)])
+def test_misc(shape):
+    both(case_misc, *shape)
+
+
+def case_pool_up(L, dev, N, C, H, W, Ho, Wo):
+    s = stream(dev)
+    x = T(np.maximum(rnd(1, N, C, H, W), 0), dev)  # relu-like: exercises ties at 0
+    y = torch.full((N, C, H // 2, W // 2), float("nan"), device=dev)
+    assert L.smaat_maxpool2_fwd(P(x), C * H * W, P(y), C * (H // 2) * (W // 2), N, C, H, W, s) == 0
+    dy = T(rnd(2, N, C, H // 2, W // 2), dev)
+    dx = torch.full((N, C, H, W), float("nan"), device=dev)
+    assert L.smaat_maxpool2_bwd(P(x), C * H * W, P(dy), C * (H // 2) * (W // 2), P(dx), C * H * W, N, C, H, W, 0,
+                                s) == 0
+    # upsample into a padded slice of a cat buffer
+    pt, pl = (Ho - 2 * H) // 2, (Wo - 2 * W) // 2
+    cat = torch.full((N, C + 2, Ho, Wo), float("nan"), device=dev)
+    assert L.smaat_upsample2x_fwd(P(x), C * H * W, cat.data_ptr() + 4 * 2 * Ho * Wo, (C + 2) * Ho * Wo, N, C, H, W, Ho,
+                                  Wo, pt, pl, s) == 0
+    dcat = T(rnd(3, N, C + 2, Ho, Wo), dev)
+    dxu = torch.full((N, C, H, W), float("nan"), device=dev)
+    assert L.smaat_upsample2x_bwd(dcat.data_ptr() + 4 * 2 * Ho * Wo, (C + 2) * Ho * Wo, P(dxu), C * H * W, N, C, H, W,
+                                  Ho, Wo, pt, pl, s) == 0
+    return dict(y=y, dx=dx, up=cat[:, 2:], dxu=dxu)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 8, 8, 16, 16), (2, 4, 5, 6, 11, 13), (1, 2, 11, 13, 22, 26),
+                                   (2, 8, 18, 18, 36, 36), (1, 2, 144, 144, 288, 288), (2, 3, 2, 2, 4, 4),
+                                   (1, 2, 2, 3, 5, 7)])
+def test_pool_upsample(shape):
+    both(case_pool_up, *shape)
+
+
+# ----------------------------------------------------------------------------------------
+def case_cbam(L, dev, N, C, H, W, ks=7, rr=16):
+    Pn, Cr = H * W, max(C // rr, 1)
+    s = stream(dev)
+    x = T(np.maximum(rnd(1, N, C, H, W), 0), dev)
+    w1, b1 = T(rnd(2, Cr, C, scale=0.3), dev), T(rnd(3, Cr, scale=0.1), dev)
+    w2, b2 = T(rnd(4, C, Cr, scale=0.3), dev), T(rnd(5, C, scale=0.1), dev)
+    wc = T(rnd(6, 2, ks, ks, scale=0.2), dev)
+    gamma, beta = T(np.array([1.3], np.float32), dev), T(np.array([0.1], np.float32), dev)
+    avg, mx = torch.empty((N, C), device=dev), torch.empty((N, C), device=dev)
+    amax = torch.empty((N, C), dtype=torch.int32, device=dev)
+    assert L.smaat_cbam_chpool(P(x), C * Pn, N, C, Pn, P(avg), P(mx), P(amax), s) == 0
+    ha, hm, sc = torch.empty((N, Cr), device=dev), torch.empty((N, Cr), device=dev), torch.empty((N, C), device=dev)
+    assert L.smaat_cbam_mlp(P(avg), P(mx), P(w1), P(b1), P(w2), P(b2), N, C, Cr, P(ha), P(hm), P(sc), s) == 0
+    maps = torch.empty((N, 2, H, W), device=dev)
+    assert L.smaat_cbam_sppool(P(x), C * Pn, P(sc), N, C, Pn, P(maps), s) == 0
+    nb = L.smaat_cbam_spconv_blocks(N, H, W)
+    conv, part = torch.empty((N, 1, H, W), device=dev), torch.empty((2, nb, 1), device=dev)
+    assert L.smaat_cbam_spconv(P(maps), P(wc), ks, N, H, W, P(conv), P(part), s) == 0
+    st = torch.empty((4, 1), device=dev)
+    assert L.smaat_bn_finalize(P(part), nb, 1, float(N * Pn), None, P(gamma), P(beta), 1e-5, 0.1, None, None,
+                               P(st[0]), P(st[1]), P(st[2]), P(st[3]), s) == 0
+    gate = torch.empty((N, 1, H, W), device=dev)
+    assert L.smaat_cbam_gate(P(conv), P(st[2]), P(st[3]), N * Pn, P(gate), s) == 0
+    out = torch.full((N, C, H, W), float("nan"), device=dev)
+    assert L.smaat_cbam_apply(P(x), C * Pn, P(sc), P(gate), P(out), C * Pn, N, C, Pn, s) == 0
+    # ---- backward
+    dout = T(rnd(7, N, C, H, W), dev)
+    nbp = L.smaat_cbam_pix_blocks(N, Pn)
+    dbn, bpart = torch.empty((N, Pn), device=dev), torch.empty((2, nbp, 1), device=dev)
+    assert L.smaat_cbam_bwd_gate(P(dout), C * Pn, P(x), C * Pn, P(sc), P(gate), P(conv), P(st[0]), P(st[1]), N, C, Pn,
+                                 P(dbn), P(bpart), s) == 0
+    dgamma, dbeta, coef = torch.empty(1, device=dev), torch.empty(1, device=dev), torch.empty((3, 1), device=dev)
+    assert L.smaat_bn_bwd_finalize(P(bpart), nbp, 1, float(N * Pn), P(gamma), P(st[1]), P(dgamma), P(dbeta), P(coef),
+                                   s) == 0
+    dmaps, wpart = torch.empty((N, 2, H, W), device=dev), torch.empty((nb, 2 * ks * ks), device=dev)
+    assert L.smaat_cbam_bwd_spconv(P(dbn), P(conv), P(st[0]), P(st[1]), P(coef), P(maps), P(wc), ks, N, H, W, P(dmaps),
+                                   P(wpart), s) == 0
+    dx = torch.full((N, C, H, W), float("nan"), device=dev)
+    dspart = torch.empty((nbp, C), device=dev)
+    assert L.smaat_cbam_bwd_main(P(dout), C * Pn, P(x), C * Pn, P(sc), P(gate), P(maps), P(dmaps), N, C, Pn, P(dx),
+                                 C * Pn, P(dspart), s) == 0
+    per = nbp // N
+    ds = dspart.view(per, N, C).double().sum(0).float().contiguous()
+    pgs = C * Cr + C + Cr * C + Cr
+    pg, davg, dmx = torch.empty((N, pgs), device=dev), torch.empty((N, C), device=dev), torch.empty((N, C), device=dev)
+    assert L.smaat_cbam_bwd_mlp(P(ds), P(sc), P(avg), P(mx), P(ha), P(hm), P(w1), P(w2), N, C, Cr, P(pg), P(davg),
+                                P(dmx), s) == 0
+    dx_main = dx.clone()
+    assert L.smaat_cbam_bwd_final(P(dx), C * Pn, P(davg), P(dmx), P(amax), N, C, Pn, s) == 0
+    return dict(avg=avg, mx=mx, amax=amax.float(), ha=ha, hm=hm, sc=sc, maps=maps, conv=conv,
+                psum=part[0].double().sum(), psq=part[1].double().sum(), st=st, gate=gate, out=out, dbn=dbn,
+                bsum=bpart.double().sum(1), dgamma=dgamma, dbeta=dbeta, coef=coef, dmaps=dmaps,
+                dwc=wpart.double().sum(0), dx_main=dx_main, ds=ds, pg=pg, davg=davg, dmx=dmx, dx=dx)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 10, 10), (2, 64, 4, 4), (3, 16, 9, 12), (2, 64, 72, 72), (2, 512, 18, 18),
+                                   (1, 64, 288, 288), (2, 128, 37, 41)])
+def test_cbam_chain(shape):
+    both(case_cbam, *shape, tol=3e-5)
+
+
+def test_cbam_ks3():
+    both(case_cbam, 2, 32, 10, 10, ks=3, tol=3e-5)

@@ -1,0 +1,188 @@
+"""GPU: the module-level drop-ins (HIP path through the C ABI) against
+  * the reference-generated golden fixtures (tests/golden, made by oracle/gen_golden.py),
+  * the numpy oracle on seeded inputs at sizes it finishes in seconds,
+  * size-independent properties at BASELINE.json's full size (288x288, batch 32).
+Tolerances (north_star: 1e-4 relative fp32 on outputs): forward rel-L2 <= 1e-4;
+per-op gradients <= 3e-4; end-to-end gradients <= 2e-2 (the reference disagrees with ITSELF
+at 2-5e-3 end to end)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import smaat_unet_amd as S
+from oracle import params as oparams
+from oracle import smaat_oracle as O
+from tests.test_host_emu import check_summary, rel
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops.npz"))
+
+
+def run_case(ops, tag, mod, tol_out=2e-5, tol_grad=3e-4, zero_bias=True):
+    pre = f"{tag}/param/"
+    mod.load_state_dict({k[len(pre):]: torch.from_numpy(ops[k]) for k in ops.files if k.startswith(pre)})
+    mod.to(DEV).train()
+    ins, i = [], 0
+    while f"{tag}/in{i}" in ops.files:
+        ins.append(torch.from_numpy(ops[f"{tag}/in{i}"]).to(DEV).requires_grad_(True))
+        i += 1
+    out = mod(*ins)
+    assert rel(out.detach().cpu().numpy(), ops[f"{tag}/out"]) < tol_out
+    (out * torch.from_numpy(ops[f"{tag}/cot"]).to(DEV)).sum().backward()
+    for i, x in enumerate(ins):
+        assert rel(x.grad.cpu().numpy(), ops[f"{tag}/din{i}"]) < tol_grad, f"din{i}"
+    for k, p in mod.named_parameters():
+        ref = ops[f"{tag}/grad/{k}"]
+        if zero_bias and ".double_conv." in "." + k and (k.endswith("depthwise.bias") or k.endswith("pointwise.bias")):
+            wn = np.linalg.norm(ops[f"{tag}/grad/{k.replace('bias', 'weight')}"])
+            assert np.abs(p.grad.cpu().numpy()).max() <= 1e-3 * wn + 1e-5, k
+            continue
+        assert rel(p.grad.cpu().numpy(), ref) < tol_grad, k
+    for k, v in mod.state_dict().items():
+        if "running" in k:
+            assert rel(v.cpu().numpy(), ops[f"{tag}/after/{k}"]) < 1e-5, k
+
+
+@pytest.mark.parametrize("tag,ctor,zb", [
+    ("dsconv_k2", lambda: S.DepthwiseSeparableConv(6, 10, kernel_size=3, padding=1, kernels_per_layer=2), False),
+    ("dsconv_k1", lambda: S.DepthwiseSeparableConv(5, 7, kernel_size=3, padding=1, kernels_per_layer=1), False),
+    ("dsconv_k4", lambda: S.DepthwiseSeparableConv(3, 8, kernel_size=3, padding=1, kernels_per_layer=4), False),
+    ("doubleconv", lambda: S.DoubleConvDS(6, 16, kernels_per_layer=2), True),
+    ("doubleconv_mid", lambda: S.DoubleConvDS(8, 4, mid_channels=12, kernels_per_layer=2), True),
+    ("down", lambda: S.DownDS(6, 12, kernels_per_layer=2), True),
+    ("down_odd", lambda: S.DownDS(4, 8, kernels_per_layer=2), True),
+    ("up", lambda: S.UpDS(16, 6, bilinear=True, kernels_per_layer=2), True),
+    ("up_pad", lambda: S.UpDS(8, 4, bilinear=True, kernels_per_layer=2), True),
+    ("chatt", lambda: S.ChannelAttention(32, reduction_ratio=16), True),
+    ("spatt", lambda: S.SpatialAttention(kernel_size=7), True),
+    ("cbam", lambda: S.CBAM(32, reduction_ratio=16), True),
+    ("cbam_small", lambda: S.CBAM(64, reduction_ratio=16), True),
+    ("outconv", lambda: S.OutConv(16, 3), False),
+])
+def test_module_vs_reference_golden(ops, tag, ctor, zb):
+    run_case(ops, tag, ctor(), zero_bias=zb)
+
+
+def _load_model(meta):
+    P = oparams.make_smaat_params(meta["n_channels"], meta["n_classes"], 2, 16, meta["param_seed"])
+    model = S.SmaAt_UNet(meta["n_channels"], meta["n_classes"])
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in P.items()})
+    return model.to(DEV).train(), P
+
+
+@pytest.mark.parametrize("name", ["unet_12x1_n2_32", "unet_12x1_n2_64x48", "unet_3x21_n1_32"])
+def test_unet_vs_reference_golden(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    meta = json.loads(str(g["meta"]))
+    model, _ = _load_model(meta)
+    x = torch.from_numpy(g["x"]).to(DEV).requires_grad_(True)
+    logits = model(x)
+    e = rel(logits.detach().cpu().numpy(), g["logits"])
+    assert e < 1e-4, e
+    tgt = torch.from_numpy(g["target"]).to(DEV)
+    if meta["loss"] == "mse":  # reference: models/regression_lightning.py:57-65
+        loss = torch.nn.functional.mse_loss(logits.squeeze(1), tgt, reduction="sum") / meta["n"]
+        assert abs(loss.item() - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    else:
+        loss = (logits * tgt).sum()
+    loss.backward()
+    worst = ("", 0.0)
+    for k, p in model.named_parameters():
+        if ".double_conv." in k and (k.endswith("depthwise.bias") or k.endswith("pointwise.bias")):
+            continue
+        e = check_summary(g, "grad/" + k, p.grad.cpu().numpy())
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] < 2e-2, worst
+    assert check_summary(g, "dx", x.grad.cpu().numpy()) < 2e-2
+    sd = model.state_dict()
+    for k in g.files:
+        if k.startswith("after/"):
+            assert rel(sd[k[6:]].cpu().numpy(), g[k]) < 1e-4, k
+
+
+def test_unet_vs_oracle_288():
+    """one 288x288 frame pair, forward + backward, against the numpy oracle."""
+    meta = dict(n_channels=12, n_classes=1, param_seed=3)
+    model, P = _load_model(meta)
+    xn, yn = O.synthetic_precip(2, 12, 288, 288, seed=1234)
+    loss_o, G, dx_o, acts = O.train_step_loss_and_grads(P, xn, yn)
+    x = torch.from_numpy(xn).to(DEV).requires_grad_(True)
+    logits = model(x)
+    assert rel(logits.detach().cpu().numpy(), acts["logits"]) < 1e-4
+    loss = torch.nn.functional.mse_loss(logits.squeeze(1), torch.from_numpy(yn).to(DEV), reduction="sum") / 2
+    assert abs(loss.item() - float(loss_o)) < 1e-4 * abs(float(loss_o))
+    loss.backward()
+    worst = ("", 0.0)
+    for k, p in model.named_parameters():
+        if ".double_conv." in k and (k.endswith("depthwise.bias") or k.endswith("pointwise.bias")):
+            continue
+        e = rel(p.grad.cpu().numpy(), G[k])
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] < 3e-2, worst
+    assert rel(x.grad.cpu().numpy(), dx_o) < 3e-2
+
+
+def test_full_size_properties():
+    """BASELINE config 2 size (batch 32, 12x288x288): properties that need no oracle run."""
+    torch.manual_seed(0)
+    model = S.SmaAt_UNet(12, 1).to(DEV)
+    xn, yn = O.synthetic_precip(32, 12, 288, 288, seed=7)
+    x, y = torch.from_numpy(xn).to(DEV), torch.from_numpy(yn).to(DEV)
+    # (a) eval mode is per-sample: a batch of 32 == two batches of 16 (different tile configs, same k order)
+    model.train()
+    with torch.no_grad():
+        model(x[:4])  # move running stats off their init
+    model.eval()
+    with torch.no_grad():
+        full = model(x)
+        halves = torch.cat([model(x[:16]), model(x[16:])])
+    assert torch.isfinite(full).all()
+    assert rel(full.cpu().numpy(), halves.cpu().numpy()) < 1e-6
+    # (b) train-mode BN invariants on the first fused stage: mean(bn(z)) = beta, var = gamma^2 var/(var+eps)
+    from smaat_unet_amd import ops as K
+    c0, bn0 = model.inc.double_conv[0], model.inc.double_conv[1]
+    with torch.no_grad():
+        bn0.weight.uniform_(0.5, 1.5)
+        bn0.bias.uniform_(-0.3, 0.3)
+    z, part, slots = K._dsconv_fwd_raw(x, c0.depthwise.weight.detach(), c0.depthwise.bias.detach(),
+                                       c0.pointwise.weight.detach(), c0.pointwise.bias.detach(), 2, True)
+    st = K._bn_finalize_raw(part, slots, 64, 32 * 288 * 288, c0.pointwise.bias.detach(), bn0.weight.detach(),
+                            bn0.bias.detach(), 1e-5, 0.1, None, None)
+    a = K._affine_act_raw(z, st[2], st[3], False).double()
+    m = a.mean(dim=(0, 2, 3)).float()
+    v = a.var(dim=(0, 2, 3), unbiased=False).float()
+    zvar = z.double().var(dim=(0, 2, 3), unbiased=False).float()
+    assert (m - bn0.bias).abs().max().item() < 2e-5
+    assert rel((v / (bn0.weight ** 2 * zvar / (zvar + 1e-5))).cpu().numpy(), np.ones(64)) < 1e-4
+    # (c) backward is linear in the cotangent: scaling the loss by 2 scales every gradient by exactly 2
+    model.train()
+    grads = []
+    for scale in (1.0, 2.0):
+        model.zero_grad(set_to_none=True)
+        for mod in model.modules():  # same BN momentum state does not matter; stats are batch stats
+            pass
+        out = model(x)
+        (torch.nn.functional.mse_loss(out.squeeze(1), y, reduction="sum") / 32 * scale).backward()
+        grads.append([p.grad.clone() for p in model.parameters()])
+    for g1, g2 in zip(*grads):
+        assert torch.equal(g1 * 2.0, g2)
+    tot = torch.cat([g.flatten() for g in grads[0]])
+    assert torch.isfinite(tot).all() and tot.abs().sum().item() > 0
+
+
+def test_library_is_the_hip_one():
+    from smaat_unet_amd import _lib
+    L = _lib.get()
+    assert type(L).__name__ == "_Lib" and os.path.basename(_lib.LIB_PATH) == "libsmaat_hip.so"
+    with open(f"/proc/{os.getpid()}/maps") as f:
+        assert "libsmaat_hip.so" in f.read()

@@ -1,0 +1,166 @@
+"""CPU: the Python host layer (modules, autograd wiring, buffer sizing) driven through a
+numpy EMULATION of the C ABI (tests/emu_backend.py) must reproduce the reference-generated
+goldens.  This checks the host logic only; the HIP kernels are checked by the -m gpu tests."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import smaat_unet_amd as S
+from oracle import params as oparams
+from tests import emu_backend
+
+
+@pytest.fixture(autouse=True)
+def _emu():
+    emu_backend.install()
+    yield
+    emu_backend.uninstall()
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def ops(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops.npz"))
+
+
+def load_case(ops, tag, mod):
+    pre = f"{tag}/param/"
+    sd = {k[len(pre):]: torch.from_numpy(ops[k]) for k in ops.files if k.startswith(pre)}
+    mod.load_state_dict(sd)
+    mod.train()
+    ins = []
+    i = 0
+    while f"{tag}/in{i}" in ops.files:
+        ins.append(torch.from_numpy(ops[f"{tag}/in{i}"]).requires_grad_(True))
+        i += 1
+    return ins
+
+
+def run_case(ops, tag, mod, tol_out=1e-5, tol_grad=3e-4, zero_bias=True):
+    ins = load_case(ops, tag, mod)
+    out = mod(*ins)
+    assert rel(out.detach().numpy(), ops[f"{tag}/out"]) < tol_out
+    (out * torch.from_numpy(ops[f"{tag}/cot"])).sum().backward()
+    for i, x in enumerate(ins):
+        assert rel(x.grad.numpy(), ops[f"{tag}/din{i}"]) < tol_grad, f"din{i}"
+    for k, p in mod.named_parameters():
+        ref = ops[f"{tag}/grad/{k}"]
+        if zero_bias and ".double_conv." in "." + k and (k.endswith("depthwise.bias") or k.endswith("pointwise.bias")):
+            wn = np.linalg.norm(ops[f"{tag}/grad/{k.replace('bias', 'weight')}"])
+            assert np.abs(p.grad.numpy()).max() <= 1e-3 * wn + 1e-5, k
+            continue
+        assert rel(p.grad.numpy(), ref) < tol_grad, k
+    for k, v in mod.state_dict().items():
+        if "running" in k:
+            assert rel(v.numpy(), ops[f"{tag}/after/{k}"]) < 1e-5, k
+        if "num_batches" in k:
+            assert int(v) == int(ops[f"{tag}/after/{k}"])
+
+
+def test_dsconv(ops):
+    run_case(ops, "dsconv_k2", S.DepthwiseSeparableConv(6, 10, kernel_size=3, padding=1, kernels_per_layer=2),
+             zero_bias=False)
+    run_case(ops, "dsconv_k1", S.DepthwiseSeparableConv(5, 7, kernel_size=3, padding=1, kernels_per_layer=1),
+             zero_bias=False)
+    run_case(ops, "dsconv_k4", S.DepthwiseSeparableConv(3, 8, kernel_size=3, padding=1, kernels_per_layer=4),
+             zero_bias=False)
+
+
+def test_doubleconv(ops):
+    run_case(ops, "doubleconv", S.DoubleConvDS(6, 16, kernels_per_layer=2))
+    run_case(ops, "doubleconv_mid", S.DoubleConvDS(8, 4, mid_channels=12, kernels_per_layer=2))
+
+
+def test_down(ops):
+    run_case(ops, "down", S.DownDS(6, 12, kernels_per_layer=2))
+    run_case(ops, "down_odd", S.DownDS(4, 8, kernels_per_layer=2))
+
+
+def test_up(ops):
+    run_case(ops, "up", S.UpDS(16, 6, bilinear=True, kernels_per_layer=2))
+    run_case(ops, "up_pad", S.UpDS(8, 4, bilinear=True, kernels_per_layer=2))
+
+
+def test_attention(ops):
+    run_case(ops, "chatt", S.ChannelAttention(32, reduction_ratio=16))
+    run_case(ops, "spatt", S.SpatialAttention(kernel_size=7))
+    run_case(ops, "cbam", S.CBAM(32, reduction_ratio=16))
+    run_case(ops, "cbam_small", S.CBAM(64, reduction_ratio=16))
+
+
+def test_outconv(ops):
+    run_case(ops, "outconv", S.OutConv(16, 3), zero_bias=False)
+
+
+def check_summary(store, tag, arr):
+    a = np.asarray(arr, np.float32)
+    if tag + "#full" in store.files:
+        ref = store[tag + "#full"]
+        return np.linalg.norm(a.astype(np.float64) - ref) / max(float(store[tag + "#l2"]), 1e-30)
+    idx, ref = store[tag + "#idx"], store[tag + "#vals"]
+    return np.linalg.norm(a.ravel()[idx].astype(np.float64) - ref) / max(np.linalg.norm(ref), 1e-30)
+
+
+@pytest.mark.parametrize("name", ["unet_12x1_n2_32", "unet_3x21_n1_32"])
+def test_unet(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    meta = json.loads(str(g["meta"]))
+    P = oparams.make_smaat_params(meta["n_channels"], meta["n_classes"], 2, 16, meta["param_seed"])
+    model = S.SmaAt_UNet(meta["n_channels"], meta["n_classes"])
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in P.items()})
+    model.train()
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    logits = model(x)
+    assert rel(logits.detach().numpy(), g["logits"]) < 1e-4
+    if meta["loss"] == "mse":
+        loss = torch.nn.functional.mse_loss(logits.squeeze(1), torch.from_numpy(g["target"]), reduction="sum") / \
+            meta["n"]
+        assert abs(loss.item() - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    else:
+        loss = (logits * torch.from_numpy(g["target"])).sum()
+    loss.backward()
+    for k, p in model.named_parameters():
+        if ".double_conv." in k and (k.endswith("depthwise.bias") or k.endswith("pointwise.bias")):
+            continue
+        assert check_summary(g, "grad/" + k, p.grad.numpy()) < 2e-2, k
+    assert check_summary(g, "dx", x.grad.numpy()) < 2e-2
+    sd = model.state_dict()
+    for k in g.files:
+        if k.startswith("after/"):
+            assert rel(sd[k[6:]].numpy(), g[k]) < 1e-4, k
+    assert int(sd["inc.double_conv.1.num_batches_tracked"]) == 1
+
+
+def test_eval_mode_matches_oracle(ops):
+    """eval: BN uses running stats (reference call stack D)."""
+    mod = S.DoubleConvDS(6, 16, kernels_per_layer=2)
+    ins = load_case(ops, "doubleconv", mod)
+    with torch.no_grad():
+        mod(ins[0])  # one train step to move the running stats
+        mod.eval()
+        y = mod(ins[0]).numpy()
+    ref = torch.nn.Sequential()
+    from oracle import smaat_oracle as O
+    sd = {k: v.numpy() for k, v in mod.state_dict().items()}
+    h = ins[0].detach().numpy()
+    for a, b in (("0", "1"), ("3", "4")):
+        yy = O.dw3x3_fwd(h, sd[f"double_conv.{a}.depthwise.weight"], sd[f"double_conv.{a}.depthwise.bias"], 2)
+        z = O.pw1x1_fwd(yy, sd[f"double_conv.{a}.pointwise.weight"], sd[f"double_conv.{a}.pointwise.bias"])
+        h = O.relu_fwd(O.bn_eval_fwd(z, sd[f"double_conv.{b}.weight"], sd[f"double_conv.{b}.bias"],
+                                     sd[f"double_conv.{b}.running_mean"], sd[f"double_conv.{b}.running_var"]))
+    assert rel(y, h) < 1e-5
+
+
+def test_no_cpu_fallback():
+    emu_backend.uninstall()
+    m = S.OutConv(4, 2)
+    with pytest.raises(Exception, match="no CPU fallback"):
+        m(torch.zeros(1, 4, 4, 4))

@@ -216,3 +216,20 @@ def test_state_dict_keys(golden_dir):
         mine = [[k, list(s)] for k, s in oparams.smaat_unet_keys(nc, ncl)]
         assert mine == ref[tag]
         assert len(mine) == 214
+
+
+@pytest.mark.parametrize("name", ["unet_12x1_n2_32", "unet_12x1_n2_64x48"])
+def test_torch_functional_port_vs_golden(golden_dir, name):
+    """oracle/torch_ref.py (bench.py's cpu_baseline port) reproduces the reference."""
+    import torch
+    from oracle import torch_ref
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    meta = json.loads(str(g["meta"]))
+    P = torch_ref.params_from_numpy(oparams.make_smaat_params(meta["n_channels"], meta["n_classes"], 2, 16,
+                                                               meta["param_seed"]))
+    loss, logits = torch_ref.train_step(P, torch.from_numpy(g["x"]), torch.from_numpy(g["target"]))
+    assert rel(logits.numpy(), g["logits"]) < 2e-5
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    for k in ["outc.conv.weight", "up4.conv.double_conv.3.pointwise.weight", "inc.double_conv.0.depthwise.weight",
+              "cbam3.channel_att.MLP.1.weight"]:
+        assert check_summary(g, "grad/" + k, P[k].grad.numpy(), 2e-2) < 2e-2, k
