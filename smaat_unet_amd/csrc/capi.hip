@@ -59,7 +59,7 @@ int launch_cbam_bwd_mlp(const float*, const float*, const float*, const float*, 
                         const float*, const float*, int, int, int, float*, float*, float*, hipStream_t);
 int launch_cbam_bwd_final(float*, long, const float*, const float*, const int*, int, int, int, hipStream_t);
 
-#define ST ((hipStream_t)stream)
+#define ST ((hipStream_t)(((void)hipGetLastError()), stream))
 #define CHK(e)              \
     do {                    \
         int _r = (e);       \

@@ -250,7 +250,7 @@ struct WgArgs {
     const float* dz;
     long dz_bs;
     float* dwpart;  // [nsplit][M][Kdim]
-    int N, Cin, kpl, Kdim, M, nco, nkt, nsplit, tiles_per_split;
+    int N, Cin, kpl, Kdim, M, nco, nkt, nsplit, tiles_per_split, sstride;
     TileGeom g;  // PT == PSW
 };
 
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(SMAAT_THREADS) void k_wgrad(const WgArgs a) {
                             v = plane[goff[j]];
                             if (AFF) v = fmaxf(fmaf(v, sc_, sh_), 0.f);
                         }
-                        S[cl * SMAXW + tid + SMAAT_THREADS * j] = v;
+                        S[cl * a.sstride + tid + SMAAT_THREADS * j] = v;
                     }
                 }
             }
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(SMAAT_THREADS) void k_wgrad(const WgArgs a) {
             const int sb = pv ? (pr - rg.row_lo) * SW + (pc - rg.col_lo) : (SW + 1);
             const int wv = __builtin_amdgcn_readfirstlane(wave);
             for (int cl = wv; cl < kci; cl += 4) {
-                const float* sp = S + cl * SMAXW + sb;
+                const float* sp = S + cl * a.sstride + sb;
                 const float s00 = sp[-SW - 1], s01 = sp[-SW], s02 = sp[-SW + 1];
                 const float s10 = sp[-1], s11 = sp[0], s12 = sp[1];
                 const float s20 = sp[SW - 1], s21 = sp[SW], s22 = sp[SW + 1];
@@ -506,13 +506,24 @@ int launch_pwgemm(PwArgs& a, bool dw, hipStream_t st) {
     return launch_pwgemm_cfg<1, 2, 4, 1>(a, dw, aff, st);           // 64 x 128
 }
 
+static int wgrad_smax(int M, int kpl, bool dw) {
+    // staged floats per input channel that fit next to the dz / Y tiles in 160 KiB of LDS
+    if (!dw) return SMAXW;
+    const int cot = (M > 64) ? 128 : 64;
+    const int fixed = PSW * (cot + 1) + PSW * (64 + 1);
+    const int kci = 64 / kpl;
+    int smax = (38 * 1024 - fixed) / kci;  // 152 KiB budget in floats
+    if (smax > SMAXW) smax = SMAXW;
+    return smax;
+}
+
 template <int WCO, int CT, int WK, int KW>
 static int launch_wgrad_cfg(WgArgs& a, bool dw, bool aff, hipStream_t st) {
     constexpr int COT = WCO * CT * 32, KT = WK * KW * 32;
     a.nco = ceil_div(a.M, COT);
     a.nkt = ceil_div(a.Kdim, KT);
     const int kci = KT / a.kpl;
-    size_t lds = sizeof(float) * (size_t)(PSW * (COT + 1) + PSW * (KT + 1) + (dw ? kci * SMAXW : 0));
+    size_t lds = sizeof(float) * (size_t)(PSW * (COT + 1) + PSW * (KT + 1) + (dw ? kci * a.sstride : 0));
     const int grid = ceil_div(a.nsplit, 8) * 8 * a.nco * a.nkt;
 #define LAUNCH(DWF, AFFF)                                                                                 \
     do {                                                                                                  \
@@ -532,23 +543,23 @@ static int launch_wgrad_cfg(WgArgs& a, bool dw, bool aff, hipStream_t st) {
 
 // number of pixel splits used by the weight-gradient kernel (size of the partial buffer)
 int smaat_wgrad_num_splits_impl(int N, int H, int W, int M, int Kdim) {
-    TileGeom g;
-    g.H = H;
-    g.W = W;
-    choose_geom(N, H, W, PSW, SMAXW, &g);
+    // independent of the tile mode: bounded by the minimal tile count N*ceil(P/PSW)
+    const int tmin = N * ceil_div(H * W, PSW);
     const int cot = (M > 64) ? 128 : 64;
     const int ntile = ceil_div(M, cot) * ceil_div(Kdim, 64);
     int ns = ceil_div(2048, ntile);
-    if (ns > g.T) ns = g.T;
+    if (ns > tmin) ns = tmin;
     if (ns < 1) ns = 1;
-    const int tps = ceil_div(g.T, ns);
-    return ceil_div(g.T, tps);
+    return ns;
 }
 
 int launch_wgrad(WgArgs& a, bool dw, hipStream_t st) {
     if (a.kpl != 1 && a.kpl != 2 && a.kpl != 4) return -1;
     const bool aff = dw && a.in_scale != nullptr;
-    choose_geom(a.N, a.g.H, a.g.W, PSW, SMAXW, &a.g);
+    const int smax = wgrad_smax(a.M, a.kpl, dw);
+    choose_geom(a.N, a.g.H, a.g.W, PSW, smax, &a.g);
+    if (a.g.mode < 0) return -1;
+    a.sstride = smax;
     a.nsplit = smaat_wgrad_num_splits_impl(a.N, a.g.H, a.g.W, a.M, a.Kdim);
     a.tiles_per_split = ceil_div(a.g.T, a.nsplit);
     if (a.M > 64) return launch_wgrad_cfg<2, 2, 2, 1>(a, dw, aff, st);  // 128 x 64

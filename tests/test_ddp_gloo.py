@@ -1,0 +1,82 @@
+"""CPU, world_size 2, gloo: the N > 1 path of the training step -- identical
+replicas after broadcast, ONE flat all-reduce per step, gradients = mean over ranks of the
+per-shard gradients (per-replica BatchNorm statistics, stock-DDP semantics).  The kernels
+are emulated (tests/emu_backend.py); what is under test is smaat_unet_amd/ddp.py + the host
+wiring."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import smaat_unet_amd as S
+from oracle import params as oparams
+from oracle import smaat_oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard(rank):
+    return O.synthetic_precip(1, 12, 32, 32, seed=100 + rank)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import emu_backend
+    from smaat_unet_amd.ddp import FlatGradAllReduce
+    emu_backend.install()
+    torch.manual_seed(1234 + rank)  # deliberately different inits: broadcast must fix that
+    model = S.SmaAt_UNet(12, 1).train()
+    if rank == 0:
+        P = oparams.make_smaat_params(12, 1, 2, 16, 0)
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in P.items()})
+    ddp = FlatGradAllReduce(model.parameters())
+    assert ddp.world == world and ddp.numel == 4033537
+    ddp.broadcast_parameters(0)
+    xn, yn = _shard(rank)
+    out = model(torch.from_numpy(xn))
+    loss = torch.nn.functional.mse_loss(out.squeeze(1), torch.from_numpy(yn), reduction="sum") / 1
+    loss.backward()
+    flat = ddp.reduce()
+    assert all(p.grad.data_ptr() >= flat.data_ptr() for p in model.parameters())
+    np.save(os.path.join(out_dir, f"flat{rank}.npy"), flat.numpy())
+    np.save(os.path.join(out_dir, f"w{rank}.npy"), model.outc.conv.weight.detach().numpy())
+    dist.destroy_process_group()
+
+
+def test_flat_allreduce_world2(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    f0, f1 = np.load(tmp_path / "flat0.npy"), np.load(tmp_path / "flat1.npy")
+    assert np.array_equal(f0, f1)  # every rank holds the same averaged gradient
+    P = oparams.make_smaat_params(12, 1, 2, 16, 0)
+    assert np.array_equal(np.load(tmp_path / "w1.npy"), P["outc.conv.weight"])  # broadcast worked
+    # oracle: mean of the per-shard gradients (fresh BN statistics per shard)
+    names = [k for k, _ in oparams.smaat_unet_keys(12, 1) if "running" not in k and "num_batches" not in k]
+    acc = None
+    for r in range(2):
+        xn, yn = _shard(r)
+        _, G, _, _ = O.train_step_loss_and_grads(P, xn, yn)
+        flat = np.concatenate([np.asarray(G[k], np.float32).ravel() for k in names])
+        acc = flat if acc is None else acc + flat
+    acc = acc / 2
+    # exact-zero conv-bias gradients are roundoff in the oracle: compare on the rest
+    mask = np.ones_like(acc, bool)
+    off = 0
+    for k in names:
+        n = int(np.prod(P[k].shape))
+        if ".double_conv." in k and (k.endswith("depthwise.bias") or k.endswith("pointwise.bias")):
+            mask[off:off + n] = False
+        off += n
+    err = np.linalg.norm(f0[mask] - acc[mask]) / np.linalg.norm(acc[mask])
+    assert err < 2e-2, err

@@ -110,26 +110,37 @@ def test_unet_vs_reference_golden(golden_dir, name):
 
 
 def test_unet_vs_oracle_288():
-    """one 288x288 frame pair, forward + backward, against the numpy oracle."""
+    """one 288x288 frame, forward + backward, against the numpy oracle.  End-to-end gradients
+    are judged the way SURVEY.md 8(c) prescribes: our error against the FP64 oracle must be no
+    worse than 2x the FP32 oracle's own error against FP64 (floor 1e-3)."""
     meta = dict(n_channels=12, n_classes=1, param_seed=3)
     model, P = _load_model(meta)
-    xn, yn = O.synthetic_precip(2, 12, 288, 288, seed=1234)
-    loss_o, G, dx_o, acts = O.train_step_loss_and_grads(P, xn, yn)
+    xn, yn = O.synthetic_precip(1, 12, 288, 288, seed=1234)
+    loss_o, G32, dx32, acts = O.train_step_loss_and_grads(P, xn, yn)
+    P64 = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in P.items()}
+    _, G64, dx64, acts64 = O.train_step_loss_and_grads(P64, xn.astype(np.float64), yn.astype(np.float64))
     x = torch.from_numpy(xn).to(DEV).requires_grad_(True)
     logits = model(x)
     assert rel(logits.detach().cpu().numpy(), acts["logits"]) < 1e-4
-    loss = torch.nn.functional.mse_loss(logits.squeeze(1), torch.from_numpy(yn).to(DEV), reduction="sum") / 2
+    assert rel(logits.detach().cpu().numpy(), acts64["logits"]) < 1e-4
+    loss = torch.nn.functional.mse_loss(logits.squeeze(1), torch.from_numpy(yn).to(DEV), reduction="sum") / 1
     assert abs(loss.item() - float(loss_o)) < 1e-4 * abs(float(loss_o))
     loss.backward()
-    worst = ("", 0.0)
+    bad = []
     for k, p in model.named_parameters():
         if ".double_conv." in k and (k.endswith("depthwise.bias") or k.endswith("pointwise.bias")):
             continue
-        e = rel(p.grad.cpu().numpy(), G[k])
-        if e > worst[1]:
-            worst = (k, e)
-    assert worst[1] < 3e-2, worst
-    assert rel(x.grad.cpu().numpy(), dx_o) < 3e-2
+        ours = rel(p.grad.cpu().numpy(), G64[k])
+        ref = rel(G32[k], G64[k])
+        if ours > max(2.0 * ref, 1e-3):
+            bad.append((k, ours, ref))
+    assert not bad, bad[:8]
+    assert rel(x.grad.cpu().numpy(), dx64) < max(2.0 * rel(dx32, dx64), 1e-3)
+    flat_o = np.concatenate([G64[k].ravel() for k, _ in model.named_parameters()
+                             if not (".double_conv." in k and k.endswith(("depthwise.bias", "pointwise.bias")))])
+    flat_m = np.concatenate([p.grad.cpu().numpy().ravel() for k, p in model.named_parameters()
+                             if not (".double_conv." in k and k.endswith(("depthwise.bias", "pointwise.bias")))])
+    assert rel(flat_m, flat_o) < 1e-2
 
 
 def test_full_size_properties():
@@ -162,8 +173,8 @@ def test_full_size_properties():
     m = a.mean(dim=(0, 2, 3)).float()
     v = a.var(dim=(0, 2, 3), unbiased=False).float()
     zvar = z.double().var(dim=(0, 2, 3), unbiased=False).float()
-    assert (m - bn0.bias).abs().max().item() < 2e-5
-    assert rel((v / (bn0.weight ** 2 * zvar / (zvar + 1e-5))).cpu().numpy(), np.ones(64)) < 1e-4
+    assert (m - bn0.bias.detach()).abs().max().item() < 2e-5
+    assert rel((v / (bn0.weight.detach() ** 2 * zvar / (zvar + 1e-5))).cpu().numpy(), np.ones(64)) < 1e-4
     # (c) backward is linear in the cotangent: scaling the loss by 2 scales every gradient by exactly 2
     model.train()
     grads = []
