@@ -33,11 +33,13 @@ int smaat_abi_version(void);
  *   z        [N][Cout][H][W]
  *   part     nullable; [2][slots][Cout] per-tile sum / sum-of-squares of (z - b_pw) for the
  *            following train-mode BatchNorm; slots = smaat_pw_num_slots(N,H,W,Cout)
+ *   y_out    nullable; [N][Cin*kpl][H][W] depthwise output, written as a side product so that the
+ *            backward pass can form the pointwise weight gradient as one streamed GEMM
  */
 int smaat_pw_num_slots(int N, int H, int W, int M);
 int smaat_dsconv_fwd(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
                      const float* b_dw, const float* wt_pw, const float* b_pw, float* z, long z_bs, float* part,
-                     int N, int Cin, int kpl, int Cout, int H, int W, void* stream);
+                     float* y_out, int N, int Cin, int kpl, int Cout, int H, int W, void* stream);
 
 /* ---- plain pointwise conv  out[n][m][p] = sum_c wt[c][m] * x[n][c][p] + bias[m]
  *      reference: OutConv models/unet_parts.py:67-73; also the data gradient of the
@@ -47,11 +49,15 @@ int smaat_dsconv_fwd(const float* x, long x_bs, const float* in_scale, const flo
 int smaat_pointwise_fwd(const float* x, long x_bs, const float* wt, const float* bias, float* out, long out_bs,
                         float* part, int N, int Cin, int M, int H, int W, void* stream);
 
-/* ---- pointwise weight gradient  dW[m][k] = sum_{n,p} dz[n][m][p] * Y[n][k][p]
- *      dsconv variant recomputes Y = depthwise(x) on the fly (the expanded tensor never
- *      touches HBM).  ws: [smaat_wgrad_num_splits(...)][M][K] floats.  dw_out [M][K].
+/* ---- pointwise weight gradient  dW[m][k] = sum_{n,p} dz[n][m][p] * Y[n][k][p]   (dw_out [M][K])
+ *      (autograd of nn.Conv2d(K, M, 1), models/layers.py:45 / models/unet_parts.py:70)
+ *      smaat_pointwise_wgrad: Y given (the y_out of smaat_dsconv_fwd, or the OutConv input);
+ *                             ws: [smaat_wgrad_num_splits(...)][M][K] floats.
+ *      smaat_dsconv_wgrad:    memory-lean variant, Y = depthwise(x) recomputed in the kernel;
+ *                             ws: [smaat_dsconv_wgrad_num_splits(...)][Cout][Cin*kpl] floats.
  */
 int smaat_wgrad_num_splits(int N, int H, int W, int M, int K);
+int smaat_dsconv_wgrad_num_splits(int N, int H, int W, int Cout, int K);
 int smaat_dsconv_wgrad(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
                        const float* b_dw, const float* dz, long dz_bs, float* ws, float* dw_out, int N, int Cin,
                        int kpl, int Cout, int H, int W, void* stream);

@@ -23,9 +23,10 @@ _D = ctypes.c_double
 SIGNATURES = {
     "smaat_abi_version": [],
     "smaat_pw_num_slots": [_I, _I, _I, _I],
-    "smaat_dsconv_fwd": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P],
+    "smaat_dsconv_fwd": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "smaat_pointwise_fwd": [_P, _L, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P],
     "smaat_wgrad_num_splits": [_I, _I, _I, _I, _I],
+    "smaat_dsconv_wgrad_num_splits": [_I, _I, _I, _I, _I],
     "smaat_dsconv_wgrad": [_P, _L, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "smaat_pointwise_wgrad": [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _P],
     "smaat_dw3x3_bwd": [_P, _L, _P, _L, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -112,7 +113,7 @@ def check(rc, what):
 # optional per-entry-point timing (HIP events on the launch stream) used by bench.py
 # --------------------------------------------------------------------------------------
 def _w_dsconv_fwd(a):
-    n, cin, kpl, cout, h, w = a[11:17]
+    n, cin, kpl, cout, h, w = a[12:18]
     return 2.0 * n * cin * kpl * cout * h * w, 4.0 * n * (cin + cout) * h * w
 
 

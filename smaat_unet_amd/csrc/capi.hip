@@ -5,18 +5,24 @@
 // ---- launchers defined in the kernel files -------------------------------------------
 struct PwArgs {
     const float* x; long x_bs; const float* in_scale; const float* in_shift; const float* w_dw; const float* b_dw;
-    const float* wt; const float* bias; float* out; long out_bs; float* part;
-    int N, Cin, kpl, Kdim, M, nco; TileGeom g;
+    const float* wt; const float* bias; float* out; long out_bs; float* part; float* y_out;
+    int N, Cin, kpl, Kdim, M, nco, sstride; TileGeom g;
 };
 struct WgArgs {
     const float* x; long x_bs; const float* in_scale; const float* in_shift; const float* w_dw; const float* b_dw;
     const float* dz; long dz_bs; float* dwpart;
-    int N, Cin, kpl, Kdim, M, nco, nkt, nsplit, tiles_per_split; TileGeom g;
+    int N, Cin, kpl, Kdim, M, nco, nkt, nsplit, tiles_per_split, sstride; TileGeom g;
 };
+struct Wg2Args {
+    const float* dz; long dz_bs; const float* y; long y_bs; float* part;
+    int N, M, K, P, nmt, nkt, nsplit, chunks_per_split, nchunk_img, total_chunks;
+};
+int launch_wgrad2(Wg2Args& a, hipStream_t st);
+int smaat_dsconv_wgrad_num_splits_impl(int N, int H, int W, int M, int Kdim);
 int launch_pwgemm(PwArgs& a, bool dw, hipStream_t st);
 int launch_wgrad(WgArgs& a, bool dw, hipStream_t st);
 int smaat_pw_num_slots_impl(int N, int H, int W, int M);
-int smaat_wgrad_num_splits_impl(int N, int H, int W, int M, int Kdim);
+int smaat_wgrad_num_splits_impl(int N, int P, int M, int K);
 
 int launch_bn_finalize(const float*, int, int, double, const float*, const float*, const float*, float, float, float*,
                        float*, float*, float*, float*, float*, hipStream_t);
@@ -74,11 +80,11 @@ int smaat_pw_num_slots(int N, int H, int W, int M) { return smaat_pw_num_slots_i
 
 int smaat_dsconv_fwd(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
                      const float* b_dw, const float* wt_pw, const float* b_pw, float* z, long z_bs, float* part,
-                     int N, int Cin, int kpl, int Cout, int H, int W, void* stream) {
+                     float* y_out, int N, int Cin, int kpl, int Cout, int H, int W, void* stream) {
     if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return -1;
     PwArgs a{};
     a.x = x; a.x_bs = x_bs; a.in_scale = in_scale; a.in_shift = in_shift; a.w_dw = w_dw; a.b_dw = b_dw;
-    a.wt = wt_pw; a.bias = b_pw; a.out = z; a.out_bs = z_bs; a.part = part;
+    a.wt = wt_pw; a.bias = b_pw; a.out = z; a.out_bs = z_bs; a.part = part; a.y_out = y_out;
     a.N = N; a.Cin = Cin; a.kpl = kpl; a.Kdim = Cin * kpl; a.M = Cout; a.g.H = H; a.g.W = W;
     return launch_pwgemm(a, true, ST);
 }
@@ -92,7 +98,10 @@ int smaat_pointwise_fwd(const float* x, long x_bs, const float* wt, const float*
     return launch_pwgemm(a, false, ST);
 }
 
-int smaat_wgrad_num_splits(int N, int H, int W, int M, int K) { return smaat_wgrad_num_splits_impl(N, H, W, M, K); }
+int smaat_wgrad_num_splits(int N, int H, int W, int M, int K) { return smaat_wgrad_num_splits_impl(N, H * W, M, K); }
+int smaat_dsconv_wgrad_num_splits(int N, int H, int W, int Cout, int K) {
+    return smaat_dsconv_wgrad_num_splits_impl(N, H, W, Cout, K);
+}
 
 int smaat_dsconv_wgrad(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
                        const float* b_dw, const float* dz, long dz_bs, float* ws, float* dw_out, int N, int Cin,
@@ -109,11 +118,12 @@ int smaat_dsconv_wgrad(const float* x, long x_bs, const float* in_scale, const f
 int smaat_pointwise_wgrad(const float* x, long x_bs, const float* dz, long dz_bs, float* ws, float* dw_out, int N,
                           int Cin, int M, int H, int W, void* stream) {
     if (N < 1 || Cin < 1 || M < 1 || H < 1 || W < 1) return -1;
-    WgArgs a{};
-    a.x = x; a.x_bs = x_bs; a.dz = dz; a.dz_bs = dz_bs; a.dwpart = ws;
-    a.N = N; a.Cin = Cin; a.kpl = 1; a.Kdim = Cin; a.M = M; a.g.H = H; a.g.W = W;
-    CHK(launch_wgrad(a, false, ST));
-    return launch_reduce_rows(ws, a.nsplit, (long)M * a.Kdim, dw_out, 1.f, ST);
+    Wg2Args a{};
+    a.dz = dz; a.dz_bs = dz_bs; a.y = x; a.y_bs = x_bs; a.part = ws;
+    a.N = N; a.M = M; a.K = Cin; a.P = H * W;
+    hipStream_t st = ST;
+    CHK(launch_wgrad2(a, st));
+    return launch_reduce_rows(ws, a.nsplit, (long)M * Cin, dw_out, 1.f, st);
 }
 
 int smaat_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, const float* w_dw, float* dx, long dx_bs,

@@ -31,23 +31,35 @@ struct PwArgs {
     const float* bias;  // [M] or null
     float* out;
     long out_bs;
-    float* part;  // [2][T][M] or null
-    int N, Cin, kpl, Kdim, M, nco;
+    float* part;   // [2][T][M] or null
+    float* y_out;  // [N][Kdim][P] or null: depthwise output side product (kept for the weight gradient)
+    int N, Cin, kpl, Kdim, M, nco, sstride;
     TileGeom g;
 };
 
-template <int WCO, int CT, int WPX, int PXT, bool DW, bool AFF>
+// MODE 0: B operand rows are loaded straight from global (plain pointwise conv / dgrad)
+// MODE 1,2,4: B operand rows are produced by the depthwise 3x3 stage, kpl = MODE
+//
+// Software pipeline per 16-row chunk (T14 "issue early / write late"): the global loads of
+// chunk c+1 (input halo tile or B rows, and the weight slab) are issued into registers
+// right before the MFMA block of chunk c and written to LDS after it.
+template <int WCO, int CT, int WPX, int PXT, int MODE>
 __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
+    constexpr bool DW = MODE > 0;
+    constexpr int KPL = DW ? MODE : 1;
+    constexpr int KCI = KC / KPL;  // input channels per chunk (DW)
     constexpr int COT = WCO * CT * 32;
     constexpr int PT = WPX * PXT * 32;
-    constexpr int G = SMAAT_THREADS / PT;  // channel sub-groups in the depthwise stage
+    constexpr int G = SMAAT_THREADS / PT;  // channel sub-groups
+    constexpr int NW = KC * COT / SMAAT_THREADS;
+    constexpr int NY = KC / G;
     extern __shared__ float smem[];
     float* Yl = smem;                   // [KC][PT]
     float* Wl = Yl + KC * PT;           // [KC][COT]
     float* stat = Wl + KC * COT;        // [WPX][2][COT]
     int* pixoff = (int*)(stat + WPX * 2 * COT);  // [PT]
     int* sidx = pixoff + PT;            // [PT]
-    float* S = (float*)(sidx + PT);     // [kci][SMAX]
+    float* S = (float*)(sidx + PT);     // [KCI][sstride]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wco = wave % WCO, wpx = wave / WCO;
@@ -62,6 +74,7 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
     const int n = ptg / g.tiles_per_img, tl = ptg - n * g.tiles_per_img;
     const int co0 = cot * COT;
     const StageRegion rg = stage_region(g, tl);
+    const int sstride = a.sstride;
 
     for (int i = tid; i < PT; i += SMAAT_THREADS) {
         int r, c;
@@ -69,8 +82,7 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
         pixoff[i] = v ? r * g.W + c : -1;
         sidx[i] = v ? (r - rg.row_lo) * rg.SW + (c - rg.col_lo) : (rg.SW + 1);
     }
-    // staging slots of this thread (same for every channel)
-    int goff[3];
+    int goff[3] = {-2, -2, -2};
     if (DW) {
         const int rsize = rg.nrows * rg.SW;
 #pragma unroll
@@ -80,8 +92,6 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
                 const int sr = e / rg.SW, sc = e - sr * rg.SW;
                 const int gr = rg.row_lo + sr, gc = rg.col_lo + sc;
                 goff[j] = (gr >= 0 && gr < g.H && gc >= 0 && gc < g.W) ? gr * g.W + gc : -1;
-            } else {
-                goff[j] = -2;
             }
         }
     }
@@ -94,47 +104,83 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
 
-    const int kci = KC / a.kpl;
     const int nchunks = (a.Kdim + KC - 1) / KC;
     const int pi = tid % PT;
     const int g0 = __builtin_amdgcn_readfirstlane(tid / PT);
     __syncthreads();
+    const int po = pixoff[pi];
+    const bool aff = DW && (a.in_scale != nullptr);
+    const float* xn = a.x + (long)n * a.x_bs;
 
-    for (int ch = 0; ch < nchunks; ++ch) {
+    float sreg[DW ? KCI : 1][3];
+    float yreg[DW ? 1 : NY];
+    float wreg[NW];
+
+    auto prefetch = [&](int ch) {
         const int k0 = ch * KC;
         if (DW) {
-            const int ci0 = k0 / a.kpl;
-            for (int cl = 0; cl < kci; ++cl) {
+            const int ci0 = k0 / KPL;
+#pragma unroll
+            for (int cl = 0; cl < KCI; ++cl) {
                 const int ci = ci0 + cl;
                 const bool cv = ci < a.Cin;
-                const float* plane = a.x + (long)n * a.x_bs + (long)ci * g.P;
+                const float* plane = xn + (long)ci * g.P;
                 float sc_ = 1.f, sh_ = 0.f;
-                if (AFF && cv) {
+                if (aff && cv) {
                     sc_ = a.in_scale[ci];
                     sh_ = a.in_shift[ci];
                 }
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    if (goff[j] != -2) {
-                        float v = 0.f;
-                        if (cv && goff[j] >= 0) {
-                            v = plane[goff[j]];
-                            if (AFF) v = fmaxf(fmaf(v, sc_, sh_), 0.f);
-                        }
-                        S[cl * SMAX + tid + SMAAT_THREADS * j] = v;
+                    float v = 0.f;
+                    if (cv && goff[j] >= 0) {
+                        v = plane[goff[j]];
+                        if (aff) v = fmaxf(fmaf(v, sc_, sh_), 0.f);
                     }
+                    sreg[cl][j] = v;
                 }
             }
-            __syncthreads();  // also orders the previous chunk's MFMA reads before Yl/Wl are rewritten
+        } else {
+#pragma unroll
+            for (int r = 0; r < NY; ++r) {
+                const int kg = k0 + g0 + r * G;
+                float v = 0.f;
+                if (kg < a.Kdim && po >= 0) v = xn[(long)kg * g.P + po];
+                yreg[r] = v;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NW; ++r) {
+            const int e = tid + SMAAT_THREADS * r;
+            const int k = e / COT, co = e - k * COT;
+            const int kg = k0 + k, m = co0 + co;
+            wreg[r] = (kg < a.Kdim && m < a.M) ? a.wt[(long)kg * a.M + m] : 0.f;
+        }
+    };
+
+    prefetch(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int k0 = ch * KC;
+        if (DW) {
+            // S is free: its readers (the depthwise stage of chunk ch-1) finished before that chunk's 2nd barrier
+#pragma unroll
+            for (int cl = 0; cl < KCI; ++cl)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (goff[j] != -2) S[cl * sstride + tid + SMAAT_THREADS * j] = sreg[cl][j];
+        }
+        __syncthreads();  // B1: S visible; every wave is past the MFMA block of chunk ch-1
+        if (DW) {
             const int sb = sidx[pi];
             const int SW = rg.SW;
-            for (int cl = g0; cl < kci; cl += G) {
-                const float* sp = S + cl * SMAX + sb;
+            for (int cl = g0; cl < KCI; cl += G) {
+                const float* sp = S + cl * sstride + sb;
                 const float s00 = sp[-SW - 1], s01 = sp[-SW], s02 = sp[-SW + 1];
                 const float s10 = sp[-1], s11 = sp[0], s12 = sp[1];
                 const float s20 = sp[SW - 1], s21 = sp[SW], s22 = sp[SW + 1];
-                for (int j = 0; j < a.kpl; ++j) {
-                    const int k = cl * a.kpl + j, kg = k0 + k;
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+                    const int k = cl * KPL + j, kg = k0 + k;
                     float y = 0.f;
                     if (kg < a.Kdim) {
                         const float* w = a.w_dw + kg * 9;
@@ -148,26 +194,20 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
                         y = fmaf(w[6], s20, y);
                         y = fmaf(w[7], s21, y);
                         y = fmaf(w[8], s22, y);
+                        if (a.y_out && cot == 0 && po >= 0)
+                            a.y_out[((long)n * a.Kdim + kg) * g.P + po] = y;
                     }
                     Yl[k * PT + pi] = y;
                 }
             }
         } else {
-            if (ch > 0) __syncthreads();  // previous chunk's MFMA reads are done
-            const int po = pixoff[pi];
-            for (int k = g0; k < KC; k += G) {
-                const int kg = k0 + k;
-                float v = 0.f;
-                if (kg < a.Kdim && po >= 0) v = a.x[(long)n * a.x_bs + (long)kg * g.P + po];
-                Yl[k * PT + pi] = v;
-            }
+#pragma unroll
+            for (int r = 0; r < NY; ++r) Yl[(g0 + r * G) * PT + pi] = yreg[r];
         }
-        for (int e = tid; e < KC * COT; e += SMAAT_THREADS) {
-            const int k = e / COT, co = e - k * COT;
-            const int kg = k0 + k, m = co0 + co;
-            Wl[e] = (kg < a.Kdim && m < a.M) ? a.wt[(long)kg * a.M + m] : 0.f;
-        }
-        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NW; ++r) Wl[tid + SMAAT_THREADS * r] = wreg[r];
+        __syncthreads();  // B2
+        if (ch + 1 < nchunks) prefetch(ch + 1);  // in flight during the MFMA block
 #pragma unroll
         for (int kk = 0; kk < KC / 2; ++kk) {
             const int krow = 2 * kk + half;
@@ -238,7 +278,131 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
 }
 
 // =====================================================================================
-// weight gradient
+// streamed weight gradient  dW[m][k] = sum_{n,p} dz[n][m][p] * y[n][k][p]
+//   output-stationary 64*CT x 128 tile per workgroup, contraction over 64-pixel chunks,
+//   both operands staged row-major with an odd LDS stride (conflict-free column reads),
+//   next chunk prefetched into registers during the MFMA block.
+// =====================================================================================
+struct Wg2Args {
+    const float* dz;
+    long dz_bs;
+    const float* y;
+    long y_bs;
+    float* part;  // [nsplit][M][K]
+    int N, M, K, P, nmt, nkt, nsplit, chunks_per_split, nchunk_img, total_chunks;
+};
+
+template <int CT>
+__global__ __launch_bounds__(SMAAT_THREADS, 2) void k_wgrad2(const Wg2Args a) {
+    constexpr int MT = 64 * CT, KT = 128, PS = 64, LS = PS + 1;
+    constexpr int NPF = (MT + KT) / 16;
+    extern __shared__ float smem[];
+    float* Zs = smem;            // [MT][LS]
+    float* Ys = Zs + MT * LS;    // [KT][LS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wk = wave >> 1;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int r16 = tid >> 4, px4 = (tid & 15) * 4;
+
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int ntile = a.nmt * a.nkt;
+    const int rest = idx % ntile;
+    const int split = (idx / ntile) * 8 + xcd;
+    if (split >= a.nsplit) return;
+    const int mt = rest % a.nmt, kt = rest / a.nmt;
+    const int m0 = mt * MT, k0 = kt * KT;
+    const bool vec = ((a.P & 3) == 0) && ((a.dz_bs & 3) == 0) && ((a.y_bs & 3) == 0) &&
+                     ((((uintptr_t)a.dz) & 15) == 0) && ((((uintptr_t)a.y) & 15) == 0);
+
+    f32x16 acc[CT][2];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int kw = 0; kw < 2; ++kw)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][kw][r] = 0.f;
+
+    float4 pf[NPF];
+    auto prefetch = [&](int c) {
+        const int n = c / a.nchunk_img;
+        const int p0 = (c - n * a.nchunk_img) * PS + px4;
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            const int row = r16 + 16 * j;
+            const float* src;
+            bool rv;
+            if (row < MT) {
+                rv = (m0 + row) < a.M;
+                src = a.dz + (long)n * a.dz_bs + (long)(m0 + row) * a.P + p0;
+            } else {
+                rv = (k0 + row - MT) < a.K;
+                src = a.y + (long)n * a.y_bs + (long)(k0 + row - MT) * a.P + p0;
+            }
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rv) {
+                if (vec && p0 + 3 < a.P) {
+                    v = *(const float4*)src;
+                } else {
+                    if (p0 + 0 < a.P) v.x = src[0];
+                    if (p0 + 1 < a.P) v.y = src[1];
+                    if (p0 + 2 < a.P) v.z = src[2];
+                    if (p0 + 3 < a.P) v.w = src[3];
+                }
+            }
+            pf[j] = v;
+        }
+    };
+
+    int c_end = (split + 1) * a.chunks_per_split;
+    if (c_end > a.total_chunks) c_end = a.total_chunks;
+    const int c_begin = split * a.chunks_per_split;
+    if (c_begin < c_end) prefetch(c_begin);
+    for (int c = c_begin; c < c_end; ++c) {
+        __syncthreads();  // previous MFMA block done with Zs / Ys
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            const int row = r16 + 16 * j;
+            float* dst = (row < MT ? Zs + row * LS : Ys + (row - MT) * LS) + px4;
+            dst[0] = pf[j].x;
+            dst[1] = pf[j].y;
+            dst[2] = pf[j].z;
+            dst[3] = pf[j].w;
+        }
+        __syncthreads();
+        if (c + 1 < c_end) prefetch(c + 1);
+#pragma unroll 8
+        for (int s = 0; s < PS / 2; ++s) {
+            const int px = 2 * s + half;
+            float av[CT], bv[2];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) av[ct] = Zs[((wm * CT + ct) * 32 + l31) * LS + px];
+#pragma unroll
+            for (int kw = 0; kw < 2; ++kw) bv[kw] = Ys[((wk * 2 + kw) * 32 + l31) * LS + px];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int kw = 0; kw < 2; ++kw)
+                    acc[ct][kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ct], bv[kw], acc[ct][kw], 0, 0, 0);
+        }
+    }
+    float* ob = a.part + (long)split * a.M * a.K;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (wm * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m < a.M) {
+#pragma unroll
+                for (int kw = 0; kw < 2; ++kw) {
+                    const int kg = k0 + (wk * 2 + kw) * 32 + l31;
+                    if (kg < a.K) ob[(long)m * a.K + kg] = acc[ct][kw][r];
+                }
+            }
+        }
+}
+
+// =====================================================================================
+// weight gradient with the depthwise stage recomputed in the kernel (memory-lean variant)
 // =====================================================================================
 struct WgArgs {
     const float* x;
@@ -459,51 +623,104 @@ static void choose_geom(int N, int H, int W, int PT, int smax, TileGeom* g) {
     g->T = N * g->tiles_per_img;
 }
 
-template <int WCO, int CT, int WPX, int PXT>
-static int launch_pwgemm_cfg(PwArgs& a, bool dw, bool aff, hipStream_t st) {
+// cached per-kernel dynamic-LDS opt-in (hipFuncSetAttribute is not free)
+template <auto KERN>
+static int ensure_lds(size_t lds) {
+    static size_t granted = 0;  // one per kernel instantiation
+    if (lds > granted) {
+        HIP_RET(hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        granted = lds;
+    }
+    return 0;
+}
+
+template <int WCO, int CT, int WPX, int PXT, int MODE>
+static int launch_pwgemm_mode(PwArgs& a, hipStream_t st) {
     constexpr int COT = WCO * CT * 32, PT = WPX * PXT * 32;
+    constexpr bool DW = MODE > 0;
     choose_geom(a.N, a.g.H, a.g.W, PT, SMAX, &a.g);
+    if (a.g.mode < 0) return -1;
     a.nco = ceil_div(a.M, COT);
-    const int kci = KC / a.kpl;
-    size_t lds = sizeof(float) * (size_t)(KC * PT + KC * COT + WPX * 2 * COT + 2 * PT + (dw ? kci * SMAX : 0));
+    // staged floats per input channel: the exact region size, padded to a multiple of 32
+    int sstride = 0;
+    if (DW) {
+        const int rs = (a.g.mode == 0) ? ((PT + a.g.W - 2) / a.g.W + 2) * (a.g.W + 2) : (a.g.TH + 2) * (a.g.TW + 2);
+        sstride = (rs + 31) & ~31;
+    }
+    a.sstride = sstride;
+    const int kci = KC / (DW ? MODE : 1);
+    const size_t lds = sizeof(float) * (size_t)(KC * PT + KC * COT + WPX * 2 * COT + 2 * PT + (DW ? kci * sstride : 0));
     const int grid = ceil_div(a.g.T, 8) * 8 * a.nco;
-#define LAUNCH(DWF, AFFF)                                                                                 \
-    do {                                                                                                  \
-        auto kern = k_pwgemm<WCO, CT, WPX, PXT, DWF, AFFF>;                                                  \
-        HIP_RET(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(SMAAT_THREADS), lds, st, a);                             \
-    } while (0)
-    if (dw && aff)
-        LAUNCH(true, true);
-    else if (dw)
-        LAUNCH(true, false);
-    else
-        LAUNCH(false, false);
-#undef LAUNCH
+    constexpr auto kern = k_pwgemm<WCO, CT, WPX, PXT, MODE>;
+    int rc = ensure_lds<kern>(lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SMAAT_THREADS), lds, st, a);
     return (int)hipGetLastError();
 }
+
+template <int WCO, int CT, int WPX, int PXT>
+static int launch_pwgemm_cfg(PwArgs& a, bool dw, hipStream_t st) {
+    if (!dw) return launch_pwgemm_mode<WCO, CT, WPX, PXT, 0>(a, st);
+    switch (a.kpl) {
+        case 1: return launch_pwgemm_mode<WCO, CT, WPX, PXT, 1>(a, st);
+        case 2: return launch_pwgemm_mode<WCO, CT, WPX, PXT, 2>(a, st);
+        case 4: return launch_pwgemm_mode<WCO, CT, WPX, PXT, 4>(a, st);
+    }
+    return -1;
+}
+
+static bool pw_big(int N, int H, int W) { return (long)N * H * W >= 256L * 1024; }
 
 int smaat_pw_num_slots_impl(int N, int H, int W, int M) {
     // must mirror the tile choice of launch_pwgemm()
     TileGeom g;
-    g.H = H;
-    g.W = W;
-    const int PT = ((long)N * H * W >= 256L * 1024) ? 256 : 128;
-    choose_geom(N, H, W, PT, SMAX, &g);
+    choose_geom(N, H, W, pw_big(N, H, W) ? 256 : 128, SMAX, &g);
     (void)M;
     return g.T;
 }
 
 int launch_pwgemm(PwArgs& a, bool dw, hipStream_t st) {
     if (a.kpl != 1 && a.kpl != 2 && a.kpl != 4) return -1;
-    const bool aff = dw && a.in_scale != nullptr;
-    const bool big = ((long)a.N * a.g.H * a.g.W >= 256L * 1024);
+    const bool big = pw_big(a.N, a.g.H, a.g.W);
     if (a.M > 64) {
-        if (big) return launch_pwgemm_cfg<2, 2, 2, 4>(a, dw, aff, st);  // 128 x 256
-        return launch_pwgemm_cfg<2, 2, 2, 2>(a, dw, aff, st);           // 128 x 128
+        if (big) return launch_pwgemm_cfg<2, 2, 2, 4>(a, dw, st);  // 128 x 256
+        return launch_pwgemm_cfg<2, 2, 2, 2>(a, dw, st);           // 128 x 128
     }
-    if (big) return launch_pwgemm_cfg<1, 2, 4, 2>(a, dw, aff, st);  // 64 x 256
-    return launch_pwgemm_cfg<1, 2, 4, 1>(a, dw, aff, st);           // 64 x 128
+    if (big) return launch_pwgemm_cfg<1, 2, 4, 2>(a, dw, st);  // 64 x 256
+    return launch_pwgemm_cfg<1, 2, 4, 1>(a, dw, st);           // 64 x 128
+}
+
+// ---- streamed weight gradient ------------------------------------------------------------
+int smaat_wgrad_num_splits_impl(int N, int P, int M, int K) {
+    const int total = N * ceil_div(P, 64);
+    const int mt = (M > 64) ? 128 : 64;
+    const int ntile = ceil_div(M, mt) * ceil_div(K, 128);
+    int ns = ceil_div(2048, ntile);
+    if (ns > total) ns = total;
+    if (ns < 1) ns = 1;
+    return ns;
+}
+
+int launch_wgrad2(Wg2Args& a, hipStream_t st) {
+    a.nchunk_img = ceil_div(a.P, 64);
+    a.total_chunks = a.N * a.nchunk_img;
+    a.nsplit = smaat_wgrad_num_splits_impl(a.N, a.P, a.M, a.K);
+    a.chunks_per_split = ceil_div(a.total_chunks, a.nsplit);
+    a.nkt = ceil_div(a.K, 128);
+    if (a.M > 64) {
+        a.nmt = ceil_div(a.M, 128);
+        const size_t lds = sizeof(float) * (size_t)((128 + 128) * 65);
+        int rc = ensure_lds<k_wgrad2<2>>(lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_wgrad2<2>, dim3(ceil_div(a.nsplit, 8) * 8 * a.nmt * a.nkt), dim3(SMAAT_THREADS), lds, st, a);
+    } else {
+        a.nmt = 1;
+        const size_t lds = sizeof(float) * (size_t)((64 + 128) * 65);
+        int rc = ensure_lds<k_wgrad2<1>>(lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_wgrad2<1>, dim3(ceil_div(a.nsplit, 8) * 8 * a.nkt), dim3(SMAAT_THREADS), lds, st, a);
+    }
+    return (int)hipGetLastError();
 }
 
 static int wgrad_smax(int M, int kpl, bool dw) {
@@ -531,18 +748,17 @@ static int launch_wgrad_cfg(WgArgs& a, bool dw, bool aff, hipStream_t st) {
         HIP_RET(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(SMAAT_THREADS), lds, st, a);                             \
     } while (0)
-    if (dw && aff)
+    if (aff)
         LAUNCH(true, true);
-    else if (dw)
-        LAUNCH(true, false);
     else
-        LAUNCH(false, false);
+        LAUNCH(true, false);
 #undef LAUNCH
+    (void)dw;
     return (int)hipGetLastError();
 }
 
 // number of pixel splits used by the weight-gradient kernel (size of the partial buffer)
-int smaat_wgrad_num_splits_impl(int N, int H, int W, int M, int Kdim) {
+int smaat_dsconv_wgrad_num_splits_impl(int N, int H, int W, int M, int Kdim) {
     // independent of the tile mode: bounded by the minimal tile count N*ceil(P/PSW)
     const int tmin = N * ceil_div(H * W, PSW);
     const int cot = (M > 64) ? 128 : 64;
@@ -556,11 +772,12 @@ int smaat_wgrad_num_splits_impl(int N, int H, int W, int M, int Kdim) {
 int launch_wgrad(WgArgs& a, bool dw, hipStream_t st) {
     if (a.kpl != 1 && a.kpl != 2 && a.kpl != 4) return -1;
     const bool aff = dw && a.in_scale != nullptr;
+    if (!dw) return -1;
     const int smax = wgrad_smax(a.M, a.kpl, dw);
     choose_geom(a.N, a.g.H, a.g.W, PSW, smax, &a.g);
     if (a.g.mode < 0) return -1;
     a.sstride = smax;
-    a.nsplit = smaat_wgrad_num_splits_impl(a.N, a.g.H, a.g.W, a.M, a.Kdim);
+    a.nsplit = smaat_dsconv_wgrad_num_splits_impl(a.N, a.g.H, a.g.W, a.M, a.Kdim);
     a.tiles_per_split = ceil_div(a.g.T, a.nsplit);
     if (a.M > 64) return launch_wgrad_cfg<2, 2, 2, 1>(a, dw, aff, st);  // 128 x 64
     return launch_wgrad_cfg<2, 1, 2, 1>(a, dw, aff, st);                // 64 x 64

@@ -61,7 +61,7 @@ def _new(ref, *shape, dtype=torch.float32):
 # --------------------------------------------------------------------------------------
 # raw kernel wrappers (thin; shapes derived from tensors)
 # --------------------------------------------------------------------------------------
-def _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, in_shift=None):
+def _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, in_shift=None, want_y=False):
     L = _lib.get()
     x, x_bs = _planes(x)
     n, cin, h, w = x.shape
@@ -74,9 +74,12 @@ def _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, i
     if want_stats:
         slots = L.smaat_pw_num_slots(n, h, w, cout)
         part = _new(x, 2, slots, cout)
+    y = _new(x, n, k, h, w) if want_y else None
     _lib.check(L.smaat_dsconv_fwd(_ptr(x), x_bs, _ptr(in_scale), _ptr(in_shift), _ptr(w_dw), _ptr(b_dw), _ptr(wt),
-                                  _ptr(b_pw), _ptr(z), cout * h * w, _ptr(part), n, cin, kpl, cout, h, w,
+                                  _ptr(b_pw), _ptr(z), cout * h * w, _ptr(part), _ptr(y), n, cin, kpl, cout, h, w,
                                   _stream(x)), "smaat_dsconv_fwd")
+    if want_y:
+        return z, part, slots, y
     return z, part, slots
 
 
@@ -149,8 +152,24 @@ def _channel_sum_raw(x):
     return out
 
 
-def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, in_scale=None, in_shift=None):
-    """gradients of z = pointwise(depthwise(x)) given dz: dx, dw_dw, db_dw, dw_pw."""
+def _pointwise_wgrad_raw(y, dz, m):
+    """dW[m][k] = sum_{n,p} dz[n][m][p] * y[n][k][p]  -> tensor [m][k][1][1]"""
+    L = _lib.get()
+    y, y_bs = _planes(y)
+    dz, dz_bs = _planes(dz)
+    n, k, h, w = y.shape
+    ns = L.smaat_wgrad_num_splits(n, h, w, m, k)
+    ws = _new(y, ns, m, k)
+    dw = _new(y, m, k, 1, 1)
+    _lib.check(L.smaat_pointwise_wgrad(_ptr(y), y_bs, _ptr(dz), dz_bs, _ptr(ws), _ptr(dw), n, k, m, h, w,
+                                       _stream(y)), "smaat_pointwise_wgrad")
+    return dw
+
+
+def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None):
+    """gradients of z = pointwise(depthwise(x)) given dz: dx, dw_dw, db_dw, dw_pw.
+    y: the depthwise output kept by the forward (streamed weight gradient); when None the
+    memory-lean kernel recomputes it from x."""
     L = _lib.get()
     x, x_bs = _planes(x)
     dz, dz_bs = _planes(dz)
@@ -158,13 +177,15 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, in_scale=None, in_shi
     cout = w_pw.shape[0]
     k = cin * kpl
     s = _stream(x)
-    # pointwise weight gradient, Y recomputed on the fly
-    ns = L.smaat_wgrad_num_splits(n, h, w, cout, k)
-    ws = _new(x, ns, cout, k)
-    dw_pw = _new(x, cout, k, 1, 1)
-    _lib.check(L.smaat_dsconv_wgrad(_ptr(x), x_bs, _ptr(in_scale), _ptr(in_shift), _ptr(w_dw), _ptr(b_dw), _ptr(dz),
-                                    dz_bs, _ptr(ws), _ptr(dw_pw), n, cin, kpl, cout, h, w, s), "smaat_dsconv_wgrad")
-    del ws
+    if y is not None:
+        dw_pw = _pointwise_wgrad_raw(y, dz, cout)
+    else:
+        ns = L.smaat_dsconv_wgrad_num_splits(n, h, w, cout, k)
+        ws = _new(x, ns, cout, k)
+        dw_pw = _new(x, cout, k, 1, 1)
+        _lib.check(L.smaat_dsconv_wgrad(_ptr(x), x_bs, None, None, _ptr(w_dw), _ptr(b_dw), _ptr(dz), dz_bs, _ptr(ws),
+                                        _ptr(dw_pw), n, cin, kpl, cout, h, w, s), "smaat_dsconv_wgrad")
+        del ws
     # data gradient of the pointwise conv: dY = W^T dZ  (wt := w_pw in its natural [Cout][K] layout)
     dy = _new(x, n, k, h, w)
     _lib.check(L.smaat_pointwise_fwd(_ptr(dz), dz_bs, _ptr(w_pw), None, _ptr(dy), k * h * w, None, n, cout, k, h, w,
@@ -179,6 +200,11 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, in_scale=None, in_shi
     return dx, dw_dw, db_dw, dw_pw
 
 
+# keep the depthwise output of the forward for the backward (streamed weight gradient).  Set to
+# False to trade speed for memory: the backward then recomputes it inside the wgrad kernel.
+KEEP_DEPTHWISE_OUTPUT = True
+
+
 # --------------------------------------------------------------------------------------
 # DepthwiseSeparableConv (+ BatchNorm2d + ReLU)
 # --------------------------------------------------------------------------------------
@@ -191,20 +217,27 @@ class _DSConvBNReLU(torch.autograd.Function):
         n, cin, h, w = x.shape
         cout = w_pw.shape[0]
         use_batch_stats = training or rm is None
+        keep_y = KEEP_DEPTHWISE_OUTPUT and torch.is_grad_enabled() and any(
+            t is not None and t.requires_grad for t in (x, w_dw, w_pw))
+        y_dw = None
         if use_batch_stats:
-            z, part, slots = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, True)
+            r = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, True, want_y=keep_y)
+            z, part, slots = r[:3]
+            y_dw = r[3] if keep_y else None
             st = _bn_finalize_raw(part, slots, cout, n * h * w, b_pw, gamma, beta, eps,
                                   momentum if momentum is not None else 0.0, rm if training else None,
                                   rv if training else None)
         else:
-            z, _, _ = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, False)
+            r = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, False, want_y=keep_y)
+            z = r[0]
+            y_dw = r[3] if keep_y else None
             invstd = torch.rsqrt(rv + eps)
             g = gamma if gamma is not None else torch.ones_like(rm)
             b = beta if beta is not None else torch.zeros_like(rm)
             scale = g * invstd
             st = torch.stack([rm, invstd, scale, b - rm * scale]).contiguous()
         y = _affine_act_raw(z, st[2], st[3], True)
-        ctx.save_for_backward(x, w_dw, b_dw, w_pw, gamma, z, st)
+        ctx.save_for_backward(x, w_dw, b_dw, w_pw, gamma, z, st, y_dw)
         ctx.kpl = kpl
         ctx.train_stats = use_batch_stats
         ctx.has_bias = (b_dw is not None, b_pw is not None)
@@ -212,10 +245,10 @@ class _DSConvBNReLU(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, w_dw, b_dw, w_pw, gamma, z, st = ctx.saved_tensors
+        x, w_dw, b_dw, w_pw, gamma, z, st, y_dw = ctx.saved_tensors
         dz, dgamma, dbeta = _bn_bwd_raw(dy, z, st, gamma, True, ctx.train_stats)
         need_dx = ctx.needs_input_grad[0]
-        dx, dw_dw, db_dw, dw_pw = _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, ctx.kpl, need_dx)
+        dx, dw_dw, db_dw, dw_pw = _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, ctx.kpl, need_dx, y=y_dw)
         if ctx.train_stats:
             # a bias in front of a train-mode BatchNorm has an exactly-zero gradient
             db_pw = torch.zeros_like(dgamma) if ctx.has_bias[1] else None
@@ -239,16 +272,19 @@ class _DSConv(torch.autograd.Function):
         _check(x, w_dw, b_dw, w_pw, b_pw)
         w_dw = w_dw.contiguous()
         w_pw = w_pw.contiguous()
-        z, _, _ = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, False)
-        ctx.save_for_backward(x, w_dw, b_dw, w_pw)
+        keep_y = KEEP_DEPTHWISE_OUTPUT and torch.is_grad_enabled() and any(
+            t is not None and t.requires_grad for t in (x, w_dw, w_pw))
+        r = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, False, want_y=keep_y)
+        z = r[0]
+        ctx.save_for_backward(x, w_dw, b_dw, w_pw, r[3] if keep_y else None)
         ctx.kpl = kpl
         ctx.has_bias = (b_dw is not None, b_pw is not None)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        x, w_dw, b_dw, w_pw = ctx.saved_tensors
-        dx, dw_dw, db_dw, dw_pw = _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, ctx.kpl, ctx.needs_input_grad[0])
+        x, w_dw, b_dw, w_pw, y_dw = ctx.saved_tensors
+        dx, dw_dw, db_dw, dw_pw = _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, ctx.kpl, ctx.needs_input_grad[0], y=y_dw)
         db_pw = _channel_sum_raw(dz) if ctx.has_bias[1] else None
         if not ctx.has_bias[0]:
             db_dw = None
@@ -276,20 +312,12 @@ class _Pointwise(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz):
-        L = _lib.get()
         x, w = ctx.saved_tensors
         m, c = w.shape[0], w.shape[1]
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _pointwise_raw(dz, w.reshape(m, c), None, c)  # wt[c'=m][m'=c] = w natural
-        x_, x_bs = _planes(x)
-        dz_, dz_bs = _planes(dz)
-        n, _, h, wd = x_.shape
-        ns = L.smaat_wgrad_num_splits(n, h, wd, m, c)
-        ws = _new(x_, ns, m, c)
-        dw = _new(x_, m, c, 1, 1)
-        _lib.check(L.smaat_pointwise_wgrad(_ptr(x_), x_bs, _ptr(dz_), dz_bs, _ptr(ws), _ptr(dw), n, c, m, h, wd,
-                                           _stream(x_)), "smaat_pointwise_wgrad")
+        dw = _pointwise_wgrad_raw(x, dz, m)
         db = _channel_sum_raw(dz) if ctx.has_bias else None
         return dx, dw, db
 

@@ -71,8 +71,11 @@ class EmuLib:
         pp[0, T - 1] = a64.sum(axis=(0, 2))
         pp[1, T - 1] = (a64 * a64).sum(axis=(0, 2))
 
-    def smaat_dsconv_fwd(self, x, x_bs, in_scale, in_shift, w_dw, b_dw, wt_pw, b_pw, z, z_bs, part, N, Cin, kpl, Cout,
-                         H, W, stream):
+    def smaat_dsconv_wgrad_num_splits(self, N, H, W, M, K):
+        return WG_SPLITS + 1
+
+    def smaat_dsconv_fwd(self, x, x_bs, in_scale, in_shift, w_dw, b_dw, wt_pw, b_pw, z, z_bs, part, y_out, N, Cin, kpl,
+                         Cout, H, W, stream):
         P, K = H * W, Cin * kpl
         xv = np.array(planes(x, N, Cin, P, x_bs)).reshape(N, Cin, H, W)
         if in_scale:
@@ -84,6 +87,8 @@ class EmuLib:
         zz = planes(z, N, Cout, P, z_bs)
         zz[:] = acc + (f32(b_pw, Cout)[None, :, None] if b_pw else 0)
         self._write_part(part, PW_SLOTS, Cout, acc)
+        if y_out:
+            f32(y_out, N * K * P)[:] = y.reshape(-1)
         return 0
 
     def smaat_pointwise_fwd(self, x, x_bs, wt, bias, out, out_bs, part, N, Cin, M, H, W, stream):

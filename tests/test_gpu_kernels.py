@@ -63,12 +63,13 @@ def case_dsconv_fwd(L, dev, N, Cin, kpl, Cout, H, W, aff=False, pad_c=0, bias=Tr
     z = torch.full((N, Cout, H, W), float("nan"), device=dev)
     slots = L.smaat_pw_num_slots(N, H, W, Cout)
     part = torch.full((2, slots, Cout), float("nan"), device=dev)
+    y = torch.full((N, K, H, W), float("nan"), device=dev)
     xptr = x.data_ptr()
     rc = L.smaat_dsconv_fwd(xptr, x_bs, P(sc), P(sh), P(w_dw), P(b_dw) if bias else None, P(wt),
-                            P(b_pw) if bias else None, P(z), Cout * H * W, P(part), N, Cin, kpl, Cout, H, W,
+                            P(b_pw) if bias else None, P(z), Cout * H * W, P(part), P(y), N, Cin, kpl, Cout, H, W,
                             stream(dev))
     assert rc == 0
-    return dict(z=z, psum=part[0].double().sum(0), psq=part[1].double().sum(0))
+    return dict(z=z, y=y, psum=part[0].double().sum(0), psq=part[1].double().sum(0))
 
 
 DS_SHAPES = [
@@ -125,7 +126,7 @@ def case_dsconv_wgrad(L, dev, N, Cin, kpl, Cout, H, W):
     x = T(rnd(1, N, Cin, H, W), dev)
     w_dw, b_dw = T(rnd(2, K, 9, scale=0.3), dev), T(rnd(3, K, scale=0.3), dev)
     dz = T(rnd(4, N, Cout, H, W), dev)
-    ns = L.smaat_wgrad_num_splits(N, H, W, Cout, K)
+    ns = L.smaat_dsconv_wgrad_num_splits(N, H, W, Cout, K)
     ws = torch.empty((ns, Cout, K), device=dev)
     dw = torch.full((Cout, K), float("nan"), device=dev)
     assert L.smaat_dsconv_wgrad(P(x), Cin * H * W, None, None, P(w_dw), P(b_dw), P(dz), Cout * H * W, P(ws), P(dw), N,
@@ -150,7 +151,9 @@ def case_pointwise_wgrad(L, dev, N, C, M, H, W):
     return dict(dw=dw)
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 1, 32, 32), (2, 64, 21, 16, 16), (2, 16, 3, 6, 7), (2, 64, 1, 288, 288)])
+@pytest.mark.parametrize("shape", [(2, 64, 1, 32, 32), (2, 64, 21, 16, 16), (2, 16, 3, 6, 7), (2, 64, 1, 288, 288),
+                                   (2, 128, 64, 36, 36), (2, 24, 64, 64, 64), (3, 130, 70, 9, 11), (2, 256, 200, 18, 18),
+                                   (1, 1024, 512, 18, 18), (2, 256, 64, 144, 144), (1, 5, 3, 7, 9)])
 def test_pointwise_wgrad(shape):
     both(case_pointwise_wgrad, *shape, tol=2e-5)
 
