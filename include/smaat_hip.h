@@ -66,8 +66,9 @@ int smaat_pointwise_wgrad(const float* x, long x_bs, const float* dz, long dz_bs
 
 /* ---- depthwise 3x3 backward (autograd of nn.Conv2d(groups=Cin), models/layers.py:38-44)
  *   dy [N][Cin*kpl][H][W] -> dx [N][Cin][H][W] (nullable), dw_out [Cin*kpl][9], db_out [Cin*kpl] (nullable)
- *   ws: [N+1][Cin*kpl][10] floats
+ *   ws: [smaat_dw3x3_bwd_ws_rows(N,Cin,H,W)][Cin*kpl][10] floats
  */
+int smaat_dw3x3_bwd_ws_rows(int N, int Cin, int H, int W);
 int smaat_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, const float* w_dw, float* dx, long dx_bs,
                     float* ws, float* dw_out, float* db_out, int N, int Cin, int kpl, int H, int W, void* stream);
 

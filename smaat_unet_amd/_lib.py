@@ -29,6 +29,7 @@ SIGNATURES = {
     "smaat_dsconv_wgrad_num_splits": [_I, _I, _I, _I, _I],
     "smaat_dsconv_wgrad": [_P, _L, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "smaat_pointwise_wgrad": [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _P],
+    "smaat_dw3x3_bwd_ws_rows": [_I, _I, _I, _I],
     "smaat_dw3x3_bwd": [_P, _L, _P, _L, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "smaat_bn_finalize": [_P, _I, _I, _D, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P],
     "smaat_affine_act": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P],
@@ -161,7 +162,7 @@ class Profiler:
         self._orig = {}
         for name in SIGNATURES:
             fn = getattr(self.lib, name)
-            if name.endswith(("_slots", "_splits", "_blocks", "_version")):
+            if name.endswith(("_slots", "_splits", "_blocks", "_version", "_rows")):
                 continue
             self._orig[name] = fn
             setattr(self.lib, name, self._wrap(name, fn))

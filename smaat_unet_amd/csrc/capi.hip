@@ -45,6 +45,7 @@ int launch_upsample2x_bwd(const float*, long, float*, long, int, int, int, int, 
 int launch_dw3x3_bwd(const float*, long, const float*, long, const float*, float*, long, float*, int, int, int, int,
                      int, hipStream_t);
 int launch_dw_split(const float*, int, float*, float*, hipStream_t);
+int dw_bwd_groups(int N, int Cin, int H, int W);
 
 int smaat_cbam_spconv_blocks_impl(int N, int H, int W);
 int smaat_cbam_pix_blocks_impl(int N, int P);
@@ -126,13 +127,17 @@ int smaat_pointwise_wgrad(const float* x, long x_bs, const float* dz, long dz_bs
     return launch_reduce_rows(ws, a.nsplit, (long)M * Cin, dw_out, 1.f, st);
 }
 
+int smaat_dw3x3_bwd_ws_rows(int N, int Cin, int H, int W) { return N * dw_bwd_groups(N, Cin, H, W) + 1; }
+
 int smaat_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, const float* w_dw, float* dx, long dx_bs,
                     float* ws, float* dw_out, float* db_out, int N, int Cin, int kpl, int H, int W, void* stream) {
     const int Cdw = Cin * kpl;
-    CHK(launch_dw3x3_bwd(x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, ws, N, Cin, kpl, H, W, ST));
-    float* tmp = ws + (long)N * Cdw * 10;
-    CHK(launch_reduce_rows(ws, N, (long)Cdw * 10, tmp, 1.f, ST));
-    return launch_dw_split(tmp, Cdw, dw_out, db_out, ST);
+    hipStream_t st = ST;
+    const int rows = N * dw_bwd_groups(N, Cin, H, W);
+    CHK(launch_dw3x3_bwd(x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, ws, N, Cin, kpl, H, W, st));
+    float* tmp = ws + (long)rows * Cdw * 10;
+    CHK(launch_reduce_rows(ws, rows, (long)Cdw * 10, tmp, 1.f, st));
+    return launch_dw_split(tmp, Cdw, dw_out, db_out, st);
 }
 
 int smaat_bn_finalize(const float* part, int T, int C, double count, const float* bias_shift, const float* gamma,

@@ -592,7 +592,7 @@ static void choose_geom(int N, int H, int W, int PT, int smax, TileGeom* g) {
     // score = tile utilisation, discounted by the halo over-read, with a small bonus for
     // layouts whose rows are >= 128 B contiguous
     {   // candidate 0: PT consecutive pixels of the flattened plane
-        const int rows = (PT + W - 2) / W + 2;
+        const int rows = (PT + W - 2) / W + 3;  // rows spanned by PT consecutive pixels (worst start column) + 2 halo rows
         const int staged = rows * (W + 2);
         if (staged <= smax) {
             const int tiles = ceil_div(P, PT);
@@ -644,7 +644,7 @@ static int launch_pwgemm_mode(PwArgs& a, hipStream_t st) {
     // staged floats per input channel: the exact region size, padded to a multiple of 32
     int sstride = 0;
     if (DW) {
-        const int rs = (a.g.mode == 0) ? ((PT + a.g.W - 2) / a.g.W + 2) * (a.g.W + 2) : (a.g.TH + 2) * (a.g.TW + 2);
+        const int rs = (a.g.mode == 0) ? ((PT + a.g.W - 2) / a.g.W + 3) * (a.g.W + 2) : (a.g.TH + 2) * (a.g.TW + 2);
         sstride = (rs + 31) & ~31;
     }
     a.sstride = sstride;

@@ -175,12 +175,14 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd(const float* __restrict__ x, 
                                                    const float* __restrict__ w_dw, float* __restrict__ dx,
                                                    long dx_bs, float* __restrict__ part, int Cin, int kpl,
                                                    TileGeom g) {
+    // grid: (N*Cin planes, tile groups).  part: [N*groups][Cdw][10]
     __shared__ float S[DWB_KPL_MAX * DWB_SMAX];
     __shared__ float red[4 * 10 * DWB_KPL_MAX];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int plane = blockIdx.x, n = plane / Cin, ci = plane - n * Cin;
     const int Cdw = Cin * kpl;
     const float* xp = x + (long)n * x_bs + (long)ci * g.P;
+    const float* dyp = dy + (long)n * dy_bs + (long)(ci * kpl) * g.P;
     float* dxp = dx ? dx + (long)n * dx_bs + (long)ci * g.P : nullptr;
 
     float accw[DWB_KPL_MAX][10];
@@ -189,7 +191,21 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd(const float* __restrict__ x, 
 #pragma unroll
         for (int t = 0; t < 10; ++t) accw[j][t] = 0.f;
 
-    for (int tl = 0; tl < g.tiles_per_img; ++tl) {
+    // per-thread constants of the 2D tile mode (identical for every tile)
+    int sr2[3], sc2[3], tr2 = 0, tc2 = 0;
+    if (g.mode == 1) {
+        const int SW = g.TW + 2;
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+            const int e = tid + 256 * jj;
+            sr2[jj] = e / SW;
+            sc2[jj] = e - sr2[jj] * SW;
+        }
+        tr2 = tid / g.TW;
+        tc2 = tid - tr2 * g.TW;
+    }
+
+    for (int tl = blockIdx.y; tl < g.tiles_per_img; tl += gridDim.y) {
         const StageRegion rg = stage_region(g, tl);
         const int rsize = rg.nrows * rg.SW;
         __syncthreads();  // previous tile's reads are done
@@ -197,19 +213,32 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd(const float* __restrict__ x, 
         for (int jj = 0; jj < 3; ++jj) {
             const int e = tid + 256 * jj;
             if (e < rsize) {
-                const int sr = e / rg.SW, sc = e - sr * rg.SW;
+                int sr, sc;
+                if (g.mode == 1) {
+                    sr = sr2[jj];
+                    sc = sc2[jj];
+                } else {
+                    sr = e / rg.SW;
+                    sc = e - sr * rg.SW;
+                }
                 const int gr = rg.row_lo + sr, gc = rg.col_lo + sc;
                 const bool in = (gr >= 0 && gr < g.H && gc >= 0 && gc < g.W);
-                for (int j = 0; j < kpl; ++j) {
-                    float v = 0.f;
-                    if (in) v = dy[(long)n * dy_bs + (long)(ci * kpl + j) * g.P + gr * g.W + gc];
-                    S[j * DWB_SMAX + e] = v;
-                }
+                const int go = gr * g.W + gc;
+#pragma unroll
+                for (int j = 0; j < DWB_KPL_MAX; ++j)
+                    if (j < kpl) S[j * DWB_SMAX + e] = in ? dyp[(long)j * g.P + go] : 0.f;
             }
         }
         __syncthreads();
         int r, c;
-        const bool pv = tile_pixel(g, tl, tid, r, c);
+        bool pv;
+        if (g.mode == 1) {
+            r = rg.row_lo + 1 + tr2;
+            c = rg.col_lo + 1 + tc2;
+            pv = (r < g.H) && (c < g.W);
+        } else {
+            pv = tile_pixel(g, tl, tid, r, c);
+        }
         if (pv) {
             const int po = r * g.W + c;
             const int sb = (r - rg.row_lo) * rg.SW + (c - rg.col_lo);
@@ -265,7 +294,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd(const float* __restrict__ x, 
         const int j = tid / 10, t = tid - j * 10;
         const float v = red[(0 * DWB_KPL_MAX + j) * 10 + t] + red[(1 * DWB_KPL_MAX + j) * 10 + t] +
                         red[(2 * DWB_KPL_MAX + j) * 10 + t] + red[(3 * DWB_KPL_MAX + j) * 10 + t];
-        part[((long)n * Cdw + ci * kpl + j) * 10 + t] = v;
+        part[(((long)n * gridDim.y + blockIdx.y) * Cdw + ci * kpl + j) * 10 + t] = v;
     }
 }
 
@@ -327,13 +356,27 @@ int launch_upsample2x_bwd(const float* dout, long dout_bs, float* dx, long dx_bs
 
 void choose_geom_pub(int N, int H, int W, int PT, int smax, TileGeom* g);  // pwgemm.hip
 
+// tile groups per plane: enough workgroups to fill the chip, few enough to keep the partials small
+int dw_bwd_groups(int N, int Cin, int H, int W) {
+    TileGeom g;
+    choose_geom_pub(N, H, W, 256, DWB_SMAX, &g);
+    long planes = (long)N * Cin;
+    int groups = (int)((8192 + planes - 1) / planes);
+    if (groups > g.tiles_per_img) groups = g.tiles_per_img;
+    if (groups > 64) groups = 64;
+    if (groups < 1) groups = 1;
+    return groups;
+}
+
 int launch_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, const float* w_dw, float* dx, long dx_bs,
                      float* part, int N, int Cin, int kpl, int H, int W, hipStream_t st) {
     if (kpl < 1 || kpl > DWB_KPL_MAX) return -1;
     TileGeom g;
     choose_geom_pub(N, H, W, 256, DWB_SMAX, &g);
-    hipLaunchKernelGGL(k_dw3x3_bwd, dim3(N * Cin), dim3(256), 0, st, x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, part, Cin,
-                       kpl, g);
+    if (g.mode < 0) return -1;
+    const int groups = dw_bwd_groups(N, Cin, H, W);
+    hipLaunchKernelGGL(k_dw3x3_bwd, dim3(N * Cin, groups), dim3(256), 0, st, x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, part,
+                       Cin, kpl, g);
     return (int)hipGetLastError();
 }
 

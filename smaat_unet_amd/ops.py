@@ -192,7 +192,7 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None):
                                      s), "smaat_pointwise_fwd(dgrad)")
     # depthwise backward
     dx = _new(x, n, cin, h, w) if need_dx else None
-    ws2 = _new(x, n + 1, k, 10)
+    ws2 = _new(x, L.smaat_dw3x3_bwd_ws_rows(n, cin, h, w), k, 10)
     dw_dw = _new(x, k, 1, 3, 3)
     db_dw = _new(x, k)
     _lib.check(L.smaat_dw3x3_bwd(_ptr(x), x_bs, _ptr(dy), k * h * w, _ptr(w_dw), _ptr(dx), cin * h * w, _ptr(ws2),
@@ -217,8 +217,7 @@ class _DSConvBNReLU(torch.autograd.Function):
         n, cin, h, w = x.shape
         cout = w_pw.shape[0]
         use_batch_stats = training or rm is None
-        keep_y = KEEP_DEPTHWISE_OUTPUT and torch.is_grad_enabled() and any(
-            t is not None and t.requires_grad for t in (x, w_dw, w_pw))
+        keep_y = KEEP_DEPTHWISE_OUTPUT and any(ctx.needs_input_grad[:4])  # forward runs under no_grad
         y_dw = None
         if use_batch_stats:
             r = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, True, want_y=keep_y)
@@ -272,8 +271,7 @@ class _DSConv(torch.autograd.Function):
         _check(x, w_dw, b_dw, w_pw, b_pw)
         w_dw = w_dw.contiguous()
         w_pw = w_pw.contiguous()
-        keep_y = KEEP_DEPTHWISE_OUTPUT and torch.is_grad_enabled() and any(
-            t is not None and t.requires_grad for t in (x, w_dw, w_pw))
+        keep_y = KEEP_DEPTHWISE_OUTPUT and any(ctx.needs_input_grad[:4])
         r = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, False, want_y=keep_y)
         z = r[0]
         ctx.save_for_backward(x, w_dw, b_dw, w_pw, r[3] if keep_y else None)

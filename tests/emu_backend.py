@@ -71,6 +71,9 @@ class EmuLib:
         pp[0, T - 1] = a64.sum(axis=(0, 2))
         pp[1, T - 1] = (a64 * a64).sum(axis=(0, 2))
 
+    def smaat_dw3x3_bwd_ws_rows(self, N, Cin, H, W):
+        return N + 1
+
     def smaat_dsconv_wgrad_num_splits(self, N, H, W, M, K):
         return WG_SPLITS + 1
 

@@ -163,7 +163,7 @@ def case_dw_bwd(L, dev, N, Cin, kpl, H, W, need_dx=True):
     x, dy = T(rnd(1, N, Cin, H, W), dev), T(rnd(2, N, K, H, W), dev)
     w_dw = T(rnd(3, K, 9, scale=0.3), dev)
     dx = torch.full((N, Cin, H, W), float("nan"), device=dev) if need_dx else None
-    ws = torch.empty((N + 1, K, 10), device=dev)
+    ws = torch.empty((L.smaat_dw3x3_bwd_ws_rows(N, Cin, H, W), K, 10), device=dev)
     dw, db = torch.full((K, 9), float("nan"), device=dev), torch.full((K,), float("nan"), device=dev)
     assert L.smaat_dw3x3_bwd(P(x), Cin * H * W, P(dy), K * H * W, P(w_dw), P(dx), Cin * H * W, P(ws), P(dw), P(db), N,
                              Cin, kpl, H, W, stream(dev)) == 0
