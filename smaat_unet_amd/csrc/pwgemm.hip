@@ -59,7 +59,8 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
     float* stat = Wl + KC * COT;        // [WPX][2][COT]
     int* pixoff = (int*)(stat + WPX * 2 * COT);  // [PT]
     int* sidx = pixoff + PT;            // [PT]
-    float* S = (float*)(sidx + PT);     // [KCI][sstride]
+    float* biasl = (float*)(sidx + PT); // [COT]
+    float* S = biasl + COT;             // [KCI][sstride]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wco = wave % WCO, wpx = wave / WCO;
@@ -75,6 +76,12 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
     const int co0 = cot * COT;
     const StageRegion rg = stage_region(g, tl);
     const int sstride = a.sstride;
+    if (tid < COT) {  // bias slab -> LDS (unconditional clamped load + select: no branch around a load)
+        const int m = co0 + tid;
+        const float* bp = a.bias ? a.bias : a.wt;
+        const float v = bp[m < a.M ? m : 0];
+        biasl[tid] = (a.bias && m < a.M) ? v : 0.f;
+    }
 
     for (int i = tid; i < PT; i += SMAAT_THREADS) {
         int r, c;
@@ -116,6 +123,29 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
     float yreg[DW ? 1 : NY];
     float wreg[NW];
 
+    // All prefetch loads are UNCONDITIONAL (clamped, always-valid addresses) and the validity is
+    // applied with a select afterwards: a branch around a load makes hipcc serialise the loads
+    // behind per-element vmcnt(0) waits.
+    int gsafe[3];
+    bool gm[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        gm[j] = goff[j] >= 0;
+        gsafe[j] = gm[j] ? goff[j] : 0;
+    }
+    const int po_s = po >= 0 ? po : 0;
+    int wk_[NW], wm_[NW];
+    bool wmv[NW];
+#pragma unroll
+    for (int r = 0; r < NW; ++r) {
+        const int e = tid + SMAAT_THREADS * r;
+        wk_[r] = e / COT;
+        const int m = co0 + (e - wk_[r] * COT);
+        wmv[r] = m < a.M;
+        wm_[r] = wmv[r] ? m : a.M - 1;
+    }
+    // prefetch = address arithmetic + loads ONLY (no consumer of the loaded values, no branch):
+    // the masks / input affine are applied when the registers are committed to LDS.
     auto prefetch = [&](int ch) {
         const int k0 = ch * KC;
         if (DW) {
@@ -123,38 +153,21 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
 #pragma unroll
             for (int cl = 0; cl < KCI; ++cl) {
                 const int ci = ci0 + cl;
-                const bool cv = ci < a.Cin;
-                const float* plane = xn + (long)ci * g.P;
-                float sc_ = 1.f, sh_ = 0.f;
-                if (aff && cv) {
-                    sc_ = a.in_scale[ci];
-                    sh_ = a.in_shift[ci];
-                }
+                const float* plane = xn + (long)(ci < a.Cin ? ci : a.Cin - 1) * g.P;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    float v = 0.f;
-                    if (cv && goff[j] >= 0) {
-                        v = plane[goff[j]];
-                        if (aff) v = fmaxf(fmaf(v, sc_, sh_), 0.f);
-                    }
-                    sreg[cl][j] = v;
-                }
+                for (int j = 0; j < 3; ++j) sreg[cl][j] = plane[gsafe[j]];
             }
         } else {
 #pragma unroll
             for (int r = 0; r < NY; ++r) {
                 const int kg = k0 + g0 + r * G;
-                float v = 0.f;
-                if (kg < a.Kdim && po >= 0) v = xn[(long)kg * g.P + po];
-                yreg[r] = v;
+                yreg[r] = xn[(long)(kg < a.Kdim ? kg : a.Kdim - 1) * g.P + po_s];
             }
         }
 #pragma unroll
         for (int r = 0; r < NW; ++r) {
-            const int e = tid + SMAAT_THREADS * r;
-            const int k = e / COT, co = e - k * COT;
-            const int kg = k0 + k, m = co0 + co;
-            wreg[r] = (kg < a.Kdim && m < a.M) ? a.wt[(long)kg * a.M + m] : 0.f;
+            const int kg = k0 + wk_[r];
+            wreg[r] = a.wt[(long)(kg < a.Kdim ? kg : a.Kdim - 1) * a.M + wm_[r]];
         }
     };
 
@@ -163,17 +176,35 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
         const int k0 = ch * KC;
         if (DW) {
             // S is free: its readers (the depthwise stage of chunk ch-1) finished before that chunk's 2nd barrier
+            const int ci0 = k0 / KPL;
 #pragma unroll
-            for (int cl = 0; cl < KCI; ++cl)
+            for (int cl = 0; cl < KCI; ++cl) {
+                const int ci = ci0 + cl;
+                const bool cv = ci < a.Cin;
+                float sc_ = 1.f, sh_ = 0.f;
+                if (aff) {
+                    sc_ = a.in_scale[cv ? ci : a.Cin - 1];
+                    sh_ = a.in_shift[cv ? ci : a.Cin - 1];
+                }
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    if (goff[j] != -2) S[cl * sstride + tid + SMAAT_THREADS * j] = sreg[cl][j];
+                for (int j = 0; j < 3; ++j) {
+                    float v = sreg[cl][j];
+                    if (aff) v = fmaxf(fmaf(v, sc_, sh_), 0.f);
+                    v = (cv && gm[j]) ? v : 0.f;
+                    if (goff[j] != -2) S[cl * sstride + tid + SMAAT_THREADS * j] = v;
+                }
+            }
         }
         __syncthreads();  // B1: S visible; every wave is past the MFMA block of chunk ch-1
         if (DW) {
             const int sb = sidx[pi];
             const int SW = rg.SW;
-            for (int cl = g0; cl < KCI; cl += G) {
+            const bool wy = (a.y_out != nullptr) && (cot == 0) && (po >= 0);
+            const float* bdw = a.b_dw ? a.b_dw : a.w_dw;
+            float yv[(KCI / G) * KPL];
+#pragma unroll
+            for (int it = 0; it < KCI / G; ++it) {
+                const int cl = g0 + it * G;
                 const float* sp = S + cl * sstride + sb;
                 const float s00 = sp[-SW - 1], s01 = sp[-SW], s02 = sp[-SW + 1];
                 const float s10 = sp[-1], s11 = sp[0], s12 = sp[1];
@@ -181,31 +212,44 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
 #pragma unroll
                 for (int j = 0; j < KPL; ++j) {
                     const int k = cl * KPL + j, kg = k0 + k;
-                    float y = 0.f;
-                    if (kg < a.Kdim) {
-                        const float* w = a.w_dw + kg * 9;
-                        y = a.b_dw ? a.b_dw[kg] : 0.f;
-                        y = fmaf(w[0], s00, y);
-                        y = fmaf(w[1], s01, y);
-                        y = fmaf(w[2], s02, y);
-                        y = fmaf(w[3], s10, y);
-                        y = fmaf(w[4], s11, y);
-                        y = fmaf(w[5], s12, y);
-                        y = fmaf(w[6], s20, y);
-                        y = fmaf(w[7], s21, y);
-                        y = fmaf(w[8], s22, y);
-                        if (a.y_out && cot == 0 && po >= 0)
-                            a.y_out[((long)n * a.Kdim + kg) * g.P + po] = y;
-                    }
+                    const bool kv = kg < a.Kdim;
+                    const int kgs = kv ? kg : a.Kdim - 1;  // clamped: weight loads are unconditional
+                    const float* w = a.w_dw + kgs * 9;
+                    float y = bdw[kgs];
+                    y = a.b_dw ? y : 0.f;
+                    y = fmaf(w[0], s00, y);
+                    y = fmaf(w[1], s01, y);
+                    y = fmaf(w[2], s02, y);
+                    y = fmaf(w[3], s10, y);
+                    y = fmaf(w[4], s11, y);
+                    y = fmaf(w[5], s12, y);
+                    y = fmaf(w[6], s20, y);
+                    y = fmaf(w[7], s21, y);
+                    y = fmaf(w[8], s22, y);
+                    y = kv ? y : 0.f;
+                    yv[it * KPL + j] = y;
                     Yl[k * PT + pi] = y;
                 }
             }
+            if (wy) {  // side output, kept out of the compute loop so that the loop stays branch-free
+#pragma unroll
+                for (int it = 0; it < KCI / G; ++it)
+#pragma unroll
+                    for (int j = 0; j < KPL; ++j) {
+                        const int kg = k0 + (g0 + it * G) * KPL + j;
+                        if (kg < a.Kdim) a.y_out[((long)n * a.Kdim + kg) * g.P + po] = yv[it * KPL + j];
+                    }
+            }
         } else {
 #pragma unroll
-            for (int r = 0; r < NY; ++r) Yl[(g0 + r * G) * PT + pi] = yreg[r];
+            for (int r = 0; r < NY; ++r) {
+                const int kg = k0 + g0 + r * G;
+                Yl[(g0 + r * G) * PT + pi] = (kg < a.Kdim && po >= 0) ? yreg[r] : 0.f;
+            }
         }
 #pragma unroll
-        for (int r = 0; r < NW; ++r) Wl[tid + SMAAT_THREADS * r] = wreg[r];
+        for (int r = 0; r < NW; ++r)
+            Wl[tid + SMAAT_THREADS * r] = ((k0 + wk_[r]) < a.Kdim && wmv[r]) ? wreg[r] : 0.f;
         __syncthreads();  // B2
         if (ch + 1 < nchunks) prefetch(ch + 1);  // in flight during the MFMA block
 #pragma unroll
@@ -233,9 +277,10 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
     for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = co0 + (wco * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int col = (wco * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int m = co0 + col;
             if (m < a.M) {
-                const float bvv = a.bias ? a.bias[m] : 0.f;
+                const float bvv = biasl[col];
                 float* rowp = obase + (long)m * g.P;
 #pragma unroll
                 for (int pt = 0; pt < PXT; ++pt)
@@ -323,33 +368,37 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_wgrad2(const Wg2Args a) {
             for (int r = 0; r < 16; ++r) acc[ct][kw][r] = 0.f;
 
     float4 pf[NPF];
+    // row pointers with clamped (always valid) row indices; validity applied by select
+    const float* rowp[NPF];
+    bool rowv[NPF];
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+        const int row = r16 + 16 * j;
+        if (row < MT) {
+            rowv[j] = (m0 + row) < a.M;
+            rowp[j] = a.dz + (long)(rowv[j] ? m0 + row : a.M - 1) * a.P;
+        } else {
+            rowv[j] = (k0 + row - MT) < a.K;
+            rowp[j] = a.y + (long)(rowv[j] ? k0 + row - MT : a.K - 1) * a.P;
+        }
+    }
     auto prefetch = [&](int c) {
         const int n = c / a.nchunk_img;
-        const int p0 = (c - n * a.nchunk_img) * PS + px4;
+        const int pc = (c - n * a.nchunk_img) * PS;
+        const int p0 = pc + px4;
+        const bool full = vec && (pc + PS <= a.P);  // workgroup-uniform
+        if (full) {
 #pragma unroll
-        for (int j = 0; j < NPF; ++j) {
-            const int row = r16 + 16 * j;
-            const float* src;
-            bool rv;
-            if (row < MT) {
-                rv = (m0 + row) < a.M;
-                src = a.dz + (long)n * a.dz_bs + (long)(m0 + row) * a.P + p0;
-            } else {
-                rv = (k0 + row - MT) < a.K;
-                src = a.y + (long)n * a.y_bs + (long)(k0 + row - MT) * a.P + p0;
+            for (int j = 0; j < NPF; ++j)
+                pf[j] = *(const float4*)(rowp[j] + (long)n * ((r16 + 16 * j) < MT ? a.dz_bs : a.y_bs) + p0);
+        } else {
+            const int q0 = p0 + 0 < a.P ? p0 + 0 : a.P - 1, q1 = p0 + 1 < a.P ? p0 + 1 : a.P - 1;
+            const int q2 = p0 + 2 < a.P ? p0 + 2 : a.P - 1, q3 = p0 + 3 < a.P ? p0 + 3 : a.P - 1;
+#pragma unroll
+            for (int j = 0; j < NPF; ++j) {
+                const float* src = rowp[j] + (long)n * ((r16 + 16 * j) < MT ? a.dz_bs : a.y_bs);
+                pf[j] = make_float4(src[q0], src[q1], src[q2], src[q3]);
             }
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rv) {
-                if (vec && p0 + 3 < a.P) {
-                    v = *(const float4*)src;
-                } else {
-                    if (p0 + 0 < a.P) v.x = src[0];
-                    if (p0 + 1 < a.P) v.y = src[1];
-                    if (p0 + 2 < a.P) v.z = src[2];
-                    if (p0 + 3 < a.P) v.w = src[3];
-                }
-            }
-            pf[j] = v;
         }
     };
 
@@ -359,14 +408,17 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_wgrad2(const Wg2Args a) {
     if (c_begin < c_end) prefetch(c_begin);
     for (int c = c_begin; c < c_end; ++c) {
         __syncthreads();  // previous MFMA block done with Zs / Ys
+        {
+            const int pc = (c % a.nchunk_img) * PS + px4;
 #pragma unroll
-        for (int j = 0; j < NPF; ++j) {
-            const int row = r16 + 16 * j;
-            float* dst = (row < MT ? Zs + row * LS : Ys + (row - MT) * LS) + px4;
-            dst[0] = pf[j].x;
-            dst[1] = pf[j].y;
-            dst[2] = pf[j].z;
-            dst[3] = pf[j].w;
+            for (int j = 0; j < NPF; ++j) {
+                const int row = r16 + 16 * j;
+                float* dst = (row < MT ? Zs + row * LS : Ys + (row - MT) * LS) + px4;
+                dst[0] = (rowv[j] && pc + 0 < a.P) ? pf[j].x : 0.f;
+                dst[1] = (rowv[j] && pc + 1 < a.P) ? pf[j].y : 0.f;
+                dst[2] = (rowv[j] && pc + 2 < a.P) ? pf[j].z : 0.f;
+                dst[3] = (rowv[j] && pc + 3 < a.P) ? pf[j].w : 0.f;
+            }
         }
         __syncthreads();
         if (c + 1 < c_end) prefetch(c + 1);
@@ -649,7 +701,7 @@ static int launch_pwgemm_mode(PwArgs& a, hipStream_t st) {
     }
     a.sstride = sstride;
     const int kci = KC / (DW ? MODE : 1);
-    const size_t lds = sizeof(float) * (size_t)(KC * PT + KC * COT + WPX * 2 * COT + 2 * PT + (DW ? kci * sstride : 0));
+    const size_t lds = sizeof(float) * (size_t)(KC * PT + KC * COT + WPX * 2 * COT + 2 * PT + COT + (DW ? kci * sstride : 0));
     const int grid = ceil_div(a.g.T, 8) * 8 * a.nco;
     constexpr auto kern = k_pwgemm<WCO, CT, WPX, PXT, MODE>;
     int rc = ensure_lds<kern>(lds);

@@ -110,15 +110,20 @@ def test_unet_vs_reference_golden(golden_dir, name):
 
 
 def test_unet_vs_oracle_288():
-    """one 288x288 frame, forward + backward, against the numpy oracle.  End-to-end gradients
-    are judged the way SURVEY.md 8(c) prescribes: our error against the FP64 oracle must be no
-    worse than 2x the FP32 oracle's own error against FP64 (floor 1e-3)."""
+    """one 288x288 frame, forward + backward, against the oracle.  End-to-end gradients are
+    judged the way SURVEY.md 8(c) prescribes: per tensor, our error against the FP64 oracle
+    must be no worse than 2x the error that FP32 CPU arithmetic itself shows against FP64
+    (numpy fp32 oracle and the ATen-CPU port oracle/torch_ref.py; floor 1e-3)."""
+    from oracle import torch_ref
     meta = dict(n_channels=12, n_classes=1, param_seed=3)
     model, P = _load_model(meta)
     xn, yn = O.synthetic_precip(1, 12, 288, 288, seed=1234)
     loss_o, G32, dx32, acts = O.train_step_loss_and_grads(P, xn, yn)
     P64 = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in P.items()}
     _, G64, dx64, acts64 = O.train_step_loss_and_grads(P64, xn.astype(np.float64), yn.astype(np.float64))
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    Pt = torch_ref.params_from_numpy(P)
+    torch_ref.train_step(Pt, torch.from_numpy(xn), torch.from_numpy(yn))
     x = torch.from_numpy(xn).to(DEV).requires_grad_(True)
     logits = model(x)
     assert rel(logits.detach().cpu().numpy(), acts["logits"]) < 1e-4
@@ -126,21 +131,28 @@ def test_unet_vs_oracle_288():
     loss = torch.nn.functional.mse_loss(logits.squeeze(1), torch.from_numpy(yn).to(DEV), reduction="sum") / 1
     assert abs(loss.item() - float(loss_o)) < 1e-4 * abs(float(loss_o))
     loss.backward()
-    bad = []
+    bad, table = [], {}
+    skip = lambda k: ".double_conv." in k and k.endswith(("depthwise.bias", "pointwise.bias"))  # noqa: E731
     for k, p in model.named_parameters():
-        if ".double_conv." in k and (k.endswith("depthwise.bias") or k.endswith("pointwise.bias")):
+        if skip(k):
             continue
         ours = rel(p.grad.cpu().numpy(), G64[k])
-        ref = rel(G32[k], G64[k])
+        ref = max(rel(G32[k], G64[k]), rel(Pt[k].grad.numpy(), G64[k]))
+        table[k] = (ours, rel(G32[k], G64[k]), rel(Pt[k].grad.numpy(), G64[k]))
         if ours > max(2.0 * ref, 1e-3):
             bad.append((k, ours, ref))
-    assert not bad, bad[:8]
+    flat_o = np.concatenate([G64[k].ravel() for k, _ in model.named_parameters() if not skip(k)])
+    flat_m = np.concatenate([p.grad.cpu().numpy().ravel() for k, p in model.named_parameters() if not skip(k)])
+    flat_t = np.concatenate([Pt[k].grad.numpy().ravel() for k, _ in model.named_parameters() if not skip(k)])
+    summary = dict(flat_ours_vs_fp64=rel(flat_m, flat_o), flat_aten_cpu_vs_fp64=rel(flat_t, flat_o),
+                   worst_ours=max(table.items(), key=lambda kv: kv[1][0]),
+                   worst_aten=max(table.items(), key=lambda kv: kv[1][2]))
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/grad_errors_288.json", "w") as f:
+            json.dump(dict(summary=summary, per_tensor=table), f, indent=1, default=float)
+    assert not bad, (bad[:8], summary)
     assert rel(x.grad.cpu().numpy(), dx64) < max(2.0 * rel(dx32, dx64), 1e-3)
-    flat_o = np.concatenate([G64[k].ravel() for k, _ in model.named_parameters()
-                             if not (".double_conv." in k and k.endswith(("depthwise.bias", "pointwise.bias")))])
-    flat_m = np.concatenate([p.grad.cpu().numpy().ravel() for k, p in model.named_parameters()
-                             if not (".double_conv." in k and k.endswith(("depthwise.bias", "pointwise.bias")))])
-    assert rel(flat_m, flat_o) < 1e-2
+    assert summary["flat_ours_vs_fp64"] < max(2.0 * summary["flat_aten_cpu_vs_fp64"], 3e-3)
 
 
 def test_full_size_properties():
