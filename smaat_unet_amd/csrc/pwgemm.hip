@@ -251,7 +251,7 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
         for (int r = 0; r < NW; ++r)
             Wl[tid + SMAAT_THREADS * r] = ((k0 + wk_[r]) < a.Kdim && wmv[r]) ? wreg[r] : 0.f;
         __syncthreads();  // B2
-        if (ch + 1 < nchunks) prefetch(ch + 1);  // in flight during the MFMA block
+        prefetch(ch + 1 < nchunks ? ch + 1 : ch);  // in flight during the MFMA block (unconditional: no phi copies)
 #pragma unroll
         for (int kk = 0; kk < KC / 2; ++kk) {
             const int krow = 2 * kk + half;
@@ -337,7 +337,7 @@ struct Wg2Args {
     int N, M, K, P, nmt, nkt, nsplit, chunks_per_split, nchunk_img, total_chunks;
 };
 
-template <int CT>
+template <int CT, bool VEC>
 __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_wgrad2(const Wg2Args a) {
     constexpr int MT = 64 * CT, KT = 128, PS = 64, LS = PS + 1;
     constexpr int NPF = (MT + KT) / 16;
@@ -356,9 +356,6 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_wgrad2(const Wg2Args a) {
     if (split >= a.nsplit) return;
     const int mt = rest % a.nmt, kt = rest / a.nmt;
     const int m0 = mt * MT, k0 = kt * KT;
-    const bool vec = ((a.P & 3) == 0) && ((a.dz_bs & 3) == 0) && ((a.y_bs & 3) == 0) &&
-                     ((((uintptr_t)a.dz) & 15) == 0) && ((((uintptr_t)a.y) & 15) == 0);
-
     f32x16 acc[CT][2];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -382,15 +379,16 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_wgrad2(const Wg2Args a) {
             rowp[j] = a.y + (long)(rowv[j] ? k0 + row - MT : a.K - 1) * a.P;
         }
     }
+    // ONE load path per kernel instantiation (a runtime choice between two paths would make
+    // the compiler copy the loaded registers at the merge point, i.e. wait for them at once).
     auto prefetch = [&](int c) {
         const int n = c / a.nchunk_img;
-        const int pc = (c - n * a.nchunk_img) * PS;
-        const int p0 = pc + px4;
-        const bool full = vec && (pc + PS <= a.P);  // workgroup-uniform
-        if (full) {
+        const int p0 = (c - n * a.nchunk_img) * PS + px4;
+        if (VEC) {  // P % 4 == 0: a lane is entirely inside or entirely outside the plane
+            const int p0c = p0 + 3 < a.P ? p0 : a.P - 4;
 #pragma unroll
             for (int j = 0; j < NPF; ++j)
-                pf[j] = *(const float4*)(rowp[j] + (long)n * ((r16 + 16 * j) < MT ? a.dz_bs : a.y_bs) + p0);
+                pf[j] = *(const float4*)(rowp[j] + (long)n * ((r16 + 16 * j) < MT ? a.dz_bs : a.y_bs) + p0c);
         } else {
             const int q0 = p0 + 0 < a.P ? p0 + 0 : a.P - 1, q1 = p0 + 1 < a.P ? p0 + 1 : a.P - 1;
             const int q2 = p0 + 2 < a.P ? p0 + 2 : a.P - 1, q3 = p0 + 3 < a.P ? p0 + 3 : a.P - 1;
@@ -421,7 +419,7 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_wgrad2(const Wg2Args a) {
             }
         }
         __syncthreads();
-        if (c + 1 < c_end) prefetch(c + 1);
+        prefetch(c + 1 < c_end ? c + 1 : c);
 #pragma unroll 8
         for (int s = 0; s < PS / 2; ++s) {
             const int px = 2 * s + half;
@@ -753,26 +751,28 @@ int smaat_wgrad_num_splits_impl(int N, int P, int M, int K) {
     return ns;
 }
 
+template <int CT, bool VEC>
+static int launch_wgrad2_cfg(Wg2Args& a, hipStream_t st) {
+    constexpr int MT = 64 * CT;
+    a.nmt = ceil_div(a.M, MT);
+    const size_t lds = sizeof(float) * (size_t)((MT + 128) * 65);
+    constexpr auto kern = k_wgrad2<CT, VEC>;
+    int rc = ensure_lds<kern>(lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(ceil_div(a.nsplit, 8) * 8 * a.nmt * a.nkt), dim3(SMAAT_THREADS), lds, st, a);
+    return (int)hipGetLastError();
+}
+
 int launch_wgrad2(Wg2Args& a, hipStream_t st) {
     a.nchunk_img = ceil_div(a.P, 64);
     a.total_chunks = a.N * a.nchunk_img;
     a.nsplit = smaat_wgrad_num_splits_impl(a.N, a.P, a.M, a.K);
     a.chunks_per_split = ceil_div(a.total_chunks, a.nsplit);
     a.nkt = ceil_div(a.K, 128);
-    if (a.M > 64) {
-        a.nmt = ceil_div(a.M, 128);
-        const size_t lds = sizeof(float) * (size_t)((128 + 128) * 65);
-        int rc = ensure_lds<k_wgrad2<2>>(lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_wgrad2<2>, dim3(ceil_div(a.nsplit, 8) * 8 * a.nmt * a.nkt), dim3(SMAAT_THREADS), lds, st, a);
-    } else {
-        a.nmt = 1;
-        const size_t lds = sizeof(float) * (size_t)((64 + 128) * 65);
-        int rc = ensure_lds<k_wgrad2<1>>(lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_wgrad2<1>, dim3(ceil_div(a.nsplit, 8) * 8 * a.nkt), dim3(SMAAT_THREADS), lds, st, a);
-    }
-    return (int)hipGetLastError();
+    const bool vec = ((a.P & 3) == 0) && (a.P >= 4) && ((a.dz_bs & 3) == 0) && ((a.y_bs & 3) == 0) &&
+                     ((((uintptr_t)a.dz) & 15) == 0) && ((((uintptr_t)a.y) & 15) == 0);
+    if (a.M > 64) return vec ? launch_wgrad2_cfg<2, true>(a, st) : launch_wgrad2_cfg<2, false>(a, st);
+    return vec ? launch_wgrad2_cfg<1, true>(a, st) : launch_wgrad2_cfg<1, false>(a, st);
 }
 
 static int wgrad_smax(int M, int kpl, bool dw) {
