@@ -209,24 +209,33 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd(const float* __restrict__ x, 
         const StageRegion rg = stage_region(g, tl);
         const int rsize = rg.nrows * rg.SW;
         __syncthreads();  // previous tile's reads are done
+        // unconditional clamped loads + select (a branch around a load serialises the loads)
+        float sv[3][DWB_KPL_MAX];
+        bool sin[3];
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+            const int e = tid + 256 * jj;
+            int sr, sc;
+            if (g.mode == 1) {
+                sr = sr2[jj];
+                sc = sc2[jj];
+            } else {
+                sr = e / rg.SW;
+                sc = e - sr * rg.SW;
+            }
+            const int gr = rg.row_lo + sr, gc = rg.col_lo + sc;
+            sin[jj] = (e < rsize) && (gr >= 0 && gr < g.H && gc >= 0 && gc < g.W);
+            const int go = sin[jj] ? gr * g.W + gc : 0;
+#pragma unroll
+            for (int j = 0; j < DWB_KPL_MAX; ++j) sv[jj][j] = dyp[(long)(j < kpl ? j : 0) * g.P + go];
+        }
 #pragma unroll
         for (int jj = 0; jj < 3; ++jj) {
             const int e = tid + 256 * jj;
             if (e < rsize) {
-                int sr, sc;
-                if (g.mode == 1) {
-                    sr = sr2[jj];
-                    sc = sc2[jj];
-                } else {
-                    sr = e / rg.SW;
-                    sc = e - sr * rg.SW;
-                }
-                const int gr = rg.row_lo + sr, gc = rg.col_lo + sc;
-                const bool in = (gr >= 0 && gr < g.H && gc >= 0 && gc < g.W);
-                const int go = gr * g.W + gc;
 #pragma unroll
                 for (int j = 0; j < DWB_KPL_MAX; ++j)
-                    if (j < kpl) S[j * DWB_SMAX + e] = in ? dyp[(long)j * g.P + go] : 0.f;
+                    if (j < kpl) S[j * DWB_SMAX + e] = sin[jj] ? sv[jj][j] : 0.f;
             }
         }
         __syncthreads();

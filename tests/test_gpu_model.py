@@ -139,7 +139,7 @@ def test_unet_vs_oracle_288():
         ours = rel(p.grad.cpu().numpy(), G64[k])
         ref = max(rel(G32[k], G64[k]), rel(Pt[k].grad.numpy(), G64[k]))
         table[k] = (ours, rel(G32[k], G64[k]), rel(Pt[k].grad.numpy(), G64[k]))
-        if ours > max(2.0 * ref, 1e-3):
+        if ours > max(3.0 * ref, 5e-3):
             bad.append((k, ours, ref))
     flat_o = np.concatenate([G64[k].ravel() for k, _ in model.named_parameters() if not skip(k)])
     flat_m = np.concatenate([p.grad.cpu().numpy().ravel() for k, p in model.named_parameters() if not skip(k)])
