@@ -97,6 +97,8 @@ int smaat_bn_bwd_apply(const float* dy, long dy_bs, const float* z, long z_bs, c
                        long dz_bs, int N, int C, int P, int relu, void* stream);
 
 /* ---- small helpers */
+/* out[j] = alpha * sum_r part[r][j] (fp64 accumulation, fixed order); `part` is SCRATCH: rows of it
+ * may be overwritten by the first level of the reduction. */
 int smaat_reduce_rows(const float* part, int rows, long len, float* out, float alpha, void* stream);
 /* out[c] = sum_{n,p} x[n][c][p]; ws: [smaat_plane_num_slots(N,P)][C] */
 int smaat_channel_sum(const float* x, long x_bs, int N, int C, int P, float* ws, float* out, void* stream);

@@ -230,13 +230,35 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
 // ---------------------------------------------------------------------------------
 // generic helpers
 // ---------------------------------------------------------------------------------
-// out[j] = sum_r part[r][j], fp64 accumulation (deterministic order)
-__global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ part, int rows, long len,
+// out[j] = alpha * sum_r part[r][j], fp64 accumulation, deterministic order.
+// Two levels so that a tall skinny partial buffer (thousands of rows x a few thousand columns)
+// still fills the chip: level 1 reduces row slices IN PLACE into the first row of each slice,
+// level 2 sums the slice heads.
+__global__ __launch_bounds__(256) void k_reduce_rows_l1(float* __restrict__ part, int rows, long len, int q) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= len) return;
+    const int r0 = blockIdx.y * q;
+    int r1 = r0 + q;
+    if (r1 > rows) r1 = rows;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {
+        s0 += (double)part[(long)(r + 0) * len + j];
+        s1 += (double)part[(long)(r + 1) * len + j];
+        s2 += (double)part[(long)(r + 2) * len + j];
+        s3 += (double)part[(long)(r + 3) * len + j];
+    }
+    for (; r < r1; ++r) s0 += (double)part[(long)r * len + j];
+    // NOTE: the slice head keeps a float; the final sum of <= 64 heads is again fp64
+    if (r0 < rows) part[(long)r0 * len + j] = (float)((s0 + s1) + (s2 + s3));
+}
+
+__global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ part, int rows, long len, int stride,
                                                      float* __restrict__ out, float alpha) {
     const long j = (long)blockIdx.x * 256 + threadIdx.x;
     if (j >= len) return;
     double s = 0.0;
-    for (int r = 0; r < rows; ++r) s += (double)part[(long)r * len + j];
+    for (int r = 0; r < rows; r += stride) s += (double)part[(long)r * len + j];
     out[j] = (float)(s * alpha);
 }
 
@@ -350,7 +372,20 @@ int launch_bn_bwd_apply(const float* dy, long dy_bs, const float* z, long z_bs, 
 }
 
 int launch_reduce_rows(const float* part, int rows, long len, float* out, float alpha, hipStream_t st) {
-    hipLaunchKernelGGL(k_reduce_rows, dim3(cdiv(len, 256)), dim3(256), 0, st, part, rows, len, out, alpha);
+    // NB: the partial buffer is scratch -- level 1 overwrites the head row of every slice.
+    const int gx = cdiv(len, 256);
+    int stride = 1;
+    if (rows > 16 && (long)gx * 1 < 2048) {
+        int slices = (2048 + gx - 1) / gx;   // aim at ~2048 blocks
+        if (slices > 64) slices = 64;
+        if (slices > rows / 4) slices = rows / 4;
+        if (slices > 1) {
+            stride = cdiv(rows, slices);
+            const int ns = cdiv(rows, stride);
+            hipLaunchKernelGGL(k_reduce_rows_l1, dim3(gx, ns), dim3(256), 0, st, (float*)part, rows, len, stride);
+        }
+    }
+    hipLaunchKernelGGL(k_reduce_rows, dim3(gx), dim3(256), 0, st, part, rows, len, stride, out, alpha);
     return (int)hipGetLastError();
 }
 
@@ -359,7 +394,7 @@ int launch_channel_sum(const float* x, long x_bs, int N, int C, int P, float* ws
     dim3 grid(N * C, cdiv(P, seg));
     hipLaunchKernelGGL(k_plane_sum, grid, dim3(256), 0, st, x, x_bs, C, P, seg, ws);
     const int slots = N * grid.y;
-    hipLaunchKernelGGL(k_reduce_rows, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)ws, slots, (long)C, out, 1.f);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)ws, slots, (long)C, 1, out, 1.f);
     return (int)hipGetLastError();
 }
 

@@ -400,11 +400,11 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_wgrad2(const Wg2Args a) {
         }
     };
 
-    int c_end = (split + 1) * a.chunks_per_split;
-    if (c_end > a.total_chunks) c_end = a.total_chunks;
-    const int c_begin = split * a.chunks_per_split;
+    // chunk i of this split is chunk (split + i*nsplit): the workgroups that run at the same time
+    // stream adjacent 256 B pieces of every row (DRAM page / L2 locality)
+    const int c_begin = split, c_end = a.total_chunks, c_step = a.nsplit;
     if (c_begin < c_end) prefetch(c_begin);
-    for (int c = c_begin; c < c_end; ++c) {
+    for (int c = c_begin; c < c_end; c += c_step) {
         __syncthreads();  // previous MFMA block done with Zs / Ys
         {
             const int pc = (c % a.nchunk_img) * PS + px4;
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_wgrad2(const Wg2Args a) {
             }
         }
         __syncthreads();
-        prefetch(c + 1 < c_end ? c + 1 : c);
+        prefetch(c + c_step < c_end ? c + c_step : c);
 #pragma unroll 8
         for (int s = 0; s < PS / 2; ++s) {
             const int px = 2 * s + half;
@@ -745,7 +745,7 @@ int smaat_wgrad_num_splits_impl(int N, int P, int M, int K) {
     const int total = N * ceil_div(P, 64);
     const int mt = (M > 64) ? 128 : 64;
     const int ntile = ceil_div(M, mt) * ceil_div(K, 128);
-    int ns = ceil_div(2048, ntile);
+    int ns = ceil_div(1024, ntile);
     if (ns > total) ns = total;
     if (ns < 1) ns = 1;
     return ns;

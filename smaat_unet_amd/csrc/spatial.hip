@@ -205,13 +205,16 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd(const float* __restrict__ x, 
         tc2 = tid - tr2 * g.TW;
     }
 
-    for (int tl = blockIdx.y; tl < g.tiles_per_img; tl += gridDim.y) {
+    // software pipeline over the tiles of this group: the loads of tile t+1 (dY halo patch and
+    // the x centre value) are in flight while tile t is being computed.
+    float sv[3][DWB_KPL_MAX];
+    bool sin[3];
+    float xnext = 0.f;
+    int pnext = 0;
+    bool pvnext = false;
+    auto prefetch = [&](int tl) {
         const StageRegion rg = stage_region(g, tl);
         const int rsize = rg.nrows * rg.SW;
-        __syncthreads();  // previous tile's reads are done
-        // unconditional clamped loads + select (a branch around a load serialises the loads)
-        float sv[3][DWB_KPL_MAX];
-        bool sin[3];
 #pragma unroll
         for (int jj = 0; jj < 3; ++jj) {
             const int e = tid + 256 * jj;
@@ -229,6 +232,24 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd(const float* __restrict__ x, 
 #pragma unroll
             for (int j = 0; j < DWB_KPL_MAX; ++j) sv[jj][j] = dyp[(long)(j < kpl ? j : 0) * g.P + go];
         }
+        int r, c;
+        if (g.mode == 1) {
+            r = rg.row_lo + 1 + tr2;
+            c = rg.col_lo + 1 + tc2;
+            pvnext = (r < g.H) && (c < g.W);
+        } else {
+            pvnext = tile_pixel(g, tl, tid, r, c);
+        }
+        pnext = pvnext ? r * g.W + c : 0;
+        xnext = xp[pnext];
+    };
+
+    int tl = blockIdx.y;
+    if (tl < g.tiles_per_img) prefetch(tl);
+    for (; tl < g.tiles_per_img; tl += gridDim.y) {
+        const StageRegion rg = stage_region(g, tl);
+        const int rsize = rg.nrows * rg.SW;
+        __syncthreads();  // previous tile's reads are done
 #pragma unroll
         for (int jj = 0; jj < 3; ++jj) {
             const int e = tid + 256 * jj;
@@ -238,21 +259,18 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd(const float* __restrict__ x, 
                     if (j < kpl) S[j * DWB_SMAX + e] = sin[jj] ? sv[jj][j] : 0.f;
             }
         }
+        const bool pv = pvnext;
+        const int po = pnext;
+        const float xv = xnext;
         __syncthreads();
-        int r, c;
-        bool pv;
-        if (g.mode == 1) {
-            r = rg.row_lo + 1 + tr2;
-            c = rg.col_lo + 1 + tc2;
-            pv = (r < g.H) && (c < g.W);
-        } else {
-            pv = tile_pixel(g, tl, tid, r, c);
+        {
+            const int tn = tl + gridDim.y;
+            prefetch(tn < g.tiles_per_img ? tn : tl);
         }
         if (pv) {
-            const int po = r * g.W + c;
+            const int r = po / g.W, c = po - r * g.W;
             const int sb = (r - rg.row_lo) * rg.SW + (c - rg.col_lo);
             const int SW = rg.SW;
-            const float xv = xp[po];
             float dxa = 0.f;
 #pragma unroll
             for (int j = 0; j < DWB_KPL_MAX; ++j) {

@@ -233,10 +233,13 @@ def case_misc(L, dev, N, C, H, W):
     rows = T(rnd(2, 7, 1000), dev)
     rr = torch.empty(1000, device=dev)
     assert L.smaat_reduce_rows(P(rows), 7, 1000, P(rr), 0.5, s) == 0
+    rows2 = T(rnd(4, 1037, 3001), dev)  # tall: exercises the two-level path (part is scratch)
+    rr2 = torch.empty(3001, device=dev)
+    assert L.smaat_reduce_rows(P(rows2), 1037, 3001, P(rr2), 1.0, s) == 0
     big = torch.zeros((N, C + 3, H, W), device=dev)
     assert L.smaat_copy_planes(P(x), C * Pn, big.data_ptr() + 4 * 2 * Pn, (C + 3) * Pn, N, C * Pn, 0, s) == 0
     assert L.smaat_copy_planes(P(x), C * Pn, big.data_ptr() + 4 * 2 * Pn, (C + 3) * Pn, N, C * Pn, 1, s) == 0
-    return dict(cs=cs, rr=rr, big=big)
+    return dict(cs=cs, rr=rr, rr2=rr2, big=big)
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 5, 7), (2, 16, 64, 64), (1, 1, 288, 288)])
