@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsmaat_hip.so")
+LIB_PATH = os.environ.get("SMAAT_LIB") or os.path.join(_HERE, "libsmaat_hip.so")  # SMAAT_LIB: experiment builds only
 CSRC = os.path.join(_HERE, "csrc")
 
 _P = ctypes.c_void_p

@@ -6,7 +6,7 @@
 struct PwArgs {
     const float* x; long x_bs; const float* in_scale; const float* in_shift; const float* w_dw; const float* b_dw;
     const float* wt; const float* bias; float* out; long out_bs; float* part; float* y_out;
-    int N, Cin, kpl, Kdim, M, nco, sstride; TileGeom g;
+    int N, Cin, kpl, Kdim, M, nco, sstride; TileGeom g; int dbg;
 };
 struct WgArgs {
     const float* x; long x_bs; const float* in_scale; const float* in_shift; const float* w_dw; const float* b_dw;

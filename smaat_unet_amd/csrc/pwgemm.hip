@@ -14,11 +14,20 @@
 // (cols), so that for a fixed accumulator register the 32 lanes of a half-wave hold 32
 // consecutive pixels of one output channel -> every global store is a full 128 B row.
 #include "common.h"
+#include <stdlib.h>
 
 #define KC 16       // contraction rows staged per chunk
 #define SMAX 768    // staged floats per input channel (3 per thread)
 #define SMAXW 512   // same for the weight-gradient kernel (64-pixel sub tiles, 2 per thread)
 #define PSW 64      // pixels per sub tile in the weight-gradient kernel
+#ifndef DWUNROLL
+#define DWUNROLL 2
+#endif
+#ifndef TAPS_SMEM
+#define TAPS_SMEM 0  // depthwise taps: 1 = scalar loads (constant address space), 0 = staged through LDS (measured faster)
+#endif
+typedef const float __attribute__((address_space(4))) cfloat;
+#define SMAX_WS 512 // staged floats per input channel in the wave-specialised kernel (fixed stride)
 
 struct PwArgs {
     const float* x;
@@ -35,6 +44,7 @@ struct PwArgs {
     float* y_out;  // [N][Kdim][P] or null: depthwise output side product (kept for the weight gradient)
     int N, Cin, kpl, Kdim, M, nco, sstride;
     TileGeom g;
+    int dbg;  // timing ablations only (SMAAT_PW_ABLATE): 1 = consumers skip the MFMAs, 2 = producers idle
 };
 
 // MODE 0: B operand rows are loaded straight from global (plain pointwise conv / dgrad)
@@ -312,6 +322,705 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
         }
         __syncthreads();
         for (int t = tid; t < 2 * COT; t += SMAAT_THREADS) {
+            const int which = t / COT, col = t - which * COT;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < WPX; ++w) v += stat[(w * 2 + which) * COT + col];
+            const int m = co0 + col;
+            if (m < a.M) a.part[((long)which * g.T + ptg) * a.M + m] = v;
+        }
+    }
+}
+
+// =====================================================================================
+// Wave-specialised variant of k_pwgemm: 4 CONSUMER waves (one per SIMD) do nothing but
+// ds_read + v_mfma_f32_32x32x2_f32 on chunk i, while NPT/64 PRODUCER waves stage chunk i+1
+// (halo tile -> LDS -> depthwise 3x3 in VALU -> B-operand rows, weight slab) and keep the
+// global loads of chunks i+2 / i+3 in flight.  All LDS buffers are double buffered, so there
+// is exactly ONE workgroup barrier per 16-row chunk and the matrix pipe and the VALU/LDS/VMEM
+// pipes of a SIMD work on different chunks at the same time (CDNA4 issues MFMA and VALU of
+// different waves concurrently).
+//   iteration i:   consumers  M(i)      : Yl[i&1], Wl[i&1] -> MFMA
+//                  producers  D(i+1)    : S[(i+1)&1] -> depthwise -> Yl[(i+1)&1]
+//                             Wc(i+1)   : weight registers -> Wl[(i+1)&1];  issue loads W(i+2)
+//                             Sc(i+2)   : halo registers   -> S[i&1];       issue loads S(i+3)
+//                  barrier
+// =====================================================================================
+template <int WCO, int CT, int WPX, int PXT, int MODE, int NPT>
+__global__ __launch_bounds__(256 + NPT) void k_pwgemm_ws(const PwArgs a) {
+    constexpr bool DW = MODE > 0;
+    constexpr int KPL = DW ? MODE : 1;
+    constexpr int KCI = KC / KPL;  // input channels per chunk (DW)
+    constexpr int COT = WCO * CT * 32;
+    constexpr int PT = WPX * PXT * 32;
+    constexpr int NTH = 256 + NPT;
+    constexpr int G = NPT / PT;         // producer channel sub-groups
+    constexpr int NW = KC * COT / NPT;  // weight-slab elements per producer thread
+    constexpr int NY = KC / G;          // MODE 0: B rows per producer thread
+    constexpr int SST = SMAX_WS;                // staged floats per input channel (fixed LDS stride)
+    constexpr int NS = SST / NPT;               // staged halo elements per producer thread and channel
+    static_assert(WCO * WPX == 4, "4 consumer waves");
+    static_assert(NPT % PT == 0 && KC % G == 0 && (KC * COT) % NPT == 0 && SST % NPT == 0, "producer mapping");
+    static_assert(!DW || (KCI % G == 0), "depthwise mapping");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Yl = smem;                   // [2][KC][PT]
+    float* Wl = Yl + 2 * KC * PT;       // [2][KC][COT]
+    float* DWl = Wl + 2 * KC * COT;     // [2][256]: per chunk [KC][12] = 9 depthwise taps, bias, 2 pad
+    float* stat = DWl + 2 * 256;        // [WPX][2][COT]
+    int* pixoff = (int*)(stat + WPX * 2 * COT);  // [PT]
+    int* sidx = pixoff + PT;            // [PT]
+    float* biasl = (float*)(sidx + PT); // [COT]
+    float* S = biasl + COT;             // [2][KCI][sstride]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wv >= 4;
+    const int wave = wv & 3;
+    const int wco = wave % WCO, wpx = wave / WCO;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int ptid = producer ? tid - 256 : 0;  // producer thread index
+    const TileGeom& g = a.g;
+
+    // XCD-aware block map: the co tiles of one pixel tile run back to back on ONE XCD.
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int cot = idx % a.nco;
+    const int ptg = (idx / a.nco) * 8 + xcd;
+    if (ptg >= g.T) return;
+    const int n = ptg / g.tiles_per_img, tl = ptg - n * g.tiles_per_img;
+    const int co0 = cot * COT;
+    const StageRegion rg = stage_region(g, tl);
+    constexpr int sstride = SST;
+    if (tid < COT) {
+        const int m = co0 + tid;
+        const float* bp = a.bias ? a.bias : a.wt;
+        const float v = bp[m < a.M ? m : 0];
+        biasl[tid] = (a.bias && m < a.M) ? v : 0.f;
+    }
+    for (int i = tid; i < PT; i += NTH) {
+        int r, c;
+        const bool v = tile_pixel(g, tl, i, r, c);
+        pixoff[i] = v ? r * g.W + c : -1;
+        sidx[i] = v ? (r - rg.row_lo) * rg.SW + (c - rg.col_lo) : (rg.SW + 1);
+    }
+    int goff[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) goff[j] = -2;
+    if (DW) {
+        const int rsize = rg.nrows * rg.SW;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int e = ptid + NPT * j;
+            if (e < rsize) {
+                const int sr = e / rg.SW, sc = e - sr * rg.SW;
+                const int gr = rg.row_lo + sr, gc = rg.col_lo + sc;
+                goff[j] = (gr >= 0 && gr < g.H && gc >= 0 && gc < g.W) ? gr * g.W + gc : -1;
+            }
+        }
+    }
+
+    const int nchunks = (a.Kdim + KC - 1) / KC;
+    const int pi = ptid % PT;
+    const int g0 = __builtin_amdgcn_readfirstlane(ptid / PT);
+    __syncthreads();  // pixoff / sidx / biasl visible
+    const int po = pixoff[pi];
+    const float* xn = a.x + (long)n * a.x_bs;
+
+    float sreg[DW ? KCI : 1][NS];
+    float yreg[DW ? 1 : NY];
+    float wreg[NW];
+    int gsafe[NS];
+    bool gm[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        gm[j] = goff[j] >= 0;
+        gsafe[j] = gm[j] ? goff[j] : 0;
+    }
+    const int po_s = po >= 0 ? po : 0;
+    int wk_[NW], wm_[NW];
+    bool wmv[NW];
+#pragma unroll
+    for (int r = 0; r < NW; ++r) {
+        const int e = ptid + NPT * r;
+        wk_[r] = e / COT;
+        const int m = co0 + (e - wk_[r] * COT);
+        wmv[r] = m < a.M;
+        wm_[r] = wmv[r] ? m : a.M - 1;
+    }
+    // depthwise taps + bias of the chunk travel with the halo tile (same pipeline stage as S:
+    // committed one barrier before the depthwise stage that reads them): slot (k, t) of [KC][12],
+    // t < 9 tap, t == 9 bias.  (Read from global inside the depthwise stage they would be
+    // per-channel dependent L2 round trips: the pointers are not provably read-only, so hipcc
+    // cannot use scalar loads for them.)
+    const int dwi = ptid & 255;
+    const int dwk = dwi / 12, dwt = dwi - dwk * 12;
+    const float* dwsrc = (dwt < 9) ? a.w_dw : (a.b_dw ? a.b_dw : a.w_dw);
+    const int dwmul = (dwt < 9) ? 9 : 1, dwadd = (dwt < 9) ? dwt : 0;
+    const bool dwvalid = DW && (dwk < KC) && (dwt < 9 || (dwt == 9 && a.b_dw != nullptr));
+    float dwreg = 0.f;
+    // ---- producer stages (loads are unconditional on clamped addresses; masks at commit) ----
+    auto clampc = [&](int ch) { return ch < nchunks ? ch : nchunks - 1; };
+    auto prefetch_b = [&](int ch_) {  // halo tile (DW) or B rows (plain) of chunk ch -> registers
+        const int k0 = clampc(ch_) * KC;
+        if (DW) {
+            const int ci0 = k0 / KPL;
+#pragma unroll
+            for (int cl = 0; cl < KCI; ++cl) {
+                const int ci = ci0 + cl;
+                const float* plane = xn + (long)(ci < a.Cin ? ci : a.Cin - 1) * g.P;
+#pragma unroll
+                for (int j = 0; j < NS; ++j) sreg[cl][j] = plane[gsafe[j]];
+            }
+            if (!TAPS_SMEM) {
+                const int kg = k0 + (dwk < KC ? dwk : 0);
+                dwreg = dwsrc[(kg < a.Kdim ? kg : a.Kdim - 1) * dwmul + dwadd];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < NY; ++r) {
+                const int kg = k0 + g0 + r * G;
+                yreg[r] = xn[(long)(kg < a.Kdim ? kg : a.Kdim - 1) * g.P + po_s];
+            }
+        }
+    };
+    auto prefetch_w = [&](int ch_) {
+        const int k0 = clampc(ch_) * KC;
+#pragma unroll
+        for (int r = 0; r < NW; ++r) {
+            const int kg = k0 + wk_[r];
+            wreg[r] = a.wt[(long)(kg < a.Kdim ? kg : a.Kdim - 1) * a.M + wm_[r]];
+        }
+    };
+    auto commit_w = [&](int ch_, int buf) {
+        const int k0 = clampc(ch_) * KC;
+        float* Wb = Wl + buf * (KC * COT);
+#pragma unroll
+        for (int r = 0; r < NW; ++r) Wb[ptid + NPT * r] = ((k0 + wk_[r]) < a.Kdim && wmv[r]) ? wreg[r] : 0.f;
+    };
+    auto commit_b = [&](int ch_, int buf) {  // registers -> S[buf] (DW) or Yl[buf] (plain)
+        const int k0 = clampc(ch_) * KC;
+        if (DW) {
+            float* Sb = S + buf * (KCI * sstride);
+            const int ci0 = k0 / KPL;
+#pragma unroll
+            for (int cl = 0; cl < KCI; ++cl) {
+                const int ci = ci0 + cl;
+                const bool cv = ci < a.Cin;
+#pragma unroll
+                for (int j = 0; j < NS; ++j) {
+                    float v = sreg[cl][j];
+                    v = (cv && gm[j]) ? v : 0.f;
+                    Sb[cl * sstride + ptid + NPT * j] = v;  // every slot of the stripe is written: no divergent branch
+                }
+            }
+            if (!TAPS_SMEM) DWl[buf * 256 + dwi] = (dwvalid && (k0 + dwk) < a.Kdim) ? dwreg : 0.f;
+        } else {
+            float* Yb = Yl + buf * (KC * PT);
+#pragma unroll
+            for (int r = 0; r < NY; ++r) {
+                const int kg = k0 + g0 + r * G;
+                Yb[(g0 + r * G) * PT + pi] = (kg < a.Kdim && po >= 0) ? yreg[r] : 0.f;
+            }
+        }
+    };
+    auto dwstage = [&](int ch_, int buf) {  // S[buf] -> depthwise 3x3 -> Yl[buf] (+ side output)
+        const int k0 = ch_ * KC;
+        const float* Sb = S + buf * (KCI * sstride);
+        float* Yb = Yl + buf * (KC * PT);
+        const int sb = sidx[pi];
+        const int SW = rg.SW;
+        const bool wy = (a.y_out != nullptr) && (cot == 0) && (po >= 0);
+        const float4* DWb = (const float4*)(DWl + buf * 256);
+        const cfloat* wdw_c = (const cfloat*)a.w_dw;
+        const cfloat* bdw_c = (const cfloat*)(a.b_dw ? a.b_dw : a.w_dw);
+        float* yo = a.y_out + ((long)n * a.Kdim) * g.P + po_s;
+        // partially unrolled on purpose: the accumulators of the consumer role stay allocated
+        // in this role too, so the depthwise stage must stay small in registers
+#pragma unroll DWUNROLL
+        for (int it = 0; it < KCI / G; ++it) {
+            const int cl = g0 + it * G;
+            const float* sp = Sb + cl * sstride + sb;
+            const float s00 = sp[-SW - 1], s01 = sp[-SW], s02 = sp[-SW + 1];
+            const float s10 = sp[-1], s11 = sp[0], s12 = sp[1];
+            const float s20 = sp[SW - 1], s21 = sp[SW], s22 = sp[SW + 1];
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                const int k = cl * KPL + j, kg = k0 + k;
+                const bool kv = kg < a.Kdim;
+                float y;
+                if (TAPS_SMEM) {
+                    // wave-uniform taps through the scalar cache (constant address space -> s_load)
+                    const int kgs = kv ? kg : a.Kdim - 1;
+                    const cfloat* w = wdw_c + kgs * 9;
+                    y = a.b_dw ? bdw_c[kgs] : 0.f;
+                    y = fmaf(w[0], s00, y);
+                    y = fmaf(w[1], s01, y);
+                    y = fmaf(w[2], s02, y);
+                    y = fmaf(w[3], s10, y);
+                    y = fmaf(w[4], s11, y);
+                    y = fmaf(w[5], s12, y);
+                    y = fmaf(w[6], s20, y);
+                    y = fmaf(w[7], s21, y);
+                    y = fmaf(w[8], s22, y);
+                    y = kv ? y : 0.f;
+                } else {
+                    const float4 wa = DWb[k * 3], wb = DWb[k * 3 + 1], wc = DWb[k * 3 + 2];  // zeros when kg >= Kdim
+                    y = wc.y;
+                    y = fmaf(wa.x, s00, y);
+                    y = fmaf(wa.y, s01, y);
+                    y = fmaf(wa.z, s02, y);
+                    y = fmaf(wa.w, s10, y);
+                    y = fmaf(wb.x, s11, y);
+                    y = fmaf(wb.y, s12, y);
+                    y = fmaf(wb.z, s20, y);
+                    y = fmaf(wb.w, s21, y);
+                    y = fmaf(wc.x, s22, y);
+                }
+                Yb[k * PT + pi] = y;
+                if (wy && kv) yo[(long)kg * g.P] = y;
+            }
+        }
+    };
+    // The two roles run SEPARATE loops (wave-uniform scalar branch on `producer`): the accumulators
+    // exist only on the consumer side, so the register allocation is max(role), not the sum, and the
+    // MFMA chain carries no phi copies.  Every wave executes the same number of barriers.
+    if (producer) {
+        // ---- prologue ----
+        prefetch_b(0);
+        prefetch_w(0);
+        commit_b(0, 0);
+        commit_w(0, 0);
+        prefetch_b(1);
+        prefetch_w(1);
+        __syncthreads();
+        if (DW) {
+            dwstage(0, 0);
+            commit_b(1, 1);
+            prefetch_b(2);
+        }
+        __syncthreads();
+        // ---- main loop: one barrier per chunk ----
+        for (int i = 0; i < nchunks; ++i) {
+            if (i + 1 < nchunks && (a.dbg & 3) != 2) {
+                const int nb = (i + 1) & 1;
+                if (DW) {
+                    // commits first (their loads were issued one iteration ago), then the new loads,
+                    // then the LDS-only depthwise stage: nothing waits on a freshly issued load
+                    commit_w(i + 1, nb);
+                    commit_b(i + 2, i & 1);
+                    prefetch_w(i + 2);
+                    prefetch_b(i + 3);
+                    dwstage(i + 1, nb);
+                } else {
+                    commit_b(i + 1, nb);
+                    commit_w(i + 1, nb);
+                    prefetch_b(i + 2);
+                    prefetch_w(i + 2);
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        f32x16 acc[CT][PXT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PXT; ++pt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
+        __syncthreads();
+        __syncthreads();
+        if (a.dbg & 8) __builtin_amdgcn_s_setprio(3);  // experiment: matrix waves win issue arbitration
+        for (int i = 0; i < nchunks; ++i) {
+            const float* Wb = Wl + (i & 1) * (KC * COT);
+            const float* Yb = Yl + (i & 1) * (KC * PT);
+            // fragments of step kk+1 are read while the MFMAs of step kk run (two register sets)
+            float av[2][CT], bv[2][PXT];
+            const float* wp = Wb + half * COT + wco * CT * 32 + l31;
+            const float* yp = Yb + half * PT + wpx * PXT * 32 + l31;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) av[0][ct] = wp[ct * 32];
+#pragma unroll
+            for (int pt = 0; pt < PXT; ++pt) bv[0][pt] = yp[pt * 32];
+            if ((a.dbg & 3) != 1)
+#pragma unroll
+            for (int kk = 0; kk < KC / 2; ++kk) {
+                if (kk + 1 < KC / 2) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) av[(kk + 1) & 1][ct] = wp[(2 * kk + 2) * COT + ct * 32];
+#pragma unroll
+                    for (int pt = 0; pt < PXT; ++pt) bv[(kk + 1) & 1][pt] = yp[(2 * kk + 2) * PT + pt * 32];
+                }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < PXT; ++pt)
+                        acc[ct][pt] =
+                            __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][ct], bv[kk & 1][pt], acc[ct][pt], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+
+        // ---- epilogue (consumer waves): bias + coalesced row stores, BatchNorm partials ----
+        int off[PXT];
+#pragma unroll
+        for (int pt = 0; pt < PXT; ++pt) off[pt] = pixoff[(wpx * PXT + pt) * 32 + l31];
+        float* obase = a.out + (long)n * a.out_bs;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = (wco * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int m = co0 + col;
+                if (m < a.M) {
+                    const float bvv = biasl[col];
+                    float* rowp = obase + (long)m * g.P;
+#pragma unroll
+                    for (int pt = 0; pt < PXT; ++pt)
+                        if (off[pt] >= 0) rowp[off[pt]] = acc[ct][pt][r] + bvv;
+                }
+            }
+        }
+        if (a.part) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float s = 0.f, q = 0.f;
+#pragma unroll
+                    for (int pt = 0; pt < PXT; ++pt) {
+                        const float v = (off[pt] >= 0) ? acc[ct][pt][r] : 0.f;
+                        s += v;
+                        q = fmaf(v, v, q);
+                    }
+                    s = half32_sum_hi(s);
+                    q = half32_sum_hi(q);
+                    if (l31 == 16 + r) {
+                        const int col = (wco * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        stat[(wpx * 2 + 0) * COT + col] = s;
+                        stat[(wpx * 2 + 1) * COT + col] = q;
+                    }
+                }
+            }
+        }
+    }
+    if (a.part) {
+        __syncthreads();
+        for (int t = tid; t < 2 * COT; t += NTH) {
+            const int which = t / COT, col = t - which * COT;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < WPX; ++w) v += stat[(w * 2 + which) * COT + col];
+            const int m = co0 + col;
+            if (m < a.M) a.part[((long)which * g.T + ptg) * a.M + m] = v;
+        }
+    }
+}
+
+// =====================================================================================
+// k_dsconv_strip: wave-specialised fused depthwise->pointwise forward for 2-D pixel tiles
+// (TH x TW pixels, TH % 4 == 0, W % 4 == 0, 16-B aligned planes).  Same pipeline and consumer
+// as k_pwgemm_ws; the PRODUCER is rebuilt around instruction count, its real limit:
+//   * the halo tile is staged as aligned float4 columns [c0-4, c0+TW+4) x rows [r0-1, r0+TH]:
+//     one global_load_dwordx4 + one ds_write_b128 per 4 staged floats;
+//   * the depthwise stage works on STRIPS of 4 vertically adjacent pixels of one input channel:
+//     18 LDS reads (6 rows x 3 columns) feed 4 pixels x kpl outputs (2.25 reads per output
+//     instead of 9), and the 9 taps + bias of an output channel are read once per strip.
+// =====================================================================================
+template <int WCO, int CT, int WPX, int PXT, int KPL, int NPT>
+__global__ __launch_bounds__(256 + NPT) void k_dsconv_strip(const PwArgs a) {
+    constexpr int KCI = KC / KPL;
+    constexpr int COT = WCO * CT * 32;
+    constexpr int PT = WPX * PXT * 32;
+    constexpr int NTH = 256 + NPT;
+    constexpr int NW = KC * COT / NPT;
+    constexpr int SST = SMAX_WS;                      // floats per staged channel
+    constexpr int NSL = (KCI * 108 + NPT - 1) / NPT;  // float4 staging slots per producer thread
+    constexpr int SPC = PT / 4;                       // strips per input channel
+    constexpr int TASKS = KCI * SPC;                  // strip tasks per chunk
+    constexpr int NTK = (TASKS + NPT - 1) / NPT;      // strip tasks per producer thread
+    static_assert(WCO * WPX == 4, "4 consumer waves");
+    static_assert((KC * COT) % NPT == 0 && TASKS % 64 == 0, "producer mapping");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Yl = smem;                   // [2][KC][PT]
+    float* Wl = Yl + 2 * KC * PT;       // [2][KC][COT]
+    float* DWl = Wl + 2 * KC * COT;     // [2][256]: per chunk [KC][12] = 9 taps, bias, 2 pad
+    float* stat = DWl + 2 * 256;        // [WPX][2][COT]
+    int* pixoff = (int*)(stat + WPX * 2 * COT);  // [PT]
+    float* biasl = (float*)(pixoff + PT);        // [COT]
+    float* S = biasl + COT;             // [2][KCI][SST]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wv >= 4;
+    const int wave = wv & 3;
+    const int wco = wave % WCO, wpx = wave / WCO;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int ptid = producer ? tid - 256 : 0;
+    const TileGeom& g = a.g;
+
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int cot = idx % a.nco;
+    const int ptg = (idx / a.nco) * 8 + xcd;
+    if (ptg >= g.T) return;
+    const int n = ptg / g.tiles_per_img, tl = ptg - n * g.tiles_per_img;
+    const int co0 = cot * COT;
+    const int TW = g.TW, TH = g.TH;
+    const int twl = __builtin_ctz(TW);
+    const int ty = tl / g.tiles_x, tx = tl - ty * g.tiles_x;
+    const int r0 = ty * TH, c0 = tx * TW;
+    const int stride = a.sstride;       // staged row stride (floats, multiple of 4)
+    const int nrow = TH + 2, ncol4 = (TW + 8) >> 2;
+    if (tid < COT) {
+        const int m = co0 + tid;
+        const float* bp = a.bias ? a.bias : a.wt;
+        const float v = bp[m < a.M ? m : 0];
+        biasl[tid] = (a.bias && m < a.M) ? v : 0.f;
+    }
+    for (int i = tid; i < PT; i += NTH) {
+        const int r = r0 + (i >> twl), c = c0 + (i & (TW - 1));
+        pixoff[i] = (r < g.H && c < g.W) ? r * g.W + c : -1;
+    }
+    const int nchunks = (a.Kdim + KC - 1) / KC;
+    const float* xn = a.x + (long)n * a.x_bs;
+
+    // ---- producer-side invariants ----
+    int s_cl[NSL], s_in[NSL], s_lo[NSL];
+    bool s_ok[NSL];
+    {
+        const int per = nrow * ncol4, F = KCI * per;
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) {
+            const int f = (ptid + NPT * j) % F;  // surplus slots re-stage a valid element: no branches
+            const int cl = f / per, rem = f - cl * per;
+            const int rr = rem / ncol4, q = rem - rr * ncol4;
+            const int gr = r0 - 1 + rr, gc = c0 - 4 + 4 * q;
+            const bool ok = gr >= 0 && gr < g.H && gc >= 0 && gc < g.W;
+            s_cl[j] = cl;
+            s_in[j] = ok ? gr * g.W + gc : 0;
+            s_lo[j] = cl * SST + rr * stride + 4 * q;
+            s_ok[j] = ok;
+        }
+    }
+    int t_cl[NTK], t_sb[NTK], t_px[NTK], t_go[NTK], t_gr[NTK];
+    bool t_cok[NTK];
+#pragma unroll
+    for (int u = 0; u < NTK; ++u) {
+        const int t = ptid + NPT * u;
+        const int cl = (t / SPC) % KCI, sidx_ = t % SPC;  // (% KCI keeps surplus tasks in range; they are skipped)
+        const int rgp = sidx_ >> twl, c = sidx_ & (TW - 1);
+        t_cl[u] = cl;
+        t_sb[u] = cl * SST + (rgp * 4) * stride + c + 3;
+        t_px[u] = (rgp * 4) * TW + c;
+        t_gr[u] = r0 + rgp * 4;
+        t_go[u] = (r0 + rgp * 4) * g.W + c0 + c;
+        t_cok[u] = (c0 + c) < g.W;
+    }
+    int wk_[NW], wm_[NW];
+    bool wmv[NW];
+#pragma unroll
+    for (int r = 0; r < NW; ++r) {
+        const int e = ptid + NPT * r;
+        wk_[r] = e / COT;
+        const int m = co0 + (e - wk_[r] * COT);
+        wmv[r] = m < a.M;
+        wm_[r] = wmv[r] ? m : a.M - 1;
+    }
+    const int dwi = ptid & 255;
+    const int dwk = dwi / 12, dwt = dwi - dwk * 12;
+    const float* dwsrc = (dwt < 9) ? a.w_dw : (a.b_dw ? a.b_dw : a.w_dw);
+    const int dwmul = (dwt < 9) ? 9 : 1, dwadd = (dwt < 9) ? dwt : 0;
+    const bool dwvalid = (dwk < KC) && (dwt < 9 || (dwt == 9 && a.b_dw != nullptr));
+    float dwreg = 0.f;
+    float4 sreg[NSL];
+    float wreg[NW];
+
+    auto clampc = [&](int ch) { return ch < nchunks ? ch : nchunks - 1; };
+    auto prefetch_b = [&](int ch_) {
+        const int ci0 = clampc(ch_) * KCI;
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) {
+            const int ci = ci0 + s_cl[j];
+            sreg[j] = *(const float4*)(xn + (long)(ci < a.Cin ? ci : a.Cin - 1) * g.P + s_in[j]);
+        }
+        const int kg = clampc(ch_) * KC + (dwk < KC ? dwk : 0);
+        dwreg = dwsrc[(kg < a.Kdim ? kg : a.Kdim - 1) * dwmul + dwadd];
+    };
+    auto commit_b = [&](int ch_, int buf) {
+        const int ci0 = clampc(ch_) * KCI;
+        float* Sb = S + buf * (KCI * SST);
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) {
+            const bool ok = s_ok[j] && (ci0 + s_cl[j]) < a.Cin;
+            float4 v = sreg[j];
+            v.x = ok ? v.x : 0.f;
+            v.y = ok ? v.y : 0.f;
+            v.z = ok ? v.z : 0.f;
+            v.w = ok ? v.w : 0.f;
+            *(float4*)(Sb + s_lo[j]) = v;
+        }
+        DWl[buf * 256 + dwi] = (dwvalid && (clampc(ch_) * KC + dwk) < a.Kdim) ? dwreg : 0.f;
+    };
+    auto prefetch_w = [&](int ch_) {
+        const int k0 = clampc(ch_) * KC;
+#pragma unroll
+        for (int r = 0; r < NW; ++r) {
+            const int kg = k0 + wk_[r];
+            wreg[r] = a.wt[(long)(kg < a.Kdim ? kg : a.Kdim - 1) * a.M + wm_[r]];
+        }
+    };
+    auto commit_w = [&](int ch_, int buf) {
+        const int k0 = clampc(ch_) * KC;
+        float* Wb = Wl + buf * (KC * COT);
+#pragma unroll
+        for (int r = 0; r < NW; ++r) Wb[ptid + NPT * r] = ((k0 + wk_[r]) < a.Kdim && wmv[r]) ? wreg[r] : 0.f;
+    };
+    auto dwstage = [&](int ch_, int buf) {
+        const int k0 = ch_ * KC;
+        const float* Sb = S + buf * (KCI * SST);
+        float* Yb = Yl + buf * (KC * PT);
+        const float4* DWb = (const float4*)(DWl + buf * 256);
+        const bool wy = (a.y_out != nullptr) && (cot == 0);
+        float* yo = a.y_out + ((long)n * a.Kdim) * g.P;
+#pragma unroll
+        for (int u = 0; u < NTK; ++u) {
+            if (NTK * NPT == TASKS || (ptid + NPT * u) < TASKS) {  // wave-uniform (TASKS % 64 == 0)
+                const float* sp = Sb + t_sb[u];
+                float v[6][3];
+#pragma unroll
+                for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+                    for (int dc = 0; dc < 3; ++dc) v[rr][dc] = sp[rr * stride + dc];
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+                    const int k = t_cl[u] * KPL + j, kg = k0 + k;
+                    const float4 wa = DWb[k * 3], wb = DWb[k * 3 + 1], wc = DWb[k * 3 + 2];  // zeros when kg >= Kdim
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float y = wc.y;
+                        y = fmaf(wa.x, v[i][0], y);
+                        y = fmaf(wa.y, v[i][1], y);
+                        y = fmaf(wa.z, v[i][2], y);
+                        y = fmaf(wa.w, v[i + 1][0], y);
+                        y = fmaf(wb.x, v[i + 1][1], y);
+                        y = fmaf(wb.y, v[i + 1][2], y);
+                        y = fmaf(wb.z, v[i + 2][0], y);
+                        y = fmaf(wb.w, v[i + 2][1], y);
+                        y = fmaf(wc.x, v[i + 2][2], y);
+                        Yb[k * PT + t_px[u] + i * TW] = y;
+                        if (wy && kg < a.Kdim && t_cok[u] && (t_gr[u] + i) < g.H)
+                            yo[(long)kg * g.P + t_go[u] + i * g.W] = y;
+                    }
+                }
+            }
+        }
+    };
+
+    if (producer) {
+        prefetch_b(0);
+        prefetch_w(0);
+        commit_b(0, 0);
+        commit_w(0, 0);
+        prefetch_b(1);
+        prefetch_w(1);
+        __syncthreads();
+        dwstage(0, 0);
+        commit_b(1, 1);
+        prefetch_b(2);
+        __syncthreads();
+        for (int i = 0; i < nchunks; ++i) {
+            if (i + 1 < nchunks && (a.dbg & 3) != 2) {
+                const int nb = (i + 1) & 1;
+                commit_w(i + 1, nb);
+                commit_b(i + 2, i & 1);
+                prefetch_w(i + 2);
+                prefetch_b(i + 3);
+                dwstage(i + 1, nb);
+            }
+            __syncthreads();
+        }
+    } else {
+        f32x16 acc[CT][PXT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PXT; ++pt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
+        __syncthreads();
+        __syncthreads();
+        for (int i = 0; i < nchunks; ++i) {
+            const float* Wb = Wl + (i & 1) * (KC * COT);
+            const float* Yb = Yl + (i & 1) * (KC * PT);
+            float av[2][CT], bv[2][PXT];
+            const float* wp = Wb + half * COT + wco * CT * 32 + l31;
+            const float* yp = Yb + half * PT + wpx * PXT * 32 + l31;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) av[0][ct] = wp[ct * 32];
+#pragma unroll
+            for (int pt = 0; pt < PXT; ++pt) bv[0][pt] = yp[pt * 32];
+            if ((a.dbg & 3) != 1)
+#pragma unroll
+            for (int kk = 0; kk < KC / 2; ++kk) {
+                if (kk + 1 < KC / 2) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) av[(kk + 1) & 1][ct] = wp[(2 * kk + 2) * COT + ct * 32];
+#pragma unroll
+                    for (int pt = 0; pt < PXT; ++pt) bv[(kk + 1) & 1][pt] = yp[(2 * kk + 2) * PT + pt * 32];
+                }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < PXT; ++pt)
+                        acc[ct][pt] =
+                            __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][ct], bv[kk & 1][pt], acc[ct][pt], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+        int off[PXT];
+#pragma unroll
+        for (int pt = 0; pt < PXT; ++pt) off[pt] = pixoff[(wpx * PXT + pt) * 32 + l31];
+        float* obase = a.out + (long)n * a.out_bs;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = (wco * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int m = co0 + col;
+                if (m < a.M) {
+                    const float bvv = biasl[col];
+                    float* rowp = obase + (long)m * g.P;
+#pragma unroll
+                    for (int pt = 0; pt < PXT; ++pt)
+                        if (off[pt] >= 0) rowp[off[pt]] = acc[ct][pt][r] + bvv;
+                }
+            }
+        }
+        if (a.part) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float s = 0.f, q = 0.f;
+#pragma unroll
+                    for (int pt = 0; pt < PXT; ++pt) {
+                        const float v = (off[pt] >= 0) ? acc[ct][pt][r] : 0.f;
+                        s += v;
+                        q = fmaf(v, v, q);
+                    }
+                    s = half32_sum_hi(s);
+                    q = half32_sum_hi(q);
+                    if (l31 == 16 + r) {
+                        const int col = (wco * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        stat[(wpx * 2 + 0) * COT + col] = s;
+                        stat[(wpx * 2 + 1) * COT + col] = q;
+                    }
+                }
+            }
+        }
+    }
+    if (a.part) {
+        __syncthreads();
+        for (int t = tid; t < 2 * COT; t += NTH) {
             const int which = t / COT, col = t - which * COT;
             float v = 0.f;
 #pragma unroll
@@ -719,12 +1428,127 @@ static int launch_pwgemm_cfg(PwArgs& a, bool dw, hipStream_t st) {
     return -1;
 }
 
+// Geometry of the wave-specialised family: a 2-D tile that the strip producer can use when one
+// covers the plane well (>= 85 % of the tile pixels inside the image), else the generic choice.
+static int strip_row_stride(int TW) { return TW + 8 + (TW == 16 ? 4 : 0); }  // 16-wide: +4 spreads the 4 row groups of a wave over the banks
+static void choose_geom_ws(int N, int H, int W, int PT, TileGeom* g) {
+    const int P = H * W;
+    double best = -1.0;
+    int bTW = 0;
+    const int tws[3] = {32, 16, 8};
+    for (int c = 0; c < 3; ++c) {
+        const int TW = tws[c], TH = PT / TW;
+        if (TH < 4 || (TH & 3)) continue;
+        if ((TH + 2) * strip_row_stride(TW) > SMAX_WS) continue;
+        if ((TH + 2) * ((TW + 8) / 4) > 108) continue;
+        const int tx = ceil_div(W, TW), ty = ceil_div(H, TH);
+        const double util = (double)P / ((double)tx * ty * PT);
+        const double sc = util + (TW == 32 ? 0.02 : TW == 16 ? 0.01 : 0.0);
+        if (util >= 0.85 && sc > best) {
+            best = sc;
+            bTW = TW;
+        }
+    }
+    if (bTW == 0) {
+        choose_geom(N, H, W, PT, SMAX_WS, g);
+        return;
+    }
+    g->H = H;
+    g->W = W;
+    g->P = P;
+    g->PT = PT;
+    g->mode = 1;
+    g->TW = bTW;
+    g->TH = PT / bTW;
+    g->tiles_x = ceil_div(W, bTW);
+    g->tiles_per_img = g->tiles_x * ceil_div(H, g->TH);
+    g->T = N * g->tiles_per_img;
+}
+
+static bool strip_ok(const PwArgs& a) {
+    const TileGeom& g = a.g;
+    if (g.mode != 1 || (g.TH & 3) || g.TH < 4 || (g.W & 3)) return false;
+    if ((g.TH + 2) * strip_row_stride(g.TW) > SMAX_WS || (g.TH + 2) * ((g.TW + 8) / 4) > 108) return false;
+    if ((((uintptr_t)a.x) & 15) || (a.x_bs & 3)) return false;
+    return a.in_scale == nullptr;
+}
+
+template <int WCO, int CT, int WPX, int PXT, int KPL, int NPT>
+static int launch_dsconv_strip_kpl(PwArgs& a, hipStream_t st) {
+    constexpr int COT = WCO * CT * 32, PT = WPX * PXT * 32;
+    constexpr int kci = KC / KPL;
+    a.nco = ceil_div(a.M, COT);
+    a.sstride = strip_row_stride(a.g.TW);
+    const size_t lds = sizeof(float) * (size_t)(2 * KC * PT + 2 * KC * COT + 2 * 256 + WPX * 2 * COT + PT + COT +
+                                                2 * kci * SMAX_WS);
+    const int grid = ceil_div(a.g.T, 8) * 8 * a.nco;
+    constexpr auto kern = k_dsconv_strip<WCO, CT, WPX, PXT, KPL, NPT>;
+    int rc = ensure_lds<kern>(lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 + NPT), lds, st, a);
+    return (int)hipGetLastError();
+}
+
+template <int WCO, int CT, int WPX, int PXT, int NPT>
+static int launch_dsconv_strip(PwArgs& a, hipStream_t st) {
+    switch (a.kpl) {
+        case 1: return launch_dsconv_strip_kpl<WCO, CT, WPX, PXT, 1, NPT>(a, st);
+        case 2: return launch_dsconv_strip_kpl<WCO, CT, WPX, PXT, 2, NPT>(a, st);
+        case 4: return launch_dsconv_strip_kpl<WCO, CT, WPX, PXT, 4, NPT>(a, st);
+    }
+    return -1;
+}
+
+template <int WCO, int CT, int WPX, int PXT, int MODE, int NPT>
+static int launch_pwgemm_ws_mode(PwArgs& a, hipStream_t st) {
+    constexpr int COT = WCO * CT * 32, PT = WPX * PXT * 32;
+    constexpr bool DW = MODE > 0;
+    choose_geom_ws(a.N, a.g.H, a.g.W, PT, &a.g);
+    if (a.g.mode < 0) return -1;
+    a.nco = ceil_div(a.M, COT);
+    a.sstride = SMAX_WS;
+    const int kci = KC / (DW ? MODE : 1);
+    const size_t lds = sizeof(float) * (size_t)(2 * KC * PT + 2 * KC * COT + 2 * 256 + WPX * 2 * COT + 2 * PT + COT +
+                                                (DW ? 2 * kci * SMAX_WS : 0));
+    const int grid = ceil_div(a.g.T, 8) * 8 * a.nco;
+    constexpr auto kern = k_pwgemm_ws<WCO, CT, WPX, PXT, MODE, NPT>;
+    int rc = ensure_lds<kern>(lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 + NPT), lds, st, a);
+    return (int)hipGetLastError();
+}
+
+template <int WCO, int CT, int WPX, int PXT, int NPT>
+static int launch_pwgemm_ws_cfg(PwArgs& a, bool dw, hipStream_t st) {
+    if (!dw) return launch_pwgemm_ws_mode<WCO, CT, WPX, PXT, 0, NPT>(a, st);
+    switch (a.kpl) {
+        case 1: return launch_pwgemm_ws_mode<WCO, CT, WPX, PXT, 1, NPT>(a, st);
+        case 2: return launch_pwgemm_ws_mode<WCO, CT, WPX, PXT, 2, NPT>(a, st);
+        case 4: return launch_pwgemm_ws_mode<WCO, CT, WPX, PXT, 4, NPT>(a, st);
+    }
+    return -1;
+}
+
+// SMAAT_PW_IMPL: 0 = single-role kernel (k_pwgemm), 1 = wave-specialised, 4 producer waves,
+// 2 = wave-specialised with 8 producer waves where the accumulator tile leaves room for them
+static int pw_impl() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("SMAAT_PW_IMPL");
+        v = e ? atoi(e) : 5;
+    }
+    return v;
+}
+
 static bool pw_big(int N, int H, int W) { return (long)N * H * W >= 256L * 1024; }
 
 int smaat_pw_num_slots_impl(int N, int H, int W, int M) {
     // must mirror the tile choice of launch_pwgemm()
     TileGeom g;
-    choose_geom(N, H, W, pw_big(N, H, W) ? 256 : 128, SMAX, &g);
+    if (pw_impl() >= 1)
+        choose_geom_ws(N, H, W, pw_big(N, H, W) ? 256 : 128, &g);
+    else
+        choose_geom(N, H, W, pw_big(N, H, W) ? 256 : 128, SMAX, &g);
     (void)M;
     return g.T;
 }
@@ -732,6 +1556,55 @@ int smaat_pw_num_slots_impl(int N, int H, int W, int M) {
 int launch_pwgemm(PwArgs& a, bool dw, hipStream_t st) {
     if (a.kpl != 1 && a.kpl != 2 && a.kpl != 4) return -1;
     const bool big = pw_big(a.N, a.g.H, a.g.W);
+    {
+        static int abl = -1;
+        if (abl < 0) {
+            const char* e = getenv("SMAAT_PW_ABLATE");
+            abl = e ? atoi(e) : 0;
+        }
+        a.dbg = abl;
+    }
+    const int impl = (dw && a.in_scale != nullptr) ? 0 : pw_impl();  // the input-affine form stays on the single-role kernel
+    // impl 5 (default): per-shape choice measured on MI355X (profiles/r1): the strip producer for
+    // wide co tiles on 2-D pixel tiles, the generic wave-specialised kernel with 8 producer waves
+    // for everything else that has a depthwise stage, and the single-role kernel for the plain
+    // pointwise / data-gradient GEMM (its producer is trivial; 2 co-resident blocks overlap better).
+    if (impl >= 4 && dw) {
+        choose_geom_ws(a.N, a.g.H, a.g.W, big ? 256 : 128, &a.g);
+        if (strip_ok(a) && (a.M > 64 || impl == 4)) {
+            if (a.M > 64) {
+                if (big) return launch_dsconv_strip<2, 2, 2, 4, 256>(a, st);  // 128 x 256
+                return launch_dsconv_strip<2, 2, 2, 2, 256>(a, st);           // 128 x 128
+            }
+            if (big) return launch_dsconv_strip<1, 2, 4, 2, 512>(a, st);  // 64 x 256, 8 producer waves
+            return launch_dsconv_strip<1, 2, 4, 1, 256>(a, st);           // 64 x 128
+        }
+    }
+    if (impl >= 5 && !dw && a.part == nullptr) {  // (with partial statistics the tile geometry must match smaat_pw_num_slots)
+        if (a.M > 64) {
+            if (big) return launch_pwgemm_cfg<2, 2, 2, 4>(a, dw, st);
+            return launch_pwgemm_cfg<2, 2, 2, 2>(a, dw, st);
+        }
+        if (big) return launch_pwgemm_cfg<1, 2, 4, 2>(a, dw, st);
+        return launch_pwgemm_cfg<1, 2, 4, 1>(a, dw, st);
+    }
+    if (impl >= 1) {
+        if (a.M > 64) {
+            if (impl >= 3) {  // 8 producer waves everywhere: more waves to hide the producer's latency chains
+                if (big) return launch_pwgemm_ws_cfg<2, 2, 2, 4, 512>(a, dw, st);
+                return launch_pwgemm_ws_cfg<2, 2, 2, 2, 512>(a, dw, st);
+            }
+            if (big) return launch_pwgemm_ws_cfg<2, 2, 2, 4, 256>(a, dw, st);  // 128 x 256
+            return launch_pwgemm_ws_cfg<2, 2, 2, 2, 256>(a, dw, st);           // 128 x 128
+        }
+        if (impl >= 2) {
+            if (big) return launch_pwgemm_ws_cfg<1, 2, 4, 2, 512>(a, dw, st);  // 64 x 256, 8 producer waves
+            if (impl >= 3) return launch_pwgemm_ws_cfg<1, 2, 4, 1, 512>(a, dw, st);
+            return launch_pwgemm_ws_cfg<1, 2, 4, 1, 256>(a, dw, st);           // 64 x 128
+        }
+        if (big) return launch_pwgemm_ws_cfg<1, 2, 4, 2, 256>(a, dw, st);  // 64 x 256
+        return launch_pwgemm_ws_cfg<1, 2, 4, 1, 256>(a, dw, st);           // 64 x 128
+    }
     if (a.M > 64) {
         if (big) return launch_pwgemm_cfg<2, 2, 2, 4>(a, dw, st);  // 128 x 256
         return launch_pwgemm_cfg<2, 2, 2, 2>(a, dw, st);           // 128 x 128

@@ -84,6 +84,8 @@ DS_SHAPES = [
     (2, 32, 2, 64, 144, 144),   # 16-wide 2D tiles
     (4, 12, 2, 64, 288, 288),   # "big" config (256-pixel tiles, 8x32)
     (4, 8, 2, 128, 288, 288),   # big + 128 co tile
+    (4, 40, 2, 130, 288, 288),  # big, 5 contraction chunks, 2 co tiles (one partial)
+    (4, 20, 2, 40, 288, 288),   # big, 64-wide co tile (partial), 3 chunks
     (1, 4, 2, 16, 100, 100),    # partial 2D tiles
     (2, 24, 2, 32, 4, 4),       # tiny maps (64x64 config bottoms out at 4x4)
     (1, 8, 2, 16, 2, 2),
@@ -115,7 +117,8 @@ def case_pointwise(L, dev, N, C, M, H, W, with_part=False):
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 1, 32, 32), (2, 64, 21, 16, 16), (2, 16, 3, 6, 7), (2, 128, 256, 36, 36),
-                                   (4, 64, 1, 288, 288), (2, 1, 64, 20, 20), (2, 512, 1024, 18, 18)])
+                                   (4, 64, 1, 288, 288), (2, 1, 64, 20, 20), (2, 512, 1024, 18, 18),
+                                   (4, 40, 130, 288, 288)])
 def test_pointwise_fwd(shape):
     both(case_pointwise, *shape)
     both(case_pointwise, *shape, with_part=True)
