@@ -3,6 +3,7 @@
 //   Upsample(x2, bilinear, align_corners=True) + F.pad + cat slice write   :64, :78-85
 //   depthwise 3x3 backward (dX, dW, db)   (nn.Conv2d groups=Cin, models/layers.py:38-44)
 #include "common.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------
 // MaxPool 2x2 (floor mode).  grid: (N*C planes, segments of output pixels)
@@ -325,6 +326,161 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd(const float* __restrict__ x, 
     }
 }
 
+// ---------------------------------------------------------------------------------
+// depthwise 3x3 backward, strip form (W % 4 == 0, 16-B aligned planes).
+// The kernel above spends its time issuing instructions (one pixel per thread: 9 LDS reads and
+// 18 FMAs per pixel and output channel, dword staging).  Here
+//   * the dY halo tile is staged as aligned float4 columns [c0-4, c0+TW+4) x rows [r0-1, r0+TH]
+//     (one global_load_dwordx4 + one ds_write_b128 per 4 floats);
+//   * a thread owns a STRIP of 4 vertically adjacent pixels: 18 LDS reads (6 rows x 3 columns)
+//     per output channel feed 4 pixels of dX and the 9+1 weight/bias accumulators.
+// Same partial-result layout as k_dw3x3_bwd: part[(n*groups + group)][Cdw][10].
+// ---------------------------------------------------------------------------------
+struct DwbGeom {
+    int H, W, P, TH, TW, tiles_x, tiles, stride, nrow, ncol4, ssz;
+};
+
+template <int KPL>
+__global__ __launch_bounds__(256) void k_dw3x3_bwd_strip(const float* __restrict__ x, long x_bs,
+                                                         const float* __restrict__ dy, long dy_bs,
+                                                         const float* __restrict__ w_dw, float* __restrict__ dx,
+                                                         long dx_bs, float* __restrict__ part, int Cin,
+                                                         const DwbGeom g) {
+    constexpr int NSL = 6;  // float4 staging slots per thread: KPL * nrow * ncol4 <= 1536
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    float* S = dsm;                   // [KPL][ssz]
+    float* red = dsm + KPL * g.ssz;   // [4][KPL][10]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int plane = blockIdx.x, n = plane / Cin, ci = plane - n * Cin;
+    const int Cdw = Cin * KPL;
+    const float* xp = x + (long)n * x_bs + (long)ci * g.P;
+    const float* dyp = dy + (long)n * dy_bs + (long)(ci * KPL) * g.P;
+    float* dxp = dx ? dx + (long)n * dx_bs + (long)ci * g.P : nullptr;
+
+    float accw[KPL][10];
+#pragma unroll
+    for (int j = 0; j < KPL; ++j)
+#pragma unroll
+        for (int t = 0; t < 10; ++t) accw[j][t] = 0.f;
+    float wt[KPL][9];
+#pragma unroll
+    for (int j = 0; j < KPL; ++j)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wt[j][t] = w_dw[(ci * KPL + j) * 9 + t];
+
+    // tile-independent thread constants
+    const int per = g.nrow * g.ncol4, F = KPL * per;
+    int s_j[NSL], s_rr[NSL], s_q[NSL], s_lo[NSL];
+#pragma unroll
+    for (int k = 0; k < NSL; ++k) {
+        const int f = (tid + 256 * k) % F;  // surplus slots re-stage a valid element
+        const int jj = f / per, rem = f - jj * per;
+        s_j[k] = jj;
+        s_rr[k] = rem / g.ncol4;
+        s_q[k] = rem - s_rr[k] * g.ncol4;
+        s_lo[k] = jj * g.ssz + s_rr[k] * g.stride + 4 * s_q[k];
+    }
+    const int nstrips = (g.TH >> 2) * g.TW;
+    const int nit = (nstrips + 255) >> 8;  // strips per thread (tiles are as wide as the plane when it fits:
+                                           // every staged row is a run of full cache lines)
+    float4 sv[NSL];
+    bool sok[NSL];
+    auto prefetch = [&](int tl) {
+        const int ty = tl / g.tiles_x, tx = tl - ty * g.tiles_x;
+        const int r0 = ty * g.TH, c0 = tx * g.TW;
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) {
+            const int gr = r0 - 1 + s_rr[k], gc = c0 - 4 + 4 * s_q[k];
+            sok[k] = gr >= 0 && gr < g.H && gc >= 0 && gc < g.W;
+            sv[k] = *(const float4*)(dyp + (long)s_j[k] * g.P + (sok[k] ? gr * g.W + gc : 0));
+        }
+    };
+
+    int tl = blockIdx.y;
+    if (tl < g.tiles) prefetch(tl);
+    for (; tl < g.tiles; tl += gridDim.y) {
+        const int ty = tl / g.tiles_x, tx = tl - ty * g.tiles_x;
+        const int r0 = ty * g.TH, c0 = tx * g.TW;
+        __syncthreads();  // previous tile's reads are done
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) {
+            float4 v = sv[k];
+            v.x = sok[k] ? v.x : 0.f;
+            v.y = sok[k] ? v.y : 0.f;
+            v.z = sok[k] ? v.z : 0.f;
+            v.w = sok[k] ? v.w : 0.f;
+            *(float4*)(S + s_lo[k]) = v;
+        }
+        __syncthreads();
+        {
+            const int tn = tl + gridDim.y;
+            prefetch(tn < g.tiles ? tn : tl);  // in flight during the compute below
+        }
+#pragma unroll 1
+        for (int it = 0; it < nit; ++it) {
+            const int sidx = tid + (it << 8);
+            if (sidx < nstrips) {
+                const int srg = sidx / g.TW, sc = sidx - srg * g.TW;
+                const int sb = (srg * 4) * g.stride + sc + 3;
+                const int prow = r0 + srg * 4;
+                const bool pcol = (c0 + sc) < g.W;
+                const int po = prow * g.W + c0 + sc;
+                float xc[4];
+                bool ok[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ok[i] = pcol && (prow + i) < g.H;
+                    xc[i] = xp[ok[i] ? po + i * g.W : 0];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xc[i] = ok[i] ? xc[i] : 0.f;
+                float dxa[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+                    const float* sp = S + j * g.ssz + sb;
+                    float d[6][3];
+#pragma unroll
+                    for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+                        for (int dc = 0; dc < 3; ++dc) d[rr][dc] = sp[rr * g.stride + dc];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+                            for (int tc = 0; tc < 3; ++tc) {
+                                const float dv = d[i + 2 - tr][2 - tc];  // dY at q - tap offset
+                                dxa[i] = fmaf(wt[j][tr * 3 + tc], dv, dxa[i]);
+                                accw[j][tr * 3 + tc] = fmaf(xc[i], dv, accw[j][tr * 3 + tc]);
+                            }
+                        accw[j][9] += d[i + 1][1];
+                    }
+                }
+                if (dxp) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (ok[i]) dxp[po + i * g.W] = dxa[i];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            const float v = wave_sum_l63(accw[j][t]);
+            if (lane == 63) red[(wave * KPL + j) * 10 + t] = v;
+        }
+    }
+    __syncthreads();
+    if (tid < KPL * 10) {
+        const int j = tid / 10, t = tid - j * 10;
+        const float v = red[(0 * KPL + j) * 10 + t] + red[(1 * KPL + j) * 10 + t] + red[(2 * KPL + j) * 10 + t] +
+                        red[(3 * KPL + j) * 10 + t];
+        part[(((long)n * gridDim.y + blockIdx.y) * Cdw + ci * KPL + j) * 10 + t] = v;
+    }
+}
+
 // split part[N][Cdw][10] (already reduced over N into tmp[Cdw][10]) into dW[Cdw][9], db[Cdw]
 __global__ __launch_bounds__(256) void k_dw_split(const float* __restrict__ tmp, int Cdw, float* __restrict__ dw,
                                                   float* __restrict__ db) {
@@ -398,10 +554,66 @@ int dw_bwd_groups(int N, int Cin, int H, int W) {
 int launch_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, const float* w_dw, float* dx, long dx_bs,
                      float* part, int N, int Cin, int kpl, int H, int W, hipStream_t st) {
     if (kpl < 1 || kpl > DWB_KPL_MAX) return -1;
+    const int groups = dw_bwd_groups(N, Cin, H, W);
+    static int use_strip = -1;
+    if (use_strip < 0) {
+        const char* e = getenv("SMAAT_DWB_STRIP");
+        use_strip = e ? atoi(e) : 1;
+    }
+    const bool aligned = ((W & 3) == 0) && ((x_bs & 3) == 0) && ((dy_bs & 3) == 0) && ((dx_bs & 3) == 0) &&
+                         ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)dy) & 15) == 0) &&
+                         ((((uintptr_t)dx) & 15) == 0) && (kpl == 1 || kpl == 2 || kpl == 4) && H >= 4;
+    if (use_strip && aligned) {
+        DwbGeom sg;
+        sg.H = H;
+        sg.W = W;
+        sg.P = H * W;
+        // widest tile whose staged halo (kpl channels) fits the 6 float4 slots per thread; a tile as wide
+        // as the plane makes every staged row a run of full cache lines
+        const int cand[4] = {W <= 288 ? W : 0, 96, 48, 32};
+        const int hq = (H + 3) / 4;
+        sg.TW = 0;
+        int th0 = 0;
+        for (int c = 0; c < 4 && sg.TW == 0; ++c) {
+            const int tw = cand[c];
+            if (tw <= 0 || tw > W) continue;
+            const int rows = (1536 / kpl) / ((tw + 8) / 4) - 2;
+            th0 = 4 * (rows / 4);
+            if (th0 > 4 * hq) th0 = 4 * hq;
+            if (tw <= 72 && th0 > 4 * (256 / tw)) th0 = 4 * (256 / tw);  // narrow planes: one strip per thread
+            if (th0 >= 4) sg.TW = tw;
+        }
+        if (sg.TW == 0) {
+            sg.TW = W < 32 ? W : 32;
+            th0 = 4;
+        }
+        const int nty = (hq + th0 / 4 - 1) / (th0 / 4);
+        sg.TH = 4 * ((hq + nty - 1) / nty);
+        sg.tiles_x = (W + sg.TW - 1) / sg.TW;
+        sg.tiles = sg.tiles_x * nty;
+        sg.stride = sg.TW + 8;
+        if (((4 * sg.stride) & 31) == 0) sg.stride += 4;   // row groups of one wave on different banks
+        sg.nrow = sg.TH + 2;
+        sg.ncol4 = (sg.TW + 8) / 4;
+        sg.ssz = sg.nrow * sg.stride;
+        if (kpl * sg.nrow * sg.ncol4 <= 1536) {
+            const size_t lds = sizeof(float) * ((size_t)kpl * sg.ssz + 4 * kpl * 10);
+            dim3 grid(N * Cin, groups);
+            if (kpl == 1)
+                hipLaunchKernelGGL(k_dw3x3_bwd_strip<1>, grid, dim3(256), lds, st, x, x_bs, dy, dy_bs, w_dw, dx, dx_bs,
+                                   part, Cin, sg);
+            else if (kpl == 2)
+                hipLaunchKernelGGL(k_dw3x3_bwd_strip<2>, grid, dim3(256), lds, st, x, x_bs, dy, dy_bs, w_dw, dx, dx_bs,
+                                   part, Cin, sg);
+            else
+                hipLaunchKernelGGL(k_dw3x3_bwd_strip<4>, grid, dim3(256), lds, st, x, x_bs, dy, dy_bs, w_dw, dx, dx_bs,
+                                   part, Cin, sg);
+            return (int)hipGetLastError();
+        }
+    }
     TileGeom g;
     choose_geom_pub(N, H, W, 256, DWB_SMAX, &g);
     if (g.mode < 0) return -1;
-    const int groups = dw_bwd_groups(N, Cin, H, W);
     hipLaunchKernelGGL(k_dw3x3_bwd, dim3(N * Cin, groups), dim3(256), 0, st, x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, part,
                        Cin, kpl, g);
     return (int)hipGetLastError();

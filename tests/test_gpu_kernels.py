@@ -178,7 +178,8 @@ def case_dw_bwd(L, dev, N, Cin, kpl, H, W, need_dx=True):
 
 @pytest.mark.parametrize("shape", [(2, 12, 2, 32, 32), (2, 6, 2, 9, 11), (1, 3, 4, 6, 10), (2, 5, 1, 8, 8),
                                    (2, 8, 2, 36, 36), (2, 4, 2, 144, 144), (2, 3, 2, 288, 288), (1, 4, 2, 100, 100),
-                                   (2, 8, 2, 4, 4), (1, 8, 2, 2, 2)])
+                                   (2, 8, 2, 4, 4), (1, 8, 2, 2, 2), (1, 3, 4, 8, 12), (2, 4, 2, 72, 72),
+                                   (1, 5, 2, 10, 12), (1, 2, 2, 50, 64), (1, 2, 1, 21, 48)])
 def test_dw3x3_bwd(shape):
     both(case_dw_bwd, *shape, tol=2e-5)
     both(case_dw_bwd, *shape, need_dx=False, tol=2e-5)
