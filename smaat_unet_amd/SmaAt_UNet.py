@@ -41,9 +41,37 @@ class SmaAt_UNet(nn.Module):
 
         self.outc = OutConv(64, self.n_classes)
 
+    def _fusable(self):
+        """the fused skip wiring bypasses the `forward` of cbamN / downN.maxpool / upN: keep the
+        module-by-module path whenever a user hooked one of them (or uses an exotic configuration)."""
+        mods = [self.cbam1, self.cbam2, self.cbam3, self.cbam4, self.down1, self.down2, self.down3, self.down4,
+                self.up1, self.up2, self.up3, self.up4]
+        for top in mods:
+            for mm in top.modules():
+                if mm._forward_hooks or mm._forward_pre_hooks or mm._backward_hooks:
+                    return False
+        return self.bilinear
+
     def forward(self, x):
         # NB (reference :41-57): the encoder continues from the UN-attended x_i; the CBAM
         # outputs feed only the skip connections and the bottleneck.
+        if not self._fusable():
+            return self._forward_modular(x)
+        ups = (self.up4, self.up3, self.up2, self.up1)
+        cats = []
+        h = self.inc(x)
+        for cbam, down, up in zip((self.cbam1, self.cbam2, self.cbam3, self.cbam4),
+                                  (self.down1, self.down2, self.down3, self.down4), ups):
+            c_extra = up.conv.double_conv[0].depthwise.in_channels - h.shape[1]
+            cat, pooled = cbam.forward_pool_cat(h, c_extra)   # skip written straight into the decoder's cat buffer
+            cats.append(cat)
+            h = down.maxpool_conv[1](pooled)
+        h = self.cbam5(h)
+        for up, cat in zip(reversed(ups), reversed(cats)):
+            h = up.forward_into(h, cat)
+        return self.outc(h)
+
+    def _forward_modular(self, x):
         x1 = self.inc(x)
         x1Att = self.cbam1(x1)
         x2 = self.down1(x1)

@@ -131,29 +131,44 @@ __global__ __launch_bounds__(256) void k_upsample2x_bwd(const float* __restrict_
         int plo = 2 * w - 2, phi = 2 * w + 3;
         if (plo < 0) plo = 0;
         if (phi > W2 - 1) phi = W2 - 1;
+        // column taps of this input pixel, computed once (not once per candidate row)
+        float wcv[6];
+        int gcv[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int ocol = plo + t;
+            int c0, c1;
+            float b0, b1;
+            ac_coef(ocol < W2 ? ocol : W2 - 1, sw, W, c0, c1, b0, b1);
+            float wc = 0.f;
+            if (c0 == w) wc += b0;
+            if (c1 == w) wc += b1;
+            const int gc = ocol + pad_l;
+            const bool v = ocol <= phi && gc >= 0 && gc < Wo;
+            wcv[t] = v ? wc : 0.f;
+            gcv[t] = v ? gc : 0;
+        }
         float acc = 0.f;
-        for (int orow = olo; orow <= ohi; ++orow) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int orow = olo + u;
             int r0, r1;
             float a0, a1;
-            ac_coef(orow, sh, H, r0, r1, a0, a1);
+            ac_coef(orow < H2 ? orow : H2 - 1, sh, H, r0, r1, a0, a1);
             float wr = 0.f;
             if (r0 == h) wr += a0;
             if (r1 == h) wr += a1;
-            if (wr == 0.f) continue;
             const int gr = orow + pad_t;
-            if (gr < 0 || gr >= Ho) continue;
-            float rowacc = 0.f;
-            for (int ocol = plo; ocol <= phi; ++ocol) {
-                int c0, c1;
-                float b0, b1;
-                ac_coef(ocol, sw, W, c0, c1, b0, b1);
-                float wc = 0.f;
-                if (c0 == w) wc += b0;
-                if (c1 == w) wc += b1;
-                const int gc = ocol + pad_l;
-                if (wc != 0.f && gc >= 0 && gc < Wo) rowacc = fmaf(wc, gp[gr * Wo + gc], rowacc);
+            const bool rv = orow <= ohi && gr >= 0 && gr < Ho;
+            wr = rv ? wr : 0.f;
+            if (wr != 0.f) {
+                const float* grow = gp + (long)gr * Wo;
+                float rowacc = 0.f;
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+                    if (wcv[t] != 0.f) rowacc = fmaf(wcv[t], grow[gcv[t]], rowacc);
+                acc = fmaf(wr, rowacc, acc);
             }
-            acc = fmaf(wr, rowacc, acc);
         }
         dp[p] = acc;
     }

@@ -107,3 +107,12 @@ class CBAM(nn.Module):
         sp = self.spatial_att
         g, b, rm, rv, training, momentum, eps = _bn_args(sp.bn)
         return ops.cbam(x, w1, b1, w2, b2, sp.conv.weight, g, b, rm, rv, training, momentum, eps, True, True)
+
+    def forward_pool_cat(self, x, c_extra):
+        """(cat, pooled): CBAM(x) written into channels [0, C) of a fresh [N, C + c_extra, H, W]
+        concatenation buffer, and maxpool2(x) -- the two consumers of an encoder level in
+        SmaAt_UNet.forward, sharing one backward pass over x."""
+        w1, b1, w2, b2 = self.channel_att._mlp_params()
+        sp = self.spatial_att
+        g, b, rm, rv, training, momentum, eps = _bn_args(sp.bn)
+        return ops.cbam_pool_cat(x, w1, b1, w2, b2, sp.conv.weight, g, b, rm, rv, training, momentum, eps, c_extra)

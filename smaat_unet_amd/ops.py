@@ -409,141 +409,249 @@ def upsample_cat(x1, x2):
 # --------------------------------------------------------------------------------------
 # CBAM (channel attention and/or spatial attention)
 # --------------------------------------------------------------------------------------
+def _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, use_ch, use_sp,
+                       out=None):
+    """out = spatial_att(channel_att(x)); `out` may be a channel slice of a larger buffer (dense
+    planes, any batch stride).  Returns (out, saved tensors, flags)."""
+    _check(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv)
+    L = _lib.get()
+    x, x_bs = _planes(x)
+    n, c, h, w = x.shape
+    p = h * w
+    s_ = _stream(x)
+    dev = x
+    if use_ch:
+        cr = w1.shape[0]
+        w1 = w1.contiguous()
+        w2 = w2.contiguous()
+        avg = _new(dev, n, c)
+        mx = _new(dev, n, c)
+        amax = _new(dev, n, c, dtype=torch.int32)
+        _lib.check(L.smaat_cbam_chpool(_ptr(x), x_bs, n, c, p, _ptr(avg), _ptr(mx), _ptr(amax), s_),
+                   "smaat_cbam_chpool")
+        ha = _new(dev, n, cr)
+        hm = _new(dev, n, cr)
+        sc = _new(dev, n, c)
+        _lib.check(L.smaat_cbam_mlp(_ptr(avg), _ptr(mx), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), n, c, cr,
+                                    _ptr(ha), _ptr(hm), _ptr(sc), s_), "smaat_cbam_mlp")
+    else:
+        avg = mx = amax = ha = hm = None
+        sc = torch.ones(n, c, dtype=torch.float32, device=x.device)
+    if use_sp:
+        wconv = wconv.contiguous()
+        ks = wconv.shape[-1]
+        maps = _new(dev, n, 2, h, w)
+        _lib.check(L.smaat_cbam_sppool(_ptr(x), x_bs, _ptr(sc), n, c, p, _ptr(maps), s_), "smaat_cbam_sppool")
+        nb = L.smaat_cbam_spconv_blocks(n, h, w)
+        conv = _new(dev, n, 1, h, w)
+        use_batch_stats = training or rm is None
+        part = _new(dev, 2, nb, 1)
+        _lib.check(L.smaat_cbam_spconv(_ptr(maps), _ptr(wconv), ks, n, h, w, _ptr(conv), _ptr(part), s_),
+                   "smaat_cbam_spconv")
+        if use_batch_stats:
+            st = _bn_finalize_raw(part, nb, 1, n * p, None, gamma, beta, eps,
+                                  momentum if momentum is not None else 0.0, rm if training else None,
+                                  rv if training else None)
+        else:
+            invstd = torch.rsqrt(rv + eps)
+            g = gamma if gamma is not None else torch.ones_like(rm)
+            b = beta if beta is not None else torch.zeros_like(rm)
+            scale = g * invstd
+            st = torch.stack([rm, invstd, scale, b - rm * scale]).contiguous()
+        gate = _new(dev, n, 1, h, w)
+        _lib.check(L.smaat_cbam_gate(_ptr(conv), _ptr(st[2]), _ptr(st[3]), n * p, _ptr(gate), s_),
+                   "smaat_cbam_gate")
+    else:
+        maps = conv = st = None
+        use_batch_stats = False
+        gate = torch.ones(n, 1, h, w, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = _new(dev, n, c, h, w)
+    out_t, o_bs = _planes(out)
+    assert out_t is out, "cbam: the output slice must have dense [C][H][W] planes"
+    _lib.check(L.smaat_cbam_apply(_ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(out), o_bs, n, c, p, s_),
+               "smaat_cbam_apply")
+    saved = (x, w1, w2, wconv, gamma, avg, mx, amax, ha, hm, sc, maps, conv, st, gate)
+    return out, saved, (use_ch, use_sp, use_batch_stats)
+
+
+def _cbam_backward_impl(saved, flags, dout):
+    """-> dx, dw1, db1, dw2, db2, dwconv, dgamma, dbeta.  `dout` may be a channel slice of a larger
+    gradient buffer (dense planes, any batch stride)."""
+    L = _lib.get()
+    x, w1, w2, wconv, gamma, avg, mx, amax, ha, hm, sc, maps, conv, st, gate = saved
+    use_ch, use_sp, train_stats = flags
+    x, x_bs = _planes(x)
+    dout, do_bs = _planes(dout)
+    n, c, h, w = x.shape
+    p = h * w
+    s_ = _stream(x)
+    dev = x
+    dwconv = dgamma = dbeta = None
+    if use_sp:
+        ks = wconv.shape[-1]
+        nbp = L.smaat_cbam_pix_blocks(n, p)
+        dbn = _new(dev, n, p)
+        part = _new(dev, 2, nbp, 1)
+        _lib.check(L.smaat_cbam_bwd_gate(_ptr(dout), do_bs, _ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(conv),
+                                         _ptr(st[0]), _ptr(st[1]), n, c, p, _ptr(dbn), _ptr(part), s_),
+                   "smaat_cbam_bwd_gate")
+        dgamma = _new(dev, 1)
+        dbeta = _new(dev, 1)
+        coef = _new(dev, 3, 1)
+        _lib.check(L.smaat_bn_bwd_finalize(_ptr(part), nbp, 1, float(n * p), _ptr(gamma), _ptr(st[1]),
+                                           _ptr(dgamma), _ptr(dbeta), _ptr(coef), s_), "smaat_bn_bwd_finalize")
+        if not train_stats:
+            coef[1:].zero_()
+        nb = L.smaat_cbam_spconv_blocks(n, h, w)
+        dmaps = _new(dev, n, 2, h, w)
+        wpart = _new(dev, nb, 2 * ks * ks)
+        _lib.check(L.smaat_cbam_bwd_spconv(_ptr(dbn), _ptr(conv), _ptr(st[0]), _ptr(st[1]), _ptr(coef),
+                                           _ptr(maps), _ptr(wconv), ks, n, h, w, _ptr(dmaps), _ptr(wpart), s_),
+                   "smaat_cbam_bwd_spconv")
+        dwconv = _new(dev, 1, 2, ks, ks)
+        _lib.check(L.smaat_reduce_rows(_ptr(wpart), nb, 2 * ks * ks, _ptr(dwconv), 1.0, s_), "smaat_reduce_rows")
+        if gamma is None:
+            dgamma = dbeta = None
+    else:
+        # no spatial half: gate == 1, no pooled-map gradients
+        maps = torch.full((n, 2, h, w), float("inf"), dtype=torch.float32, device=x.device)
+        dmaps = torch.zeros(n, 2, h, w, dtype=torch.float32, device=x.device)
+    nbp = L.smaat_cbam_pix_blocks(n, p)
+    dx = _new(dev, n, c, h, w)
+    dspart = _new(dev, nbp, c)
+    _lib.check(L.smaat_cbam_bwd_main(_ptr(dout), do_bs, _ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(maps),
+                                     _ptr(dmaps), n, c, p, _ptr(dx), c * p, _ptr(dspart), s_),
+               "smaat_cbam_bwd_main")
+    dw1 = db1 = dw2 = db2 = None
+    if use_ch:
+        cr = w1.shape[0]
+        per = nbp // n
+        ds = _new(dev, n, c)
+        # dspart is [per][n][c]: one deterministic row reduction
+        _lib.check(L.smaat_reduce_rows(_ptr(dspart), per, n * c, _ptr(ds), 1.0, s_), "smaat_reduce_rows")
+        pgs = c * cr + c + cr * c + cr
+        pg = _new(dev, n, pgs)
+        davg = _new(dev, n, c)
+        dmx = _new(dev, n, c)
+        _lib.check(L.smaat_cbam_bwd_mlp(_ptr(ds), _ptr(sc), _ptr(avg), _ptr(mx), _ptr(ha), _ptr(hm), _ptr(w1),
+                                        _ptr(w2), n, c, cr, _ptr(pg), _ptr(davg), _ptr(dmx), s_),
+                   "smaat_cbam_bwd_mlp")
+        pgr = _new(dev, pgs)
+        _lib.check(L.smaat_reduce_rows(_ptr(pg), n, pgs, _ptr(pgr), 1.0, s_), "smaat_reduce_rows")
+        dw2 = pgr[:c * cr].view(c, cr)
+        db2 = pgr[c * cr:c * cr + c]
+        dw1 = pgr[c * cr + c:c * cr + c + cr * c].view(cr, c)
+        db1 = pgr[c * cr + c + cr * c:]
+        _lib.check(L.smaat_cbam_bwd_final(_ptr(dx), c * p, _ptr(davg), _ptr(dmx), _ptr(amax), n, c, p, s_),
+                   "smaat_cbam_bwd_final")
+    return dx, dw1, db1, dw2, db2, dwconv, dgamma, dbeta
+
+
 class _CBAM(torch.autograd.Function):
     """out = spatial_att(channel_att(x)); either half can be switched off (standalone
     ChannelAttention / SpatialAttention modules reuse the same kernels)."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, use_ch, use_sp):
-        _check(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv)
-        L = _lib.get()
-        x, x_bs = _planes(x)
-        n, c, h, w = x.shape
-        p = h * w
-        s_ = _stream(x)
-        dev = x
-        if use_ch:
-            cr = w1.shape[0]
-            w1 = w1.contiguous()
-            w2 = w2.contiguous()
-            avg = _new(dev, n, c)
-            mx = _new(dev, n, c)
-            amax = _new(dev, n, c, dtype=torch.int32)
-            _lib.check(L.smaat_cbam_chpool(_ptr(x), x_bs, n, c, p, _ptr(avg), _ptr(mx), _ptr(amax), s_),
-                       "smaat_cbam_chpool")
-            ha = _new(dev, n, cr)
-            hm = _new(dev, n, cr)
-            sc = _new(dev, n, c)
-            _lib.check(L.smaat_cbam_mlp(_ptr(avg), _ptr(mx), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), n, c, cr,
-                                        _ptr(ha), _ptr(hm), _ptr(sc), s_), "smaat_cbam_mlp")
-        else:
-            avg = mx = amax = ha = hm = None
-            sc = torch.ones(n, c, dtype=torch.float32, device=x.device)
-        if use_sp:
-            wconv = wconv.contiguous()
-            ks = wconv.shape[-1]
-            maps = _new(dev, n, 2, h, w)
-            _lib.check(L.smaat_cbam_sppool(_ptr(x), x_bs, _ptr(sc), n, c, p, _ptr(maps), s_), "smaat_cbam_sppool")
-            nb = L.smaat_cbam_spconv_blocks(n, h, w)
-            conv = _new(dev, n, 1, h, w)
-            use_batch_stats = training or rm is None
-            part = _new(dev, 2, nb, 1)
-            _lib.check(L.smaat_cbam_spconv(_ptr(maps), _ptr(wconv), ks, n, h, w, _ptr(conv), _ptr(part), s_),
-                       "smaat_cbam_spconv")
-            if use_batch_stats:
-                st = _bn_finalize_raw(part, nb, 1, n * p, None, gamma, beta, eps,
-                                      momentum if momentum is not None else 0.0, rm if training else None,
-                                      rv if training else None)
-            else:
-                invstd = torch.rsqrt(rv + eps)
-                g = gamma if gamma is not None else torch.ones_like(rm)
-                b = beta if beta is not None else torch.zeros_like(rm)
-                scale = g * invstd
-                st = torch.stack([rm, invstd, scale, b - rm * scale]).contiguous()
-            gate = _new(dev, n, 1, h, w)
-            _lib.check(L.smaat_cbam_gate(_ptr(conv), _ptr(st[2]), _ptr(st[3]), n * p, _ptr(gate), s_),
-                       "smaat_cbam_gate")
-        else:
-            maps = conv = st = None
-            use_batch_stats = False
-            gate = torch.ones(n, 1, h, w, dtype=torch.float32, device=x.device)
-        out = _new(dev, n, c, h, w)
-        _lib.check(L.smaat_cbam_apply(_ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(out), c * p, n, c, p, s_),
-                   "smaat_cbam_apply")
-        ctx.save_for_backward(x, w1, w2, wconv, gamma, avg, mx, amax, ha, hm, sc, maps, conv, st, gate)
-        ctx.flags = (use_ch, use_sp, use_batch_stats)
+        out, saved, flags = _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum,
+                                               eps, use_ch, use_sp)
+        ctx.save_for_backward(*saved)
+        ctx.flags = flags
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        g = _cbam_backward_impl(ctx.saved_tensors, ctx.flags, dout)
+        return g + (None,) * 7
+
+
+class _CBAMPoolCat(torch.autograd.Function):
+    """One encoder level of SmaAt_UNet.forward (reference models/SmaAt_UNet.py:43-50): the level output
+    x feeds BOTH CBAM (-> skip connection) and MaxPool2d(2) (-> next DownDS).
+      cat[:, :C]  = CBAM(x)   written straight into the decoder's concatenation buffer
+                              (channels [C, C + c_extra) are filled later by upsample_into)
+      pooled      = maxpool2(x)
+    Backward: ONE dx = cbam_bwd(dcat[:, :C]) (+)= maxpool_bwd(dpooled) -- no torch.cat copies, no
+    gradient-accumulation add."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, c_extra):
         L = _lib.get()
-        x, w1, w2, wconv, gamma, avg, mx, amax, ha, hm, sc, maps, conv, st, gate = ctx.saved_tensors
-        use_ch, use_sp, train_stats = ctx.flags
         x, x_bs = _planes(x)
-        dout, do_bs = _planes(dout)
         n, c, h, w = x.shape
-        p = h * w
-        s_ = _stream(x)
-        dev = x
-        dwconv = dgamma = dbeta = None
-        if use_sp:
-            ks = wconv.shape[-1]
-            nbp = L.smaat_cbam_pix_blocks(n, p)
-            dbn = _new(dev, n, p)
-            part = _new(dev, 2, nbp, 1)
-            _lib.check(L.smaat_cbam_bwd_gate(_ptr(dout), do_bs, _ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(conv),
-                                             _ptr(st[0]), _ptr(st[1]), n, c, p, _ptr(dbn), _ptr(part), s_),
-                       "smaat_cbam_bwd_gate")
-            dgamma = _new(dev, 1)
-            dbeta = _new(dev, 1)
-            coef = _new(dev, 3, 1)
-            _lib.check(L.smaat_bn_bwd_finalize(_ptr(part), nbp, 1, float(n * p), _ptr(gamma), _ptr(st[1]),
-                                               _ptr(dgamma), _ptr(dbeta), _ptr(coef), s_), "smaat_bn_bwd_finalize")
-            if not train_stats:
-                coef[1:].zero_()
-            nb = L.smaat_cbam_spconv_blocks(n, h, w)
-            dmaps = _new(dev, n, 2, h, w)
-            wpart = _new(dev, nb, 2 * ks * ks)
-            _lib.check(L.smaat_cbam_bwd_spconv(_ptr(dbn), _ptr(conv), _ptr(st[0]), _ptr(st[1]), _ptr(coef),
-                                               _ptr(maps), _ptr(wconv), ks, n, h, w, _ptr(dmaps), _ptr(wpart), s_),
-                       "smaat_cbam_bwd_spconv")
-            dwconv = _new(dev, 1, 2, ks, ks)
-            _lib.check(L.smaat_reduce_rows(_ptr(wpart), nb, 2 * ks * ks, _ptr(dwconv), 1.0, s_), "smaat_reduce_rows")
-            if gamma is None:
-                dgamma = dbeta = None
+        cat = _new(x, n, c + c_extra, h, w)
+        _, saved, flags = _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps,
+                                             True, True, out=cat[:, :c])
+        pooled = _new(x, n, c, h // 2, w // 2)
+        _lib.check(L.smaat_maxpool2_fwd(_ptr(x), x_bs, _ptr(pooled), c * (h // 2) * (w // 2), n, c, h, w,
+                                        _stream(x)), "smaat_maxpool2_fwd")
+        ctx.save_for_backward(*saved)
+        ctx.flags = flags
+        return cat, pooled
+
+    @staticmethod
+    def backward(ctx, dcat, dpooled):
+        L = _lib.get()
+        saved = ctx.saved_tensors
+        x = saved[0]
+        n, c, h, w = x.shape
+        if dcat is not None:
+            g = _cbam_backward_impl(saved, ctx.flags, dcat[:, :c])
+            dx = g[0]
         else:
-            # no spatial half: gate == 1, no pooled-map gradients
-            maps = torch.full((n, 2, h, w), float("inf"), dtype=torch.float32, device=x.device)
-            dmaps = torch.zeros(n, 2, h, w, dtype=torch.float32, device=x.device)
-        nbp = L.smaat_cbam_pix_blocks(n, p)
-        dx = _new(dev, n, c, h, w)
-        dspart = _new(dev, nbp, c)
-        _lib.check(L.smaat_cbam_bwd_main(_ptr(dout), do_bs, _ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(maps),
-                                         _ptr(dmaps), n, c, p, _ptr(dx), c * p, _ptr(dspart), s_),
-                   "smaat_cbam_bwd_main")
-        dw1 = db1 = dw2 = db2 = None
-        if use_ch:
-            cr = w1.shape[0]
-            per = nbp // n
-            ds = _new(dev, n, c)
-            # dspart is [per][n][c]: one deterministic row reduction
-            _lib.check(L.smaat_reduce_rows(_ptr(dspart), per, n * c, _ptr(ds), 1.0, s_), "smaat_reduce_rows")
-            pgs = c * cr + c + cr * c + cr
-            pg = _new(dev, n, pgs)
-            davg = _new(dev, n, c)
-            dmx = _new(dev, n, c)
-            _lib.check(L.smaat_cbam_bwd_mlp(_ptr(ds), _ptr(sc), _ptr(avg), _ptr(mx), _ptr(ha), _ptr(hm), _ptr(w1),
-                                            _ptr(w2), n, c, cr, _ptr(pg), _ptr(davg), _ptr(dmx), s_),
-                       "smaat_cbam_bwd_mlp")
-            pgr = _new(dev, pgs)
-            _lib.check(L.smaat_reduce_rows(_ptr(pg), n, pgs, _ptr(pgr), 1.0, s_), "smaat_reduce_rows")
-            dw2 = pgr[:c * cr].view(c, cr)
-            db2 = pgr[c * cr:c * cr + c]
-            dw1 = pgr[c * cr + c:c * cr + c + cr * c].view(cr, c)
-            db1 = pgr[c * cr + c + cr * c:]
-            _lib.check(L.smaat_cbam_bwd_final(_ptr(dx), c * p, _ptr(davg), _ptr(dmx), _ptr(amax), n, c, p, s_),
-                       "smaat_cbam_bwd_final")
-        return dx, dw1, db1, dw2, db2, dwconv, dgamma, dbeta, None, None, None, None, None, None, None
+            g = (None,) * 8
+            dx = torch.zeros_like(x)
+        if dpooled is not None:
+            xx, x_bs = _planes(x)
+            dpooled, dp_bs = _planes(dpooled)
+            _lib.check(L.smaat_maxpool2_bwd(_ptr(xx), x_bs, _ptr(dpooled), dp_bs, _ptr(dx), c * h * w, n, c, h, w, 1,
+                                            _stream(x)), "smaat_maxpool2_bwd")
+        return (dx,) + tuple(g[1:]) + (None,) * 6
+
+
+def cbam_pool_cat(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, c_extra):
+    return _CBAMPoolCat.apply(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, c_extra)
+
+
+class _UpsampleInto(torch.autograd.Function):
+    """cat[:, c_off:] = pad(upsample2x(x1)) in place (reference unet_parts_depthwise_separable.py:64,76-85:
+    Upsample + F.pad + the second operand of torch.cat); the first c_off channels already hold the skip."""
+
+    @staticmethod
+    def forward(ctx, cat, x1, c_off):
+        _check(cat, x1)
+        L = _lib.get()
+        x1, x1_bs = _planes(x1)
+        n, c1, h, w = x1.shape
+        n2, ct, ho, wo = cat.shape
+        assert n == n2 and ct == c_off + c1 and cat.is_contiguous()
+        dy_, dx_ = ho - 2 * h, wo - 2 * w
+        if dy_ < 0 or dx_ < 0:
+            raise NotImplementedError("UpDS with a skip connection smaller than the upsampled map (negative pad)")
+        pt, pl = dy_ // 2, dx_ // 2
+        _lib.check(L.smaat_upsample2x_fwd(_ptr(x1), x1_bs, cat.data_ptr() + 4 * c_off * ho * wo, ct * ho * wo, n, c1,
+                                          h, w, ho, wo, pt, pl, _stream(x1)), "smaat_upsample2x_fwd")
+        ctx.geom = (n, c1, h, w, c_off, ho, wo, pt, pl)
+        ctx.mark_dirty(cat)
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        L = _lib.get()
+        n, c1, h, w, c_off, ho, wo, pt, pl = ctx.geom
+        dcat = dcat.contiguous()
+        dx1 = None
+        if ctx.needs_input_grad[1]:
+            dx1 = _new(dcat, n, c1, h, w)
+            _lib.check(L.smaat_upsample2x_bwd(dcat.data_ptr() + 4 * c_off * ho * wo, (c_off + c1) * ho * wo, _ptr(dx1),
+                                              c1 * h * w, n, c1, h, w, ho, wo, pt, pl, _stream(dcat)),
+                       "smaat_upsample2x_bwd")
+        return dcat, dx1, None
+
+
+def upsample_into(cat, x1, c_off):
+    return _UpsampleInto.apply(cat, x1, c_off)
 
 
 def cbam(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, use_ch=True, use_sp=True):

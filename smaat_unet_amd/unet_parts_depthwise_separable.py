@@ -89,6 +89,11 @@ class UpDS(nn.Module):
     def forward(self, x1, x2):
         return self.conv(ops.upsample_cat(x1, x2))
 
+    def forward_into(self, x1, cat):
+        """same as forward(x1, x2) when x2 already sits in channels [0, C2) of `cat`
+        ([N, C2 + C1, H2, W2]): the upsampled x1 is written behind it, no torch.cat copy."""
+        return self.conv(ops.upsample_into(cat, x1, cat.shape[1] - x1.shape[1]))
+
 
 class OutConv(nn.Module):
     """reference :89-95 (duplicate of models/unet_parts.py:67-73)."""

@@ -139,6 +139,34 @@ def test_unet(golden_dir, name):
     assert int(sd["inc.double_conv.1.num_batches_tracked"]) == 1
 
 
+def test_unet_hooked_modular_path_equals_fused(golden_dir):
+    """A forward hook on a skip-path submodule switches SmaAt_UNet.forward to the module-by-module
+    wiring (reference models/SmaAt_UNet.py:41-57 verbatim); both wirings must agree."""
+    g = np.load(os.path.join(golden_dir, "unet_12x1_n2_32.npz"))
+    meta = json.loads(str(g["meta"]))
+    P = oparams.make_smaat_params(meta["n_channels"], meta["n_classes"], 2, 16, meta["param_seed"])
+    outs, grads = [], []
+    for hooked in (False, True):
+        model = S.SmaAt_UNet(meta["n_channels"], meta["n_classes"])
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in P.items()})
+        model.train()
+        seen = []
+        if hooked:
+            model.cbam2.register_forward_hook(lambda m, i, o: seen.append(tuple(o.shape)))
+        x = torch.from_numpy(g["x"]).requires_grad_(True)
+        y = model(x)
+        (y * torch.from_numpy(g["target"]).reshape(y.shape[0], -1)[:, :1, None, None]).sum().backward()
+        assert bool(seen) == hooked
+        outs.append(y.detach().numpy())
+        grads.append({k: p.grad.numpy().copy() for k, p in model.named_parameters()})
+        grads[-1]["x"] = x.grad.numpy().copy()
+    assert rel(outs[1], outs[0]) < 1e-6
+    for k in grads[0]:
+        if ".double_conv." in k and k.endswith(("depthwise.bias", "pointwise.bias")):
+            continue
+        assert rel(grads[1][k], grads[0][k]) < 1e-4, k
+
+
 def test_eval_mode_matches_oracle(ops):
     """eval: BN uses running stats (reference call stack D)."""
     mod = S.DoubleConvDS(6, 16, kernels_per_layer=2)
