@@ -145,6 +145,26 @@ int smaat_cbam_bwd_mlp(const float* ds, const float* s, const float* avg, const 
 int smaat_cbam_bwd_final(float* dx, long dx_bs, const float* davg, const float* dmx, const int* amax, int N, int C,
                          int P, void* stream);
 
+/* ---- bf16-split matrix path (f32 operands split exactly into three bf16 terms, six bf16 MFMAs per
+ *      product, f32 accumulation: f32-class error at 2.7x the f32-MFMA rate).  Same reference call
+ *      sites as smaat_dsconv_fwd / smaat_pointwise_fwd; the depthwise stage runs as its own kernel
+ *      and the pointwise GEMM reads its output.
+ *   smaat_split_enabled: 1 when the path is switched on (env SMAAT_SPLIT != 0, default on)
+ *   smaat_split_planes:  w [R][C] f32 -> planes u16 [3][R][Cp], Cp = C rounded up to 16 (zero padded);
+ *                        R x C = Cout x K for the forward, K x Cout (the transposed weight) for dX
+ *   smaat_dw3x3_fwd:     depthwise 3x3, pad 1 (models/layers.py:38-44,48): x [N][Cin][H][W] -> y [N][Cin*kpl][H][W];
+ *                        returns -2 when the shape/alignment is not handled (W % 4 != 0): use smaat_dsconv_fwd
+ *   smaat_pointwise_fwd_split: out[n][m][p] = sum_c A[m][c] x[n][c][p] + bias[m], A given as planes;
+ *                        part: nullable [2][smaat_pw_split_num_slots(N,H,W)][M] BatchNorm partials of out - bias
+ */
+int smaat_split_enabled(void);
+int smaat_split_planes(const float* w, int R, int C, void* planes, void* stream);
+int smaat_pw_split_num_slots(int N, int H, int W);
+int smaat_dw3x3_fwd(const float* x, long x_bs, const float* w_dw, const float* b_dw, float* y, long y_bs, int N,
+                    int Cin, int kpl, int H, int W, void* stream);
+int smaat_pointwise_fwd_split(const float* x, long x_bs, const void* planes, const float* bias, float* out,
+                              long out_bs, float* part, int N, int Cin, int M, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,29 @@ def main():
         ws2 = torch.empty(L.smaat_dw3x3_bwd_ws_rows(N, cin, h, w), k, 10, device=dev)
         dwd, dbd = torch.empty(k, 9, device=dev), torch.empty(k, device=dev)
 
+        split = bool(L.smaat_split_enabled())
+        pl_f = torch.empty(3, cout, (k + 15) // 16 * 16, dtype=torch.int16, device=dev)
+        pl_b = torch.empty(3, k, (cout + 15) // 16 * 16, dtype=torch.int16, device=dev)
+        wtt = w_pw.t().contiguous()
+        slots_s = L.smaat_pw_split_num_slots(N, h, w)
+        part_s = torch.empty(2, slots_s, cout, device=dev)
+
+        def f_fwd_split():
+            assert L.smaat_dw3x3_fwd(x.data_ptr(), cin * p, w_dw.data_ptr(), b_dw.data_ptr(), y.data_ptr(), k * p, N, cin,
+                                     2, h, w, st) == 0
+            assert L.smaat_split_planes(w_pw.data_ptr(), cout, k, pl_f.data_ptr(), st) == 0
+            assert L.smaat_pointwise_fwd_split(y.data_ptr(), k * p, pl_f.data_ptr(), b_pw.data_ptr(), z.data_ptr(),
+                                               cout * p, part_s.data_ptr(), N, k, cout, h, w, st) == 0
+
+        def f_gemm_split():
+            assert L.smaat_pointwise_fwd_split(y.data_ptr(), k * p, pl_f.data_ptr(), b_pw.data_ptr(), z.data_ptr(),
+                                               cout * p, part_s.data_ptr(), N, k, cout, h, w, st) == 0
+
+        def f_dgrad_split():
+            assert L.smaat_split_planes(wtt.data_ptr(), k, cout, pl_b.data_ptr(), st) == 0
+            assert L.smaat_pointwise_fwd_split(dz.data_ptr(), cout * p, pl_b.data_ptr(), None, dy.data_ptr(), k * p, None,
+                                               N, cout, k, h, w, st) == 0
+
         def f_fwd():
             assert L.smaat_dsconv_fwd(x.data_ptr(), cin * p, None, None, w_dw.data_ptr(), b_dw.data_ptr(),
                                       wt.data_ptr(), b_pw.data_ptr(), z.data_ptr(), cout * p, part.data_ptr(),
@@ -88,7 +111,12 @@ def main():
                                      st) == 0
 
         fl = 2.0 * N * k * cout * p
-        t_f, t_fn, t_d, t_w, t_b = timeit(f_fwd), timeit(f_fwd_noy), timeit(f_dgrad), timeit(f_wgrad), timeit(f_dwb)
+        if split and w % 4 == 0:  # split path: fwd = depthwise kernel + split GEMM ("noY" column = the GEMM alone)
+            t_f, t_fn, t_d = timeit(f_fwd_split), timeit(f_gemm_split), timeit(f_dgrad_split)
+            t_w, t_b = timeit(f_wgrad), timeit(f_dwb)
+        else:
+            t_f, t_fn, t_d, t_w, t_b = (timeit(f_fwd), timeit(f_fwd_noy), timeit(f_dgrad), timeit(f_wgrad),
+                                        timeit(f_dwb))
         bw = 4.0 * N * (k + 2 * cin) * p
         rows.append(dict(layer=name, cin=cin, k=k, cout=cout, hw=h, gflop=fl / 1e9, fwd_ms=t_f, fwd_noy_ms=t_fn,
                          dgrad_ms=t_d, wgrad_ms=t_w, dwb_ms=t_b, fwd_tf=fl / t_f / 1e9, fwd_noy_tf=fl / t_fn / 1e9,

@@ -57,6 +57,11 @@ SIGNATURES = {
     "smaat_cbam_bwd_main": [_P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P, _P],
     "smaat_cbam_bwd_mlp": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "smaat_cbam_bwd_final": [_P, _L, _P, _P, _P, _I, _I, _I, _P],
+    "smaat_split_enabled": [],
+    "smaat_split_planes": [_P, _I, _I, _P, _P],
+    "smaat_pw_split_num_slots": [_I, _I, _I],
+    "smaat_dw3x3_fwd": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P],
+    "smaat_pointwise_fwd_split": [_P, _L, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P],
 }
 
 _instance = None
@@ -138,7 +143,14 @@ def _w_dw_bwd(a):
     return 38.0 * n * cin * kpl * h * w, 4.0 * n * (cin * kpl + 2 * cin) * h * w
 
 
+def _w_pw_split(a):
+    n, cin, m, h, w = a[7:12]
+    return 2.0 * n * cin * m * h * w, 4.0 * n * (cin + m) * h * w
+
+
 WORK_MODELS = {
+    "smaat_pointwise_fwd_split": _w_pw_split,
+    "smaat_dw3x3_fwd": lambda a: (18.0 * a[6] * a[7] * a[8] * a[9] * a[10], 4.0 * a[6] * a[7] * (1 + a[8]) * a[9] * a[10]),
     "smaat_dsconv_fwd": _w_dsconv_fwd,
     "smaat_pointwise_fwd": _w_pointwise_fwd,
     "smaat_dsconv_wgrad": _w_dsconv_wgrad,
@@ -162,7 +174,7 @@ class Profiler:
         self._orig = {}
         for name in SIGNATURES:
             fn = getattr(self.lib, name)
-            if name.endswith(("_slots", "_splits", "_blocks", "_version", "_rows")):
+            if name.endswith(("_slots", "_splits", "_blocks", "_version", "_rows", "_enabled")):
                 continue
             self._orig[name] = fn
             setattr(self.lib, name, self._wrap(name, fn))

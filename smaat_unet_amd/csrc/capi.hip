@@ -3,20 +3,9 @@
 #include "common.h"
 
 // ---- launchers defined in the kernel files -------------------------------------------
-struct PwArgs {
-    const float* x; long x_bs; const float* in_scale; const float* in_shift; const float* w_dw; const float* b_dw;
-    const float* wt; const float* bias; float* out; long out_bs; float* part; float* y_out;
-    int N, Cin, kpl, Kdim, M, nco, sstride; TileGeom g; int dbg;
-};
-struct WgArgs {
-    const float* x; long x_bs; const float* in_scale; const float* in_shift; const float* w_dw; const float* b_dw;
-    const float* dz; long dz_bs; float* dwpart;
-    int N, Cin, kpl, Kdim, M, nco, nkt, nsplit, tiles_per_split, sstride; TileGeom g;
-};
-struct Wg2Args {
-    const float* dz; long dz_bs; const float* y; long y_bs; float* part;
-    int N, M, K, P, nmt, nkt, nsplit, chunks_per_split, nchunk_img, total_chunks;
-};
+
+
+
 int launch_wgrad2(Wg2Args& a, hipStream_t st);
 int smaat_dsconv_wgrad_num_splits_impl(int N, int H, int W, int M, int Kdim);
 int launch_pwgemm(PwArgs& a, bool dw, hipStream_t st);
@@ -65,6 +54,13 @@ int launch_cbam_bwd_main(const float*, long, const float*, long, const float*, c
 int launch_cbam_bwd_mlp(const float*, const float*, const float*, const float*, const float*, const float*,
                         const float*, const float*, int, int, int, float*, float*, float*, hipStream_t);
 int launch_cbam_bwd_final(float*, long, const float*, const float*, const int*, int, int, int, hipStream_t);
+
+
+int split_mode();
+int launch_split_planes(const float* w, int R, int C, unsigned short* out, hipStream_t st);
+int pw_split_num_slots(int N, int P);
+int launch_pw_split(PwSplitArgs& a, hipStream_t st);
+int launch_dw3x3_fwd(const float*, long, const float*, const float*, float*, long, int, int, int, int, int, hipStream_t);
 
 #define ST ((hipStream_t)(((void)hipGetLastError()), stream))
 #define CHK(e)              \
@@ -240,4 +236,24 @@ int smaat_cbam_bwd_final(float* dx, long dx_bs, const float* davg, const float* 
     return launch_cbam_bwd_final(dx, dx_bs, davg, dmx, amax, N, C, P, ST);
 }
 
+
+int smaat_split_enabled(void) { return split_mode() >= 2 ? 1 : 0; }
+int smaat_split_planes(const float* w, int R, int C, void* planes, void* stream) {
+    if (R < 1 || C < 1) return -1;
+    return launch_split_planes(w, R, C, (unsigned short*)planes, ST);
+}
+int smaat_pw_split_num_slots(int N, int H, int W) { return pw_split_num_slots(N, H * W); }
+int smaat_dw3x3_fwd(const float* x, long x_bs, const float* w_dw, const float* b_dw, float* y, long y_bs, int N,
+                    int Cin, int kpl, int H, int W, void* stream) {
+    if (N < 1 || Cin < 1 || H < 1 || W < 1) return -1;
+    return launch_dw3x3_fwd(x, x_bs, w_dw, b_dw, y, y_bs, N, Cin, kpl, H, W, ST);
+}
+int smaat_pointwise_fwd_split(const float* x, long x_bs, const void* planes, const float* bias, float* out,
+                              long out_bs, float* part, int N, int Cin, int M, int H, int W, void* stream) {
+    if (N < 1 || Cin < 1 || M < 1 || H < 1 || W < 1) return -1;
+    PwSplitArgs a{};
+    a.x = x; a.x_bs = x_bs; a.planes = (const unsigned short*)planes; a.bias = bias; a.out = out; a.out_bs = out_bs;
+    a.part = part; a.N = N; a.Cin = Cin; a.Cp = (Cin + 15) & ~15; a.M = M; a.P = H * W;
+    return launch_pw_split(a, ST);
+}
 }  // extern "C"

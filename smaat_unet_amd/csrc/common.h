@@ -115,6 +115,59 @@ __device__ __forceinline__ bool tile_pixel(const TileGeom& g, int tl, int i, int
     return (r < g.H) && (c < g.W);
 }
 
+// ---- launch-argument blocks of the GEMM family (shared by the kernels and the C ABI) ----
+struct PwArgs {
+    const float* x;
+    long x_bs;
+    const float* in_scale;
+    const float* in_shift;
+    const float* w_dw;
+    const float* b_dw;
+    const float* wt;    // [Kdim][M]
+    const float* bias;  // [M] or null
+    float* out;
+    long out_bs;
+    float* part;   // [2][T][M] or null
+    float* y_out;  // [N][Kdim][P] or null: depthwise output side product (kept for the weight gradient)
+    int N, Cin, kpl, Kdim, M, nco, sstride;
+    TileGeom g;
+    int dbg;  // timing ablations only (SMAAT_PW_ABLATE): 1 = consumers skip the MFMAs, 2 = producers idle
+};
+
+struct Wg2Args {
+    const float* dz;
+    long dz_bs;
+    const float* y;
+    long y_bs;
+    float* part;  // [nsplit][M][K]
+    int N, M, K, P, nmt, nkt, nsplit, chunks_per_split, nchunk_img, total_chunks;
+};
+
+struct WgArgs {
+    const float* x;
+    long x_bs;
+    const float* in_scale;
+    const float* in_shift;
+    const float* w_dw;
+    const float* b_dw;
+    const float* dz;
+    long dz_bs;
+    float* dwpart;  // [nsplit][M][Kdim]
+    int N, Cin, kpl, Kdim, M, nco, nkt, nsplit, tiles_per_split, sstride;
+    TileGeom g;  // PT == PSW
+};
+
+struct PwSplitArgs {
+    const float* x;
+    long x_bs;
+    const unsigned short* planes;  // [3][M][Cp]
+    const float* bias;             // [M] or null
+    float* out;
+    long out_bs;
+    float* part;  // [2][T][M] or null
+    int N, Cin, Cp, M, P, nco, tiles_per_img, T;
+};
+
 #define HIP_RET(expr)                          \
     do {                                       \
         hipError_t _e = (expr);                \

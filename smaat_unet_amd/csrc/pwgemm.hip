@@ -29,23 +29,7 @@
 typedef const float __attribute__((address_space(4))) cfloat;
 #define SMAX_WS 512 // staged floats per input channel in the wave-specialised kernel (fixed stride)
 
-struct PwArgs {
-    const float* x;
-    long x_bs;
-    const float* in_scale;
-    const float* in_shift;
-    const float* w_dw;
-    const float* b_dw;
-    const float* wt;    // [Kdim][M]
-    const float* bias;  // [M] or null
-    float* out;
-    long out_bs;
-    float* part;   // [2][T][M] or null
-    float* y_out;  // [N][Kdim][P] or null: depthwise output side product (kept for the weight gradient)
-    int N, Cin, kpl, Kdim, M, nco, sstride;
-    TileGeom g;
-    int dbg;  // timing ablations only (SMAAT_PW_ABLATE): 1 = consumers skip the MFMAs, 2 = producers idle
-};
+
 
 // MODE 0: B operand rows are loaded straight from global (plain pointwise conv / dgrad)
 // MODE 1,2,4: B operand rows are produced by the depthwise 3x3 stage, kpl = MODE
@@ -1037,14 +1021,7 @@ __global__ __launch_bounds__(256 + NPT) void k_dsconv_strip(const PwArgs a) {
 //   both operands staged row-major with an odd LDS stride (conflict-free column reads),
 //   next chunk prefetched into registers during the MFMA block.
 // =====================================================================================
-struct Wg2Args {
-    const float* dz;
-    long dz_bs;
-    const float* y;
-    long y_bs;
-    float* part;  // [nsplit][M][K]
-    int N, M, K, P, nmt, nkt, nsplit, chunks_per_split, nchunk_img, total_chunks;
-};
+
 
 template <int CT, bool VEC>
 __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_wgrad2(const Wg2Args a) {
@@ -1163,19 +1140,7 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_wgrad2(const Wg2Args a) {
 // =====================================================================================
 // weight gradient with the depthwise stage recomputed in the kernel (memory-lean variant)
 // =====================================================================================
-struct WgArgs {
-    const float* x;
-    long x_bs;
-    const float* in_scale;
-    const float* in_shift;
-    const float* w_dw;
-    const float* b_dw;
-    const float* dz;
-    long dz_bs;
-    float* dwpart;  // [nsplit][M][Kdim]
-    int N, Cin, kpl, Kdim, M, nco, nkt, nsplit, tiles_per_split, sstride;
-    TileGeom g;  // PT == PSW
-};
+
 
 template <int WCO, int CT, int WK, int KW, bool DW, bool AFF>
 __global__ __launch_bounds__(SMAAT_THREADS) void k_wgrad(const WgArgs a) {
@@ -1636,12 +1601,21 @@ static int launch_wgrad2_cfg(Wg2Args& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+int split_mode();                                             // splitmma.hip
+int launch_wgrad_split(Wg2Args& a, int nt, hipStream_t st);   // splitmma.hip
+
 int launch_wgrad2(Wg2Args& a, hipStream_t st) {
     a.nchunk_img = ceil_div(a.P, 64);
     a.total_chunks = a.N * a.nchunk_img;
     a.nsplit = smaat_wgrad_num_splits_impl(a.N, a.P, a.M, a.K);
     a.chunks_per_split = ceil_div(a.total_chunks, a.nsplit);
     a.nkt = ceil_div(a.K, 128);
+    if (split_mode() >= 2) {  // bf16-split matrix path (splitmma.hip); -2 = shape not handled there
+        const int rc = launch_wgrad_split(a, split_mode() >= 3 ? 3 : 2, st);
+        if (rc != -2) return rc;
+        a.nchunk_img = ceil_div(a.P, 64);
+        a.total_chunks = a.N * a.nchunk_img;
+    }
     const bool vec = ((a.P & 3) == 0) && (a.P >= 4) && ((a.dz_bs & 3) == 0) && ((a.y_bs & 3) == 0) &&
                      ((((uintptr_t)a.dz) & 15) == 0) && ((((uintptr_t)a.y) & 15) == 0);
     if (a.M > 64) return vec ? launch_wgrad2_cfg<2, true>(a, st) : launch_wgrad2_cfg<2, false>(a, st);

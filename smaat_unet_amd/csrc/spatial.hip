@@ -554,6 +554,164 @@ int launch_upsample2x_bwd(const float* dout, long dout_bs, float* dx, long dx_bs
 
 void choose_geom_pub(int N, int H, int W, int PT, int smax, TileGeom* g);  // pwgemm.hip
 
+// strip-kernel tile geometry: widest tile (preferably the whole plane width) whose staged halo of
+// `nplanes` channels fits the 6 float4 staging slots of a 256-thread block
+static DwbGeom strip_geom(int H, int W, int nplanes) {
+    DwbGeom sg;
+    sg.H = H;
+    sg.W = W;
+    sg.P = H * W;
+    const int cand[4] = {W <= 288 ? W : 0, 96, 48, 32};
+    const int hq = (H + 3) / 4;
+    sg.TW = 0;
+    int th0 = 0;
+    for (int c = 0; c < 4 && sg.TW == 0; ++c) {
+        const int tw = cand[c];
+        if (tw <= 0 || tw > W) continue;
+        const int rows = (1536 / nplanes) / ((tw + 8) / 4) - 2;
+        th0 = 4 * (rows / 4);
+        if (th0 > 4 * hq) th0 = 4 * hq;
+        if (tw <= 72 && th0 > 4 * (256 / tw)) th0 = 4 * (256 / tw);  // narrow planes: one strip per thread
+        if (th0 >= 4) sg.TW = tw;
+    }
+    if (sg.TW == 0) {
+        sg.TW = W < 32 ? W : 32;
+        th0 = 4;
+    }
+    const int nty = (hq + th0 / 4 - 1) / (th0 / 4);
+    sg.TH = 4 * ((hq + nty - 1) / nty);
+    sg.tiles_x = (W + sg.TW - 1) / sg.TW;
+    sg.tiles = sg.tiles_x * nty;
+    sg.stride = sg.TW + 8;
+    if (((4 * sg.stride) & 31) == 0) sg.stride += 4;  // row groups of one wave on different banks
+    sg.nrow = sg.TH + 2;
+    sg.ncol4 = (sg.TW + 8) / 4;
+    sg.ssz = sg.nrow * sg.stride;
+    return sg;
+}
+
+// ---------------------------------------------------------------------------------
+// standalone depthwise 3x3 forward, strip form (used by the bf16-split matrix path, where the
+// pointwise GEMM reads the depthwise output from HBM; the f32-MFMA path fuses this stage instead).
+//   y[ci*kpl + j][q] = b[j] + sum_tap w[j][tap] * x[ci][q + tap offset]
+// reference: models/layers.py:38-44,48
+// ---------------------------------------------------------------------------------
+template <int KPL>
+__global__ __launch_bounds__(256) void k_dw3x3_fwd_strip(const float* __restrict__ x, long x_bs,
+                                                         const float* __restrict__ w_dw,
+                                                         const float* __restrict__ b_dw, float* __restrict__ y,
+                                                         long y_bs, int Cin, const DwbGeom g) {
+    constexpr int NSL = 6;
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    float* S = dsm;  // [ssz]
+    const int tid = threadIdx.x;
+    const int plane = blockIdx.x, n = plane / Cin, ci = plane - n * Cin;
+    const float* xp = x + (long)n * x_bs + (long)ci * g.P;
+    float* yp = y + (long)n * y_bs + (long)(ci * KPL) * g.P;
+    float wt[KPL][9], bs[KPL];
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wt[j][t] = w_dw[(ci * KPL + j) * 9 + t];
+        bs[j] = b_dw ? b_dw[ci * KPL + j] : 0.f;
+    }
+    const int F = g.nrow * g.ncol4;
+    int s_rr[NSL], s_q[NSL], s_lo[NSL];
+#pragma unroll
+    for (int k = 0; k < NSL; ++k) {
+        const int f = (tid + 256 * k) % F;
+        s_rr[k] = f / g.ncol4;
+        s_q[k] = f - s_rr[k] * g.ncol4;
+        s_lo[k] = s_rr[k] * g.stride + 4 * s_q[k];
+    }
+    const int nstrips = (g.TH >> 2) * g.TW;
+    const int nit = (nstrips + 255) >> 8;
+    float4 sv[NSL];
+    bool sok[NSL];
+    auto prefetch = [&](int tl) {
+        const int ty = tl / g.tiles_x, tx = tl - ty * g.tiles_x;
+        const int r0 = ty * g.TH, c0 = tx * g.TW;
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) {
+            const int gr = r0 - 1 + s_rr[k], gc = c0 - 4 + 4 * s_q[k];
+            sok[k] = gr >= 0 && gr < g.H && gc >= 0 && gc < g.W;
+            sv[k] = *(const float4*)(xp + (sok[k] ? gr * g.W + gc : 0));
+        }
+    };
+    int tl = blockIdx.y;
+    if (tl < g.tiles) prefetch(tl);
+    for (; tl < g.tiles; tl += gridDim.y) {
+        const int ty = tl / g.tiles_x, tx = tl - ty * g.tiles_x;
+        const int r0 = ty * g.TH, c0 = tx * g.TW;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) {
+            float4 v = sv[k];
+            v.x = sok[k] ? v.x : 0.f;
+            v.y = sok[k] ? v.y : 0.f;
+            v.z = sok[k] ? v.z : 0.f;
+            v.w = sok[k] ? v.w : 0.f;
+            *(float4*)(S + s_lo[k]) = v;
+        }
+        __syncthreads();
+        {
+            const int tn = tl + gridDim.y;
+            prefetch(tn < g.tiles ? tn : tl);
+        }
+#pragma unroll 1
+        for (int it = 0; it < nit; ++it) {
+            const int sidx = tid + (it << 8);
+            if (sidx < nstrips) {
+                const int srg = sidx / g.TW, sc = sidx - srg * g.TW;
+                const float* sp = S + (srg * 4) * g.stride + sc + 3;
+                const int prow = r0 + srg * 4;
+                const bool pcol = (c0 + sc) < g.W;
+                const int po = prow * g.W + c0 + sc;
+                float v[6][3];
+#pragma unroll
+                for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+                    for (int dc = 0; dc < 3; ++dc) v[rr][dc] = sp[rr * g.stride + dc];
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float acc = bs[j];
+#pragma unroll
+                        for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+                            for (int tc = 0; tc < 3; ++tc) acc = fmaf(wt[j][tr * 3 + tc], v[i + tr][tc], acc);
+                        if (pcol && (prow + i) < g.H) yp[(long)j * g.P + po + i * g.W] = acc;
+                    }
+                }
+            }
+        }
+    }
+}
+
+int launch_dw3x3_fwd(const float* x, long x_bs, const float* w_dw, const float* b_dw, float* y, long y_bs, int N,
+                     int Cin, int kpl, int H, int W, hipStream_t st) {
+    const bool aligned = ((W & 3) == 0) && ((x_bs & 3) == 0) && ((((uintptr_t)x) & 15) == 0) && H >= 1 &&
+                         (kpl == 1 || kpl == 2 || kpl == 4);
+    if (!aligned) return -2;  // caller falls back to the fused f32 kernel
+    const DwbGeom sg = strip_geom(H, W, 1);
+    if (sg.nrow * sg.ncol4 > 1536) return -2;
+    long planes = (long)N * Cin;
+    int groups = (int)((8192 + planes - 1) / planes);
+    if (groups > sg.tiles) groups = sg.tiles;
+    if (groups > 64) groups = 64;
+    if (groups < 1) groups = 1;
+    const size_t lds = sizeof(float) * (size_t)sg.ssz;
+    dim3 grid(N * Cin, groups);
+    if (kpl == 1)
+        hipLaunchKernelGGL(k_dw3x3_fwd_strip<1>, grid, dim3(256), lds, st, x, x_bs, w_dw, b_dw, y, y_bs, Cin, sg);
+    else if (kpl == 2)
+        hipLaunchKernelGGL(k_dw3x3_fwd_strip<2>, grid, dim3(256), lds, st, x, x_bs, w_dw, b_dw, y, y_bs, Cin, sg);
+    else
+        hipLaunchKernelGGL(k_dw3x3_fwd_strip<4>, grid, dim3(256), lds, st, x, x_bs, w_dw, b_dw, y, y_bs, Cin, sg);
+    return (int)hipGetLastError();
+}
+
 // tile groups per plane: enough workgroups to fill the chip, few enough to keep the partials small
 int dw_bwd_groups(int N, int Cin, int H, int W) {
     TileGeom g;
@@ -579,38 +737,7 @@ int launch_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, con
                          ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)dy) & 15) == 0) &&
                          ((((uintptr_t)dx) & 15) == 0) && (kpl == 1 || kpl == 2 || kpl == 4) && H >= 4;
     if (use_strip && aligned) {
-        DwbGeom sg;
-        sg.H = H;
-        sg.W = W;
-        sg.P = H * W;
-        // widest tile whose staged halo (kpl channels) fits the 6 float4 slots per thread; a tile as wide
-        // as the plane makes every staged row a run of full cache lines
-        const int cand[4] = {W <= 288 ? W : 0, 96, 48, 32};
-        const int hq = (H + 3) / 4;
-        sg.TW = 0;
-        int th0 = 0;
-        for (int c = 0; c < 4 && sg.TW == 0; ++c) {
-            const int tw = cand[c];
-            if (tw <= 0 || tw > W) continue;
-            const int rows = (1536 / kpl) / ((tw + 8) / 4) - 2;
-            th0 = 4 * (rows / 4);
-            if (th0 > 4 * hq) th0 = 4 * hq;
-            if (tw <= 72 && th0 > 4 * (256 / tw)) th0 = 4 * (256 / tw);  // narrow planes: one strip per thread
-            if (th0 >= 4) sg.TW = tw;
-        }
-        if (sg.TW == 0) {
-            sg.TW = W < 32 ? W : 32;
-            th0 = 4;
-        }
-        const int nty = (hq + th0 / 4 - 1) / (th0 / 4);
-        sg.TH = 4 * ((hq + nty - 1) / nty);
-        sg.tiles_x = (W + sg.TW - 1) / sg.TW;
-        sg.tiles = sg.tiles_x * nty;
-        sg.stride = sg.TW + 8;
-        if (((4 * sg.stride) & 31) == 0) sg.stride += 4;   // row groups of one wave on different banks
-        sg.nrow = sg.TH + 2;
-        sg.ncol4 = (sg.TW + 8) / 4;
-        sg.ssz = sg.nrow * sg.stride;
+        const DwbGeom sg = strip_geom(H, W, kpl);
         if (kpl * sg.nrow * sg.ncol4 <= 1536) {
             const size_t lds = sizeof(float) * ((size_t)kpl * sg.ssz + 4 * kpl * 10);
             dim3 grid(N * Cin, groups);

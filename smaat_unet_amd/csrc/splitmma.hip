@@ -1,0 +1,539 @@
+// f32 GEMMs on the bf16 matrix pipe by operand splitting (gfx950 has no xf32/TF32 MFMA and its
+// f32-input MFMA runs at 1/16 of the bf16 rate).
+//
+// Every f32 operand a is split EXACTLY into three bf16 terms  a = a1 + a2 + a3  (8 significant bits
+// each; truncation splits, residuals computed in f32 are exact).  A product a*b is then
+//     a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1)  +  O(2^-24 |a b|)
+// i.e. SIX v_mfma_f32_32x32x16_bf16 per 16-deep step, each term exact in the f32 accumulator input
+// (8 bit x 8 bit products), f32 accumulation as in the f32 MFMA.  The dropped terms are below one f32
+// ulp of the product, so the result has f32-class error (tests compare against the fp64 oracle next
+// to the f32-MFMA kernels).  NT = 2 keeps only  a1 b1 + a1 b2 + a2 b1  (a2 rounded to nearest):
+// ~2^-17 relative per product, three MFMAs.
+//
+//   k_wgrad_split   dW[m][k] = sum_{n,p} dz[n][m][p] * y[n][k][p]      (pointwise weight gradient)
+//
+// Structure = the wave-specialised pipeline of pwgemm.hip: 4 consumer waves (ds_read_b128 + MFMA
+// only), NPW producer waves (global float4 loads -> split -> ds_write_b64 into [plane][row][32 px]
+// bf16 images), double-buffered LDS, one barrier per 32-pixel chunk.
+#include "common.h"
+#include <stdlib.h>
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float bitsf(unsigned x) { return __builtin_bit_cast(float, x); }
+// low half <- bf16 of x, high half <- bf16 of y (both already have zero low 16 bits or are truncated here)
+__device__ __forceinline__ unsigned pack_hi16(float x, float y) { return (fbits(x) >> 16) | (fbits(y) & 0xFFFF0000u); }
+__device__ __forceinline__ float rne_bf16(float x) {  // round-to-nearest-even to 8 significant bits, kept as f32
+    const unsigned b = fbits(x);
+    return bitsf((b + 0x7FFFu + ((b >> 16) & 1u)) & 0xFFFF0000u);
+}
+
+// split 4 consecutive f32 into NT bf16 planes; plane t of the 4 values -> uint2
+template <int NT>
+__device__ __forceinline__ void split4(const float4 v, uint2 (&out)[NT]) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    float p1[4], p2[4], p3[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        p1[i] = bitsf(fbits(x[i]) & 0xFFFF0000u);
+        const float r1 = x[i] - p1[i];  // exact
+        if (NT == 2) {
+            p2[i] = rne_bf16(r1);
+            p3[i] = 0.f;
+        } else {
+            p2[i] = bitsf(fbits(r1) & 0xFFFF0000u);
+            p3[i] = r1 - p2[i];  // exact, <= 8 significant bits: its truncation to bf16 is exact
+        }
+    }
+    out[0] = make_uint2(pack_hi16(p1[0], p1[1]), pack_hi16(p1[2], p1[3]));
+    out[1] = make_uint2(pack_hi16(p2[0], p2[1]), pack_hi16(p2[2], p2[3]));
+    if (NT == 3) out[2] = make_uint2(pack_hi16(p3[0], p3[1]), pack_hi16(p3[2], p3[3]));
+}
+
+#define SPS 32       // pixels per chunk
+#define SROW 80      // bytes per LDS row (32 bf16 + 16 B pad: conflict-free ds_read_b128 / ds_write_b64)
+
+// MTT: 32-row m tiles per consumer wave (2 -> 128-row block tile, 1 -> 64-row block tile); k tile = 128
+template <int NT, int MTT, int NPT>
+__global__ __launch_bounds__(256 + NPT) void k_wgrad_split(const Wg2Args a) {
+    constexpr int MT = 64 * MTT, KT = 128, ROWS = MT + KT;
+    constexpr int PLSZ = ROWS * SROW;          // bytes per plane
+    constexpr int BUFSZ = NT * PLSZ;           // bytes per buffer
+    constexpr int NF4 = ROWS * (SPS / 4) / NPT;  // float4 loads per producer thread per chunk
+    static_assert((ROWS * (SPS / 4)) % NPT == 0, "producer mapping");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wv >= 4;
+    const int wave = wv & 3;
+    const int wm = wave & 1, wk = wave >> 1;  // consumer wave -> (m half, k half)
+    const int l31 = lane & 31, half = lane >> 5;
+    const int ptid = producer ? tid - 256 : 0;
+
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int ntile = a.nmt * a.nkt;
+    const int rest = idx % ntile;
+    const int split = (idx / ntile) * 8 + xcd;
+    if (split >= a.nsplit) return;
+    const int mt = rest % a.nmt, kt = rest / a.nmt;
+    const int m0 = mt * MT, k0 = kt * KT;
+    const int c_begin = split, c_end = a.total_chunks, c_step = a.nsplit;
+    int nit = 0;
+    if (c_begin < c_end) nit = (c_end - c_begin + c_step - 1) / c_step;
+
+    if (producer) {
+        // thread -> (row group, float4 column): 8 lanes cover one 128-byte row segment
+        const int q = ptid & 7, rbase = ptid >> 3;
+        constexpr int RSTEP = NPT / 8;
+        const float* rowp[NF4];
+        bool rowv[NF4];
+        int lofs[NF4];
+#pragma unroll
+        for (int j = 0; j < NF4; ++j) {
+            const int row = rbase + RSTEP * j;
+            if (row < MT) {
+                rowv[j] = (m0 + row) < a.M;
+                rowp[j] = a.dz + (long)(rowv[j] ? m0 + row : a.M - 1) * a.P;
+            } else {
+                rowv[j] = (k0 + row - MT) < a.K;
+                rowp[j] = a.y + (long)(rowv[j] ? k0 + row - MT : a.K - 1) * a.P;
+            }
+            lofs[j] = row * SROW + q * 8;
+        }
+        float4 pf[NF4];
+        bool pv[NF4];
+        auto prefetch = [&](int it) {
+            const int c = c_begin + (it < nit ? it : nit - 1) * c_step;
+            const int n = c / a.nchunk_img;
+            const int p0 = (c - n * a.nchunk_img) * SPS + q * 4;
+            const bool in = p0 < a.P;  // P % 4 == 0: a float4 is entirely inside or outside the plane
+            const int p0c = in ? p0 : 0;
+#pragma unroll
+            for (int j = 0; j < NF4; ++j) {
+                const int row = rbase + RSTEP * j;
+                pf[j] = *(const float4*)(rowp[j] + (long)n * (row < MT ? a.dz_bs : a.y_bs) + p0c);
+                pv[j] = in && rowv[j];
+            }
+        };
+        auto commit = [&](int buf) {
+            unsigned char* base = lds + buf * BUFSZ;
+#pragma unroll
+            for (int j = 0; j < NF4; ++j) {
+                float4 v = pf[j];
+                v.x = pv[j] ? v.x : 0.f;
+                v.y = pv[j] ? v.y : 0.f;
+                v.z = pv[j] ? v.z : 0.f;
+                v.w = pv[j] ? v.w : 0.f;
+                uint2 pl[NT];
+                split4<NT>(v, pl);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) *(uint2*)(base + t * PLSZ + lofs[j]) = pl[t];
+            }
+        };
+        if (nit > 0) {
+            prefetch(0);
+            commit(0);
+            prefetch(1);
+        }
+        __syncthreads();
+        for (int it = 0; it < nit; ++it) {
+            if (it + 1 < nit) {
+                commit((it + 1) & 1);   // chunk it+1 (its loads were issued one iteration ago)
+                prefetch(it + 2);
+            }
+            __syncthreads();
+        }
+    } else {
+        f32x16 acc[MTT][2];
+#pragma unroll
+        for (int i = 0; i < MTT; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        __syncthreads();
+        for (int it = 0; it < nit; ++it) {
+            const unsigned char* base = lds + (it & 1) * BUFSZ;
+            // A rows = dz rows of this wave's m tiles, B rows = y rows of its k tiles; lane -> row l31,
+            // 8 consecutive pixels at 16*step + 8*half
+            const unsigned char* ap = base + ((wm * MTT) * 32 + l31) * SROW + half * 16;
+            const unsigned char* bp = base + (MT + (wk * 2) * 32 + l31) * SROW + half * 16;
+#pragma unroll
+            for (int s = 0; s < SPS / 16; ++s) {
+                bf16x8 af[MTT][NT], bf[2][NT];
+#pragma unroll
+                for (int i = 0; i < MTT; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) af[i][t] = *(const bf16x8*)(ap + t * PLSZ + i * 32 * SROW + s * 32);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) bf[j][t] = *(const bf16x8*)(bp + t * PLSZ + j * 32 * SROW + s * 32);
+#pragma unroll
+                for (int i = 0; i < MTT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        // smallest terms first
+                        if (NT == 3) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                    }
+            }
+            __syncthreads();
+        }
+        float* ob = a.part + (long)split * a.M * a.K;
+#pragma unroll
+        for (int i = 0; i < MTT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * MTT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < a.M) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int kg = k0 + (wk * 2 + j) * 32 + l31;
+                        if (kg < a.K) ob[(long)m * a.K + kg] = acc[i][j][r];
+                    }
+                }
+            }
+    }
+}
+
+template <auto KERN>
+static int ensure_lds_s(size_t lds) {
+    static size_t granted = 0;
+    if (lds > granted) {
+        HIP_RET(hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        granted = lds;
+    }
+    return 0;
+}
+
+template <int NT, int MTT, int NPT>
+static int launch_wgrad_split_cfg(Wg2Args& a, hipStream_t st) {
+    constexpr int MT = 64 * MTT;
+    a.nmt = (a.M + MT - 1) / MT;
+    a.nkt = (a.K + 127) / 128;
+    const size_t lds = (size_t)2 * NT * (MT + 128) * SROW;
+    constexpr auto kern = k_wgrad_split<NT, MTT, NPT>;
+    int rc = ensure_lds_s<kern>(lds);
+    if (rc) return rc;
+    const int grid = ((a.nsplit + 7) / 8) * 8 * a.nmt * a.nkt;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 + NPT), lds, st, a);
+    return (int)hipGetLastError();
+}
+
+// SMAAT_SPLIT: 0 = f32 MFMA kernels only, 3 (default) = three-term split (six bf16 MFMAs per product),
+// 2 = two-term split (three bf16 MFMAs)
+int split_mode() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("SMAAT_SPLIT");
+        v = e ? atoi(e) : 3;
+    }
+    return v;
+}
+
+// returns -2 when the shape / alignment is not handled here (caller falls back to the f32 MFMA kernel)
+int launch_wgrad_split(Wg2Args& a, int nt, hipStream_t st) {
+    const bool vec = ((a.P & 3) == 0) && (a.P >= 4) && ((a.dz_bs & 3) == 0) && ((a.y_bs & 3) == 0) &&
+                     ((((uintptr_t)a.dz) & 15) == 0) && ((((uintptr_t)a.y) & 15) == 0);
+    if (!vec) return -2;
+    a.nchunk_img = (a.P + SPS - 1) / SPS;
+    a.total_chunks = a.N * a.nchunk_img;
+    if (a.nsplit > a.total_chunks) a.nsplit = a.total_chunks;
+    if (nt == 3) {
+        if (a.M > 64) return launch_wgrad_split_cfg<3, 2, 256>(a, st);
+        return launch_wgrad_split_cfg<3, 1, 256>(a, st);
+    }
+    if (a.M > 64) return launch_wgrad_split_cfg<2, 2, 256>(a, st);
+    return launch_wgrad_split_cfg<2, 1, 256>(a, st);
+}
+
+// =====================================================================================
+// k_split_planes: f32 matrix [R][C] (row stride ld) -> three bf16 planes [3][R][Cp], Cp = C rounded up
+// to 16 (zero padded), so that an MFMA A fragment (8 consecutive contraction indices of one row) is
+// one aligned 16-byte load.  Run once per weight tensor per step.
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ w, int R, int C, int Cp,
+                                                      unsigned short* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)R * Cp) return;
+    const int r = (int)(i / Cp), c = (int)(i - (long)r * Cp);
+    const float x = c < C ? w[(long)r * C + c] : 0.f;
+    const float p1 = bitsf(fbits(x) & 0xFFFF0000u);
+    const float r1 = x - p1;
+    const float p2 = bitsf(fbits(r1) & 0xFFFF0000u);
+    const float p3 = r1 - p2;
+    const long plane = (long)R * Cp;
+    out[i] = (unsigned short)(fbits(p1) >> 16);
+    out[plane + i] = (unsigned short)(fbits(p2) >> 16);
+    out[2 * plane + i] = (unsigned short)(fbits(p3) >> 16);
+}
+
+int launch_split_planes(const float* w, int R, int C, unsigned short* out, hipStream_t st) {
+    const int Cp = (C + 15) & ~15;
+    const long n = (long)R * Cp;
+    hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, R, C, Cp, out);
+    return (int)hipGetLastError();
+}
+
+// =====================================================================================
+// k_pw_split:  out[n][m][p] = sum_c A[m][c] * x[n][c][p] + bias[m]   (+ BatchNorm partials)
+//   A = pre-split planes [3][M][Cp] (k_split_planes); x split on the fly by the producer waves.
+//   Used for the pointwise conv of the forward pass (x = depthwise output) and for its data gradient
+//   (x = dZ, A = transposed weight).  Pixel tiles are PT consecutive pixels of the flattened plane.
+// =====================================================================================
+
+
+#define BROW 48   // bytes per LDS row of a [row][16 bf16] image (32 + 16 pad: conflict-free b128)
+
+template <int WCO, int CT, int WPX, int PXT, int NPT>
+__global__ __launch_bounds__(256 + NPT) void k_pw_split(const PwSplitArgs a) {
+    constexpr int COT = WCO * CT * 32;
+    constexpr int PT = WPX * PXT * 32;
+    constexpr int NTH = 256 + NPT;
+    constexpr int APL = COT * BROW, BPL = PT * BROW;  // bytes per plane
+    constexpr int BUFSZ = 3 * (APL + BPL);
+    constexpr int NBT = PT * 2 / NPT;    // B tasks (pixel, k half) per producer thread
+    constexpr int NAT = (COT * 2 * 3 + NPT - 1) / NPT;  // A copy tasks per producer thread
+    static_assert(WCO * WPX == 4, "4 consumer waves");
+    static_assert((PT * 2) % NPT == 0, "producer mapping");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float* stat = (float*)(lds + 2 * BUFSZ);  // [WPX][2][COT]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wv >= 4;
+    const int wave = wv & 3;
+    const int wco = wave % WCO, wpx = wave / WCO;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int ptid = producer ? tid - 256 : 0;
+
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int cot = idx % a.nco;
+    const int ptg = (idx / a.nco) * 8 + xcd;
+    if (ptg >= a.T) return;
+    const int n = ptg / a.tiles_per_img, tl = ptg - n * a.tiles_per_img;
+    const int co0 = cot * COT, p0 = tl * PT;
+    const int nchunks = (a.Cin + 15) >> 4;
+    const float* xn = a.x + (long)n * a.x_bs;
+
+    if (producer) {
+        // B tasks: task u of this thread -> (pixel, k half); 8 channel values of one pixel per task
+        int bpix[NBT], bhalf[NBT], bp[NBT];
+        bool bv[NBT];
+#pragma unroll
+        for (int u = 0; u < NBT; ++u) {
+            const int t = ptid + NPT * u;
+            bpix[u] = t % PT;
+            bhalf[u] = t / PT;
+            const int p = p0 + bpix[u];
+            bv[u] = p < a.P;
+            bp[u] = bv[u] ? p : 0;
+        }
+        // A tasks: (plane, row, half)
+        int arow[NAT], aofs[NAT];
+        long asrc[NAT];
+        bool av[NAT];
+#pragma unroll
+        for (int u = 0; u < NAT; ++u) {
+            int t = ptid + NPT * u;
+            const bool inr = t < COT * 6;
+            t = inr ? t : 0;
+            const int pl = t / (COT * 2), rem = t - pl * (COT * 2);
+            const int row = rem >> 1, h = rem & 1;
+            arow[u] = row;
+            av[u] = inr && (co0 + row) < a.M;
+            asrc[u] = ((long)pl * a.M + (av[u] ? co0 + row : 0)) * a.Cp + h * 8;
+            aofs[u] = inr ? pl * APL + row * BROW + h * 16 : -1;
+        }
+        float breg[NBT][8];
+        uint4 areg[NAT];
+        auto prefetch = [&](int ch_) {
+            const int ch = ch_ < nchunks ? ch_ : nchunks - 1;
+            const int k0 = ch * 16;
+#pragma unroll
+            for (int u = 0; u < NBT; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = k0 + bhalf[u] * 8 + e;
+                    breg[u][e] = xn[(long)(c < a.Cin ? c : a.Cin - 1) * a.P + bp[u]];
+                }
+#pragma unroll
+            for (int u = 0; u < NAT; ++u) areg[u] = *(const uint4*)(a.planes + asrc[u] + k0);
+        };
+        auto commit = [&](int ch_, int buf) {
+            const int ch = ch_ < nchunks ? ch_ : nchunks - 1;
+            const int k0 = ch * 16;
+            unsigned char* base = lds + buf * BUFSZ;
+#pragma unroll
+            for (int u = 0; u < NBT; ++u) {
+                float p1[8], p2[8], p3[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = k0 + bhalf[u] * 8 + e;
+                    const float x = (bv[u] && c < a.Cin) ? breg[u][e] : 0.f;
+                    p1[e] = bitsf(fbits(x) & 0xFFFF0000u);
+                    const float r1 = x - p1[e];
+                    p2[e] = bitsf(fbits(r1) & 0xFFFF0000u);
+                    p3[e] = r1 - p2[e];
+                }
+                unsigned char* dst = base + 3 * APL + bpix[u] * BROW + bhalf[u] * 16;
+                *(uint4*)(dst) = make_uint4(pack_hi16(p1[0], p1[1]), pack_hi16(p1[2], p1[3]), pack_hi16(p1[4], p1[5]),
+                                            pack_hi16(p1[6], p1[7]));
+                *(uint4*)(dst + BPL) = make_uint4(pack_hi16(p2[0], p2[1]), pack_hi16(p2[2], p2[3]),
+                                                  pack_hi16(p2[4], p2[5]), pack_hi16(p2[6], p2[7]));
+                *(uint4*)(dst + 2 * BPL) = make_uint4(pack_hi16(p3[0], p3[1]), pack_hi16(p3[2], p3[3]),
+                                                      pack_hi16(p3[4], p3[5]), pack_hi16(p3[6], p3[7]));
+            }
+#pragma unroll
+            for (int u = 0; u < NAT; ++u) {
+                if (aofs[u] >= 0) {
+                    uint4 v = areg[u];
+                    if (!av[u]) v = make_uint4(0, 0, 0, 0);
+                    *(uint4*)(base + aofs[u]) = v;
+                }
+            }
+        };
+        prefetch(0);
+        commit(0, 0);
+        prefetch(1);
+        __syncthreads();
+        for (int i = 0; i < nchunks; ++i) {
+            if (i + 1 < nchunks) {
+                commit(i + 1, (i + 1) & 1);
+                prefetch(i + 2);
+            }
+            __syncthreads();
+        }
+    } else {
+        f32x16 acc[CT][PXT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PXT; ++pt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
+        __syncthreads();
+        for (int i = 0; i < nchunks; ++i) {
+            const unsigned char* base = lds + (i & 1) * BUFSZ;
+            const unsigned char* ap = base + ((wco * CT) * 32 + l31) * BROW + half * 16;
+            const unsigned char* bp = base + 3 * APL + ((wpx * PXT) * 32 + l31) * BROW + half * 16;
+            bf16x8 af[CT][3], bf[PXT][3];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) af[ct][t] = *(const bf16x8*)(ap + t * APL + ct * 32 * BROW);
+#pragma unroll
+            for (int pt = 0; pt < PXT; ++pt)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) bf[pt][t] = *(const bf16x8*)(bp + t * BPL + pt * 32 * BROW);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < PXT; ++pt) {
+                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][0], bf[pt][2], acc[ct][pt], 0, 0, 0);
+                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][2], bf[pt][0], acc[ct][pt], 0, 0, 0);
+                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][1], bf[pt][1], acc[ct][pt], 0, 0, 0);
+                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][0], bf[pt][1], acc[ct][pt], 0, 0, 0);
+                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][1], bf[pt][0], acc[ct][pt], 0, 0, 0);
+                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][0], bf[pt][0], acc[ct][pt], 0, 0, 0);
+                }
+            __syncthreads();
+        }
+        // ---- epilogue: bias + coalesced row stores, BatchNorm partials of the raw accumulators ----
+        int off[PXT];
+#pragma unroll
+        for (int pt = 0; pt < PXT; ++pt) {
+            const int p = p0 + (wpx * PXT + pt) * 32 + l31;
+            off[pt] = p < a.P ? p : -1;
+        }
+        float* obase = a.out + (long)n * a.out_bs;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = (wco * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int m = co0 + col;
+                if (m < a.M) {
+                    const float bvv = a.bias ? a.bias[m] : 0.f;
+                    float* rowp = obase + (long)m * a.P;
+#pragma unroll
+                    for (int pt = 0; pt < PXT; ++pt)
+                        if (off[pt] >= 0) rowp[off[pt]] = acc[ct][pt][r] + bvv;
+                }
+            }
+        }
+        if (a.part) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float s = 0.f, q = 0.f;
+#pragma unroll
+                    for (int pt = 0; pt < PXT; ++pt) {
+                        const float v = (off[pt] >= 0) ? acc[ct][pt][r] : 0.f;
+                        s += v;
+                        q = fmaf(v, v, q);
+                    }
+                    s = half32_sum_hi(s);
+                    q = half32_sum_hi(q);
+                    if (l31 == 16 + r) {
+                        const int col = (wco * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        stat[(wpx * 2 + 0) * COT + col] = s;
+                        stat[(wpx * 2 + 1) * COT + col] = q;
+                    }
+                }
+            }
+        }
+    }
+    if (a.part) {
+        __syncthreads();
+        for (int t = tid; t < 2 * COT; t += NTH) {
+            const int which = t / COT, col = t - which * COT;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < WPX; ++w) v += stat[(w * 2 + which) * COT + col];
+            const int m = co0 + col;
+            if (m < a.M) a.part[((long)which * a.T + ptg) * a.M + m] = v;
+        }
+    }
+}
+
+static bool pws_big(int N, int P) { return (long)N * P >= 256L * 1024; }
+
+int pw_split_num_slots(int N, int P) {
+    const int PT = pws_big(N, P) ? 256 : 128;
+    return N * ((P + PT - 1) / PT);
+}
+
+template <int WCO, int CT, int WPX, int PXT, int NPT>
+static int launch_pw_split_cfg(PwSplitArgs& a, hipStream_t st) {
+    constexpr int COT = WCO * CT * 32, PT = WPX * PXT * 32;
+    a.nco = (a.M + COT - 1) / COT;
+    a.tiles_per_img = (a.P + PT - 1) / PT;
+    a.T = a.N * a.tiles_per_img;
+    const size_t lds = (size_t)2 * 3 * (COT + PT) * BROW + sizeof(float) * WPX * 2 * COT;
+    constexpr auto kern = k_pw_split<WCO, CT, WPX, PXT, NPT>;
+    int rc = ensure_lds_s<kern>(lds);
+    if (rc) return rc;
+    const int grid = ((a.T + 7) / 8) * 8 * a.nco;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 + NPT), lds, st, a);
+    return (int)hipGetLastError();
+}
+
+int launch_pw_split(PwSplitArgs& a, hipStream_t st) {
+    const bool big = pws_big(a.N, a.P);
+    if (a.M > 64) {
+        if (big) return launch_pw_split_cfg<2, 2, 2, 4, 256>(a, st);  // 128 x 256
+        return launch_pw_split_cfg<2, 2, 2, 2, 256>(a, st);           // 128 x 128
+    }
+    if (big) return launch_pw_split_cfg<1, 2, 4, 2, 256>(a, st);  // 64 x 256
+    return launch_pw_split_cfg<1, 2, 4, 1, 256>(a, st);           // 64 x 128
+}

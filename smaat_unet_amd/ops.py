@@ -94,6 +94,79 @@ def _pointwise_raw(x, wt, bias, m):
     return out
 
 
+# --------------------------------------------------------------------------------------
+# bf16-split matrix path (include/smaat_hip.h "bf16-split matrix path"): f32 operands split exactly
+# into three bf16 terms, six bf16 MFMAs per product, f32 accumulation.  On when the library says so
+# (env SMAAT_SPLIT, default on); shapes it does not handle use the fused f32-MFMA kernel.
+# --------------------------------------------------------------------------------------
+def _split_on():
+    return bool(_lib.get().smaat_split_enabled())
+
+
+# Measured per-shape policy (profiles/r1, MI355X, batch 32): the split GEMMs win where the contraction is
+# deep and the co tile wide; the shallow, plane-dominated layers stay on the fused f32-MFMA kernels
+# (they are HBM/latency bound and the fusion saves a pass over the depthwise output).
+SPLIT_POLICY = "auto"  # "auto" = the measured policy; "all" = every supported shape (parity tests)
+
+
+def _split_fwd_ok(k, cout):
+    return _split_on() and (SPLIT_POLICY == "all" or (k >= 256 and cout >= 128))
+
+
+def _split_dgrad_ok(cout):
+    return _split_on() and (SPLIT_POLICY == "all" or cout >= 256)
+
+
+def _split_planes_raw(w2d):
+    """w2d [R][C] f32 contiguous -> int16 [3][R][ceil16(C)] bf16 planes"""
+    L = _lib.get()
+    r, c = w2d.shape
+    cp = (c + 15) // 16 * 16
+    planes = torch.empty((3, r, cp), dtype=torch.int16, device=w2d.device)
+    _lib.check(L.smaat_split_planes(_ptr(w2d), r, c, _ptr(planes), _stream(w2d)), "smaat_split_planes")
+    return planes
+
+
+def _pointwise_split_raw(x, planes, bias, m, want_stats=False):
+    """out[n][m][p] = sum_c A[m][c] x[n][c][p] + bias[m] with A given as split planes"""
+    L = _lib.get()
+    x, x_bs = _planes(x)
+    n, c, h, w = x.shape
+    out = _new(x, n, m, h, w)
+    part, slots = None, 0
+    if want_stats:
+        slots = L.smaat_pw_split_num_slots(n, h, w)
+        part = _new(x, 2, slots, m)
+    _lib.check(L.smaat_pointwise_fwd_split(_ptr(x), x_bs, _ptr(planes), _ptr(bias), _ptr(out), m * h * w, _ptr(part),
+                                           n, c, m, h, w, _stream(x)), "smaat_pointwise_fwd_split")
+    return out, part, slots
+
+
+def _dw3x3_fwd_raw(x, w_dw, b_dw, kpl):
+    """standalone depthwise 3x3 forward; None when the library does not handle the shape"""
+    L = _lib.get()
+    x, x_bs = _planes(x)
+    n, cin, h, w = x.shape
+    k = cin * kpl
+    y = _new(x, n, k, h, w)
+    rc = L.smaat_dw3x3_fwd(_ptr(x), x_bs, _ptr(w_dw), _ptr(b_dw), _ptr(y), k * h * w, n, cin, kpl, h, w, _stream(x))
+    if rc == -2:
+        return None
+    _lib.check(rc, "smaat_dw3x3_fwd")
+    return y
+
+
+def _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats):
+    """depthwise kernel + split pointwise GEMM; returns (z, part, slots, y) or None (unsupported shape)"""
+    y = _dw3x3_fwd_raw(x, w_dw, b_dw, kpl)
+    if y is None:
+        return None
+    cout = w_pw.shape[0]
+    planes = _split_planes_raw(w_pw.reshape(cout, -1))
+    z, part, slots = _pointwise_split_raw(y, planes, b_pw, cout, want_stats)
+    return z, part, slots, y
+
+
 def _bn_finalize_raw(part, slots, c, count, bias_shift, gamma, beta, eps, momentum, rm, rv):
     L = _lib.get()
     st = _new(part, 4, c)
@@ -187,9 +260,14 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None):
                                         _ptr(dw_pw), n, cin, kpl, cout, h, w, s), "smaat_dsconv_wgrad")
         del ws
     # data gradient of the pointwise conv: dY = W^T dZ  (wt := w_pw in its natural [Cout][K] layout)
-    dy = _new(x, n, k, h, w)
-    _lib.check(L.smaat_pointwise_fwd(_ptr(dz), dz_bs, _ptr(w_pw), None, _ptr(dy), k * h * w, None, n, cout, k, h, w,
-                                     s), "smaat_pointwise_fwd(dgrad)")
+    if _split_dgrad_ok(cout):
+        # A[m' = k][c = co] = w_pw[co][k]: planes of the transposed weight
+        planes_t = _split_planes_raw(w_pw.reshape(cout, k).t().contiguous())
+        dy, _, _ = _pointwise_split_raw(dz, planes_t, None, k)
+    else:
+        dy = _new(x, n, k, h, w)
+        _lib.check(L.smaat_pointwise_fwd(_ptr(dz), dz_bs, _ptr(w_pw), None, _ptr(dy), k * h * w, None, n, cout, k, h,
+                                         w, s), "smaat_pointwise_fwd(dgrad)")
     # depthwise backward
     dx = _new(x, n, cin, h, w) if need_dx else None
     ws2 = _new(x, L.smaat_dw3x3_bwd_ws_rows(n, cin, h, w), k, 10)
@@ -219,7 +297,16 @@ class _DSConvBNReLU(torch.autograd.Function):
         use_batch_stats = training or rm is None
         keep_y = KEEP_DEPTHWISE_OUTPUT and any(ctx.needs_input_grad[:4])  # forward runs under no_grad
         y_dw = None
-        if use_batch_stats:
+        rs = (_dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats)
+              if _split_fwd_ok(cin * kpl, cout) else None)
+        if rs is not None and use_batch_stats:
+            z, part, slots, y_dw = rs
+            if not keep_y:
+                y_dw = None
+            st = _bn_finalize_raw(part, slots, cout, n * h * w, b_pw, gamma, beta, eps,
+                                  momentum if momentum is not None else 0.0, rm if training else None,
+                                  rv if training else None)
+        elif use_batch_stats:
             r = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, True, want_y=keep_y)
             z, part, slots = r[:3]
             y_dw = r[3] if keep_y else None
@@ -227,9 +314,12 @@ class _DSConvBNReLU(torch.autograd.Function):
                                   momentum if momentum is not None else 0.0, rm if training else None,
                                   rv if training else None)
         else:
-            r = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, False, want_y=keep_y)
-            z = r[0]
-            y_dw = r[3] if keep_y else None
+            if rs is not None:
+                z, y_dw = rs[0], (rs[3] if keep_y else None)
+            else:
+                r = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, False, want_y=keep_y)
+                z = r[0]
+                y_dw = r[3] if keep_y else None
             invstd = torch.rsqrt(rv + eps)
             g = gamma if gamma is not None else torch.ones_like(rm)
             b = beta if beta is not None else torch.zeros_like(rm)
@@ -272,7 +362,14 @@ class _DSConv(torch.autograd.Function):
         w_dw = w_dw.contiguous()
         w_pw = w_pw.contiguous()
         keep_y = KEEP_DEPTHWISE_OUTPUT and any(ctx.needs_input_grad[:4])
-        r = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, False, want_y=keep_y)
+        rs = (_dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, False)
+              if _split_fwd_ok(w_pw.shape[1], w_pw.shape[0]) else None)
+        if rs is not None:
+            r = (rs[0], None, 0, rs[3])
+        else:
+            r = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, False, want_y=keep_y)
+            if not keep_y:
+                r = (r[0], None, 0, None)
         z = r[0]
         ctx.save_for_backward(x, w_dw, b_dw, w_pw, r[3] if keep_y else None)
         ctx.kpl = kpl

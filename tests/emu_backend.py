@@ -71,6 +71,49 @@ class EmuLib:
         pp[0, T - 1] = a64.sum(axis=(0, 2))
         pp[1, T - 1] = (a64 * a64).sum(axis=(0, 2))
 
+    # ------------------------------------------------------------------ bf16-split matrix path
+    SPLIT_ENABLED = 1  # the CPU suite exercises the split wiring of ops.py; test_host_emu also runs it off
+
+    def smaat_split_enabled(self):
+        return EmuLib.SPLIT_ENABLED
+
+    def smaat_pw_split_num_slots(self, N, H, W):
+        return PW_SLOTS + 1
+
+    def smaat_split_planes(self, w, R, C, out, stream):
+        """exact three-term bf16 split (truncation), planes [3][R][Cp] of uint16"""
+        Cp = (C + 15) // 16 * 16
+        wv = f32(w, R * C).reshape(R, C)
+        o = np.ctypeslib.as_array((ctypes.c_uint16 * (3 * R * Cp)).from_address(int(out))).reshape(3, R, Cp)
+        o[:] = 0
+        rem = wv.astype(np.float32).copy()
+        for t in range(3):
+            bits = rem.view(np.uint32) & np.uint32(0xFFFF0000)
+            o[t, :, :C] = (bits >> np.uint32(16)).astype(np.uint16)
+            rem = (rem - bits.view(np.float32)).astype(np.float32)
+        assert not rem.any(), "three bf16 terms must represent an f32 exactly"
+        return 0
+
+    def smaat_dw3x3_fwd(self, x, x_bs, w_dw, b_dw, y, y_bs, N, Cin, kpl, H, W, stream):
+        if W % 4:
+            return -2
+        P, K = H * W, Cin * kpl
+        xv = np.array(planes(x, N, Cin, P, x_bs)).reshape(N, Cin, H, W)
+        yy = O.dw3x3_fwd(xv, f32(w_dw, K * 9).reshape(K, 1, 3, 3), f32(b_dw, K) if b_dw else None, kpl)
+        planes(y, N, K, P, y_bs)[:] = yy.reshape(N, K, P)
+        return 0
+
+    def smaat_pointwise_fwd_split(self, x, x_bs, pl, bias, out, out_bs, part, N, Cin, M, H, W, stream):
+        P = H * W
+        Cp = (Cin + 15) // 16 * 16
+        u = np.ctypeslib.as_array((ctypes.c_uint16 * (3 * M * Cp)).from_address(int(pl))).reshape(3, M, Cp)
+        a = ((u.astype(np.uint32) << np.uint32(16)).view(np.float32)).astype(np.float64).sum(axis=0)[:, :Cin]
+        xv = planes(x, N, Cin, P, x_bs)
+        acc = np.einsum("mc,ncp->nmp", a.astype(np.float32), xv)
+        planes(out, N, M, P, out_bs)[:] = acc + (f32(bias, M)[None, :, None] if bias else 0)
+        self._write_part(part, PW_SLOTS + 1, M, acc)
+        return 0
+
     def smaat_dw3x3_bwd_ws_rows(self, N, Cin, H, W):
         return N + 1
 

@@ -186,6 +186,55 @@ def test_dw3x3_bwd(shape):
 
 
 # ----------------------------------------------------------------------------------------
+# bf16-split matrix path: exact three-term operand split, six bf16 MFMAs per product
+def case_pw_split(L, dev, N, C, M, H, W, with_part=False):
+    x = T(rnd(1, N, C, H, W) * np.exp(rnd(7, N, C, 1, 1)), dev)   # wide dynamic range across channels
+    w, b = T(rnd(2, M, C, scale=0.2), dev), T(rnd(3, M), dev)
+    Cp = (C + 15) // 16 * 16
+    pl = torch.full((3, M, Cp), -1, dtype=torch.int16, device=dev)
+    assert L.smaat_split_planes(P(w), M, C, P(pl), stream(dev)) == 0
+    out = torch.full((N, M, H, W), float("nan"), device=dev)
+    slots = L.smaat_pw_split_num_slots(N, H, W)
+    part = torch.full((2, slots, M), float("nan"), device=dev) if with_part else None
+    assert L.smaat_pointwise_fwd_split(P(x), C * H * W, P(pl), P(b), P(out), M * H * W, P(part), N, C, M, H, W,
+                                       stream(dev)) == 0
+    r = dict(out=out, planes=pl.to(torch.int32))
+    if with_part:
+        r["psum"] = part[0].double().sum(0)
+        r["psq"] = part[1].double().sum(0)
+    return r
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 1, 32, 32), (2, 64, 21, 16, 16), (2, 16, 3, 6, 7), (2, 128, 256, 36, 36),
+                                   (4, 64, 70, 288, 288), (2, 1, 64, 20, 20), (2, 512, 1024, 18, 18),
+                                   (4, 40, 130, 288, 288), (2, 24, 64, 32, 32), (1, 37, 19, 5, 9)])
+def test_pointwise_fwd_split(shape):
+    both(case_pw_split, *shape)
+    both(case_pw_split, *shape, with_part=True)
+
+
+def case_dw_fwd(L, dev, N, Cin, kpl, H, W, bias=True, pad_c=0):
+    K = Cin * kpl
+    xfull = T(rnd(1, N, Cin + pad_c, H, W), dev)
+    x = xfull[:, pad_c:]
+    w_dw, b_dw = T(rnd(2, K, 9, scale=0.3), dev), T(rnd(3, K, scale=0.3), dev)
+    y = torch.full((N, K, H, W), float("nan"), device=dev)
+    rc = L.smaat_dw3x3_fwd(x.data_ptr(), (Cin + pad_c) * H * W, P(w_dw), P(b_dw) if bias else None, P(y), K * H * W, N,
+                           Cin, kpl, H, W, stream(dev))
+    assert rc == 0
+    return dict(y=y)
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 2, 32, 32), (2, 5, 1, 8, 8), (2, 8, 2, 36, 36), (2, 4, 2, 144, 144),
+                                   (2, 3, 2, 288, 288), (1, 4, 2, 100, 100), (2, 8, 2, 4, 4), (1, 3, 4, 8, 12),
+                                   (2, 4, 2, 72, 72), (1, 5, 2, 10, 12), (1, 2, 2, 50, 64), (1, 2, 1, 21, 48),
+                                   (1, 2, 2, 3, 4), (1, 2, 2, 1, 8)])
+def test_dw3x3_fwd(shape):
+    both(case_dw_fwd, *shape)
+    both(case_dw_fwd, *shape, bias=False, pad_c=4)
+
+
+# ----------------------------------------------------------------------------------------
 def case_bn(L, dev, N, C, H, W, relu=1, slice_pad=0):
     Pn = H * W
     zfull = T(rnd(1, N, C + slice_pad, H, W) * 1.7 + 0.3, dev)

@@ -78,8 +78,12 @@ def _load_model(meta):
     return model.to(DEV).train(), P
 
 
-@pytest.mark.parametrize("name", ["unet_12x1_n2_32", "unet_12x1_n2_64x48", "unet_3x21_n1_32"])
-def test_unet_vs_reference_golden(golden_dir, name):
+@pytest.mark.parametrize("name,policy", [("unet_12x1_n2_32", "auto"), ("unet_12x1_n2_64x48", "auto"),
+                                         ("unet_3x21_n1_32", "auto"), ("unet_12x1_n2_32", "all"),
+                                         ("unet_12x1_n2_64x48", "all")])
+def test_unet_vs_reference_golden(golden_dir, name, policy, monkeypatch):
+    from smaat_unet_amd import ops as _ops
+    monkeypatch.setattr(_ops, "SPLIT_POLICY", policy)  # "all": every supported layer on the bf16-split path
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     meta = json.loads(str(g["meta"]))
     model, _ = _load_model(meta)

@@ -109,8 +109,11 @@ def check_summary(store, tag, arr):
     return np.linalg.norm(a.ravel()[idx].astype(np.float64) - ref) / max(np.linalg.norm(ref), 1e-30)
 
 
-@pytest.mark.parametrize("name", ["unet_12x1_n2_32", "unet_3x21_n1_32"])
-def test_unet(golden_dir, name):
+@pytest.mark.parametrize("name,policy", [("unet_12x1_n2_32", "auto"), ("unet_3x21_n1_32", "auto"),
+                                         ("unet_12x1_n2_32", "all")])
+def test_unet(golden_dir, name, policy, monkeypatch):
+    from smaat_unet_amd import ops as _ops
+    monkeypatch.setattr(_ops, "SPLIT_POLICY", policy)  # "all": every layer through the split wiring
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     meta = json.loads(str(g["meta"]))
     P = oparams.make_smaat_params(meta["n_channels"], meta["n_classes"], 2, 16, meta["param_seed"])
