@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+static int pws_cfg();
 
 __device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(unsigned, x); }
 __device__ __forceinline__ float bitsf(unsigned x) { return __builtin_bit_cast(float, x); }
@@ -248,6 +249,7 @@ int launch_wgrad_split(Wg2Args& a, int nt, hipStream_t st) {
     a.total_chunks = a.N * a.nchunk_img;
     if (a.nsplit > a.total_chunks) a.nsplit = a.total_chunks;
     if (nt == 3) {
+        if (a.M > 64 && (pws_cfg() & 8)) return launch_wgrad_split_cfg<3, 2, 512>(a, st);
         if (a.M > 64) return launch_wgrad_split_cfg<3, 2, 256>(a, st);
         return launch_wgrad_split_cfg<3, 1, 256>(a, st);
     }
@@ -294,26 +296,28 @@ int launch_split_planes(const float* w, int R, int C, unsigned short* out, hipSt
 #define BROW 48   // bytes per LDS row of a [row][16 bf16] image (32 + 16 pad: conflict-free b128)
 
 template <int WCO, int CT, int WPX, int PXT, int NPT>
-__global__ __launch_bounds__(256 + NPT) void k_pw_split(const PwSplitArgs a) {
+__global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplitArgs a) {
     constexpr int COT = WCO * CT * 32;
     constexpr int PT = WPX * PXT * 32;
-    constexpr int NTH = 256 + NPT;
+    constexpr int NCW = WCO * WPX;      // consumer waves (4 or 8)
+    constexpr int NCT = NCW * 64;       // consumer threads
+    constexpr int NTH = NCT + NPT;
     constexpr int APL = COT * BROW, BPL = PT * BROW;  // bytes per plane
     constexpr int BUFSZ = 3 * (APL + BPL);
     constexpr int NBT = PT * 2 / NPT;    // B tasks (pixel, k half) per producer thread
     constexpr int NAT = (COT * 2 * 3 + NPT - 1) / NPT;  // A copy tasks per producer thread
-    static_assert(WCO * WPX == 4, "4 consumer waves");
+    static_assert(NCW == 4 || NCW == 8, "4 or 8 consumer waves");
     static_assert((PT * 2) % NPT == 0, "producer mapping");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float* stat = (float*)(lds + 2 * BUFSZ);  // [WPX][2][COT]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool producer = wv >= 4;
-    const int wave = wv & 3;
+    const bool producer = wv >= NCW;
+    const int wave = producer ? 0 : wv;
     const int wco = wave % WCO, wpx = wave / WCO;
     const int l31 = lane & 31, half = lane >> 5;
-    const int ptid = producer ? tid - 256 : 0;
+    const int ptid = producer ? tid - NCT : 0;
 
     const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
     const int cot = idx % a.nco;
@@ -524,12 +528,23 @@ static int launch_pw_split_cfg(PwSplitArgs& a, hipStream_t st) {
     int rc = ensure_lds_s<kern>(lds);
     if (rc) return rc;
     const int grid = ((a.T + 7) / 8) * 8 * a.nco;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 + NPT), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WCO * WPX * 64 + NPT), lds, st, a);
     return (int)hipGetLastError();
+}
+
+static int pws_cfg() {  // SMAAT_PWS_CFG: tuning experiments (0 = default)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("SMAAT_PWS_CFG");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
 }
 
 int launch_pw_split(PwSplitArgs& a, hipStream_t st) {
     const bool big = pws_big(a.N, a.P);
+    const int cfg = pws_cfg();
+    if (!big && a.M >= 256 && (cfg & 1)) return launch_pw_split_cfg<4, 2, 2, 2, 256>(a, st);  // 256 x 128, 8 consumer waves
     if (a.M > 64) {
         if (big) return launch_pw_split_cfg<2, 2, 2, 4, 256>(a, st);  // 128 x 256
         return launch_pw_split_cfg<2, 2, 2, 2, 256>(a, st);           // 128 x 128
