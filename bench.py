@@ -67,6 +67,48 @@ def cpu_baseline(seconds_budget=20.0):
                       f"(torch {torch.__version__} CPU ops, {threads} threads)"}
 
 
+def fwd_latency(model, size, dev, iters=50):
+    """eval-mode, no_grad, batch-1 forward (reference call stack D: notebook / calc_metrics_test_set.py
+    inference); median of `iters` HIP-event timings, eager launches and one captured HIP graph."""
+    model.eval()
+    x1, _ = synthetic_batch(1, size, size, 99, dev)
+    res = {"batch": 1, "mode": "eval/no_grad", "iters": iters}
+    with torch.no_grad():
+        for _ in range(3):
+            model(x1)
+        torch.cuda.synchronize()
+
+        def timed(fn):
+            ts = []
+            for _ in range(iters):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                e1.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            ts.sort()
+            return round(ts[len(ts) // 2], 4)
+
+        res["eager_ms"] = timed(lambda: model(x1))
+        try:  # the whole forward as ONE hipGraph launch (launch-bound at batch 1)
+            g = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                model(x1)
+            torch.cuda.current_stream().wait_stream(s)
+            with torch.cuda.graph(g):
+                y_static = model(x1)
+            g.replay()
+            torch.cuda.synchronize()
+            res["hipgraph_ms"] = timed(g.replay)
+            res["graph_output_checksum"] = round(float(y_static.double().abs().sum().item()), 4)
+        except Exception as e:  # noqa: BLE001
+            res["hipgraph_error"] = str(e)[:160]
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +119,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the f32-MFMA-only reference run")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 eval forward latency")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -190,6 +233,12 @@ def main():
                                "(f32-class error, tests/ + profiles/); SMAAT_SPLIT=0 selects the f32-MFMA kernels only"
                                if split else "f32 MFMA (v_mfma_f32_32x32x2_f32) only")
 
+    # ---- per-frame forward latency (second half of BASELINE.json's metric): eval mode, batch 1 ----
+    latency = None
+    if rank == 0 and not args.no_latency:
+        latency = fwd_latency(model, args.size, dev)
+        model.train()
+
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -202,7 +251,7 @@ def main():
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(min(args.steps, 5)), "--warmup",
                                 "2", "--batch", str(args.batch), "--size", str(args.size), "--no-cpu-baseline",
-                                "--no-profile", "--no-alt"], env=env, capture_output=True, text=True, timeout=600)
+                                "--no-profile", "--no-alt", "--no-latency"], env=env, capture_output=True, text=True, timeout=600)
             j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
             alt = {"matrix_path": "f32 MFMA only (SMAAT_SPLIT=0)", "value": j["value"], "unit": j["unit"],
                    "ms_per_step": j["ms_per_step"]}
@@ -233,6 +282,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "f32_mfma_only": alt,
+            "fwd_latency": latency,
             "kernels": kernels,
         }
         print(json.dumps(line))

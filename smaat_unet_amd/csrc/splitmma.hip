@@ -295,7 +295,7 @@ int launch_split_planes(const float* w, int R, int C, unsigned short* out, hipSt
 
 #define BROW 48   // bytes per LDS row of a [row][16 bf16] image (32 + 16 pad: conflict-free b128)
 
-template <int WCO, int CT, int WPX, int PXT, int NPT>
+template <int WCO, int CT, int WPX, int PXT, int NPT, int NBUF>
 __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplitArgs a) {
     constexpr int COT = WCO * CT * 32;
     constexpr int PT = WPX * PXT * 32;
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
     static_assert(NCW == 4 || NCW == 8, "4 or 8 consumer waves");
     static_assert((PT * 2) % NPT == 0, "producer mapping");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    float* stat = (float*)(lds + 2 * BUFSZ);  // [WPX][2][COT]
+    float* stat = (float*)(lds + NBUF * BUFSZ);  // [WPX][2][COT]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -405,16 +405,34 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
                 }
             }
         };
-        prefetch(0);
-        commit(0, 0);
-        prefetch(1);
-        __syncthreads();
-        for (int i = 0; i < nchunks; ++i) {
-            if (i + 1 < nchunks) {
-                commit(i + 1, (i + 1) & 1);
-                prefetch(i + 2);
-            }
+        if (NBUF == 2) {
+            prefetch(0);
+            commit(0, 0);
+            prefetch(1);
             __syncthreads();
+            for (int i = 0; i < nchunks; ++i) {
+                if (i + 1 < nchunks) {
+                    commit(i + 1, (i + 1) & 1);
+                    prefetch(i + 2);
+                }
+                __syncthreads();
+            }
+        } else {
+            // three LDS buffers: the producers run TWO chunks ahead, so the consumers can fetch the
+            // fragments of chunk i+1 while the MFMAs of chunk i run (no LDS latency after the barrier)
+            prefetch(0);
+            commit(0, 0);
+            prefetch(1);
+            commit(1, 1);
+            prefetch(2);
+            __syncthreads();
+            for (int i = 0; i < nchunks; ++i) {
+                if (i + 2 < nchunks) {
+                    commit(i + 2, (i + 2) % 3);
+                    prefetch(i + 3);
+                }
+                __syncthreads();
+            }
         }
     } else {
         f32x16 acc[CT][PXT];
@@ -424,20 +442,20 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
             for (int pt = 0; pt < PXT; ++pt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
-        __syncthreads();
-        for (int i = 0; i < nchunks; ++i) {
-            const unsigned char* base = lds + (i & 1) * BUFSZ;
-            const unsigned char* ap = base + ((wco * CT) * 32 + l31) * BROW + half * 16;
-            const unsigned char* bp = base + 3 * APL + ((wpx * PXT) * 32 + l31) * BROW + half * 16;
-            bf16x8 af[CT][3], bf[PXT][3];
+        const int aoff = ((wco * CT) * 32 + l31) * BROW + half * 16;
+        const int boff = 3 * APL + ((wpx * PXT) * 32 + l31) * BROW + half * 16;
+        auto load = [&](bf16x8 (&af)[CT][3], bf16x8 (&bf)[PXT][3], int buf) {
+            const unsigned char* base = lds + buf * BUFSZ;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) af[ct][t] = *(const bf16x8*)(ap + t * APL + ct * 32 * BROW);
+                for (int t = 0; t < 3; ++t) af[ct][t] = *(const bf16x8*)(base + aoff + t * APL + ct * 32 * BROW);
 #pragma unroll
             for (int pt = 0; pt < PXT; ++pt)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) bf[pt][t] = *(const bf16x8*)(bp + t * BPL + pt * 32 * BROW);
+                for (int t = 0; t < 3; ++t) bf[pt][t] = *(const bf16x8*)(base + boff + t * BPL + pt * 32 * BROW);
+        };
+        auto mma = [&](const bf16x8 (&af)[CT][3], const bf16x8 (&bf)[PXT][3]) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -449,7 +467,31 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
                     acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][1], bf[pt][0], acc[ct][pt], 0, 0, 0);
                     acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][0], bf[pt][0], acc[ct][pt], 0, 0, 0);
                 }
-            __syncthreads();
+        };
+        __syncthreads();
+        if (NBUF == 2) {
+            for (int i = 0; i < nchunks; ++i) {
+                bf16x8 af[CT][3], bf[PXT][3];
+                load(af, bf, i & 1);
+                mma(af, bf);
+                __syncthreads();
+            }
+        } else {
+            bf16x8 afA[CT][3], bfA[PXT][3], afB[CT][3], bfB[PXT][3];
+            load(afA, bfA, 0);
+            int bn = 1;  // buffer of the NEXT chunk
+            for (int i = 0; i < nchunks; i += 2) {
+                if (i + 1 < nchunks) load(afB, bfB, bn);
+                mma(afA, bfA);
+                __syncthreads();
+                bn = bn == 2 ? 0 : bn + 1;
+                if (i + 1 < nchunks) {
+                    if (i + 2 < nchunks) load(afA, bfA, bn);
+                    mma(afB, bfB);
+                    __syncthreads();
+                    bn = bn == 2 ? 0 : bn + 1;
+                }
+            }
         }
         // ---- epilogue: bias + coalesced row stores, BatchNorm partials of the raw accumulators ----
         int off[PXT];
@@ -517,14 +559,14 @@ int pw_split_num_slots(int N, int P) {
     return N * ((P + PT - 1) / PT);
 }
 
-template <int WCO, int CT, int WPX, int PXT, int NPT>
+template <int WCO, int CT, int WPX, int PXT, int NPT, int NBUF = 2>
 static int launch_pw_split_cfg(PwSplitArgs& a, hipStream_t st) {
     constexpr int COT = WCO * CT * 32, PT = WPX * PXT * 32;
     a.nco = (a.M + COT - 1) / COT;
     a.tiles_per_img = (a.P + PT - 1) / PT;
     a.T = a.N * a.tiles_per_img;
-    const size_t lds = (size_t)2 * 3 * (COT + PT) * BROW + sizeof(float) * WPX * 2 * COT;
-    constexpr auto kern = k_pw_split<WCO, CT, WPX, PXT, NPT>;
+    const size_t lds = (size_t)NBUF * 3 * (COT + PT) * BROW + sizeof(float) * WPX * 2 * COT;
+    constexpr auto kern = k_pw_split<WCO, CT, WPX, PXT, NPT, NBUF>;
     int rc = ensure_lds_s<kern>(lds);
     if (rc) return rc;
     const int grid = ((a.T + 7) / 8) * 8 * a.nco;
@@ -545,6 +587,8 @@ int launch_pw_split(PwSplitArgs& a, hipStream_t st) {
     const bool big = pws_big(a.N, a.P);
     const int cfg = pws_cfg();
     if (!big && a.M >= 256 && (cfg & 1)) return launch_pw_split_cfg<4, 2, 2, 2, 256>(a, st);  // 256 x 128, 8 consumer waves
+    if (!big && a.M > 64 && (cfg & 2)) return launch_pw_split_cfg<2, 2, 2, 2, 256, 3>(a, st);  // 128 x 128, 3 LDS buffers
+    if (!big && a.M >= 256 && (cfg & 4)) return launch_pw_split_cfg<4, 2, 2, 2, 256, 3>(a, st);  // 256 x 128, 8 consumers, 3 buffers
     if (a.M > 64) {
         if (big) return launch_pw_split_cfg<2, 2, 2, 4, 256>(a, st);  // 128 x 256
         return launch_pw_split_cfg<2, 2, 2, 2, 256>(a, st);           // 128 x 128
