@@ -165,7 +165,7 @@ struct PwSplitArgs {
     float* out;
     long out_bs;
     float* part;  // [2][T][M] or null
-    int N, Cin, Cp, M, P, nco, tiles_per_img, T;
+    int N, Cin, Cp, M, P, nco, tiles_per_img, T, slots;
 };
 
 #define HIP_RET(expr)                          \

@@ -64,7 +64,9 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
     // XCD-aware block map: the co tiles of one pixel tile run back to back on ONE XCD.
     const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
     const int cot = idx % a.nco;
-    const int ptg = (idx / a.nco) * 8 + xcd;
+    // each XCD owns a CONTIGUOUS range of pixel tiles: neighbouring tiles (shared halo lines, shared
+    // weight slabs) meet in one L2 instead of being dealt round-robin over the eight L2s
+    const int ptg = (a.dbg & 16) ? (idx / a.nco) * 8 + xcd : xcd * ((g.T + 7) >> 3) + idx / a.nco;
     if (ptg >= g.T) return;
     const int n = ptg / g.tiles_per_img, tl = ptg - n * g.tiles_per_img;
     const int co0 = cot * COT;
@@ -368,7 +370,9 @@ __global__ __launch_bounds__(256 + NPT) void k_pwgemm_ws(const PwArgs a) {
     // XCD-aware block map: the co tiles of one pixel tile run back to back on ONE XCD.
     const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
     const int cot = idx % a.nco;
-    const int ptg = (idx / a.nco) * 8 + xcd;
+    // each XCD owns a CONTIGUOUS range of pixel tiles: neighbouring tiles (shared halo lines, shared
+    // weight slabs) meet in one L2 instead of being dealt round-robin over the eight L2s
+    const int ptg = (a.dbg & 16) ? (idx / a.nco) * 8 + xcd : xcd * ((g.T + 7) >> 3) + idx / a.nco;
     if (ptg >= g.T) return;
     const int n = ptg / g.tiles_per_img, tl = ptg - n * g.tiles_per_img;
     const int co0 = cot * COT;
@@ -744,7 +748,9 @@ __global__ __launch_bounds__(256 + NPT) void k_dsconv_strip(const PwArgs a) {
 
     const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
     const int cot = idx % a.nco;
-    const int ptg = (idx / a.nco) * 8 + xcd;
+    // each XCD owns a CONTIGUOUS range of pixel tiles: neighbouring tiles (shared halo lines, shared
+    // weight slabs) meet in one L2 instead of being dealt round-robin over the eight L2s
+    const int ptg = (a.dbg & 16) ? (idx / a.nco) * 8 + xcd : xcd * ((g.T + 7) >> 3) + idx / a.nco;
     if (ptg >= g.T) return;
     const int n = ptg / g.tiles_per_img, tl = ptg - n * g.tiles_per_img;
     const int co0 = cot * COT;

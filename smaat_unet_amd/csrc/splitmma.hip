@@ -321,7 +321,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
 
     const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
     const int cot = idx % a.nco;
-    const int ptg = (idx / a.nco) * 8 + xcd;
+    const int ptg = xcd * ((a.T + 7) >> 3) + idx / a.nco;  // contiguous tile range per XCD (L2 locality)
     if (ptg >= a.T) return;
     const int n = ptg / a.tiles_per_img, tl = ptg - n * a.tiles_per_img;
     const int co0 = cot * COT, p0 = tl * PT;
@@ -547,15 +547,15 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
 #pragma unroll
             for (int w = 0; w < WPX; ++w) v += stat[(w * 2 + which) * COT + col];
             const int m = co0 + col;
-            if (m < a.M) a.part[((long)which * a.T + ptg) * a.M + m] = v;
+            if (m < a.M) a.part[((long)which * a.slots + ptg) * a.M + m] = v;
         }
     }
 }
 
-static bool pws_big(int N, int P) { return (long)N * P >= 256L * 1024; }
 
 int pw_split_num_slots(int N, int P) {
-    const int PT = pws_big(N, P) ? 256 : 128;
+    // upper bound over the tile choices of launch_pw_split (unused slots are never written: see below)
+    const int PT = 128;
     return N * ((P + PT - 1) / PT);
 }
 
@@ -565,12 +565,17 @@ static int launch_pw_split_cfg(PwSplitArgs& a, hipStream_t st) {
     a.nco = (a.M + COT - 1) / COT;
     a.tiles_per_img = (a.P + PT - 1) / PT;
     a.T = a.N * a.tiles_per_img;
+    a.slots = pw_split_num_slots(a.N, a.P);
     const size_t lds = (size_t)NBUF * 3 * (COT + PT) * BROW + sizeof(float) * WPX * 2 * COT;
     constexpr auto kern = k_pw_split<WCO, CT, WPX, PXT, NPT, NBUF>;
     int rc = ensure_lds_s<kern>(lds);
     if (rc) return rc;
     const int grid = ((a.T + 7) / 8) * 8 * a.nco;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WCO * WPX * 64 + NPT), lds, st, a);
+    if (a.part && a.T < a.slots) {  // partial-statistics rows this tile choice does not use
+        for (int w = 0; w < 2; ++w)
+            HIP_RET(hipMemsetAsync(a.part + ((long)w * a.slots + a.T) * a.M, 0, sizeof(float) * (size_t)(a.slots - a.T) * a.M, st));
+    }
     return (int)hipGetLastError();
 }
 
@@ -584,15 +589,11 @@ static int pws_cfg() {  // SMAAT_PWS_CFG: tuning experiments (0 = default)
 }
 
 int launch_pw_split(PwSplitArgs& a, hipStream_t st) {
-    const bool big = pws_big(a.N, a.P);
+    // 128-pixel tiles everywhere: two workgroups per CU overlap each other's fill/drain and barriers
+    // (measured faster than 256-pixel tiles with one workgroup per CU on every layer shape)
     const int cfg = pws_cfg();
-    if (!big && a.M >= 256 && (cfg & 1)) return launch_pw_split_cfg<4, 2, 2, 2, 256>(a, st);  // 256 x 128, 8 consumer waves
-    if (!big && a.M > 64 && (cfg & 2)) return launch_pw_split_cfg<2, 2, 2, 2, 256, 3>(a, st);  // 128 x 128, 3 LDS buffers
-    if (!big && a.M >= 256 && (cfg & 4)) return launch_pw_split_cfg<4, 2, 2, 2, 256, 3>(a, st);  // 256 x 128, 8 consumers, 3 buffers
-    if (a.M > 64) {
-        if (big) return launch_pw_split_cfg<2, 2, 2, 4, 256>(a, st);  // 128 x 256
-        return launch_pw_split_cfg<2, 2, 2, 2, 256>(a, st);           // 128 x 128
-    }
-    if (big) return launch_pw_split_cfg<1, 2, 4, 2, 256>(a, st);  // 64 x 256
-    return launch_pw_split_cfg<1, 2, 4, 1, 256>(a, st);           // 64 x 128
+    if (a.M >= 256 && (cfg & 1)) return launch_pw_split_cfg<4, 2, 2, 2, 256>(a, st);  // 256 x 128, 8 consumer waves
+    if (a.M > 64 && (cfg & 2)) return launch_pw_split_cfg<2, 2, 2, 2, 256, 3>(a, st);  // 128 x 128, 3 LDS buffers
+    if (a.M > 64) return launch_pw_split_cfg<2, 2, 2, 2, 256>(a, st);  // 128 x 128
+    return launch_pw_split_cfg<1, 2, 4, 1, 256>(a, st);                // 64 x 128
 }

@@ -110,7 +110,7 @@ SPLIT_POLICY = "auto"  # "auto" = the measured policy; "all" = every supported s
 
 
 def _split_fwd_ok(k, cout):
-    return _split_on() and (SPLIT_POLICY == "all" or (k >= 256 and cout >= 128))
+    return _split_on() and (SPLIT_POLICY == "all" or (k >= 128 and cout >= 128))
 
 
 def _split_dgrad_ok(cout):
