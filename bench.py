@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the f32-MFMA-only reference run")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 eval forward latency")
+    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
+                    help="bf16 = mixed precision (BASELINE configs[3]): bf16 GEMM operands, f32 storage/accumulation")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,6 +139,9 @@ def main():
     from smaat_unet_amd import _lib
     from smaat_unet_amd.ddp import FlatGradAllReduce
     _lib.get()
+    if args.precision == "bf16":
+        from smaat_unet_amd import ops as K
+        K.set_matrix_mode("bf16")
 
     torch.manual_seed(0)
     model = S.SmaAt_UNet(12, 1).to(dev).train()
@@ -244,7 +249,8 @@ def main():
         cpu = cpu_baseline()
 
     alt = None
-    if rank == 0 and args.gpus == 1 and not args.no_alt and os.environ.get("SMAAT_SPLIT", "") != "0":
+    if (rank == 0 and args.gpus == 1 and not args.no_alt and os.environ.get("SMAAT_SPLIT", "") != "0"
+            and args.precision == "f32"):
         # same step with the f32-MFMA kernels only (no bf16 operand splitting), for reference
         import subprocess
         env = dict(os.environ, SMAAT_SPLIT="0")
@@ -271,7 +277,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.precision == "f32" else "bf16 (GEMM operands; f32 storage and accumulation)",
             "data": "synthetic",
             "config": {"workload": f"SmaAt-UNet 12->1ch, {args.size}x{args.size} synthetic precip, batch={args.batch}/GPU "
                                    "fp32, fwd+MSE+bwd+Adam (BASELINE.json configs[1])",

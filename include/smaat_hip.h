@@ -149,7 +149,11 @@ int smaat_cbam_bwd_final(float* dx, long dx_bs, const float* davg, const float* 
  *      product, f32 accumulation: f32-class error at 2.7x the f32-MFMA rate).  Same reference call
  *      sites as smaat_dsconv_fwd / smaat_pointwise_fwd; the depthwise stage runs as its own kernel
  *      and the pointwise GEMM reads its output.
- *   smaat_split_enabled: 1 when the path is switched on (env SMAAT_SPLIT != 0, default on)
+ *   smaat_split_mode / smaat_set_split_mode (process-wide switch, initial value from env SMAAT_SPLIT, default 3):
+ *        0 = f32-MFMA kernels only; 3 = exact three-term split (f32-class error); 2 = two-term split (~1e-5);
+ *        1 = operands rounded to bf16, ONE MFMA per product = the bf16 mixed-precision mode of BASELINE
+ *        configs[3] (f32 storage, f32 accumulation, ~1e-2 class).  set returns the previous mode, -1 on a bad argument.
+ *   smaat_split_enabled: 1 when mode != 0
  *   smaat_split_planes:  w [R][C] f32 -> planes u16 [3][R][Cp], Cp = C rounded up to 16 (zero padded);
  *                        R x C = Cout x K for the forward, K x Cout (the transposed weight) for dX
  *   smaat_dw3x3_fwd:     depthwise 3x3, pad 1 (models/layers.py:38-44,48): x [N][Cin][H][W] -> y [N][Cin*kpl][H][W];
@@ -158,6 +162,8 @@ int smaat_cbam_bwd_final(float* dx, long dx_bs, const float* davg, const float* 
  *                        part: nullable [2][smaat_pw_split_num_slots(N,H,W)][M] BatchNorm partials of out - bias
  */
 int smaat_split_enabled(void);
+int smaat_split_mode(void);
+int smaat_set_split_mode(int mode);
 int smaat_split_planes(const float* w, int R, int C, void* planes, void* stream);
 int smaat_pw_split_num_slots(int N, int H, int W);
 int smaat_dw3x3_fwd(const float* x, long x_bs, const float* w_dw, const float* b_dw, float* y, long y_bs, int N,

@@ -58,6 +58,8 @@ SIGNATURES = {
     "smaat_cbam_bwd_mlp": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "smaat_cbam_bwd_final": [_P, _L, _P, _P, _P, _I, _I, _I, _P],
     "smaat_split_enabled": [],
+    "smaat_split_mode": [],
+    "smaat_set_split_mode": [_I],
     "smaat_split_planes": [_P, _I, _I, _P, _P],
     "smaat_pw_split_num_slots": [_I, _I, _I],
     "smaat_dw3x3_fwd": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P],
@@ -174,7 +176,7 @@ class Profiler:
         self._orig = {}
         for name in SIGNATURES:
             fn = getattr(self.lib, name)
-            if name.endswith(("_slots", "_splits", "_blocks", "_version", "_rows", "_enabled")):
+            if name.endswith(("_slots", "_splits", "_blocks", "_version", "_rows", "_enabled", "_mode")):
                 continue
             self._orig[name] = fn
             setattr(self.lib, name, self._wrap(name, fn))

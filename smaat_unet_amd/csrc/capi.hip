@@ -57,6 +57,7 @@ int launch_cbam_bwd_final(float*, long, const float*, const float*, const int*, 
 
 
 int split_mode();
+int set_split_mode(int m);
 int launch_split_planes(const float* w, int R, int C, unsigned short* out, hipStream_t st);
 int pw_split_num_slots(int N, int P);
 int launch_pw_split(PwSplitArgs& a, hipStream_t st);
@@ -237,7 +238,12 @@ int smaat_cbam_bwd_final(float* dx, long dx_bs, const float* davg, const float* 
 }
 
 
-int smaat_split_enabled(void) { return split_mode() >= 2 ? 1 : 0; }
+int smaat_split_enabled(void) { return split_mode() >= 1 ? 1 : 0; }
+int smaat_split_mode(void) { return split_mode(); }
+int smaat_set_split_mode(int mode) {
+    if (mode < 0 || mode > 3) return -1;
+    return set_split_mode(mode);
+}
 int smaat_split_planes(const float* w, int R, int C, void* planes, void* stream) {
     if (R < 1 || C < 1) return -1;
     return launch_split_planes(w, R, C, (unsigned short*)planes, ST);

@@ -1616,8 +1616,8 @@ int launch_wgrad2(Wg2Args& a, hipStream_t st) {
     a.nsplit = smaat_wgrad_num_splits_impl(a.N, a.P, a.M, a.K);
     a.chunks_per_split = ceil_div(a.total_chunks, a.nsplit);
     a.nkt = ceil_div(a.K, 128);
-    if (split_mode() >= 2) {  // bf16-split matrix path (splitmma.hip); -2 = shape not handled there
-        const int rc = launch_wgrad_split(a, split_mode() >= 3 ? 3 : 2, st);
+    if (split_mode() >= 1) {  // bf16 matrix path (splitmma.hip); -2 = shape not handled there
+        const int rc = launch_wgrad_split(a, split_mode() >= 3 ? 3 : split_mode(), st);
         if (rc != -2) return rc;
         a.nchunk_img = ceil_div(a.P, 64);
         a.total_chunks = a.N * a.nchunk_img;

@@ -20,6 +20,7 @@
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 static int pws_cfg();
+int split_mode();
 
 __device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(unsigned, x); }
 __device__ __forceinline__ float bitsf(unsigned x) { return __builtin_bit_cast(float, x); }
@@ -37,9 +38,11 @@ __device__ __forceinline__ void split4(const float4 v, uint2 (&out)[NT]) {
     float p1[4], p2[4], p3[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        p1[i] = bitsf(fbits(x[i]) & 0xFFFF0000u);
+        p1[i] = NT == 1 ? rne_bf16(x[i]) : bitsf(fbits(x[i]) & 0xFFFF0000u);
         const float r1 = x[i] - p1[i];  // exact
-        if (NT == 2) {
+        if (NT == 1) {
+            p2[i] = p3[i] = 0.f;
+        } else if (NT == 2) {
             p2[i] = rne_bf16(r1);
             p3[i] = 0.f;
         } else {
@@ -48,7 +51,7 @@ __device__ __forceinline__ void split4(const float4 v, uint2 (&out)[NT]) {
         }
     }
     out[0] = make_uint2(pack_hi16(p1[0], p1[1]), pack_hi16(p1[2], p1[3]));
-    out[1] = make_uint2(pack_hi16(p2[0], p2[1]), pack_hi16(p2[2], p2[3]));
+    if (NT >= 2) out[1] = make_uint2(pack_hi16(p2[0], p2[1]), pack_hi16(p2[2], p2[3]));
     if (NT == 3) out[2] = make_uint2(pack_hi16(p3[0], p3[1]), pack_hi16(p3[2], p3[3]));
 }
 
@@ -181,8 +184,10 @@ __global__ __launch_bounds__(256 + NPT) void k_wgrad_split(const Wg2Args a) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
                         }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                        if (NT >= 2) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                        }
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
                     }
             }
@@ -229,15 +234,21 @@ static int launch_wgrad_split_cfg(Wg2Args& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-// SMAAT_SPLIT: 0 = f32 MFMA kernels only, 3 (default) = three-term split (six bf16 MFMAs per product),
-// 2 = two-term split (three bf16 MFMAs)
+// SMAAT_SPLIT / smaat_set_split_mode: 0 = f32 MFMA kernels only, 3 (default) = exact three-term split (six
+// bf16 MFMAs per product, f32-class error), 2 = two-term split (three MFMAs, ~1e-5), 1 = operands rounded to
+// bf16 (ONE MFMA: the bf16 mixed-precision mode of BASELINE configs[3], ~1e-2)
+static int g_split_mode = -1;
 int split_mode() {
-    static int v = -1;
-    if (v < 0) {
+    if (g_split_mode < 0) {
         const char* e = getenv("SMAAT_SPLIT");
-        v = e ? atoi(e) : 3;
+        g_split_mode = e ? atoi(e) : 3;
     }
-    return v;
+    return g_split_mode;
+}
+int set_split_mode(int m) {
+    const int prev = split_mode();
+    g_split_mode = m;
+    return prev;
 }
 
 // returns -2 when the shape / alignment is not handled here (caller falls back to the f32 MFMA kernel)
@@ -248,6 +259,10 @@ int launch_wgrad_split(Wg2Args& a, int nt, hipStream_t st) {
     a.nchunk_img = (a.P + SPS - 1) / SPS;
     a.total_chunks = a.N * a.nchunk_img;
     if (a.nsplit > a.total_chunks) a.nsplit = a.total_chunks;
+    if (nt == 1) {  // plain bf16 operands (mixed-precision mode)
+        if (a.M > 64) return launch_wgrad_split_cfg<1, 2, 256>(a, st);
+        return launch_wgrad_split_cfg<1, 1, 256>(a, st);
+    }
     if (nt == 3) {
         if (a.M > 64 && (pws_cfg() & 8)) return launch_wgrad_split_cfg<3, 2, 512>(a, st);
         if (a.M > 64) return launch_wgrad_split_cfg<3, 2, 256>(a, st);
@@ -263,13 +278,13 @@ int launch_wgrad_split(Wg2Args& a, int nt, hipStream_t st) {
 // one aligned 16-byte load.  Run once per weight tensor per step.
 // =====================================================================================
 __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ w, int R, int C, int Cp,
-                                                      unsigned short* __restrict__ out) {
+                                                      unsigned short* __restrict__ out, int bf16_only) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)R * Cp) return;
     const int r = (int)(i / Cp), c = (int)(i - (long)r * Cp);
     const float x = c < C ? w[(long)r * C + c] : 0.f;
-    const float p1 = bitsf(fbits(x) & 0xFFFF0000u);
-    const float r1 = x - p1;
+    const float p1 = bf16_only ? rne_bf16(x) : bitsf(fbits(x) & 0xFFFF0000u);
+    const float r1 = bf16_only ? 0.f : x - p1;
     const float p2 = bitsf(fbits(r1) & 0xFFFF0000u);
     const float p3 = r1 - p2;
     const long plane = (long)R * Cp;
@@ -281,7 +296,8 @@ __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ 
 int launch_split_planes(const float* w, int R, int C, unsigned short* out, hipStream_t st) {
     const int Cp = (C + 15) & ~15;
     const long n = (long)R * Cp;
-    hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, R, C, Cp, out);
+    hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, R, C, Cp, out,
+                       split_mode() == 1 ? 1 : 0);
     return (int)hipGetLastError();
 }
 
@@ -295,7 +311,7 @@ int launch_split_planes(const float* w, int R, int C, unsigned short* out, hipSt
 
 #define BROW 48   // bytes per LDS row of a [row][16 bf16] image (32 + 16 pad: conflict-free b128)
 
-template <int WCO, int CT, int WPX, int PXT, int NPT, int NBUF>
+template <int WCO, int CT, int WPX, int PXT, int NPT, int NBUF, int NT>
 __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplitArgs a) {
     constexpr int COT = WCO * CT * 32;
     constexpr int PT = WPX * PXT * 32;
@@ -303,9 +319,9 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
     constexpr int NCT = NCW * 64;       // consumer threads
     constexpr int NTH = NCT + NPT;
     constexpr int APL = COT * BROW, BPL = PT * BROW;  // bytes per plane
-    constexpr int BUFSZ = 3 * (APL + BPL);
+    constexpr int BUFSZ = NT * (APL + BPL);  // NT planes of A then NT planes of B
     constexpr int NBT = PT * 2 / NPT;    // B tasks (pixel, k half) per producer thread
-    constexpr int NAT = (COT * 2 * 3 + NPT - 1) / NPT;  // A copy tasks per producer thread
+    constexpr int NAT = (COT * 2 * NT + NPT - 1) / NPT;  // A copy tasks per producer thread
     static_assert(NCW == 4 || NCW == 8, "4 or 8 consumer waves");
     static_assert((PT * 2) % NPT == 0, "producer mapping");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -326,6 +342,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
     const int n = ptg / a.tiles_per_img, tl = ptg - n * a.tiles_per_img;
     const int co0 = cot * COT, p0 = tl * PT;
     const int nchunks = (a.Cin + 15) >> 4;
+    const int npad = (nchunks + 3) & ~3;  // barrier trip count of both roles (multiple of the prefetch depth)
     const float* xn = a.x + (long)n * a.x_bs;
 
     if (producer) {
@@ -347,19 +364,22 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
         bool av[NAT];
 #pragma unroll
         for (int u = 0; u < NAT; ++u) {
-            int t = ptid + NPT * u;
-            const bool inr = t < COT * 6;
-            t = inr ? t : 0;
+            // surplus tasks wrap around and re-copy a valid piece: every task stores unconditionally (a
+            // divergent branch around the store makes hipcc drain ALL outstanding loads with vmcnt(0))
+            const int t = (ptid + NPT * u) % (COT * 2 * NT);
             const int pl = t / (COT * 2), rem = t - pl * (COT * 2);
             const int row = rem >> 1, h = rem & 1;
             arow[u] = row;
-            av[u] = inr && (co0 + row) < a.M;
+            av[u] = (co0 + row) < a.M;
             asrc[u] = ((long)pl * a.M + (av[u] ? co0 + row : 0)) * a.Cp + h * 8;
-            aofs[u] = inr ? pl * APL + row * BROW + h * 16 : -1;
+            aofs[u] = pl * APL + row * BROW + h * 16;
         }
-        float breg[NBT][8];
-        uint4 areg[NAT];
-        auto prefetch = [&](int ch_) {
+        // PD register sets: the global loads of PD chunks are in flight at any time (an iteration lasts
+        // ~0.8-1.5k cycles, an L2/HBM round trip under load longer than that)
+        constexpr int PD = 4;
+        float breg[PD][NBT][8];
+        uint4 areg[PD][NAT];
+        auto prefetch = [&](int ch_, int set) {
             const int ch = ch_ < nchunks ? ch_ : nchunks - 1;
             const int k0 = ch * 16;
 #pragma unroll
@@ -367,12 +387,12 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int c = k0 + bhalf[u] * 8 + e;
-                    breg[u][e] = xn[(long)(c < a.Cin ? c : a.Cin - 1) * a.P + bp[u]];
+                    breg[set][u][e] = xn[(long)(c < a.Cin ? c : a.Cin - 1) * a.P + bp[u]];
                 }
 #pragma unroll
-            for (int u = 0; u < NAT; ++u) areg[u] = *(const uint4*)(a.planes + asrc[u] + k0);
+            for (int u = 0; u < NAT; ++u) areg[set][u] = *(const uint4*)(a.planes + asrc[u] + k0);
         };
-        auto commit = [&](int ch_, int buf) {
+        auto commit = [&](int ch_, int buf, int set) {
             const int ch = ch_ < nchunks ? ch_ : nchunks - 1;
             const int k0 = ch * 16;
             unsigned char* base = lds + buf * BUFSZ;
@@ -382,54 +402,64 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int c = k0 + bhalf[u] * 8 + e;
-                    const float x = (bv[u] && c < a.Cin) ? breg[u][e] : 0.f;
-                    p1[e] = bitsf(fbits(x) & 0xFFFF0000u);
+                    const float x = (bv[u] && c < a.Cin) ? breg[set][u][e] : 0.f;
+                    p1[e] = NT == 1 ? rne_bf16(x) : bitsf(fbits(x) & 0xFFFF0000u);
                     const float r1 = x - p1[e];
                     p2[e] = bitsf(fbits(r1) & 0xFFFF0000u);
                     p3[e] = r1 - p2[e];
                 }
-                unsigned char* dst = base + 3 * APL + bpix[u] * BROW + bhalf[u] * 16;
+                unsigned char* dst = base + NT * APL + bpix[u] * BROW + bhalf[u] * 16;
                 *(uint4*)(dst) = make_uint4(pack_hi16(p1[0], p1[1]), pack_hi16(p1[2], p1[3]), pack_hi16(p1[4], p1[5]),
                                             pack_hi16(p1[6], p1[7]));
-                *(uint4*)(dst + BPL) = make_uint4(pack_hi16(p2[0], p2[1]), pack_hi16(p2[2], p2[3]),
-                                                  pack_hi16(p2[4], p2[5]), pack_hi16(p2[6], p2[7]));
-                *(uint4*)(dst + 2 * BPL) = make_uint4(pack_hi16(p3[0], p3[1]), pack_hi16(p3[2], p3[3]),
-                                                      pack_hi16(p3[4], p3[5]), pack_hi16(p3[6], p3[7]));
+                if (NT == 3) {
+                    *(uint4*)(dst + BPL) = make_uint4(pack_hi16(p2[0], p2[1]), pack_hi16(p2[2], p2[3]),
+                                                      pack_hi16(p2[4], p2[5]), pack_hi16(p2[6], p2[7]));
+                    *(uint4*)(dst + 2 * BPL) = make_uint4(pack_hi16(p3[0], p3[1]), pack_hi16(p3[2], p3[3]),
+                                                          pack_hi16(p3[4], p3[5]), pack_hi16(p3[6], p3[7]));
+                }
             }
 #pragma unroll
             for (int u = 0; u < NAT; ++u) {
-                if (aofs[u] >= 0) {
-                    uint4 v = areg[u];
-                    if (!av[u]) v = make_uint4(0, 0, 0, 0);
-                    *(uint4*)(base + aofs[u]) = v;
-                }
+                uint4 v = areg[set][u];
+                v.x = av[u] ? v.x : 0u;
+                v.y = av[u] ? v.y : 0u;
+                v.z = av[u] ? v.z : 0u;
+                v.w = av[u] ? v.w : 0u;
+                *(uint4*)(base + aofs[u]) = v;
             }
         };
         if (NBUF == 2) {
-            prefetch(0);
-            commit(0, 0);
-            prefetch(1);
+#pragma unroll
+            for (int j = 0; j < PD; ++j) prefetch(j, j);
+            commit(0, 0, 0);
+            prefetch(PD, 0);
             __syncthreads();
-            for (int i = 0; i < nchunks; ++i) {
-                if (i + 1 < nchunks) {
-                    commit(i + 1, (i + 1) & 1);
-                    prefetch(i + 2);
+            for (int i0 = 0; i0 < nchunks; i0 += PD) {
+#pragma unroll
+                for (int u = 0; u < PD; ++u) {
+                    const int i = i0 + u;
+                    if (i < nchunks) {
+                        if (i + 1 < nchunks) {
+                            commit(i + 1, (i + 1) & 1, (u + 1) % PD);   // loads issued PD iterations ago
+                            prefetch(i + 1 + PD, (u + 1) % PD);
+                        }
+                        __syncthreads();
+                    }
                 }
-                __syncthreads();
             }
         } else {
             // three LDS buffers: the producers run TWO chunks ahead, so the consumers can fetch the
             // fragments of chunk i+1 while the MFMAs of chunk i run (no LDS latency after the barrier)
-            prefetch(0);
-            commit(0, 0);
-            prefetch(1);
-            commit(1, 1);
-            prefetch(2);
+            prefetch(0, 0);
+            commit(0, 0, 0);
+            prefetch(1, 1);
+            commit(1, 1, 1);
+            prefetch(2, 0);
             __syncthreads();
             for (int i = 0; i < nchunks; ++i) {
                 if (i + 2 < nchunks) {
-                    commit(i + 2, (i + 2) % 3);
-                    prefetch(i + 3);
+                    commit(i + 2, (i + 2) % 3, 0);
+                    prefetch(i + 3, 0);
                 }
                 __syncthreads();
             }
@@ -443,41 +473,43 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
         const int aoff = ((wco * CT) * 32 + l31) * BROW + half * 16;
-        const int boff = 3 * APL + ((wpx * PXT) * 32 + l31) * BROW + half * 16;
-        auto load = [&](bf16x8 (&af)[CT][3], bf16x8 (&bf)[PXT][3], int buf) {
+        const int boff = NT * APL + ((wpx * PXT) * 32 + l31) * BROW + half * 16;
+        auto load = [&](bf16x8 (&af)[CT][NT], bf16x8 (&bf)[PXT][NT], int buf) {
             const unsigned char* base = lds + buf * BUFSZ;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) af[ct][t] = *(const bf16x8*)(base + aoff + t * APL + ct * 32 * BROW);
+                for (int t = 0; t < NT; ++t) af[ct][t] = *(const bf16x8*)(base + aoff + t * APL + ct * 32 * BROW);
 #pragma unroll
             for (int pt = 0; pt < PXT; ++pt)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) bf[pt][t] = *(const bf16x8*)(base + boff + t * BPL + pt * 32 * BROW);
+                for (int t = 0; t < NT; ++t) bf[pt][t] = *(const bf16x8*)(base + boff + t * BPL + pt * 32 * BROW);
         };
-        auto mma = [&](const bf16x8 (&af)[CT][3], const bf16x8 (&bf)[PXT][3]) {
+        auto mma = [&](const bf16x8 (&af)[CT][NT], const bf16x8 (&bf)[PXT][NT]) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int pt = 0; pt < PXT; ++pt) {
-                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][0], bf[pt][2], acc[ct][pt], 0, 0, 0);
-                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][2], bf[pt][0], acc[ct][pt], 0, 0, 0);
-                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][1], bf[pt][1], acc[ct][pt], 0, 0, 0);
-                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][0], bf[pt][1], acc[ct][pt], 0, 0, 0);
-                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][1], bf[pt][0], acc[ct][pt], 0, 0, 0);
+                    if (NT == 3) {
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][0], bf[pt][NT - 1], acc[ct][pt], 0, 0, 0);
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][NT - 1], bf[pt][0], acc[ct][pt], 0, 0, 0);
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][NT / 2], bf[pt][NT / 2], acc[ct][pt], 0, 0, 0);
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][0], bf[pt][NT / 2], acc[ct][pt], 0, 0, 0);
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][NT / 2], bf[pt][0], acc[ct][pt], 0, 0, 0);
+                    }
                     acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][0], bf[pt][0], acc[ct][pt], 0, 0, 0);
                 }
         };
         __syncthreads();
         if (NBUF == 2) {
             for (int i = 0; i < nchunks; ++i) {
-                bf16x8 af[CT][3], bf[PXT][3];
+                bf16x8 af[CT][NT], bf[PXT][NT];
                 load(af, bf, i & 1);
                 mma(af, bf);
                 __syncthreads();
             }
         } else {
-            bf16x8 afA[CT][3], bfA[PXT][3], afB[CT][3], bfB[PXT][3];
+            bf16x8 afA[CT][NT], bfA[PXT][NT], afB[CT][NT], bfB[PXT][NT];
             load(afA, bfA, 0);
             int bn = 1;  // buffer of the NEXT chunk
             for (int i = 0; i < nchunks; i += 2) {
@@ -559,15 +591,23 @@ int pw_split_num_slots(int N, int P) {
     return N * ((P + PT - 1) / PT);
 }
 
-template <int WCO, int CT, int WPX, int PXT, int NPT, int NBUF = 2>
+template <int WCO, int CT, int WPX, int PXT, int NPT, int NBUF = 2, int NT = 3>
 static int launch_pw_split_cfg(PwSplitArgs& a, hipStream_t st) {
     constexpr int COT = WCO * CT * 32, PT = WPX * PXT * 32;
     a.nco = (a.M + COT - 1) / COT;
     a.tiles_per_img = (a.P + PT - 1) / PT;
     a.T = a.N * a.tiles_per_img;
     a.slots = pw_split_num_slots(a.N, a.P);
-    const size_t lds = (size_t)NBUF * 3 * (COT + PT) * BROW + sizeof(float) * WPX * 2 * COT;
-    constexpr auto kern = k_pw_split<WCO, CT, WPX, PXT, NPT, NBUF>;
+    {
+        static int abl = -1;
+        if (abl < 0) {
+            const char* e = getenv("SMAAT_PWS_ABLATE");
+            abl = e ? atoi(e) : 0;
+        }
+        a.dbg = abl;
+    }
+    const size_t lds = (size_t)NBUF * NT * (COT + PT) * BROW + sizeof(float) * WPX * 2 * COT;
+    constexpr auto kern = k_pw_split<WCO, CT, WPX, PXT, NPT, NBUF, NT>;
     int rc = ensure_lds_s<kern>(lds);
     if (rc) return rc;
     const int grid = ((a.T + 7) / 8) * 8 * a.nco;
@@ -592,6 +632,10 @@ int launch_pw_split(PwSplitArgs& a, hipStream_t st) {
     // 128-pixel tiles everywhere: two workgroups per CU overlap each other's fill/drain and barriers
     // (measured faster than 256-pixel tiles with one workgroup per CU on every layer shape)
     const int cfg = pws_cfg();
+    if (split_mode() == 1) {  // plain bf16 operands, one MFMA per product
+        if (a.M > 64) return launch_pw_split_cfg<2, 2, 2, 2, 256, 2, 1>(a, st);
+        return launch_pw_split_cfg<1, 2, 4, 1, 256, 2, 1>(a, st);
+    }
     if (a.M >= 256 && (cfg & 1)) return launch_pw_split_cfg<4, 2, 2, 2, 256>(a, st);  // 256 x 128, 8 consumer waves
     if (a.M > 64 && (cfg & 2)) return launch_pw_split_cfg<2, 2, 2, 2, 256, 3>(a, st);  // 128 x 128, 3 LDS buffers
     if (a.M > 64) return launch_pw_split_cfg<2, 2, 2, 2, 256>(a, st);  // 128 x 128

@@ -109,12 +109,26 @@ def _split_on():
 SPLIT_POLICY = "auto"  # "auto" = the measured policy; "all" = every supported shape (parity tests)
 
 
+def _split_all():
+    # mode 1 (plain bf16 operands, one MFMA per product) is 6x cheaper on the matrix pipe: use it wherever supported
+    return SPLIT_POLICY == "all" or _lib.get().smaat_split_mode() == 1
+
+
 def _split_fwd_ok(k, cout):
-    return _split_on() and (SPLIT_POLICY == "all" or (k >= 128 and cout >= 128))
+    return _split_on() and (_split_all() or (k >= 128 and cout >= 128))
 
 
 def _split_dgrad_ok(cout):
-    return _split_on() and (SPLIT_POLICY == "all" or cout >= 256)
+    return _split_on() and (_split_all() or cout >= 256)
+
+
+def set_matrix_mode(mode):
+    """"f32" = f32-MFMA kernels only; "f32_split" (default) = exact three-term bf16 operand split (f32-class
+    error); "bf16" = bf16 operands / f32 accumulation (mixed precision, BASELINE configs[3]).  Returns the
+    previous mode string."""
+    codes = {"f32": 0, "bf16": 1, "f32_split": 3}
+    prev = _lib.get().smaat_set_split_mode(codes[mode])
+    return {0: "f32", 1: "bf16", 2: "f32_split2", 3: "f32_split"}[prev]
 
 
 def _split_planes_raw(w2d):

@@ -77,6 +77,14 @@ class EmuLib:
     def smaat_split_enabled(self):
         return EmuLib.SPLIT_ENABLED
 
+    def smaat_split_mode(self):
+        return 3 if EmuLib.SPLIT_ENABLED else 0
+
+    def smaat_set_split_mode(self, mode):
+        prev = self.smaat_split_mode()
+        EmuLib.SPLIT_ENABLED = 1 if mode else 0
+        return prev
+
     def smaat_pw_split_num_slots(self, N, H, W):
         return PW_SLOTS + 1
 
