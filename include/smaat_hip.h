@@ -71,6 +71,14 @@ int smaat_pointwise_wgrad(const float* x, long x_bs, const float* dz, long dz_bs
 int smaat_dw3x3_bwd_ws_rows(int N, int Cin, int H, int W);
 int smaat_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, const float* w_dw, float* dx, long dx_bs,
                     float* ws, float* dw_out, float* db_out, int N, int Cin, int kpl, int H, int W, void* stream);
+/* same, when x is the output y = relu(bn(z)) of a preceding train-mode BatchNorm2d + ReLU (the first half of a
+ * DoubleConvDS, unet_parts_depthwise_separable.py:17-36): additionally emits that BatchNorm's backward reduction
+ *   rpart[0][r][ci] = sum dX*[y>0],  rpart[1][r][ci] = sum dX*[y>0]*(y - beta)/gamma     (r < smaat_dw3x3_bwd_ws_rows - 1)
+ * which smaat_bn_bwd_finalize consumes in place of the output of smaat_bn_bwd_reduce (one pass over dy and z saved).
+ * Returns -2 when the shape is not handled by the strip kernel (W % 4 != 0 ...): run the two kernels separately. */
+int smaat_dw3x3_bwd_bnred(const float* x, long x_bs, const float* dy, long dy_bs, const float* w_dw, float* dx,
+                          long dx_bs, float* ws, float* dw_out, float* db_out, const float* bn_gamma,
+                          const float* bn_beta, float* rpart, int N, int Cin, int kpl, int H, int W, void* stream);
 
 /* ---- BatchNorm2d (train) + ReLU   reference: unet_parts_depthwise_separable.py:25-26,34-35,
  *      layers.py:120,127.  Statistics arrive as partial sums (from smaat_dsconv_fwd etc.).

@@ -32,7 +32,7 @@ int launch_maxpool2_bwd(const float*, long, const float*, long, float*, long, in
 int launch_upsample2x_fwd(const float*, long, float*, long, int, int, int, int, int, int, int, int, hipStream_t);
 int launch_upsample2x_bwd(const float*, long, float*, long, int, int, int, int, int, int, int, int, hipStream_t);
 int launch_dw3x3_bwd(const float*, long, const float*, long, const float*, float*, long, float*, int, int, int, int,
-                     int, hipStream_t);
+                     int, hipStream_t, const float*, const float*, float*);
 int launch_dw_split(const float*, int, float*, float*, hipStream_t);
 int dw_bwd_groups(int N, int Cin, int H, int W);
 
@@ -131,7 +131,20 @@ int smaat_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, cons
     const int Cdw = Cin * kpl;
     hipStream_t st = ST;
     const int rows = N * dw_bwd_groups(N, Cin, H, W);
-    CHK(launch_dw3x3_bwd(x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, ws, N, Cin, kpl, H, W, st));
+    CHK(launch_dw3x3_bwd(x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, ws, N, Cin, kpl, H, W, st, nullptr, nullptr, nullptr));
+    float* tmp = ws + (long)rows * Cdw * 10;
+    CHK(launch_reduce_rows(ws, rows, (long)Cdw * 10, tmp, 1.f, st));
+    return launch_dw_split(tmp, Cdw, dw_out, db_out, st);
+}
+
+int smaat_dw3x3_bwd_bnred(const float* x, long x_bs, const float* dy, long dy_bs, const float* w_dw, float* dx,
+                          long dx_bs, float* ws, float* dw_out, float* db_out, const float* bn_gamma,
+                          const float* bn_beta, float* rpart, int N, int Cin, int kpl, int H, int W, void* stream) {
+    if (!dx || !rpart) return -1;
+    const int Cdw = Cin * kpl;
+    hipStream_t st = ST;
+    const int rows = N * dw_bwd_groups(N, Cin, H, W);
+    CHK(launch_dw3x3_bwd(x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, ws, N, Cin, kpl, H, W, st, bn_gamma, bn_beta, rpart));
     float* tmp = ws + (long)rows * Cdw * 10;
     CHK(launch_reduce_rows(ws, rows, (long)Cdw * 10, tmp, 1.f, st));
     return launch_dw_split(tmp, Cdw, dw_out, db_out, st);

@@ -463,7 +463,13 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd_strip(const float* __restrict
                                                          const float* __restrict__ dy, long dy_bs,
                                                          const float* __restrict__ w_dw, float* __restrict__ dx,
                                                          long dx_bs, float* __restrict__ part, int Cin,
-                                                         const DwbGeom g) {
+                                                         const DwbGeom g, const float* __restrict__ bn_g,
+                                                         const float* __restrict__ bn_b, float* __restrict__ rpart) {
+    // rpart (nullable): x is the output y = relu(bn(z)) of a preceding train-mode BatchNorm with affine
+    // (bn_g, bn_b); the kernel then also emits that BatchNorm's backward reduction over its planes,
+    //   rpart[0][row][ci] = sum g,  rpart[1][row][ci] = sum g * zhat,   g = dX * [y > 0],  zhat = (y - beta) / gamma
+    // (for y > 0, (y - beta) / gamma IS the normalised pre-activation), so the separate pass over (dy, z) of
+    // smaat_bn_bwd_reduce is not needed.
     constexpr int NSL = 6;  // float4 staging slots per thread: KPL * nrow * ncol4 <= 1536
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     float* S = dsm;                   // [KPL][ssz]
@@ -485,6 +491,10 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd_strip(const float* __restrict
     for (int j = 0; j < KPL; ++j)
 #pragma unroll
         for (int t = 0; t < 9; ++t) wt[j][t] = w_dw[(ci * KPL + j) * 9 + t];
+    float r1 = 0.f, r2 = 0.f;
+    const float rbeta = (rpart && bn_b) ? bn_b[ci] : 0.f;
+    const float rgam = (rpart && bn_g) ? bn_g[ci] : 1.f;
+    const float rinvg = rgam != 0.f ? 1.f / rgam : 0.f;
 
     // tile-independent thread constants
     const int per = g.nrow * g.ncol4, F = KPL * per;
@@ -579,7 +589,22 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd_strip(const float* __restrict
                     for (int i = 0; i < 4; ++i)
                         if (ok[i]) dxp[po + i * g.W] = dxa[i];
                 }
+                if (rpart) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float gg = (xc[i] > 0.f) ? dxa[i] : 0.f;  // xc is 0 outside the image
+                        r1 += gg;
+                        r2 = fmaf(gg, (xc[i] - rbeta) * rinvg, r2);
+                    }
+                }
             }
+        }
+    }
+    if (rpart) {
+        const float v1 = wave_sum_l63(r1), v2 = wave_sum_l63(r2);
+        if (lane == 63) {
+            red[4 * KPL * 10 + wave * 2 + 0] = v1;
+            red[4 * KPL * 10 + wave * 2 + 1] = v2;
         }
     }
 #pragma unroll
@@ -591,6 +616,12 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd_strip(const float* __restrict
         }
     }
     __syncthreads();
+    if (rpart && tid < 2) {
+        const float* rr_ = red + 4 * KPL * 10;
+        const float v = rr_[tid] + rr_[2 + tid] + rr_[4 + tid] + rr_[6 + tid];
+        const long rows = (long)gridDim.y * (gridDim.x / Cin);
+        rpart[((long)tid * rows + (long)n * gridDim.y + blockIdx.y) * Cin + ci] = v;
+    }
     if (tid < KPL * 10) {
         const int j = tid / 10, t = tid - j * 10;
         const float v = red[(0 * KPL + j) * 10 + t] + red[(1 * KPL + j) * 10 + t] + red[(2 * KPL + j) * 10 + t] +
@@ -839,7 +870,8 @@ int dw_bwd_groups(int N, int Cin, int H, int W) {
 }
 
 int launch_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, const float* w_dw, float* dx, long dx_bs,
-                     float* part, int N, int Cin, int kpl, int H, int W, hipStream_t st) {
+                     float* part, int N, int Cin, int kpl, int H, int W, hipStream_t st, const float* bn_g,
+                     const float* bn_b, float* rpart) {
     if (kpl < 1 || kpl > DWB_KPL_MAX) return -1;
     const int groups = dw_bwd_groups(N, Cin, H, W);
     static int use_strip = -1;
@@ -853,20 +885,21 @@ int launch_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, con
     if (use_strip && aligned) {
         const DwbGeom sg = strip_geom(H, W, kpl);
         if (kpl * sg.nrow * sg.ncol4 <= 1536) {
-            const size_t lds = sizeof(float) * ((size_t)kpl * sg.ssz + 4 * kpl * 10);
+            const size_t lds = sizeof(float) * ((size_t)kpl * sg.ssz + 4 * kpl * 10 + 8);
             dim3 grid(N * Cin, groups);
             if (kpl == 1)
                 hipLaunchKernelGGL(k_dw3x3_bwd_strip<1>, grid, dim3(256), lds, st, x, x_bs, dy, dy_bs, w_dw, dx, dx_bs,
-                                   part, Cin, sg);
+                                   part, Cin, sg, bn_g, bn_b, rpart);
             else if (kpl == 2)
                 hipLaunchKernelGGL(k_dw3x3_bwd_strip<2>, grid, dim3(256), lds, st, x, x_bs, dy, dy_bs, w_dw, dx, dx_bs,
-                                   part, Cin, sg);
+                                   part, Cin, sg, bn_g, bn_b, rpart);
             else
                 hipLaunchKernelGGL(k_dw3x3_bwd_strip<4>, grid, dim3(256), lds, st, x, x_bs, dy, dy_bs, w_dw, dx, dx_bs,
-                                   part, Cin, sg);
+                                   part, Cin, sg, bn_g, bn_b, rpart);
             return (int)hipGetLastError();
         }
     }
+    if (rpart) return -2;  // the fused BatchNorm reduction exists in the strip kernel only
     TileGeom g;
     choose_geom_pub(N, H, W, 256, DWB_SMAX, &g);
     if (g.mode < 0) return -1;

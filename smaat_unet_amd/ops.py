@@ -203,18 +203,23 @@ def _affine_act_raw(z, scale, shift, relu, out=None):
     return out
 
 
-def _bn_bwd_raw(dy, z, st, gamma, relu, train):
-    """dz, dgamma, dbeta for y = relu?(bn(z)).  st rows: mean, invstd, scale, shift."""
+def _bn_bwd_raw(dy, z, st, gamma, relu, train, pre_part=None):
+    """dz, dgamma, dbeta for y = relu?(bn(z)).  st rows: mean, invstd, scale, shift.
+    pre_part = (part [2][slots][C], slots): the reduction already produced by smaat_dw3x3_bwd_bnred."""
     L = _lib.get()
     dy, dy_bs = _planes(dy)
     z, z_bs = _planes(z)
     n, c, h, w = z.shape
     p = h * w
-    slots = L.smaat_plane_num_slots(n, p)
-    part = _new(z, 2, slots, c)
     s = _stream(z)
-    _lib.check(L.smaat_bn_bwd_reduce(_ptr(dy), dy_bs, _ptr(z), z_bs, _ptr(st[2]), _ptr(st[3]), _ptr(st[0]),
-                                     _ptr(st[1]), _ptr(part), n, c, p, 1 if relu else 0, s), "smaat_bn_bwd_reduce")
+    if pre_part is not None:
+        part, slots = pre_part
+    else:
+        slots = L.smaat_plane_num_slots(n, p)
+        part = _new(z, 2, slots, c)
+        _lib.check(L.smaat_bn_bwd_reduce(_ptr(dy), dy_bs, _ptr(z), z_bs, _ptr(st[2]), _ptr(st[3]), _ptr(st[0]),
+                                         _ptr(st[1]), _ptr(part), n, c, p, 1 if relu else 0, s),
+                   "smaat_bn_bwd_reduce")
     dgamma = _new(z, c)
     dbeta = _new(z, c)
     coef = _new(z, 3, c)
@@ -253,7 +258,7 @@ def _pointwise_wgrad_raw(y, dz, m):
     return dw
 
 
-def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None):
+def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None):
     """gradients of z = pointwise(depthwise(x)) given dz: dx, dw_dw, db_dw, dw_pw.
     y: the depthwise output kept by the forward (streamed weight gradient); when None the
     memory-lean kernel recomputes it from x."""
@@ -287,8 +292,22 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None):
     ws2 = _new(x, L.smaat_dw3x3_bwd_ws_rows(n, cin, h, w), k, 10)
     dw_dw = _new(x, k, 1, 3, 3)
     db_dw = _new(x, k)
+    red = None
+    if bnred is not None and need_dx:
+        # x = relu(bn(z_prev)): let the depthwise backward also reduce the previous BatchNorm's backward sums
+        gam, bet = bnred
+        rows = L.smaat_dw3x3_bwd_ws_rows(n, cin, h, w) - 1
+        rpart = _new(x, 2, rows, cin)
+        rc = L.smaat_dw3x3_bwd_bnred(_ptr(x), x_bs, _ptr(dy), k * h * w, _ptr(w_dw), _ptr(dx), cin * h * w, _ptr(ws2),
+                                     _ptr(dw_dw), _ptr(db_dw), _ptr(gam), _ptr(bet), _ptr(rpart), n, cin, kpl, h, w, s)
+        if rc == 0:
+            return dx, dw_dw, db_dw, dw_pw, (rpart, rows)
+        if rc != -2:
+            _lib.check(rc, "smaat_dw3x3_bwd_bnred")
     _lib.check(L.smaat_dw3x3_bwd(_ptr(x), x_bs, _ptr(dy), k * h * w, _ptr(w_dw), _ptr(dx), cin * h * w, _ptr(ws2),
                                  _ptr(dw_dw), _ptr(db_dw), n, cin, kpl, h, w, s), "smaat_dw3x3_bwd")
+    if bnred is not None:
+        return dx, dw_dw, db_dw, dw_pw, red
     return dx, dw_dw, db_dw, dw_pw
 
 
@@ -300,68 +319,125 @@ KEEP_DEPTHWISE_OUTPUT = True
 # --------------------------------------------------------------------------------------
 # DepthwiseSeparableConv (+ BatchNorm2d + ReLU)
 # --------------------------------------------------------------------------------------
+def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, momentum, eps, kpl, keep_y):
+    """DepthwiseSeparableConv -> BatchNorm2d -> ReLU.  Returns y, z, st, y_dw, use_batch_stats."""
+    n, cin, h, w = x.shape
+    cout = w_pw.shape[0]
+    use_batch_stats = training or rm is None
+    y_dw = None
+    rs = (_dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats)
+          if _split_fwd_ok(cin * kpl, cout) else None)
+    if rs is not None and use_batch_stats:
+        z, part, slots, y_dw = rs
+        if not keep_y:
+            y_dw = None
+        st = _bn_finalize_raw(part, slots, cout, n * h * w, b_pw, gamma, beta, eps,
+                              momentum if momentum is not None else 0.0, rm if training else None,
+                              rv if training else None)
+    elif use_batch_stats:
+        r = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, True, want_y=keep_y)
+        z, part, slots = r[:3]
+        y_dw = r[3] if keep_y else None
+        st = _bn_finalize_raw(part, slots, cout, n * h * w, b_pw, gamma, beta, eps,
+                              momentum if momentum is not None else 0.0, rm if training else None,
+                              rv if training else None)
+    else:
+        if rs is not None:
+            z, y_dw = rs[0], (rs[3] if keep_y else None)
+        else:
+            r = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, False, want_y=keep_y)
+            z = r[0]
+            y_dw = r[3] if keep_y else None
+        invstd = torch.rsqrt(rv + eps)
+        g = gamma if gamma is not None else torch.ones_like(rm)
+        b = beta if beta is not None else torch.zeros_like(rm)
+        scale = g * invstd
+        st = torch.stack([rm, invstd, scale, b - rm * scale]).contiguous()
+    y = _affine_act_raw(z, st[2], st[3], True)
+    return y, z, st, y_dw, use_batch_stats
+
+
+def _half_backward(x, w_dw, b_dw, w_pw, gamma, z, st, y_dw, dy, kpl, train_stats, has_bias, need_dx, pre_part=None,
+                   bnred=None):
+    """-> (dx, dw_dw, db_dw, dw_pw, db_pw, dgamma, dbeta), red.  pre_part: this BatchNorm's backward sums
+    (from the following block's depthwise backward); bnred=(gamma_prev, beta_prev): emit the previous one's."""
+    dz, dgamma, dbeta = _bn_bwd_raw(dy, z, st, gamma, True, train_stats, pre_part=pre_part)
+    r = _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=y_dw, bnred=bnred)
+    dx, dw_dw, db_dw, dw_pw = r[:4]
+    red = r[4] if bnred is not None else None
+    if train_stats:
+        # a bias in front of a train-mode BatchNorm has an exactly-zero gradient
+        db_pw = torch.zeros_like(dgamma) if has_bias[1] else None
+    else:
+        db_pw = _channel_sum_raw(dz) if has_bias[1] else None
+    if not has_bias[0]:
+        db_dw = None
+    if gamma is None:
+        dgamma = dbeta = None
+    return (dx, dw_dw, db_dw, dw_pw, db_pw, dgamma, dbeta), red
+
+
 class _DSConvBNReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, momentum, eps, kpl):
         _check(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv)
         w_dw = w_dw.contiguous()
         w_pw = w_pw.contiguous()
-        n, cin, h, w = x.shape
-        cout = w_pw.shape[0]
-        use_batch_stats = training or rm is None
         keep_y = KEEP_DEPTHWISE_OUTPUT and any(ctx.needs_input_grad[:4])  # forward runs under no_grad
-        y_dw = None
-        rs = (_dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats)
-              if _split_fwd_ok(cin * kpl, cout) else None)
-        if rs is not None and use_batch_stats:
-            z, part, slots, y_dw = rs
-            if not keep_y:
-                y_dw = None
-            st = _bn_finalize_raw(part, slots, cout, n * h * w, b_pw, gamma, beta, eps,
-                                  momentum if momentum is not None else 0.0, rm if training else None,
-                                  rv if training else None)
-        elif use_batch_stats:
-            r = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, True, want_y=keep_y)
-            z, part, slots = r[:3]
-            y_dw = r[3] if keep_y else None
-            st = _bn_finalize_raw(part, slots, cout, n * h * w, b_pw, gamma, beta, eps,
-                                  momentum if momentum is not None else 0.0, rm if training else None,
-                                  rv if training else None)
-        else:
-            if rs is not None:
-                z, y_dw = rs[0], (rs[3] if keep_y else None)
-            else:
-                r = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, False, want_y=keep_y)
-                z = r[0]
-                y_dw = r[3] if keep_y else None
-            invstd = torch.rsqrt(rv + eps)
-            g = gamma if gamma is not None else torch.ones_like(rm)
-            b = beta if beta is not None else torch.zeros_like(rm)
-            scale = g * invstd
-            st = torch.stack([rm, invstd, scale, b - rm * scale]).contiguous()
-        y = _affine_act_raw(z, st[2], st[3], True)
+        y, z, st, y_dw, ubs = _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, momentum, eps,
+                                            kpl, keep_y)
         ctx.save_for_backward(x, w_dw, b_dw, w_pw, gamma, z, st, y_dw)
         ctx.kpl = kpl
-        ctx.train_stats = use_batch_stats
+        ctx.train_stats = ubs
         ctx.has_bias = (b_dw is not None, b_pw is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w_dw, b_dw, w_pw, gamma, z, st, y_dw = ctx.saved_tensors
-        dz, dgamma, dbeta = _bn_bwd_raw(dy, z, st, gamma, True, ctx.train_stats)
-        need_dx = ctx.needs_input_grad[0]
-        dx, dw_dw, db_dw, dw_pw = _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, ctx.kpl, need_dx, y=y_dw)
-        if ctx.train_stats:
-            # a bias in front of a train-mode BatchNorm has an exactly-zero gradient
-            db_pw = torch.zeros_like(dgamma) if ctx.has_bias[1] else None
-        else:
-            db_pw = _channel_sum_raw(dz) if ctx.has_bias[1] else None
-        if not ctx.has_bias[0]:
-            db_dw = None
-        if gamma is None:
-            dgamma = dbeta = None
-        return dx, dw_dw, db_dw, dw_pw, db_pw, dgamma, dbeta, None, None, None, None, None, None
+        g, _ = _half_backward(x, w_dw, b_dw, w_pw, gamma, z, st, y_dw, dy, ctx.kpl, ctx.train_stats, ctx.has_bias,
+                              ctx.needs_input_grad[0])
+        return g + (None,) * 6
+
+
+class _DoubleConvDS(torch.autograd.Function):
+    """(DepthwiseSeparableConv => BN => ReLU) * 2 as ONE autograd node (reference
+    unet_parts_depthwise_separable.py:10-39), so that the backward of the second half can hand the first
+    BatchNorm's backward reduction to the first half (computed inside the depthwise backward kernel, which
+    already streams dX and y1): one pass over (dy1, z1) less."""
+
+    @staticmethod
+    def forward(ctx, x, w_dw1, b_dw1, w_pw1, b_pw1, g1, be1, rm1, rv1, w_dw2, b_dw2, w_pw2, b_pw2, g2, be2, rm2, rv2,
+                tr1, mo1, eps1, tr2, mo2, eps2, kpl):
+        _check(x, w_dw1, b_dw1, w_pw1, b_pw1, g1, be1, rm1, rv1, w_dw2, b_dw2, w_pw2, b_pw2, g2, be2, rm2, rv2)
+        w_dw1, w_pw1, w_dw2, w_pw2 = (t.contiguous() for t in (w_dw1, w_pw1, w_dw2, w_pw2))
+        keep_y = KEEP_DEPTHWISE_OUTPUT and any(ctx.needs_input_grad[:17])
+        y1, z1, st1, ydw1, ubs1 = _half_forward(x, w_dw1, b_dw1, w_pw1, b_pw1, g1, be1, rm1, rv1, tr1, mo1, eps1, kpl,
+                                                keep_y)
+        y2, z2, st2, ydw2, ubs2 = _half_forward(y1, w_dw2, b_dw2, w_pw2, b_pw2, g2, be2, rm2, rv2, tr2, mo2, eps2, kpl,
+                                                keep_y)
+        ctx.save_for_backward(x, w_dw1, b_dw1, w_pw1, g1, be1, z1, st1, ydw1, y1, w_dw2, b_dw2, w_pw2, g2, z2, st2,
+                              ydw2)
+        ctx.kpl = kpl
+        ctx.train_stats = (ubs1, ubs2)
+        ctx.has_bias = ((b_dw1 is not None, b_pw1 is not None), (b_dw2 is not None, b_pw2 is not None))
+        return y2
+
+    @staticmethod
+    def backward(ctx, dy2):
+        (x, w_dw1, b_dw1, w_pw1, g1, be1, z1, st1, ydw1, y1, w_dw2, b_dw2, w_pw2, g2, z2, st2,
+         ydw2) = ctx.saved_tensors
+        gr2, red = _half_backward(y1, w_dw2, b_dw2, w_pw2, g2, z2, st2, ydw2, dy2, ctx.kpl, ctx.train_stats[1],
+                                  ctx.has_bias[1], True, bnred=(g1, be1))
+        gr1, _ = _half_backward(x, w_dw1, b_dw1, w_pw1, g1, z1, st1, ydw1, gr2[0], ctx.kpl, ctx.train_stats[0],
+                                ctx.has_bias[0], ctx.needs_input_grad[0], pre_part=red)
+        return gr1 + (None, None) + gr2[1:] + (None, None) + (None,) * 7
+
+
+def double_conv_ds(x, half1, half2, kpl):
+    """half = (w_dw, b_dw, w_pw, b_pw, gamma, beta, running_mean, running_var, training, momentum, eps)"""
+    a, b = half1, half2
+    return _DoubleConvDS.apply(x, *a[:8], *b[:8], a[8], a[9], a[10], b[8], b[9], b[10], kpl)
 
 
 def dsconv_bn_relu(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, running_mean, running_var, training, momentum, eps, kpl):

@@ -46,8 +46,16 @@ class DoubleConvDS(nn.Module):
 
     def forward(self, x):
         seq = self.double_conv
-        x = self._half(x, seq[0], seq[1])
-        return self._half(x, seq[3], seq[4])
+        hooked = any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks for m in seq.modules())
+        if hooked or seq[0].kernels_per_layer_ != seq[3].kernels_per_layer_:
+            x = self._half(x, seq[0], seq[1])
+            return self._half(x, seq[3], seq[4])
+        halves = []
+        for conv, bn in ((seq[0], seq[1]), (seq[3], seq[4])):
+            conv._check_geometry()
+            halves.append((conv.depthwise.weight, conv.depthwise.bias, conv.pointwise.weight, conv.pointwise.bias)
+                          + _bn_args(bn))
+        return ops.double_conv_ds(x, halves[0], halves[1], seq[0].kernels_per_layer_)
 
 
 class _MaxPool2(nn.MaxPool2d):

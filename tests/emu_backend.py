@@ -184,6 +184,24 @@ class EmuLib:
             f32(db_out, K)[:] = gb
         return 0
 
+    def smaat_dw3x3_bwd_bnred(self, x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, ws, dw_out, db_out, bn_gamma, bn_beta, rpart,
+                              N, Cin, kpl, H, W, stream):
+        if W % 4 or H < 4:
+            return -2
+        self.smaat_dw3x3_bwd(x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, ws, dw_out, db_out, N, Cin, kpl, H, W, stream)
+        P = H * W
+        xv = np.array(planes(x, N, Cin, P, x_bs)).astype(np.float64)
+        g = np.array(planes(dx, N, Cin, P, dx_bs)).astype(np.float64) * (xv > 0)
+        gam = f32(bn_gamma, Cin).astype(np.float64) if bn_gamma else np.ones(Cin)
+        bet = f32(bn_beta, Cin).astype(np.float64) if bn_beta else np.zeros(Cin)
+        invg = np.where(gam != 0, 1.0 / np.where(gam != 0, gam, 1.0), 0.0)
+        rows = N
+        rp = f32(rpart, 2 * rows * Cin).reshape(2, rows, Cin)
+        rp[:] = 0
+        rp[0, rows - 1] = g.sum(axis=(0, 2))
+        rp[1, rows - 1] = (g * (xv - bet[None, :, None]) * invg[None, :, None]).sum(axis=(0, 2))
+        return 0
+
     # ------------------------------------------------------------------ batch norm
     def smaat_bn_finalize(self, part, T, C, count, bias_shift, gamma, beta, eps, momentum, rm, rv, mean, invstd, scale,
                           shift, stream):

@@ -234,6 +234,30 @@ def test_dw3x3_fwd(shape):
     both(case_dw_fwd, *shape, bias=False, pad_c=4)
 
 
+def case_dw_bwd_bnred(L, dev, N, Cin, kpl, H, W):
+    K = Cin * kpl
+    x = T(np.maximum(rnd(1, N, Cin, H, W) + 0.3, 0), dev)   # a post-ReLU activation
+    dy = T(rnd(2, N, K, H, W), dev)
+    w_dw = T(rnd(3, K, 9, scale=0.3), dev)
+    gam = T(np.random.default_rng(4).uniform(0.5, 1.5, Cin).astype(np.float32), dev)
+    bet = T(rnd(5, Cin, scale=0.3), dev)
+    dx = torch.full((N, Cin, H, W), float("nan"), device=dev)
+    rows = L.smaat_dw3x3_bwd_ws_rows(N, Cin, H, W)
+    ws = torch.empty((rows, K, 10), device=dev)
+    rpart = torch.full((2, rows - 1, Cin), float("nan"), device=dev)
+    dw, db = torch.full((K, 9), float("nan"), device=dev), torch.full((K,), float("nan"), device=dev)
+    rc = L.smaat_dw3x3_bwd_bnred(P(x), Cin * H * W, P(dy), K * H * W, P(w_dw), P(dx), Cin * H * W, P(ws), P(dw), P(db),
+                                 P(gam), P(bet), P(rpart), N, Cin, kpl, H, W, stream(dev))
+    assert rc == 0
+    return dict(dw=dw, db=db, dx=dx, r1=rpart[0].double().sum(0), r2=rpart[1].double().sum(0))
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 2, 32, 32), (2, 5, 1, 8, 8), (2, 8, 2, 36, 36), (2, 4, 2, 144, 144),
+                                   (2, 3, 2, 288, 288), (1, 4, 2, 100, 100), (1, 3, 4, 8, 12), (1, 5, 2, 10, 12)])
+def test_dw3x3_bwd_bnred(shape):
+    both(case_dw_bwd_bnred, *shape, tol=2e-5)
+
+
 # ----------------------------------------------------------------------------------------
 def case_bn(L, dev, N, C, H, W, relu=1, slice_pad=0):
     Pn = H * W
