@@ -75,10 +75,13 @@ int smaat_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, cons
  * DoubleConvDS, unet_parts_depthwise_separable.py:17-36): additionally emits that BatchNorm's backward reduction
  *   rpart[0][r][ci] = sum dX*[y>0],  rpart[1][r][ci] = sum dX*[y>0]*(y - beta)/gamma     (r < smaat_dw3x3_bwd_ws_rows - 1)
  * which smaat_bn_bwd_finalize consumes in place of the output of smaat_bn_bwd_reduce (one pass over dy and z saved).
+ * in_scale/in_shift (nullable, [Cin]): x then holds the PRE-BatchNorm tensor z and y = relu(z*in_scale + in_shift) is
+ * recomputed on load (the activation of the first half is never written to memory).
  * Returns -2 when the shape is not handled by the strip kernel (W % 4 != 0 ...): run the two kernels separately. */
-int smaat_dw3x3_bwd_bnred(const float* x, long x_bs, const float* dy, long dy_bs, const float* w_dw, float* dx,
-                          long dx_bs, float* ws, float* dw_out, float* db_out, const float* bn_gamma,
-                          const float* bn_beta, float* rpart, int N, int Cin, int kpl, int H, int W, void* stream);
+int smaat_dw3x3_bwd_bnred(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* dy,
+                          long dy_bs, const float* w_dw, float* dx, long dx_bs, float* ws, float* dw_out, float* db_out,
+                          const float* bn_gamma, const float* bn_beta, float* rpart, int N, int Cin, int kpl, int H,
+                          int W, void* stream);
 
 /* ---- BatchNorm2d (train) + ReLU   reference: unet_parts_depthwise_separable.py:25-26,34-35,
  *      layers.py:120,127.  Statistics arrive as partial sums (from smaat_dsconv_fwd etc.).
@@ -165,6 +168,7 @@ int smaat_cbam_bwd_final(float* dx, long dx_bs, const float* davg, const float* 
  *   smaat_split_planes:  w [R][C] f32 -> planes u16 [3][R][Cp], Cp = C rounded up to 16 (zero padded);
  *                        R x C = Cout x K for the forward, K x Cout (the transposed weight) for dX
  *   smaat_dw3x3_fwd:     depthwise 3x3, pad 1 (models/layers.py:38-44,48): x [N][Cin][H][W] -> y [N][Cin*kpl][H][W];
+ *                        optional in_scale/in_shift[Cin]: x := relu(x*sc+sh) on load (as smaat_dsconv_fwd);
  *                        returns -2 when the shape/alignment is not handled (W % 4 != 0): use smaat_dsconv_fwd
  *   smaat_pointwise_fwd_split: out[n][m][p] = sum_c A[m][c] x[n][c][p] + bias[m], A given as planes;
  *                        part: nullable [2][smaat_pw_split_num_slots(N,H,W)][M] BatchNorm partials of out - bias
@@ -174,8 +178,8 @@ int smaat_split_mode(void);
 int smaat_set_split_mode(int mode);
 int smaat_split_planes(const float* w, int R, int C, void* planes, void* stream);
 int smaat_pw_split_num_slots(int N, int H, int W);
-int smaat_dw3x3_fwd(const float* x, long x_bs, const float* w_dw, const float* b_dw, float* y, long y_bs, int N,
-                    int Cin, int kpl, int H, int W, void* stream);
+int smaat_dw3x3_fwd(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                    const float* b_dw, float* y, long y_bs, int N, int Cin, int kpl, int H, int W, void* stream);
 int smaat_pointwise_fwd_split(const float* x, long x_bs, const void* planes, const float* bias, float* out,
                               long out_bs, float* part, int N, int Cin, int M, int H, int W, void* stream);
 

@@ -72,7 +72,7 @@ def main():
         part_s = torch.empty(2, slots_s, cout, device=dev)
 
         def f_fwd_split():
-            assert L.smaat_dw3x3_fwd(x.data_ptr(), cin * p, w_dw.data_ptr(), b_dw.data_ptr(), y.data_ptr(), k * p, N, cin,
+            assert L.smaat_dw3x3_fwd(x.data_ptr(), cin * p, None, None, w_dw.data_ptr(), b_dw.data_ptr(), y.data_ptr(), k * p, N, cin,
                                      2, h, w, st) == 0
             assert L.smaat_split_planes(w_pw.data_ptr(), cout, k, pl_f.data_ptr(), st) == 0
             assert L.smaat_pointwise_fwd_split(y.data_ptr(), k * p, pl_f.data_ptr(), b_pw.data_ptr(), z.data_ptr(),

@@ -56,7 +56,7 @@ def main():
             z = torch.empty(N, cout, h, h, device=dev)
             if L.smaat_split_enabled():
                 yy = torch.empty(N, k, h, h, device=dev)
-                assert L.smaat_dw3x3_fwd(x.data_ptr(), cin * p, w_dw.data_ptr(), b_dw.data_ptr(), yy.data_ptr(), k * p,
+                assert L.smaat_dw3x3_fwd(x.data_ptr(), cin * p, None, None, w_dw.data_ptr(), b_dw.data_ptr(), yy.data_ptr(), k * p,
                                          N, cin, 2, h, h, st) == 0
                 pl = torch.empty(3, cout, (k + 15) // 16 * 16, dtype=torch.int16, device=dev)
                 assert L.smaat_split_planes(w.data_ptr(), cout, k, pl.data_ptr(), st) == 0

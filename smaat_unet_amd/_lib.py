@@ -31,7 +31,7 @@ SIGNATURES = {
     "smaat_pointwise_wgrad": [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _P],
     "smaat_dw3x3_bwd_ws_rows": [_I, _I, _I, _I],
     "smaat_dw3x3_bwd": [_P, _L, _P, _L, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "smaat_dw3x3_bwd_bnred": [_P, _L, _P, _L, _P, _P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "smaat_dw3x3_bwd_bnred": [_P, _L, _P, _P, _P, _L, _P, _P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "smaat_bn_finalize": [_P, _I, _I, _D, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P],
     "smaat_affine_act": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "smaat_plane_num_slots": [_I, _I],
@@ -63,7 +63,7 @@ SIGNATURES = {
     "smaat_set_split_mode": [_I],
     "smaat_split_planes": [_P, _I, _I, _P, _P],
     "smaat_pw_split_num_slots": [_I, _I, _I],
-    "smaat_dw3x3_fwd": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P],
+    "smaat_dw3x3_fwd": [_P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P],
     "smaat_pointwise_fwd_split": [_P, _L, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P],
 }
 
@@ -152,10 +152,11 @@ def _w_pw_split(a):
 
 
 WORK_MODELS = {
-    "smaat_dw3x3_bwd_bnred": lambda a: (38.0 * a[13] * a[14] * a[15] * a[16] * a[17],
-                                        4.0 * a[13] * (a[14] * a[15] + 2 * a[14]) * a[16] * a[17]),
+    "smaat_dw3x3_bwd_bnred": lambda a: (38.0 * a[15] * a[16] * a[17] * a[18] * a[19],
+                                        4.0 * a[15] * (a[16] * a[17] + 2 * a[16]) * a[18] * a[19]),
     "smaat_pointwise_fwd_split": _w_pw_split,
-    "smaat_dw3x3_fwd": lambda a: (18.0 * a[6] * a[7] * a[8] * a[9] * a[10], 4.0 * a[6] * a[7] * (1 + a[8]) * a[9] * a[10]),
+    "smaat_dw3x3_fwd": lambda a: (18.0 * a[8] * a[9] * a[10] * a[11] * a[12],
+                                  4.0 * a[8] * a[9] * (1 + a[10]) * a[11] * a[12]),
     "smaat_dsconv_fwd": _w_dsconv_fwd,
     "smaat_pointwise_fwd": _w_pointwise_fwd,
     "smaat_dsconv_wgrad": _w_dsconv_wgrad,

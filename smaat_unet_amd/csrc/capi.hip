@@ -32,7 +32,7 @@ int launch_maxpool2_bwd(const float*, long, const float*, long, float*, long, in
 int launch_upsample2x_fwd(const float*, long, float*, long, int, int, int, int, int, int, int, int, hipStream_t);
 int launch_upsample2x_bwd(const float*, long, float*, long, int, int, int, int, int, int, int, int, hipStream_t);
 int launch_dw3x3_bwd(const float*, long, const float*, long, const float*, float*, long, float*, int, int, int, int,
-                     int, hipStream_t, const float*, const float*, float*);
+                     int, hipStream_t, const float*, const float*, float*, const float*, const float*);
 int launch_dw_split(const float*, int, float*, float*, hipStream_t);
 int dw_bwd_groups(int N, int Cin, int H, int W);
 
@@ -61,7 +61,8 @@ int set_split_mode(int m);
 int launch_split_planes(const float* w, int R, int C, unsigned short* out, hipStream_t st);
 int pw_split_num_slots(int N, int P);
 int launch_pw_split(PwSplitArgs& a, hipStream_t st);
-int launch_dw3x3_fwd(const float*, long, const float*, const float*, float*, long, int, int, int, int, int, hipStream_t);
+int launch_dw3x3_fwd(const float*, long, const float*, const float*, float*, long, int, int, int, int, int, hipStream_t,
+                     const float*, const float*);
 
 #define ST ((hipStream_t)(((void)hipGetLastError()), stream))
 #define CHK(e)              \
@@ -131,20 +132,21 @@ int smaat_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, cons
     const int Cdw = Cin * kpl;
     hipStream_t st = ST;
     const int rows = N * dw_bwd_groups(N, Cin, H, W);
-    CHK(launch_dw3x3_bwd(x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, ws, N, Cin, kpl, H, W, st, nullptr, nullptr, nullptr));
+    CHK(launch_dw3x3_bwd(x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, ws, N, Cin, kpl, H, W, st, nullptr, nullptr, nullptr, nullptr, nullptr));
     float* tmp = ws + (long)rows * Cdw * 10;
     CHK(launch_reduce_rows(ws, rows, (long)Cdw * 10, tmp, 1.f, st));
     return launch_dw_split(tmp, Cdw, dw_out, db_out, st);
 }
 
-int smaat_dw3x3_bwd_bnred(const float* x, long x_bs, const float* dy, long dy_bs, const float* w_dw, float* dx,
-                          long dx_bs, float* ws, float* dw_out, float* db_out, const float* bn_gamma,
-                          const float* bn_beta, float* rpart, int N, int Cin, int kpl, int H, int W, void* stream) {
+int smaat_dw3x3_bwd_bnred(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* dy,
+                          long dy_bs, const float* w_dw, float* dx, long dx_bs, float* ws, float* dw_out, float* db_out,
+                          const float* bn_gamma, const float* bn_beta, float* rpart, int N, int Cin, int kpl, int H,
+                          int W, void* stream) {
     if (!dx || !rpart) return -1;
     const int Cdw = Cin * kpl;
     hipStream_t st = ST;
     const int rows = N * dw_bwd_groups(N, Cin, H, W);
-    CHK(launch_dw3x3_bwd(x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, ws, N, Cin, kpl, H, W, st, bn_gamma, bn_beta, rpart));
+    CHK(launch_dw3x3_bwd(x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, ws, N, Cin, kpl, H, W, st, bn_gamma, bn_beta, rpart, in_scale, in_shift));
     float* tmp = ws + (long)rows * Cdw * 10;
     CHK(launch_reduce_rows(ws, rows, (long)Cdw * 10, tmp, 1.f, st));
     return launch_dw_split(tmp, Cdw, dw_out, db_out, st);
@@ -262,10 +264,10 @@ int smaat_split_planes(const float* w, int R, int C, void* planes, void* stream)
     return launch_split_planes(w, R, C, (unsigned short*)planes, ST);
 }
 int smaat_pw_split_num_slots(int N, int H, int W) { return pw_split_num_slots(N, H * W); }
-int smaat_dw3x3_fwd(const float* x, long x_bs, const float* w_dw, const float* b_dw, float* y, long y_bs, int N,
-                    int Cin, int kpl, int H, int W, void* stream) {
+int smaat_dw3x3_fwd(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                    const float* b_dw, float* y, long y_bs, int N, int Cin, int kpl, int H, int W, void* stream) {
     if (N < 1 || Cin < 1 || H < 1 || W < 1) return -1;
-    return launch_dw3x3_fwd(x, x_bs, w_dw, b_dw, y, y_bs, N, Cin, kpl, H, W, ST);
+    return launch_dw3x3_fwd(x, x_bs, w_dw, b_dw, y, y_bs, N, Cin, kpl, H, W, ST, in_scale, in_shift);
 }
 int smaat_pointwise_fwd_split(const float* x, long x_bs, const void* planes, const float* bias, float* out,
                               long out_bs, float* part, int N, int Cin, int M, int H, int W, void* stream) {

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
 //                             Sc(i+2)   : halo registers   -> S[i&1];       issue loads S(i+3)
 //                  barrier
 // =====================================================================================
-template <int WCO, int CT, int WPX, int PXT, int MODE, int NPT>
+template <int WCO, int CT, int WPX, int PXT, int MODE, int NPT, bool AFF = false>
 __global__ __launch_bounds__(256 + NPT) void k_pwgemm_ws(const PwArgs a) {
     constexpr bool DW = MODE > 0;
     constexpr int KPL = DW ? MODE : 1;
@@ -414,6 +414,7 @@ __global__ __launch_bounds__(256 + NPT) void k_pwgemm_ws(const PwArgs a) {
     const float* xn = a.x + (long)n * a.x_bs;
 
     float sreg[DW ? KCI : 1][NS];
+    float ascr[(DW && AFF) ? KCI : 1], ashr[(DW && AFF) ? KCI : 1];  // input affine of the chunk's channels
     float yreg[DW ? 1 : NY];
     float wreg[NW];
     int gsafe[NS];
@@ -457,6 +458,10 @@ __global__ __launch_bounds__(256 + NPT) void k_pwgemm_ws(const PwArgs a) {
                 const float* plane = xn + (long)(ci < a.Cin ? ci : a.Cin - 1) * g.P;
 #pragma unroll
                 for (int j = 0; j < NS; ++j) sreg[cl][j] = plane[gsafe[j]];
+                if (AFF) {
+                    ascr[cl] = a.in_scale[ci < a.Cin ? ci : a.Cin - 1];
+                    ashr[cl] = a.in_shift[ci < a.Cin ? ci : a.Cin - 1];
+                }
             }
             if (!TAPS_SMEM) {
                 const int kg = k0 + (dwk < KC ? dwk : 0);
@@ -496,7 +501,8 @@ __global__ __launch_bounds__(256 + NPT) void k_pwgemm_ws(const PwArgs a) {
 #pragma unroll
                 for (int j = 0; j < NS; ++j) {
                     float v = sreg[cl][j];
-                    v = (cv && gm[j]) ? v : 0.f;
+                    if (AFF) v = fmaxf(fmaf(v, ascr[cl], ashr[cl]), 0.f);  // relu(bn(z)) of the previous half on load
+                    v = (cv && gm[j]) ? v : 0.f;                           // zero padding stays zero
                     Sb[cl * sstride + ptid + NPT * j] = v;  // every slot of the stripe is written: no divergent branch
                 }
             }
@@ -1364,11 +1370,17 @@ static int ensure_lds(size_t lds) {
     return 0;
 }
 
+static int pw_impl();
+static void choose_geom_ws(int N, int H, int W, int PT, TileGeom* g);
+
 template <int WCO, int CT, int WPX, int PXT, int MODE>
 static int launch_pwgemm_mode(PwArgs& a, hipStream_t st) {
     constexpr int COT = WCO * CT * 32, PT = WPX * PXT * 32;
     constexpr bool DW = MODE > 0;
-    choose_geom(a.N, a.g.H, a.g.W, PT, SMAX, &a.g);
+    if (DW && pw_impl() >= 1)
+        choose_geom_ws(a.N, a.g.H, a.g.W, PT, &a.g);  // same tiles (= partial-statistics slots) as the ws family
+    else
+        choose_geom(a.N, a.g.H, a.g.W, PT, SMAX, &a.g);
     if (a.g.mode < 0) return -1;
     a.nco = ceil_div(a.M, COT);
     // staged floats per input channel: the exact region size, padded to a multiple of 32
@@ -1470,7 +1482,7 @@ static int launch_dsconv_strip(PwArgs& a, hipStream_t st) {
     return -1;
 }
 
-template <int WCO, int CT, int WPX, int PXT, int MODE, int NPT>
+template <int WCO, int CT, int WPX, int PXT, int MODE, int NPT, bool AFF = false>
 static int launch_pwgemm_ws_mode(PwArgs& a, hipStream_t st) {
     constexpr int COT = WCO * CT * 32, PT = WPX * PXT * 32;
     constexpr bool DW = MODE > 0;
@@ -1482,7 +1494,7 @@ static int launch_pwgemm_ws_mode(PwArgs& a, hipStream_t st) {
     const size_t lds = sizeof(float) * (size_t)(2 * KC * PT + 2 * KC * COT + 2 * 256 + WPX * 2 * COT + 2 * PT + COT +
                                                 (DW ? 2 * kci * SMAX_WS : 0));
     const int grid = ceil_div(a.g.T, 8) * 8 * a.nco;
-    constexpr auto kern = k_pwgemm_ws<WCO, CT, WPX, PXT, MODE, NPT>;
+    constexpr auto kern = k_pwgemm_ws<WCO, CT, WPX, PXT, MODE, NPT, AFF>;
     int rc = ensure_lds<kern>(lds);
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256 + NPT), lds, st, a);
@@ -1535,7 +1547,16 @@ int launch_pwgemm(PwArgs& a, bool dw, hipStream_t st) {
         }
         a.dbg = abl;
     }
-    const int impl = (dw && a.in_scale != nullptr) ? 0 : pw_impl();  // the input-affine form stays on the single-role kernel
+    if (dw && a.in_scale != nullptr && a.M <= 64 && pw_impl() >= 1) {
+        // input-affine form (second half of a DoubleConvDS reading the first half's pre-BN tensor) on the
+        // wave-specialised kernel for the 64-wide co tile; wider tiles use the single-role kernel below
+        switch (a.kpl) {
+            case 1: return big ? launch_pwgemm_ws_mode<1, 2, 4, 2, 1, 512, true>(a, st) : launch_pwgemm_ws_mode<1, 2, 4, 1, 1, 512, true>(a, st);
+            case 2: return big ? launch_pwgemm_ws_mode<1, 2, 4, 2, 2, 512, true>(a, st) : launch_pwgemm_ws_mode<1, 2, 4, 1, 2, 512, true>(a, st);
+            case 4: return big ? launch_pwgemm_ws_mode<1, 2, 4, 2, 4, 512, true>(a, st) : launch_pwgemm_ws_mode<1, 2, 4, 1, 4, 512, true>(a, st);
+        }
+    }
+    const int impl = (dw && a.in_scale != nullptr) ? 0 : pw_impl();  // other input-affine shapes: single-role kernel
     // impl 5 (default): per-shape choice measured on MI355X (profiles/r1): the strip producer for
     // wide co tiles on 2-D pixel tiles, the generic wave-specialised kernel with 8 producer waves
     // for everything else that has a depthwise stage, and the single-role kernel for the plain

@@ -464,7 +464,9 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd_strip(const float* __restrict
                                                          const float* __restrict__ w_dw, float* __restrict__ dx,
                                                          long dx_bs, float* __restrict__ part, int Cin,
                                                          const DwbGeom g, const float* __restrict__ bn_g,
-                                                         const float* __restrict__ bn_b, float* __restrict__ rpart) {
+                                                         const float* __restrict__ bn_b, float* __restrict__ rpart,
+                                                         const float* __restrict__ in_scale,
+                                                         const float* __restrict__ in_shift) {
     // rpart (nullable): x is the output y = relu(bn(z)) of a preceding train-mode BatchNorm with affine
     // (bn_g, bn_b); the kernel then also emits that BatchNorm's backward reduction over its planes,
     //   rpart[0][row][ci] = sum g,  rpart[1][row][ci] = sum g * zhat,   g = dX * [y > 0],  zhat = (y - beta) / gamma
@@ -492,6 +494,10 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd_strip(const float* __restrict
 #pragma unroll
         for (int t = 0; t < 9; ++t) wt[j][t] = w_dw[(ci * KPL + j) * 9 + t];
     float r1 = 0.f, r2 = 0.f;
+    // in_scale/in_shift (nullable): x holds the PRE-BatchNorm tensor z of the previous half-block and the
+    // activation is recomputed on load, y = relu(z * in_scale[ci] + in_shift[ci])
+    const bool aff = in_scale != nullptr;
+    const float asc = aff ? in_scale[ci] : 1.f, ash = aff ? in_shift[ci] : 0.f;
     const float rbeta = (rpart && bn_b) ? bn_b[ci] : 0.f;
     const float rgam = (rpart && bn_g) ? bn_g[ci] : 1.f;
     const float rinvg = rgam != 0.f ? 1.f / rgam : 0.f;
@@ -561,7 +567,11 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd_strip(const float* __restrict
                     xc[i] = xp[ok[i] ? po + i * g.W : 0];
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) xc[i] = ok[i] ? xc[i] : 0.f;
+                for (int i = 0; i < 4; ++i) {
+                    float v = xc[i];
+                    if (aff) v = fmaxf(fmaf(v, asc, ash), 0.f);
+                    xc[i] = ok[i] ? v : 0.f;
+                }
                 float dxa[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < KPL; ++j) {
@@ -745,7 +755,11 @@ template <int KPL>
 __global__ __launch_bounds__(256) void k_dw3x3_fwd_strip(const float* __restrict__ x, long x_bs,
                                                          const float* __restrict__ w_dw,
                                                          const float* __restrict__ b_dw, float* __restrict__ y,
-                                                         long y_bs, int Cin, const DwbGeom g) {
+                                                         long y_bs, int Cin, const DwbGeom g,
+                                                         const float* __restrict__ in_scale,
+                                                         const float* __restrict__ in_shift) {
+    // in_scale/in_shift (nullable): the input is read as relu(x * in_scale[ci] + in_shift[ci]) -- the
+    // BatchNorm-apply + ReLU of the previous half-block fused into this load (zero padding stays zero)
     constexpr int NSL = 6;
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     float* S = dsm;  // [ssz]
@@ -760,6 +774,8 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_strip(const float* __restrict
         for (int t = 0; t < 9; ++t) wt[j][t] = w_dw[(ci * KPL + j) * 9 + t];
         bs[j] = b_dw ? b_dw[ci * KPL + j] : 0.f;
     }
+    const bool aff = in_scale != nullptr;
+    const float asc = aff ? in_scale[ci] : 1.f, ash = aff ? in_shift[ci] : 0.f;
     const int F = g.nrow * g.ncol4;
     int s_rr[NSL], s_q[NSL], s_lo[NSL];
 #pragma unroll
@@ -792,6 +808,12 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_strip(const float* __restrict
 #pragma unroll
         for (int k = 0; k < NSL; ++k) {
             float4 v = sv[k];
+            if (aff) {  // uniform per block
+                v.x = fmaxf(fmaf(v.x, asc, ash), 0.f);
+                v.y = fmaxf(fmaf(v.y, asc, ash), 0.f);
+                v.z = fmaxf(fmaf(v.z, asc, ash), 0.f);
+                v.w = fmaxf(fmaf(v.w, asc, ash), 0.f);
+            }
             v.x = sok[k] ? v.x : 0.f;
             v.y = sok[k] ? v.y : 0.f;
             v.z = sok[k] ? v.z : 0.f;
@@ -835,7 +857,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_strip(const float* __restrict
 }
 
 int launch_dw3x3_fwd(const float* x, long x_bs, const float* w_dw, const float* b_dw, float* y, long y_bs, int N,
-                     int Cin, int kpl, int H, int W, hipStream_t st) {
+                     int Cin, int kpl, int H, int W, hipStream_t st, const float* in_scale, const float* in_shift) {
     const bool aligned = ((W & 3) == 0) && ((x_bs & 3) == 0) && ((((uintptr_t)x) & 15) == 0) && H >= 1 &&
                          (kpl == 1 || kpl == 2 || kpl == 4);
     if (!aligned) return -2;  // caller falls back to the fused f32 kernel
@@ -849,11 +871,14 @@ int launch_dw3x3_fwd(const float* x, long x_bs, const float* w_dw, const float* 
     const size_t lds = sizeof(float) * (size_t)sg.ssz;
     dim3 grid(N * Cin, groups);
     if (kpl == 1)
-        hipLaunchKernelGGL(k_dw3x3_fwd_strip<1>, grid, dim3(256), lds, st, x, x_bs, w_dw, b_dw, y, y_bs, Cin, sg);
+        hipLaunchKernelGGL(k_dw3x3_fwd_strip<1>, grid, dim3(256), lds, st, x, x_bs, w_dw, b_dw, y, y_bs, Cin, sg,
+                           in_scale, in_shift);
     else if (kpl == 2)
-        hipLaunchKernelGGL(k_dw3x3_fwd_strip<2>, grid, dim3(256), lds, st, x, x_bs, w_dw, b_dw, y, y_bs, Cin, sg);
+        hipLaunchKernelGGL(k_dw3x3_fwd_strip<2>, grid, dim3(256), lds, st, x, x_bs, w_dw, b_dw, y, y_bs, Cin, sg,
+                           in_scale, in_shift);
     else
-        hipLaunchKernelGGL(k_dw3x3_fwd_strip<4>, grid, dim3(256), lds, st, x, x_bs, w_dw, b_dw, y, y_bs, Cin, sg);
+        hipLaunchKernelGGL(k_dw3x3_fwd_strip<4>, grid, dim3(256), lds, st, x, x_bs, w_dw, b_dw, y, y_bs, Cin, sg,
+                           in_scale, in_shift);
     return (int)hipGetLastError();
 }
 
@@ -871,7 +896,7 @@ int dw_bwd_groups(int N, int Cin, int H, int W) {
 
 int launch_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, const float* w_dw, float* dx, long dx_bs,
                      float* part, int N, int Cin, int kpl, int H, int W, hipStream_t st, const float* bn_g,
-                     const float* bn_b, float* rpart) {
+                     const float* bn_b, float* rpart, const float* in_scale, const float* in_shift) {
     if (kpl < 1 || kpl > DWB_KPL_MAX) return -1;
     const int groups = dw_bwd_groups(N, Cin, H, W);
     static int use_strip = -1;
@@ -889,17 +914,17 @@ int launch_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, con
             dim3 grid(N * Cin, groups);
             if (kpl == 1)
                 hipLaunchKernelGGL(k_dw3x3_bwd_strip<1>, grid, dim3(256), lds, st, x, x_bs, dy, dy_bs, w_dw, dx, dx_bs,
-                                   part, Cin, sg, bn_g, bn_b, rpart);
+                                   part, Cin, sg, bn_g, bn_b, rpart, in_scale, in_shift);
             else if (kpl == 2)
                 hipLaunchKernelGGL(k_dw3x3_bwd_strip<2>, grid, dim3(256), lds, st, x, x_bs, dy, dy_bs, w_dw, dx, dx_bs,
-                                   part, Cin, sg, bn_g, bn_b, rpart);
+                                   part, Cin, sg, bn_g, bn_b, rpart, in_scale, in_shift);
             else
                 hipLaunchKernelGGL(k_dw3x3_bwd_strip<4>, grid, dim3(256), lds, st, x, x_bs, dy, dy_bs, w_dw, dx, dx_bs,
-                                   part, Cin, sg, bn_g, bn_b, rpart);
+                                   part, Cin, sg, bn_g, bn_b, rpart, in_scale, in_shift);
             return (int)hipGetLastError();
         }
     }
-    if (rpart) return -2;  // the fused BatchNorm reduction exists in the strip kernel only
+    if (rpart || in_scale) return -2;  // the fused BatchNorm pieces exist in the strip kernel only
     TileGeom g;
     choose_geom_pub(N, H, W, 256, DWB_SMAX, &g);
     if (g.mode < 0) return -1;

@@ -106,6 +106,7 @@ def _split_on():
 # Measured per-shape policy (profiles/r1, MI355X, batch 32): the split GEMMs win where the contraction is
 # deep and the co tile wide; the shallow, plane-dominated layers stay on the fused f32-MFMA kernels
 # (they are HBM/latency bound and the fusion saves a pass over the depthwise output).
+FUSE_FIRST_ACTIVATION = True  # DoubleConvDS: apply the first BatchNorm + ReLU on load instead of writing y1
 SPLIT_POLICY = "auto"  # "auto" = the measured policy; "all" = every supported shape (parity tests)
 
 
@@ -156,23 +157,24 @@ def _pointwise_split_raw(x, planes, bias, m, want_stats=False):
     return out, part, slots
 
 
-def _dw3x3_fwd_raw(x, w_dw, b_dw, kpl):
+def _dw3x3_fwd_raw(x, w_dw, b_dw, kpl, in_scale=None, in_shift=None):
     """standalone depthwise 3x3 forward; None when the library does not handle the shape"""
     L = _lib.get()
     x, x_bs = _planes(x)
     n, cin, h, w = x.shape
     k = cin * kpl
     y = _new(x, n, k, h, w)
-    rc = L.smaat_dw3x3_fwd(_ptr(x), x_bs, _ptr(w_dw), _ptr(b_dw), _ptr(y), k * h * w, n, cin, kpl, h, w, _stream(x))
+    rc = L.smaat_dw3x3_fwd(_ptr(x), x_bs, _ptr(in_scale), _ptr(in_shift), _ptr(w_dw), _ptr(b_dw), _ptr(y), k * h * w,
+                           n, cin, kpl, h, w, _stream(x))
     if rc == -2:
         return None
     _lib.check(rc, "smaat_dw3x3_fwd")
     return y
 
 
-def _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats):
+def _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, in_shift=None):
     """depthwise kernel + split pointwise GEMM; returns (z, part, slots, y) or None (unsupported shape)"""
-    y = _dw3x3_fwd_raw(x, w_dw, b_dw, kpl)
+    y = _dw3x3_fwd_raw(x, w_dw, b_dw, kpl, in_scale, in_shift)
     if y is None:
         return None
     cout = w_pw.shape[0]
@@ -258,7 +260,7 @@ def _pointwise_wgrad_raw(y, dz, m):
     return dw
 
 
-def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None):
+def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None, in_aff=None):
     """gradients of z = pointwise(depthwise(x)) given dz: dx, dw_dw, db_dw, dw_pw.
     y: the depthwise output kept by the forward (streamed weight gradient); when None the
     memory-lean kernel recomputes it from x."""
@@ -296,14 +298,17 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None):
     if bnred is not None and need_dx:
         # x = relu(bn(z_prev)): let the depthwise backward also reduce the previous BatchNorm's backward sums
         gam, bet = bnred
+        isc, ish = in_aff if in_aff is not None else (None, None)
         rows = L.smaat_dw3x3_bwd_ws_rows(n, cin, h, w) - 1
         rpart = _new(x, 2, rows, cin)
-        rc = L.smaat_dw3x3_bwd_bnred(_ptr(x), x_bs, _ptr(dy), k * h * w, _ptr(w_dw), _ptr(dx), cin * h * w, _ptr(ws2),
-                                     _ptr(dw_dw), _ptr(db_dw), _ptr(gam), _ptr(bet), _ptr(rpart), n, cin, kpl, h, w, s)
+        rc = L.smaat_dw3x3_bwd_bnred(_ptr(x), x_bs, _ptr(isc), _ptr(ish), _ptr(dy), k * h * w, _ptr(w_dw), _ptr(dx),
+                                     cin * h * w, _ptr(ws2), _ptr(dw_dw), _ptr(db_dw), _ptr(gam), _ptr(bet),
+                                     _ptr(rpart), n, cin, kpl, h, w, s)
         if rc == 0:
             return dx, dw_dw, db_dw, dw_pw, (rpart, rows)
         if rc != -2:
             _lib.check(rc, "smaat_dw3x3_bwd_bnred")
+    assert in_aff is None, "input-affine depthwise backward needs the strip kernel (checked by _fuse_act_ok)"
     _lib.check(L.smaat_dw3x3_bwd(_ptr(x), x_bs, _ptr(dy), k * h * w, _ptr(w_dw), _ptr(dx), cin * h * w, _ptr(ws2),
                                  _ptr(dw_dw), _ptr(db_dw), n, cin, kpl, h, w, s), "smaat_dw3x3_bwd")
     if bnred is not None:
@@ -319,13 +324,17 @@ KEEP_DEPTHWISE_OUTPUT = True
 # --------------------------------------------------------------------------------------
 # DepthwiseSeparableConv (+ BatchNorm2d + ReLU)
 # --------------------------------------------------------------------------------------
-def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, momentum, eps, kpl, keep_y):
-    """DepthwiseSeparableConv -> BatchNorm2d -> ReLU.  Returns y, z, st, y_dw, use_batch_stats."""
+def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, momentum, eps, kpl, keep_y, in_aff=None,
+                  want_act=True):
+    """DepthwiseSeparableConv -> BatchNorm2d -> ReLU.  Returns y, z, st, y_dw, use_batch_stats.
+    in_aff = (scale, shift): x is a PRE-BatchNorm tensor and relu(x*scale + shift) is applied on load.
+    want_act=False: do not materialise y (the consumer applies this BatchNorm + ReLU on load)."""
     n, cin, h, w = x.shape
     cout = w_pw.shape[0]
     use_batch_stats = training or rm is None
     y_dw = None
-    rs = (_dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats)
+    isc, ish = in_aff if in_aff is not None else (None, None)
+    rs = (_dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish)
           if _split_fwd_ok(cin * kpl, cout) else None)
     if rs is not None and use_batch_stats:
         z, part, slots, y_dw = rs
@@ -335,7 +344,7 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
                               momentum if momentum is not None else 0.0, rm if training else None,
                               rv if training else None)
     elif use_batch_stats:
-        r = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, True, want_y=keep_y)
+        r = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, True, in_scale=isc, in_shift=ish, want_y=keep_y)
         z, part, slots = r[:3]
         y_dw = r[3] if keep_y else None
         st = _bn_finalize_raw(part, slots, cout, n * h * w, b_pw, gamma, beta, eps,
@@ -345,7 +354,7 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
         if rs is not None:
             z, y_dw = rs[0], (rs[3] if keep_y else None)
         else:
-            r = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, False, want_y=keep_y)
+            r = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, False, in_scale=isc, in_shift=ish, want_y=keep_y)
             z = r[0]
             y_dw = r[3] if keep_y else None
         invstd = torch.rsqrt(rv + eps)
@@ -353,16 +362,16 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
         b = beta if beta is not None else torch.zeros_like(rm)
         scale = g * invstd
         st = torch.stack([rm, invstd, scale, b - rm * scale]).contiguous()
-    y = _affine_act_raw(z, st[2], st[3], True)
+    y = _affine_act_raw(z, st[2], st[3], True) if want_act else None
     return y, z, st, y_dw, use_batch_stats
 
 
 def _half_backward(x, w_dw, b_dw, w_pw, gamma, z, st, y_dw, dy, kpl, train_stats, has_bias, need_dx, pre_part=None,
-                   bnred=None):
+                   bnred=None, in_aff=None):
     """-> (dx, dw_dw, db_dw, dw_pw, db_pw, dgamma, dbeta), red.  pre_part: this BatchNorm's backward sums
     (from the following block's depthwise backward); bnred=(gamma_prev, beta_prev): emit the previous one's."""
     dz, dgamma, dbeta = _bn_bwd_raw(dy, z, st, gamma, True, train_stats, pre_part=pre_part)
-    r = _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=y_dw, bnred=bnred)
+    r = _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=y_dw, bnred=bnred, in_aff=in_aff)
     dx, dw_dw, db_dw, dw_pw = r[:4]
     red = r[4] if bnred is not None else None
     if train_stats:
@@ -412,12 +421,18 @@ class _DoubleConvDS(torch.autograd.Function):
         _check(x, w_dw1, b_dw1, w_pw1, b_pw1, g1, be1, rm1, rv1, w_dw2, b_dw2, w_pw2, b_pw2, g2, be2, rm2, rv2)
         w_dw1, w_pw1, w_dw2, w_pw2 = (t.contiguous() for t in (w_dw1, w_pw1, w_dw2, w_pw2))
         keep_y = KEEP_DEPTHWISE_OUTPUT and any(ctx.needs_input_grad[:17])
+        # the activation y1 = relu(bn1(z1)) is never written when every consumer can apply it on load:
+        # the second half's forward (depthwise stage) and its depthwise backward (strip kernel: W % 4 == 0),
+        # and the weight gradient reads the kept depthwise output, not y1
+        n, _, h, w = x.shape
+        fuse = FUSE_FIRST_ACTIVATION and keep_y and (w % 4 == 0) and h >= 4 and g1 is not None
         y1, z1, st1, ydw1, ubs1 = _half_forward(x, w_dw1, b_dw1, w_pw1, b_pw1, g1, be1, rm1, rv1, tr1, mo1, eps1, kpl,
-                                                keep_y)
-        y2, z2, st2, ydw2, ubs2 = _half_forward(y1, w_dw2, b_dw2, w_pw2, b_pw2, g2, be2, rm2, rv2, tr2, mo2, eps2, kpl,
-                                                keep_y)
+                                                keep_y, want_act=not fuse)
+        y2, z2, st2, ydw2, ubs2 = _half_forward(z1 if fuse else y1, w_dw2, b_dw2, w_pw2, b_pw2, g2, be2, rm2, rv2, tr2,
+                                                mo2, eps2, kpl, keep_y, in_aff=(st1[2], st1[3]) if fuse else None)
         ctx.save_for_backward(x, w_dw1, b_dw1, w_pw1, g1, be1, z1, st1, ydw1, y1, w_dw2, b_dw2, w_pw2, g2, z2, st2,
                               ydw2)
+        ctx.fuse = fuse
         ctx.kpl = kpl
         ctx.train_stats = (ubs1, ubs2)
         ctx.has_bias = ((b_dw1 is not None, b_pw1 is not None), (b_dw2 is not None, b_pw2 is not None))
@@ -427,8 +442,9 @@ class _DoubleConvDS(torch.autograd.Function):
     def backward(ctx, dy2):
         (x, w_dw1, b_dw1, w_pw1, g1, be1, z1, st1, ydw1, y1, w_dw2, b_dw2, w_pw2, g2, z2, st2,
          ydw2) = ctx.saved_tensors
-        gr2, red = _half_backward(y1, w_dw2, b_dw2, w_pw2, g2, z2, st2, ydw2, dy2, ctx.kpl, ctx.train_stats[1],
-                                  ctx.has_bias[1], True, bnred=(g1, be1))
+        gr2, red = _half_backward(z1 if ctx.fuse else y1, w_dw2, b_dw2, w_pw2, g2, z2, st2, ydw2, dy2, ctx.kpl,
+                                  ctx.train_stats[1], ctx.has_bias[1], True, bnred=(g1, be1),
+                                  in_aff=(st1[2], st1[3]) if ctx.fuse else None)
         gr1, _ = _half_backward(x, w_dw1, b_dw1, w_pw1, g1, z1, st1, ydw1, gr2[0], ctx.kpl, ctx.train_stats[0],
                                 ctx.has_bias[0], ctx.needs_input_grad[0], pre_part=red)
         return gr1 + (None, None) + gr2[1:] + (None, None) + (None,) * 7

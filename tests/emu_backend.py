@@ -102,11 +102,14 @@ class EmuLib:
         assert not rem.any(), "three bf16 terms must represent an f32 exactly"
         return 0
 
-    def smaat_dw3x3_fwd(self, x, x_bs, w_dw, b_dw, y, y_bs, N, Cin, kpl, H, W, stream):
+    def smaat_dw3x3_fwd(self, x, x_bs, in_scale, in_shift, w_dw, b_dw, y, y_bs, N, Cin, kpl, H, W, stream):
         if W % 4:
             return -2
         P, K = H * W, Cin * kpl
         xv = np.array(planes(x, N, Cin, P, x_bs)).reshape(N, Cin, H, W)
+        if in_scale:
+            sc, sh = f32(in_scale, Cin), f32(in_shift, Cin)
+            xv = np.maximum(xv * sc[None, :, None, None] + sh[None, :, None, None], 0).astype(np.float32)
         yy = O.dw3x3_fwd(xv, f32(w_dw, K * 9).reshape(K, 1, 3, 3), f32(b_dw, K) if b_dw else None, kpl)
         planes(y, N, K, P, y_bs)[:] = yy.reshape(N, K, P)
         return 0
@@ -184,13 +187,19 @@ class EmuLib:
             f32(db_out, K)[:] = gb
         return 0
 
-    def smaat_dw3x3_bwd_bnred(self, x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, ws, dw_out, db_out, bn_gamma, bn_beta, rpart,
-                              N, Cin, kpl, H, W, stream):
+    def smaat_dw3x3_bwd_bnred(self, x, x_bs, in_scale, in_shift, dy, dy_bs, w_dw, dx, dx_bs, ws, dw_out, db_out,
+                              bn_gamma, bn_beta, rpart, N, Cin, kpl, H, W, stream):
         if W % 4 or H < 4:
             return -2
-        self.smaat_dw3x3_bwd(x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, ws, dw_out, db_out, N, Cin, kpl, H, W, stream)
         P = H * W
-        xv = np.array(planes(x, N, Cin, P, x_bs)).astype(np.float64)
+        xin = np.array(planes(x, N, Cin, P, x_bs))
+        if in_scale:  # x holds z of the previous half: recompute the activation
+            sc, sh = f32(in_scale, Cin), f32(in_shift, Cin)
+            xin = np.maximum(xin * sc[None, :, None] + sh[None, :, None], 0).astype(np.float32)
+        xin = np.ascontiguousarray(xin)
+        self.smaat_dw3x3_bwd(xin.ctypes.data, Cin * P, dy, dy_bs, w_dw, dx, dx_bs, ws, dw_out, db_out, N, Cin, kpl, H, W,
+                             stream)
+        xv = xin.astype(np.float64)
         g = np.array(planes(dx, N, Cin, P, dx_bs)).astype(np.float64) * (xv > 0)
         gam = f32(bn_gamma, Cin).astype(np.float64) if bn_gamma else np.ones(Cin)
         bet = f32(bn_beta, Cin).astype(np.float64) if bn_beta else np.zeros(Cin)

@@ -213,14 +213,16 @@ def test_pointwise_fwd_split(shape):
     both(case_pw_split, *shape, with_part=True)
 
 
-def case_dw_fwd(L, dev, N, Cin, kpl, H, W, bias=True, pad_c=0):
+def case_dw_fwd(L, dev, N, Cin, kpl, H, W, bias=True, pad_c=0, aff=False):
     K = Cin * kpl
     xfull = T(rnd(1, N, Cin + pad_c, H, W), dev)
     x = xfull[:, pad_c:]
     w_dw, b_dw = T(rnd(2, K, 9, scale=0.3), dev), T(rnd(3, K, scale=0.3), dev)
     y = torch.full((N, K, H, W), float("nan"), device=dev)
-    rc = L.smaat_dw3x3_fwd(x.data_ptr(), (Cin + pad_c) * H * W, P(w_dw), P(b_dw) if bias else None, P(y), K * H * W, N,
-                           Cin, kpl, H, W, stream(dev))
+    sc = T(np.random.default_rng(6).uniform(0.5, 1.5, Cin).astype(np.float32), dev) if aff else None
+    sh = T(rnd(7, Cin, scale=0.3), dev) if aff else None
+    rc = L.smaat_dw3x3_fwd(x.data_ptr(), (Cin + pad_c) * H * W, P(sc), P(sh), P(w_dw), P(b_dw) if bias else None, P(y),
+                           K * H * W, N, Cin, kpl, H, W, stream(dev))
     assert rc == 0
     return dict(y=y)
 
@@ -232,11 +234,15 @@ def case_dw_fwd(L, dev, N, Cin, kpl, H, W, bias=True, pad_c=0):
 def test_dw3x3_fwd(shape):
     both(case_dw_fwd, *shape)
     both(case_dw_fwd, *shape, bias=False, pad_c=4)
+    both(case_dw_fwd, *shape, aff=True)
 
 
-def case_dw_bwd_bnred(L, dev, N, Cin, kpl, H, W):
+def case_dw_bwd_bnred(L, dev, N, Cin, kpl, H, W, aff=False):
     K = Cin * kpl
-    x = T(np.maximum(rnd(1, N, Cin, H, W) + 0.3, 0), dev)   # a post-ReLU activation
+    # a post-ReLU activation, or (aff) the pre-BatchNorm tensor whose activation is recomputed on load
+    x = T(rnd(1, N, Cin, H, W) if aff else np.maximum(rnd(1, N, Cin, H, W) + 0.3, 0), dev)
+    sc = T(np.random.default_rng(8).uniform(0.5, 1.5, Cin).astype(np.float32), dev) if aff else None
+    sh = T(rnd(9, Cin, scale=0.3), dev) if aff else None
     dy = T(rnd(2, N, K, H, W), dev)
     w_dw = T(rnd(3, K, 9, scale=0.3), dev)
     gam = T(np.random.default_rng(4).uniform(0.5, 1.5, Cin).astype(np.float32), dev)
@@ -246,8 +252,8 @@ def case_dw_bwd_bnred(L, dev, N, Cin, kpl, H, W):
     ws = torch.empty((rows, K, 10), device=dev)
     rpart = torch.full((2, rows - 1, Cin), float("nan"), device=dev)
     dw, db = torch.full((K, 9), float("nan"), device=dev), torch.full((K,), float("nan"), device=dev)
-    rc = L.smaat_dw3x3_bwd_bnred(P(x), Cin * H * W, P(dy), K * H * W, P(w_dw), P(dx), Cin * H * W, P(ws), P(dw), P(db),
-                                 P(gam), P(bet), P(rpart), N, Cin, kpl, H, W, stream(dev))
+    rc = L.smaat_dw3x3_bwd_bnred(P(x), Cin * H * W, P(sc), P(sh), P(dy), K * H * W, P(w_dw), P(dx), Cin * H * W, P(ws),
+                                 P(dw), P(db), P(gam), P(bet), P(rpart), N, Cin, kpl, H, W, stream(dev))
     assert rc == 0
     return dict(dw=dw, db=db, dx=dx, r1=rpart[0].double().sum(0), r2=rpart[1].double().sum(0))
 
@@ -256,6 +262,7 @@ def case_dw_bwd_bnred(L, dev, N, Cin, kpl, H, W):
                                    (2, 3, 2, 288, 288), (1, 4, 2, 100, 100), (1, 3, 4, 8, 12), (1, 5, 2, 10, 12)])
 def test_dw3x3_bwd_bnred(shape):
     both(case_dw_bwd_bnred, *shape, tol=2e-5)
+    both(case_dw_bwd_bnred, *shape, aff=True, tol=2e-5)
 
 
 # ----------------------------------------------------------------------------------------
