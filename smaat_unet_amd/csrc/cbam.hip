@@ -350,6 +350,126 @@ __global__ __launch_bounds__(256) void k_cbam_bwd_main(const float* __restrict__
         dspart[((long)blockIdx.x * N + n) * C + c] = red[c] + red[C + c] + red[2 * C + c] + red[3 * C + c];
 }
 
+// ---------------------------------------------------------------------------------
+// float4 forms of the three pixel-major CBAM passes (P % 4 == 0, 16-byte aligned planes): ONE wave per
+// workgroup covers the same 256 pixels as a 256-thread block of the scalar kernels (same partial-result
+// slots), each lane owns 4 consecutive pixels: 16-byte loads/stores and one wave reduction per channel
+// instead of four.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_cbam_sppool_v4(const float* __restrict__ x, long x_bs,
+                                                       const float* __restrict__ s, int C, int P,
+                                                       float* __restrict__ maps) {
+    const int n = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x * 4;
+    if (p >= P) return;
+    const float* xp = x + (long)n * x_bs + p;
+    const float* sp = s + (long)n * C;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f), m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) {
+        const float4 v = *(const float4*)(xp + (long)c * P);
+        const float sv = sp[c];
+        const float a = v.x * sv, b = v.y * sv, cc = v.z * sv, d = v.w * sv;
+        sum.x += a; sum.y += b; sum.z += cc; sum.w += d;
+        m.x = fmaxf(m.x, a); m.y = fmaxf(m.y, b); m.z = fmaxf(m.z, cc); m.w = fmaxf(m.w, d);
+    }
+    const float ic = (float)C;
+    *(float4*)(maps + ((long)n * 2 + 0) * P + p) = make_float4(sum.x / ic, sum.y / ic, sum.z / ic, sum.w / ic);
+    *(float4*)(maps + ((long)n * 2 + 1) * P + p) = m;
+}
+
+__global__ __launch_bounds__(64) void k_cbam_bwd_gate_v4(const float* __restrict__ dout, long dout_bs,
+                                                         const float* __restrict__ x, long x_bs,
+                                                         const float* __restrict__ s, const float* __restrict__ gate,
+                                                         const float* __restrict__ conv,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, int C, int P,
+                                                         float* __restrict__ dbn, float* __restrict__ part,
+                                                         int nblocks) {
+    const int n = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x * 4;
+    float t1 = 0.f, t2 = 0.f;
+    if (p < P) {
+        const float* xp = x + (long)n * x_bs + p;
+        const float* gp = dout + (long)n * dout_bs + p;
+        const float* sp = s + (long)n * C;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int c = 0; c < C; ++c) {
+            const float4 g = *(const float4*)(gp + (long)c * P);
+            const float4 v = *(const float4*)(xp + (long)c * P);
+            const float sv = sp[c];
+            acc.x = fmaf(g.x * v.x, sv, acc.x);
+            acc.y = fmaf(g.y * v.y, sv, acc.y);
+            acc.z = fmaf(g.z * v.z, sv, acc.z);
+            acc.w = fmaf(g.w * v.w, sv, acc.w);
+        }
+        const float4 m = *(const float4*)(gate + (long)n * P + p);
+        const float4 cv = *(const float4*)(conv + (long)n * P + p);
+        const float mu = mean[0], is = invstd[0];
+        float4 d;
+        d.x = acc.x * m.x * (1.f - m.x);
+        d.y = acc.y * m.y * (1.f - m.y);
+        d.z = acc.z * m.z * (1.f - m.z);
+        d.w = acc.w * m.w * (1.f - m.w);
+        *(float4*)(dbn + (long)n * P + p) = d;
+        t1 = (d.x + d.y) + (d.z + d.w);
+        t2 = (d.x * (cv.x - mu) + d.y * (cv.y - mu) + d.z * (cv.z - mu) + d.w * (cv.w - mu)) * is;
+    }
+    t1 = wave_sum_l63(t1);
+    t2 = wave_sum_l63(t2);
+    if (threadIdx.x == 63) {
+        const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+        part[blk] = t1;
+        part[nblocks + blk] = t2;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_cbam_bwd_main_v4(const float* __restrict__ dout, long dout_bs,
+                                                         const float* __restrict__ x, long x_bs,
+                                                         const float* __restrict__ s, const float* __restrict__ gate,
+                                                         const float* __restrict__ maps,
+                                                         const float* __restrict__ dmaps, int C, int P,
+                                                         float* __restrict__ dx, long dx_bs,
+                                                         float* __restrict__ dspart) {
+    const int n = blockIdx.y, N = gridDim.y;
+    const int p = blockIdx.x * 256 + threadIdx.x * 4;
+    const bool valid = p < P;
+    const int pp = valid ? p : 0;
+    const float* xp = x + (long)n * x_bs + pp;
+    const float* gp = dout + (long)n * dout_bs + pp;
+    float* dp = dx + (long)n * dx_bs + pp;
+    const float* sp = s + (long)n * C;
+    const float4 g = *(const float4*)(gate + (long)n * P + pp);
+    const float4 mxv = *(const float4*)(maps + ((long)n * 2 + 1) * P + pp);
+    float4 da = *(const float4*)(dmaps + ((long)n * 2 + 0) * P + pp);
+    const float4 dm = *(const float4*)(dmaps + ((long)n * 2 + 1) * P + pp);
+    const float ic = 1.f / (float)C;
+    da.x /= (float)C; da.y /= (float)C; da.z /= (float)C; da.w /= (float)C;
+    (void)ic;
+    bool f0 = false, f1 = false, f2 = false, f3 = false;
+    float* dsrow = dspart + ((long)blockIdx.x * N + n) * C;
+#pragma unroll 2
+    for (int c = 0; c < C; ++c) {
+        const float4 xv = *(const float4*)(xp + (long)c * P);
+        const float4 gv = *(const float4*)(gp + (long)c * P);
+        const float sv = sp[c];
+        float4 dxs;
+        dxs.x = fmaf(gv.x, g.x, da.x);
+        dxs.y = fmaf(gv.y, g.y, da.y);
+        dxs.z = fmaf(gv.z, g.z, da.z);
+        dxs.w = fmaf(gv.w, g.w, da.w);
+        if (!f0 && xv.x * sv == mxv.x) { dxs.x += dm.x; f0 = true; }
+        if (!f1 && xv.y * sv == mxv.y) { dxs.y += dm.y; f1 = true; }
+        if (!f2 && xv.z * sv == mxv.z) { dxs.z += dm.z; f2 = true; }
+        if (!f3 && xv.w * sv == mxv.w) { dxs.w += dm.w; f3 = true; }
+        if (valid) *(float4*)(dp + (long)c * P) = make_float4(dxs.x * sv, dxs.y * sv, dxs.z * sv, dxs.w * sv);
+        float r = valid ? (dxs.x * xv.x + dxs.y * xv.y) + (dxs.z * xv.z + dxs.w * xv.w) : 0.f;
+        r = wave_sum_l63(r);
+        if (threadIdx.x == 63) dsrow[c] = r;
+    }
+}
+
 // B4: MLP backward, one block per sample.  Per-sample parameter-gradient partials:
 //   pg[n][ C*Cr (dW2) | C (db2) | Cr*C (dW1) | Cr (db1) ]  -> reduced over n by k_reduce_rows
 //   davg[n][c], dmx[n][c]
@@ -444,7 +564,10 @@ int launch_cbam_mlp(const float* avg, const float* mx, const float* w1, const fl
     return (int)hipGetLastError();
 }
 int launch_cbam_sppool(const float* x, long x_bs, const float* s, int N, int C, int P, float* maps, hipStream_t st) {
-    hipLaunchKernelGGL(k_cbam_sppool, dim3(cdivc(P, 256), N), dim3(256), 0, st, x, x_bs, s, C, P, maps);
+    if (((P & 3) == 0) && ((x_bs & 3) == 0) && ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)maps) & 15) == 0))
+        hipLaunchKernelGGL(k_cbam_sppool_v4, dim3(cdivc(P, 256), N), dim3(64), 0, st, x, x_bs, s, C, P, maps);
+    else
+        hipLaunchKernelGGL(k_cbam_sppool, dim3(cdivc(P, 256), N), dim3(256), 0, st, x, x_bs, s, C, P, maps);
     return (int)hipGetLastError();
 }
 int launch_cbam_spconv(const float* maps, const float* wc, int ks, int N, int H, int W, float* conv, float* part,
@@ -471,8 +594,15 @@ int launch_cbam_bwd_gate(const float* dout, long dout_bs, const float* x, long x
                          const float* gate, const float* conv, const float* mean, const float* invstd, int N, int C,
                          int P, float* dbn, float* part, hipStream_t st) {
     dim3 grid(cdivc(P, 256), N);
-    hipLaunchKernelGGL(k_cbam_bwd_gate, grid, dim3(256), 0, st, dout, dout_bs, x, x_bs, s, gate, conv, mean, invstd,
-                       C, P, dbn, part, (int)(grid.x * grid.y));
+    const bool v4 = ((P & 3) == 0) && ((x_bs & 3) == 0) && ((dout_bs & 3) == 0) && ((((uintptr_t)x) & 15) == 0) &&
+                    ((((uintptr_t)dout) & 15) == 0) && ((((uintptr_t)gate) & 15) == 0) &&
+                    ((((uintptr_t)conv) & 15) == 0) && ((((uintptr_t)dbn) & 15) == 0);
+    if (v4)
+        hipLaunchKernelGGL(k_cbam_bwd_gate_v4, grid, dim3(64), 0, st, dout, dout_bs, x, x_bs, s, gate, conv, mean,
+                           invstd, C, P, dbn, part, (int)(grid.x * grid.y));
+    else
+        hipLaunchKernelGGL(k_cbam_bwd_gate, grid, dim3(256), 0, st, dout, dout_bs, x, x_bs, s, gate, conv, mean,
+                           invstd, C, P, dbn, part, (int)(grid.x * grid.y));
     return (int)hipGetLastError();
 }
 int launch_cbam_bwd_spconv(const float* dbn, const float* conv, const float* mean, const float* invstd,
@@ -487,6 +617,15 @@ int launch_cbam_bwd_spconv(const float* dbn, const float* conv, const float* mea
 int launch_cbam_bwd_main(const float* dout, long dout_bs, const float* x, long x_bs, const float* s,
                          const float* gate, const float* maps, const float* dmaps, int N, int C, int P, float* dx,
                          long dx_bs, float* dspart, hipStream_t st) {
+    const bool v4 = ((P & 3) == 0) && ((x_bs & 3) == 0) && ((dout_bs & 3) == 0) && ((dx_bs & 3) == 0) &&
+                    ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)dout) & 15) == 0) &&
+                    ((((uintptr_t)dx) & 15) == 0) && ((((uintptr_t)gate) & 15) == 0) &&
+                    ((((uintptr_t)maps) & 15) == 0) && ((((uintptr_t)dmaps) & 15) == 0);
+    if (v4) {
+        hipLaunchKernelGGL(k_cbam_bwd_main_v4, dim3(cdivc(P, 256), N), dim3(64), 0, st, dout, dout_bs, x, x_bs, s, gate,
+                           maps, dmaps, C, P, dx, dx_bs, dspart);
+        return (int)hipGetLastError();
+    }
     const size_t lds = sizeof(float) * (size_t)(4 * C);
     hipLaunchKernelGGL(k_cbam_bwd_main, dim3(cdivc(P, 256), N), dim3(256), lds, st, dout, dout_bs, x, x_bs, s, gate,
                        maps, dmaps, C, P, dx, dx_bs, dspart);
