@@ -95,6 +95,9 @@ int smaat_dw3x3_bwd_bnred(const float* x, long x_bs, const float* in_scale, cons
 int smaat_bn_finalize(const float* part, int T, int C, double count, const float* bias_shift, const float* gamma,
                       const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                       float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* eval mode: st[4][C] = running_mean, 1/sqrt(running_var+eps), gamma*invstd, beta - mean*gamma*invstd */
+int smaat_bn_eval_coefs(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
+                        float eps, int C, float* st, void* stream);
 int smaat_affine_act(const float* z, long z_bs, const float* scale, const float* shift, float* y, long y_bs, int N,
                      int C, int P, int relu, void* stream);
 int smaat_plane_num_slots(int N, int P);

@@ -8,7 +8,7 @@ OUT=gpurun_out/${1:-r1}
 mkdir -p "$OUT"
 rocminfo 2>/dev/null | grep -E "Marketing Name|gfx" | head -4 > "$OUT/device.txt"
 nproc >> "$OUT/device.txt"
-for grp in dsconv_fwd "pointwise_fwd and not split" pointwise_fwd_split dw3x3_fwd dsconv_wgrad pointwise_wgrad "dw3x3_bwd and not bnred" dw3x3_bwd_bnred bn_chain misc pool_upsample cbam; do
+for grp in dsconv_fwd "pointwise_fwd and not split" pointwise_fwd_split dw3x3_fwd dsconv_wgrad pointwise_wgrad "dw3x3_bwd and not bnred" dw3x3_bwd_bnred "bn_chain or bn_eval" misc pool_upsample cbam; do
   timeout 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "$grp" --tb=short -p no:cacheprovider \
       > "$OUT/k_${grp// /_}.log" 2>&1
   echo "$grp exit=$? $(tail -1 "$OUT/k_${grp// /_}.log")"

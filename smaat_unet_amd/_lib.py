@@ -33,6 +33,7 @@ SIGNATURES = {
     "smaat_dw3x3_bwd": [_P, _L, _P, _L, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "smaat_dw3x3_bwd_bnred": [_P, _L, _P, _P, _P, _L, _P, _P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "smaat_bn_finalize": [_P, _I, _I, _D, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P],
+    "smaat_bn_eval_coefs": [_P, _P, _P, _P, _F, _I, _P, _P],
     "smaat_affine_act": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "smaat_plane_num_slots": [_I, _I],
     "smaat_bn_bwd_reduce": [_P, _L, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -406,3 +406,26 @@ int launch_copy_planes(const float* src, long s_bs, float* dst, long d_bs, int N
     hipLaunchKernelGGL(k_copy_planes, dim3(gx, N), dim3(256), 0, st, src, s_bs, dst, d_bs, plane_len, accum);
     return (int)hipGetLastError();
 }
+
+// eval-mode BatchNorm coefficients from the running statistics (one launch instead of a chain of
+// element-wise torch kernels: the batch-1 inference path is launch bound)
+__global__ __launch_bounds__(256) void k_bn_eval_coefs(const float* __restrict__ rm, const float* __restrict__ rv,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, int C,
+                                                       float* __restrict__ st) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float m = rm[c];
+    const float is = 1.f / sqrtf(rv[c] + eps);
+    const float sc = (gamma ? gamma[c] : 1.f) * is;
+    st[c] = m;
+    st[C + c] = is;
+    st[2 * C + c] = sc;
+    st[3 * C + c] = (beta ? beta[c] : 0.f) - m * sc;
+}
+
+int launch_bn_eval_coefs(const float* rm, const float* rv, const float* gamma, const float* beta, float eps, int C,
+                         float* st, hipStream_t stream) {
+    hipLaunchKernelGGL(k_bn_eval_coefs, dim3((C + 255) / 256), dim3(256), 0, stream, rm, rv, gamma, beta, eps, C, st);
+    return (int)hipGetLastError();
+}

@@ -15,6 +15,7 @@ int smaat_wgrad_num_splits_impl(int N, int P, int M, int K);
 
 int launch_bn_finalize(const float*, int, int, double, const float*, const float*, const float*, float, float, float*,
                        float*, float*, float*, float*, float*, hipStream_t);
+int launch_bn_eval_coefs(const float*, const float*, const float*, const float*, float, int, float*, hipStream_t);
 int launch_affine_act(const float*, long, const float*, const float*, float*, long, int, int, int, int, hipStream_t);
 int smaat_bn_bwd_num_slots_impl(int N, int P);
 int launch_bn_bwd_reduce(const float*, long, const float*, long, const float*, const float*, const float*, const float*,
@@ -157,6 +158,11 @@ int smaat_bn_finalize(const float* part, int T, int C, double count, const float
                       float* mean, float* invstd, float* scale, float* shift, void* stream) {
     return launch_bn_finalize(part, T, C, count, bias_shift, gamma, beta, eps, momentum, running_mean, running_var,
                               mean, invstd, scale, shift, ST);
+}
+int smaat_bn_eval_coefs(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
+                        float eps, int C, float* st, void* stream) {
+    if (C < 1 || !running_mean || !running_var) return -1;
+    return launch_bn_eval_coefs(running_mean, running_var, gamma, beta, eps, C, st, ST);
 }
 int smaat_affine_act(const float* z, long z_bs, const float* scale, const float* shift, float* y, long y_bs, int N,
                      int C, int P, int relu, void* stream) {

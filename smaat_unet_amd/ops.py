@@ -192,6 +192,16 @@ def _bn_finalize_raw(part, slots, c, count, bias_shift, gamma, beta, eps, moment
     return st  # rows: mean, invstd, scale, shift
 
 
+def _bn_eval_coefs_raw(rm, rv, gamma, beta, eps):
+    """st rows (mean, invstd, scale, shift) from the running statistics: one launch"""
+    L = _lib.get()
+    c = rm.numel()
+    st = _new(rm, 4, c)
+    _lib.check(L.smaat_bn_eval_coefs(_ptr(rm), _ptr(rv), _ptr(gamma), _ptr(beta), float(eps), c, _ptr(st), _stream(rm)),
+               "smaat_bn_eval_coefs")
+    return st
+
+
 def _affine_act_raw(z, scale, shift, relu, out=None):
     L = _lib.get()
     z, z_bs = _planes(z)
@@ -357,11 +367,7 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
             r = _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, False, in_scale=isc, in_shift=ish, want_y=keep_y)
             z = r[0]
             y_dw = r[3] if keep_y else None
-        invstd = torch.rsqrt(rv + eps)
-        g = gamma if gamma is not None else torch.ones_like(rm)
-        b = beta if beta is not None else torch.zeros_like(rm)
-        scale = g * invstd
-        st = torch.stack([rm, invstd, scale, b - rm * scale]).contiguous()
+        st = _bn_eval_coefs_raw(rm, rv, gamma, beta, eps)
     y = _affine_act_raw(z, st[2], st[3], True) if want_act else None
     return y, z, st, y_dw, use_batch_stats
 
@@ -656,11 +662,7 @@ def _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, 
                                   momentum if momentum is not None else 0.0, rm if training else None,
                                   rv if training else None)
         else:
-            invstd = torch.rsqrt(rv + eps)
-            g = gamma if gamma is not None else torch.ones_like(rm)
-            b = beta if beta is not None else torch.zeros_like(rm)
-            scale = g * invstd
-            st = torch.stack([rm, invstd, scale, b - rm * scale]).contiguous()
+            st = _bn_eval_coefs_raw(rm, rv, gamma, beta, eps)
         gate = _new(dev, n, 1, h, w)
         _lib.check(L.smaat_cbam_gate(_ptr(conv), _ptr(st[2]), _ptr(st[3]), n * p, _ptr(gate), s_),
                    "smaat_cbam_gate")

@@ -234,6 +234,16 @@ class EmuLib:
             r2[:] = ((1 - momentum) * r2.astype(np.float64) + momentum * unb).astype(np.float32)
         return 0
 
+    def smaat_bn_eval_coefs(self, rm, rv, gamma, beta, eps, C, st, stream):
+        m, v = f32(rm, C).astype(np.float32), f32(rv, C).astype(np.float32)
+        g = f32(gamma, C) if gamma else np.ones(C, np.float32)
+        b = f32(beta, C) if beta else np.zeros(C, np.float32)
+        o = f32(st, 4 * C).reshape(4, C)
+        inv = (1.0 / np.sqrt(v + np.float32(eps))).astype(np.float32)
+        o[0], o[1], o[2] = m, inv, g * inv
+        o[3] = b - m * o[2]
+        return 0
+
     def smaat_affine_act(self, z, z_bs, scale, shift, y, y_bs, N, C, P, relu, stream):
         v = planes(z, N, C, P, z_bs) * f32(scale, C)[None, :, None] + f32(shift, C)[None, :, None]
         planes(y, N, C, P, y_bs)[:] = np.maximum(v, 0) if relu else v

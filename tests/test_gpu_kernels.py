@@ -265,6 +265,21 @@ def test_dw3x3_bwd_bnred(shape):
     both(case_dw_bwd_bnred, *shape, aff=True, tol=2e-5)
 
 
+def case_bn_eval(L, dev, C):
+    rm, rv = T(rnd(1, C, scale=0.3), dev), T(np.random.default_rng(2).uniform(0.2, 2, C).astype(np.float32), dev)
+    g, b = T(np.random.default_rng(3).uniform(0.5, 1.5, C).astype(np.float32), dev), T(rnd(4, C, scale=0.2), dev)
+    st = torch.full((4, C), float("nan"), device=dev)
+    assert L.smaat_bn_eval_coefs(P(rm), P(rv), P(g), P(b), 1e-5, C, P(st), stream(dev)) == 0
+    st2 = torch.full((4, C), float("nan"), device=dev)
+    assert L.smaat_bn_eval_coefs(P(rm), P(rv), None, None, 1e-5, C, P(st2), stream(dev)) == 0
+    return dict(st=st, st_noaffine=st2)
+
+
+@pytest.mark.parametrize("C", [1, 64, 300])
+def test_bn_eval_coefs(C):
+    both(case_bn_eval, C, tol=1e-6)
+
+
 # ----------------------------------------------------------------------------------------
 def case_bn(L, dev, N, C, H, W, relu=1, slice_pad=0):
     Pn = H * W
