@@ -168,7 +168,7 @@ int smaat_cbam_bwd_final(float* dx, long dx_bs, const float* davg, const float* 
  *        1 = operands rounded to bf16, ONE MFMA per product = the bf16 mixed-precision mode of BASELINE
  *        configs[3] (f32 storage, f32 accumulation, ~1e-2 class).  set returns the previous mode, -1 on a bad argument.
  *   smaat_split_enabled: 1 when mode != 0
- *   smaat_split_planes:  w [R][C] f32 -> planes u16 [3][R][Cp], Cp = C rounded up to 16 (zero padded);
+ *   smaat_split_planes:  w [R][C] f32 -> planes u16, chunk-major [Cp/16][3][R][16], Cp = C rounded up to 16 (zero padded);
  *                        R x C = Cout x K for the forward, K x Cout (the transposed weight) for dX
  *   smaat_dw3x3_fwd:     depthwise 3x3, pad 1 (models/layers.py:38-44,48): x [N][Cin][H][W] -> y [N][Cin*kpl][H][W];
  *                        optional in_scale/in_shift[Cin]: x := relu(x*sc+sh) on load (as smaat_dsconv_fwd);

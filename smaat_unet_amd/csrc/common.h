@@ -160,7 +160,7 @@ struct WgArgs {
 struct PwSplitArgs {
     const float* x;
     long x_bs;
-    const unsigned short* planes;  // [3][M][Cp]
+    const unsigned short* planes;  // [Cp/16][3][M][16]
     const float* bias;             // [M] or null
     float* out;
     long out_bs;

@@ -37,7 +37,11 @@ typedef const float __attribute__((address_space(4))) cfloat;
 // Software pipeline per 16-row chunk (T14 "issue early / write late"): the global loads of
 // chunk c+1 (input halo tile or B rows, and the weight slab) are issued into registers
 // right before the MFMA block of chunk c and written to LDS after it.
-template <int WCO, int CT, int WPX, int PXT, int MODE>
+// TR (plain pointwise, flattened pixel tiles, P % 4 == 0, no partial statistics): the MFMA operands are
+// swapped (A = pixels, B = output channels), so that a lane's accumulator registers hold 4 CONSECUTIVE
+// pixels of one channel and the epilogue is 16-byte stores (4x fewer store instructions: the short-
+// contraction data-gradient GEMMs of the plane-dominated layers are epilogue/store-issue bound).
+template <int WCO, int CT, int WPX, int PXT, int MODE, bool TR = false>
 __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
     constexpr bool DW = MODE > 0;
     constexpr int KPL = DW ? MODE : 1;
@@ -260,8 +264,34 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int pt = 0; pt < PXT; ++pt)
-                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ct], bv[pt], acc[ct][pt], 0, 0, 0);
+                    acc[ct][pt] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(bv[pt], av[ct], acc[ct][pt], 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_32x32x2f32(av[ct], bv[pt], acc[ct][pt], 0, 0, 0);
         }
+    }
+
+    if (TR) {
+        // lane -> channel (wco*CT+ct)*32 + l31; register r -> pixel (r&3) + 8*(r>>2) + 4*half of the 32-pixel tile
+        float* obase = a.out + (long)n * a.out_bs;
+        const int p0 = tl * PT;  // flattened tiles: tile pixel i is plane pixel p0 + i
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int col = (wco * CT + ct) * 32 + l31;
+            const int m = co0 + col;
+            if (m < a.M) {
+                const float bvv = biasl[col];
+                float* rowp = obase + (long)m * g.P + p0;
+#pragma unroll
+                for (int pt = 0; pt < PXT; ++pt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int i0 = (wpx * PXT + pt) * 32 + 8 * q + 4 * half;
+                        if (p0 + i0 < g.P)  // P % 4 == 0: a group of 4 is entirely inside or outside
+                            *(float4*)(rowp + i0) = make_float4(acc[ct][pt][4 * q] + bvv, acc[ct][pt][4 * q + 1] + bvv,
+                                                                acc[ct][pt][4 * q + 2] + bvv, acc[ct][pt][4 * q + 3] + bvv);
+                    }
+            }
+        }
+        return;
     }
 
     // ---- epilogue: bias + coalesced row stores --------------------------------------
@@ -1377,6 +1407,25 @@ template <int WCO, int CT, int WPX, int PXT, int MODE>
 static int launch_pwgemm_mode(PwArgs& a, hipStream_t st) {
     constexpr int COT = WCO * CT * 32, PT = WPX * PXT * 32;
     constexpr bool DW = MODE > 0;
+    if (MODE == 0 && a.part == nullptr && (a.g.H * a.g.W) % 4 == 0 && (a.out_bs & 3) == 0 &&
+        ((((uintptr_t)a.out) & 15) == 0) && !(a.dbg & 32)) {
+        // transposed-accumulator form on flattened tiles
+        a.g.P = a.g.H * a.g.W;
+        a.g.PT = PT;
+        a.g.mode = 0;
+        a.g.TH = a.g.TW = a.g.tiles_x = 0;
+        a.g.tiles_per_img = ceil_div(a.g.P, PT);
+        a.g.T = a.N * a.g.tiles_per_img;
+        a.nco = ceil_div(a.M, COT);
+        a.sstride = 0;
+        const size_t lds = sizeof(float) * (size_t)(KC * PT + KC * COT + WPX * 2 * COT + 2 * PT + COT);
+        const int grid = ceil_div(a.g.T, 8) * 8 * a.nco;
+        constexpr auto kern = k_pwgemm<WCO, CT, WPX, PXT, 0, true>;
+        int rc = ensure_lds<kern>(lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(SMAAT_THREADS), lds, st, a);
+        return (int)hipGetLastError();
+    }
     if (DW && pw_impl() >= 1)
         choose_geom_ws(a.N, a.g.H, a.g.W, PT, &a.g);  // same tiles (= partial-statistics slots) as the ws family
     else

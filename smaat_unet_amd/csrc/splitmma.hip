@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 static int pws_cfg();
 int split_mode();
 
@@ -273,9 +274,13 @@ int launch_wgrad_split(Wg2Args& a, int nt, hipStream_t st) {
 }
 
 // =====================================================================================
-// k_split_planes: f32 matrix [R][C] (row stride ld) -> three bf16 planes [3][R][Cp], Cp = C rounded up
-// to 16 (zero padded), so that an MFMA A fragment (8 consecutive contraction indices of one row) is
-// one aligned 16-byte load.  Run once per weight tensor per step.
+// k_split_planes: f32 matrix [R][C] -> three bf16 planes in CHUNK-MAJOR order [Cp/16][3][R][16], Cp = C
+// rounded up to 16 (zero padded): the A operand of one 16-deep contraction chunk for a block of rows is
+// one contiguous run per plane (rows x 32 B), so the producer waves fetch it with fully coalesced
+// 16-byte loads.  (Row-major planes [3][R][Cp] made every chunk load touch one 32-byte piece of `rows`
+// different cache lines, and the next chunks re-touch those lines while they are still pending: the
+// vector L1 spent ~70% of the short-contraction GEMMs stalled on pending lines.)  Run once per weight
+// tensor per step.
 // =====================================================================================
 __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ w, int R, int C, int Cp,
                                                       unsigned short* __restrict__ out, int bf16_only) {
@@ -287,10 +292,12 @@ __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ 
     const float r1 = bf16_only ? 0.f : x - p1;
     const float p2 = bitsf(fbits(r1) & 0xFFFF0000u);
     const float p3 = r1 - p2;
-    const long plane = (long)R * Cp;
-    out[i] = (unsigned short)(fbits(p1) >> 16);
-    out[plane + i] = (unsigned short)(fbits(p2) >> 16);
-    out[2 * plane + i] = (unsigned short)(fbits(p3) >> 16);
+    // chunk-major image: element (chunk c / 16, plane t, row r, c % 16)
+    const long o = ((long)(c >> 4) * 3 * R + r) * 16 + (c & 15);
+    const long plane = (long)R * 16;
+    out[o] = (unsigned short)(fbits(p1) >> 16);
+    out[o + plane] = (unsigned short)(fbits(p2) >> 16);
+    out[o + 2 * plane] = (unsigned short)(fbits(p3) >> 16);
 }
 
 int launch_split_planes(const float* w, int R, int C, unsigned short* out, hipStream_t st) {
@@ -303,12 +310,15 @@ int launch_split_planes(const float* w, int R, int C, unsigned short* out, hipSt
 
 // =====================================================================================
 // k_pw_split:  out[n][m][p] = sum_c A[m][c] * x[n][c][p] + bias[m]   (+ BatchNorm partials)
-//   A = pre-split planes [3][M][Cp] (k_split_planes); x split on the fly by the producer waves.
+//   A = pre-split planes, chunk-major [Cp/16][3][M][16] (k_split_planes); x split on the fly by the producer waves.
 //   Used for the pointwise conv of the forward pass (x = depthwise output) and for its data gradient
 //   (x = dZ, A = transposed weight).  Pixel tiles are PT consecutive pixels of the flattened plane.
 // =====================================================================================
 
 
+#ifndef PWSP_ABL
+#define PWSP_ABL 0  // timing ablations of k_pw_split_p (compile time): 1 no stores, 2 no MFMAs, 4 no global B loads
+#endif
 #define BROW 48   // bytes per LDS row of a [row][16 bf16] image (32 + 16 pad: conflict-free b128)
 
 template <int WCO, int CT, int WPX, int PXT, int NPT, int NBUF, int NT>
@@ -326,6 +336,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
     static_assert((PT * 2) % NPT == 0, "producer mapping");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     float* stat = (float*)(lds + NBUF * BUFSZ);  // [WPX][2][COT]
+    float* biasl = stat + WPX * 2 * COT;         // [COT]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -342,8 +353,13 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
     const int n = ptg / a.tiles_per_img, tl = ptg - n * a.tiles_per_img;
     const int co0 = cot * COT, p0 = tl * PT;
     const int nchunks = (a.Cin + 15) >> 4;
-    const int npad = (nchunks + 3) & ~3;  // barrier trip count of both roles (multiple of the prefetch depth)
     const float* xn = a.x + (long)n * a.x_bs;
+    if (tid < COT) {  // bias through LDS (visible after the first barrier): a global load in the epilogue would
+        const int m = co0 + tid;  // serialise the stores behind vmcnt(0)
+        const float* bp = a.bias ? a.bias : (const float*)a.planes;
+        const float v = bp[m < a.M ? m : 0];
+        biasl[tid] = (a.bias && m < a.M) ? v : 0.f;
+    }
 
     if (producer) {
         // B tasks: task u of this thread -> (pixel, k half); 8 channel values of one pixel per task
@@ -371,7 +387,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
             const int row = rem >> 1, h = rem & 1;
             arow[u] = row;
             av[u] = (co0 + row) < a.M;
-            asrc[u] = ((long)pl * a.M + (av[u] ? co0 + row : 0)) * a.Cp + h * 8;
+            asrc[u] = ((long)pl * a.M + (av[u] ? co0 + row : 0)) * 16 + h * 8;  // + chunk * 3 * M * 16
             aofs[u] = pl * APL + row * BROW + h * 16;
         }
         // PD register sets: the global loads of PD chunks are in flight at any time (an iteration lasts
@@ -390,7 +406,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
                     breg[set][u][e] = xn[(long)(c < a.Cin ? c : a.Cin - 1) * a.P + bp[u]];
                 }
 #pragma unroll
-            for (int u = 0; u < NAT; ++u) areg[set][u] = *(const uint4*)(a.planes + asrc[u] + k0);
+            for (int u = 0; u < NAT; ++u) areg[set][u] = *(const uint4*)(a.planes + asrc[u] + (long)k0 * 3 * a.M);
         };
         auto commit = [&](int ch_, int buf, int set) {
             const int ch = ch_ < nchunks ? ch_ : nchunks - 1;
@@ -540,7 +556,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
                 const int col = (wco * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int m = co0 + col;
                 if (m < a.M) {
-                    const float bvv = a.bias ? a.bias[m] : 0.f;
+                    const float bvv = biasl[col];
                     float* rowp = obase + (long)m * a.P;
 #pragma unroll
                     for (int pt = 0; pt < PXT; ++pt)
@@ -585,6 +601,336 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
 }
 
 
+// -------------------------------------------------------------------------------------
+// k_pw_split_p: the same GEMM as k_pw_split, PERSISTENT over (pixel tile, channel tile) items.
+// A workgroup walks items  idx0, idx0 + gstep, ...  of its XCD; the producer waves run a single
+// flattened chunk stream across item boundaries, so the global loads of the next PD chunks (= the whole
+// next tile when the contraction is short) are in flight while the consumer waves run the epilogue of
+// the current tile.  For the short-contraction GEMMs (data gradients of the plane-dominated layers:
+// 4-8 chunks per tile, 64 KB of output per tile) this is what keeps HBM busy: in the one-tile-per-
+// workgroup form fill, MFMAs and the store epilogue of a tile are serial and only two workgroups per
+// CU overlap them.  Out-of-range rows/pixels are CLAMPED to valid addresses rather than zeroed: their
+// accumulator rows/columns are never stored and are masked out of the statistics.
+// BatchNorm partials: each consumer wave leaves its per-channel sums in stat[item parity]; they are
+// combined and written one item later (all waves have passed a barrier in between).
+// -------------------------------------------------------------------------------------
+template <int WCO, int CT, int WPX, int PXT, int NPT, int NT>
+__global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) void k_pw_split_p(const PwSplitArgs a) {
+    constexpr int COT = WCO * CT * 32;
+    constexpr int PT = WPX * PXT * 32;
+    constexpr int NCW = WCO * WPX;
+    constexpr int NCT = NCW * 64;
+    constexpr int APL = COT * BROW, BPL = PT * BROW;
+    constexpr int BUFSZ = NT * (APL + BPL);
+    constexpr int NBT = PT * 2 / NPT;
+    constexpr int NAT = (COT * 2 * NT + NPT - 1) / NPT;
+    static_assert(NCW == 4 || NCW == 8, "4 or 8 consumer waves");
+    static_assert((PT * 2) % NPT == 0, "producer mapping");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float* stat = (float*)(lds + 2 * BUFSZ);  // [2][WPX][2][COT]
+    float* biasl = stat + 2 * WPX * 2 * COT;  // [4][COT]: bias of the channel tile of item k in slot k & 3
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wv >= NCW;
+    const int wave = producer ? 0 : wv;
+    const int wco = wave % WCO, wpx = wave / WCO;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int ptid = producer ? tid - NCT : 0;
+
+    // items of this workgroup: idx = idx0 + k * gstep on XCD xcd; idx -> (pixel tile idx / nco of the XCD's
+    // contiguous tile range, channel tile idx % nco)
+    const int b = blockIdx.x, xcd = b & 7, idx0 = b >> 3;
+    const int gstep = gridDim.x >> 3;
+    const int tpx = (a.T + 7) >> 3;
+    int lim_t = a.T - xcd * tpx;
+    lim_t = lim_t < tpx ? lim_t : tpx;
+    const int lim = lim_t > 0 ? lim_t * a.nco : 0;
+    if (idx0 >= lim) return;
+    const int nitems = (lim - 1 - idx0) / gstep + 1;
+    const int nchunks = (a.Cin + 15) >> 4;
+    const int G = nitems * nchunks;  // chunks of this workgroup
+
+    if (producer) {
+        int bpix[NBT], bhalf[NBT];
+#pragma unroll
+        for (int u = 0; u < NBT; ++u) {
+            const int t = ptid + NPT * u;
+            bpix[u] = t % PT;
+            bhalf[u] = t / PT;
+        }
+        // A tasks: (plane, row, k half).  When a plane is exactly NPT tasks, task u of a thread is plane u of
+        // ONE (row, half): the per-task state collapses to a base + compile-time offsets.
+        constexpr bool ASIMPLE = (COT * 2 == NPT);
+        int apl[NAT], arow[NAT], ah8[NAT], aofs[NAT];
+#pragma unroll
+        for (int u = 0; u < NAT; ++u) {
+            const int t = ASIMPLE ? ptid + NPT * u : (ptid + NPT * u) % (COT * 2 * NT);  // surplus tasks re-copy a valid piece
+            const int pl = ASIMPLE ? u : t / (COT * 2), rem = ASIMPLE ? ptid : t - pl * (COT * 2);
+            apl[u] = pl;
+            arow[u] = rem >> 1;
+            ah8[u] = (rem & 1) * 8;
+            aofs[u] = pl * APL + arow[u] * BROW + (rem & 1) * 16;
+        }
+        constexpr int PD = 4;
+        float breg[PD][NBT][8];
+        u32x4 areg[PD][NAT];
+        float bias_reg[PD];  // bias of channel (ptid % COT) of the chunk's item: reaches the consumers through LDS
+        const float* biasp = a.bias ? a.bias : (const float*)a.planes;  // any readable address when there is no bias  // native vector: a struct copy global -> private -> LDS would stay a memcpy through scratch
+        // prefetch cursor: (item, chunk) + the per-item address bases
+        int pf_item = 0, pf_ch = 0;
+        const float* pf_x = a.x;
+        int pf_bp[NBT], pf_bidx = 0;
+        long pf_as[NAT];
+        auto pf_setup = [&]() __attribute__((always_inline)) {
+            const int it = pf_item < nitems ? pf_item : nitems - 1;
+            const int idx = idx0 + it * gstep;
+            const int j = idx / a.nco, cot = idx - j * a.nco;
+            const int ptg = xcd * tpx + j;
+            const int n = ptg / a.tiles_per_img, tl = ptg - n * a.tiles_per_img;
+            pf_x = a.x + (long)n * a.x_bs;
+            pf_bidx = cot * COT + ptid % COT;
+            pf_bidx = pf_bidx < a.M ? pf_bidx : a.M - 1;
+#pragma unroll
+            for (int u = 0; u < NBT; ++u) {
+                const int p = tl * PT + bpix[u];
+                pf_bp[u] = p < a.P ? p : a.P - 1;
+            }
+#pragma unroll
+            for (int u = 0; u < NAT; ++u) {
+                const int r = cot * COT + arow[ASIMPLE ? 0 : u];
+                const long o = (long)(r < a.M ? r : a.M - 1) * 16 + ah8[ASIMPLE ? 0 : u];
+                pf_as[u] = ASIMPLE ? o : o + (long)apl[u] * a.M * 16;
+            }
+        };
+        const long aplane = (long)a.M * 16;  // planes are chunk-major [Cp/16][3][M][16]
+        // The global loads of the producers are issued through inline asm and waited for with an explicit
+        // counted s_waitcnt: hipcc's own bookkeeping drains to vmcnt(0) at every commit of this loop (the
+        // conditionals and the rotating register sets defeat its counting), which caps the prefetch depth at
+        // ONE chunk however many register sets exist.  With LPC loads per chunk and PD sets, the loads of
+        // the chunk being committed are complete when at most (PD - 1) * LPC younger ones are outstanding.
+        constexpr int LPC = NBT * 8 + NAT + 1;
+        static_assert((PD - 1) * LPC <= 63, "vmcnt is a 6-bit counter");
+        auto prefetch = [&](int set) __attribute__((always_inline)) {
+            const int k0 = pf_ch * 16;
+#pragma unroll
+            for (int u = 0; u < NBT; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = k0 + bhalf[u] * 8 + e;
+#if (PWSP_ABL & 4)
+                    breg[set][u][e] = (float)(c + pf_bp[u]);
+#else
+                    const float* src = pf_x + (long)(c < a.Cin ? c : a.Cin - 1) * a.P + pf_bp[u];
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(breg[set][u][e]) : "v"(src));
+#endif
+                }
+#pragma unroll
+            for (int u = 0; u < NAT; ++u) {
+                const unsigned short* src = a.planes + pf_as[ASIMPLE ? 0 : u] + (ASIMPLE ? u * aplane : 0) + (long)k0 * 3 * a.M;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(areg[set][u]) : "v"(src));
+            }
+            {
+                const float* src = biasp + pf_bidx;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(bias_reg[set]) : "v"(src));
+            }
+            if (++pf_ch == nchunks) {  // wave-uniform: address arithmetic only
+                pf_ch = 0;
+                ++pf_item;
+                pf_setup();
+            }
+        };
+        auto commit = [&](int ch, int buf, int set, int slot) __attribute__((always_inline)) {
+            const int k0 = ch * 16;
+            // wait for this set's loads; the "+v" ties keep every use of the set's registers behind the wait
+#if !(PWSP_ABL & 4)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * LPC) : "memory");
+#endif
+#pragma unroll
+            for (int u = 0; u < NBT; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(breg[set][u][e]));
+#pragma unroll
+            for (int u = 0; u < NAT; ++u) asm volatile("" : "+v"(areg[set][u]));
+            asm volatile("" : "+v"(bias_reg[set]));
+            biasl[slot * COT + ptid % COT] = a.bias ? bias_reg[set] : 0.f;  // every chunk of the item rewrites the same values
+            unsigned char* base = lds + buf * BUFSZ;
+#pragma unroll
+            for (int u = 0; u < NBT; ++u) {
+                float p1[8], p2[8], p3[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = k0 + bhalf[u] * 8 + e;
+                    const float x = (c < a.Cin) ? breg[set][u][e] : 0.f;
+                    p1[e] = NT == 1 ? rne_bf16(x) : bitsf(fbits(x) & 0xFFFF0000u);
+                    const float r1 = x - p1[e];
+                    p2[e] = bitsf(fbits(r1) & 0xFFFF0000u);
+                    p3[e] = r1 - p2[e];
+                }
+                unsigned char* dst = base + NT * APL + bpix[u] * BROW + bhalf[u] * 16;
+                *(uint4*)(dst) = make_uint4(pack_hi16(p1[0], p1[1]), pack_hi16(p1[2], p1[3]), pack_hi16(p1[4], p1[5]),
+                                            pack_hi16(p1[6], p1[7]));
+                if (NT == 3) {
+                    *(uint4*)(dst + BPL) = make_uint4(pack_hi16(p2[0], p2[1]), pack_hi16(p2[2], p2[3]),
+                                                      pack_hi16(p2[4], p2[5]), pack_hi16(p2[6], p2[7]));
+                    *(uint4*)(dst + 2 * BPL) = make_uint4(pack_hi16(p3[0], p3[1]), pack_hi16(p3[2], p3[3]),
+                                                          pack_hi16(p3[4], p3[5]), pack_hi16(p3[6], p3[7]));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NAT; ++u) *(u32x4*)(base + (ASIMPLE ? aofs[0] + u * APL : aofs[u])) = areg[set][u];
+        };
+        pf_setup();
+#pragma unroll
+        for (int j = 0; j < PD; ++j) prefetch(j);
+        commit(0, 0, 0, 0);
+        prefetch(0);
+        int cm_ch = nchunks > 1 ? 1 : 0;  // chunk (within its item) of the NEXT commit
+        int cm_slot = nchunks > 1 ? 0 : 1;  // ... and its item & 3
+        __syncthreads();
+        for (int g0 = 0; g0 < G; g0 += PD) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                const int g = g0 + u;
+                if (g < G) {
+                    if (g + 1 < G) {
+                        commit(cm_ch, (g + 1) & 1, (u + 1) % PD, cm_slot);  // loads issued PD chunks ago
+                        if (++cm_ch == nchunks) {
+                            cm_ch = 0;
+                            cm_slot = (cm_slot + 1) & 3;
+                        }
+                        prefetch((u + 1) % PD);
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus prefetches of the tail still target live registers
+        if (a.part) __syncthreads();
+    } else {
+        const int aoff = ((wco * CT) * 32 + l31) * BROW + half * 16;
+        const int boff = NT * APL + ((wpx * PXT) * 32 + l31) * BROW + half * 16;
+        auto flush = [&](int par, int ptg, int co0) __attribute__((always_inline)) {  // combine the WPX waves' sums of a finished item
+            const float* sp = stat + par * (WPX * 2 * COT);
+            for (int t = tid; t < 2 * COT; t += NCT) {
+                const int which = t / COT, col = t - which * COT;
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < WPX; ++w) v += sp[(w * 2 + which) * COT + col];
+                const int m = co0 + col;
+                if (m < a.M) a.part[((long)which * a.slots + ptg) * a.M + m] = v;
+            }
+        };
+        __syncthreads();
+        int g = 0, prev_ptg = 0, prev_co0 = 0;
+        for (int k = 0; k < nitems; ++k) {
+            const int idx = idx0 + k * gstep;
+            const int j = idx / a.nco, cot = idx - j * a.nco;
+            const int ptg = xcd * tpx + j;
+            const int n = ptg / a.tiles_per_img, tl = ptg - n * a.tiles_per_img;
+            const int co0 = cot * COT, p0 = tl * PT;
+            f32x16 acc[CT][PXT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < PXT; ++pt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
+            for (int i = 0; i < nchunks; ++i, ++g) {
+                const unsigned char* base = lds + (g & 1) * BUFSZ;
+                bf16x8 af[CT][NT], bf[PXT][NT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) af[ct][t] = *(const bf16x8*)(base + aoff + t * APL + ct * 32 * BROW);
+#pragma unroll
+                for (int pt = 0; pt < PXT; ++pt)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) bf[pt][t] = *(const bf16x8*)(base + boff + t * BPL + pt * 32 * BROW);
+#if (PWSP_ABL & 2)
+                acc[0][0][0] += (float)(af[0][0][0] + bf[0][0][0] + af[CT - 1][NT - 1][7] + bf[PXT - 1][NT - 1][7]);
+#else
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < PXT; ++pt) {
+                        if (NT == 3) {
+                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][0], bf[pt][NT - 1], acc[ct][pt], 0, 0, 0);
+                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][NT - 1], bf[pt][0], acc[ct][pt], 0, 0, 0);
+                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][NT / 2], bf[pt][NT / 2], acc[ct][pt], 0, 0, 0);
+                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][0], bf[pt][NT / 2], acc[ct][pt], 0, 0, 0);
+                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][NT / 2], bf[pt][0], acc[ct][pt], 0, 0, 0);
+                        }
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][0], bf[pt][0], acc[ct][pt], 0, 0, 0);
+                    }
+#endif
+                __syncthreads();
+            }
+            // ---- epilogue (no barriers: the producers keep streaming the next item meanwhile) ----
+            // Branch-free and load-free: a global load (bias) or a divergent branch in here makes hipcc put an
+            // s_waitcnt vmcnt(0) in front of every store, i.e. each store waits for the previous one to be
+            // acknowledged (that, not bandwidth, was the cost of the store tail).  Stores go through a buffer
+            // descriptor of the output image: rows >= M fall beyond num_records and pixels >= P get an offset
+            // with bit 31 set, so the hardware range check drops them.
+            if (a.part && k > 0) flush((k - 1) & 1, prev_ptg, prev_co0);
+            unsigned pvo[PXT];
+            bool pval[PXT];
+#pragma unroll
+            for (int pt = 0; pt < PXT; ++pt) {
+                const int p = p0 + (wpx * PXT + pt) * 32 + l31;
+                pval[pt] = p < a.P;
+                pvo[pt] = pval[pt] ? (unsigned)p * 4u : 0x80000000u;
+            }
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc(a.out + (long)n * a.out_bs, 0, a.M * a.P * 4, 0x00020000);
+            const unsigned rowb = (unsigned)(co0 + wco * CT * 32 + 4 * half) * (unsigned)a.P * 4u;
+            const float* bl = biasl + (k & 3) * COT + wco * CT * 32 + 4 * half;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rc = ct * 32 + (r & 3) + 8 * (r >> 2);  // row of the wave tile (+ 4 * half): constant
+                    const float bvv = bl[rc];
+                    const unsigned ro = rowb + (unsigned)rc * (unsigned)a.P * 4u;
+#pragma unroll
+                    for (int pt = 0; pt < PXT; ++pt)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[ct][pt][r] + bvv), rs,
+                                                              ro + pvo[pt], 0, 0);
+                }
+            }
+            if (a.part) {
+                float* sp = stat + (k & 1) * (WPX * 2 * COT) + wpx * 2 * COT + wco * CT * 32 + 4 * half;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float s = 0.f, q = 0.f;
+#pragma unroll
+                        for (int pt = 0; pt < PXT; ++pt) {
+                            const float v = pval[pt] ? acc[ct][pt][r] : 0.f;
+                            s += v;
+                            q = fmaf(v, v, q);
+                        }
+                        s = half32_sum_hi(s);
+                        q = half32_sum_hi(q);
+                        if (l31 == 16 + r) {
+                            const int rc = ct * 32 + (r & 3) + 8 * (r >> 2);
+                            sp[rc] = s;
+                            sp[COT + rc] = q;
+                        }
+                    }
+                }
+                prev_ptg = ptg;
+                prev_co0 = co0;
+            }
+        }
+        if (a.part) {
+            __syncthreads();
+            flush((nitems - 1) & 1, prev_ptg, prev_co0);
+        }
+    }
+}
+
 int pw_split_num_slots(int N, int P) {
     // upper bound over the tile choices of launch_pw_split (unused slots are never written: see below)
     const int PT = 128;
@@ -606,12 +952,21 @@ static int launch_pw_split_cfg(PwSplitArgs& a, hipStream_t st) {
         }
         a.dbg = abl;
     }
-    const size_t lds = (size_t)NBUF * NT * (COT + PT) * BROW + sizeof(float) * WPX * 2 * COT;
-    constexpr auto kern = k_pw_split<WCO, CT, WPX, PXT, NPT, NBUF, NT>;
-    int rc = ensure_lds_s<kern>(lds);
-    if (rc) return rc;
-    const int grid = ((a.T + 7) / 8) * 8 * a.nco;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WCO * WPX * 64 + NPT), lds, st, a);
+    const int items = ((a.T + 7) / 8) * 8 * a.nco;
+    if (NBUF == 2 && !(pws_cfg() & 16) && (long)(a.M + COT) * a.P * 4 < (1L << 31)) {  // persistent form: 2 workgroups per CU walk the items
+        const size_t lds = (size_t)2 * NT * (COT + PT) * BROW + sizeof(float) * (2 * WPX * 2 * COT + 4 * COT);
+        constexpr auto kern = k_pw_split_p<WCO, CT, WPX, PXT, NPT, NT>;
+        int rc = ensure_lds_s<kern>(lds);
+        if (rc) return rc;
+        const int grid = items < 512 ? items : 512;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WCO * WPX * 64 + NPT), lds, st, a);
+    } else {
+        const size_t lds = (size_t)NBUF * NT * (COT + PT) * BROW + sizeof(float) * (WPX * 2 * COT + COT);
+        constexpr auto kern = k_pw_split<WCO, CT, WPX, PXT, NPT, NBUF, NT>;
+        int rc = ensure_lds_s<kern>(lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3(items), dim3(WCO * WPX * 64 + NPT), lds, st, a);
+    }
     if (a.part && a.T < a.slots) {  // partial-statistics rows this tile choice does not use
         for (int w = 0; w < 2; ++w)
             HIP_RET(hipMemsetAsync(a.part + ((long)w * a.slots + a.T) * a.M, 0, sizeof(float) * (size_t)(a.slots - a.T) * a.M, st));

@@ -133,7 +133,7 @@ def set_matrix_mode(mode):
 
 
 def _split_planes_raw(w2d):
-    """w2d [R][C] f32 contiguous -> int16 [3][R][ceil16(C)] bf16 planes"""
+    """w2d [R][C] f32 contiguous -> int16 bf16 planes, 3 * R * ceil16(C) elements (chunk-major [ceil16(C)/16][3][R][16])"""
     L = _lib.get()
     r, c = w2d.shape
     cp = (c + 15) // 16 * 16

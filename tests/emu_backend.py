@@ -89,15 +89,15 @@ class EmuLib:
         return PW_SLOTS + 1
 
     def smaat_split_planes(self, w, R, C, out, stream):
-        """exact three-term bf16 split (truncation), planes [3][R][Cp] of uint16"""
+        """exact three-term bf16 split (truncation), chunk-major planes [Cp/16][3][R][16] of uint16"""
         Cp = (C + 15) // 16 * 16
         wv = f32(w, R * C).reshape(R, C)
-        o = np.ctypeslib.as_array((ctypes.c_uint16 * (3 * R * Cp)).from_address(int(out))).reshape(3, R, Cp)
-        o[:] = 0
-        rem = wv.astype(np.float32).copy()
+        o = np.ctypeslib.as_array((ctypes.c_uint16 * (3 * R * Cp)).from_address(int(out))).reshape(Cp // 16, 3, R, 16)
+        rem = np.zeros((R, Cp), np.float32)
+        rem[:, :C] = wv
         for t in range(3):
             bits = rem.view(np.uint32) & np.uint32(0xFFFF0000)
-            o[t, :, :C] = (bits >> np.uint32(16)).astype(np.uint16)
+            o[:, t] = (bits >> np.uint32(16)).astype(np.uint16).reshape(R, Cp // 16, 16).transpose(1, 0, 2)
             rem = (rem - bits.view(np.float32)).astype(np.float32)
         assert not rem.any(), "three bf16 terms must represent an f32 exactly"
         return 0
@@ -117,7 +117,8 @@ class EmuLib:
     def smaat_pointwise_fwd_split(self, x, x_bs, pl, bias, out, out_bs, part, N, Cin, M, H, W, stream):
         P = H * W
         Cp = (Cin + 15) // 16 * 16
-        u = np.ctypeslib.as_array((ctypes.c_uint16 * (3 * M * Cp)).from_address(int(pl))).reshape(3, M, Cp)
+        u = np.ctypeslib.as_array((ctypes.c_uint16 * (3 * M * Cp)).from_address(int(pl))).reshape(Cp // 16, 3, M, 16)
+        u = u.transpose(1, 2, 0, 3).reshape(3, M, Cp)
         a = ((u.astype(np.uint32) << np.uint32(16)).view(np.float32)).astype(np.float64).sum(axis=0)[:, :Cin]
         xv = planes(x, N, Cin, P, x_bs)
         acc = np.einsum("mc,ncp->nmp", a.astype(np.float32), xv)
