@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/${1:-pers2}
 mkdir -p "$OUT"
-timeout 300 python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "split" --tb=short -p no:cacheprovider > "$OUT/k_split.log" 2>&1
+timeout 300 python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "split or wgrad" --tb=short -p no:cacheprovider > "$OUT/k_split.log" 2>&1
 echo "split kernels exit=$? $(tail -1 "$OUT/k_split.log")"
 timeout 600 python -m pytest tests/test_gpu_model.py -q -m gpu -x --tb=short -p no:cacheprovider > "$OUT/model.log" 2>&1
 echo "model exit=$? $(tail -1 "$OUT/model.log")"

@@ -106,30 +106,45 @@ __global__ __launch_bounds__(256 + NPT) void k_wgrad_split(const Wg2Args a) {
             }
             lofs[j] = row * SROW + q * 8;
         }
-        float4 pf[NF4];
-        bool pv[NF4];
-        auto prefetch = [&](int it) {
-            const int c = c_begin + (it < nit ? it : nit - 1) * c_step;
+        // PD register sets of loads in flight.  The loads are issued through inline asm and waited for with an
+        // explicit counted s_waitcnt (hipcc's own bookkeeping drains to vmcnt(0) at every commit, which would
+        // leave ONE chunk in flight per CU: the iteration time was the memory latency, ~1.7 us, against
+        // ~0.65 us of MFMA work).  Invariant: between the prefetch of a set and its commit exactly PD - 1
+        // other prefetches (NF4 loads each) are issued.
+        constexpr int PD = 4;
+        static_assert((PD - 1) * NF4 <= 63, "vmcnt is a 6-bit counter");
+        f32x4 pf[PD][NF4];
+        bool pin[PD];
+        int pf_it = 0;  // next chunk to prefetch
+        auto prefetch = [&](int set) __attribute__((always_inline)) {
+            const int it = pf_it < nit ? pf_it : nit - 1;
+            ++pf_it;
+            const int c = c_begin + it * c_step;
             const int n = c / a.nchunk_img;
             const int p0 = (c - n * a.nchunk_img) * SPS + q * 4;
             const bool in = p0 < a.P;  // P % 4 == 0: a float4 is entirely inside or outside the plane
             const int p0c = in ? p0 : 0;
+            pin[set] = in;
 #pragma unroll
             for (int j = 0; j < NF4; ++j) {
                 const int row = rbase + RSTEP * j;
-                pf[j] = *(const float4*)(rowp[j] + (long)n * (row < MT ? a.dz_bs : a.y_bs) + p0c);
-                pv[j] = in && rowv[j];
+                const float* src = rowp[j] + (long)n * (row < MT ? a.dz_bs : a.y_bs) + p0c;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pf[set][j]) : "v"(src));
             }
         };
-        auto commit = [&](int buf) {
+        auto commit = [&](int buf, int set) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * NF4) : "memory");
+#pragma unroll
+            for (int j = 0; j < NF4; ++j) asm volatile("" : "+v"(pf[set][j]));  // uses stay behind the wait
             unsigned char* base = lds + buf * BUFSZ;
 #pragma unroll
             for (int j = 0; j < NF4; ++j) {
-                float4 v = pf[j];
-                v.x = pv[j] ? v.x : 0.f;
-                v.y = pv[j] ? v.y : 0.f;
-                v.z = pv[j] ? v.z : 0.f;
-                v.w = pv[j] ? v.w : 0.f;
+                const bool ok = pin[set] && rowv[j];
+                float4 v;
+                v.x = ok ? pf[set][j][0] : 0.f;
+                v.y = ok ? pf[set][j][1] : 0.f;
+                v.z = ok ? pf[set][j][2] : 0.f;
+                v.w = ok ? pf[set][j][3] : 0.f;
                 uint2 pl[NT];
                 split4<NT>(v, pl);
 #pragma unroll
@@ -137,18 +152,26 @@ __global__ __launch_bounds__(256 + NPT) void k_wgrad_split(const Wg2Args a) {
             }
         };
         if (nit > 0) {
+#pragma unroll
+            for (int j = 0; j < PD; ++j) prefetch(j);
+            commit(0, 0);
             prefetch(0);
-            commit(0);
-            prefetch(1);
         }
         __syncthreads();
-        for (int it = 0; it < nit; ++it) {
-            if (it + 1 < nit) {
-                commit((it + 1) & 1);   // chunk it+1 (its loads were issued one iteration ago)
-                prefetch(it + 2);
+        for (int it0 = 0; it0 < nit; it0 += PD) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                const int it = it0 + u;
+                if (it < nit) {
+                    if (it + 1 < nit) {
+                        commit((it + 1) & 1, (u + 1) % PD);  // chunk it+1: its loads were issued PD chunks ago
+                        prefetch((u + 1) % PD);
+                    }
+                    __syncthreads();
+                }
             }
-            __syncthreads();
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus prefetches of the tail
     } else {
         f32x16 acc[MTT][2];
 #pragma unroll

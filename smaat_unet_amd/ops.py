@@ -119,8 +119,10 @@ def _split_fwd_ok(k, cout):
     return _split_on() and (_split_all() or (k >= 128 and cout >= 128))
 
 
-def _split_dgrad_ok(cout):
-    return _split_on() and (_split_all() or cout >= 256)
+def _split_dgrad_ok(cout, k):
+    # the persistent split kernel beats the f32-MFMA one on every data gradient with a GEMM-sized output
+    # (profiles/r1/r1p); the 24-channel stem stays on the f32 kernel
+    return _split_on() and (_split_all() or (cout >= 64 and k >= 64))
 
 
 def set_matrix_mode(mode):
@@ -291,7 +293,7 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None, i
                                         _ptr(dw_pw), n, cin, kpl, cout, h, w, s), "smaat_dsconv_wgrad")
         del ws
     # data gradient of the pointwise conv: dY = W^T dZ  (wt := w_pw in its natural [Cout][K] layout)
-    if _split_dgrad_ok(cout):
+    if _split_dgrad_ok(cout, k):
         # A[m' = k][c = co] = w_pw[co][k]: planes of the transposed weight
         planes_t = _split_planes_raw(w_pw.reshape(cout, k).t().contiguous())
         dy, _, _ = _pointwise_split_raw(dz, planes_t, None, k)
