@@ -26,7 +26,9 @@ int split_mode();
 __device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(unsigned, x); }
 __device__ __forceinline__ float bitsf(unsigned x) { return __builtin_bit_cast(float, x); }
 // low half <- bf16 of x, high half <- bf16 of y (both already have zero low 16 bits or are truncated here)
-__device__ __forceinline__ unsigned pack_hi16(float x, float y) { return (fbits(x) >> 16) | (fbits(y) & 0xFFFF0000u); }
+__device__ __forceinline__ unsigned pack_hi16(float x, float y) {
+    return __builtin_amdgcn_perm(fbits(y), fbits(x), 0x07060302u);  // one v_perm_b32: {y.hi16, x.hi16}
+}
 __device__ __forceinline__ float rne_bf16(float x) {  // round-to-nearest-even to 8 significant bits, kept as f32
     const unsigned b = fbits(x);
     return bitsf((b + 0x7FFFu + ((b >> 16) & 1u)) & 0xFFFF0000u);
@@ -704,6 +706,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
         int pf_item = 0, pf_ch = 0;
         const float* pf_x = a.x;
         int pf_bp[NBT], pf_bidx = 0;
+        unsigned pf_bvo[NBT], pf_avo[NAT];  // per-lane byte offsets of the scalar-base (saddr) loads
         long pf_as[NAT];
         auto pf_setup = [&]() __attribute__((always_inline)) {
             const int it = pf_item < nitems ? pf_item : nitems - 1;
@@ -718,12 +721,14 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
             for (int u = 0; u < NBT; ++u) {
                 const int p = tl * PT + bpix[u];
                 pf_bp[u] = p < a.P ? p : a.P - 1;
+                pf_bvo[u] = (unsigned)(bhalf[u] * 8 * a.P + pf_bp[u]) * 4u;
             }
 #pragma unroll
             for (int u = 0; u < NAT; ++u) {
                 const int r = cot * COT + arow[ASIMPLE ? 0 : u];
                 const long o = (long)(r < a.M ? r : a.M - 1) * 16 + ah8[ASIMPLE ? 0 : u];
                 pf_as[u] = ASIMPLE ? o : o + (long)apl[u] * a.M * 16;
+                pf_avo[u] = (unsigned)pf_as[u] * 2u;
             }
         };
         const long aplane = (long)a.M * 16;  // planes are chunk-major [Cp/16][3][M][16]
@@ -734,28 +739,38 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
         // the chunk being committed are complete when at most (PD - 1) * LPC younger ones are outstanding.
         constexpr int LPC = NBT * 8 + NAT + 1;
         static_assert((PD - 1) * LPC <= 63, "vmcnt is a 6-bit counter");
+        // Addresses: a wave-uniform 64-bit base in SGPRs (image, chunk, channel: scalar arithmetic) plus a 32-bit
+        // per-lane byte offset that only changes with the item -> no vector address arithmetic per load.
         auto prefetch = [&](int set) __attribute__((always_inline)) {
             const int k0 = pf_ch * 16;
+            if (k0 + 16 <= a.Cin) {  // wave-uniform: all 16 channels of the chunk exist
+                const float* sb = pf_x + (long)k0 * a.P;
 #pragma unroll
-            for (int u = 0; u < NBT; ++u)
+                for (int u = 0; u < NBT; ++u)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int c = k0 + bhalf[u] * 8 + e;
-#if (PWSP_ABL & 4)
-                    breg[set][u][e] = (float)(c + pf_bp[u]);
-#else
-                    const float* src = pf_x + (long)(c < a.Cin ? c : a.Cin - 1) * a.P + pf_bp[u];
-                    asm volatile("global_load_dword %0, %1, off" : "=v"(breg[set][u][e]) : "v"(src));
-#endif
-                }
+                    for (int e = 0; e < 8; ++e) {
+                        const float* sbe = sb + (long)e * a.P;
+                        asm volatile("global_load_dword %0, %1, %2" : "=v"(breg[set][u][e]) : "v"(pf_bvo[u]), "s"(sbe));
+                    }
+            } else {  // last, partial chunk: clamp the channel per lane (the values are zeroed at the commit)
 #pragma unroll
-            for (int u = 0; u < NAT; ++u) {
-                const unsigned short* src = a.planes + pf_as[ASIMPLE ? 0 : u] + (ASIMPLE ? u * aplane : 0) + (long)k0 * 3 * a.M;
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(areg[set][u]) : "v"(src));
+                for (int u = 0; u < NBT; ++u)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int c = k0 + bhalf[u] * 8 + e;
+                        const float* src = pf_x + (long)(c < a.Cin ? c : a.Cin - 1) * a.P + pf_bp[u];
+                        asm volatile("global_load_dword %0, %1, off" : "=v"(breg[set][u][e]) : "v"(src));
+                    }
             }
             {
-                const float* src = biasp + pf_bidx;
-                asm volatile("global_load_dword %0, %1, off" : "=v"(bias_reg[set]) : "v"(src));
+                const unsigned short* sa = a.planes + (long)k0 * 3 * a.M;
+#pragma unroll
+                for (int u = 0; u < NAT; ++u) {
+                    const unsigned short* sau = sa + (ASIMPLE ? u * aplane : 0);
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(areg[set][u]) : "v"(pf_avo[ASIMPLE ? 0 : u]), "s"(sau));
+                }
+                const unsigned bvo = (unsigned)pf_bidx * 4u;
+                asm volatile("global_load_dword %0, %1, %2" : "=v"(bias_reg[set]) : "v"(bvo), "s"(biasp));
             }
             if (++pf_ch == nchunks) {  // wave-uniform: address arithmetic only
                 pf_ch = 0;
@@ -776,6 +791,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
 #pragma unroll
             for (int u = 0; u < NAT; ++u) asm volatile("" : "+v"(areg[set][u]));
             asm volatile("" : "+v"(bias_reg[set]));
+            const bool partial = k0 + 16 > a.Cin;  // wave-uniform
             biasl[slot * COT + ptid % COT] = a.bias ? bias_reg[set] : 0.f;  // every chunk of the item rewrites the same values
             unsigned char* base = lds + buf * BUFSZ;
 #pragma unroll
@@ -783,8 +799,8 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
                 float p1[8], p2[8], p3[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const int c = k0 + bhalf[u] * 8 + e;
-                    const float x = (c < a.Cin) ? breg[set][u][e] : 0.f;
+                    float x = breg[set][u][e];
+                    if (partial) x = (k0 + bhalf[u] * 8 + e < a.Cin) ? x : 0.f;
                     p1[e] = NT == 1 ? rne_bf16(x) : bitsf(fbits(x) & 0xFFFF0000u);
                     const float r1 = x - p1[e];
                     p2[e] = bitsf(fbits(r1) & 0xFFFF0000u);
