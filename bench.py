@@ -219,7 +219,7 @@ def main():
         # (= 6 x the algorithmic f32 rate in `algorithmic`), priced against the dense bf16 peak.
         classes = [
             klass(["smaat_pointwise_fwd_split"], "mfma", PEAK_BF16_MFMA_TFLOPS, "TFLOP/s", 6.0,
-                  "k_pw_split (v_mfma_f32_32x32x16_bf16 x6 per f32 product, exact 3-term operand split)"),
+                  "k_pw_split_p: persistent wave-specialised GEMM (v_mfma_f32_32x32x16_bf16 x6 per f32 product, exact 3-term operand split)"),
             klass(["smaat_pointwise_wgrad"], "mfma", PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
                   6.0 if split else 1.0, "k_wgrad_split (bf16 x6)" if split else "k_wgrad2 (v_mfma_f32_32x32x2_f32)"),
             klass(["smaat_dsconv_fwd", "smaat_pointwise_fwd"], "mfma", PEAK_F32_MFMA_TFLOPS, "TFLOP/s", 1.0,

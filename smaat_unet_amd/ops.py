@@ -15,6 +15,8 @@ Mapping to the reference (HansBambel/SmaAt-UNet):
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -107,7 +109,7 @@ def _split_on():
 # deep and the co tile wide; the shallow, plane-dominated layers stay on the fused f32-MFMA kernels
 # (they are HBM/latency bound and the fusion saves a pass over the depthwise output).
 FUSE_FIRST_ACTIVATION = True  # DoubleConvDS: apply the first BatchNorm + ReLU on load instead of writing y1
-SPLIT_POLICY = "auto"  # "auto" = the measured policy; "all" = every supported shape (parity tests)
+SPLIT_POLICY = os.environ.get("SMAAT_SPLIT_POLICY", "auto")  # "auto" = the measured policy; "all" = every supported shape
 
 
 def _split_all():
