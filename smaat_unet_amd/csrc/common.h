@@ -166,7 +166,7 @@ struct PwSplitArgs {
     long out_bs;
     float* part;  // [2][T][M] or null
     int N, Cin, Cp, M, P, nco, tiles_per_img, T, slots;
-    int dbg;  // timing ablations only (SMAAT_PWS_ABLATE): 1 = no MFMAs, 2 = producers idle, 4 = no fragment reads
+    int dbg;  // reserved (0)
 };
 
 #define HIP_RET(expr)                          \

@@ -91,7 +91,12 @@ __global__ __launch_bounds__(256 + NPT) void k_wgrad_split(const Wg2Args a) {
 
     if (producer) {
         // thread -> (row group, float4 column): 8 lanes cover one 128-byte row segment
-        const int q = ptid & 7, rbase = ptid >> 3;
+        // 8 lanes cover one 128-byte row segment (32 pixels).  Within a group of 8 rows the row order is
+        // 0,4,1,5,2,6,3,7: the two rows a 16-lane group writes with one ds_write_b64 are 4 rows (320 B = 16
+        // banks mod 32) apart, so their 64-byte pieces tile the 32 banks (consecutive rows, 20 banks apart,
+        // overlap on a quarter of the banks).
+        const int q = ptid & 7, g8 = ptid >> 3;
+        const int rbase = (g8 & ~7) | ((g8 & 1) << 2) | ((g8 >> 1) & 3);
         constexpr int RSTEP = NPT / 8;
         const float* rowp[NF4];
         bool rowv[NF4];
@@ -341,12 +346,9 @@ int launch_split_planes(const float* w, int R, int C, unsigned short* out, hipSt
 // =====================================================================================
 
 
-#ifndef PWSP_ABL
-#define PWSP_ABL 0  // timing ablations of k_pw_split_p (compile time): 1 no stores, 2 no MFMAs, 4 no global B loads
-#endif
 #define BROW 48   // bytes per LDS row of a [row][16 bf16] image (32 + 16 pad: conflict-free b128)
 
-template <int WCO, int CT, int WPX, int PXT, int NPT, int NBUF, int NT>
+template <int WCO, int CT, int WPX, int PXT, int NPT, int NT>
 __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplitArgs a) {
     constexpr int COT = WCO * CT * 32;
     constexpr int PT = WPX * PXT * 32;
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
     static_assert(NCW == 4 || NCW == 8, "4 or 8 consumer waves");
     static_assert((PT * 2) % NPT == 0, "producer mapping");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    float* stat = (float*)(lds + NBUF * BUFSZ);  // [WPX][2][COT]
+    float* stat = (float*)(lds + 2 * BUFSZ);  // [WPX][2][COT]
     float* biasl = stat + WPX * 2 * COT;         // [COT]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -469,40 +471,22 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
                 *(uint4*)(base + aofs[u]) = v;
             }
         };
-        if (NBUF == 2) {
 #pragma unroll
-            for (int j = 0; j < PD; ++j) prefetch(j, j);
-            commit(0, 0, 0);
-            prefetch(PD, 0);
-            __syncthreads();
-            for (int i0 = 0; i0 < nchunks; i0 += PD) {
+        for (int j = 0; j < PD; ++j) prefetch(j, j);
+        commit(0, 0, 0);
+        prefetch(PD, 0);
+        __syncthreads();
+        for (int i0 = 0; i0 < nchunks; i0 += PD) {
 #pragma unroll
-                for (int u = 0; u < PD; ++u) {
-                    const int i = i0 + u;
-                    if (i < nchunks) {
-                        if (i + 1 < nchunks) {
-                            commit(i + 1, (i + 1) & 1, (u + 1) % PD);   // loads issued PD iterations ago
-                            prefetch(i + 1 + PD, (u + 1) % PD);
-                        }
-                        __syncthreads();
+            for (int u = 0; u < PD; ++u) {
+                const int i = i0 + u;
+                if (i < nchunks) {
+                    if (i + 1 < nchunks) {
+                        commit(i + 1, (i + 1) & 1, (u + 1) % PD);   // loads issued PD iterations ago
+                        prefetch(i + 1 + PD, (u + 1) % PD);
                     }
+                    __syncthreads();
                 }
-            }
-        } else {
-            // three LDS buffers: the producers run TWO chunks ahead, so the consumers can fetch the
-            // fragments of chunk i+1 while the MFMAs of chunk i run (no LDS latency after the barrier)
-            prefetch(0, 0);
-            commit(0, 0, 0);
-            prefetch(1, 1);
-            commit(1, 1, 1);
-            prefetch(2, 0);
-            __syncthreads();
-            for (int i = 0; i < nchunks; ++i) {
-                if (i + 2 < nchunks) {
-                    commit(i + 2, (i + 2) % 3, 0);
-                    prefetch(i + 3, 0);
-                }
-                __syncthreads();
             }
         }
     } else {
@@ -542,29 +526,11 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
                 }
         };
         __syncthreads();
-        if (NBUF == 2) {
-            for (int i = 0; i < nchunks; ++i) {
-                bf16x8 af[CT][NT], bf[PXT][NT];
-                load(af, bf, i & 1);
-                mma(af, bf);
-                __syncthreads();
-            }
-        } else {
-            bf16x8 afA[CT][NT], bfA[PXT][NT], afB[CT][NT], bfB[PXT][NT];
-            load(afA, bfA, 0);
-            int bn = 1;  // buffer of the NEXT chunk
-            for (int i = 0; i < nchunks; i += 2) {
-                if (i + 1 < nchunks) load(afB, bfB, bn);
-                mma(afA, bfA);
-                __syncthreads();
-                bn = bn == 2 ? 0 : bn + 1;
-                if (i + 1 < nchunks) {
-                    if (i + 2 < nchunks) load(afA, bfA, bn);
-                    mma(afB, bfB);
-                    __syncthreads();
-                    bn = bn == 2 ? 0 : bn + 1;
-                }
-            }
+        for (int i = 0; i < nchunks; ++i) {
+            bf16x8 af[CT][NT], bf[PXT][NT];
+            load(af, bf, i & 1);
+            mma(af, bf);
+            __syncthreads();
         }
         // ---- epilogue: bias + coalesced row stores, BatchNorm partials of the raw accumulators ----
         int off[PXT];
@@ -781,9 +747,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
         auto commit = [&](int ch, int buf, int set, int slot) __attribute__((always_inline)) {
             const int k0 = ch * 16;
             // wait for this set's loads; the "+v" ties keep every use of the set's registers behind the wait
-#if !(PWSP_ABL & 4)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * LPC) : "memory");
-#endif
 #pragma unroll
             for (int u = 0; u < NBT; ++u)
 #pragma unroll
@@ -886,9 +850,6 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
                 for (int pt = 0; pt < PXT; ++pt)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) bf[pt][t] = *(const bf16x8*)(base + boff + t * BPL + pt * 32 * BROW);
-#if (PWSP_ABL & 2)
-                acc[0][0][0] += (float)(af[0][0][0] + bf[0][0][0] + af[CT - 1][NT - 1][7] + bf[PXT - 1][NT - 1][7]);
-#else
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -902,7 +863,6 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
                         }
                         acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][0], bf[pt][0], acc[ct][pt], 0, 0, 0);
                     }
-#endif
                 __syncthreads();
             }
             // ---- epilogue (no barriers: the producers keep streaming the next item meanwhile) ----
@@ -976,23 +936,19 @@ int pw_split_num_slots(int N, int P) {
     return N * ((P + PT - 1) / PT);
 }
 
-template <int WCO, int CT, int WPX, int PXT, int NPT, int NBUF = 2, int NT = 3>
+template <int WCO, int CT, int WPX, int PXT, int NPT, int NT = 3>
 static int launch_pw_split_cfg(PwSplitArgs& a, hipStream_t st) {
     constexpr int COT = WCO * CT * 32, PT = WPX * PXT * 32;
     a.nco = (a.M + COT - 1) / COT;
     a.tiles_per_img = (a.P + PT - 1) / PT;
     a.T = a.N * a.tiles_per_img;
     a.slots = pw_split_num_slots(a.N, a.P);
-    {
-        static int abl = -1;
-        if (abl < 0) {
-            const char* e = getenv("SMAAT_PWS_ABLATE");
-            abl = e ? atoi(e) : 0;
-        }
-        a.dbg = abl;
-    }
+    a.dbg = 0;
     const int items = ((a.T + 7) / 8) * 8 * a.nco;
-    if (NBUF == 2 && !(pws_cfg() & 16) && (long)(a.M + COT) * a.P * 4 < (1L << 31)) {  // persistent form: 2 workgroups per CU walk the items
+    // persistent form: 2 workgroups per CU walk the items.  Its store tail addresses an output image through a
+    // 32-bit buffer offset with bit 31 as the "dropped" marker: images of 2 GiB and more (and SMAAT_PWS_CFG=16,
+    // for A/B timing) take the one-tile-per-workgroup kernel.
+    if (!(pws_cfg() & 16) && (long)(a.M + COT) * a.P * 4 < (1L << 31)) {
         const size_t lds = (size_t)2 * NT * (COT + PT) * BROW + sizeof(float) * (2 * WPX * 2 * COT + 4 * COT);
         constexpr auto kern = k_pw_split_p<WCO, CT, WPX, PXT, NPT, NT>;
         int rc = ensure_lds_s<kern>(lds);
@@ -1000,8 +956,8 @@ static int launch_pw_split_cfg(PwSplitArgs& a, hipStream_t st) {
         const int grid = items < 512 ? items : 512;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WCO * WPX * 64 + NPT), lds, st, a);
     } else {
-        const size_t lds = (size_t)NBUF * NT * (COT + PT) * BROW + sizeof(float) * (WPX * 2 * COT + COT);
-        constexpr auto kern = k_pw_split<WCO, CT, WPX, PXT, NPT, NBUF, NT>;
+        const size_t lds = (size_t)2 * NT * (COT + PT) * BROW + sizeof(float) * (WPX * 2 * COT + COT);
+        constexpr auto kern = k_pw_split<WCO, CT, WPX, PXT, NPT, NT>;
         int rc = ensure_lds_s<kern>(lds);
         if (rc) return rc;
         hipLaunchKernelGGL(kern, dim3(items), dim3(WCO * WPX * 64 + NPT), lds, st, a);
@@ -1024,14 +980,12 @@ static int pws_cfg() {  // SMAAT_PWS_CFG: tuning experiments (0 = default)
 
 int launch_pw_split(PwSplitArgs& a, hipStream_t st) {
     // 128-pixel tiles everywhere: two workgroups per CU overlap each other's fill/drain and barriers
-    // (measured faster than 256-pixel tiles with one workgroup per CU on every layer shape)
-    const int cfg = pws_cfg();
+    // (measured faster than 256-pixel tiles with one workgroup per CU, than 256 x 128 tiles with eight
+    // consumer waves, and than three LDS buffers with a fragment prefetch, on every layer shape)
     if (split_mode() == 1) {  // plain bf16 operands, one MFMA per product
-        if (a.M > 64) return launch_pw_split_cfg<2, 2, 2, 2, 256, 2, 1>(a, st);
-        return launch_pw_split_cfg<1, 2, 4, 1, 256, 2, 1>(a, st);
+        if (a.M > 64) return launch_pw_split_cfg<2, 2, 2, 2, 256, 1>(a, st);
+        return launch_pw_split_cfg<1, 2, 4, 1, 256, 1>(a, st);
     }
-    if (a.M >= 256 && (cfg & 1)) return launch_pw_split_cfg<4, 2, 2, 2, 256>(a, st);  // 256 x 128, 8 consumer waves
-    if (a.M > 64 && (cfg & 2)) return launch_pw_split_cfg<2, 2, 2, 2, 256, 3>(a, st);  // 128 x 128, 3 LDS buffers
     if (a.M > 64) return launch_pw_split_cfg<2, 2, 2, 2, 256>(a, st);  // 128 x 128
     return launch_pw_split_cfg<1, 2, 4, 1, 256>(a, st);                // 64 x 128
 }

@@ -207,7 +207,10 @@ def case_pw_split(L, dev, N, C, M, H, W, with_part=False):
 
 @pytest.mark.parametrize("shape", [(2, 64, 1, 32, 32), (2, 64, 21, 16, 16), (2, 16, 3, 6, 7), (2, 128, 256, 36, 36),
                                    (4, 64, 70, 288, 288), (2, 1, 64, 20, 20), (2, 512, 1024, 18, 18),
-                                   (4, 40, 130, 288, 288), (2, 24, 64, 32, 32), (1, 37, 19, 5, 9)])
+                                   (4, 40, 130, 288, 288), (2, 24, 64, 32, 32), (1, 37, 19, 5, 9),
+                                   # persistent kernel, several items per workgroup with ONE chunk per item (the bias /
+                                   # statistics slots rotate every barrier), full and partial chunk, 1 and 2 channel tiles
+                                   (4, 16, 64, 288, 288), (3, 8, 200, 144, 144)])
 def test_pointwise_fwd_split(shape):
     both(case_pw_split, *shape)
     both(case_pw_split, *shape, with_part=True)
