@@ -121,15 +121,15 @@ def gen_ops():
     print("ops.npz:", len(s), "arrays")
 
 
-def summarize(store, tag, arr):
+def summarize(store, tag, arr, full_max=8192, nsample=4096):
     a = np.asarray(arr, np.float32).ravel()
     store[tag + "#l2"] = np.float64(np.sqrt((a.astype(np.float64) ** 2).sum()))
     store[tag + "#sum"] = np.float64(a.astype(np.float64).sum())
     store[tag + "#n"] = np.int64(a.size)
-    if a.size <= 8192:
+    if a.size <= full_max:
         store[tag + "#full"] = np.asarray(arr, np.float32)
     else:
-        idx = np.linspace(0, a.size - 1, 4096).astype(np.int64)
+        idx = np.linspace(0, a.size - 1, nsample).astype(np.int64)
         store[tag + "#idx"] = idx
         store[tag + "#vals"] = a[idx]
 
@@ -179,6 +179,94 @@ def gen_unet(name, n_channels, n_classes, n, h, w, loss_kind, seed):
     print(name, "loss", loss.item(), "arrays", len(s))
 
 
+class _RefVariant(torch.nn.Module):
+    """The sibling networks of /root/reference/models/unet_precip_regression_lightning.py wired from the
+    REFERENCE blocks.  The reference classes themselves are Lightning modules (`lightning` is not in this
+    image), so their constructor (:87-106 UNetDS, :168-190 UNetDSAttention4CBAMs) and forward (:108-118,
+    :192-208) are restated here line by line; every block is the reference's own."""
+
+    def __init__(self, n_channels, n_classes, kpl, cbams, rr=16):
+        super().__init__()
+        self.cbams = cbams
+        self.inc = DoubleConvDS(n_channels, 64, kernels_per_layer=kpl)
+        if cbams:
+            self.cbam1 = CBAM(64, reduction_ratio=rr)
+        self.down1 = DownDS(64, 128, kernels_per_layer=kpl)
+        if cbams:
+            self.cbam2 = CBAM(128, reduction_ratio=rr)
+        self.down2 = DownDS(128, 256, kernels_per_layer=kpl)
+        if cbams:
+            self.cbam3 = CBAM(256, reduction_ratio=rr)
+        self.down3 = DownDS(256, 512, kernels_per_layer=kpl)
+        if cbams:
+            self.cbam4 = CBAM(512, reduction_ratio=rr)
+        self.down4 = DownDS(512, 512, kernels_per_layer=kpl)
+        self.up1 = UpDS(1024, 256, True, kernels_per_layer=kpl)
+        self.up2 = UpDS(512, 128, True, kernels_per_layer=kpl)
+        self.up3 = UpDS(256, 64, True, kernels_per_layer=kpl)
+        self.up4 = UpDS(128, 64, True, kernels_per_layer=kpl)
+        self.outc = OutConv(64, n_classes)
+
+    def forward(self, x):
+        x1 = self.inc(x)
+        x2 = self.down1(x1)
+        x3 = self.down2(x2)
+        x4 = self.down3(x3)
+        x5 = self.down4(x4)
+        if self.cbams:  # :192-208: attention on the four skips, un-attended bottleneck
+            s1, s2, s3, s4 = self.cbam1(x1), self.cbam2(x2), self.cbam3(x3), self.cbam4(x4)
+        else:           # :108-118
+            s1, s2, s3, s4 = x1, x2, x3, x4
+        x = self.up1(x5, s4)
+        x = self.up2(x, s3)
+        x = self.up3(x, s2)
+        x = self.up4(x, s1)
+        return self.outc(x)
+
+
+def gen_variant(name, cbams, kpl, n_channels, n_classes, n, h, w, seed):
+    keys = oparams.unetds_keys(n_channels, n_classes, kpl, 16, cbams)
+    model = _RefVariant(n_channels, n_classes, kpl, cbams)
+    ref = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    assert ref == [(k, tuple(s)) for k, s in keys], "oracle.params.unetds_keys != reference-block state_dict"
+    load_np_state(model, oparams.fill(keys, seed))
+    model.train()
+    rng = np.random.default_rng(seed + 100)
+    u = rng.random((n, n_channels, h, w), dtype=np.float32)
+    x = np.where(u > 0.6, (u - 0.6) / 0.4, 0).astype(np.float32)
+    cot = rng.standard_normal((n, n_classes, h, w)).astype(np.float32)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    logits = model(xt)
+    (logits * torch.from_numpy(cot)).sum().backward()
+    s = {"x": x, "cot": cot, "logits": t2n(logits),
+         "meta": np.array(json.dumps(dict(n_channels=n_channels, n_classes=n_classes, n=n, h=h, w=w, kpl=kpl,
+                                          cbams=cbams, param_seed=seed)))}
+    summarize(s, "dx", t2n(xt.grad), 1024, 1024)
+    for k, p in model.named_parameters():
+        summarize(s, "grad/" + k, t2n(p.grad), 1024, 1024)
+    for k, v in model.state_dict().items():
+        if "running" in k:
+            s["after/" + k] = t2n(v)
+    # the same reference blocks in float64: these random-parameter networks amplify fp32 round-off end to
+    # end (the reference's OWN fp32 gradients are up to 3e-2 from its fp64 ones), so the parity test bounds
+    # "error against fp64" by the reference's own figure (DESIGN.md section 2) where the plain bound fails
+    m64 = _RefVariant(n_channels, n_classes, kpl, cbams)
+    load_np_state(m64, oparams.fill(keys, seed))
+    m64 = m64.double().train()
+    x64 = torch.from_numpy(x).double().requires_grad_(True)
+    (m64(x64) * torch.from_numpy(cot).double()).sum().backward()
+    worst = 0.0
+    for (k, p), (_, p64) in zip(model.named_parameters(), m64.named_parameters()):
+        g64 = p64.grad.numpy()
+        summarize(s, "grad64/" + k, g64.astype(np.float32), 1024, 1024)
+        noise = float(np.linalg.norm(t2n(p.grad).astype(np.float64) - g64) / max(np.linalg.norm(g64), 1e-30))
+        s["noise/" + k] = np.float64(noise)
+        if not (".double_conv." in k and k.endswith(("depthwise.bias", "pointwise.bias"))):  # exact-zero gradients
+            worst = max(worst, noise)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **s)
+    print(name, "arrays", len(s), "logits l2", float(np.linalg.norm(s["logits"])), "worst fp32-vs-fp64 grad", worst)
+
+
 def gen_keys():
     out = {}
     for (nc, ncl) in ((12, 1), (3, 21)):
@@ -198,3 +286,9 @@ if __name__ == "__main__":
     gen_unet("unet_12x1_n2_32", 12, 1, 2, 32, 32, "mse", 0)
     gen_unet("unet_12x1_n2_64x48", 12, 1, 2, 64, 48, "mse", 1)
     gen_unet("unet_3x21_n1_32", 3, 21, 1, 32, 32, "cot", 2)
+    # sibling networks: no attention / four CBAMs, kernels_per_layer 1, 2 and 4;
+    # 48 x 40: the width is not a multiple of 16, so UpDS has to F.pad (unet_parts_depthwise_separable.py:78-81)
+    gen_variant("unetds_k2_n2_32", 0, 2, 12, 1, 2, 32, 32, 3)
+    gen_variant("unetds_k1_n1_48x40", 0, 1, 5, 2, 1, 48, 40, 4)
+    gen_variant("unetds4cbam_k2_n2_32", 4, 2, 12, 1, 2, 32, 32, 5)
+    gen_variant("unetds4cbam_k4_n1_32", 4, 4, 3, 2, 1, 32, 32, 6)

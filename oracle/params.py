@@ -72,6 +72,27 @@ def smaat_unet_keys(n_channels, n_classes, kpl=2, rr=16):
     return k
 
 
+def unetds_keys(n_channels, n_classes, kpl=2, rr=16, cbams=0):
+    """[(name, shape)] of the sibling networks of models/unet_precip_regression_lightning.py (bilinear=True):
+    cbams = 0 -> UNetDS (:86-118), 4 -> UNetDSAttention4CBAMs (:167-208), 5 -> UNetDSAttention (:121-164)."""
+    k = []
+    double_conv_ds_keys(k, "inc", n_channels, 64, None, kpl)
+    chans = (64, 128, 256, 512, 512)
+    for lvl in range(1, 5):
+        if cbams >= lvl:
+            cbam_keys(k, f"cbam{lvl}", chans[lvl - 1], rr)
+        double_conv_ds_keys(k, f"down{lvl}.maxpool_conv.1", chans[lvl - 1], chans[lvl], None, kpl)
+    if cbams >= 5:
+        cbam_keys(k, "cbam5", 512, rr)
+    double_conv_ds_keys(k, "up1.conv", 1024, 256, 512, kpl)
+    double_conv_ds_keys(k, "up2.conv", 512, 128, 256, kpl)
+    double_conv_ds_keys(k, "up3.conv", 256, 64, 128, kpl)
+    double_conv_ds_keys(k, "up4.conv", 128, 64, 64, kpl)
+    k.append(("outc.conv.weight", (n_classes, 64, 1, 1)))
+    k.append(("outc.conv.bias", (n_classes,)))
+    return k
+
+
 def fill(keys, seed=0):
     """name -> np.ndarray (float32; int64 for num_batches_tracked)."""
     rng = np.random.default_rng(seed)

@@ -7,6 +7,7 @@ from . import _lib  # noqa: F401
 from .SmaAt_UNet import SmaAt_UNet  # noqa: F401
 from .layers import CBAM, ChannelAttention, DepthwiseSeparableConv, SpatialAttention  # noqa: F401
 from .unet_parts_depthwise_separable import DoubleConvDS, DownDS, OutConv, UpDS  # noqa: F401
+from .unet_precip_variants import UNetDS, UNetDSAttention, UNetDSAttention4CBAMs  # noqa: F401
 
 __all__ = ["SmaAt_UNet", "CBAM", "ChannelAttention", "SpatialAttention", "DepthwiseSeparableConv", "DoubleConvDS",
-           "DownDS", "UpDS", "OutConv"]
+           "DownDS", "UpDS", "OutConv", "UNetDS", "UNetDSAttention", "UNetDSAttention4CBAMs"]

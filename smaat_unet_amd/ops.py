@@ -105,9 +105,11 @@ def _split_on():
     return bool(_lib.get().smaat_split_enabled())
 
 
-# Measured per-shape policy (profiles/r1, MI355X, batch 32): the split GEMMs win where the contraction is
-# deep and the co tile wide; the shallow, plane-dominated layers stay on the fused f32-MFMA kernels
-# (they are HBM/latency bound and the fusion saves a pass over the depthwise output).
+# Measured policy (profiles/r1, MI355X, batch 32): in training every supported layer runs on the split GEMMs
+# (standalone strip depthwise kernel + persistent split GEMM; +1.7 % on the step against keeping the fused
+# f32-MFMA forward for the plane-dominated layers, which is MFMA-bound at the f32 rate).  Inference
+# (running statistics, typically batch 1) keeps the fused f32 kernel for the narrow layers: one launch
+# instead of three matters more there than the matrix rate.
 FUSE_FIRST_ACTIVATION = True  # DoubleConvDS: apply the first BatchNorm + ReLU on load instead of writing y1
 SPLIT_POLICY = os.environ.get("SMAAT_SPLIT_POLICY", "auto")  # "auto" = the measured policy; "all" = every supported shape
 
@@ -117,8 +119,10 @@ def _split_all():
     return SPLIT_POLICY == "all" or _lib.get().smaat_split_mode() == 1
 
 
-def _split_fwd_ok(k, cout):
-    return _split_on() and (_split_all() or (k >= 128 and cout >= 128))
+def _split_fwd_ok(k, cout, train=True):
+    if not _split_on():
+        return False
+    return _split_all() or train or (k >= 128 and cout >= 128)
 
 
 def _split_dgrad_ok(cout, k):
@@ -349,7 +353,7 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
     y_dw = None
     isc, ish = in_aff if in_aff is not None else (None, None)
     rs = (_dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish)
-          if _split_fwd_ok(cin * kpl, cout) else None)
+          if _split_fwd_ok(cin * kpl, cout, use_batch_stats) else None)
     if rs is not None and use_batch_stats:
         z, part, slots, y_dw = rs
         if not keep_y:
@@ -479,7 +483,7 @@ class _DSConv(torch.autograd.Function):
         w_pw = w_pw.contiguous()
         keep_y = KEEP_DEPTHWISE_OUTPUT and any(ctx.needs_input_grad[:4])
         rs = (_dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, False)
-              if _split_fwd_ok(w_pw.shape[1], w_pw.shape[0]) else None)
+              if _split_fwd_ok(w_pw.shape[1], w_pw.shape[0], any(ctx.needs_input_grad[:5])) else None)
         if rs is not None:
             r = (rs[0], None, 0, rs[3])
         else:

@@ -15,7 +15,7 @@ import torch
 import smaat_unet_amd as S
 from oracle import params as oparams
 from oracle import smaat_oracle as O
-from tests.test_host_emu import check_summary, rel
+from tests.test_host_emu import VARIANTS, check_summary, rel, run_variant
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
@@ -69,6 +69,12 @@ def run_case(ops, tag, mod, tol_out=2e-5, tol_grad=3e-4, zero_bias=True):
 ])
 def test_module_vs_reference_golden(ops, tag, ctor, zb):
     run_case(ops, tag, ctor(), zero_bias=zb)
+
+
+@pytest.mark.parametrize("name", VARIANTS)
+def test_sibling_networks_vs_reference_golden(golden_dir, name):
+    """UNetDS / UNetDSAttention4CBAMs, kernels_per_layer 1, 2, 4, a size that needs the UpDS padding"""
+    run_variant(golden_dir, name, DEV)
 
 
 def _load_model(meta):

@@ -142,6 +142,65 @@ def test_unet(golden_dir, name, policy, monkeypatch):
     assert int(sd["inc.double_conv.1.num_batches_tracked"]) == 1
 
 
+VARIANTS = ["unetds_k2_n2_32", "unetds_k1_n1_48x40", "unetds4cbam_k2_n2_32", "unetds4cbam_k4_n1_32"]
+
+
+def run_variant(golden_dir, name, dev="cpu", hooked=False):
+    """sibling networks (reference models/unet_precip_regression_lightning.py:86-118, :167-208) against the
+    goldens produced from the reference's own blocks (oracle/gen_golden.py gen_variant)."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    meta = json.loads(str(g["meta"]))
+    cls = {0: S.UNetDS, 4: S.UNetDSAttention4CBAMs}[meta["cbams"]]
+    model = cls(n_channels=meta["n_channels"], n_classes=meta["n_classes"], kernels_per_layer=meta["kpl"])
+    P = oparams.fill(oparams.unetds_keys(meta["n_channels"], meta["n_classes"], meta["kpl"], 16, meta["cbams"]),
+                     meta["param_seed"])
+    assert list(model.state_dict().keys()) == list(P.keys())
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in P.items()})
+    model.to(dev).train()
+    seen = []
+    if hooked:  # a hook on a skip-path submodule selects the module-by-module wiring
+        model.down2.register_forward_hook(lambda m, i, o: seen.append(1))
+    x = torch.from_numpy(g["x"]).to(dev).requires_grad_(True)
+    logits = model(x)
+    assert bool(seen) == hooked
+    assert rel(logits.detach().cpu().numpy(), g["logits"]) < 1e-4
+    (logits * torch.from_numpy(g["cot"]).to(dev)).sum().backward()
+    for k, p in model.named_parameters():
+        if ".double_conv." in k and (k.endswith("depthwise.bias") or k.endswith("pointwise.bias")):
+            continue
+        gk = p.grad.cpu().numpy()
+        e32 = check_summary(g, "grad/" + k, gk)
+        if e32 >= 2e-2:  # ill-conditioned tensor: no worse than 2x the reference's own fp32 error against fp64
+            e64 = check_summary(g, "grad64/" + k, gk)
+            assert e64 <= max(2.0 * float(g["noise/" + k]), 5e-3), (k, e32, e64, float(g["noise/" + k]))
+    assert check_summary(g, "dx", x.grad.cpu().numpy()) < 2e-2
+    sd = model.state_dict()
+    for k in g.files:
+        if k.startswith("after/"):
+            assert rel(sd[k[6:]].cpu().numpy(), g[k]) < 1e-4, k
+
+
+@pytest.mark.parametrize("name", VARIANTS)
+def test_sibling_networks(golden_dir, name):
+    run_variant(golden_dir, name)
+
+
+def test_sibling_network_modular_wiring(golden_dir):
+    run_variant(golden_dir, "unetds4cbam_k2_n2_32", hooked=True)
+
+
+def test_sibling_network_hparams_constructor():
+    import argparse
+    hp = argparse.Namespace(n_channels=3, n_classes=2, bilinear=True, kernels_per_layer=1, reduction_ratio=8,
+                            learning_rate=1e-3)  # extra Lightning fields are ignored
+    m = S.UNetDSAttention(hparams=hp)
+    assert m.n_channels == 3 and m.n_classes == 2 and m.cbam1.channel_att.MLP[1].out_features == 8
+    assert len(S.UNetDS(hparams=vars(hp)).state_dict()) == len(S.UNetDS(n_channels=3, n_classes=2,
+                                                                          kernels_per_layer=1).state_dict())
+    with pytest.raises(TypeError):
+        S.UNetDS(n_chanels=3)
+
+
 def test_unet_hooked_modular_path_equals_fused(golden_dir):
     """A forward hook on a skip-path submodule switches SmaAt_UNet.forward to the module-by-module
     wiring (reference models/SmaAt_UNet.py:41-57 verbatim); both wirings must agree."""
