@@ -291,4 +291,4 @@ if __name__ == "__main__":
     gen_variant("unetds_k2_n2_32", 0, 2, 12, 1, 2, 32, 32, 3)
     gen_variant("unetds_k1_n1_48x40", 0, 1, 5, 2, 1, 48, 40, 4)
     gen_variant("unetds4cbam_k2_n2_32", 4, 2, 12, 1, 2, 32, 32, 5)
-    gen_variant("unetds4cbam_k4_n1_32", 4, 4, 3, 2, 1, 32, 32, 6)
+    gen_variant("unetds_k4_n1_32", 0, 4, 3, 2, 1, 32, 32, 6)
