@@ -257,6 +257,57 @@ def test_eval_mode_matches_oracle(ops):
     assert rel(y, h) < 1e-5
 
 
+def _recorded_calls(fn):
+    """run fn() with every entry point of the installed (emulated) library wrapped; returns name -> calls"""
+    from smaat_unet_amd import _lib
+    lib = _lib.get()
+    calls = {}
+    names = [n for n in dir(lib) if n.startswith("smaat_")]
+    orig = {n: getattr(lib, n) for n in names}
+
+    def wrap(n, f):
+        def w(*a):
+            calls[n] = calls.get(n, 0) + 1
+            return f(*a)
+        return w
+    for n in names:
+        setattr(lib, n, wrap(n, orig[n]))
+    try:
+        fn()
+    finally:
+        for n in names:
+            try:
+                delattr(lib, n)  # instance attribute shadowing the class method
+            except AttributeError:
+                pass
+    return calls
+
+
+def test_matrix_path_policy_training_vs_inference():
+    """training runs every supported layer on the split GEMMs (standalone depthwise kernel +
+    smaat_pointwise_fwd_split); inference keeps the fused f32 kernel for the narrow layers."""
+    from smaat_unet_amd import ops as _ops
+    assert _ops.SPLIT_POLICY == "auto"
+    mod = S.DoubleConvDS(8, 16, kernels_per_layer=2)  # K = 16 / 32, Cout = 16: "narrow"
+    x = torch.randn(2, 8, 8, 8)
+    mod.train()
+    c = _recorded_calls(lambda: mod(x.clone().requires_grad_(True)).sum().backward())
+    assert c.get("smaat_dw3x3_fwd", 0) == 2 and c.get("smaat_pointwise_fwd_split", 0) >= 2, c
+    assert c.get("smaat_dsconv_fwd", 0) == 0, c
+    mod.eval()
+    with torch.no_grad():
+        c = _recorded_calls(lambda: mod(x))
+    assert c.get("smaat_dsconv_fwd", 0) == 2 and c.get("smaat_pointwise_fwd_split", 0) == 0, c
+    wide = S.DoubleConvDS(64, 128, kernels_per_layer=2).eval()  # K = 128 / 256, Cout = 128: split also at inference
+    with torch.no_grad():
+        c = _recorded_calls(lambda: wide(torch.randn(1, 64, 8, 8)))
+    assert c.get("smaat_pointwise_fwd_split", 0) == 2, c
+    # a width the strip depthwise kernel does not take (W % 4 != 0) falls back to the fused kernel
+    mod.train()
+    c = _recorded_calls(lambda: mod(torch.randn(2, 8, 6, 6)))
+    assert c.get("smaat_dsconv_fwd", 0) == 2, c
+
+
 def test_no_cpu_fallback():
     emu_backend.uninstall()
     m = S.OutConv(4, 2)
