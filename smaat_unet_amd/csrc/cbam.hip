@@ -438,7 +438,6 @@ __global__ __launch_bounds__(64) void k_cbam_bwd_main_v4(const float* __restrict
     const int pp = valid ? p : 0;
     const float* xp = x + (long)n * x_bs + pp;
     const float* gp = dout + (long)n * dout_bs + pp;
-    float* dp = dx + (long)n * dx_bs + pp;
     const float* sp = s + (long)n * C;
     const float4 g = *(const float4*)(gate + (long)n * P + pp);
     const float4 mxv = *(const float4*)(maps + ((long)n * 2 + 1) * P + pp);
@@ -449,24 +448,50 @@ __global__ __launch_bounds__(64) void k_cbam_bwd_main_v4(const float* __restrict
     (void)ic;
     bool f0 = false, f1 = false, f2 = false, f3 = false;
     float* dsrow = dspart + ((long)blockIdx.x * N + n) * C;
-#pragma unroll 2
+    // The channel loop is a dependent chain per iteration (load x, dOut -> arithmetic -> store dX -> wave sum),
+    // so it is software-pipelined by hand: the loads of channel c+1 are issued before channel c is processed,
+    // and the body has no branches (the first-maximum rule as selects; the stores through buffer descriptors
+    // whose range check drops the lanes that must not write) -- a divergent branch or a load between the
+    // stores makes hipcc drain the prefetch with vmcnt(0).
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(dx + (long)n * dx_bs, 0, C * P * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(dsrow, 0, C * 4, 0x00020000);
+    const unsigned dvo = valid ? (unsigned)pp * 4u : 0x80000000u;
+    const unsigned svo = threadIdx.x == 63 ? 0u : 0x80000000u;
+    float4 xn = *(const float4*)(xp);
+    float4 gn = *(const float4*)(gp);
+    float sn = sp[0];
     for (int c = 0; c < C; ++c) {
-        const float4 xv = *(const float4*)(xp + (long)c * P);
-        const float4 gv = *(const float4*)(gp + (long)c * P);
-        const float sv = sp[c];
+        const float4 xv = xn, gv = gn;
+        const float sv = sn;
+        const int cn = c + 1 < C ? c + 1 : c;
+        xn = *(const float4*)(xp + (long)cn * P);
+        gn = *(const float4*)(gp + (long)cn * P);
+        sn = sp[cn];
         float4 dxs;
         dxs.x = fmaf(gv.x, g.x, da.x);
         dxs.y = fmaf(gv.y, g.y, da.y);
         dxs.z = fmaf(gv.z, g.z, da.z);
         dxs.w = fmaf(gv.w, g.w, da.w);
-        if (!f0 && xv.x * sv == mxv.x) { dxs.x += dm.x; f0 = true; }
-        if (!f1 && xv.y * sv == mxv.y) { dxs.y += dm.y; f1 = true; }
-        if (!f2 && xv.z * sv == mxv.z) { dxs.z += dm.z; f2 = true; }
-        if (!f3 && xv.w * sv == mxv.w) { dxs.w += dm.w; f3 = true; }
-        if (valid) *(float4*)(dp + (long)c * P) = make_float4(dxs.x * sv, dxs.y * sv, dxs.z * sv, dxs.w * sv);
+        const bool h0 = !f0 && xv.x * sv == mxv.x, h1 = !f1 && xv.y * sv == mxv.y;
+        const bool h2 = !f2 && xv.z * sv == mxv.z, h3 = !f3 && xv.w * sv == mxv.w;
+        dxs.x += h0 ? dm.x : 0.f;
+        dxs.y += h1 ? dm.y : 0.f;
+        dxs.z += h2 ? dm.z : 0.f;
+        dxs.w += h3 ? dm.w : 0.f;
+        f0 |= h0;
+        f1 |= h1;
+        f2 |= h2;
+        f3 |= h3;
+        u4 o;
+        o.x = __builtin_bit_cast(unsigned, dxs.x * sv);
+        o.y = __builtin_bit_cast(unsigned, dxs.y * sv);
+        o.z = __builtin_bit_cast(unsigned, dxs.z * sv);
+        o.w = __builtin_bit_cast(unsigned, dxs.w * sv);
+        __builtin_amdgcn_raw_buffer_store_b128(o, drs, dvo + (unsigned)c * (unsigned)P * 4u, 0, 0);
         float r = valid ? (dxs.x * xv.x + dxs.y * xv.y) + (dxs.z * xv.z + dxs.w * xv.w) : 0.f;
         r = wave_sum_l63(r);
-        if (threadIdx.x == 63) dsrow[c] = r;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r), srs, svo + (unsigned)c * 4u, 0, 0);
     }
 }
 
@@ -620,7 +645,8 @@ int launch_cbam_bwd_main(const float* dout, long dout_bs, const float* x, long x
     const bool v4 = ((P & 3) == 0) && ((x_bs & 3) == 0) && ((dout_bs & 3) == 0) && ((dx_bs & 3) == 0) &&
                     ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)dout) & 15) == 0) &&
                     ((((uintptr_t)dx) & 15) == 0) && ((((uintptr_t)gate) & 15) == 0) &&
-                    ((((uintptr_t)maps) & 15) == 0) && ((((uintptr_t)dmaps) & 15) == 0);
+                    ((((uintptr_t)maps) & 15) == 0) && ((((uintptr_t)dmaps) & 15) == 0) &&
+                    ((long)C * P * 4 < (1L << 31));  // dX goes through a 32-bit buffer offset (bit 31 = dropped)
     if (v4) {
         hipLaunchKernelGGL(k_cbam_bwd_main_v4, dim3(cdivc(P, 256), N), dim3(64), 0, st, dout, dout_bs, x, x_bs, s, gate,
                            maps, dmaps, C, P, dx, dx_bs, dspart);
