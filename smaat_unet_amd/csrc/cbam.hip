@@ -22,13 +22,40 @@ __global__ __launch_bounds__(256) void k_cbam_chpool(const float* __restrict__ x
     const float* xp = x + (long)n * x_bs + (long)c * P;
     float s = 0.f, m = -INFINITY;
     int mi = 0x7fffffff;
-    for (int p = threadIdx.x; p < P; p += 256) {
-        const float v = xp[p];
+    // branch-free running maximum (strictly greater: the first index wins, positions are visited in increasing
+    // order), 16-byte loads, four of them in flight per thread: with a divergent `if (v > m)` around the update
+    // hipcc waits for every load before issuing the next one
+    auto upd = [&](float v, int p) {
         s += v;
-        if (v > m) {
-            m = v;
-            mi = p;
+        const bool gt = v > m;
+        m = gt ? v : m;
+        mi = gt ? p : mi;
+    };
+    if ((P & 3) == 0 && (x_bs & 3) == 0 && ((((uintptr_t)x) & 15) == 0)) {
+        const int P4 = P >> 2;
+        int q = threadIdx.x;
+        for (; q + 768 < P4; q += 1024) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(xp + 4 * (q + 256 * u));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = 4 * (q + 256 * u);
+                upd(v[u].x, p);
+                upd(v[u].y, p + 1);
+                upd(v[u].z, p + 2);
+                upd(v[u].w, p + 3);
+            }
         }
+        for (; q < P4; q += 256) {
+            const float4 v = *(const float4*)(xp + 4 * q);
+            upd(v.x, 4 * q);
+            upd(v.y, 4 * q + 1);
+            upd(v.z, 4 * q + 2);
+            upd(v.w, 4 * q + 3);
+        }
+    } else {
+        for (int p = threadIdx.x; p < P; p += 256) upd(xp[p], p);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float ws = wave_sum_all(s);
