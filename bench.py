@@ -199,7 +199,22 @@ def main():
             kernels[name] = e
         split = bool(_lib.get().smaat_split_enabled())
 
-        def klass(names, bound, peak, unit, mult=1.0, what=""):
+        def pmc_traffic(kernel_prefixes):
+            """HBM bytes per launch of a kernel class from the committed rocprofv3 counter passes
+            (profiles/hbm_traffic.json, scripts/make_traffic_json.py): (2 x FETCH_SIZE + WRITE_SIZE) / dispatches
+            over the kernels whose name starts with one of the prefixes; None when there is no such record."""
+            try:
+                rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))["kernels"]
+                tot, nd = 0.0, 0
+                for kname, v in rec.items():
+                    if any(kname.startswith(pfx) for pfx in kernel_prefixes):
+                        tot += float(v["fetch_bytes"]) + float(v["write_bytes"])
+                        nd += int(v["dispatches"])
+                return round(tot / nd) if nd else None
+            except Exception:  # noqa: BLE001  (a missing or malformed record must not break the bench line)
+                return None
+
+        def klass(names, bound, peak, unit, mult=1.0, what="", pmc=()):
             names = [k for k in names if k in summ]
             if not names:
                 return None
@@ -211,7 +226,8 @@ def main():
                 alg = sum(summ[k]["bytes"] for k in names) / 2.0 / (ms * 1e-3) / 1e9
             ach = alg * mult
             return {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
-                    "traffic": None, "kernel": what, "entry_points": names, "launches_per_step": calls,
+                    "traffic": pmc_traffic(pmc) if pmc else None, "kernel": what, "entry_points": names,
+                    "launches_per_step": calls,
                     "avg_launch_ms": round(ms / max(calls, 1), 4), "ms_per_step": round(ms, 3),
                     "algorithmic": round(alg, 2)}
 
@@ -219,16 +235,18 @@ def main():
         # (= 6 x the algorithmic f32 rate in `algorithmic`), priced against the dense bf16 peak.
         classes = [
             klass(["smaat_pointwise_fwd_split"], "mfma", PEAK_BF16_MFMA_TFLOPS, "TFLOP/s", 6.0,
-                  "k_pw_split_p: persistent wave-specialised GEMM (v_mfma_f32_32x32x16_bf16 x6 per f32 product, exact 3-term operand split)"),
+                  "k_pw_split_p: persistent wave-specialised GEMM (v_mfma_f32_32x32x16_bf16 x6 per f32 product, exact 3-term operand split)",
+                  pmc=("k_pw_split",)),
             klass(["smaat_pointwise_wgrad"], "mfma", PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
-                  6.0 if split else 1.0, "k_wgrad_split (bf16 x6)" if split else "k_wgrad2 (v_mfma_f32_32x32x2_f32)"),
+                  6.0 if split else 1.0, "k_wgrad_split (bf16 x6)" if split else "k_wgrad2 (v_mfma_f32_32x32x2_f32)",
+                  pmc=("k_wgrad_split",) if split else ("k_wgrad2",)),
             klass(["smaat_dsconv_fwd", "smaat_pointwise_fwd"], "mfma", PEAK_F32_MFMA_TFLOPS, "TFLOP/s", 1.0,
                   "k_pwgemm_ws / k_dsconv_strip / k_pwgemm (v_mfma_f32_32x32x2_f32): fused depthwise->pointwise "
-                  "forward and data gradient of the plane-dominated layers"),
-            klass(["smaat_dw3x3_bwd"], "hbm", PEAK_HBM_GBS, "GB/s", 1.0, "k_dw3x3_bwd_strip"),
-            klass(["smaat_dw3x3_fwd"], "hbm", PEAK_HBM_GBS, "GB/s", 1.0, "k_dw3x3_fwd_strip"),
+                  "forward and data gradient of the plane-dominated layers", pmc=("k_pwgemm", "k_dsconv_strip")),
+            klass(["smaat_dw3x3_bwd"], "hbm", PEAK_HBM_GBS, "GB/s", 1.0, "k_dw3x3_bwd_strip", pmc=("k_dw3x3_bwd",)),
+            klass(["smaat_dw3x3_fwd"], "hbm", PEAK_HBM_GBS, "GB/s", 1.0, "k_dw3x3_fwd_strip", pmc=("k_dw3x3_fwd",)),
             klass(["smaat_bn_bwd_apply", "smaat_bn_bwd_reduce", "smaat_affine_act"], "hbm", PEAK_HBM_GBS, "GB/s", 1.0,
-                  "BatchNorm/ReLU streaming kernels"),
+                  "BatchNorm/ReLU streaming kernels", pmc=("k_bn_bwd_apply", "k_bn_bwd_reduce", "k_affine_act")),
         ]
         classes = [c for c in classes if c]
         classes.sort(key=lambda c: -c["ms_per_step"])
