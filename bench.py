@@ -129,11 +129,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SMAAT_BENCH_BACKEND=gloo (testing only): lets several ranks share one GPU to exercise the multi-rank control
+    # flow on a single-GPU box; the driver's runs use nccl (= RCCL), one rank per GPU
+    backend = os.environ.get("SMAAT_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import smaat_unet_amd as S
     from smaat_unet_amd import _lib
@@ -150,12 +157,12 @@ def main():
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, foreach=True)
     x, y = synthetic_batch(args.batch, args.size, args.size, 1234 + rank, dev)
 
-    def step():
+    def step(exchange=True):
         out = model(x)
         loss = torch.nn.functional.mse_loss(out.squeeze(1), y, reduction="sum") / y.size(0)
         opt.zero_grad(set_to_none=True)
         loss.backward()
-        if world > 1:
+        if world > 1 and exchange:
             ddp.reduce()
         opt.step()
         return loss
@@ -186,7 +193,7 @@ def main():
     if rank == 0 and not args.no_profile:
         prof = _lib.Profiler()
         for _ in range(2):
-            step()
+            step(exchange=False)  # rank 0 only: per-kernel timing of one replica, no collective in here
         summ = prof.summary()
         prof.close()
         kernels = {}
@@ -311,6 +318,7 @@ def main():
         }
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()  # the other ranks wait for rank 0's per-kernel / latency passes before tearing down
         dist.destroy_process_group()
 
 
