@@ -1,5 +1,12 @@
-"""Drop-in for /root/reference/models/SmaAt_UNet.py: same constructor, attributes,
-submodule names (=> identical 214 state_dict keys) and forward wiring (:41-57)."""
+"""SmaAt-UNet and its depthwise-separable siblings on the MI355X blocks.
+
+`SmaAt_UNet` is the drop-in for /root/reference/models/SmaAt_UNet.py (constructor :8-15, attributes :17-20,
+submodule names :23-39 => the same 214 `state_dict` keys in the same order, wiring :41-57).  The network is
+described by a small table instead of one statement per layer: an encoder of four `DownDS` levels behind `inc`,
+`cbam_levels` attention blocks (5: every level and the bottleneck, 4: the skips only, 0: none) and a decoder of
+four `UpDS` levels.  Submodules are registered in the reference's order (inc, cbam1, down1, cbam2, ... , up1..4,
+outc), which is what fixes the `state_dict` key order.
+"""
 from __future__ import annotations
 
 from torch import nn
@@ -8,82 +15,87 @@ from .layers import CBAM
 from .unet_parts import OutConv
 from .unet_parts_depthwise_separable import DoubleConvDS, DownDS, UpDS
 
+_ENCODER_WIDTHS = (64, 128, 256, 512)
 
-class SmaAt_UNet(nn.Module):
-    def __init__(
-        self,
-        n_channels,
-        n_classes,
-        kernels_per_layer=2,
-        bilinear=True,
-        reduction_ratio=16,
-    ):
+
+class UNetDSFamily(nn.Module):
+    """inc -> 4 x (CBAM on the skip?, DownDS) -> (CBAM on the bottleneck?) -> 4 x UpDS -> OutConv"""
+
+    def __init__(self, n_channels, n_classes, kernels_per_layer, bilinear, reduction_ratio, cbam_levels):
         super().__init__()
-        self.n_channels = n_channels
-        self.n_classes = n_classes
-        self.bilinear = bilinear
+        if cbam_levels not in (0, 4, 5):
+            raise ValueError("cbam_levels must be 0, 4 or 5")
+        self.n_channels, self.n_classes, self.bilinear = n_channels, n_classes, bilinear
+        self.cbam_levels = cbam_levels
+        shrink = 2 if bilinear else 1
+        widths = _ENCODER_WIDTHS + (1024 // shrink,)
+        kw = dict(kernels_per_layer=kernels_per_layer)
+        self.inc = DoubleConvDS(n_channels, widths[0], **kw)
+        for lvl in range(1, 5):
+            if cbam_levels >= lvl:
+                setattr(self, f"cbam{lvl}", CBAM(widths[lvl - 1], reduction_ratio=reduction_ratio))
+            setattr(self, f"down{lvl}", DownDS(widths[lvl - 1], widths[lvl], **kw))
+        if cbam_levels == 5:
+            self.cbam5 = CBAM(widths[4], reduction_ratio=reduction_ratio)
+        cat_channels = 1024
+        for i in range(1, 5):  # up_i takes the concatenation [skip, upsampled] of cat_channels channels
+            out = 64 if i == 4 else cat_channels // 2 // shrink
+            setattr(self, f"up{i}", UpDS(cat_channels, out, bilinear, **kw))
+            cat_channels //= 2
+        self.outc = OutConv(64, n_classes)
 
-        self.inc = DoubleConvDS(self.n_channels, 64, kernels_per_layer=kernels_per_layer)
-        self.cbam1 = CBAM(64, reduction_ratio=reduction_ratio)
-        self.down1 = DownDS(64, 128, kernels_per_layer=kernels_per_layer)
-        self.cbam2 = CBAM(128, reduction_ratio=reduction_ratio)
-        self.down2 = DownDS(128, 256, kernels_per_layer=kernels_per_layer)
-        self.cbam3 = CBAM(256, reduction_ratio=reduction_ratio)
-        self.down3 = DownDS(256, 512, kernels_per_layer=kernels_per_layer)
-        self.cbam4 = CBAM(512, reduction_ratio=reduction_ratio)
-        factor = 2 if self.bilinear else 1
-        self.down4 = DownDS(512, 1024 // factor, kernels_per_layer=kernels_per_layer)
-        self.cbam5 = CBAM(1024 // factor, reduction_ratio=reduction_ratio)
-        self.up1 = UpDS(1024, 512 // factor, self.bilinear, kernels_per_layer=kernels_per_layer)
-        self.up2 = UpDS(512, 256 // factor, self.bilinear, kernels_per_layer=kernels_per_layer)
-        self.up3 = UpDS(256, 128 // factor, self.bilinear, kernels_per_layer=kernels_per_layer)
-        self.up4 = UpDS(128, 64, self.bilinear, kernels_per_layer=kernels_per_layer)
-
-        self.outc = OutConv(64, self.n_classes)
+    # -- pieces ------------------------------------------------------------------------------------------
+    def _levels(self):
+        downs = [getattr(self, f"down{l}") for l in range(1, 5)]
+        ups = [getattr(self, f"up{i}") for i in range(1, 5)]
+        cbams = [getattr(self, f"cbam{l}", None) for l in range(1, 6)]
+        return downs, ups, cbams
 
     def _fusable(self):
         """the fused skip wiring bypasses the `forward` of cbamN / downN.maxpool / upN: keep the
         module-by-module path whenever a user hooked one of them (or uses an exotic configuration)."""
-        mods = [self.cbam1, self.cbam2, self.cbam3, self.cbam4, self.down1, self.down2, self.down3, self.down4,
-                self.up1, self.up2, self.up3, self.up4]
-        for top in mods:
+        if not self.bilinear or self.cbam_levels < 4:
+            return False
+        downs, ups, cbams = self._levels()
+        for top in downs + ups + [c for c in cbams[:4] if c is not None]:
             for mm in top.modules():
                 if mm._forward_hooks or mm._forward_pre_hooks or mm._backward_hooks:
                     return False
-        return self.bilinear
+        return True
 
     def forward(self, x):
-        # NB (reference :41-57): the encoder continues from the UN-attended x_i; the CBAM
+        # NB (reference SmaAt_UNet.py:41-57): the encoder continues from the UN-attended x_i; the CBAM
         # outputs feed only the skip connections and the bottleneck.
         if not self._fusable():
             return self._forward_modular(x)
-        ups = (self.up4, self.up3, self.up2, self.up1)
+        downs, ups, cbams = self._levels()
         cats = []
         h = self.inc(x)
-        for cbam, down, up in zip((self.cbam1, self.cbam2, self.cbam3, self.cbam4),
-                                  (self.down1, self.down2, self.down3, self.down4), ups):
+        for lvl in range(4):
+            up = ups[3 - lvl]  # the decoder level that consumes this skip
             c_extra = up.conv.double_conv[0].depthwise.in_channels - h.shape[1]
-            cat, pooled = cbam.forward_pool_cat(h, c_extra)   # skip written straight into the decoder's cat buffer
+            cat, pooled = cbams[lvl].forward_pool_cat(h, c_extra)  # skip written straight into the decoder's cat buffer
             cats.append(cat)
-            h = down.maxpool_conv[1](pooled)
-        h = self.cbam5(h)
-        for up, cat in zip(reversed(ups), reversed(cats)):
+            h = downs[lvl].maxpool_conv[1](pooled)
+        if cbams[4] is not None:
+            h = cbams[4](h)
+        for up, cat in zip(ups, reversed(cats)):
             h = up.forward_into(h, cat)
         return self.outc(h)
 
     def _forward_modular(self, x):
-        x1 = self.inc(x)
-        x1Att = self.cbam1(x1)
-        x2 = self.down1(x1)
-        x2Att = self.cbam2(x2)
-        x3 = self.down2(x2)
-        x3Att = self.cbam3(x3)
-        x4 = self.down3(x3)
-        x4Att = self.cbam4(x4)
-        x5 = self.down4(x4)
-        x5Att = self.cbam5(x5)
-        x = self.up1(x5Att, x4Att)
-        x = self.up2(x, x3Att)
-        x = self.up3(x, x2Att)
-        x = self.up4(x, x1Att)
-        return self.outc(x)
+        """module-by-module wiring (what the reference spells out statement by statement)"""
+        downs, ups, cbams = self._levels()
+        feats = [self.inc(x)]
+        for down in downs:
+            feats.append(down(feats[-1]))
+        att = [f if c is None else c(f) for f, c in zip(feats, cbams)]
+        h = att[4]
+        for up, skip in zip(ups, reversed(att[:4])):
+            h = up(h, skip)
+        return self.outc(h)
+
+
+class SmaAt_UNet(UNetDSFamily):
+    def __init__(self, n_channels, n_classes, kernels_per_layer=2, bilinear=True, reduction_ratio=16):
+        super().__init__(n_channels, n_classes, kernels_per_layer, bilinear, reduction_ratio, cbam_levels=5)

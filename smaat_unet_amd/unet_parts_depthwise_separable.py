@@ -13,28 +13,12 @@ class DoubleConvDS(nn.Module):
 
     def __init__(self, in_channels, out_channels, mid_channels=None, kernels_per_layer=1):
         super().__init__()
-        if not mid_channels:
-            mid_channels = out_channels
-        self.double_conv = nn.Sequential(
-            DepthwiseSeparableConv(
-                in_channels,
-                mid_channels,
-                kernel_size=3,
-                kernels_per_layer=kernels_per_layer,
-                padding=1,
-            ),
-            nn.BatchNorm2d(mid_channels),
-            nn.ReLU(inplace=True),
-            DepthwiseSeparableConv(
-                mid_channels,
-                out_channels,
-                kernel_size=3,
-                kernels_per_layer=kernels_per_layer,
-                padding=1,
-            ),
-            nn.BatchNorm2d(out_channels),
-            nn.ReLU(inplace=True),
-        )
+        widths = (in_channels, mid_channels or out_channels, out_channels)
+        stages = []
+        for cin, cout in zip(widths[:-1], widths[1:]):  # Sequential indices 0,1,2 / 3,4,5 as in the reference
+            stages += [DepthwiseSeparableConv(cin, cout, kernel_size=3, padding=1, kernels_per_layer=kernels_per_layer),
+                       nn.BatchNorm2d(cout), nn.ReLU(inplace=True)]
+        self.double_conv = nn.Sequential(*stages)
 
     @staticmethod
     def _half(x, conv: DepthwiseSeparableConv, bn: nn.BatchNorm2d):
@@ -68,10 +52,8 @@ class DownDS(nn.Module):
 
     def __init__(self, in_channels, out_channels, kernels_per_layer=1):
         super().__init__()
-        self.maxpool_conv = nn.Sequential(
-            _MaxPool2(2),
-            DoubleConvDS(in_channels, out_channels, kernels_per_layer=kernels_per_layer),
-        )
+        conv = DoubleConvDS(in_channels, out_channels, kernels_per_layer=kernels_per_layer)
+        self.maxpool_conv = nn.Sequential(_MaxPool2(2), conv)
 
     def forward(self, x):
         return self.maxpool_conv(x)
@@ -83,16 +65,13 @@ class UpDS(nn.Module):
 
     def __init__(self, in_channels, out_channels, bilinear=True, kernels_per_layer=1):
         super().__init__()
-        if bilinear:
-            self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
-            self.conv = DoubleConvDS(
-                in_channels,
-                out_channels,
-                in_channels // 2,
-                kernels_per_layer=kernels_per_layer,
-            )
-        else:
+        if not bilinear:
             raise NotImplementedError("UpDS(bilinear=False) (ConvTranspose2d) is outside the accelerated hot path")
+        # `up` is kept as a (parameter-free) submodule for interface parity; the upsampling itself runs fused with
+        # the pad + concatenation in ops.upsample_cat / ops.upsample_into
+        self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+        self.conv = DoubleConvDS(in_channels, out_channels, mid_channels=in_channels // 2,
+                                 kernels_per_layer=kernels_per_layer)
 
     def forward(self, x1, x2):
         return self.conv(ops.upsample_cat(x1, x2))
