@@ -1,0 +1,29 @@
+"""CPU (hipcc cross-compiles gfx950 without a GPU): the generated ISA of the bf16-split GEMM family must keep
+the two properties that were worth 30-40 % of those kernels:
+  * no loop of the producer waves drains the vector-memory counter (s_waitcnt vmcnt(0)) while loads are in
+    flight -- the prefetch depth is what the explicit counted waits say, not one chunk;
+  * the store tail of a tile is not serialised (no s_waitcnt vmcnt(0) between consecutive stores).
+Uses scripts/asm_lint.py, the same check that produced profiles/r1/r1s/asm_lint.txt."""
+import importlib.util
+import os
+import shutil
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc not available")
+def test_split_gemm_isa_has_no_drained_loops_or_serialised_stores():
+    spec = importlib.util.spec_from_file_location("asm_lint", os.path.join(ROOT, "scripts", "asm_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    rows = lint.analyse(lint.compile_asm(os.path.join(ROOT, "smaat_unet_amd", "csrc", "splitmma.hip")))
+    seen = 0
+    for fn, nloops, drains, nstore, serial in rows:
+        if "k_pw_split_p" in fn or "k_wgrad_split" in fn:
+            seen += 1
+            assert drains == 0, (fn, "a producer/consumer loop waits with vmcnt(0) with < 3 loads in flight")
+            assert serial <= 2, (fn, f"{serial}/{nstore} stores follow an s_waitcnt vmcnt(0)")
+    assert seen >= 8  # every instantiation of the two kernels was inspected
