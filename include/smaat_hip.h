@@ -186,6 +186,20 @@ int smaat_dw3x3_fwd(const float* x, long x_bs, const float* in_scale, const floa
 int smaat_pointwise_fwd_split(const float* x, long x_bs, const void* planes, const float* bias, float* out,
                               long out_bs, float* part, int N, int Cin, int M, int H, int W, void* stream);
 
+/* ---- on-device PrecipitationMetrics.update ---------------------------------------------
+ * replaces metric/precipitation_metrics.py:37-95 (called every train/val/test step, models/regression_lightning.py:
+ * 75,86,94): NaN check, sum (p-t)^2 / batch, sum (p*f - t*f)^2 / batch, and the 4-bin confusion counts of
+ * (x * f * 12 > threshold), accumulated INTO the persistent state without a host synchronisation:
+ *   state_f64[2] = { total_loss, total_loss_denorm }
+ *   state_i64[7] = { batches skipped because they contained a NaN, tn, fp, fn, tp, total_samples, total_pixels }
+ * preds / target: n contiguous floats; batch = target.size(0); denormalize = 0 leaves the factor out (:77-78).
+ * ws: smaat_precip_metrics_ws_bytes(n) bytes, 8-byte aligned.  A batch with a NaN changes only state_i64[0].
+ */
+int smaat_precip_metrics_ws_bytes(long n);
+int smaat_precip_metrics_update(const float* preds, const float* target, long n, int batch, float factor,
+                                float threshold, int denormalize, void* ws, double* state_f64, long long* state_i64,
+                                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

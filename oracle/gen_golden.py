@@ -267,6 +267,57 @@ def gen_variant(name, cbams, kpl, n_channels, n_classes, n, h, w, seed):
     print(name, "arrays", len(s), "logits l2", float(np.linalg.norm(s["logits"])), "worst fp32-vs-fp64 grad", worst)
 
 
+def gen_metrics():
+    """tests/golden/precip_metrics.npz from the reference's own PrecipitationMetrics
+    (/root/reference/metric/precipitation_metrics.py).  `torchmetrics` is not installed; the class only uses
+    Metric.__init__ and Metric.add_state, so a ten-line stand-in for that base class is enough to import and run
+    the reference code itself."""
+    import types
+    tm = types.ModuleType("torchmetrics")
+
+    class Metric:  # stand-in for torchmetrics.Metric: stores the states as attributes
+        def __init__(self, dist_sync_on_step=False):
+            self._defaults = {}
+
+        def add_state(self, name, default, dist_reduce_fx=None):
+            self._defaults[name] = default.clone()
+            setattr(self, name, default.clone())
+
+    tm.Metric = Metric
+    sys.modules["torchmetrics"] = tm
+    from metric.precipitation_metrics import PrecipitationMetrics as RefMetrics
+    rng = np.random.default_rng(77)
+    s = {}
+    cases = [dict(tag="default", threshold=0.5, denormalize=True, shape=(3, 1, 24, 20), squeeze=True),
+             dict(tag="nodenorm", threshold=0.5, denormalize=False, shape=(2, 1, 16, 16), squeeze=False),
+             dict(tag="thr2", threshold=2.0, denormalize=True, shape=(4, 1, 9, 11), squeeze=True)]
+    for c in cases:
+        m = RefMetrics(threshold=c["threshold"], denormalize=c["denormalize"])
+        for b in range(3):
+            n, ch, h, w = c["shape"]
+            u = rng.random((n, h, w), dtype=np.float32)
+            target = np.where(u > 0.6, (u - 0.6) * 0.02, 0).astype(np.float32)  # normalised rain rates, mostly dry
+            preds = (target + 0.002 * rng.standard_normal((n, ch, h, w)).astype(np.float32)[:, 0]).astype(np.float32)
+            preds = preds[:, None] if not c["squeeze"] else preds[:, None]  # model output [N,1,H,W]
+            if b == 1 and c["tag"] == "default":
+                bad = preds.copy()
+                bad[0, 0, 0, 0] = np.nan  # a NaN batch must be ignored (:46-48)
+                m.update(torch.from_numpy(bad), torch.from_numpy(target))
+                s[f"{c['tag']}/b{b}/preds"], s[f"{c['tag']}/b{b}/target"] = bad, target
+                continue
+            m.update(torch.from_numpy(preds), torch.from_numpy(target))
+            s[f"{c['tag']}/b{b}/preds"], s[f"{c['tag']}/b{b}/target"] = preds, target
+        out = m.compute()
+        for k, v in out.items():
+            s[f"{c['tag']}/compute/{k}"] = np.float64(float(v))
+        for k in ("total_loss", "total_loss_denorm", "total_samples", "total_pixels", "total_tp", "total_fp", "total_tn",
+                  "total_fn"):
+            s[f"{c['tag']}/state/{k}"] = np.float64(float(getattr(m, k)))
+        s[f"{c['tag']}/cfg"] = np.array(json.dumps(dict(threshold=c["threshold"], denormalize=c["denormalize"])))
+    np.savez_compressed(os.path.join(OUT, "precip_metrics.npz"), **s)
+    print("precip_metrics.npz:", len(s), "arrays")
+
+
 def gen_keys():
     out = {}
     for (nc, ncl) in ((12, 1), (3, 21)):
@@ -281,6 +332,7 @@ def gen_keys():
 
 
 if __name__ == "__main__":
+    gen_metrics()
     gen_keys()
     gen_ops()
     gen_unet("unet_12x1_n2_32", 12, 1, 2, 32, 32, "mse", 0)

@@ -533,3 +533,71 @@ def synthetic_precip(n, c, h, w, seed=1234, dtype=np.float32):
     x = np.where(u > 0.7, (u - 0.7) / 0.3 * 0.5, 0.0).astype(dtype)
     y = (rng.random((n, h, w), dtype=np.float32) * 0.3).astype(dtype)
     return x, y
+
+
+# ======================================================================================
+# PrecipitationMetrics -- restates /root/reference/metric/precipitation_metrics.py
+# ======================================================================================
+PRECIP_FACTOR = 47.83  # precipitation_metrics.py:23
+
+
+def precip_metrics_new_state():
+    """the eight add_state entries (:26-35) + a count of batches skipped because of a NaN (:46-48)"""
+    return dict(total_loss=0.0, total_loss_denorm=0.0, total_samples=0, total_pixels=0, total_tp=0, total_fp=0,
+                total_tn=0, total_fn=0, nan_batches=0)
+
+
+def precip_metrics_update(state, preds, target, threshold=0.5, denormalize=True):
+    """update() :37-95 in float32 arithmetic where the reference computes in float32"""
+    preds = np.asarray(preds, np.float32)
+    target = np.asarray(target, np.float32)
+    if np.isnan(preds).any() or np.isnan(target).any():  # :46-48
+        state["nan_batches"] += 1
+        return state
+    if preds.shape != target.shape:  # :51-58
+        if preds.ndim < target.ndim:
+            preds = preds[None]
+        elif preds.ndim > target.ndim:
+            preds = np.squeeze(preds)
+            if preds.ndim < target.ndim:
+                preds = preds[None]
+    batch = target.shape[0]
+    d = (preds - target).astype(np.float32)
+    state["total_loss"] += float(np.sum(d.astype(np.float64) ** 2)) / batch  # :62-63
+    state["total_samples"] += batch  # :64
+    state["total_pixels"] += int(target.size)  # :65
+    f = np.float32(PRECIP_FACTOR)
+    if denormalize:  # :68-74
+        pu, tu = (preds * f).astype(np.float32), (target * f).astype(np.float32)
+        dd = (pu - tu).astype(np.float32)
+        state["total_loss_denorm"] += float(np.sum(dd.astype(np.float64) ** 2)) / batch
+    else:  # :77-78
+        pu, tu = preds, target
+    pm = (pu * np.float32(12)).astype(np.float32) > np.float32(threshold)  # :79-85
+    tm = (tu * np.float32(12)).astype(np.float32) > np.float32(threshold)
+    conf = tm.reshape(-1).astype(np.int64) * 2 + pm.reshape(-1).astype(np.int64)  # :88
+    bc = np.bincount(conf, minlength=4)
+    state["total_tn"] += int(bc[0])  # :92-95
+    state["total_fp"] += int(bc[1])
+    state["total_fn"] += int(bc[2])
+    state["total_tp"] += int(bc[3])
+    return state
+
+
+def precip_metrics_compute(state, denormalize=True):
+    """compute() :97-142"""
+    nan = float("nan")
+    tp, fp, tn, fn = (state[k] for k in ("total_tp", "total_fp", "total_tn", "total_fn"))
+    mse = state["total_loss"] / state["total_samples"] if state["total_samples"] else nan
+    mse_denorm = state["total_loss_denorm"] / state["total_samples"] if denormalize and state["total_samples"] else nan
+    mse_pixel = state["total_loss_denorm"] / state["total_pixels"] if denormalize and state["total_pixels"] else nan
+    precision = tp / (tp + fp) if (tp + fp) > 0 else nan
+    recall = tp / (tp + fn) if (tp + fn) > 0 else nan
+    accuracy = (tp + tn) / (tp + tn + fp + fn) if (tp + tn + fp + fn) > 0 else nan
+    f1 = 2 * precision * recall / (precision + recall) if (precision + recall) > 0 else nan
+    csi = tp / (tp + fn + fp) if (tp + fn + fp) > 0 else nan
+    far = fp / (tp + fp) if (tp + fp) > 0 else nan
+    denom = (tp + fn) * (fn + tn) + (tp + fp) * (fp + tn)
+    hss = ((tp * tn) - (fn * fp)) / denom if denom > 0 else nan
+    return dict(mse=mse, mse_denorm=mse_denorm, mse_pixel=mse_pixel, precision=precision, recall=recall,
+                accuracy=accuracy, f1=f1, csi=csi, far=far, hss=hss)

@@ -8,6 +8,7 @@ from .SmaAt_UNet import SmaAt_UNet  # noqa: F401
 from .layers import CBAM, ChannelAttention, DepthwiseSeparableConv, SpatialAttention  # noqa: F401
 from .unet_parts_depthwise_separable import DoubleConvDS, DownDS, OutConv, UpDS  # noqa: F401
 from .unet_precip_variants import UNetDS, UNetDSAttention, UNetDSAttention4CBAMs  # noqa: F401
+from .metrics import PrecipitationMetrics  # noqa: F401
 
 __all__ = ["SmaAt_UNet", "CBAM", "ChannelAttention", "SpatialAttention", "DepthwiseSeparableConv", "DoubleConvDS",
-           "DownDS", "UpDS", "OutConv", "UNetDS", "UNetDSAttention", "UNetDSAttention4CBAMs"]
+           "DownDS", "UpDS", "OutConv", "UNetDS", "UNetDSAttention", "UNetDSAttention4CBAMs", "PrecipitationMetrics"]

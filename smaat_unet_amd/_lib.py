@@ -66,6 +66,8 @@ SIGNATURES = {
     "smaat_pw_split_num_slots": [_I, _I, _I],
     "smaat_dw3x3_fwd": [_P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P],
     "smaat_pointwise_fwd_split": [_P, _L, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P],
+    "smaat_precip_metrics_ws_bytes": [_L],
+    "smaat_precip_metrics_update": [_P, _P, _L, _I, _F, _F, _I, _P, _P, _P, _P],
 }
 
 _instance = None
@@ -181,7 +183,7 @@ class Profiler:
         self._orig = {}
         for name in SIGNATURES:
             fn = getattr(self.lib, name)
-            if name.endswith(("_slots", "_splits", "_blocks", "_version", "_rows", "_enabled", "_mode")):
+            if name.endswith(("_slots", "_splits", "_blocks", "_version", "_rows", "_enabled", "_mode", "_bytes")):
                 continue
             self._orig[name] = fn
             setattr(self.lib, name, self._wrap(name, fn))

@@ -61,6 +61,9 @@ int split_mode();
 int set_split_mode(int m);
 int launch_split_planes(const float* w, int R, int C, unsigned short* out, hipStream_t st);
 int pw_split_num_slots(int N, int P);
+long precip_metrics_ws_bytes(long n);                                                    // metrics.hip
+int launch_precip_metrics_update(const float* preds, const float* target, long n, int batch, float factor, float thr,
+                                 int denorm, void* ws, double* state_f64, long long* state_i64, hipStream_t st);
 int launch_pw_split(PwSplitArgs& a, hipStream_t st);
 int launch_dw3x3_fwd(const float*, long, const float*, const float*, float*, long, int, int, int, int, int, hipStream_t,
                      const float*, const float*);
@@ -282,5 +285,12 @@ int smaat_pointwise_fwd_split(const float* x, long x_bs, const void* planes, con
     a.x = x; a.x_bs = x_bs; a.planes = (const unsigned short*)planes; a.bias = bias; a.out = out; a.out_bs = out_bs;
     a.part = part; a.N = N; a.Cin = Cin; a.Cp = (Cin + 15) & ~15; a.M = M; a.P = H * W;
     return launch_pw_split(a, ST);
+}
+int smaat_precip_metrics_ws_bytes(long n) { return (int)precip_metrics_ws_bytes(n); }
+int smaat_precip_metrics_update(const float* preds, const float* target, long n, int batch, float factor,
+                                float threshold, int denormalize, void* ws, double* state_f64, long long* state_i64,
+                                void* stream) {
+    return launch_precip_metrics_update(preds, target, n, batch, factor, threshold, denormalize, ws, state_f64,
+                                        state_i64, ST);
 }
 }  // extern "C"

@@ -465,6 +465,41 @@ class EmuLib:
         return 0
 
 
+def _emu_precip_metrics_ws_bytes(self, n):
+    return 64
+
+
+def _emu_precip_metrics_update(self, preds, target, n, batch, factor, threshold, denormalize, ws, state_f64, state_i64,
+                               stream):
+    """numpy restatement of csrc/metrics.hip (same float32 operation order per pixel)"""
+    p, t = f32(preds, n), f32(target, n)
+    sf = np.ctypeslib.as_array((ctypes.c_double * 2).from_address(int(state_f64)))
+    si = np.ctypeslib.as_array((ctypes.c_int64 * 7).from_address(int(state_i64)))
+    if np.isnan(p).any() or np.isnan(t).any():
+        si[0] += 1
+        return 0
+    f, thr = np.float32(factor), np.float32(threshold)
+    d = (p - t).astype(np.float32)
+    pu, tu = ((p * f).astype(np.float32), (t * f).astype(np.float32)) if denormalize else (p, t)
+    dd = (pu - tu).astype(np.float32)
+    sf[0] += float(np.sum(d.astype(np.float64) ** 2)) / batch
+    if denormalize:
+        sf[1] += float(np.sum(dd.astype(np.float64) ** 2)) / batch
+    pm = (pu * np.float32(12)).astype(np.float32) > thr
+    tm = (tu * np.float32(12)).astype(np.float32) > thr
+    si[1] += int(np.sum(~tm & ~pm))
+    si[2] += int(np.sum(~tm & pm))
+    si[3] += int(np.sum(tm & ~pm))
+    si[4] += int(np.sum(tm & pm))
+    si[5] += batch
+    si[6] += n
+    return 0
+
+
+EmuLib.smaat_precip_metrics_ws_bytes = _emu_precip_metrics_ws_bytes
+EmuLib.smaat_precip_metrics_update = _emu_precip_metrics_update
+
+
 def install():
     """Swap the emulation in for libsmaat_hip.so (CPU tests only)."""
     from smaat_unet_amd import _lib
