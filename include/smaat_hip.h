@@ -31,8 +31,9 @@ int smaat_abi_version(void);
  *   w_dw     [Cin*kpl][9], b_dw [Cin*kpl] (nullable)
  *   wt_pw    [Cin*kpl][Cout]  = pointwise.weight TRANSPOSED (k-major), b_pw [Cout] (nullable)
  *   z        [N][Cout][H][W]
- *   part     nullable; [2][slots][Cout] per-tile sum / sum-of-squares of (z - b_pw) for the
- *            following train-mode BatchNorm; slots = smaat_pw_num_slots(N,H,W,Cout)
+ *   part     nullable; [3][slots][Cout] per-tile (mean, M2 = sum of squared deviations from that mean, pixel
+ *            count) of (z - b_pw) for the following train-mode BatchNorm; slots = smaat_pw_num_slots(N,H,W,Cout).
+ *            smaat_bn_finalize merges the tiles pairwise in fp64 (no E[z^2] - E[z]^2 cancellation).
  *   y_out    nullable; [N][Cin*kpl][H][W] depthwise output, written as a side product so that the
  *            backward pass can form the pointwise weight gradient as one streamed GEMM
  */
@@ -71,22 +72,28 @@ int smaat_pointwise_wgrad(const float* x, long x_bs, const float* dz, long dz_bs
 int smaat_dw3x3_bwd_ws_rows(int N, int Cin, int H, int W);
 int smaat_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, const float* w_dw, float* dx, long dx_bs,
                     float* ws, float* dw_out, float* db_out, int N, int Cin, int kpl, int H, int W, void* stream);
-/* same, when x is the output y = relu(bn(z)) of a preceding train-mode BatchNorm2d + ReLU (the first half of a
- * DoubleConvDS, unet_parts_depthwise_separable.py:17-36): additionally emits that BatchNorm's backward reduction
- *   rpart[0][r][ci] = sum dX*[y>0],  rpart[1][r][ci] = sum dX*[y>0]*(y - beta)/gamma     (r < smaat_dw3x3_bwd_ws_rows - 1)
+/* same, fused with the backward reduction of the train-mode BatchNorm2d + ReLU in FRONT of this depthwise conv (the
+ * first half of a DoubleConvDS, unet_parts_depthwise_separable.py:17-36).  x holds that BatchNorm's INPUT z (the
+ * pre-BatchNorm tensor); the activation y = relu(z*in_scale + in_shift) is recomputed on load (it is never written to
+ * memory) and the kernel additionally emits
+ *   rpart[0][r][ci] = sum dX*[y>0],  rpart[1][r][ci] = sum dX*[y>0]*(z - bn_mean)*bn_invstd   (r < smaat_dw3x3_bwd_ws_rows - 1)
  * which smaat_bn_bwd_finalize consumes in place of the output of smaat_bn_bwd_reduce (one pass over dy and z saved).
- * in_scale/in_shift (nullable, [Cin]): x then holds the PRE-BatchNorm tensor z and y = relu(z*in_scale + in_shift) is
- * recomputed on load (the activation of the first half is never written to memory).
+ * bn_mean / bn_invstd [Cin]: the batch statistics of that BatchNorm (rows 0 and 1 of smaat_bn_finalize's output): the
+ * normalised value is formed exactly as ATen does, for any gamma (zero included).
+ * in_scale, in_shift, bn_mean, bn_invstd, dx, rpart are all required.
  * Returns -2 when the shape is not handled by the strip kernel (W % 4 != 0 ...): run the two kernels separately. */
+/* 1 when the strip-form depthwise kernels (smaat_dw3x3_fwd with in_scale/in_shift and smaat_dw3x3_bwd_bnred) handle
+ * planes of this shape given dense, 16-byte aligned tensors; 0 otherwise (they would return -2). */
+int smaat_dw3x3_strip_ok(int kpl, int H, int W);
 int smaat_dw3x3_bwd_bnred(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* dy,
                           long dy_bs, const float* w_dw, float* dx, long dx_bs, float* ws, float* dw_out, float* db_out,
-                          const float* bn_gamma, const float* bn_beta, float* rpart, int N, int Cin, int kpl, int H,
+                          const float* bn_mean, const float* bn_invstd, float* rpart, int N, int Cin, int kpl, int H,
                           int W, void* stream);
 
 /* ---- BatchNorm2d (train) + ReLU   reference: unet_parts_depthwise_separable.py:25-26,34-35,
  *      layers.py:120,127.  Statistics arrive as partial sums (from smaat_dsconv_fwd etc.).
- *   finalize: part [2][T][C], count = N*H*W; bias_shift[C] (nullable) is added to the mean
- *             (the partials are of z - bias).  Writes mean/invstd/scale/shift [C] and updates
+ *   finalize: part [3][T][C] = per-tile (mean, M2, count) as written by the GEMM kernels (tiles with count 0 are
+ *             ignored), count = N*H*W; bias_shift[C] (nullable) is added to the mean (the partials are of z - bias).  Writes mean/invstd/scale/shift [C] and updates
  *             running_mean/var (nullable) with `momentum` and the unbiased variance.
  *   affine_act: y = relu?(z*scale[c] + shift[c])
  *   bwd: g = dy*[y>0]; part [2][slots][C] with slots = smaat_plane_num_slots(N,P);
@@ -174,7 +181,7 @@ int smaat_cbam_bwd_final(float* dx, long dx_bs, const float* davg, const float* 
  *                        optional in_scale/in_shift[Cin]: x := relu(x*sc+sh) on load (as smaat_dsconv_fwd);
  *                        returns -2 when the shape/alignment is not handled (W % 4 != 0): use smaat_dsconv_fwd
  *   smaat_pointwise_fwd_split: out[n][m][p] = sum_c A[m][c] x[n][c][p] + bias[m], A given as planes;
- *                        part: nullable [2][smaat_pw_split_num_slots(N,H,W)][M] BatchNorm partials of out - bias
+ *                        part: nullable [3][smaat_pw_split_num_slots(N,H,W)][M] BatchNorm partials (mean, M2, count per tile) of out - bias
  */
 int smaat_split_enabled(void);
 int smaat_split_mode(void);

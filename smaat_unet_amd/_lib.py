@@ -31,6 +31,7 @@ SIGNATURES = {
     "smaat_pointwise_wgrad": [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _P],
     "smaat_dw3x3_bwd_ws_rows": [_I, _I, _I, _I],
     "smaat_dw3x3_bwd": [_P, _L, _P, _L, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "smaat_dw3x3_strip_ok": [_I, _I, _I],
     "smaat_dw3x3_bwd_bnred": [_P, _L, _P, _P, _P, _L, _P, _P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "smaat_bn_finalize": [_P, _I, _I, _D, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P],
     "smaat_bn_eval_coefs": [_P, _P, _P, _P, _F, _I, _P, _P],
@@ -183,7 +184,7 @@ class Profiler:
         self._orig = {}
         for name in SIGNATURES:
             fn = getattr(self.lib, name)
-            if name.endswith(("_slots", "_splits", "_blocks", "_version", "_rows", "_enabled", "_mode", "_bytes")):
+            if name.endswith(("_slots", "_splits", "_blocks", "_version", "_rows", "_enabled", "_mode", "_bytes", "_ok")):
                 continue
             self._orig[name] = fn
             setattr(self.lib, name, self._wrap(name, fn))

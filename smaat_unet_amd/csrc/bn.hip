@@ -5,34 +5,52 @@
 #include "common.h"
 
 // ---------------------------------------------------------------------------------
-// finalize forward statistics: part[2][T][C] (sum, sumsq of z - shift_bias) -> per channel
+// finalize forward statistics: per-tile partials part[3][T][C] = (mean_t, M2_t, n_t) of (z - shift_bias)
+// (common.h "BatchNorm partial statistics") -> per channel.  The tiles are merged in fp64 with the pairwise
+// update  M2 = sum_t M2_t + n_t (mean_t - mean)^2  in two passes over the (L2-resident) partials: no
+// E[z^2] - E[z]^2 anywhere, so the variance keeps its accuracy when |mean| >> std.
 // ---------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_f64(double v, double* red) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+
 __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ part, int T, int C, double count,
                                                      const float* __restrict__ bias_shift,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, float momentum, float* running_mean,
                                                      float* running_var, float* mean_out, float* invstd_out,
                                                      float* scale_out, float* shift_out) {
+    __shared__ double red[256];
     const int c = blockIdx.x;
-    double s = 0.0, q = 0.0;
+    const float* pm = part + c;
+    const float* pq = part + (long)T * C + c;
+    const float* pn = part + 2L * T * C + c;
+    double n = 0.0, s = 0.0;
     for (int t = threadIdx.x; t < T; t += 256) {
-        s += (double)part[(long)t * C + c];
-        q += (double)part[((long)T + t) * C + c];
+        const double nt = (double)pn[(long)t * C];
+        n += nt;
+        s += nt * (double)pm[(long)t * C];
     }
-    __shared__ double rs[256], rq[256];
-    rs[threadIdx.x] = s;
-    rq[threadIdx.x] = q;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if (threadIdx.x < st) {
-            rs[threadIdx.x] += rs[threadIdx.x + st];
-            rq[threadIdx.x] += rq[threadIdx.x + st];
-        }
-        __syncthreads();
+    const double ntot = block_sum_f64(n, red);
+    const double stot = block_sum_f64(s, red);
+    const double m0 = ntot > 0.0 ? stot / ntot : 0.0;
+    double q = 0.0;
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const double nt = (double)pn[(long)t * C];
+        const double d = (double)pm[(long)t * C] - m0;
+        q += (double)pq[(long)t * C] + nt * d * d;
     }
+    const double qtot = block_sum_f64(q, red);
     if (threadIdx.x == 0) {
-        const double m0 = rs[0] / count;
-        double var = rq[0] / count - m0 * m0;
+        double var = ntot > 0.0 ? qtot / ntot : 0.0;
         if (var < 0.0) var = 0.0;
         const double mean = m0 + (bias_shift ? (double)bias_shift[c] : 0.0);
         const double invstd = 1.0 / sqrt(var + (double)eps);

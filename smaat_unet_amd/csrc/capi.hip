@@ -36,6 +36,7 @@ int launch_dw3x3_bwd(const float*, long, const float*, long, const float*, float
                      int, hipStream_t, const float*, const float*, float*, const float*, const float*);
 int launch_dw_split(const float*, int, float*, float*, hipStream_t);
 int dw_bwd_groups(int N, int Cin, int H, int W);
+int dw3x3_strip_ok(int kpl, int H, int W);
 
 int smaat_cbam_spconv_blocks_impl(int N, int H, int W);
 int smaat_cbam_pix_blocks_impl(int N, int P);
@@ -130,6 +131,7 @@ int smaat_pointwise_wgrad(const float* x, long x_bs, const float* dz, long dz_bs
 }
 
 int smaat_dw3x3_bwd_ws_rows(int N, int Cin, int H, int W) { return N * dw_bwd_groups(N, Cin, H, W) + 1; }
+int smaat_dw3x3_strip_ok(int kpl, int H, int W) { return dw3x3_strip_ok(kpl, H, W); }
 
 int smaat_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, const float* w_dw, float* dx, long dx_bs,
                     float* ws, float* dw_out, float* db_out, int N, int Cin, int kpl, int H, int W, void* stream) {
@@ -144,13 +146,14 @@ int smaat_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, cons
 
 int smaat_dw3x3_bwd_bnred(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* dy,
                           long dy_bs, const float* w_dw, float* dx, long dx_bs, float* ws, float* dw_out, float* db_out,
-                          const float* bn_gamma, const float* bn_beta, float* rpart, int N, int Cin, int kpl, int H,
+                          const float* bn_mean, const float* bn_invstd, float* rpart, int N, int Cin, int kpl, int H,
                           int W, void* stream) {
-    if (!dx || !rpart) return -1;
+    if (!dx || !rpart || !bn_mean || !bn_invstd) return -1;
+    if (!in_scale || !in_shift) return -2;  // x must be the pre-BatchNorm tensor
     const int Cdw = Cin * kpl;
     hipStream_t st = ST;
     const int rows = N * dw_bwd_groups(N, Cin, H, W);
-    CHK(launch_dw3x3_bwd(x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, ws, N, Cin, kpl, H, W, st, bn_gamma, bn_beta, rpart, in_scale, in_shift));
+    CHK(launch_dw3x3_bwd(x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, ws, N, Cin, kpl, H, W, st, bn_mean, bn_invstd, rpart, in_scale, in_shift));
     float* tmp = ws + (long)rows * Cdw * 10;
     CHK(launch_reduce_rows(ws, rows, (long)Cdw * 10, tmp, 1.f, st));
     return launch_dw_split(tmp, Cdw, dw_out, db_out, st);

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_cbam_sppool(const float* __restrict__ x
 }
 
 // k x k conv (k = 3 or 7) over the 2-channel maps, 16x16 pixel tiles, + BN(1) partials
-// part[2][nblocks]
+// part[3][nblocks] = (mean, M2, n) per block
 #define SPT 16
 __global__ __launch_bounds__(256) void k_cbam_spconv(const float* __restrict__ maps, const float* __restrict__ wc,
                                                      int ks, int H, int W, float* __restrict__ conv,
@@ -184,13 +184,18 @@ __global__ __launch_bounds__(256) void k_cbam_spconv(const float* __restrict__ m
                 for (int j = 0; j < ks; ++j) acc = fmaf(wl[(ch * ks + i) * ks + j], tile[ch][tr + i][tc + j], acc);
         conv[(long)n * P + r * W + c] = acc;
     }
+    // BN(1) partial of this block as (mean, M2, n) about the block mean (common.h "BatchNorm partial statistics")
     const float v = valid ? acc : 0.f;
-    const float t1 = block_sum_t0(v, red);
-    const float t2 = block_sum_t0(v * v, red + 4);
+    const float cntf = block_sum_t0(valid ? 1.f : 0.f, red);
+    const float t1 = block_sum_t0(v, red + 4);
+    const float mb = cntf > 0.f ? t1 / cntf : 0.f;  // every thread sees the same four wave sums -> same value
+    const float d = valid ? acc - mb : 0.f;
+    const float t2 = block_sum_t0(d * d, red);
     if (tid == 0) {
         const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        part[blk] = t1;
+        part[blk] = mb;
         part[nblocks + blk] = t2;
+        part[2 * nblocks + blk] = cntf;
     }
 }
 

@@ -64,6 +64,84 @@ __device__ __forceinline__ float block_sum_t0(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// ---- BatchNorm partial statistics of an MFMA accumulator tile ---------------------------------------
+// The train-mode BatchNorm that follows a pointwise GEMM (reference unet_parts_depthwise_separable.py:25,34)
+// needs mean and biased variance over (N, H, W).  Plain f32 sums of z and z^2 lose the variance when
+// |mean| >> std (E[z^2] - E[z]^2 cancels), so every tile reports
+//     part[0][tile][c] = mean_t,   part[1][tile][c] = M2_t = sum (z - mean_t)^2,   part[2][tile][c] = n_t
+// and k_bn_finalize merges the tiles with the pairwise (Chan) update in fp64.  Inside a tile the sums are
+// taken about a SHIFT that is itself a sample of the row (the value of its first valid pixel): with the shift
+// inside the data range, S2 - S1^2/n has no cancellation beyond the spread of the data itself.
+//
+// bn_wave_partials: the 32 lanes of a half-wave hold PXT x 32 pixels of row (r & 3) + 8 (r >> 2) + 4 half of
+// each 32-row tile ct (the 32x32 MFMA C layout).  Writes, for every row of the wave tile, (S1, S2, shift)
+// about the shift to sp[0 / COT / 2 COT + row]; returns the number of valid pixels of the wave.
+#define BN_STAT_FLOATS(WPX, COT) ((WPX) * 3 * (COT) + 8)  // LDS floats: [WPX][3][COT] wave partials + [8] pixel counts
+template <int CT, int PXT>
+__device__ __forceinline__ int bn_wave_partials(const f32x16 (&acc)[CT][PXT], const bool (&pval)[PXT], int l31,
+                                                int half, float* sp, int COT) {
+    // first valid pixel of pt = 0 (lanes l and l + 32 hold the same pixel) and the pixel count of the wave
+    const unsigned long long b0 = __ballot(pval[0]);
+    const unsigned lo = (unsigned)b0;
+    const int fl = lo ? __builtin_ctz(lo) : 0;
+    int n = __builtin_popcount(lo);
+#pragma unroll
+    for (int pt = 1; pt < PXT; ++pt) n += __builtin_popcount((unsigned)__ballot(pval[pt]));
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float a0 = acc[ct][0][r];
+            const float sh_lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a0), fl));
+            const float sh_hi =
+                __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a0), fl + 32));
+            const float sh = half ? sh_hi : sh_lo;
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int pt = 0; pt < PXT; ++pt) {
+                const float d = pval[pt] ? acc[ct][pt][r] - sh : 0.f;
+                s += d;
+                q = fmaf(d, d, q);
+            }
+            s = half32_sum_hi(s);
+            q = half32_sum_hi(q);
+            if (l31 == 16 + r) {
+                const int rc = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                sp[rc] = s;
+                sp[COT + rc] = q;
+                sp[2 * COT + rc] = sh;
+            }
+        }
+    }
+    return n;
+}
+
+// merge the WPX wave partials of one row into the tile's (mean, M2, n); stat = [WPX][3][COT], cnt = [WPX]
+template <int WPX>
+__device__ __forceinline__ void bn_tile_combine(const float* stat, const int* cnt, int COT, int col, float& mean,
+                                                float& m2, float& n) {
+    mean = 0.f;
+    m2 = 0.f;
+    n = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPX; ++w) {
+        const float nw = (float)cnt[w];
+        if (nw > 0.f) {
+            const float* sp = stat + w * 3 * COT + col;
+            const float s1 = sp[0], s2 = sp[COT], sh = sp[2 * COT];
+            const float inv = 1.f / nw;
+            const float mw = sh + s1 * inv;
+            float m2w = s2 - s1 * s1 * inv;
+            m2w = m2w > 0.f ? m2w : 0.f;
+            const float nt = n + nw;
+            const float delta = mw - mean;
+            mean += delta * (nw / nt);
+            m2 += m2w + delta * delta * (n * nw / nt);
+            n = nt;
+        }
+    }
+}
+
 // ---- pixel-tile geometry ---------------------------------------------------------
 // A "pixel tile" is PT pixels of ONE image.  mode 0: PT consecutive pixels of the
 // flattened H*W plane (small maps).  mode 1: a TH x TW patch (TH*TW == PT).

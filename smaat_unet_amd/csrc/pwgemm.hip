@@ -54,8 +54,8 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
     extern __shared__ float smem[];
     float* Yl = smem;                   // [KC][PT]
     float* Wl = Yl + KC * PT;           // [KC][COT]
-    float* stat = Wl + KC * COT;        // [WPX][2][COT]
-    int* pixoff = (int*)(stat + WPX * 2 * COT);  // [PT]
+    float* stat = Wl + KC * COT;        // [WPX][3][COT] + [8] wave pixel counts (BN_STAT_FLOATS)
+    int* pixoff = (int*)(stat + BN_STAT_FLOATS(WPX, COT));  // [PT]
     int* sidx = pixoff + PT;            // [PT]
     float* biasl = (float*)(sidx + PT); // [COT]
     float* S = biasl + COT;             // [KCI][sstride]
@@ -316,34 +316,21 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
     }
     // ---- BatchNorm partial statistics of the raw accumulators (z - bias) ---------------
     if (a.part) {
+        bool pval[PXT];
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float s = 0.f, q = 0.f;
-#pragma unroll
-                for (int pt = 0; pt < PXT; ++pt) {
-                    const float v = (off[pt] >= 0) ? acc[ct][pt][r] : 0.f;
-                    s += v;
-                    q = fmaf(v, v, q);
-                }
-                s = half32_sum_hi(s);
-                q = half32_sum_hi(q);
-                if (l31 == 16 + r) {
-                    const int col = (wco * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    stat[(wpx * 2 + 0) * COT + col] = s;
-                    stat[(wpx * 2 + 1) * COT + col] = q;
-                }
-            }
-        }
+        for (int pt = 0; pt < PXT; ++pt) pval[pt] = off[pt] >= 0;
+        const int nw = bn_wave_partials<CT, PXT>(acc, pval, l31, half, stat + wpx * 3 * COT + wco * CT * 32, COT);
+        if (lane == 0) ((int*)(stat + WPX * 3 * COT))[wpx] = nw;
         __syncthreads();
-        for (int t = tid; t < 2 * COT; t += SMAAT_THREADS) {
-            const int which = t / COT, col = t - which * COT;
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < WPX; ++w) v += stat[(w * 2 + which) * COT + col];
+        for (int col = tid; col < COT; col += SMAAT_THREADS) {
+            float mean, m2, cnt;
+            bn_tile_combine<WPX>(stat, (const int*)(stat + WPX * 3 * COT), COT, col, mean, m2, cnt);
             const int m = co0 + col;
-            if (m < a.M) a.part[((long)which * g.T + ptg) * a.M + m] = v;
+            if (m < a.M) {
+                a.part[((long)0 * g.T + ptg) * a.M + m] = mean;
+                a.part[((long)1 * g.T + ptg) * a.M + m] = m2;
+                a.part[((long)2 * g.T + ptg) * a.M + m] = cnt;
+            }
         }
     }
 }
@@ -382,8 +369,8 @@ __global__ __launch_bounds__(256 + NPT) void k_pwgemm_ws(const PwArgs a) {
     float* Yl = smem;                   // [2][KC][PT]
     float* Wl = Yl + 2 * KC * PT;       // [2][KC][COT]
     float* DWl = Wl + 2 * KC * COT;     // [2][256]: per chunk [KC][12] = 9 depthwise taps, bias, 2 pad
-    float* stat = DWl + 2 * 256;        // [WPX][2][COT]
-    int* pixoff = (int*)(stat + WPX * 2 * COT);  // [PT]
+    float* stat = DWl + 2 * 256;        // [WPX][3][COT] + [8] wave pixel counts (BN_STAT_FLOATS)
+    int* pixoff = (int*)(stat + BN_STAT_FLOATS(WPX, COT));  // [PT]
     int* sidx = pixoff + PT;            // [PT]
     float* biasl = (float*)(sidx + PT); // [COT]
     float* S = biasl + COT;             // [2][KCI][sstride]
@@ -705,37 +692,24 @@ __global__ __launch_bounds__(256 + NPT) void k_pwgemm_ws(const PwArgs a) {
             }
         }
         if (a.part) {
+            bool pval[PXT];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float s = 0.f, q = 0.f;
-#pragma unroll
-                    for (int pt = 0; pt < PXT; ++pt) {
-                        const float v = (off[pt] >= 0) ? acc[ct][pt][r] : 0.f;
-                        s += v;
-                        q = fmaf(v, v, q);
-                    }
-                    s = half32_sum_hi(s);
-                    q = half32_sum_hi(q);
-                    if (l31 == 16 + r) {
-                        const int col = (wco * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        stat[(wpx * 2 + 0) * COT + col] = s;
-                        stat[(wpx * 2 + 1) * COT + col] = q;
-                    }
-                }
-            }
+            for (int pt = 0; pt < PXT; ++pt) pval[pt] = off[pt] >= 0;
+            const int nw = bn_wave_partials<CT, PXT>(acc, pval, l31, half, stat + wpx * 3 * COT + wco * CT * 32, COT);
+            if (lane == 0) ((int*)(stat + WPX * 3 * COT))[wpx] = nw;
         }
     }
     if (a.part) {
         __syncthreads();
-        for (int t = tid; t < 2 * COT; t += NTH) {
-            const int which = t / COT, col = t - which * COT;
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < WPX; ++w) v += stat[(w * 2 + which) * COT + col];
+        for (int col = tid; col < COT; col += NTH) {
+            float mean, m2, cnt;
+            bn_tile_combine<WPX>(stat, (const int*)(stat + WPX * 3 * COT), COT, col, mean, m2, cnt);
             const int m = co0 + col;
-            if (m < a.M) a.part[((long)which * g.T + ptg) * a.M + m] = v;
+            if (m < a.M) {
+                a.part[((long)0 * g.T + ptg) * a.M + m] = mean;
+                a.part[((long)1 * g.T + ptg) * a.M + m] = m2;
+                a.part[((long)2 * g.T + ptg) * a.M + m] = cnt;
+            }
         }
     }
 }
@@ -768,8 +742,8 @@ __global__ __launch_bounds__(256 + NPT) void k_dsconv_strip(const PwArgs a) {
     float* Yl = smem;                   // [2][KC][PT]
     float* Wl = Yl + 2 * KC * PT;       // [2][KC][COT]
     float* DWl = Wl + 2 * KC * COT;     // [2][256]: per chunk [KC][12] = 9 taps, bias, 2 pad
-    float* stat = DWl + 2 * 256;        // [WPX][2][COT]
-    int* pixoff = (int*)(stat + WPX * 2 * COT);  // [PT]
+    float* stat = DWl + 2 * 256;        // [WPX][3][COT] + [8] wave pixel counts (BN_STAT_FLOATS)
+    int* pixoff = (int*)(stat + BN_STAT_FLOATS(WPX, COT));  // [PT]
     float* biasl = (float*)(pixoff + PT);        // [COT]
     float* S = biasl + COT;             // [2][KCI][SST]
 
@@ -1022,37 +996,24 @@ __global__ __launch_bounds__(256 + NPT) void k_dsconv_strip(const PwArgs a) {
             }
         }
         if (a.part) {
+            bool pval[PXT];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float s = 0.f, q = 0.f;
-#pragma unroll
-                    for (int pt = 0; pt < PXT; ++pt) {
-                        const float v = (off[pt] >= 0) ? acc[ct][pt][r] : 0.f;
-                        s += v;
-                        q = fmaf(v, v, q);
-                    }
-                    s = half32_sum_hi(s);
-                    q = half32_sum_hi(q);
-                    if (l31 == 16 + r) {
-                        const int col = (wco * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        stat[(wpx * 2 + 0) * COT + col] = s;
-                        stat[(wpx * 2 + 1) * COT + col] = q;
-                    }
-                }
-            }
+            for (int pt = 0; pt < PXT; ++pt) pval[pt] = off[pt] >= 0;
+            const int nw = bn_wave_partials<CT, PXT>(acc, pval, l31, half, stat + wpx * 3 * COT + wco * CT * 32, COT);
+            if (lane == 0) ((int*)(stat + WPX * 3 * COT))[wpx] = nw;
         }
     }
     if (a.part) {
         __syncthreads();
-        for (int t = tid; t < 2 * COT; t += NTH) {
-            const int which = t / COT, col = t - which * COT;
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < WPX; ++w) v += stat[(w * 2 + which) * COT + col];
+        for (int col = tid; col < COT; col += NTH) {
+            float mean, m2, cnt;
+            bn_tile_combine<WPX>(stat, (const int*)(stat + WPX * 3 * COT), COT, col, mean, m2, cnt);
             const int m = co0 + col;
-            if (m < a.M) a.part[((long)which * g.T + ptg) * a.M + m] = v;
+            if (m < a.M) {
+                a.part[((long)0 * g.T + ptg) * a.M + m] = mean;
+                a.part[((long)1 * g.T + ptg) * a.M + m] = m2;
+                a.part[((long)2 * g.T + ptg) * a.M + m] = cnt;
+            }
         }
     }
 }
@@ -1418,7 +1379,7 @@ static int launch_pwgemm_mode(PwArgs& a, hipStream_t st) {
         a.g.T = a.N * a.g.tiles_per_img;
         a.nco = ceil_div(a.M, COT);
         a.sstride = 0;
-        const size_t lds = sizeof(float) * (size_t)(KC * PT + KC * COT + WPX * 2 * COT + 2 * PT + COT);
+        const size_t lds = sizeof(float) * (size_t)(KC * PT + KC * COT + BN_STAT_FLOATS(WPX, COT) + 2 * PT + COT);
         const int grid = ceil_div(a.g.T, 8) * 8 * a.nco;
         constexpr auto kern = k_pwgemm<WCO, CT, WPX, PXT, 0, true>;
         int rc = ensure_lds<kern>(lds);
@@ -1440,7 +1401,7 @@ static int launch_pwgemm_mode(PwArgs& a, hipStream_t st) {
     }
     a.sstride = sstride;
     const int kci = KC / (DW ? MODE : 1);
-    const size_t lds = sizeof(float) * (size_t)(KC * PT + KC * COT + WPX * 2 * COT + 2 * PT + COT + (DW ? kci * sstride : 0));
+    const size_t lds = sizeof(float) * (size_t)(KC * PT + KC * COT + BN_STAT_FLOATS(WPX, COT) + 2 * PT + COT + (DW ? kci * sstride : 0));
     const int grid = ceil_div(a.g.T, 8) * 8 * a.nco;
     constexpr auto kern = k_pwgemm<WCO, CT, WPX, PXT, MODE>;
     int rc = ensure_lds<kern>(lds);
@@ -1511,7 +1472,7 @@ static int launch_dsconv_strip_kpl(PwArgs& a, hipStream_t st) {
     constexpr int kci = KC / KPL;
     a.nco = ceil_div(a.M, COT);
     a.sstride = strip_row_stride(a.g.TW);
-    const size_t lds = sizeof(float) * (size_t)(2 * KC * PT + 2 * KC * COT + 2 * 256 + WPX * 2 * COT + PT + COT +
+    const size_t lds = sizeof(float) * (size_t)(2 * KC * PT + 2 * KC * COT + 2 * 256 + BN_STAT_FLOATS(WPX, COT) + PT + COT +
                                                 2 * kci * SMAX_WS);
     const int grid = ceil_div(a.g.T, 8) * 8 * a.nco;
     constexpr auto kern = k_dsconv_strip<WCO, CT, WPX, PXT, KPL, NPT>;
@@ -1540,7 +1501,7 @@ static int launch_pwgemm_ws_mode(PwArgs& a, hipStream_t st) {
     a.nco = ceil_div(a.M, COT);
     a.sstride = SMAX_WS;
     const int kci = KC / (DW ? MODE : 1);
-    const size_t lds = sizeof(float) * (size_t)(2 * KC * PT + 2 * KC * COT + 2 * 256 + WPX * 2 * COT + 2 * PT + COT +
+    const size_t lds = sizeof(float) * (size_t)(2 * KC * PT + 2 * KC * COT + 2 * 256 + BN_STAT_FLOATS(WPX, COT) + 2 * PT + COT +
                                                 (DW ? 2 * kci * SMAX_WS : 0));
     const int grid = ceil_div(a.g.T, 8) * 8 * a.nco;
     constexpr auto kern = k_pwgemm_ws<WCO, CT, WPX, PXT, MODE, NPT, AFF>;

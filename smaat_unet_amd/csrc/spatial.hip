@@ -467,11 +467,11 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd_strip(const float* __restrict
                                                          const float* __restrict__ bn_b, float* __restrict__ rpart,
                                                          const float* __restrict__ in_scale,
                                                          const float* __restrict__ in_shift) {
-    // rpart (nullable): x is the output y = relu(bn(z)) of a preceding train-mode BatchNorm with affine
-    // (bn_g, bn_b); the kernel then also emits that BatchNorm's backward reduction over its planes,
-    //   rpart[0][row][ci] = sum g,  rpart[1][row][ci] = sum g * zhat,   g = dX * [y > 0],  zhat = (y - beta) / gamma
-    // (for y > 0, (y - beta) / gamma IS the normalised pre-activation), so the separate pass over (dy, z) of
-    // smaat_bn_bwd_reduce is not needed.
+    // rpart (nullable; needs in_scale/in_shift, i.e. x = the PRE-BatchNorm tensor z of the previous half-block):
+    // the kernel also emits that BatchNorm's backward reduction over its planes,
+    //   rpart[0][row][ci] = sum g,  rpart[1][row][ci] = sum g * zhat,   g = dX * [y > 0],  zhat = (z - mean) * invstd
+    // with (bn_g, bn_b) = (mean, invstd) of that BatchNorm -- the same expression ATen evaluates, valid for any
+    // gamma (0 and tiny values included) -- so the separate pass over (dy, z) of smaat_bn_bwd_reduce is not needed.
     constexpr int NSL = 6;  // float4 staging slots per thread: KPL * nrow * ncol4 <= 1536
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     float* S = dsm;                   // [KPL][ssz]
@@ -498,9 +498,8 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd_strip(const float* __restrict
     // activation is recomputed on load, y = relu(z * in_scale[ci] + in_shift[ci])
     const bool aff = in_scale != nullptr;
     const float asc = aff ? in_scale[ci] : 1.f, ash = aff ? in_shift[ci] : 0.f;
-    const float rbeta = (rpart && bn_b) ? bn_b[ci] : 0.f;
-    const float rgam = (rpart && bn_g) ? bn_g[ci] : 1.f;
-    const float rinvg = rgam != 0.f ? 1.f / rgam : 0.f;
+    const float rmean = rpart ? bn_g[ci] : 0.f;
+    const float rinvstd = rpart ? bn_b[ci] : 0.f;
 
     // tile-independent thread constants
     const int per = g.nrow * g.ncol4, F = KPL * per;
@@ -559,16 +558,16 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd_strip(const float* __restrict
                 const int prow = r0 + srg * 4;
                 const bool pcol = (c0 + sc) < g.W;
                 const int po = prow * g.W + c0 + sc;
-                float xc[4];
+                float xc[4], zr[4];
                 bool ok[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     ok[i] = pcol && (prow + i) < g.H;
-                    xc[i] = xp[ok[i] ? po + i * g.W : 0];
+                    zr[i] = xp[ok[i] ? po + i * g.W : 0];
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float v = xc[i];
+                    float v = zr[i];
                     if (aff) v = fmaxf(fmaf(v, asc, ash), 0.f);
                     xc[i] = ok[i] ? v : 0.f;
                 }
@@ -604,7 +603,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd_strip(const float* __restrict
                     for (int i = 0; i < 4; ++i) {
                         const float gg = (xc[i] > 0.f) ? dxa[i] : 0.f;  // xc is 0 outside the image
                         r1 += gg;
-                        r2 = fmaf(gg, (xc[i] - rbeta) * rinvg, r2);
+                        r2 = fmaf(gg, (zr[i] - rmean) * rinvstd, r2);
                     }
                 }
             }
@@ -907,6 +906,7 @@ int launch_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, con
     const bool aligned = ((W & 3) == 0) && ((x_bs & 3) == 0) && ((dy_bs & 3) == 0) && ((dx_bs & 3) == 0) &&
                          ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)dy) & 15) == 0) &&
                          ((((uintptr_t)dx) & 15) == 0) && (kpl == 1 || kpl == 2 || kpl == 4) && H >= 4;
+    if (rpart && !in_scale) return -2;  // the fused reduction needs the pre-BatchNorm tensor (zhat = (z - mean) * invstd)
     if (use_strip && aligned) {
         const DwbGeom sg = strip_geom(H, W, kpl);
         if (kpl * sg.nrow * sg.ncol4 <= 1536) {
@@ -931,6 +931,17 @@ int launch_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, con
     hipLaunchKernelGGL(k_dw3x3_bwd, dim3(N * Cin, groups), dim3(256), 0, st, x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, part,
                        Cin, kpl, g);
     return (int)hipGetLastError();
+}
+
+// 1 when BOTH strip kernels (forward with the activation applied on load, backward with the fused BatchNorm
+// reduction) take planes of this shape, given dense 16-byte aligned tensors: the host uses it to decide whether the
+// first activation of a DoubleConvDS can stay unmaterialised (ops.py FUSE_FIRST_ACTIVATION)
+int dw3x3_strip_ok(int kpl, int H, int W) {
+    const char* e = getenv("SMAAT_DWB_STRIP");
+    if (e && atoi(e) == 0) return 0;
+    if (!(kpl == 1 || kpl == 2 || kpl == 4) || (W & 3) != 0 || H < 4) return 0;
+    const DwbGeom f = strip_geom(H, W, 1), b = strip_geom(H, W, kpl);
+    return (f.nrow * f.ncol4 <= 1536 && kpl * b.nrow * b.ncol4 <= 1536) ? 1 : 0;
 }
 
 int launch_dw_split(const float* tmp, int Cdw, float* dw, float* db, hipStream_t st) {

@@ -362,8 +362,8 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
     static_assert(NCW == 4 || NCW == 8, "4 or 8 consumer waves");
     static_assert((PT * 2) % NPT == 0, "producer mapping");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    float* stat = (float*)(lds + 2 * BUFSZ);  // [WPX][2][COT]
-    float* biasl = stat + WPX * 2 * COT;         // [COT]
+    float* stat = (float*)(lds + 2 * BUFSZ);  // [WPX][3][COT] + [8] wave pixel counts (BN_STAT_FLOATS)
+    float* biasl = stat + BN_STAT_FLOATS(WPX, COT);  // [COT]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -556,37 +556,24 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
             }
         }
         if (a.part) {
+            bool pval[PXT];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float s = 0.f, q = 0.f;
-#pragma unroll
-                    for (int pt = 0; pt < PXT; ++pt) {
-                        const float v = (off[pt] >= 0) ? acc[ct][pt][r] : 0.f;
-                        s += v;
-                        q = fmaf(v, v, q);
-                    }
-                    s = half32_sum_hi(s);
-                    q = half32_sum_hi(q);
-                    if (l31 == 16 + r) {
-                        const int col = (wco * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        stat[(wpx * 2 + 0) * COT + col] = s;
-                        stat[(wpx * 2 + 1) * COT + col] = q;
-                    }
-                }
-            }
+            for (int pt = 0; pt < PXT; ++pt) pval[pt] = off[pt] >= 0;
+            const int nw = bn_wave_partials<CT, PXT>(acc, pval, l31, half, stat + wpx * 3 * COT + wco * CT * 32, COT);
+            if (lane == 0) ((int*)(stat + WPX * 3 * COT))[wpx] = nw;
         }
     }
     if (a.part) {
         __syncthreads();
-        for (int t = tid; t < 2 * COT; t += NTH) {
-            const int which = t / COT, col = t - which * COT;
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < WPX; ++w) v += stat[(w * 2 + which) * COT + col];
+        for (int col = tid; col < COT; col += NTH) {
+            float mean, m2, cnt;
+            bn_tile_combine<WPX>(stat, (const int*)(stat + WPX * 3 * COT), COT, col, mean, m2, cnt);
             const int m = co0 + col;
-            if (m < a.M) a.part[((long)which * a.slots + ptg) * a.M + m] = v;
+            if (m < a.M) {
+                a.part[((long)0 * a.slots + ptg) * a.M + m] = mean;
+                a.part[((long)1 * a.slots + ptg) * a.M + m] = m2;
+                a.part[((long)2 * a.slots + ptg) * a.M + m] = cnt;
+            }
         }
     }
 }
@@ -618,8 +605,9 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
     static_assert(NCW == 4 || NCW == 8, "4 or 8 consumer waves");
     static_assert((PT * 2) % NPT == 0, "producer mapping");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    float* stat = (float*)(lds + 2 * BUFSZ);  // [2][WPX][2][COT]
-    float* biasl = stat + 2 * WPX * 2 * COT;  // [4][COT]: bias of the channel tile of item k in slot k & 3
+    constexpr int STSZ = BN_STAT_FLOATS(WPX, COT);
+    float* stat = (float*)(lds + 2 * BUFSZ);  // [2][STSZ]: per item parity, [WPX][3][COT] wave partials + [8] wave pixel counts
+    float* biasl = stat + 2 * STSZ;  // [4][COT]: bias of the channel tile of item k in slot k & 3
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -813,15 +801,17 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
     } else {
         const int aoff = ((wco * CT) * 32 + l31) * BROW + half * 16;
         const int boff = NT * APL + ((wpx * PXT) * 32 + l31) * BROW + half * 16;
-        auto flush = [&](int par, int ptg, int co0) __attribute__((always_inline)) {  // combine the WPX waves' sums of a finished item
-            const float* sp = stat + par * (WPX * 2 * COT);
-            for (int t = tid; t < 2 * COT; t += NCT) {
-                const int which = t / COT, col = t - which * COT;
-                float v = 0.f;
-#pragma unroll
-                for (int w = 0; w < WPX; ++w) v += sp[(w * 2 + which) * COT + col];
+        auto flush = [&](int par, int ptg, int co0) __attribute__((always_inline)) {  // merge the WPX waves' partials of a finished item
+            const float* sp = stat + par * STSZ;
+            for (int col = tid; col < COT; col += NCT) {
+                float mean, m2, cnt;
+                bn_tile_combine<WPX>(sp, (const int*)(sp + WPX * 3 * COT), COT, col, mean, m2, cnt);
                 const int m = co0 + col;
-                if (m < a.M) a.part[((long)which * a.slots + ptg) * a.M + m] = v;
+                if (m < a.M) {
+                    a.part[((long)0 * a.slots + ptg) * a.M + m] = mean;
+                    a.part[((long)1 * a.slots + ptg) * a.M + m] = m2;
+                    a.part[((long)2 * a.slots + ptg) * a.M + m] = cnt;
+                }
             }
         };
         __syncthreads();
@@ -898,27 +888,9 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
                 }
             }
             if (a.part) {
-                float* sp = stat + (k & 1) * (WPX * 2 * COT) + wpx * 2 * COT + wco * CT * 32 + 4 * half;
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float s = 0.f, q = 0.f;
-#pragma unroll
-                        for (int pt = 0; pt < PXT; ++pt) {
-                            const float v = pval[pt] ? acc[ct][pt][r] : 0.f;
-                            s += v;
-                            q = fmaf(v, v, q);
-                        }
-                        s = half32_sum_hi(s);
-                        q = half32_sum_hi(q);
-                        if (l31 == 16 + r) {
-                            const int rc = ct * 32 + (r & 3) + 8 * (r >> 2);
-                            sp[rc] = s;
-                            sp[COT + rc] = q;
-                        }
-                    }
-                }
+                float* sb = stat + (k & 1) * STSZ;
+                const int nw = bn_wave_partials<CT, PXT>(acc, pval, l31, half, sb + wpx * 3 * COT + wco * CT * 32, COT);
+                if (lane == 0) ((int*)(sb + WPX * 3 * COT))[wpx] = nw;
                 prev_ptg = ptg;
                 prev_co0 = co0;
             }
@@ -949,21 +921,21 @@ static int launch_pw_split_cfg(PwSplitArgs& a, hipStream_t st) {
     // 32-bit buffer offset with bit 31 as the "dropped" marker: images of 2 GiB and more (and SMAAT_PWS_CFG=16,
     // for A/B timing) take the one-tile-per-workgroup kernel.
     if (!(pws_cfg() & 16) && (long)(a.M + COT) * a.P * 4 < (1L << 31)) {
-        const size_t lds = (size_t)2 * NT * (COT + PT) * BROW + sizeof(float) * (2 * WPX * 2 * COT + 4 * COT);
+        const size_t lds = (size_t)2 * NT * (COT + PT) * BROW + sizeof(float) * (2 * BN_STAT_FLOATS(WPX, COT) + 4 * COT);
         constexpr auto kern = k_pw_split_p<WCO, CT, WPX, PXT, NPT, NT>;
         int rc = ensure_lds_s<kern>(lds);
         if (rc) return rc;
         const int grid = items < 512 ? items : 512;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WCO * WPX * 64 + NPT), lds, st, a);
     } else {
-        const size_t lds = (size_t)2 * NT * (COT + PT) * BROW + sizeof(float) * (WPX * 2 * COT + COT);
+        const size_t lds = (size_t)2 * NT * (COT + PT) * BROW + sizeof(float) * (BN_STAT_FLOATS(WPX, COT) + COT);
         constexpr auto kern = k_pw_split<WCO, CT, WPX, PXT, NPT, NT>;
         int rc = ensure_lds_s<kern>(lds);
         if (rc) return rc;
         hipLaunchKernelGGL(kern, dim3(items), dim3(WCO * WPX * 64 + NPT), lds, st, a);
     }
     if (a.part && a.T < a.slots) {  // partial-statistics rows this tile choice does not use
-        for (int w = 0; w < 2; ++w)
+        for (int w = 0; w < 3; ++w)
             HIP_RET(hipMemsetAsync(a.part + ((long)w * a.slots + a.T) * a.M, 0, sizeof(float) * (size_t)(a.slots - a.T) * a.M, st));
     }
     return (int)hipGetLastError();

@@ -75,7 +75,7 @@ def _dsconv_fwd_raw(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, i
     slots = 0
     if want_stats:
         slots = L.smaat_pw_num_slots(n, h, w, cout)
-        part = _new(x, 2, slots, cout)
+        part = _new(x, 3, slots, cout)
     y = _new(x, n, k, h, w) if want_y else None
     _lib.check(L.smaat_dsconv_fwd(_ptr(x), x_bs, _ptr(in_scale), _ptr(in_shift), _ptr(w_dw), _ptr(b_dw), _ptr(wt),
                                   _ptr(b_pw), _ptr(z), cout * h * w, _ptr(part), _ptr(y), n, cin, kpl, cout, h, w,
@@ -159,7 +159,7 @@ def _pointwise_split_raw(x, planes, bias, m, want_stats=False):
     part, slots = None, 0
     if want_stats:
         slots = L.smaat_pw_split_num_slots(n, h, w)
-        part = _new(x, 2, slots, m)
+        part = _new(x, 3, slots, m)
     _lib.check(L.smaat_pointwise_fwd_split(_ptr(x), x_bs, _ptr(planes), _ptr(bias), _ptr(out), m * h * w, _ptr(part),
                                            n, c, m, h, w, _stream(x)), "smaat_pointwise_fwd_split")
     return out, part, slots
@@ -313,20 +313,25 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None, i
     dw_dw = _new(x, k, 1, 3, 3)
     db_dw = _new(x, k)
     red = None
-    if bnred is not None and need_dx:
-        # x = relu(bn(z_prev)): let the depthwise backward also reduce the previous BatchNorm's backward sums
-        gam, bet = bnred
-        isc, ish = in_aff if in_aff is not None else (None, None)
+    if in_aff is not None:
+        # x is the PRE-BatchNorm tensor of the previous half (its activation is applied on load): the strip kernel
+        # also reduces that BatchNorm's backward sums.  The forward only leaves the activation unmaterialised
+        # when smaat_dw3x3_strip_ok says this kernel takes the shape, so -2 here is a host/library mismatch.
+        if bnred is None or not need_dx:
+            raise _lib.SmaatHipError("depthwise backward with an on-load activation needs bnred=(mean, invstd) and dx")
+        mean, invstd = bnred
+        isc, ish = in_aff
         rows = L.smaat_dw3x3_bwd_ws_rows(n, cin, h, w) - 1
         rpart = _new(x, 2, rows, cin)
         rc = L.smaat_dw3x3_bwd_bnred(_ptr(x), x_bs, _ptr(isc), _ptr(ish), _ptr(dy), k * h * w, _ptr(w_dw), _ptr(dx),
-                                     cin * h * w, _ptr(ws2), _ptr(dw_dw), _ptr(db_dw), _ptr(gam), _ptr(bet),
+                                     cin * h * w, _ptr(ws2), _ptr(dw_dw), _ptr(db_dw), _ptr(mean), _ptr(invstd),
                                      _ptr(rpart), n, cin, kpl, h, w, s)
-        if rc == 0:
-            return dx, dw_dw, db_dw, dw_pw, (rpart, rows)
-        if rc != -2:
-            _lib.check(rc, "smaat_dw3x3_bwd_bnred")
-    assert in_aff is None, "input-affine depthwise backward needs the strip kernel (checked by _fuse_act_ok)"
+        if rc == -2:
+            raise _lib.SmaatHipError(
+                f"smaat_dw3x3_bwd_bnred does not take [{n},{cin},{h},{w}] kpl={kpl} although smaat_dw3x3_strip_ok did "
+                "when the forward ran (SMAAT_DWB_STRIP changed between forward and backward?)")
+        _lib.check(rc, "smaat_dw3x3_bwd_bnred")
+        return dx, dw_dw, db_dw, dw_pw, (rpart, rows)
     _lib.check(L.smaat_dw3x3_bwd(_ptr(x), x_bs, _ptr(dy), k * h * w, _ptr(w_dw), _ptr(dx), cin * h * w, _ptr(ws2),
                                  _ptr(dw_dw), _ptr(db_dw), n, cin, kpl, h, w, s), "smaat_dw3x3_bwd")
     if bnred is not None:
@@ -383,7 +388,8 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
 def _half_backward(x, w_dw, b_dw, w_pw, gamma, z, st, y_dw, dy, kpl, train_stats, has_bias, need_dx, pre_part=None,
                    bnred=None, in_aff=None):
     """-> (dx, dw_dw, db_dw, dw_pw, db_pw, dgamma, dbeta), red.  pre_part: this BatchNorm's backward sums
-    (from the following block's depthwise backward); bnred=(gamma_prev, beta_prev): emit the previous one's."""
+    (from the following block's depthwise backward); in_aff=(scale, shift) + bnred=(mean, invstd) of the PREVIOUS
+    BatchNorm: x is its input, the activation is applied on load and its backward sums are emitted (`red`)."""
     dz, dgamma, dbeta = _bn_bwd_raw(dy, z, st, gamma, True, train_stats, pre_part=pre_part)
     r = _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=y_dw, bnred=bnred, in_aff=in_aff)
     dx, dw_dw, db_dw, dw_pw = r[:4]
@@ -439,7 +445,8 @@ class _DoubleConvDS(torch.autograd.Function):
         # the second half's forward (depthwise stage) and its depthwise backward (strip kernel: W % 4 == 0),
         # and the weight gradient reads the kept depthwise output, not y1
         n, _, h, w = x.shape
-        fuse = FUSE_FIRST_ACTIVATION and keep_y and (w % 4 == 0) and h >= 4 and g1 is not None
+        fuse = (FUSE_FIRST_ACTIVATION and keep_y and g1 is not None
+                and bool(_lib.get().smaat_dw3x3_strip_ok(kpl, h, w)))
         y1, z1, st1, ydw1, ubs1 = _half_forward(x, w_dw1, b_dw1, w_pw1, b_pw1, g1, be1, rm1, rv1, tr1, mo1, eps1, kpl,
                                                 keep_y, want_act=not fuse)
         y2, z2, st2, ydw2, ubs2 = _half_forward(z1 if fuse else y1, w_dw2, b_dw2, w_pw2, b_pw2, g2, be2, rm2, rv2, tr2,
@@ -457,7 +464,8 @@ class _DoubleConvDS(torch.autograd.Function):
         (x, w_dw1, b_dw1, w_pw1, g1, be1, z1, st1, ydw1, y1, w_dw2, b_dw2, w_pw2, g2, z2, st2,
          ydw2) = ctx.saved_tensors
         gr2, red = _half_backward(z1 if ctx.fuse else y1, w_dw2, b_dw2, w_pw2, g2, z2, st2, ydw2, dy2, ctx.kpl,
-                                  ctx.train_stats[1], ctx.has_bias[1], True, bnred=(g1, be1),
+                                  ctx.train_stats[1], ctx.has_bias[1], True,
+                                  bnred=(st1[0], st1[1]) if ctx.fuse else None,
                                   in_aff=(st1[2], st1[3]) if ctx.fuse else None)
         gr1, _ = _half_backward(x, w_dw1, b_dw1, w_pw1, g1, z1, st1, ydw1, gr2[0], ctx.kpl, ctx.train_stats[0],
                                 ctx.has_bias[0], ctx.needs_input_grad[0], pre_part=red)
@@ -662,7 +670,7 @@ def _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, 
         nb = L.smaat_cbam_spconv_blocks(n, h, w)
         conv = _new(dev, n, 1, h, w)
         use_batch_stats = training or rm is None
-        part = _new(dev, 2, nb, 1)
+        part = _new(dev, 3, nb, 1)
         _lib.check(L.smaat_cbam_spconv(_ptr(maps), _ptr(wconv), ks, n, h, w, _ptr(conv), _ptr(part), s_),
                    "smaat_cbam_spconv")
         if use_batch_stats:

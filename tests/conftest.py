@@ -14,6 +14,35 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _gpu_unavailable_reason():
+    """None when the `gpu` tests can run here: a HIP device AND the in-tree library."""
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return "no HIP device (torch.cuda.is_available() is False)"
+    except Exception as e:  # noqa: BLE001
+        return f"torch import failed: {e}"
+    lib = os.path.join(ROOT, "smaat_unet_amd", "libsmaat_hip.so")
+    if not os.path.exists(lib):
+        return f"{lib} is not built (python -c 'import __graft_entry__ as g; g.build()')"
+    return None
+
+
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest tests` on a CPU box must be green: tests marked `gpu` are SKIPPED (not failed) when
+    there is no HIP device or the library is missing.  With SMAAT_REQUIRE_GPU=1 (the GPU box) they are never
+    skipped, so a missing device/library fails loudly instead of silently passing."""
+    if os.environ.get("SMAAT_REQUIRE_GPU") == "1":
+        return
+    reason = _gpu_unavailable_reason()
+    if reason is None:
+        return
+    skip = pytest.mark.skip(reason="gpu test: " + reason)
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

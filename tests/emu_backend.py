@@ -63,13 +63,23 @@ class EmuLib:
     # ------------------------------------------------------------------ pointwise family
     @staticmethod
     def _write_part(part, T, M, acc):
+        """BatchNorm partials of the raw accumulators, include/smaat_hip.h layout [3][T][M] = per-tile (mean, M2,
+        count): the emulation spreads the pixels of every image over two "tiles" (slots T-1 and 0 when T > 1) so
+        that the pairwise merge of smaat_bn_finalize is exercised; unused slots have count 0."""
         if part is None:
             return
-        pp = f32(part, 2 * T * M).reshape(2, T, M)
+        pp = f32(part, 3 * T * M).reshape(3, T, M)
         pp[:] = 0
-        a64 = acc.astype(np.float64)
-        pp[0, T - 1] = a64.sum(axis=(0, 2))
-        pp[1, T - 1] = (a64 * a64).sum(axis=(0, 2))
+        a64 = acc.astype(np.float64)  # [N][M][P]
+        P = a64.shape[2]
+        cut = P // 3 if T > 1 else 0
+        pieces = [(T - 1, a64[:, :, cut:])] + ([(0, a64[:, :, :cut])] if cut else [])
+        for slot, piece in pieces:
+            cnt = piece.shape[0] * piece.shape[2]
+            mean = piece.mean(axis=(0, 2))
+            pp[0, slot] = mean
+            pp[1, slot] = ((piece - mean[None, :, None]) ** 2).sum(axis=(0, 2))
+            pp[2, slot] = cnt
 
     # ------------------------------------------------------------------ bf16-split matrix path
     SPLIT_ENABLED = 1  # the CPU suite exercises the split wiring of ops.py; test_host_emu also runs it off
@@ -188,36 +198,39 @@ class EmuLib:
             f32(db_out, K)[:] = gb
         return 0
 
+    def smaat_dw3x3_strip_ok(self, kpl, H, W):
+        return 1 if (kpl in (1, 2, 4) and W % 4 == 0 and H >= 4) else 0
+
     def smaat_dw3x3_bwd_bnred(self, x, x_bs, in_scale, in_shift, dy, dy_bs, w_dw, dx, dx_bs, ws, dw_out, db_out,
-                              bn_gamma, bn_beta, rpart, N, Cin, kpl, H, W, stream):
-        if W % 4 or H < 4:
+                              bn_mean, bn_invstd, rpart, N, Cin, kpl, H, W, stream):
+        if not (dx and rpart and bn_mean and bn_invstd):
+            return -1
+        if not (in_scale and in_shift) or not self.smaat_dw3x3_strip_ok(kpl, H, W):
             return -2
         P = H * W
-        xin = np.array(planes(x, N, Cin, P, x_bs))
-        if in_scale:  # x holds z of the previous half: recompute the activation
-            sc, sh = f32(in_scale, Cin), f32(in_shift, Cin)
-            xin = np.maximum(xin * sc[None, :, None] + sh[None, :, None], 0).astype(np.float32)
-        xin = np.ascontiguousarray(xin)
+        zin = np.array(planes(x, N, Cin, P, x_bs))  # the PRE-BatchNorm tensor: the activation is recomputed
+        sc, sh = f32(in_scale, Cin), f32(in_shift, Cin)
+        xin = np.ascontiguousarray(np.maximum(zin * sc[None, :, None] + sh[None, :, None], 0).astype(np.float32))
         self.smaat_dw3x3_bwd(xin.ctypes.data, Cin * P, dy, dy_bs, w_dw, dx, dx_bs, ws, dw_out, db_out, N, Cin, kpl, H, W,
                              stream)
-        xv = xin.astype(np.float64)
-        g = np.array(planes(dx, N, Cin, P, dx_bs)).astype(np.float64) * (xv > 0)
-        gam = f32(bn_gamma, Cin).astype(np.float64) if bn_gamma else np.ones(Cin)
-        bet = f32(bn_beta, Cin).astype(np.float64) if bn_beta else np.zeros(Cin)
-        invg = np.where(gam != 0, 1.0 / np.where(gam != 0, gam, 1.0), 0.0)
+        g = np.array(planes(dx, N, Cin, P, dx_bs)).astype(np.float64) * (xin > 0)
+        mu = f32(bn_mean, Cin).astype(np.float64)
+        istd = f32(bn_invstd, Cin).astype(np.float64)
+        zhat = (zin.astype(np.float64) - mu[None, :, None]) * istd[None, :, None]  # as ATen: (z - mean) * invstd
         rows = N
         rp = f32(rpart, 2 * rows * Cin).reshape(2, rows, Cin)
         rp[:] = 0
         rp[0, rows - 1] = g.sum(axis=(0, 2))
-        rp[1, rows - 1] = (g * (xv - bet[None, :, None]) * invg[None, :, None]).sum(axis=(0, 2))
+        rp[1, rows - 1] = (g * zhat).sum(axis=(0, 2))
         return 0
 
     # ------------------------------------------------------------------ batch norm
     def smaat_bn_finalize(self, part, T, C, count, bias_shift, gamma, beta, eps, momentum, rm, rv, mean, invstd, scale,
                           shift, stream):
-        pp = f32(part, 2 * T * C).reshape(2, T, C).astype(np.float64)
-        m0 = pp[0].sum(0) / count
-        var = np.maximum(pp[1].sum(0) / count - m0 * m0, 0)
+        pp = f32(part, 3 * T * C).reshape(3, T, C).astype(np.float64)  # per-tile (mean, M2, count)
+        n = pp[2].sum(0)
+        m0 = (pp[2] * pp[0]).sum(0) / np.maximum(n, 1)
+        var = np.maximum((pp[1] + pp[2] * (pp[0] - m0[None]) ** 2).sum(0) / np.maximum(n, 1), 0)
         mu = m0 + (f32(bias_shift, C).astype(np.float64) if bias_shift else 0)
         istd = 1.0 / np.sqrt(var + eps)
         g = f32(gamma, C) if gamma else np.ones(C, np.float32)
@@ -373,10 +386,12 @@ class EmuLib:
         cv = O.conv2d_same_fwd(mp, f32(wc, 2 * ks * ks).reshape(1, 2, ks, ks))
         f32(conv, N * H * W)[:] = cv.reshape(-1)
         nb = 2 * N
-        pp = f32(part, 2 * nb).reshape(2, nb)
+        pp = f32(part, 3 * nb).reshape(3, nb)  # per-block (mean, M2, count)
         pp[:] = 0
-        pp[0, 1] = cv.astype(np.float64).sum()
-        pp[1, 1] = (cv.astype(np.float64) ** 2).sum()
+        c64 = cv.astype(np.float64)
+        pp[0, 1] = c64.mean()
+        pp[1, 1] = ((c64 - c64.mean()) ** 2).sum()
+        pp[2, 1] = c64.size
         return 0
 
     def smaat_cbam_gate(self, conv, scale, shift, total, gate, stream):

@@ -46,6 +46,16 @@ def both(case, *args, tol=1e-5, **kw):
     return res
 
 
+def part_stats(part):
+    """per-tile BatchNorm partials [3][T][C] = (mean, M2, count) -> (total count, mean, biased variance) per channel,
+    merged in fp64 exactly as include/smaat_hip.h specifies for smaat_bn_finalize"""
+    pp = part.double()
+    n = pp[2].sum(0)
+    mean = (pp[2] * pp[0]).sum(0) / n.clamp(min=1)
+    var = (pp[1] + pp[2] * (pp[0] - mean[None]) ** 2).sum(0) / n.clamp(min=1)
+    return n, mean, var
+
+
 def rnd(seed, *shape, scale=1.0):
     return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
 
@@ -62,14 +72,15 @@ def case_dsconv_fwd(L, dev, N, Cin, kpl, Cout, H, W, aff=False, pad_c=0, bias=Tr
     sh = T(rnd(7, Cin, scale=0.3), dev) if aff else None
     z = torch.full((N, Cout, H, W), float("nan"), device=dev)
     slots = L.smaat_pw_num_slots(N, H, W, Cout)
-    part = torch.full((2, slots, Cout), float("nan"), device=dev)
+    part = torch.full((3, slots, Cout), float("nan"), device=dev)
     y = torch.full((N, K, H, W), float("nan"), device=dev)
     xptr = x.data_ptr()
     rc = L.smaat_dsconv_fwd(xptr, x_bs, P(sc), P(sh), P(w_dw), P(b_dw) if bias else None, P(wt),
                             P(b_pw) if bias else None, P(z), Cout * H * W, P(part), P(y), N, Cin, kpl, Cout, H, W,
                             stream(dev))
     assert rc == 0
-    return dict(z=z, y=y, psum=part[0].double().sum(0), psq=part[1].double().sum(0))
+    pn, pmean, pvar = part_stats(part)
+    return dict(z=z, y=y, pn=pn, pmean=pmean, pvar=pvar)
 
 
 DS_SHAPES = [
@@ -107,12 +118,12 @@ def case_pointwise(L, dev, N, C, M, H, W, with_part=False):
     wt, b = T(rnd(2, C, M, scale=0.2), dev), T(rnd(3, M), dev)
     out = torch.full((N, M, H, W), float("nan"), device=dev)
     slots = L.smaat_pw_num_slots(N, H, W, M)
-    part = torch.zeros((2, slots, M), device=dev) if with_part else None
+    part = torch.zeros((3, slots, M), device=dev) if with_part else None
     assert L.smaat_pointwise_fwd(P(x), C * H * W, P(wt), P(b), P(out), M * H * W, P(part), N, C, M, H, W,
                                  stream(dev)) == 0
     r = dict(out=out)
     if with_part:
-        r["psum"] = part[0].double().sum(0)
+        r["pn"], r["pmean"], r["pvar"] = part_stats(part)
     return r
 
 
@@ -195,13 +206,12 @@ def case_pw_split(L, dev, N, C, M, H, W, with_part=False):
     assert L.smaat_split_planes(P(w), M, C, P(pl), stream(dev)) == 0
     out = torch.full((N, M, H, W), float("nan"), device=dev)
     slots = L.smaat_pw_split_num_slots(N, H, W)
-    part = torch.full((2, slots, M), float("nan"), device=dev) if with_part else None
+    part = torch.full((3, slots, M), float("nan"), device=dev) if with_part else None
     assert L.smaat_pointwise_fwd_split(P(x), C * H * W, P(pl), P(b), P(out), M * H * W, P(part), N, C, M, H, W,
                                        stream(dev)) == 0
     r = dict(out=out, planes=pl.to(torch.int32))
     if with_part:
-        r["psum"] = part[0].double().sum(0)
-        r["psq"] = part[1].double().sum(0)
+        r["pn"], r["pmean"], r["pvar"] = part_stats(part)
     return r
 
 
@@ -214,6 +224,43 @@ def case_pw_split(L, dev, N, C, M, H, W, with_part=False):
 def test_pointwise_fwd_split(shape):
     both(case_pw_split, *shape)
     both(case_pw_split, *shape, with_part=True)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 64, 32, 32), (2, 64, 128, 36, 36), (1, 16, 64, 2, 2), (3, 24, 70, 18, 18)])
+def test_bn_partials_keep_the_variance_under_a_large_mean(shape):
+    """per-tile (mean, M2, count) partials merged pairwise.  Outputs with |mean| = 1e3..1e4 x std
+    (sums of z and z^2 in f32 would lose the variance entirely) must still give the variance of the produced z to
+    1e-3 and the mean to 1e-6, in all three GEMM families."""
+    N, C, M, H, W = shape
+    L, dev = _lib.get(), torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(N, C, H, W, generator=g) * 1e-2 + 5.0).to(dev)    # mean 5, std 3e-3
+    w = (torch.rand(M, C, generator=g) * 0.5 + 0.75).to(dev)          # positive weights: |out mean| ~ 5 C, std ~ 2e-2
+    b = torch.randn(M, generator=g).to(dev)
+    Cp = (C + 15) // 16 * 16
+    pl = torch.empty((3, M, Cp), dtype=torch.int16, device=dev)
+    assert L.smaat_split_planes(P(w), M, C, P(pl), stream(dev)) == 0
+    outs = {}
+    z = torch.empty(N, M, H, W, device=dev)
+    part = torch.full((3, L.smaat_pw_split_num_slots(N, H, W), M), float("nan"), device=dev)
+    assert L.smaat_pointwise_fwd_split(P(x), C * H * W, P(pl), P(b), P(z), M * H * W, P(part), N, C, M, H, W,
+                                       stream(dev)) == 0
+    outs["split"] = (z.clone(), part)
+    z2 = torch.empty(N, M, H, W, device=dev)
+    part2 = torch.full((3, L.smaat_pw_num_slots(N, H, W, M), M), float("nan"), device=dev)
+    wt = w.t().contiguous()
+    assert L.smaat_pointwise_fwd(P(x), C * H * W, P(wt), P(b), P(z2), M * H * W, P(part2), N, C, M, H, W,
+                                 stream(dev)) == 0
+    outs["f32"] = (z2, part2)
+    torch.cuda.synchronize()
+    for name, (zz, pp) in outs.items():
+        n, mean, var = part_stats(pp)
+        raw = (zz - b[None, :, None, None]).double()
+        assert torch.equal(n, torch.full_like(n, N * H * W)), name
+        ref_mean, ref_var = raw.mean(dim=(0, 2, 3)), raw.var(dim=(0, 2, 3), unbiased=False)
+        assert ((mean - ref_mean).abs() / ref_mean.abs()).max().item() < 1e-6, name
+        assert (ref_mean.abs() / ref_var.sqrt()).min().item() > 1e3, "the case must be offset-dominated"
+        assert ((var - ref_var).abs() / ref_var).max().item() < 1e-3, (name, ((var - ref_var).abs() / ref_var).max())
 
 
 def case_dw_fwd(L, dev, N, Cin, kpl, H, W, bias=True, pad_c=0, aff=False):
@@ -240,24 +287,36 @@ def test_dw3x3_fwd(shape):
     both(case_dw_fwd, *shape, aff=True)
 
 
-def case_dw_bwd_bnred(L, dev, N, Cin, kpl, H, W, aff=False):
+def case_dw_bwd_bnred(L, dev, N, Cin, kpl, H, W, gamma_mode="normal"):
+    """x = the PRE-BatchNorm tensor z; y = relu(z*sc + sh) is recomputed on load and the kernel also reduces that
+    BatchNorm's backward sums with zhat = (z - mean) * invstd (valid for gamma == 0 / tiny gamma)"""
     K = Cin * kpl
-    # a post-ReLU activation, or (aff) the pre-BatchNorm tensor whose activation is recomputed on load
-    x = T(rnd(1, N, Cin, H, W) if aff else np.maximum(rnd(1, N, Cin, H, W) + 0.3, 0), dev)
-    sc = T(np.random.default_rng(8).uniform(0.5, 1.5, Cin).astype(np.float32), dev) if aff else None
-    sh = T(rnd(9, Cin, scale=0.3), dev) if aff else None
+    z = rnd(1, N, Cin, H, W) * 1.3 + 0.2
+    mean = z.mean(axis=(0, 2, 3)).astype(np.float32)
+    invstd = (1.0 / np.sqrt(z.var(axis=(0, 2, 3)) + 1e-5)).astype(np.float32)
+    gam = np.random.default_rng(8).uniform(0.5, 1.5, Cin).astype(np.float32)
+    if gamma_mode == "zero":
+        gam[::2] = 0.0            # a channel whose BatchNorm weight is exactly 0: y = relu(beta), dgamma still defined
+    elif gamma_mode == "tiny":
+        gam[:] = 1e-6             # |beta| >> |gamma * zhat|: (y - beta) / gamma would cancel
+    bet = (np.abs(rnd(9, Cin, scale=0.3)) + 0.05).astype(np.float32)  # positive: the gamma == 0 channels stay active
+    sc = (gam * invstd).astype(np.float32)
+    sh = (bet - mean * sc).astype(np.float32)
+    x, sc, sh, mean, invstd = T(z, dev), T(sc, dev), T(sh, dev), T(mean, dev), T(invstd, dev)
     dy = T(rnd(2, N, K, H, W), dev)
     w_dw = T(rnd(3, K, 9, scale=0.3), dev)
-    gam = T(np.random.default_rng(4).uniform(0.5, 1.5, Cin).astype(np.float32), dev)
-    bet = T(rnd(5, Cin, scale=0.3), dev)
     dx = torch.full((N, Cin, H, W), float("nan"), device=dev)
     rows = L.smaat_dw3x3_bwd_ws_rows(N, Cin, H, W)
     ws = torch.empty((rows, K, 10), device=dev)
     rpart = torch.full((2, rows - 1, Cin), float("nan"), device=dev)
     dw, db = torch.full((K, 9), float("nan"), device=dev), torch.full((K,), float("nan"), device=dev)
+    assert L.smaat_dw3x3_strip_ok(kpl, H, W) == 1
     rc = L.smaat_dw3x3_bwd_bnred(P(x), Cin * H * W, P(sc), P(sh), P(dy), K * H * W, P(w_dw), P(dx), Cin * H * W, P(ws),
-                                 P(dw), P(db), P(gam), P(bet), P(rpart), N, Cin, kpl, H, W, stream(dev))
+                                 P(dw), P(db), P(mean), P(invstd), P(rpart), N, Cin, kpl, H, W, stream(dev))
     assert rc == 0
+    # without the activation coefficients the fused form is refused (the caller runs the two kernels separately)
+    assert L.smaat_dw3x3_bwd_bnred(P(x), Cin * H * W, None, None, P(dy), K * H * W, P(w_dw), P(dx), Cin * H * W, P(ws),
+                                   P(dw), P(db), P(mean), P(invstd), P(rpart), N, Cin, kpl, H, W, stream(dev)) == -2
     return dict(dw=dw, db=db, dx=dx, r1=rpart[0].double().sum(0), r2=rpart[1].double().sum(0))
 
 
@@ -265,7 +324,42 @@ def case_dw_bwd_bnred(L, dev, N, Cin, kpl, H, W, aff=False):
                                    (2, 3, 2, 288, 288), (1, 4, 2, 100, 100), (1, 3, 4, 8, 12), (1, 5, 2, 10, 12)])
 def test_dw3x3_bwd_bnred(shape):
     both(case_dw_bwd_bnred, *shape, tol=2e-5)
-    both(case_dw_bwd_bnred, *shape, aff=True, tol=2e-5)
+
+
+@pytest.mark.parametrize("mode", ["zero", "tiny"])
+def test_dw3x3_bwd_bnred_degenerate_gamma(mode):
+    r = both(case_dw_bwd_bnred, 2, 8, 2, 36, 36, gamma_mode=mode, tol=2e-5)
+    assert np.abs(r["hip"]["r2"]).min() > 0  # sum g*zhat (= dgamma) is NOT silently zero on the gamma == 0 channels
+
+
+def test_dw3x3_strip_ok_matches_the_kernels():
+    """the exported predicate is what ops.py uses to leave the first activation unmaterialised: it must agree with
+    what the two strip kernels accept"""
+    L, dev = _lib.get(), torch.device("cuda:0")
+    for (kpl, H, W) in [(2, 32, 32), (1, 8, 8), (4, 8, 12), (2, 18, 18), (2, 6, 6), (3, 8, 8), (2, 3, 4), (2, 288, 288)]:
+        ok = L.smaat_dw3x3_strip_ok(kpl, H, W)
+        N, Cin = 1, 2
+        K = Cin * kpl
+        x = torch.randn(N, Cin, H, W, device=dev)
+        y = torch.empty(N, K, H, W, device=dev)
+        w = torch.randn(K, 9, device=dev)
+        sc, sh = torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev)
+        if kpl in (1, 2, 4):
+            rc_f = L.smaat_dw3x3_fwd(P(x), Cin * H * W, P(sc), P(sh), P(w), None, P(y), K * H * W, N, Cin, kpl, H, W,
+                                     stream(dev))
+        else:
+            rc_f = -2
+        rows = L.smaat_dw3x3_bwd_ws_rows(N, Cin, H, W)
+        ws, rp = torch.empty(rows, K, 10, device=dev), torch.empty(2, rows - 1, Cin, device=dev)
+        dx, dw, db = torch.empty_like(x), torch.empty(K, 9, device=dev), torch.empty(K, device=dev)
+        rc_b = L.smaat_dw3x3_bwd_bnred(P(x), Cin * H * W, P(sc), P(sh), P(y), K * H * W, P(w), P(dx), Cin * H * W, P(ws),
+                                       P(dw), P(db), P(sc), P(sc), P(rp), N, Cin, kpl, H, W, stream(dev)) \
+            if 1 <= kpl <= 4 else -2
+        torch.cuda.synchronize()
+        if ok:
+            assert rc_f == 0 and rc_b == 0, (kpl, H, W, rc_f, rc_b)
+        else:
+            assert rc_b in (-2, -1), (kpl, H, W, rc_b)
 
 
 def case_bn_eval(L, dev, C):
@@ -292,12 +386,18 @@ def case_bn(L, dev, N, C, H, W, relu=1, slice_pad=0):
     gamma = T(np.random.default_rng(2).uniform(0.5, 1.5, C).astype(np.float32), dev)
     beta = T(rnd(3, C, scale=0.2), dev)
     bias = T(rnd(4, C, scale=0.5), dev)
-    # partial sums of (z - bias) spread over 5 slots
-    zz = (z - bias[None, :, None, None]).double()
-    part = torch.zeros((2, 5, C), device=dev)
-    part[0, 1] = zz.sum(dim=(0, 2, 3)).float() * 0.25
-    part[0, 3] = zz.sum(dim=(0, 2, 3)).float() * 0.75
-    part[1, 4] = (zz * zz).sum(dim=(0, 2, 3)).float()
+    # per-tile partials (mean, M2, count) of (z - bias): three unequal "tiles" in slots 1, 3, 4 of 5 (0 and 2 empty)
+    zz = (z - bias[None, :, None, None]).double().flatten(2)  # [N][C][P]
+    part = torch.zeros((3, 5, C), device=dev)
+    cuts = [0, Pn // 4, Pn // 4 + max(Pn // 3, 1), Pn]
+    for slot, (a, b) in zip((1, 3, 4), zip(cuts[:-1], cuts[1:])):
+        piece = zz[:, :, a:b]
+        if piece.shape[2] == 0:
+            continue
+        m = piece.mean(dim=(0, 2))
+        part[0, slot] = m.float()
+        part[1, slot] = ((piece - part[0, slot].double()[None, :, None]) ** 2).sum(dim=(0, 2)).float()
+        part[2, slot] = float(N * (b - a))
     rm, rv = T(rnd(5, C, scale=0.1), dev), T(np.random.default_rng(6).uniform(0.5, 2, C).astype(np.float32), dev)
     st = torch.empty((4, C), device=dev)
     s = stream(dev)
@@ -394,7 +494,7 @@ def case_cbam(L, dev, N, C, H, W, ks=7, rr=16):
     maps = torch.empty((N, 2, H, W), device=dev)
     assert L.smaat_cbam_sppool(P(x), C * Pn, P(sc), N, C, Pn, P(maps), s) == 0
     nb = L.smaat_cbam_spconv_blocks(N, H, W)
-    conv, part = torch.empty((N, 1, H, W), device=dev), torch.empty((2, nb, 1), device=dev)
+    conv, part = torch.empty((N, 1, H, W), device=dev), torch.empty((3, nb, 1), device=dev)
     assert L.smaat_cbam_spconv(P(maps), P(wc), ks, N, H, W, P(conv), P(part), s) == 0
     st = torch.empty((4, 1), device=dev)
     assert L.smaat_bn_finalize(P(part), nb, 1, float(N * Pn), None, P(gamma), P(beta), 1e-5, 0.1, None, None,
@@ -428,7 +528,7 @@ def case_cbam(L, dev, N, C, H, W, ks=7, rr=16):
     dx_main = dx.clone()
     assert L.smaat_cbam_bwd_final(P(dx), C * Pn, P(davg), P(dmx), P(amax), N, C, Pn, s) == 0
     return dict(avg=avg, mx=mx, amax=amax.float(), ha=ha, hm=hm, sc=sc, maps=maps, conv=conv,
-                psum=part[0].double().sum(), psq=part[1].double().sum(), st=st, gate=gate, out=out, dbn=dbn,
+                pmean=part_stats(part)[1], pvar=part_stats(part)[2], st=st, gate=gate, out=out, dbn=dbn,
                 bsum=bpart.double().sum(1), dgamma=dgamma, dbeta=dbeta, coef=coef, dmaps=dmaps,
                 dwc=wpart.double().sum(0), dx_main=dx_main, ds=ds, pg=pg, davg=davg, dmx=dmx, dx=dx)
 
