@@ -128,3 +128,21 @@ def fill(keys, seed=0):
 
 def make_smaat_params(n_channels=12, n_classes=1, kpl=2, rr=16, seed=0):
     return fill(smaat_unet_keys(n_channels, n_classes, kpl, rr), seed)
+
+
+def synthetic_case(kind, n, c, h, w, n_classes, seed):
+    """Deterministic numpy inputs for the large golden cases (regenerated from the seed on both sides, so the
+    fixtures hold summaries only).  kind "precip": SURVEY 8(d) sparse radar frames + a dense target in [0, 0.3]
+    (reference loss models/regression_lightning.py:57-65); kind "voc": ImageNet-normalised-like images ~ N(0, 1)
+    and integer class maps (reference train_SmaAtUNet.py:178-183, utils/dataset_VOC.py:134-137)."""
+    rng = np.random.default_rng(seed)
+    if kind == "precip":
+        u = rng.random((n, c, h, w), dtype=np.float32)
+        x = np.where(u > 0.7, (u - 0.7) / 0.3 * 0.5, 0.0).astype(np.float32)
+        y = (rng.random((n, h, w), dtype=np.float32) * 0.3).astype(np.float32)
+        return x, y
+    if kind == "voc":
+        x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+        y = rng.integers(0, n_classes, (n, h, w)).astype(np.int64)
+        return x, y
+    raise ValueError(kind)

@@ -1,0 +1,234 @@
+"""Eval-mode parity and benchmark-size parity against fixtures the REAL reference produced
+(oracle/gen_golden.py: gen_ops_eval, gen_unet_big) -- VERDICT r1 "weak #1 / missing #7", ADVICE r1 (medium):
+
+  * every block in eval mode (random running statistics): output, input gradients, parameter gradients
+    (conv biases in front of an eval-mode BatchNorm DO have a gradient: covers the coef[1:].zero_() path);
+  * SmaAt_UNet at BASELINE.json's sizes -- 12->1 at 288x288 (configs[1]) and 3->21 at 256x256 with
+    CrossEntropyLoss (configs[4]) -- one training step (logits, loss, gradients, running statistics) and then the
+    eval-mode forward at batch n and batch 1 plus an eval-mode backward; the batch-1 forward is also replayed
+    as a captured hipGraph and compared with the eager launch and the fixture.
+
+CPU (`-m "not gpu"`): the same checks through the numpy emulation of the C ABI (small case) and the ATen port
+oracle/torch_ref.py pinned against the three big fixtures.  GPU (`-m gpu`): the HIP path.
+
+Tolerances: forward <= 1e-4 rel-L2 (north_star); eval-mode gradients <= 2e-3 per tensor; training gradients: error
+against the reference's fp64 anchors <= max(3 x the reference's own fp32-vs-fp64 error, 5e-3) per tensor
+(the reference disagrees with itself at 2e-3 .. 3e-2 end to end)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import smaat_unet_amd as S
+from oracle import params as oparams
+from tests.test_host_emu import check_summary, rel
+
+EVAL_BLOCKS = {
+    "doubleconv": lambda: S.DoubleConvDS(6, 16, kernels_per_layer=2),
+    "doubleconv_wide": lambda: S.DoubleConvDS(64, 128, kernels_per_layer=2),
+    "doubleconv_18": lambda: S.DoubleConvDS(8, 12, kernels_per_layer=2),
+    "down": lambda: S.DownDS(6, 12, kernels_per_layer=2),
+    "up_pad": lambda: S.UpDS(8, 4, bilinear=True, kernels_per_layer=2),
+    "spatt": lambda: S.SpatialAttention(kernel_size=7),
+    "cbam": lambda: S.CBAM(32, reduction_ratio=16),
+    "dsconv_k2": lambda: S.DepthwiseSeparableConv(6, 10, kernel_size=3, padding=1, kernels_per_layer=2),
+}
+BIG = ["unet_12x1_n3_64x48_eval", "unet_12x1_n2_288", "unet_3x21_n2_256"]
+
+
+def _zero_grad_key(k):
+    return ".double_conv." in "." + k and k.endswith(("depthwise.bias", "pointwise.bias"))
+
+
+def run_eval_block(ops_eval, tag, dev, tol_out=2e-5, tol_grad=3e-4):
+    mod = EVAL_BLOCKS[tag]()
+    pre = f"{tag}/param/"
+    mod.load_state_dict({k[len(pre):]: torch.from_numpy(ops_eval[k]) for k in ops_eval.files if k.startswith(pre)})
+    mod.to(dev).eval()
+    ins, i = [], 0
+    while f"{tag}/in{i}" in ops_eval.files:
+        ins.append(torch.from_numpy(ops_eval[f"{tag}/in{i}"]).to(dev).requires_grad_(True))
+        i += 1
+    out = mod(*ins)
+    assert rel(out.detach().cpu().numpy(), ops_eval[f"{tag}/out"]) < tol_out
+    (out * torch.from_numpy(ops_eval[f"{tag}/cot"]).to(dev)).sum().backward()
+    for i, x in enumerate(ins):
+        assert rel(x.grad.cpu().numpy(), ops_eval[f"{tag}/din{i}"]) < tol_grad, f"din{i}"
+    for k, p in mod.named_parameters():  # biases included
+        got, ref = p.grad.cpu().numpy(), ops_eval[f"{tag}/grad/{k}"]
+        if ref.size == 1:  # BN(1) affine of the spatial attention: ONE number summed over the whole map with heavy
+            # cancellation (here 2e-4 from terms of order 1): judged absolutely
+            assert abs(float(got.ravel()[0] - ref.ravel()[0])) < 5e-6, (k, got, ref)
+            continue
+        assert rel(got, ref) < tol_grad, k
+    for k, v in mod.state_dict().items():  # eval mode leaves the running statistics alone
+        if "running" in k:
+            assert np.array_equal(v.cpu().numpy(), ops_eval[f"{tag}/after/{k}"]), k
+        if "num_batches" in k:
+            assert int(v) == int(ops_eval[f"{tag}/after/{k}"])
+    with torch.no_grad():  # the no_grad forward (no tensors kept for backward) gives the same result
+        assert rel(mod(*[t.detach() for t in ins]).cpu().numpy(), ops_eval[f"{tag}/out"]) < tol_out
+
+
+def _loss(kind, logits, target, n):
+    if kind == "precip":  # reference models/regression_lightning.py:57-65
+        return torch.nn.functional.mse_loss(logits.squeeze(1), target, reduction="sum") / n
+    return torch.nn.functional.cross_entropy(logits, target)  # reference train_SmaAtUNet.py:183
+
+
+def big_inputs(meta):
+    a = (meta["kind"], meta["n"], meta["n_channels"], meta["h"], meta["w"], meta["n_classes"])
+    return oparams.synthetic_case(*a, meta["param_seed"] + 100), oparams.synthetic_case(*a, meta["param_seed"] + 200)
+
+
+def run_big(golden_dir, name, dev, graph=False, report=None):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    meta = json.loads(str(g["meta"]))
+    (x, target), (xe, te) = big_inputs(meta)
+    n, kind = meta["n"], meta["kind"]
+    P = oparams.make_smaat_params(meta["n_channels"], meta["n_classes"], 2, 16, meta["param_seed"])
+    model = S.SmaAt_UNet(meta["n_channels"], meta["n_classes"])
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in P.items()})
+    model.to(dev).train()
+    # ---- one training step ----
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    logits = model(xt)
+    e = check_summary(g, "train/logits", logits.detach().cpu().numpy())
+    assert e < 1e-4, ("train logits", e)
+    loss = _loss(kind, logits, torch.from_numpy(target).to(dev), n)
+    assert abs(loss.item() - float(g["train/loss"])) < 1e-4 * abs(float(g["train/loss"]))
+    loss.backward()
+    bad, table = [], {}
+    for k, p in model.named_parameters():
+        if _zero_grad_key(k):
+            continue
+        gk = p.grad.cpu().numpy()
+        ours = check_summary(g, "train/grad64/" + k, gk)
+        noise = float(g["train/noise/" + k])
+        table[k] = (ours, noise)
+        if ours > max(3.0 * noise, 5e-3):
+            bad.append((k, ours, noise))
+    if report is not None:
+        report["train"] = dict(logits=e, worst=max(table.items(), key=lambda kv: kv[1][0]),
+                               worst_ratio=max(table.items(), key=lambda kv: kv[1][0] / max(kv[1][1], 1e-6)))
+    assert not bad, bad[:6]
+    assert check_summary(g, "train/dx", xt.grad.cpu().numpy()) < 2e-2
+    sd = model.state_dict()
+    for k in g.files:
+        if k.startswith("train/after/"):
+            assert rel(sd[k[12:]].cpu().numpy(), g[k]) < 1e-4, k
+    # ---- eval mode on the running statistics of that step ----
+    model.eval()
+    model.zero_grad(set_to_none=True)
+    xb1 = torch.from_numpy(xe[:meta["n_eval"]]).to(dev)
+    with torch.no_grad():
+        out_b1 = model(xb1)
+    e1 = check_summary(g, "eval/logits_b1", out_b1.cpu().numpy())
+    assert e1 < 1e-4, ("eval logits batch 1", e1)
+    if graph:  # the same forward as ONE captured hipGraph launch (bench.py fwd_latency): replay == eager == fixture
+        with torch.no_grad():
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                model(xb1)
+            torch.cuda.current_stream().wait_stream(s)
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg):
+                y_static = model(xb1)
+            y_static.zero_()
+            cg.replay()
+            torch.cuda.synchronize()
+        assert torch.equal(y_static, out_b1), "hipGraph replay differs from the eager launch"
+        assert check_summary(g, "eval/logits_b1", y_static.cpu().numpy()) < 1e-4
+    xet = torch.from_numpy(xe).to(dev).requires_grad_(True)
+    le = model(xet)
+    e2 = check_summary(g, "eval/logits", le.detach().cpu().numpy())
+    assert e2 < 1e-4, ("eval logits", e2)
+    losse = _loss(kind, le, torch.from_numpy(te).to(dev), n)
+    assert abs(losse.item() - float(g["eval/loss"])) < 1e-4 * abs(float(g["eval/loss"]))
+    losse.backward()
+    worst = ("", 0.0)
+    for k, p in model.named_parameters():
+        ek = check_summary(g, "eval/grad/" + k, p.grad.cpu().numpy())
+        if ek > worst[1]:
+            worst = (k, ek)
+    if report is not None:
+        report["eval"] = dict(logits_b1=e1, logits=e2, worst_grad=worst)
+    assert worst[1] < 2e-3, worst
+    assert check_summary(g, "eval/dx", xet.grad.cpu().numpy()) < 2e-3
+    for k in g.files:  # eval mode did not move the running statistics
+        if k.startswith("train/after/"):
+            assert rel(model.state_dict()[k[12:]].cpu().numpy(), g[k]) < 1e-4, k
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+@pytest.fixture
+def _emu():
+    from tests import emu_backend
+    emu_backend.install()
+    yield
+    emu_backend.uninstall()
+
+
+@pytest.fixture(scope="module")
+def ops_eval(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops_eval.npz"))
+
+
+@pytest.mark.parametrize("tag", sorted(EVAL_BLOCKS))
+def test_eval_blocks_host_logic(ops_eval, tag, _emu):
+    run_eval_block(ops_eval, tag, torch.device("cpu"), tol_out=1e-5)
+
+
+def test_big_case_host_logic(golden_dir, _emu):
+    run_big(golden_dir, "unet_12x1_n3_64x48_eval", torch.device("cpu"))
+
+
+@pytest.mark.parametrize("name", BIG)
+def test_aten_port_pinned_to_big_goldens(golden_dir, name):
+    """oracle/torch_ref.py (the cpu_baseline leg of bench.py) against the reference at the benchmark sizes, train
+    and eval mode -- the same ATen operators, so agreement is at round-off level"""
+    from oracle import torch_ref
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    meta = json.loads(str(g["meta"]))
+    (x, target), (xe, _) = big_inputs(meta)
+    torch.set_num_threads(8)
+    P = torch_ref.params_from_numpy(oparams.make_smaat_params(meta["n_channels"], meta["n_classes"], 2, 16,
+                                                              meta["param_seed"]))
+    logits = torch_ref.forward(P, torch.from_numpy(x), training=True)
+    assert check_summary(g, "train/logits", logits.detach().numpy()) < 2e-5
+    loss = _loss(meta["kind"], logits, torch.from_numpy(target), meta["n"])
+    assert abs(loss.item() - float(g["train/loss"])) < 1e-5 * abs(float(g["train/loss"]))
+    for k in g.files:
+        if k.startswith("train/after/"):
+            assert rel(P[k[12:]].numpy(), g[k]) < 1e-5, k
+    with torch.no_grad():
+        le = torch_ref.forward(P, torch.from_numpy(xe), training=False)
+    assert check_summary(g, "eval/logits", le.numpy()) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", ["auto", "all"])
+@pytest.mark.parametrize("tag", sorted(EVAL_BLOCKS))
+def test_eval_blocks_gpu(ops_eval, tag, policy, monkeypatch):
+    from smaat_unet_amd import ops as _ops
+    monkeypatch.setattr(_ops, "SPLIT_POLICY", policy)
+    run_eval_block(ops_eval, tag, torch.device("cuda:0"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,policy", [(n, "auto") for n in BIG] + [("unet_12x1_n3_64x48_eval", "all"),
+                                                                      ("unet_12x1_n2_288", "all")])
+def test_big_cases_gpu(golden_dir, name, policy, monkeypatch):
+    from smaat_unet_amd import ops as _ops
+    monkeypatch.setattr(_ops, "SPLIT_POLICY", policy)
+    report = {}
+    try:
+        run_big(golden_dir, name, torch.device("cuda:0"), graph=True, report=report)
+    finally:
+        if os.path.isdir("gpurun_out"):
+            with open(f"gpurun_out/big_case_{name}_{policy}.json", "w") as f:
+                json.dump(report, f, indent=1, default=float)

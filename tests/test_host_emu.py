@@ -105,7 +105,10 @@ def check_summary(store, tag, arr):
     if tag + "#full" in store.files:
         ref = store[tag + "#full"]
         return np.linalg.norm(a.astype(np.float64) - ref) / max(float(store[tag + "#l2"]), 1e-30)
-    idx, ref = store[tag + "#idx"], store[tag + "#vals"]
+    ref = store[tag + "#vals"]
+    idx = store[tag + "#idx"] if tag + "#idx" in store.files else \
+        np.linspace(0, int(store[tag + "#n"]) - 1, ref.size).astype(np.int64)  # oracle/gen_golden.py summarize()
+    assert a.size == int(store[tag + "#n"]), (tag, a.shape)
     return np.linalg.norm(a.ravel()[idx].astype(np.float64) - ref) / max(np.linalg.norm(ref), 1e-30)
 
 
