@@ -174,6 +174,119 @@ def gen_ops_eval():
     print("ops_eval.npz:", len(s), "arrays")
 
 
+def _tie_margin(mod, xs64):
+    """smallest relative distance of any selection in `mod` (fp64 run) from a tie: |pre-ReLU value| / rms, gap between
+    the two largest entries of every MaxPool2d window / AdaptiveMaxPool2d plane / channel-max of SpatialAttention,
+    each divided by the rms of the tensor.  A fixture with margin >> fp32 round-off is the SAME function for every
+    correct fp32 implementation."""
+    margins = []
+
+    def rms(t):
+        return float(t.pow(2).mean().sqrt()) + 1e-30
+
+    def relu_pre(m, inp):
+        margins.append(float(inp[0].detach().abs().min()) / rms(inp[0].detach()))
+
+    def maxpool_pre(m, inp):
+        win = torch.nn.functional.unfold(inp[0].reshape(-1, 1, *inp[0].shape[2:]), 2, stride=2)  # [NC][4][L]
+        top = win.topk(2, dim=1).values
+        margins.append(float((top[:, 0] - top[:, 1]).min()) / rms(inp[0]))
+
+    def amax_pre(m, inp):
+        top = inp[0].flatten(2).topk(2, dim=2).values
+        margins.append(float((top[..., 0] - top[..., 1]).min()) / rms(inp[0]))
+
+    def spatt_pre(m, inp):
+        top = inp[0].topk(2, dim=1).values
+        margins.append(float((top[:, 0] - top[:, 1]).min()) / rms(inp[0]))
+    hooks = []
+    for m in mod.modules():
+        if isinstance(m, torch.nn.ReLU):
+            hooks.append(m.register_forward_pre_hook(relu_pre))
+        elif isinstance(m, torch.nn.MaxPool2d):
+            hooks.append(m.register_forward_pre_hook(maxpool_pre))
+        elif isinstance(m, torch.nn.AdaptiveMaxPool2d):
+            hooks.append(m.register_forward_pre_hook(amax_pre))
+        elif isinstance(m, SpatialAttention):
+            hooks.append(m.register_forward_pre_hook(spatt_pre))
+    mod(*xs64)
+    for hk in hooks:
+        hk.remove()
+    return min(margins) if margins else 1.0
+
+
+def module_case_strict(store, tag, make_mod, make_inputs, rng, margin=2e-4, max_tries=400):
+    """Tie-free block fixture with fp64 anchors (VERDICT r1 "next" 1c): parameters / inputs are redrawn until every
+    ReLU / max selection of the block is at least `margin` (relative to the rms of its tensor) away from a tie in an
+    fp64 run -- three orders of magnitude above fp32 round-off, so no correct fp32 implementation can take another
+    branch.  Stored: fp32 reference results, fp64 anchors and the reference's own fp32-vs-fp64 error per tensor.
+    tests/test_strict_blocks.py holds the HIP path to 2 x that error (floor: see the test)."""
+    for attempt in range(max_tries):
+        mod = make_mod()
+        mod.train()
+        randomize_(mod, rng)
+        inputs = make_inputs(rng)
+        m64 = make_mod()
+        m64.load_state_dict(mod.state_dict())
+        m64 = m64.double().train()
+        mg = _tie_margin(m64, [torch.from_numpy(a).double() for a in inputs])
+        if mg >= margin:
+            break
+    else:
+        raise RuntimeError(f"{tag}: no tie-free draw")
+    state0 = {k: v.clone() for k, v in mod.state_dict().items()}
+    for k, v in state0.items():
+        store[f"{tag}/param/{k}"] = t2n(v)
+    relv = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-30))  # noqa: E731
+    xs = [torch.from_numpy(a).requires_grad_(True) for a in inputs]
+    out = mod(*xs)
+    cot = torch.from_numpy(rng.standard_normal(tuple(out.shape)).astype(np.float32))
+    (out * cot).sum().backward()
+    m64 = make_mod()
+    m64.load_state_dict(state0)
+    m64 = m64.double().train()
+    xs64 = [torch.from_numpy(a).double().requires_grad_(True) for a in inputs]
+    out64 = m64(*xs64)
+    (out64 * cot.double()).sum().backward()
+    store[f"{tag}/out"], store[f"{tag}/out64"], store[f"{tag}/cot"] = t2n(out), t2n(out64), t2n(cot)
+    store[f"{tag}/noise/out"] = np.float64(relv(t2n(out), t2n(out64)))
+    store[f"{tag}/margin"] = np.float64(mg)
+    for i, (a, x, x64) in enumerate(zip(inputs, xs, xs64)):
+        store[f"{tag}/in{i}"] = a
+        store[f"{tag}/din64_{i}"] = t2n(x64.grad)
+        store[f"{tag}/noise/din{i}"] = np.float64(relv(t2n(x.grad), t2n(x64.grad)))
+    for (k, p), (_, p64) in zip(mod.named_parameters(), m64.named_parameters()):
+        store[f"{tag}/grad64/{k}"] = t2n(p64.grad)
+        store[f"{tag}/noise/grad/{k}"] = np.float64(relv(t2n(p.grad), t2n(p64.grad)))
+    print(f"  {tag}: margin {mg:.1e} after {attempt + 1} draws, worst fp32 noise",
+          max(float(v) for k, v in store.items() if k.startswith(f"{tag}/noise/")
+              and not k.endswith(("depthwise.bias", "pointwise.bias"))))  # (exact-zero gradients in front of a BatchNorm)
+
+
+def gen_ops_strict():
+    rng = np.random.default_rng(777)
+    s = {}
+    f32 = lambda r, *shape: r.standard_normal(shape).astype(np.float32)  # noqa: E731
+    pos = lambda r, *shape: (np.abs(r.standard_normal(shape)) + 0.05).astype(np.float32)  # noqa: E731
+    module_case_strict(s, "doubleconv_k2", lambda: DoubleConvDS(6, 16, kernels_per_layer=2),
+                       lambda r: [f32(r, 2, 6, 12, 12)], rng)
+    module_case_strict(s, "doubleconv_k1", lambda: DoubleConvDS(8, 8, kernels_per_layer=1),
+                       lambda r: [f32(r, 2, 8, 8, 8)], rng)
+    module_case_strict(s, "doubleconv_k4", lambda: DoubleConvDS(4, 16, kernels_per_layer=4),
+                       lambda r: [f32(r, 1, 4, 12, 8)], rng)
+    module_case_strict(s, "doubleconv_odd", lambda: DoubleConvDS(6, 10, mid_channels=12, kernels_per_layer=2),
+                       lambda r: [f32(r, 2, 6, 9, 11)], rng)               # W % 4 != 0: the non-strip kernels
+    module_case_strict(s, "down_k2", lambda: DownDS(6, 12, kernels_per_layer=2), lambda r: [f32(r, 2, 6, 16, 16)], rng)
+    module_case_strict(s, "up_k2", lambda: UpDS(16, 6, bilinear=True, kernels_per_layer=2),
+                       lambda r: [f32(r, 2, 8, 4, 6), f32(r, 2, 8, 8, 12)], rng)
+    module_case_strict(s, "up_pad_k4", lambda: UpDS(8, 4, bilinear=True, kernels_per_layer=4),
+                       lambda r: [f32(r, 1, 4, 4, 4), f32(r, 1, 4, 9, 10)], rng)
+    module_case_strict(s, "cbam_32", lambda: CBAM(32, reduction_ratio=16), lambda r: [pos(r, 2, 32, 8, 8)], rng)
+    module_case_strict(s, "cbam_64_rr8", lambda: CBAM(64, reduction_ratio=8), lambda r: [pos(r, 1, 64, 6, 6)], rng)
+    np.savez_compressed(os.path.join(OUT, "ops_strict.npz"), **s)
+    print("ops_strict.npz:", len(s), "arrays")
+
+
 def summarize(store, tag, arr, full_max=8192, nsample=4096, store_idx=True):
     """small tensors in full; large ones as l2 norm + sum + `nsample` evenly spaced samples (the sample positions
     are np.linspace(0, size - 1, nsample) -- stored, or with store_idx=False recomputed by the reader)"""
@@ -405,6 +518,93 @@ def gen_variant(name, cbams, kpl, n_channels, n_classes, n, h, w, seed):
     print(name, "arrays", len(s), "logits l2", float(np.linalg.norm(s["logits"])), "worst fp32-vs-fp64 grad", worst)
 
 
+def _variant_grads(model, x, cot, dtype):
+    model = model.to(dtype).train()
+    for p in model.parameters():
+        p.grad = None
+    xt = torch.from_numpy(x).to(dtype).requires_grad_(True)
+    logits = model(xt)
+    (logits * torch.from_numpy(cot).to(dtype)).sum().backward()
+    return t2n(logits), t2n(xt.grad), {k: t2n(p.grad) for k, p in model.named_parameters()}
+
+
+def gen_variant_strict(name, cbams, kpl, n_channels, n_classes, n, h, w, seed0, max_tries=200, draws=8):
+    """Sibling-network fixture with fp64 anchors and a MEASURED noise floor.
+    End-to-end gradients of these small random-parameter networks are not a smooth function of round-off: an
+    activation within ~1e-5 (relative) of zero, or a max-pool / CBAM-max near-tie, takes the other branch under
+    any change of summation order, and ONE flipped element moves a gradient tensor by 1e-4 .. 4e-3 -- in the
+    reference itself as well (measured below).  A fixture cannot be searched free of such elements at the fp32
+    noise level of the forward pass (~1e-5 on the logits for the reference AND for the HIP path): there are
+    ~4e5 activations per case.  So the fixture
+      (a) is searched (input seed) for a case whose fp32 reference gradients sit within 1e-4 of the fp64 ones on
+          every tensor, with 8 threads and with 1 thread: the stored fp32/fp64 tensors themselves contain no flip;
+      (b) records what the reference's gradients do under perturbations of the size of fp32 forward noise:
+          `draws` fp64 runs on x * (1 + 1e-6 n); per tensor the largest relative change ("sens/<key>") and the
+          largest over all tensors ("sens_global").
+    tests/test_host_emu.py::run_variant holds every tensor of the HIP path (against the fp64 anchors) to
+    2 x sens_global: the error of ONE flip anywhere in the reference -- no percentile, no minimum over references."""
+    keys = oparams.unetds_keys(n_channels, n_classes, kpl, 16, cbams)
+    zero = lambda k: ".double_conv." in k and k.endswith(("depthwise.bias", "pointwise.bias"))  # noqa: E731
+    relv = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-30))  # noqa: E731
+    for seed in range(seed0, seed0 + max_tries):
+        P = oparams.fill(keys, seed)
+        rng = np.random.default_rng(seed + 100)
+        u = rng.random((n, n_channels, h, w), dtype=np.float32)
+        x = np.where(u > 0.6, (u - 0.6) / 0.4, 0).astype(np.float32)
+        cot = rng.standard_normal((n, n_classes, h, w)).astype(np.float32)
+
+        def fresh():
+            m = _RefVariant(n_channels, n_classes, kpl, cbams)
+            load_np_state(m, P)
+            return m
+        torch.set_num_threads(8)
+        lg32, dx32, g32 = _variant_grads(fresh(), x, cot, torch.float32)
+        _, dx64, g64 = _variant_grads(fresh(), x, cot, torch.float64)
+        noise = {k: relv(g32[k], g64[k]) for k in g32 if not zero(k)}
+        if max(noise.values()) > 1e-4:
+            continue
+        torch.set_num_threads(1)
+        _, _, g32b = _variant_grads(fresh(), x, cot, torch.float32)
+        torch.set_num_threads(8)
+        if max(relv(g32b[k], g64[k]) for k in noise) > 1e-4:
+            continue
+        break
+    else:
+        raise RuntimeError(f"{name}: no flip-free fp32 reference run in {max_tries} seeds")
+    sens = {k: 0.0 for k in noise}
+    sens_dx = 0.0
+    for _ in range(draws):
+        xp = x.astype(np.float64) * (1 + 1e-6 * rng.standard_normal(x.shape))
+        m64 = fresh().double().train()
+        xpt = torch.from_numpy(xp).requires_grad_(True)
+        (m64(xpt) * torch.from_numpy(cot).double()).sum().backward()
+        for k, p in m64.named_parameters():
+            if k in sens:
+                sens[k] = max(sens[k], relv(p.grad.numpy(), g64[k]))
+        sens_dx = max(sens_dx, relv(xpt.grad.numpy(), dx64))
+    model = fresh().train()
+    model(torch.from_numpy(x))  # running statistics after one step
+    s = {"x": x, "cot": cot, "logits": lg32,
+         "meta": np.array(json.dumps(dict(n_channels=n_channels, n_classes=n_classes, n=n, h=h, w=w, kpl=kpl,
+                                          cbams=cbams, param_seed=seed, strict=True))),
+         "sens_global": np.float64(max(max(sens.values()), sens_dx))}
+    summarize(s, "dx", dx32, 1024, 1024)
+    summarize(s, "dx64", dx64.astype(np.float32), 1024, 1024)
+    s["noise/dx"] = np.float64(relv(dx32, dx64))
+    for k in g32:
+        summarize(s, "grad/" + k, g32[k], 1024, 1024)
+        summarize(s, "grad64/" + k, g64[k].astype(np.float32), 1024, 1024)
+        s["noise/" + k] = np.float64(relv(g32[k], g64[k]))
+        if k in sens:
+            s["sens/" + k] = np.float64(sens[k])
+    for k, v in model.state_dict().items():
+        if "running" in k:
+            s["after/" + k] = t2n(v)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **s)
+    print(name, "seed", seed, "worst fp32-vs-fp64 grad", max(noise.values()), "sens_global", float(s["sens_global"]),
+          "median sens", float(np.median(list(sens.values()))), "arrays", len(s))
+
+
 def gen_metrics():
     """tests/golden/precip_metrics.npz from the reference's own PrecipitationMetrics
     (/root/reference/metric/precipitation_metrics.py).  `torchmetrics` is not installed; the class only uses
@@ -474,6 +674,7 @@ if __name__ == "__main__":
     gen_keys()
     gen_ops()
     gen_ops_eval()
+    gen_ops_strict()
     # benchmark-size cases, train + eval mode (inputs regenerated from the seed, summaries only)
     gen_unet_big("unet_12x1_n2_288", "precip", 12, 1, 2, 288, 288, 7)        # BASELINE configs[1] shape
     gen_unet_big("unet_3x21_n2_256", "voc", 3, 21, 2, 256, 256, 8)           # BASELINE configs[4] shape, CE loss
@@ -482,8 +683,10 @@ if __name__ == "__main__":
     gen_unet("unet_12x1_n2_64x48", 12, 1, 2, 64, 48, "mse", 1)
     gen_unet("unet_3x21_n1_32", 3, 21, 1, 32, 32, "cot", 2)
     # sibling networks: no attention / four CBAMs, kernels_per_layer 1, 2 and 4;
-    # 48 x 40: the width is not a multiple of 16, so UpDS has to F.pad (unet_parts_depthwise_separable.py:78-81)
-    gen_variant("unetds_k2_n2_32", 0, 2, 12, 1, 2, 32, 32, 3)
-    gen_variant("unetds_k1_n1_48x40", 0, 1, 5, 2, 1, 48, 40, 4)
-    gen_variant("unetds4cbam_k2_n2_32", 4, 2, 12, 1, 2, 32, 32, 5)
-    gen_variant("unetds_k4_n1_32", 0, 4, 3, 2, 1, 32, 32, 6)
+    # 48 x 40: the width is not a multiple of 16, so UpDS has to F.pad (unet_parts_depthwise_separable.py:78-81).
+    # Tie-free fixtures (gen_variant_strict), incl. the four-CBAM network at kernels_per_layer = 4
+    gen_variant_strict("strict_unetds_k2_n2_32", 0, 2, 12, 1, 2, 32, 32, 1000)
+    gen_variant_strict("strict_unetds_k1_n1_48x40", 0, 1, 5, 2, 1, 48, 40, 2000)
+    gen_variant_strict("strict_unetds_k4_n1_32", 0, 4, 3, 2, 1, 32, 32, 3000)
+    gen_variant_strict("strict_unetds4cbam_k2_n2_32", 4, 2, 12, 1, 2, 32, 32, 4000)
+    gen_variant_strict("strict_unetds4cbam_k4_n1_32", 4, 4, 3, 2, 1, 32, 32, 5000)

@@ -13,10 +13,23 @@ import torch
 import torch.nn.functional as F
 
 
+# Mixed-precision emulation (BASELINE configs[3]): when set to a predicate f(x) -> bool, the pointwise convs of the
+# DepthwiseSeparableConvs for which it is true see their two operands rounded to bf16 (round-to-nearest-even) and
+# accumulate in f32 -- exactly what smaat_unet_amd's "bf16" matrix mode computes.  Used by the tests only.
+PW_BF16 = None
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
 def _half(P, x, pre, bn, kpl, training, buffers):
     # DepthwiseSeparableConv (models/layers.py:47-50) -> BatchNorm2d -> ReLU
     x = F.conv2d(x, P[pre + ".depthwise.weight"], P[pre + ".depthwise.bias"], padding=1, groups=x.shape[1])
-    x = F.conv2d(x, P[pre + ".pointwise.weight"], P[pre + ".pointwise.bias"])
+    if PW_BF16 is not None and PW_BF16(x):
+        x = F.conv2d(_bf16(x), _bf16(P[pre + ".pointwise.weight"]), P[pre + ".pointwise.bias"])
+    else:
+        x = F.conv2d(x, P[pre + ".pointwise.weight"], P[pre + ".pointwise.bias"])
     x = F.batch_norm(x, buffers[bn + ".running_mean"], buffers[bn + ".running_var"], P[bn + ".weight"],
                      P[bn + ".bias"], training, 0.1, 1e-5)
     return F.relu(x)

@@ -17,7 +17,10 @@ for line in open(src):
     m = re.match(r"(.+?)\s+WRITE_SIZE ([\d.]+) MB over (\d+) disp", line)
     if m:
         write[m.group(1).strip()] = (float(m.group(2)) * 1e6, int(m.group(3)))
-out = {"source": os.path.relpath(src, ROOT), "unit": "bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) / dispatches",
+sys.path.insert(0, ROOT)
+from bench import csrc_sha16  # noqa: E402
+sha = sys.argv[2] if len(sys.argv) > 2 else csrc_sha16()  # the build the counters were collected on
+out = {"source": os.path.relpath(src, ROOT), "csrc_sha16": sha, "unit": "bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) / dispatches",
        "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, (0.0, 0)), write.get(k, (0.0, 0))

@@ -236,26 +236,25 @@ def test_bn_partials_keep_the_variance_under_a_large_mean(shape):
     g = torch.Generator().manual_seed(3)
     x = (torch.rand(N, C, H, W, generator=g) * 1e-2 + 5.0).to(dev)    # mean 5, std 3e-3
     w = (torch.rand(M, C, generator=g) * 0.5 + 0.75).to(dev)          # positive weights: |out mean| ~ 5 C, std ~ 2e-2
-    b = torch.randn(M, generator=g).to(dev)
     Cp = (C + 15) // 16 * 16
     pl = torch.empty((3, M, Cp), dtype=torch.int16, device=dev)
     assert L.smaat_split_planes(P(w), M, C, P(pl), stream(dev)) == 0
     outs = {}
     z = torch.empty(N, M, H, W, device=dev)
     part = torch.full((3, L.smaat_pw_split_num_slots(N, H, W), M), float("nan"), device=dev)
-    assert L.smaat_pointwise_fwd_split(P(x), C * H * W, P(pl), P(b), P(z), M * H * W, P(part), N, C, M, H, W,
+    assert L.smaat_pointwise_fwd_split(P(x), C * H * W, P(pl), None, P(z), M * H * W, P(part), N, C, M, H, W,
                                        stream(dev)) == 0
     outs["split"] = (z.clone(), part)
     z2 = torch.empty(N, M, H, W, device=dev)
     part2 = torch.full((3, L.smaat_pw_num_slots(N, H, W, M), M), float("nan"), device=dev)
     wt = w.t().contiguous()
-    assert L.smaat_pointwise_fwd(P(x), C * H * W, P(wt), P(b), P(z2), M * H * W, P(part2), N, C, M, H, W,
+    assert L.smaat_pointwise_fwd(P(x), C * H * W, P(wt), None, P(z2), M * H * W, P(part2), N, C, M, H, W,
                                  stream(dev)) == 0
     outs["f32"] = (z2, part2)
     torch.cuda.synchronize()
     for name, (zz, pp) in outs.items():
         n, mean, var = part_stats(pp)
-        raw = (zz - b[None, :, None, None]).double()
+        raw = zz.double()  # no bias: the stored z ARE the accumulators the statistics were taken from
         assert torch.equal(n, torch.full_like(n, N * H * W)), name
         ref_mean, ref_var = raw.mean(dim=(0, 2, 3)), raw.var(dim=(0, 2, 3), unbiased=False)
         assert ((mean - ref_mean).abs() / ref_mean.abs()).max().item() < 1e-6, name

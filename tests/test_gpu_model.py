@@ -73,8 +73,15 @@ def test_module_vs_reference_golden(ops, tag, ctor, zb):
 
 @pytest.mark.parametrize("name", VARIANTS)
 def test_sibling_networks_vs_reference_golden(golden_dir, name):
-    """UNetDS / UNetDSAttention4CBAMs, kernels_per_layer 1, 2, 4, a size that needs the UpDS padding"""
-    run_variant(golden_dir, name, DEV)
+    """UNetDS / UNetDSAttention4CBAMs, kernels_per_layer 1, 2, 4, a size that needs the UpDS padding: tie-free
+    fixtures, every gradient tensor within max(2 x reference-fp32 error, 1e-4) of the fp64 anchors"""
+    report = {}
+    try:
+        run_variant(golden_dir, name, DEV, report=report)
+    finally:
+        if os.path.isdir("gpurun_out"):
+            with open(f"gpurun_out/variant_{name}.json", "w") as f:
+                json.dump(report, f, indent=1, default=float)
 
 
 def _load_model(meta):
@@ -213,19 +220,27 @@ def test_full_size_properties():
     assert torch.isfinite(tot).all() and tot.abs().sum().item() > 0
 
 
-def test_bf16_mixed_precision_mode():
+def test_bf16_mixed_precision_mode(ops):
     """BASELINE configs[3]: pointwise GEMMs with bf16 operands / f32 accumulation (ops.set_matrix_mode("bf16")).
-    Per-op error is the bf16 rounding class (2-3e-3 against fp64, checked here on one layer).  End to end this
-    randomly initialised net amplifies per-op errors by ~60-150x (f32: 1e-7 per op -> 1.5e-5 on the logits,
-    SURVEY 8c), so the logits are only required to stay within 30 % of the f32 path, the loss within 5 %, and a
-    few Adam steps must still reduce the loss."""
+    SURVEY 8(c)(5) asks ~1e-2 against the fp32 oracle.  That bound holds where the error is the bf16 rounding class
+    and is checked there:
+      (1) one GEMM against fp64: 5e-4 .. 5e-3 (the rounding class, not more and not less);
+      (2) every DoubleConvDS / DownDS / UpDS block against the reference's fp32 goldens: output <= 1e-2, gradients
+          <= 3e-2;
+      (3) the whole network against the fp32 ATen port with the SAME operand rounding emulated
+          (oracle/torch_ref.py PW_BF16): logits <= 1e-2, loss <= 1e-3 -- the path computes what "bf16 operands,
+          f32 accumulation" means and nothing else.
+    Against the plain fp32 oracle the whole randomly initialised network amplifies ANY per-op error by 60-150x
+    (f32: 1e-7 per op -> 1.5e-5 on the logits), so bf16 rounding (3e-3 per op) lands at 0.1-0.3 there:
+    that figure is reported in gpurun_out/bf16_mode.json, not asserted."""
+    from oracle import torch_ref
     from smaat_unet_amd import ops as K
     meta = dict(n_channels=12, n_classes=1, param_seed=3)
-    xn, yn = O.synthetic_precip(2, 12, 288, 288, seed=11)
+    xn, yn = O.synthetic_precip(2, 12, 64, 64, seed=11)
     x, y = torch.from_numpy(xn).to(DEV), torch.from_numpy(yn).to(DEV)
 
     def run(steps=1):
-        model, _ = _load_model(meta)
+        model, P = _load_model(meta)
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
         first, losses = None, []
         for _ in range(steps):
@@ -238,12 +253,13 @@ def test_bf16_mixed_precision_mode():
             assert all(torch.isfinite(p.grad).all() for p in model.parameters())
             opt.step()
             losses.append(loss.item())
-        return first, losses
+        return first, losses, P
 
-    ref_out, ref_losses = run()
+    ref_out, ref_losses, P = run()
     prev = K.set_matrix_mode("bf16")
+    report = {}
     try:
-        # one layer against fp64: the bf16 rounding class, not more and not less
+        # (1) one layer against fp64
         g = torch.Generator().manual_seed(0)
         xa = torch.randn(2, 256, 36, 36, generator=g).to(DEV)
         w = (torch.randn(128, 256, generator=g) * 0.1).to(DEV)
@@ -252,14 +268,34 @@ def test_bf16_mixed_precision_mode():
         ref = torch.einsum("mk,nkp->nmp", w.double(), xa.double().flatten(2)).view(2, 128, 36, 36)
         e_op = ((z.double() - ref).norm() / ref.norm()).item()
         assert 5e-4 < e_op < 5e-3, e_op
-        out, losses = run(steps=4)
+        # (2) blocks against the fp32 goldens of the reference
+        for tag, ctor in (("doubleconv", lambda: S.DoubleConvDS(6, 16, kernels_per_layer=2)),
+                          ("down", lambda: S.DownDS(6, 12, kernels_per_layer=2)),
+                          ("up", lambda: S.UpDS(16, 6, bilinear=True, kernels_per_layer=2))):
+            run_case(ops, tag, ctor(), tol_out=1e-2, tol_grad=3e-2)
+        # (3) the network against the fp32 oracle with the same operand rounding
+        out, losses, _ = run(steps=4)
+        torch_ref.PW_BF16 = lambda t: t.shape[-1] % 4 == 0  # the layers the split kernels take (ops._split_all)
+        try:
+            Pt = torch_ref.params_from_numpy(P, requires_grad=False)
+            with torch.no_grad():
+                emu = torch_ref.forward(Pt, torch.from_numpy(xn), training=True)
+            loss_emu = (torch.nn.functional.mse_loss(emu.squeeze(1), torch.from_numpy(yn), reduction="sum") / 2).item()
+        finally:
+            torch_ref.PW_BF16 = None
+        report = dict(per_op_vs_fp64=e_op, logits_vs_bf16_emulating_oracle=rel(out, emu.numpy()),
+                      logits_vs_fp32_path=rel(out, ref_out), loss=losses[0], loss_emulated=loss_emu,
+                      loss_fp32=ref_losses[0])
+        assert report["logits_vs_bf16_emulating_oracle"] < 1e-2, report
+        assert abs(losses[0] - loss_emu) < 1e-3 * abs(loss_emu), report
+        assert report["logits_vs_fp32_path"] > 1e-5                      # the mode really rounds
+        assert losses[-1] < losses[0], losses
     finally:
         K.set_matrix_mode(prev)
-    e = rel(out, ref_out)
-    assert 1e-5 < e < 0.3, e
-    assert abs(losses[0] - ref_losses[0]) < 5e-2 * abs(ref_losses[0])
-    assert losses[-1] < losses[0], losses
-    again, _ = run()                     # back on the default path: bit-identical to the first f32 run
+        if os.path.isdir("gpurun_out"):
+            with open("gpurun_out/bf16_mode.json", "w") as f:
+                json.dump(report, f, indent=1, default=float)
+    again, _, _ = run()                  # back on the default path: bit-identical to the first f32 run
     assert np.array_equal(again, ref_out)
 
 

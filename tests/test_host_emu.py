@@ -145,12 +145,19 @@ def test_unet(golden_dir, name, policy, monkeypatch):
     assert int(sd["inc.double_conv.1.num_batches_tracked"]) == 1
 
 
-VARIANTS = ["unetds_k2_n2_32", "unetds_k1_n1_48x40", "unetds_k4_n1_32", "unetds4cbam_k2_n2_32"]
+VARIANTS = ["strict_unetds_k2_n2_32", "strict_unetds_k1_n1_48x40", "strict_unetds_k4_n1_32",
+            "strict_unetds4cbam_k2_n2_32", "strict_unetds4cbam_k4_n1_32"]
 
 
-def run_variant(golden_dir, name, dev="cpu", hooked=False):
-    """sibling networks (reference models/unet_precip_regression_lightning.py:86-118, :167-208) against the
-    goldens produced from the reference's own blocks (oracle/gen_golden.py gen_variant)."""
+def run_variant(golden_dir, name, dev="cpu", hooked=False, report=None):
+    """sibling networks (reference models/unet_precip_regression_lightning.py:86-118, :167-208) against fixtures
+    produced from the reference's own blocks, with fp64 anchors and a measured noise floor
+    (oracle/gen_golden.py gen_variant_strict).  These networks flip individual ReLU / max selections under any
+    perturbation of the size of fp32 forward round-off, the reference included, and one flip moves a gradient
+    tensor by up to `sens_global` (1e-3 .. 1e-2, recorded per fixture from eight perturbed fp64 runs of the
+    reference).  Criterion: EVERY gradient tensor within 2 x sens_global of the fp64 anchor -- no percentile, no
+    minimum over references; kernel arithmetic itself is held to 2 x the reference's own fp32
+    error by the tie-free block fixtures (tests/test_strict_blocks.py)."""
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     meta = json.loads(str(g["meta"]))
     cls = {0: S.UNetDS, 4: S.UNetDSAttention4CBAMs}[meta["cbams"]]
@@ -169,22 +176,22 @@ def run_variant(golden_dir, name, dev="cpu", hooked=False):
     assert rel(logits.detach().cpu().numpy(), g["logits"]) < 1e-4
     (logits * torch.from_numpy(g["cot"]).to(dev)).sum().backward()
     zero_grad = lambda k: ".double_conv." in k and k.endswith(("depthwise.bias", "pointwise.bias"))  # noqa: E731
-    # End-to-end gradients of these small random-parameter networks are NOT a smooth function of round-off:
-    # near-ties (max-pool / CBAM max selections, ReLU masks on 8x8 .. 32x32 maps of ONE or two frames) flip
-    # between implementations.  The reference's own fp32 run is 3-4e-2 from its fp64 run on the affected
-    # tensors and 2e-5 after a 1e-7 input perturbation (same function, no flip); the HIP path shows the same
-    # bimodal picture (profiles/r1/r1q/variant_gradient_errors.txt).  This test is therefore a WIRING check:
-    # three quarters of the tensors within the usual 2e-2 of the closer reference (fp32 or fp64), none beyond
-    # 0.25 (a wrong skip / channel order gives O(1) everywhere); kernel accuracy is pinned by the per-op tests.
-    errs = {}
+    bound = float(g["sens_global"])
+    bad, table = [], {}
     for k, p in model.named_parameters():
-        if zero_grad(k):
-            continue
         gk = p.grad.cpu().numpy()
-        errs[k] = min(check_summary(g, "grad/" + k, gk), check_summary(g, "grad64/" + k, gk))
-    v = np.array(sorted(errs.values()))
-    assert v[int(0.75 * (len(v) - 1))] < 2e-2 and v[-1] < 0.25, sorted(errs.items(), key=lambda t: -t[1])[:5]
-    assert check_summary(g, "dx", x.grad.cpu().numpy()) < 2e-2
+        if zero_grad(k):  # a conv bias in front of a train-mode BatchNorm: the true gradient is exactly 0
+            wn = float(g["grad64/" + k.replace("bias", "weight") + "#l2"])
+            assert np.abs(gk).max() <= 1e-3 * wn + 1e-5, k
+            continue
+        ours, noise = check_summary(g, "grad64/" + k, gk), float(g["noise/" + k])
+        table[k] = (ours, noise, float(g["sens/" + k]))
+        if ours > 2.0 * bound:
+            bad.append((k, ours, noise))
+    if report is not None:
+        report.update(per_tensor=table, worst=max(table.items(), key=lambda kv: kv[1][0]), sens_global=bound)
+    assert not bad, (bound, sorted(bad, key=lambda t: -t[1])[:6])
+    assert check_summary(g, "dx64", x.grad.cpu().numpy()) < 2.0 * bound
     sd = model.state_dict()
     for k in g.files:
         if k.startswith("after/"):
@@ -197,7 +204,7 @@ def test_sibling_networks(golden_dir, name):
 
 
 def test_sibling_network_modular_wiring(golden_dir):
-    run_variant(golden_dir, "unetds4cbam_k2_n2_32", hooked=True)
+    run_variant(golden_dir, "strict_unetds4cbam_k2_n2_32", hooked=True)
 
 
 def test_sibling_network_hparams_constructor():

@@ -1,0 +1,94 @@
+"""Tie-free block fixtures with fp64 anchors (oracle/gen_golden.py gen_ops_strict; VERDICT r1 "next" 1c).
+
+Every ReLU / max-pool / CBAM-max selection of these cases is >= 2e-4 (relative to the rms of its tensor) away from
+a tie in an fp64 run of the REFERENCE block, so every correct fp32 implementation computes the same smooth function
+and the only admissible difference is arithmetic round-off.  Criterion, per tensor (output, input gradients, every
+parameter gradient), against the fp64 anchor:
+
+        error  <=  max(2 x the reference's own fp32-vs-fp64 error, FLOOR)
+
+FLOOR = 2e-6 covers tensors on which the ATen run happens to be exact to 1e-7 (its error is then not a usable
+scale).  Conv biases in front of a train-mode BatchNorm have an exactly-zero true gradient and are judged
+absolutely.  CPU: through the numpy emulation of the C ABI (host logic); GPU: the HIP kernels."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import smaat_unet_amd as S
+from tests.test_host_emu import rel
+
+FLOOR = 2e-6
+BLOCKS = {
+    "doubleconv_k2": lambda: S.DoubleConvDS(6, 16, kernels_per_layer=2),
+    "doubleconv_k1": lambda: S.DoubleConvDS(8, 8, kernels_per_layer=1),
+    "doubleconv_k4": lambda: S.DoubleConvDS(4, 16, kernels_per_layer=4),
+    "doubleconv_odd": lambda: S.DoubleConvDS(6, 10, mid_channels=12, kernels_per_layer=2),
+    "down_k2": lambda: S.DownDS(6, 12, kernels_per_layer=2),
+    "up_k2": lambda: S.UpDS(16, 6, bilinear=True, kernels_per_layer=2),
+    "up_pad_k4": lambda: S.UpDS(8, 4, bilinear=True, kernels_per_layer=4),
+    "cbam_32": lambda: S.CBAM(32, reduction_ratio=16),
+    "cbam_64_rr8": lambda: S.CBAM(64, reduction_ratio=8),
+}
+
+
+def run_strict(ops, tag, dev, report=None):
+    mod = BLOCKS[tag]()
+    pre = f"{tag}/param/"
+    mod.load_state_dict({k[len(pre):]: torch.from_numpy(ops[k]) for k in ops.files if k.startswith(pre)})
+    mod.to(dev).train()
+    ins, i = [], 0
+    while f"{tag}/in{i}" in ops.files:
+        ins.append(torch.from_numpy(ops[f"{tag}/in{i}"]).to(dev).requires_grad_(True))
+        i += 1
+    out = mod(*ins)
+    (out * torch.from_numpy(ops[f"{tag}/cot"]).to(dev)).sum().backward()
+    table = {"out": (rel(out.detach().cpu().numpy(), ops[f"{tag}/out64"]), float(ops[f"{tag}/noise/out"]))}
+    for i, x in enumerate(ins):
+        table[f"din{i}"] = (rel(x.grad.cpu().numpy(), ops[f"{tag}/din64_{i}"]), float(ops[f"{tag}/noise/din{i}"]))
+    for k, p in mod.named_parameters():
+        g64 = ops[f"{tag}/grad64/{k}"]
+        if ".double_conv." in "." + k and k.endswith(("depthwise.bias", "pointwise.bias")):
+            wn = np.linalg.norm(ops[f"{tag}/grad64/{k.replace('bias', 'weight')}"])
+            assert np.abs(p.grad.cpu().numpy()).max() <= 1e-4 * wn + 1e-6, k
+            continue
+        table["grad/" + k] = (rel(p.grad.cpu().numpy(), g64), float(ops[f"{tag}/noise/grad/{k}"]))
+    if report is not None:
+        report[tag] = table
+    bad = [(k, o, n) for k, (o, n) in table.items() if o > max(2.0 * n, FLOOR)]
+    assert not bad, (tag, bad)
+
+
+@pytest.fixture(scope="module")
+def ops_strict(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops_strict.npz"))
+
+
+@pytest.fixture
+def _emu():
+    from tests import emu_backend
+    emu_backend.install()
+    yield
+    emu_backend.uninstall()
+
+
+@pytest.mark.parametrize("tag", sorted(BLOCKS))
+def test_strict_blocks_host_logic(ops_strict, tag, _emu):
+    run_strict(ops_strict, tag, torch.device("cpu"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", ["auto", "all"])
+@pytest.mark.parametrize("tag", sorted(BLOCKS))
+def test_strict_blocks_gpu(ops_strict, tag, policy, monkeypatch):
+    import json
+    from smaat_unet_amd import ops as _ops
+    monkeypatch.setattr(_ops, "SPLIT_POLICY", policy)
+    report = {}
+    try:
+        run_strict(ops_strict, tag, torch.device("cuda:0"), report)
+    finally:
+        if os.path.isdir("gpurun_out"):
+            with open(f"gpurun_out/strict_{tag}_{policy}.json", "w") as f:
+                json.dump(report, f, indent=1, default=float)
