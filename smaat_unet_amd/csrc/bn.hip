@@ -7,8 +7,8 @@
 // ---------------------------------------------------------------------------------
 // finalize forward statistics: per-tile partials part[3][T][C] = (mean_t, M2_t, n_t) of (z - shift_bias)
 // (common.h "BatchNorm partial statistics") -> per channel.  The tiles are merged in fp64 with the pairwise
-// update  M2 = sum_t M2_t + n_t (mean_t - mean)^2  in two passes over the (L2-resident) partials: no
-// E[z^2] - E[z]^2 anywhere, so the variance keeps its accuracy when |mean| >> std.
+// update  M2 = sum_t M2_t + n_t (mean_t - mean)^2, evaluated in one pass about a shift taken from the data: no
+// E[z^2] - E[z]^2 of raw values anywhere, so the variance keeps its accuracy when |mean| >> std.
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ double block_sum_f64(double v, double* red) {
     red[threadIdx.x] = v;
@@ -33,22 +33,40 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ p
     const float* pm = part + c;
     const float* pq = part + (long)T * C + c;
     const float* pn = part + 2L * T * C + c;
-    double n = 0.0, s = 0.0;
-    for (int t = threadIdx.x; t < T; t += 256) {
+    // ONE pass, in fp64, about the shift K = mean of tile 0 (a value inside the data range, so the final
+    // s2 - s1^2 / N has no cancellation beyond the spread of the tile means):
+    //   N = sum n_t,  s1 = sum n_t (m_t - K),  s2 = sum [M2_t + n_t (m_t - K)^2]
+    const double K = (double)pm[0];
+    double n = 0.0, s1 = 0.0, s2 = 0.0;
+    int t = threadIdx.x;
+    for (; t + 768 < T; t += 1024) {  // four independent loads of each row in flight
+        double nn[4], dd[4], qq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long o = (long)(t + 256 * u) * C;
+            nn[u] = (double)pn[o];
+            dd[u] = (double)pm[o] - K;
+            qq[u] = (double)pq[o];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            n += nn[u];
+            s1 += nn[u] * dd[u];
+            s2 += qq[u] + nn[u] * dd[u] * dd[u];
+        }
+    }
+    for (; t < T; t += 256) {
         const double nt = (double)pn[(long)t * C];
+        const double d = (double)pm[(long)t * C] - K;
         n += nt;
-        s += nt * (double)pm[(long)t * C];
+        s1 += nt * d;
+        s2 += (double)pq[(long)t * C] + nt * d * d;
     }
     const double ntot = block_sum_f64(n, red);
-    const double stot = block_sum_f64(s, red);
-    const double m0 = ntot > 0.0 ? stot / ntot : 0.0;
-    double q = 0.0;
-    for (int t = threadIdx.x; t < T; t += 256) {
-        const double nt = (double)pn[(long)t * C];
-        const double d = (double)pm[(long)t * C] - m0;
-        q += (double)pq[(long)t * C] + nt * d * d;
-    }
-    const double qtot = block_sum_f64(q, red);
+    const double s1t = block_sum_f64(s1, red);
+    const double s2t = block_sum_f64(s2, red);
+    const double m0 = ntot > 0.0 ? K + s1t / ntot : 0.0;
+    const double qtot = ntot > 0.0 ? s2t - s1t * s1t / ntot : 0.0;
     if (threadIdx.x == 0) {
         double var = ntot > 0.0 ? qtot / ntot : 0.0;
         if (var < 0.0) var = 0.0;

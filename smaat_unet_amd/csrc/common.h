@@ -75,27 +75,32 @@ __device__ __forceinline__ float block_sum_t0(float v, float* red) {
 //
 // bn_wave_partials: the 32 lanes of a half-wave hold PXT x 32 pixels of row (r & 3) + 8 (r >> 2) + 4 half of
 // each 32-row tile ct (the 32x32 MFMA C layout).  Writes, for every row of the wave tile, (S1, S2, shift)
-// about the shift to sp[0 / COT / 2 COT + row]; returns the number of valid pixels of the wave.
+// about the shift (the row's value in lane `fl` of the half) to sp[0 / COT / 2 COT + row].
 #define BN_STAT_FLOATS(WPX, COT) ((WPX) * 3 * (COT) + 8)  // LDS floats: [WPX][3][COT] wave partials + [8] pixel counts
-template <int CT, int PXT>
-__device__ __forceinline__ int bn_wave_partials(const f32x16 (&acc)[CT][PXT], const bool (&pval)[PXT], int l31,
-                                                int half, float* sp, int COT) {
-    // first valid pixel of pt = 0 (lanes l and l + 32 hold the same pixel) and the pixel count of the wave
-    const unsigned long long b0 = __ballot(pval[0]);
-    const unsigned lo = (unsigned)b0;
-    const int fl = lo ? __builtin_ctz(lo) : 0;
+// pixel count of a wave tile and its first valid pixel of pt = 0 from the validity masks (2-D tiles; lanes l and
+// l + 32 hold the same pixel).  Kernels with flattened tiles compute both arithmetically instead.
+template <int PXT>
+__device__ __forceinline__ int bn_wave_count(const bool (&pval)[PXT], int& fl) {
+    const unsigned lo = (unsigned)__ballot(pval[0]);
+    fl = lo ? __builtin_ctz(lo) : 0;
     int n = __builtin_popcount(lo);
 #pragma unroll
     for (int pt = 1; pt < PXT; ++pt) n += __builtin_popcount((unsigned)__ballot(pval[pt]));
+    return n;
+}
+
+template <int CT, int PXT>
+__device__ __forceinline__ void bn_wave_partials(const f32x16 (&acc)[CT][PXT], const bool (&pval)[PXT], int l31,
+                                                 int half, float* sp, int COT, int fl) {
+    // the shift of a row = its value in lane fl of this half, fetched with ds_bpermute (crossbar only, result in a
+    // VGPR: v_readlane would park 64 values in SGPRs and push the kernel's scalar registers into spills)
+    const int baddr = (fl + (half << 5)) << 2;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float a0 = acc[ct][0][r];
-            const float sh_lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a0), fl));
-            const float sh_hi =
-                __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a0), fl + 32));
-            const float sh = half ? sh_hi : sh_lo;
+            const float sh = __builtin_bit_cast(
+                float, __builtin_amdgcn_ds_bpermute(baddr, __builtin_bit_cast(int, acc[ct][0][r])));
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int pt = 0; pt < PXT; ++pt) {
@@ -113,33 +118,38 @@ __device__ __forceinline__ int bn_wave_partials(const f32x16 (&acc)[CT][PXT], co
             }
         }
     }
-    return n;
 }
 
-// merge the WPX wave partials of one row into the tile's (mean, M2, n); stat = [WPX][3][COT], cnt = [WPX]
+// merge the WPX wave partials of one row into the tile's (mean, M2, n); stat = [WPX][3][COT], cnt = [WPX].
+// Two passes over <= 4 waves; v_rcp_f32 (1 ulp) is ample: it only scales deviations from a shift that is itself a
+// sample of the row.
 template <int WPX>
 __device__ __forceinline__ void bn_tile_combine(const float* stat, const int* cnt, int COT, int col, float& mean,
                                                 float& m2, float& n) {
-    mean = 0.f;
-    m2 = 0.f;
-    n = 0.f;
+    // branch-free (no per-wave predicates kept in scalar registers): an empty wave has s1 = s2 = 0 and a finite
+    // shift (its accumulators come from clamped, valid loads), and enters every sum with weight n_w = 0
+    float nw[WPX], mw[WPX], qw[WPX];
+    float nt = 0.f, sm = 0.f;
 #pragma unroll
     for (int w = 0; w < WPX; ++w) {
-        const float nw = (float)cnt[w];
-        if (nw > 0.f) {
-            const float* sp = stat + w * 3 * COT + col;
-            const float s1 = sp[0], s2 = sp[COT], sh = sp[2 * COT];
-            const float inv = 1.f / nw;
-            const float mw = sh + s1 * inv;
-            float m2w = s2 - s1 * s1 * inv;
-            m2w = m2w > 0.f ? m2w : 0.f;
-            const float nt = n + nw;
-            const float delta = mw - mean;
-            mean += delta * (nw / nt);
-            m2 += m2w + delta * delta * (n * nw / nt);
-            n = nt;
-        }
+        nw[w] = (float)cnt[w];
+        const float* sp = stat + w * 3 * COT + col;
+        const float s1 = sp[0], s2 = sp[COT], sh = sp[2 * COT];
+        const float inv = __builtin_amdgcn_rcpf(fmaxf(nw[w], 1.f));
+        mw[w] = fmaf(s1, inv, sh);
+        qw[w] = fmaxf(fmaf(-s1 * inv, s1, s2), 0.f);
+        nt += nw[w];
+        sm = fmaf(nw[w], mw[w] - mw[0], sm);  // about the first wave's mean (wave 0 holds the tile's first pixel)
     }
+    mean = fmaf(sm, __builtin_amdgcn_rcpf(fmaxf(nt, 1.f)), mw[0]);
+    float q = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPX; ++w) {
+        const float d = mw[w] - mean;
+        q += fmaf(nw[w] * d, d, qw[w]);
+    }
+    m2 = q;
+    n = nt;
 }
 
 // ---- pixel-tile geometry ---------------------------------------------------------

@@ -319,7 +319,9 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
         bool pval[PXT];
 #pragma unroll
         for (int pt = 0; pt < PXT; ++pt) pval[pt] = off[pt] >= 0;
-        const int nw = bn_wave_partials<CT, PXT>(acc, pval, l31, half, stat + wpx * 3 * COT + wco * CT * 32, COT);
+        int fl;
+        const int nw = bn_wave_count<PXT>(pval, fl);
+        bn_wave_partials<CT, PXT>(acc, pval, l31, half, stat + wpx * 3 * COT + wco * CT * 32, COT, fl);
         if (lane == 0) ((int*)(stat + WPX * 3 * COT))[wpx] = nw;
         __syncthreads();
         for (int col = tid; col < COT; col += SMAAT_THREADS) {
@@ -695,7 +697,9 @@ __global__ __launch_bounds__(256 + NPT) void k_pwgemm_ws(const PwArgs a) {
             bool pval[PXT];
 #pragma unroll
             for (int pt = 0; pt < PXT; ++pt) pval[pt] = off[pt] >= 0;
-            const int nw = bn_wave_partials<CT, PXT>(acc, pval, l31, half, stat + wpx * 3 * COT + wco * CT * 32, COT);
+            int fl;
+            const int nw = bn_wave_count<PXT>(pval, fl);
+            bn_wave_partials<CT, PXT>(acc, pval, l31, half, stat + wpx * 3 * COT + wco * CT * 32, COT, fl);
             if (lane == 0) ((int*)(stat + WPX * 3 * COT))[wpx] = nw;
         }
     }
@@ -999,7 +1003,9 @@ __global__ __launch_bounds__(256 + NPT) void k_dsconv_strip(const PwArgs a) {
             bool pval[PXT];
 #pragma unroll
             for (int pt = 0; pt < PXT; ++pt) pval[pt] = off[pt] >= 0;
-            const int nw = bn_wave_partials<CT, PXT>(acc, pval, l31, half, stat + wpx * 3 * COT + wco * CT * 32, COT);
+            int fl;
+            const int nw = bn_wave_count<PXT>(pval, fl);
+            bn_wave_partials<CT, PXT>(acc, pval, l31, half, stat + wpx * 3 * COT + wco * CT * 32, COT, fl);
             if (lane == 0) ((int*)(stat + WPX * 3 * COT))[wpx] = nw;
         }
     }

@@ -559,7 +559,10 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
             bool pval[PXT];
 #pragma unroll
             for (int pt = 0; pt < PXT; ++pt) pval[pt] = off[pt] >= 0;
-            const int nw = bn_wave_partials<CT, PXT>(acc, pval, l31, half, stat + wpx * 3 * COT + wco * CT * 32, COT);
+            // flattened tiles: the valid pixels of the wave are a prefix of its PXT x 32 pixels
+            int nw = a.P - (p0 + wpx * PXT * 32);
+            nw = nw < 0 ? 0 : (nw > PXT * 32 ? PXT * 32 : nw);
+            bn_wave_partials<CT, PXT>(acc, pval, l31, half, stat + wpx * 3 * COT + wco * CT * 32, COT, 0);
             if (lane == 0) ((int*)(stat + WPX * 3 * COT))[wpx] = nw;
         }
     }
@@ -889,7 +892,9 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
             }
             if (a.part) {
                 float* sb = stat + (k & 1) * STSZ;
-                const int nw = bn_wave_partials<CT, PXT>(acc, pval, l31, half, sb + wpx * 3 * COT + wco * CT * 32, COT);
+                int nw = a.P - (p0 + wpx * PXT * 32);  // flattened tiles: the valid pixels are a prefix
+                nw = nw < 0 ? 0 : (nw > PXT * 32 ? PXT * 32 : nw);
+                bn_wave_partials<CT, PXT>(acc, pval, l31, half, sb + wpx * 3 * COT + wco * CT * 32, COT, 0);
                 if (lane == 0) ((int*)(sb + WPX * 3 * COT))[wpx] = nw;
                 prev_ptg = ptg;
                 prev_co0 = co0;
