@@ -92,15 +92,27 @@ __device__ __forceinline__ int bn_wave_count(const bool (&pval)[PXT], int& fl) {
 template <int CT, int PXT>
 __device__ __forceinline__ void bn_wave_partials(const f32x16 (&acc)[CT][PXT], const bool (&pval)[PXT], int l31,
                                                  int half, float* sp, int COT, int fl) {
-    // the shift of a row = its value in lane fl of this half, fetched with ds_bpermute (crossbar only, result in a
-    // VGPR: v_readlane would park 64 values in SGPRs and push the kernel's scalar registers into spills)
-    const int baddr = (fl + (half << 5)) << 2;
+    // The shift of a row = its value at the first valid pixel (lane fl of each half).  It is handed to the other
+    // lanes through the wave's own shift row of the stat buffer (written by two lanes, read back by all 64: LDS
+    // operations of ONE wave execute in issue order, so no barrier is involved).  v_readlane would park 2 x 32
+    // values in SGPRs (the persistent GEMM is at the scalar-register limit: spills), and ds_bpermute of consecutive
+    // accumulator registers was miscompiled by hipcc 7.2 (every row got the shift of row 0).
+    float* shp = sp + 2 * COT;
+    if (l31 == fl) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) shp[ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = acc[ct][0][r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float sh = __builtin_bit_cast(
-                float, __builtin_amdgcn_ds_bpermute(baddr, __builtin_bit_cast(int, acc[ct][0][r])));
+            const int rc = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float sh = shp[rc];
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int pt = 0; pt < PXT; ++pt) {
@@ -111,10 +123,8 @@ __device__ __forceinline__ void bn_wave_partials(const f32x16 (&acc)[CT][PXT], c
             s = half32_sum_hi(s);
             q = half32_sum_hi(q);
             if (l31 == 16 + r) {
-                const int rc = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 sp[rc] = s;
                 sp[COT + rc] = q;
-                sp[2 * COT + rc] = sh;
             }
         }
     }
