@@ -26,3 +26,15 @@ pq = part[1].double().sum(0)
 print("M2 kernel", pq[:6].tolist()); print("M2 ref   ", m2[:6].tolist())
 ref = torch.einsum("mc,cp->mp", w.double(), x.double().flatten(2)[0])
 print("z vs fp64 GEMM (ulps):", ((zz-ref)/7.63e-6)[:3].tolist())
+# the same through the split kernel
+Cp = (C + 15) // 16 * 16
+pl = torch.empty((3, M, Cp), dtype=torch.int16, device=dev)
+assert L.smaat_split_planes(P(w), M, C, P(pl), st) == 0
+z2 = torch.empty(N, M, H, W, device=dev)
+part2 = torch.full((3, L.smaat_pw_split_num_slots(N, H, W), M), float("nan"), device=dev)
+assert L.smaat_pointwise_fwd_split(P(x), C*H*W, P(pl), None, P(z2), M*H*W, P(part2), N, C, M, H, W, st) == 0
+torch.cuda.synchronize()
+zz2 = z2.double().flatten(2)[0]
+m2b = ((zz2 - zz2.mean(1)[:, None])**2).sum(1)
+print("split: M2 kernel", part2[1].double().sum(0)[:6].tolist()); print("split: M2 ref   ", m2b[:6].tolist())
+print("f32 vs split stored z, max ulps:", ((zz - zz2).abs().max() / 7.63e-6).item())

@@ -97,35 +97,63 @@ __device__ __forceinline__ void bn_wave_partials(const f32x16 (&acc)[CT][PXT], c
     // operations of ONE wave execute in issue order, so no barrier is involved).  v_readlane would park 2 x 32
     // values in SGPRs (the persistent GEMM is at the scalar-register limit: spills), and ds_bpermute of consecutive
     // accumulator registers was miscompiled by hipcc 7.2 (every row got the shift of row 0).
-    float* shp = sp + 2 * COT;
+    // Register r of tile ct is row ct*32 + (r & 3) + 8 (r >> 2) + 4 half: registers 4g .. 4g+3 are four consecutive
+    // rows -> 16-byte LDS accesses.
+    float* shp = sp + 2 * COT + 4 * half;
     if (l31 == fl) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) shp[ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = acc[ct][0][r];
+            for (int g = 0; g < 4; ++g)
+                *(float4*)(shp + ct * 32 + 8 * g) = make_float4(acc[ct][0][4 * g], acc[ct][0][4 * g + 1],
+                                                                acc[ct][0][4 * g + 2], acc[ct][0][4 * g + 3]);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int l15 = l31 & 15;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
+        float sh[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *(const float4*)(shp + ct * 32 + 8 * g);
+            sh[4 * g] = v.x;
+            sh[4 * g + 1] = v.y;
+            sh[4 * g + 2] = v.z;
+            sh[4 * g + 3] = v.w;
+        }
+        // 16-lane (DPP row) sums of every register; lane (16 k + j) keeps the sum of register j: after the loop the
+        // two DPP rows of a half hold the two halves of each row's total, combined by ONE xor-16 swizzle.
+        float ts = 0.f, tq = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int rc = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float sh = shp[rc];
-            float s = 0.f, q = 0.f;
+            float s, q;
+            {
+                const float d = pval[0] ? acc[ct][0][r] - sh[r] : 0.f;
+                s = d;
+                q = d * d;
+            }
 #pragma unroll
-            for (int pt = 0; pt < PXT; ++pt) {
-                const float d = pval[pt] ? acc[ct][pt][r] - sh : 0.f;
+            for (int pt = 1; pt < PXT; ++pt) {
+                const float d = pval[pt] ? acc[ct][pt][r] - sh[r] : 0.f;
                 s += d;
                 q = fmaf(d, d, q);
             }
-            s = half32_sum_hi(s);
-            q = half32_sum_hi(q);
-            if (l31 == 16 + r) {
-                sp[rc] = s;
-                sp[COT + rc] = q;
-            }
+            s = row16_sum(s);
+            q = row16_sum(q);
+            int lr = l15;
+            asm volatile("" : "+v"(lr));  // a fresh compare per row: 16 hoisted lane masks would cost 32 SGPRs (spills)
+            const bool mine = lr == r;
+            ts = mine ? s : ts;
+            tq = mine ? q : tq;
+        }
+        ts += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, ts), 0x401F));  // lane ^ 16
+        tq += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, tq), 0x401F));
+        if (l31 < 16) {
+            const int rc = ct * 32 + (l31 & 3) + 8 * (l31 >> 2) + 4 * half;
+            sp[rc] = ts;
+            sp[COT + rc] = tq;
         }
     }
 }
