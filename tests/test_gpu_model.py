@@ -26,7 +26,7 @@ def ops(golden_dir):
     return np.load(os.path.join(golden_dir, "ops.npz"))
 
 
-def run_case(ops, tag, mod, tol_out=2e-5, tol_grad=3e-4, zero_bias=True):
+def run_case(ops, tag, mod, tol_out=2e-5, tol_grad=3e-4, zero_bias=True, tol_stat=1e-5):
     pre = f"{tag}/param/"
     mod.load_state_dict({k[len(pre):]: torch.from_numpy(ops[k]) for k in ops.files if k.startswith(pre)})
     mod.to(DEV).train()
@@ -48,7 +48,7 @@ def run_case(ops, tag, mod, tol_out=2e-5, tol_grad=3e-4, zero_bias=True):
         assert rel(p.grad.cpu().numpy(), ref) < tol_grad, k
     for k, v in mod.state_dict().items():
         if "running" in k:
-            assert rel(v.cpu().numpy(), ops[f"{tag}/after/{k}"]) < 1e-5, k
+            assert rel(v.cpu().numpy(), ops[f"{tag}/after/{k}"]) < tol_stat, k
 
 
 @pytest.mark.parametrize("tag,ctor,zb", [
@@ -272,7 +272,7 @@ def test_bf16_mixed_precision_mode(ops):
         for tag, ctor in (("doubleconv", lambda: S.DoubleConvDS(6, 16, kernels_per_layer=2)),
                           ("down", lambda: S.DownDS(6, 12, kernels_per_layer=2)),
                           ("up", lambda: S.UpDS(16, 6, bilinear=True, kernels_per_layer=2))):
-            run_case(ops, tag, ctor(), tol_out=1e-2, tol_grad=0.15)
+            run_case(ops, tag, ctor(), tol_out=1e-2, tol_grad=0.15, tol_stat=1e-2)
         # (3) the network against the fp32 oracle with the same operand rounding
         out, losses, _ = run(steps=4)
         torch_ref.PW_BF16 = lambda t: t.shape[-1] % 4 == 0  # the layers the split kernels take (ops._split_all)
