@@ -193,6 +193,20 @@ int smaat_dw3x3_fwd(const float* x, long x_bs, const float* in_scale, const floa
 int smaat_pointwise_fwd_split(const float* x, long x_bs, const void* planes, const float* bias, float* out,
                               long out_bs, float* part, int N, int Cin, int M, int H, int W, void* stream);
 
+/* ---- fused DepthwiseSeparableConv forward on the bf16-split matrix pipe (training path of the plane-dominated
+ *      layers; same reference call site as smaat_dsconv_fwd, models/layers.py:47-50).  The depthwise output never
+ *      goes through HBM: producer waves stage the halo tile, run the 3x3 stage and write bf16 split planes straight
+ *      into the GEMM's B operand image.  Arguments as smaat_dsconv_fwd, except that the pointwise weight is given as
+ *      split planes (smaat_split_planes of pointwise.weight [Cout][K]); part: nullable
+ *      [3][smaat_dsconv_split_num_slots(N,H,W)][Cout]; y_out: nullable side output (depthwise result, for the streamed
+ *      weight gradient).  Returns -2 when the shape is not handled (kernels_per_layer != 2, W % 16 != 0, H < 4 ...):
+ *      run smaat_dw3x3_fwd + smaat_pointwise_fwd_split instead.  smaat_dsconv_split_num_slots returns 0 for such shapes.
+ */
+int smaat_dsconv_split_num_slots(int N, int H, int W);
+int smaat_dsconv_fwd_split(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                           const float* b_dw, const void* planes, const float* b_pw, float* z, long z_bs, float* part,
+                           float* y_out, int N, int Cin, int kpl, int Cout, int H, int W, void* stream);
+
 /* ---- on-device PrecipitationMetrics.update ---------------------------------------------
  * replaces metric/precipitation_metrics.py:37-95 (called every train/val/test step, models/regression_lightning.py:
  * 75,86,94): NaN check, sum (p-t)^2 / batch, sum (p*f - t*f)^2 / batch, and the 4-bin confusion counts of

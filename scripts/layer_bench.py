@@ -54,7 +54,7 @@ def main():
         z = torch.empty(N, cout, h, w, device=dev)
         y = torch.empty(N, k, h, w, device=dev)
         slots = L.smaat_pw_num_slots(N, h, w, cout)
-        part = torch.empty(2, slots, cout, device=dev)
+        part = torch.empty(3, slots, cout, device=dev)
         dz = torch.randn(N, cout, h, w, device=dev)
         dy = torch.empty(N, k, h, w, device=dev)
         dx = torch.empty(N, cin, h, w, device=dev)
@@ -69,7 +69,7 @@ def main():
         pl_b = torch.empty(3, k, (cout + 15) // 16 * 16, dtype=torch.int16, device=dev)
         wtt = w_pw.t().contiguous()
         slots_s = L.smaat_pw_split_num_slots(N, h, w)
-        part_s = torch.empty(2, slots_s, cout, device=dev)
+        part_s = torch.empty(3, slots_s, cout, device=dev)
 
         def f_fwd_split():
             assert L.smaat_dw3x3_fwd(x.data_ptr(), cin * p, None, None, w_dw.data_ptr(), b_dw.data_ptr(), y.data_ptr(), k * p, N, cin,
@@ -77,6 +77,21 @@ def main():
             assert L.smaat_split_planes(w_pw.data_ptr(), cout, k, pl_f.data_ptr(), st) == 0
             assert L.smaat_pointwise_fwd_split(y.data_ptr(), k * p, pl_f.data_ptr(), b_pw.data_ptr(), z.data_ptr(),
                                                cout * p, part_s.data_ptr(), N, k, cout, h, w, st) == 0
+
+        slots_f = L.smaat_dsconv_split_num_slots(N, h, w)
+        part_f = torch.empty(3, max(slots_f, 1), cout, device=dev)
+
+        def f_fused(want_y):
+            assert L.smaat_split_planes(w_pw.data_ptr(), cout, k, pl_f.data_ptr(), st) == 0
+            assert L.smaat_dsconv_fwd_split(x.data_ptr(), cin * p, None, None, w_dw.data_ptr(), b_dw.data_ptr(),
+                                            pl_f.data_ptr(), b_pw.data_ptr(), z.data_ptr(), cout * p, part_f.data_ptr(),
+                                            y.data_ptr() if want_y else None, N, cin, 2, cout, h, w, st) == 0
+
+        def f_wgrad_recompute():
+            nsr = L.smaat_dsconv_wgrad_num_splits(N, h, w, cout, k)
+            wsr = torch.empty(nsr, cout, k, device=dev)
+            assert L.smaat_dsconv_wgrad(x.data_ptr(), cin * p, None, None, w_dw.data_ptr(), b_dw.data_ptr(), dz.data_ptr(),
+                                        cout * p, wsr.data_ptr(), dw.data_ptr(), N, cin, 2, cout, h, w, st) == 0
 
         def f_gemm_split():
             assert L.smaat_pointwise_fwd_split(y.data_ptr(), k * p, pl_f.data_ptr(), b_pw.data_ptr(), z.data_ptr(),
@@ -117,6 +132,12 @@ def main():
         else:
             t_f, t_fn, t_d, t_w, t_b = (timeit(f_fwd), timeit(f_fwd_noy), timeit(f_dgrad), timeit(f_wgrad),
                                         timeit(f_dwb))
+        extra = ""
+        if split and slots_f > 0 and os.environ.get("LB_FUSED", "1") != "0":
+            t_fu, t_fuy, t_wr = timeit(lambda: f_fused(False)), timeit(lambda: f_fused(True)), timeit(f_wgrad_recompute)
+            gb = 4.0 * N * (cin + cout) * p / 1e6
+            extra = (f" | FUSED fwd {t_fu:7.3f} ms {fl / t_fu / 1e9:6.1f} TF {gb / t_fu:7.1f} GB/s (with y_out {t_fuy:7.3f})"
+                     f" | f32 recompute-wgrad {t_wr:7.3f}")
         bw = 4.0 * N * (k + 2 * cin) * p
         rows.append(dict(layer=name, cin=cin, k=k, cout=cout, hw=h, gflop=fl / 1e9, fwd_ms=t_f, fwd_noy_ms=t_fn,
                          dgrad_ms=t_d, wgrad_ms=t_w, dwb_ms=t_b, fwd_tf=fl / t_f / 1e9, fwd_noy_tf=fl / t_fn / 1e9,
@@ -128,7 +149,7 @@ def main():
         r = rows[-1]
         print(f"{name:8s} K={k:5d} M={cout:4d} {h:3d}^2  fwd {t_f:7.3f} ms {r['fwd_tf']:6.1f} TF (noY {t_fn:7.3f} "
               f"{r['fwd_noy_tf']:6.1f}) | dgrad {t_d:7.3f} {r['dgrad_tf']:6.1f} | wgrad {t_w:7.3f} {r['wgrad_tf']:6.1f}"
-              f" | dwb {t_b:7.3f} ms {r['dwb_gbs']:7.1f} GB/s", flush=True)
+              f" | dwb {t_b:7.3f} ms {r['dwb_gbs']:7.1f} GB/s" + extra, flush=True)
         del x, z, y, dz, dy, dx, ws
     print("totals ms:", {k: round(v, 2) for k, v in tot.items()})
     os.makedirs("gpurun_out", exist_ok=True)

@@ -67,6 +67,8 @@ SIGNATURES = {
     "smaat_pw_split_num_slots": [_I, _I, _I],
     "smaat_dw3x3_fwd": [_P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P],
     "smaat_pointwise_fwd_split": [_P, _L, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P],
+    "smaat_dsconv_split_num_slots": [_I, _I, _I],
+    "smaat_dsconv_fwd_split": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "smaat_precip_metrics_ws_bytes": [_L],
     "smaat_precip_metrics_update": [_P, _P, _L, _I, _F, _F, _I, _P, _P, _P, _P],
 }
@@ -162,6 +164,7 @@ WORK_MODELS = {
     "smaat_dw3x3_fwd": lambda a: (18.0 * a[8] * a[9] * a[10] * a[11] * a[12],
                                   4.0 * a[8] * a[9] * (1 + a[10]) * a[11] * a[12]),
     "smaat_dsconv_fwd": _w_dsconv_fwd,
+    "smaat_dsconv_fwd_split": _w_dsconv_fwd,
     "smaat_pointwise_fwd": _w_pointwise_fwd,
     "smaat_dsconv_wgrad": _w_dsconv_wgrad,
     "smaat_pointwise_wgrad": _w_pointwise_wgrad,

@@ -58,6 +58,23 @@ int launch_cbam_bwd_mlp(const float*, const float*, const float*, const float*, 
 int launch_cbam_bwd_final(float*, long, const float*, const float*, const int*, int, int, int, hipStream_t);
 
 
+struct DsSplitArgs {  // dsconv_split.hip
+    const float* x;
+    long x_bs;
+    const float* in_scale;
+    const float* in_shift;
+    const float* w_dw;
+    const float* b_dw;
+    const unsigned short* planes;
+    const float* bias;
+    float* out;
+    long out_bs;
+    float* part;
+    float* y_out;
+    int N, Cin, Kdim, M, nco, H, W, P, tiles_x, tiles_per_img, T;
+};
+int launch_dsconv_split(DsSplitArgs& a, int kpl, hipStream_t st);
+int dsconv_split_num_slots(int N, int H, int W);
 int split_mode();
 int set_split_mode(int m);
 int launch_split_planes(const float* w, int R, int C, unsigned short* out, hipStream_t st);
@@ -288,6 +305,18 @@ int smaat_pointwise_fwd_split(const float* x, long x_bs, const void* planes, con
     a.x = x; a.x_bs = x_bs; a.planes = (const unsigned short*)planes; a.bias = bias; a.out = out; a.out_bs = out_bs;
     a.part = part; a.N = N; a.Cin = Cin; a.Cp = (Cin + 15) & ~15; a.M = M; a.P = H * W;
     return launch_pw_split(a, ST);
+}
+int smaat_dsconv_split_num_slots(int N, int H, int W) { return dsconv_split_num_slots(N, H, W); }
+int smaat_dsconv_fwd_split(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                           const float* b_dw, const void* planes, const float* b_pw, float* z, long z_bs, float* part,
+                           float* y_out, int N, int Cin, int kpl, int Cout, int H, int W, void* stream) {
+    if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || !planes) return -1;
+    if ((in_scale == nullptr) != (in_shift == nullptr)) return -1;
+    DsSplitArgs a{};
+    a.x = x; a.x_bs = x_bs; a.in_scale = in_scale; a.in_shift = in_shift; a.w_dw = w_dw; a.b_dw = b_dw;
+    a.planes = (const unsigned short*)planes; a.bias = b_pw; a.out = z; a.out_bs = z_bs; a.part = part; a.y_out = y_out;
+    a.N = N; a.Cin = Cin; a.Kdim = Cin * kpl; a.M = Cout; a.H = H; a.W = W;
+    return launch_dsconv_split(a, kpl, ST);
 }
 int smaat_precip_metrics_ws_bytes(long n) { return (int)precip_metrics_ws_bytes(n); }
 int smaat_precip_metrics_update(const float* preds, const float* target, long n, int batch, float factor,

@@ -1,0 +1,407 @@
+// Fused DepthwiseSeparableConv forward on the bf16 matrix pipe (training path of the plane-dominated layers):
+//
+//   z[n][m][p] = b_pw[m] + sum_k W_pw[m][k] * y[n][k][p],     y = depthwise3x3(act(x)) (+ b_dw)
+//   (reference models/layers.py:47-50; act = the previous BatchNorm + ReLU applied on load, optional)
+//
+// The depthwise output y NEVER goes through HBM: producer waves stage the input halo tile in LDS (aligned float4
+// columns), run the 3x3 stage in VALU on 4-pixel vertical strips, split every value exactly into three bf16 terms and
+// write them straight into the B operand image of the split GEMM ([plane][pixel][16 channels]); consumer waves do
+// nothing but ds_read_b128 + six v_mfma_f32_32x32x16_bf16 per 16-deep chunk (splitmma.hip explains the split).
+// HBM traffic = x (+ halo re-reads served by L2) + z: 4 (Cin + Cout) HW per image instead of 4 (Cin + 2 K + Cout) HW
+// for the depthwise kernel + GEMM pair (K = 2 Cin).
+//
+// Geometry: 64 output channels x 128 pixels per workgroup (2 workgroups per CU), pixel tile = 4 x 32 or 8 x 16
+// (template TWL), kernels_per_layer = 2, one barrier per chunk, every LDS buffer double buffered:
+//   iteration i:  consumers  M(i)     : A[i&1], B[i&1] -> MFMA
+//                 producers  Ac(i+1)  : weight-plane registers -> A[(i+1)&1];      issue loads A(i+2)
+//                            Sc(i+2)  : halo registers -> S[i&1] (act + zero pad); issue loads S(i+3)
+//                            D(i+1)   : S[(i+1)&1] -> depthwise -> split -> B[(i+1)&1]
+// Task map of the depthwise stage (one task per producer thread and chunk): lane -> (column c = lane & 7 + 8 wave,
+// channel cl = (lane >> 3) & 3 + 4 (lane >> 5)): the 32 lanes of a half-wave read 8 columns x 4 channels of the
+// staging buffer (channel stride = 8 mod 32 banks) and write 8 pixels x 4 channel pairs of the B image (pixel
+// stride 12 words) -- both conflict-free.
+#include "common.h"
+#include <stdlib.h>
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+#define DSS_BROW 48  // bytes per LDS row of a [row][16 bf16] image (32 + 16 pad: conflict-free ds_read_b128)
+#define DSS_CSTRIDE 264  // staged floats per input channel: 240 used (6 x 40 or 10 x 24), = 8 mod 32 banks
+
+__device__ __forceinline__ unsigned dss_fbits(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float dss_bitsf(unsigned x) { return __builtin_bit_cast(float, x); }
+__device__ __forceinline__ unsigned dss_pack_hi16(float lo, float hi) {
+    return __builtin_amdgcn_perm(dss_fbits(hi), dss_fbits(lo), 0x07060302u);  // {hi.hi16, lo.hi16}
+}
+
+struct DsSplitArgs {
+    const float* x;
+    long x_bs;
+    const float* in_scale;
+    const float* in_shift;
+    const float* w_dw;             // [K][9]
+    const float* b_dw;             // [K] or null
+    const unsigned short* planes;  // pointwise weight, split planes, chunk-major [Kp/16][3][M][16]
+    const float* bias;             // [M] or null
+    float* out;
+    long out_bs;
+    float* part;   // [3][T][M] or null
+    float* y_out;  // [N][K][P] or null (depthwise output as a side product)
+    int N, Cin, Kdim, M, nco, H, W, P, tiles_x, tiles_per_img, T;
+};
+
+// TWL: log2 of the tile width (5: 4 x 32 tile, 4: 8 x 16 tile).  NT: 3 = exact split, 1 = plain bf16 operands.
+template <int TWL, int NT, bool AFF>
+__global__ __launch_bounds__(512, 4) void k_dsconv_split(const DsSplitArgs a) {
+    constexpr int KPL = 2, KC = 16, KCI = KC / KPL;
+    constexpr int CT = 2, WPX = 4, PXT = 1;
+    constexpr int COT = 64, PT = 128, NPT = 256;
+    constexpr int TW = 1 << TWL, TH = PT / TW;
+    constexpr int STRIDE = TW + 8, NROW = TH + 2, NCOL4 = (TW + 8) / 4, PER = NROW * NCOL4;  // PER = 60 in both shapes
+    static_assert(PER == 60 && NROW * STRIDE <= DSS_CSTRIDE, "staging geometry");
+    constexpr int F = KCI * PER;                  // float4 staging slots per chunk (480)
+    constexpr int NSL = (F + NPT - 1) / NPT;      // per producer thread (2)
+    constexpr int APL = COT * DSS_BROW, BPL = PT * DSS_BROW;
+    constexpr int BUFSZ = NT * (APL + BPL);       // bytes: NT planes of A then NT planes of B
+    constexpr int NAP = COT * 2 * NT;             // 16-byte pieces of the A planes per chunk
+    constexpr int NAT = (NAP + NPT - 1) / NPT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float* S = (float*)(lds + 2 * BUFSZ);         // [2][KCI][DSS_CSTRIDE]
+    float* DWl = S + 2 * KCI * DSS_CSTRIDE;       // [2][256]: per chunk [KC][12] = 9 taps, bias, 2 pad
+    float* stat = DWl + 2 * 256;                  // BN_STAT_FLOATS(WPX, COT)
+    int* pixoff = (int*)(stat + BN_STAT_FLOATS(WPX, COT));  // [PT]
+    float* biasl = (float*)(pixoff + PT);         // [COT]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wv >= 4;
+    const int wpx = wv & 3;       // consumer wave -> 32 pixels of the tile
+    const int pw = wv & 3;        // producer wave index
+    const int l31 = lane & 31, half = lane >> 5;
+    const int ptid = producer ? tid - 256 : 0;
+
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int cot = idx % a.nco;
+    const int ptg = xcd * ((a.T + 7) >> 3) + idx / a.nco;  // contiguous tile range per XCD (halo lines meet in one L2)
+    if (ptg >= a.T) return;
+    const int n = ptg / a.tiles_per_img, tl = ptg - n * a.tiles_per_img;
+    const int ty = tl / a.tiles_x, tx = tl - ty * a.tiles_x;
+    const int r0 = ty * TH, c0 = tx * TW;
+    const int co0 = cot * COT;
+    const int nchunks = (a.Kdim + KC - 1) / KC;
+    const float* xn = a.x + (long)n * a.x_bs;
+    if (tid < COT) {
+        const int m = co0 + tid;
+        const float* bp = a.bias ? a.bias : (const float*)a.planes;
+        const float v = bp[m < a.M ? m : 0];
+        biasl[tid] = (a.bias && m < a.M) ? v : 0.f;
+    }
+    for (int i = tid; i < PT; i += 512) {
+        const int r = r0 + (i >> TWL), c = c0 + (i & (TW - 1));
+        pixoff[i] = (r < a.H && c < a.W) ? r * a.W + c : -1;
+    }
+
+    if (producer) {
+        // ---- staging slots: (channel of the chunk, halo row, float4 column) ----
+        int s_cl[NSL], s_in[NSL], s_lo[NSL];
+        bool s_ok[NSL];
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) {
+            const int f = (ptid + NPT * j) % F;  // surplus slots of the last group re-stage a valid element
+            const int cl = f / PER, rem = f - cl * PER;
+            const int rr = rem / NCOL4, q = rem - rr * NCOL4;
+            const int gr = r0 - 1 + rr, gc = c0 - 4 + 4 * q;
+            const bool ok = gr >= 0 && gr < a.H && gc >= 0 && gc < a.W;  // W % 4 == 0: a float4 is inside or outside
+            s_cl[j] = cl;
+            s_in[j] = ok ? gr * a.W + gc : 0;
+            s_lo[j] = cl * DSS_CSTRIDE + rr * STRIDE + 4 * q;
+            s_ok[j] = ok;
+        }
+        // ---- depthwise task of this thread: channel t_cl of the chunk, strip (t_rg, t_c) ----
+        const int t_cl = ((lane >> 3) & 3) + 4 * half;
+        int t_c, t_rg;
+        if (TWL == 5) {
+            t_c = (lane & 7) + 8 * pw;
+            t_rg = 0;
+        } else {
+            t_c = (lane & 7) + 8 * (pw & 1);
+            t_rg = pw >> 1;
+        }
+        const int t_sb = t_cl * DSS_CSTRIDE + (t_rg * 4) * STRIDE + t_c + 3;   // S index of (row - 1, col - 1)
+        const int t_px = (t_rg * 4) * TW + t_c;                                // tile pixel of the strip's first row
+        const int t_gr = r0 + t_rg * 4;
+        const int t_go = t_gr * a.W + c0 + t_c;
+        const bool t_cok = (c0 + t_c) < a.W;
+        // ---- A-plane pieces ----
+        int a_src[NAT], a_dst[NAT];
+#pragma unroll
+        for (int u = 0; u < NAT; ++u) {
+            const int id = (ptid + NPT * u) % NAP;
+            const int pl = id / (COT * 2), rem = id - pl * (COT * 2);
+            const int row = rem >> 1, h = rem & 1;
+            const int m = co0 + row;
+            a_src[u] = (pl * a.M + (m < a.M ? m : a.M - 1)) * 16 + h * 8;  // + chunk * 3 * M * 16 (ushort units)
+            a_dst[u] = pl * APL + row * DSS_BROW + h * 16;
+        }
+        const int dwk = ptid / 12, dwt = ptid - dwk * 12;
+        const float* dwsrc = (dwt < 9) ? a.w_dw : (a.b_dw ? a.b_dw : a.w_dw);
+        const int dwmul = (dwt < 9) ? 9 : 1, dwadd = (dwt < 9) ? dwt : 0;
+        const bool dwvalid = (dwk < KC) && (dwt < 9 || (dwt == 9 && a.b_dw != nullptr));
+        float dwreg = 0.f;
+        float4 sreg[NSL];
+        float scr[NSL], shr[NSL];
+        uint4 areg[NAT];
+
+        auto clampc = [&](int ch) { return ch < nchunks ? ch : nchunks - 1; };
+        auto prefetch_b = [&](int ch_) {
+            const int ci0 = clampc(ch_) * KCI;
+#pragma unroll
+            for (int j = 0; j < NSL; ++j) {
+                const int ci = ci0 + s_cl[j];
+                const int cic = ci < a.Cin ? ci : a.Cin - 1;
+                sreg[j] = *(const float4*)(xn + (long)cic * a.P + s_in[j]);
+                if (AFF) {
+                    scr[j] = a.in_scale[cic];
+                    shr[j] = a.in_shift[cic];
+                }
+            }
+            const int kg = clampc(ch_) * KC + (dwk < KC ? dwk : 0);
+            dwreg = dwsrc[(kg < a.Kdim ? kg : a.Kdim - 1) * dwmul + dwadd];
+        };
+        auto commit_b = [&](int ch_, int buf) {
+            const int ci0 = clampc(ch_) * KCI;
+            float* Sb = S + buf * (KCI * DSS_CSTRIDE);
+#pragma unroll
+            for (int j = 0; j < NSL; ++j) {
+                const bool ok = s_ok[j] && (ci0 + s_cl[j]) < a.Cin;
+                float4 v = sreg[j];
+                if (AFF) {  // the previous BatchNorm + ReLU applied on load; the zero padding stays zero
+                    v.x = fmaxf(fmaf(v.x, scr[j], shr[j]), 0.f);
+                    v.y = fmaxf(fmaf(v.y, scr[j], shr[j]), 0.f);
+                    v.z = fmaxf(fmaf(v.z, scr[j], shr[j]), 0.f);
+                    v.w = fmaxf(fmaf(v.w, scr[j], shr[j]), 0.f);
+                }
+                v.x = ok ? v.x : 0.f;
+                v.y = ok ? v.y : 0.f;
+                v.z = ok ? v.z : 0.f;
+                v.w = ok ? v.w : 0.f;
+                *(float4*)(Sb + s_lo[j]) = v;
+            }
+            DWl[buf * 256 + (ptid < 256 ? ptid : 0)] = (dwvalid && (clampc(ch_) * KC + dwk) < a.Kdim) ? dwreg : 0.f;
+        };
+        auto prefetch_a = [&](int ch_) {
+            const long base = (long)clampc(ch_) * 3 * a.M * 16;
+#pragma unroll
+            for (int u = 0; u < NAT; ++u) areg[u] = *(const uint4*)(a.planes + base + a_src[u]);
+        };
+        auto commit_a = [&](int buf) {
+            unsigned char* base = lds + buf * BUFSZ;
+#pragma unroll
+            for (int u = 0; u < NAT; ++u) *(uint4*)(base + a_dst[u]) = areg[u];
+        };
+        auto dwstage = [&](int ch_, int buf) {
+            const int k0 = ch_ * KC;
+            const float* sp = S + buf * (KCI * DSS_CSTRIDE) + t_sb;
+            const float4* DWb = (const float4*)(DWl + buf * 256);
+            unsigned char* Bb = lds + buf * BUFSZ + NT * APL + t_px * DSS_BROW + t_cl * 4;
+            float v[6][3];
+#pragma unroll
+            for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+                for (int dc = 0; dc < 3; ++dc) v[rr][dc] = sp[rr * STRIDE + dc];
+            float y[2][4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int k = t_cl * 2 + j;
+                const float4 wa = DWb[k * 3], wb = DWb[k * 3 + 1], wc = DWb[k * 3 + 2];  // zeros when k0 + k >= Kdim
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float acc = wc.y;
+                    acc = fmaf(wa.x, v[i][0], acc);
+                    acc = fmaf(wa.y, v[i][1], acc);
+                    acc = fmaf(wa.z, v[i][2], acc);
+                    acc = fmaf(wa.w, v[i + 1][0], acc);
+                    acc = fmaf(wb.x, v[i + 1][1], acc);
+                    acc = fmaf(wb.y, v[i + 1][2], acc);
+                    acc = fmaf(wb.z, v[i + 2][0], acc);
+                    acc = fmaf(wb.w, v[i + 2][1], acc);
+                    acc = fmaf(wc.x, v[i + 2][2], acc);
+                    y[j][i] = acc;
+                }
+            }
+            if (a.y_out != nullptr && cot == 0) {
+                float* yo = a.y_out + ((long)n * a.Kdim + k0 + t_cl * 2) * a.P + t_go;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if ((k0 + t_cl * 2 + j) < a.Kdim && t_cok && (t_gr + i) < a.H) yo[(long)j * a.P + i * a.W] = y[j][i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float p1[2], p2[2], p3[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float x = y[j][i];
+                    if (NT == 1) {
+                        const unsigned bb = dss_fbits(x);
+                        p1[j] = dss_bitsf((bb + 0x7FFFu + ((bb >> 16) & 1u)) & 0xFFFF0000u);  // round to nearest even
+                        p2[j] = p3[j] = 0.f;
+                    } else {
+                        p1[j] = dss_bitsf(dss_fbits(x) & 0xFFFF0000u);
+                        const float r1 = x - p1[j];  // exact
+                        p2[j] = dss_bitsf(dss_fbits(r1) & 0xFFFF0000u);
+                        p3[j] = r1 - p2[j];          // exact, <= 8 significant bits
+                    }
+                }
+                unsigned char* dst = Bb + i * (TW * DSS_BROW);
+                *(unsigned*)(dst) = dss_pack_hi16(p1[0], p1[1]);
+                if (NT == 3) {
+                    *(unsigned*)(dst + BPL) = dss_pack_hi16(p2[0], p2[1]);
+                    *(unsigned*)(dst + 2 * BPL) = dss_pack_hi16(p3[0], p3[1]);
+                }
+            }
+        };
+
+        prefetch_b(0);
+        prefetch_a(0);
+        commit_b(0, 0);
+        commit_a(0);
+        prefetch_b(1);
+        prefetch_a(1);
+        __syncthreads();
+        dwstage(0, 0);
+        commit_b(1, 1);
+        prefetch_b(2);
+        __syncthreads();
+        for (int i = 0; i < nchunks; ++i) {
+            if (i + 1 < nchunks) {
+                const int nb = (i + 1) & 1;
+                commit_a(nb);
+                commit_b(i + 2, i & 1);
+                prefetch_a(i + 2);
+                prefetch_b(i + 3);
+                dwstage(i + 1, nb);
+            }
+            __syncthreads();
+        }
+    } else {
+        f32x16 acc[CT][PXT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][0][r] = 0.f;
+        const int aoff = l31 * DSS_BROW + half * 16;
+        const int boff = NT * APL + (wpx * 32 + l31) * DSS_BROW + half * 16;
+        __syncthreads();
+        __syncthreads();
+        for (int i = 0; i < nchunks; ++i) {
+            const unsigned char* base = lds + (i & 1) * BUFSZ;
+            bf16x8 af[CT][NT], bf[NT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) af[ct][t] = *(const bf16x8*)(base + aoff + t * APL + ct * 32 * DSS_BROW);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bf[t] = *(const bf16x8*)(base + boff + t * BPL);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                if (NT == 3) {  // smallest terms first
+                    acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][0], bf[NT - 1], acc[ct][0], 0, 0, 0);
+                    acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][NT - 1], bf[0], acc[ct][0], 0, 0, 0);
+                    acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][NT / 2], bf[NT / 2], acc[ct][0], 0, 0, 0);
+                    acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][0], bf[NT / 2], acc[ct][0], 0, 0, 0);
+                    acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][NT / 2], bf[0], acc[ct][0], 0, 0, 0);
+                }
+                acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][0], bf[0], acc[ct][0], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+        // ---- epilogue: bias + row stores (a wave's 32 pixels are one or two full tile rows), BatchNorm partials ----
+        const int off = pixoff[wpx * 32 + l31];
+        float* obase = a.out + (long)n * a.out_bs;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int m = co0 + col;
+                if (m < a.M && off >= 0) obase[(long)m * a.P + off] = acc[ct][0][r] + biasl[col];
+            }
+        }
+        if (a.part) {
+            bool pval[PXT];
+            pval[0] = off >= 0;
+            int fl;
+            const int nw = bn_wave_count<PXT>(pval, fl);
+            bn_wave_partials<CT, PXT>(acc, pval, l31, half, stat + wpx * 3 * COT, COT, fl);
+            if (lane == 0) ((int*)(stat + WPX * 3 * COT))[wpx] = nw;
+        }
+    }
+    if (a.part) {
+        __syncthreads();
+        for (int col = tid; col < COT; col += 512) {
+            float mean, m2, cnt;
+            bn_tile_combine<WPX>(stat, (const int*)(stat + WPX * 3 * COT), COT, col, mean, m2, cnt);
+            const int m = co0 + col;
+            if (m < a.M) {
+                a.part[((long)0 * a.T + ptg) * a.M + m] = mean;
+                a.part[((long)1 * a.T + ptg) * a.M + m] = m2;
+                a.part[((long)2 * a.T + ptg) * a.M + m] = cnt;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+int split_mode();  // splitmma.hip
+
+static int dss_twl(int H, int W) {
+    if ((W & 31) == 0 && H >= 4) return 5;
+    if ((W & 15) == 0 && H >= 8) return 4;
+    return 0;
+}
+
+// tiles of the fused kernel for an N x H x W problem; 0 when the shape is not handled
+int dsconv_split_num_slots(int N, int H, int W) {
+    const int twl = dss_twl(H, W);
+    if (!twl) return 0;
+    const int TW = 1 << twl, TH = 128 / TW;
+    return N * ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+}
+
+template <int TWL, int NT, bool AFF>
+static int launch_dss_cfg(DsSplitArgs& a, hipStream_t st) {
+    constexpr int COT = 64, PT = 128, KCI = 8;
+    const size_t lds = (size_t)2 * NT * (COT + PT) * DSS_BROW +
+                       sizeof(float) * (size_t)(2 * KCI * DSS_CSTRIDE + 2 * 256 + BN_STAT_FLOATS(4, COT) + PT + COT);
+    constexpr auto kern = k_dsconv_split<TWL, NT, AFF>;
+    static size_t granted = 0;
+    if (lds > granted) {
+        HIP_RET(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        granted = lds;
+    }
+    const int grid = ((a.T + 7) / 8) * 8 * a.nco;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+    return (int)hipGetLastError();
+}
+
+// returns -2 when the shape / alignment is not handled (kernels_per_layer != 2, W % 16 != 0, unaligned planes)
+int launch_dsconv_split(DsSplitArgs& a, int kpl, hipStream_t st) {
+    const int twl = dss_twl(a.H, a.W);
+    if (kpl != 2 || !twl || (a.x_bs & 3) || (((uintptr_t)a.x) & 15) || a.Kdim != 2 * a.Cin) return -2;
+    a.P = a.H * a.W;
+    if ((long)a.M * a.P >= (1L << 31) || (long)a.Kdim * a.P >= (1L << 31)) return -2;
+    const int TW = 1 << twl, TH = 128 / TW;
+    a.tiles_x = (a.W + TW - 1) / TW;
+    a.tiles_per_img = a.tiles_x * ((a.H + TH - 1) / TH);
+    a.T = a.N * a.tiles_per_img;
+    a.nco = (a.M + 63) / 64;
+    const bool aff = a.in_scale != nullptr;
+    const int nt = split_mode() == 1 ? 1 : 3;
+    if (twl == 5) {
+        if (nt == 1) return aff ? launch_dss_cfg<5, 1, true>(a, st) : launch_dss_cfg<5, 1, false>(a, st);
+        return aff ? launch_dss_cfg<5, 3, true>(a, st) : launch_dss_cfg<5, 3, false>(a, st);
+    }
+    if (nt == 1) return aff ? launch_dss_cfg<4, 1, true>(a, st) : launch_dss_cfg<4, 1, false>(a, st);
+    return aff ? launch_dss_cfg<4, 3, true>(a, st) : launch_dss_cfg<4, 3, false>(a, st);
+}

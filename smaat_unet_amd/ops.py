@@ -191,6 +191,43 @@ def _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None,
     return z, part, slots, y
 
 
+# Fused depthwise -> split GEMM forward (csrc/dsconv_split.hip): the 2x-expanded depthwise tensor stays in LDS.
+# "auto" = the plane-dominated layers (Cout <= 128: one or two 64-channel tiles re-run the cheap depthwise stage;
+# wider layers are matrix-pipe bound and keep the depthwise kernel + persistent GEMM pair), "off", "all".
+FUSE_DW_SPLIT = os.environ.get("SMAAT_FUSE_DW", "auto")
+
+
+def _fused_dw_ok(n, h, w, kpl, cout):
+    if FUSE_DW_SPLIT == "off" or kpl != 2 or not _split_on():
+        return False
+    if _lib.get().smaat_dsconv_split_num_slots(n, h, w) <= 0:
+        return False
+    return FUSE_DW_SPLIT == "all" or cout <= 128
+
+
+def _dsconv_fwd_fused(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, in_shift=None, want_y=False):
+    """fused depthwise + split pointwise GEMM; returns (z, part, slots, y) or None (unsupported shape)"""
+    L = _lib.get()
+    x, x_bs = _planes(x)
+    n, cin, h, w = x.shape
+    cout = w_pw.shape[0]
+    k = cin * kpl
+    slots = L.smaat_dsconv_split_num_slots(n, h, w)
+    if slots <= 0:
+        return None
+    planes = _split_planes_raw(w_pw.reshape(cout, -1))
+    z = _new(x, n, cout, h, w)
+    part = _new(x, 3, slots, cout) if want_stats else None
+    y = _new(x, n, k, h, w) if want_y else None
+    rc = L.smaat_dsconv_fwd_split(_ptr(x), x_bs, _ptr(in_scale), _ptr(in_shift), _ptr(w_dw), _ptr(b_dw), _ptr(planes),
+                                  _ptr(b_pw), _ptr(z), cout * h * w, _ptr(part), _ptr(y), n, cin, kpl, cout, h, w,
+                                  _stream(x))
+    if rc == -2:
+        return None
+    _lib.check(rc, "smaat_dsconv_fwd_split")
+    return z, part, (slots if want_stats else 0), y
+
+
 def _bn_finalize_raw(part, slots, c, count, bias_shift, gamma, beta, eps, momentum, rm, rv):
     L = _lib.get()
     st = _new(part, 4, c)
@@ -357,8 +394,12 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
     use_batch_stats = training or rm is None
     y_dw = None
     isc, ish = in_aff if in_aff is not None else (None, None)
-    rs = (_dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish)
-          if _split_fwd_ok(cin * kpl, cout, use_batch_stats) else None)
+    rs = None
+    if _split_fwd_ok(cin * kpl, cout, use_batch_stats):
+        if use_batch_stats and _fused_dw_ok(n, h, w, kpl, cout):
+            rs = _dsconv_fwd_fused(x, w_dw, b_dw, w_pw, b_pw, kpl, True, isc, ish, want_y=keep_y)
+        if rs is None:
+            rs = _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish)
     if rs is not None and use_batch_stats:
         z, part, slots, y_dw = rs
         if not keep_y:

@@ -136,6 +136,31 @@ class EmuLib:
         self._write_part(part, PW_SLOTS + 1, M, acc)
         return 0
 
+    def smaat_dsconv_split_num_slots(self, N, H, W):
+        return PW_SLOTS + 2 if (W % 16 == 0 and H >= 8) or (W % 32 == 0 and H >= 4) else 0
+
+    def smaat_dsconv_fwd_split(self, x, x_bs, in_scale, in_shift, w_dw, b_dw, pl, b_pw, z, z_bs, part, y_out, N, Cin, kpl,
+                               Cout, H, W, stream):
+        T = self.smaat_dsconv_split_num_slots(N, H, W)
+        if kpl != 2 or T == 0:
+            return -2
+        P, K = H * W, Cin * kpl
+        xv = np.array(planes(x, N, Cin, P, x_bs)).reshape(N, Cin, H, W)
+        if in_scale:
+            sc, sh = f32(in_scale, Cin), f32(in_shift, Cin)
+            xv = np.maximum(xv * sc[None, :, None, None] + sh[None, :, None, None], 0).astype(np.float32)
+        y = O.dw3x3_fwd(xv, f32(w_dw, K * 9).reshape(K, 1, 3, 3), f32(b_dw, K) if b_dw else None, kpl)
+        Kp = (K + 15) // 16 * 16
+        u = np.ctypeslib.as_array((ctypes.c_uint16 * (3 * Cout * Kp)).from_address(int(pl))).reshape(Kp // 16, 3, Cout, 16)
+        u = u.transpose(1, 2, 0, 3).reshape(3, Cout, Kp)
+        a = ((u.astype(np.uint32) << np.uint32(16)).view(np.float32)).astype(np.float64).sum(axis=0)[:, :K]
+        acc = np.einsum("mk,nkp->nmp", a.astype(np.float32), y.reshape(N, K, P))
+        planes(z, N, Cout, P, z_bs)[:] = acc + (f32(b_pw, Cout)[None, :, None] if b_pw else 0)
+        self._write_part(part, T, Cout, acc)
+        if y_out:
+            f32(y_out, N * K * P)[:] = y.reshape(-1)
+        return 0
+
     def smaat_dw3x3_bwd_ws_rows(self, N, Cin, H, W):
         return N + 1
 

@@ -267,6 +267,63 @@ def test_bn_partials_keep_the_variance_under_a_large_mean(shape):
         assert ((var - ref_var).abs() / ref_var).max().item() < tol, (name, ((var - ref_var).abs() / ref_var).max())
 
 
+def case_dsconv_fwd_split(L, dev, N, Cin, Cout, H, W, aff=False, pad_c=0, bias=True, want_y=True):
+    """fused depthwise -> split GEMM forward (smaat_dsconv_fwd_split), kernels_per_layer = 2"""
+    K = Cin * 2
+    xfull = T(rnd(1, N, Cin + pad_c, H, W) * np.exp(rnd(7, 1, Cin + pad_c, 1, 1)), dev)  # wide range across channels
+    x = xfull[:, pad_c:]
+    x_bs = (Cin + pad_c) * H * W
+    w_dw, b_dw = T(rnd(2, K, 9, scale=0.3), dev), T(rnd(3, K, scale=0.3), dev)
+    w, b_pw = T(rnd(4, Cout, K, scale=0.2), dev), T(rnd(5, Cout), dev)
+    sc = T(np.random.default_rng(6).uniform(0.5, 1.5, Cin).astype(np.float32), dev) if aff else None
+    sh = T(rnd(7, Cin, scale=0.3), dev) if aff else None
+    Kp = (K + 15) // 16 * 16
+    pl = torch.full((3, Cout, Kp), -1, dtype=torch.int16, device=dev)
+    assert L.smaat_split_planes(P(w), Cout, K, P(pl), stream(dev)) == 0
+    z = torch.full((N, Cout, H, W), float("nan"), device=dev)
+    slots = L.smaat_dsconv_split_num_slots(N, H, W)
+    assert slots > 0
+    part = torch.full((3, slots, Cout), float("nan"), device=dev)
+    y = torch.full((N, K, H, W), float("nan"), device=dev) if want_y else None
+    rc = L.smaat_dsconv_fwd_split(x.data_ptr(), x_bs, P(sc), P(sh), P(w_dw), P(b_dw) if bias else None, P(pl),
+                                  P(b_pw) if bias else None, P(z), Cout * H * W, P(part), P(y), N, Cin, 2, Cout, H, W,
+                                  stream(dev))
+    assert rc == 0
+    pn, pmean, pvar = part_stats(part)
+    r = dict(z=z, pn=pn, pmean=pmean, pvar=pvar)
+    if want_y:
+        r["y"] = y
+    return r
+
+
+@pytest.mark.parametrize("shape", [
+    # N, Cin, Cout, H, W
+    (2, 12, 64, 32, 32),      # 4 x 32 tiles, partial last chunk (K = 24)
+    (2, 8, 10, 16, 16),       # 8 x 16 tiles, partial channel tile
+    (1, 64, 64, 64, 64),      # 8 chunks
+    (2, 16, 130, 48, 48),     # three channel tiles (the last partial), 8 x 16 tiles
+    (2, 5, 7, 20, 32),        # H not a multiple of the tile height, odd channel counts
+    (1, 3, 64, 8, 80),        # W = 80: 8 x 16 tiles, one tile row
+    (2, 12, 64, 288, 288),    # inc.0
+    (1, 128, 64, 288, 288),   # up4.0: 16 chunks
+    (2, 64, 128, 144, 144),   # down1.0: W = 144 -> 8 x 16 tiles, two channel tiles
+])
+def test_dsconv_fwd_split(shape):
+    both(case_dsconv_fwd_split, *shape, tol=2e-6)
+    both(case_dsconv_fwd_split, *shape, aff=True, pad_c=4, bias=False, want_y=False, tol=2e-6)
+
+
+def test_dsconv_fwd_split_refuses_what_it_does_not_handle():
+    L, dev = _lib.get(), torch.device("cuda:0")
+    assert L.smaat_dsconv_split_num_slots(2, 18, 18) == 0 and L.smaat_dsconv_split_num_slots(2, 4, 16) == 0
+    x = torch.zeros(1, 4, 18, 18, device=dev)
+    assert L.smaat_dsconv_fwd_split(P(x), 4 * 324, None, None, P(x), None, P(x), None, P(x), 4 * 324, None, None, 1, 4, 2, 4,
+                                    18, 18, stream(dev)) == -2
+    x = torch.zeros(1, 4, 32, 32, device=dev)
+    assert L.smaat_dsconv_fwd_split(P(x), 4 * 1024, None, None, P(x), None, P(x), None, P(x), 4 * 1024, None, None, 1, 4, 4,
+                                    4, 32, 32, stream(dev)) == -2  # kernels_per_layer 4
+
+
 def case_dw_fwd(L, dev, N, Cin, kpl, H, W, bias=True, pad_c=0, aff=False):
     K = Cin * kpl
     xfull = T(rnd(1, N, Cin + pad_c, H, W), dev)
