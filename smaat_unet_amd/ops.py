@@ -192,17 +192,23 @@ def _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None,
 
 
 # Fused depthwise -> split GEMM forward (csrc/dsconv_split.hip): the 2x-expanded depthwise tensor stays in LDS.
-# "auto" = the plane-dominated layers (Cout <= 128: one or two 64-channel tiles re-run the cheap depthwise stage;
-# wider layers are matrix-pipe bound and keep the depthwise kernel + persistent GEMM pair), "off", "all".
+# Measured (profiles/r2/layer_bench_fused.txt, batch 32): 1.3-1.4x faster than the depthwise kernel + GEMM pair on the
+# 288^2 layers when the depthwise output is NOT needed afterwards, but slower than the pair when it has to be written
+# as a side product for the streamed weight gradient (the write is 2/3 of the traffic it saves).  Policy:
+#   "auto" = use it where the depthwise output is not kept (forward under no_grad, eval-mode forward) on the
+#            plane-dominated layers (Cout <= 128: one or two 64-channel tiles re-run the cheap depthwise stage);
+#   "train" = also in training (side output written); "all" = every supported shape; "off".
 FUSE_DW_SPLIT = os.environ.get("SMAAT_FUSE_DW", "auto")
 
 
-def _fused_dw_ok(n, h, w, kpl, cout):
+def _fused_dw_ok(n, h, w, kpl, cout, keep_y):
     if FUSE_DW_SPLIT == "off" or kpl != 2 or not _split_on():
         return False
     if _lib.get().smaat_dsconv_split_num_slots(n, h, w) <= 0:
         return False
-    return FUSE_DW_SPLIT == "all" or cout <= 128
+    if FUSE_DW_SPLIT == "all":
+        return True
+    return cout <= 128 and (not keep_y or FUSE_DW_SPLIT == "train")
 
 
 def _dsconv_fwd_fused(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, in_shift=None, want_y=False):
@@ -395,11 +401,10 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
     y_dw = None
     isc, ish = in_aff if in_aff is not None else (None, None)
     rs = None
-    if _split_fwd_ok(cin * kpl, cout, use_batch_stats):
-        if use_batch_stats and _fused_dw_ok(n, h, w, kpl, cout):
-            rs = _dsconv_fwd_fused(x, w_dw, b_dw, w_pw, b_pw, kpl, True, isc, ish, want_y=keep_y)
-        if rs is None:
-            rs = _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish)
+    if _split_on() and _fused_dw_ok(n, h, w, kpl, cout, keep_y):
+        rs = _dsconv_fwd_fused(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish, want_y=keep_y)
+    if rs is None and _split_fwd_ok(cin * kpl, cout, use_batch_stats):
+        rs = _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish)
     if rs is not None and use_batch_stats:
         z, part, slots, y_dw = rs
         if not keep_y:

@@ -40,17 +40,39 @@ def _worker(rank, world, port, out_dir):
     if rank == 0:
         P = oparams.make_smaat_params(12, 1, 2, 16, 0)
         model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in P.items()})
-    ddp = FlatGradAllReduce(model.parameters())
-    assert ddp.world == world and ddp.numel == 4033537
+        with torch.no_grad():
+            model.inc.double_conv[1].running_mean.fill_(0.25)  # buffers travel with the parameters
+    ddp = FlatGradAllReduce(model, buckets=2)
+    assert ddp.world == world and ddp.numel == 4033537 and len(ddp._buckets) == 2
     ddp.broadcast_parameters(0)
+    assert float(model.inc.double_conv[1].running_mean[0]) == 0.25
+    flat_ptr = ddp.flat.data_ptr()
     xn, yn = _shard(rank)
-    out = model(torch.from_numpy(xn))
-    loss = torch.nn.functional.mse_loss(out.squeeze(1), torch.from_numpy(yn), reduction="sum") / 1
-    loss.backward()
-    flat = ddp.reduce()
-    assert all(p.grad.data_ptr() >= flat.data_ptr() for p in model.parameters())
+    flats = []
+    for it in range(2):  # two steps: the flat buffer and the .grad views persist
+        ddp.zero_grad()
+        out = model(torch.from_numpy(xn))
+        loss = torch.nn.functional.mse_loss(out.squeeze(1), torch.from_numpy(yn), reduction="sum") / 1
+        loss.backward()       # the hooks launch the two bucket all-reduces
+        flat = ddp.finish()
+        assert flat.data_ptr() == flat_ptr
+        for p in model.parameters():
+            a, b = ddp._range[p]
+            assert p.grad.data_ptr() == flat_ptr + 4 * a and p.grad.numel() == b - a
+        flats.append(flat.clone())
+    assert torch.equal(flats[0], flats[1])  # same input, same parameters (no optimizer step): same reduced gradient
+    # reverse registration order: the output layer's gradient leads the buffer
+    assert ddp._range[model.outc.conv.bias][0] == 0
     np.save(os.path.join(out_dir, f"flat{rank}.npy"), flat.numpy())
     np.save(os.path.join(out_dir, f"w{rank}.npy"), model.outc.conv.weight.detach().numpy())
+    # a rank-local step (bench.py's profiling pass) must not touch the process group
+    ddp.active = False
+    ddp.zero_grad()
+    if rank == 0:
+        model(torch.from_numpy(xn)).sum().backward()
+        ddp.finish()
+    ddp.active = True
+    dist.barrier()
     dist.destroy_process_group()
 
 
@@ -63,6 +85,7 @@ def test_flat_allreduce_world2(tmp_path):
     assert np.array_equal(np.load(tmp_path / "w1.npy"), P["outc.conv.weight"])  # broadcast worked
     # oracle: mean of the per-shard gradients (fresh BN statistics per shard)
     names = [k for k, _ in oparams.smaat_unet_keys(12, 1) if "running" not in k and "num_batches" not in k]
+    names = names[::-1]  # the flat buffer is laid out in REVERSE registration order (decoder gradients first)
     acc = None
     for r in range(2):
         xn, yn = _shard(r)
