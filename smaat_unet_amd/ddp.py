@@ -26,7 +26,7 @@ import torch.distributed as dist
 
 
 class FlatGradAllReduce:
-    def __init__(self, module_or_params, world_size=None, group=None, buckets=2, overlap=True):
+    def __init__(self, module_or_params, world_size=None, group=None, buckets=2, overlap=True, force_collectives=False):
         self.module = module_or_params if isinstance(module_or_params, torch.nn.Module) else None
         params = list(self.module.parameters() if self.module is not None else module_or_params)
         self.params = [p for p in params if p.requires_grad]
@@ -65,7 +65,9 @@ class FlatGradAllReduce:
         self._pending = [0] * len(self._buckets)
         self._works = []
         self._launched = [False] * len(self._buckets)
-        self.overlap = bool(overlap) and self.world > 1
+        # force_collectives: issue the all-reduces even at world size 1 (RCCL smoke test on a single-GPU box)
+        self._coll = self.world > 1 or bool(force_collectives)
+        self.overlap = bool(overlap) and self._coll
         self.active = True  # False: no collectives at all (a rank-local profiling step must not talk to its peers)
         self._hooks = []
         if self.overlap:
@@ -94,7 +96,7 @@ class FlatGradAllReduce:
     def _launch(self, i):
         a, b, _ = self._buckets[i]
         self._launched[i] = True
-        if self.world > 1 and self.active:
+        if self._coll and self.active:
             self._works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _on_grad(self, p):
@@ -147,7 +149,7 @@ class FlatGradAllReduce:
         gradient this step keep their zeros), average.  Returns the flat buffer."""
         for p in self.params:
             self._check_views(p)
-        if self.world > 1 and self.active:
+        if self._coll and self.active:
             for i in range(len(self._buckets)):
                 if not self._launched[i]:
                     self._launch(i)

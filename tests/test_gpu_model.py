@@ -326,3 +326,36 @@ def test_library_is_the_hip_one():
     assert type(L).__name__ == "_Lib" and os.path.basename(_lib.LIB_PATH) == "libsmaat_hip.so"
     with open(f"/proc/{os.getpid()}/maps") as f:
         assert "libsmaat_hip.so" in f.read()
+
+
+def test_ddp_rccl_single_rank(tmp_path):
+    """the bucketed all-reduce path of smaat_unet_amd/ddp.py on RCCL (backend "nccl") with one rank on the GPU box
+    (multi-rank behaviour is covered on CPU by tests/test_ddp_gloo.py): hooks fire, collectives run on device
+    buffers, gradients equal the plain backward."""
+    import torch.distributed as dist
+    from smaat_unet_amd.ddp import FlatGradAllReduce
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=DEV)
+    try:
+        meta = dict(n_channels=12, n_classes=1, param_seed=3)
+        xn, yn = O.synthetic_precip(2, 12, 64, 64, seed=5)
+        x, y = torch.from_numpy(xn).to(DEV), torch.from_numpy(yn).to(DEV)
+        model, _ = _load_model(meta)
+        out = model(x)
+        (torch.nn.functional.mse_loss(out.squeeze(1), y, reduction="sum") / 2).backward()
+        ref = [p.grad.clone() for p in model.parameters()]
+        model2, _ = _load_model(meta)
+        ddp = FlatGradAllReduce(model2, buckets=2, force_collectives=True)
+        for _ in range(2):
+            ddp.zero_grad()
+            out = model2(x)
+            (torch.nn.functional.mse_loss(out.squeeze(1), y, reduction="sum") / 2).backward()
+            assert all(ddp._launched), "the post-accumulate hooks did not launch the bucket all-reduces"
+            flat = ddp.finish()
+        torch.cuda.synchronize()
+        assert flat.is_cuda and flat.numel() == 4033537
+        for p, g in zip(model2.parameters(), ref):
+            assert torch.equal(p.grad, g)
+    finally:
+        dist.destroy_process_group()
