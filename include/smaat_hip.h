@@ -139,6 +139,18 @@ int smaat_upsample2x_fwd(const float* x, long x_bs, float* out, long out_bs, int
 int smaat_upsample2x_bwd(const float* dout, long dout_bs, float* dx, long dx_bs, int N, int C, int H, int W, int Ho,
                          int Wo, int pad_t, int pad_l, void* stream);
 
+/* ---- nn.ConvTranspose2d(C, Cout, kernel_size=2, stride=2) + F.pad into an [Ho][Wo] plane of the concatenation buffer
+ *      (UpDS with bilinear=False, reference unet_parts_depthwise_separable.py:72-73,78-85).  The transposed convolution
+ *      is a pointwise GEMM with 4*Cout output rows -- row (a*2+b)*Cout + co holds weight[:, co, a, b] -- run with
+ *      smaat_pointwise_fwd / smaat_pointwise_fwd_split into t [N][4*Cout][H][W], followed by this 2x2 pixel shuffle:
+ *        out[n][co][2i+a+pad_t][2j+b+pad_l] = t[n][(a*2+b)*Cout + co][i][j] + bias[co],  zeros elsewhere.
+ *      _bwd is the inverse gather dout -> dt; weight / input / bias gradients then come from smaat_pointwise_wgrad,
+ *      the pointwise data-gradient GEMM and smaat_channel_sum. */
+int smaat_pixel_shuffle2_fwd(const float* t, long t_bs, const float* bias, float* out, long out_bs, int N, int Cout,
+                             int H, int W, int Ho, int Wo, int pad_t, int pad_l, void* stream);
+int smaat_pixel_shuffle2_bwd(const float* dout, long dout_bs, float* dt, long dt_bs, int N, int Cout, int H, int W,
+                             int Ho, int Wo, int pad_t, int pad_l, void* stream);
+
 /* ---- CBAM   reference: models/layers.py:90-141 */
 int smaat_cbam_spconv_blocks(int N, int H, int W);
 int smaat_cbam_pix_blocks(int N, int P);

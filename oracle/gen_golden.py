@@ -283,6 +283,10 @@ def gen_ops_strict():
                        lambda r: [f32(r, 1, 4, 4, 4), f32(r, 1, 4, 9, 10)], rng)
     module_case_strict(s, "cbam_32", lambda: CBAM(32, reduction_ratio=16), lambda r: [pos(r, 2, 32, 8, 8)], rng)
     module_case_strict(s, "cbam_64_rr8", lambda: CBAM(64, reduction_ratio=8), lambda r: [pos(r, 1, 64, 6, 6)], rng)
+    module_case_strict(s, "up_convt_k2", lambda: UpDS(16, 6, bilinear=False, kernels_per_layer=2),
+                       lambda r: [f32(r, 2, 16, 4, 6), f32(r, 2, 8, 8, 12)], rng)
+    module_case_strict(s, "up_convt_pad_k1", lambda: UpDS(8, 4, bilinear=False, kernels_per_layer=1),
+                       lambda r: [f32(r, 1, 8, 4, 4), f32(r, 1, 4, 9, 11)], rng)
     np.savez_compressed(os.path.join(OUT, "ops_strict.npz"), **s)
     print("ops_strict.npz:", len(s), "arrays")
 
@@ -528,7 +532,7 @@ def _variant_grads(model, x, cot, dtype):
     return t2n(logits), t2n(xt.grad), {k: t2n(p.grad) for k, p in model.named_parameters()}
 
 
-def gen_variant_strict(name, cbams, kpl, n_channels, n_classes, n, h, w, seed0, max_tries=200, draws=8):
+def gen_variant_strict(name, cbams, kpl, n_channels, n_classes, n, h, w, seed0, max_tries=200, draws=8, convt=False):
     """Sibling-network fixture with fp64 anchors and a MEASURED noise floor.
     End-to-end gradients of these small random-parameter networks are not a smooth function of round-off: an
     activation within ~1e-5 (relative) of zero, or a max-pool / CBAM-max near-tie, takes the other branch under
@@ -543,7 +547,10 @@ def gen_variant_strict(name, cbams, kpl, n_channels, n_classes, n, h, w, seed0, 
           largest over all tensors ("sens_global").
     tests/test_host_emu.py::run_variant holds every tensor of the HIP path (against the fp64 anchors) to
     2 x sens_global: the error of ONE flip anywhere in the reference -- no percentile, no minimum over references."""
-    keys = oparams.unetds_keys(n_channels, n_classes, kpl, 16, cbams)
+    # convt: the reference SmaAt_UNet itself with bilinear=False (ConvTranspose2d up path, models/SmaAt_UNet.py:31-37,
+    # unet_parts_depthwise_separable.py:72-73) instead of one of the sibling networks
+    keys = (oparams.smaat_unet_keys(n_channels, n_classes, kpl, 16, bilinear=False) if convt
+            else oparams.unetds_keys(n_channels, n_classes, kpl, 16, cbams))
     zero = lambda k: ".double_conv." in k and k.endswith(("depthwise.bias", "pointwise.bias"))  # noqa: E731
     relv = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-30))  # noqa: E731
     for seed in range(seed0, seed0 + max_tries):
@@ -554,7 +561,8 @@ def gen_variant_strict(name, cbams, kpl, n_channels, n_classes, n, h, w, seed0, 
         cot = rng.standard_normal((n, n_classes, h, w)).astype(np.float32)
 
         def fresh():
-            m = _RefVariant(n_channels, n_classes, kpl, cbams)
+            m = (SmaAt_UNet(n_channels, n_classes, kernels_per_layer=kpl, bilinear=False) if convt
+                 else _RefVariant(n_channels, n_classes, kpl, cbams))
             load_np_state(m, P)
             return m
         torch.set_num_threads(8)
@@ -586,7 +594,7 @@ def gen_variant_strict(name, cbams, kpl, n_channels, n_classes, n, h, w, seed0, 
     model(torch.from_numpy(x))  # running statistics after one step
     s = {"x": x, "cot": cot, "logits": lg32,
          "meta": np.array(json.dumps(dict(n_channels=n_channels, n_classes=n_classes, n=n, h=h, w=w, kpl=kpl,
-                                          cbams=cbams, param_seed=seed, strict=True))),
+                                          cbams=cbams, param_seed=seed, strict=True, convt=bool(convt)))),
          "sens_global": np.float64(max(max(sens.values()), sens_dx))}
     summarize(s, "dx", dx32, 1024, 1024)
     summarize(s, "dx64", dx64.astype(np.float32), 1024, 1024)
@@ -690,3 +698,4 @@ if __name__ == "__main__":
     gen_variant_strict("strict_unetds_k4_n1_32", 0, 4, 3, 2, 1, 32, 32, 3000)
     gen_variant_strict("strict_unetds4cbam_k2_n2_32", 4, 2, 12, 1, 2, 32, 32, 4000)
     gen_variant_strict("strict_unetds4cbam_k4_n1_32", 4, 4, 3, 2, 1, 32, 32, 5000)
+    gen_variant_strict("strict_smaat_convt_k2_n2_32", 5, 2, 12, 1, 2, 32, 32, 6000, convt=True)  # bilinear=False

@@ -50,8 +50,34 @@ def cbam_keys(keys, pre, c, rr):
     _bn(keys, pre + ".spatial_att.bn", 1)
 
 
-def smaat_unet_keys(n_channels, n_classes, kpl=2, rr=16):
-    """[(name, shape)] in reference state_dict order (bilinear=True)."""
+def _up_keys(k, pre, cin, cout, kpl, bilinear):
+    """UpDS (models/unet_parts_depthwise_separable.py:59-73): bilinear -> DoubleConvDS(cin, cout, cin // 2);
+    else ConvTranspose2d(cin, cin // 2, 2, stride=2) (weight [cin][cin // 2][2][2]) + DoubleConvDS(cin, cout)"""
+    if bilinear:
+        double_conv_ds_keys(k, pre + ".conv", cin, cout, cin // 2, kpl)
+    else:
+        k.append((pre + ".up.weight", (cin, cin // 2, 2, 2)))
+        k.append((pre + ".up.bias", (cin // 2,)))
+        double_conv_ds_keys(k, pre + ".conv", cin, cout, None, kpl)
+
+
+def smaat_unet_keys(n_channels, n_classes, kpl=2, rr=16, bilinear=True):
+    """[(name, shape)] in reference state_dict order (models/SmaAt_UNet.py:23-39)."""
+    if not bilinear:
+        k = []
+        double_conv_ds_keys(k, "inc", n_channels, 64, None, kpl)
+        chans = (64, 128, 256, 512, 1024)
+        for lvl in range(1, 5):
+            cbam_keys(k, f"cbam{lvl}", chans[lvl - 1], rr)
+            double_conv_ds_keys(k, f"down{lvl}.maxpool_conv.1", chans[lvl - 1], chans[lvl], None, kpl)
+        cbam_keys(k, "cbam5", 1024, rr)
+        _up_keys(k, "up1", 1024, 512, kpl, False)
+        _up_keys(k, "up2", 512, 256, kpl, False)
+        _up_keys(k, "up3", 256, 128, kpl, False)
+        _up_keys(k, "up4", 128, 64, kpl, False)
+        k.append(("outc.conv.weight", (n_classes, 64, 1, 1)))
+        k.append(("outc.conv.bias", (n_classes,)))
+        return k
     k = []
     double_conv_ds_keys(k, "inc", n_channels, 64, None, kpl)
     cbam_keys(k, "cbam1", 64, rr)

@@ -54,7 +54,7 @@ class UNetDSFamily(nn.Module):
     def _fusable(self):
         """the fused skip wiring bypasses the `forward` of cbamN / downN.maxpool / upN: keep the
         module-by-module path whenever a user hooked one of them (or uses an exotic configuration)."""
-        if not self.bilinear or self.cbam_levels < 4:
+        if self.cbam_levels < 4:
             return False
         downs, ups, cbams = self._levels()
         for top in downs + ups + [c for c in cbams[:4] if c is not None]:

@@ -47,6 +47,8 @@ SIGNATURES = {
     "smaat_maxpool2_bwd": [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P],
     "smaat_upsample2x_fwd": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "smaat_upsample2x_bwd": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "smaat_pixel_shuffle2_fwd": [_P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "smaat_pixel_shuffle2_bwd": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "smaat_cbam_spconv_blocks": [_I, _I, _I],
     "smaat_cbam_pix_blocks": [_I, _I],
     "smaat_cbam_chpool": [_P, _L, _I, _I, _I, _P, _P, _P, _P],

@@ -32,6 +32,9 @@ int launch_maxpool2_fwd(const float*, long, float*, long, int, int, int, int, hi
 int launch_maxpool2_bwd(const float*, long, const float*, long, float*, long, int, int, int, int, int, hipStream_t);
 int launch_upsample2x_fwd(const float*, long, float*, long, int, int, int, int, int, int, int, int, hipStream_t);
 int launch_upsample2x_bwd(const float*, long, float*, long, int, int, int, int, int, int, int, int, hipStream_t);
+int launch_pixel_shuffle2_fwd(const float*, long, const float*, float*, long, int, int, int, int, int, int, int, int,
+                              hipStream_t);
+int launch_pixel_shuffle2_bwd(const float*, long, float*, long, int, int, int, int, int, int, int, int, hipStream_t);
 int launch_dw3x3_bwd(const float*, long, const float*, long, const float*, float*, long, float*, int, int, int, int,
                      int, hipStream_t, const float*, const float*, float*, const float*, const float*);
 int launch_dw_split(const float*, int, float*, float*, hipStream_t);
@@ -230,6 +233,16 @@ int smaat_upsample2x_fwd(const float* x, long x_bs, float* out, long out_bs, int
 int smaat_upsample2x_bwd(const float* dout, long dout_bs, float* dx, long dx_bs, int N, int C, int H, int W, int Ho,
                          int Wo, int pad_t, int pad_l, void* stream) {
     return launch_upsample2x_bwd(dout, dout_bs, dx, dx_bs, N, C, H, W, Ho, Wo, pad_t, pad_l, ST);
+}
+int smaat_pixel_shuffle2_fwd(const float* t, long t_bs, const float* bias, float* out, long out_bs, int N, int Cout,
+                             int H, int W, int Ho, int Wo, int pad_t, int pad_l, void* stream) {
+    if (N < 1 || Cout < 1 || H < 1 || W < 1 || Ho < 1 || Wo < 1) return -1;
+    return launch_pixel_shuffle2_fwd(t, t_bs, bias, out, out_bs, N, Cout, H, W, Ho, Wo, pad_t, pad_l, ST);
+}
+int smaat_pixel_shuffle2_bwd(const float* dout, long dout_bs, float* dt, long dt_bs, int N, int Cout, int H, int W,
+                             int Ho, int Wo, int pad_t, int pad_l, void* stream) {
+    if (N < 1 || Cout < 1 || H < 1 || W < 1 || Ho < 1 || Wo < 1) return -1;
+    return launch_pixel_shuffle2_bwd(dout, dout_bs, dt, dt_bs, N, Cout, H, W, Ho, Wo, pad_t, pad_l, ST);
 }
 int smaat_cbam_spconv_blocks(int N, int H, int W) { return smaat_cbam_spconv_blocks_impl(N, H, W); }
 int smaat_cbam_pix_blocks(int N, int P) { return smaat_cbam_pix_blocks_impl(N, P); }

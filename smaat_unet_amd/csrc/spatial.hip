@@ -175,6 +175,49 @@ __global__ __launch_bounds__(256) void k_upsample2x_bwd(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------
+// ConvTranspose2d(C, Co, kernel_size=2, stride=2) = a pointwise GEMM with 4 Co rows (row (a*2+b)*Co + co holds
+// w[:, co, a, b]) followed by this 2x2 pixel shuffle (reference UpDS with bilinear=False,
+// models/unet_parts_depthwise_separable.py:72-73).  Forward: the shuffled image + bias is written at (pad_t, pad_l) of an
+// [Ho][Wo] plane of the concatenation buffer, zeros elsewhere (F.pad, :78-81).  Backward: the inverse gather.
+//   out[n][co][2i+a+pad_t][2j+b+pad_l] = t[n][(a*2+b)*Co + co][i][j] + bias[co]
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pixel_shuffle2_fwd(const float* __restrict__ t, long t_bs,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            long out_bs, int Co, int H, int W, int Ho, int Wo, int pad_t,
+                                                            int pad_l) {
+    const int plane = blockIdx.x, n = plane / Co, co = plane - n * Co;
+    const float* tp = t + (long)n * t_bs;
+    float* op = out + (long)n * out_bs + (long)co * Ho * Wo;
+    const float bv = bias ? bias[co] : 0.f;
+    const int P = H * W, Po = Ho * Wo;
+    for (int o = blockIdx.y * 256 + threadIdx.x; o < Po; o += gridDim.y * 256) {
+        const int r = o / Wo, c = o - r * Wo;
+        const int ur = r - pad_t, uc = c - pad_l;
+        float v = 0.f;
+        if (ur >= 0 && ur < 2 * H && uc >= 0 && uc < 2 * W) {
+            const int ab = ((ur & 1) << 1) | (uc & 1);
+            v = tp[(long)(ab * Co + co) * P + (ur >> 1) * W + (uc >> 1)] + bv;
+        }
+        op[o] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pixel_shuffle2_bwd(const float* __restrict__ dout, long dout_bs,
+                                                            float* __restrict__ dt, long dt_bs, int Co, int H, int W,
+                                                            int Ho, int Wo, int pad_t, int pad_l) {
+    const int plane = blockIdx.x, n = plane / (4 * Co), m = plane - n * (4 * Co);
+    const int ab = m / Co, co = m - ab * Co, a = ab >> 1, b = ab & 1;
+    const float* gp = dout + (long)n * dout_bs + (long)co * Ho * Wo;
+    float* dp = dt + (long)n * dt_bs + (long)m * H * W;
+    const int P = H * W;
+    for (int p = blockIdx.y * 256 + threadIdx.x; p < P; p += gridDim.y * 256) {
+        const int i = p / W, j = p - i * W;
+        const int r = 2 * i + a + pad_t, c = 2 * j + b + pad_l;
+        dp[p] = (r >= 0 && r < Ho && c >= 0 && c < Wo) ? gp[r * Wo + c] : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // bilinear x2 (align_corners) backward, separable two-pass form for W <= 256:
 //   T[o][w]  = sum_p wc(w, p) * g[o][p]      (column contraction, <= 4 non-zero taps, per output row)
 //   dx[h][w] = sum_o wr(h, o) * T[o][w]      (row contraction from LDS)
@@ -703,6 +746,24 @@ int launch_upsample2x_bwd(const float* dout, long dout_bs, float* dx, long dx_bs
     dim3 grid(N * C, gy);
     hipLaunchKernelGGL(k_upsample2x_bwd, grid, dim3(256), 0, st, dout, dout_bs, dx, dx_bs, C, H, W, Ho, Wo, pad_t,
                        pad_l);
+    return (int)hipGetLastError();
+}
+
+int launch_pixel_shuffle2_fwd(const float* t, long t_bs, const float* bias, float* out, long out_bs, int N, int Co,
+                              int H, int W, int Ho, int Wo, int pad_t, int pad_l, hipStream_t st) {
+    int gy = cdivs((long)Ho * Wo, 2048);
+    if (gy > 64) gy = 64;
+    hipLaunchKernelGGL(k_pixel_shuffle2_fwd, dim3(N * Co, gy), dim3(256), 0, st, t, t_bs, bias, out, out_bs, Co, H, W, Ho,
+                       Wo, pad_t, pad_l);
+    return (int)hipGetLastError();
+}
+
+int launch_pixel_shuffle2_bwd(const float* dout, long dout_bs, float* dt, long dt_bs, int N, int Co, int H, int W, int Ho,
+                              int Wo, int pad_t, int pad_l, hipStream_t st) {
+    int gy = cdivs((long)H * W, 2048);
+    if (gy > 64) gy = 64;
+    hipLaunchKernelGGL(k_pixel_shuffle2_bwd, dim3(N * 4 * Co, gy), dim3(256), 0, st, dout, dout_bs, dt, dt_bs, Co, H, W,
+                       Ho, Wo, pad_t, pad_l);
     return (int)hipGetLastError();
 }
 

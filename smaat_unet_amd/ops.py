@@ -921,6 +921,117 @@ def upsample_into(cat, x1, c_off):
     return _UpsampleInto.apply(cat, x1, c_off)
 
 
+# --------------------------------------------------------------------------------------
+# ConvTranspose2d(C, C/2, kernel_size=2, stride=2) + F.pad + cat (UpDS with bilinear=False, reference
+# models/unet_parts_depthwise_separable.py:72-73,76-85): a pointwise GEMM with 4*Cout rows + a 2x2 pixel shuffle that
+# writes straight into channels [c_off, c_off + Cout) of the concatenation buffer.
+# --------------------------------------------------------------------------------------
+def _gemm_rows(x, a2d, m):
+    """out[n][m][p] = sum_c a2d[m][c] x[n][c][p] on the split GEMM when it is on, else the f32 MFMA kernel"""
+    if _split_on():
+        out, _, _ = _pointwise_split_raw(x, _split_planes_raw(a2d.contiguous()), None, m)
+        return out
+    return _pointwise_raw(x, a2d.t().contiguous(), None, m)
+
+
+def _upconv_forward(x1, w, b, cat, c_off):
+    L = _lib.get()
+    x1, _ = _planes(x1)
+    x1 = x1.contiguous()
+    n, c1, h, wd = x1.shape
+    co = w.shape[1]
+    if tuple(w.shape) != (c1, co, 2, 2):
+        raise ValueError(f"ConvTranspose2d weight {tuple(w.shape)} does not match an input with {c1} channels")
+    _, ct, ho, wo = cat.shape
+    dy_, dx_ = ho - 2 * h, wo - 2 * wd
+    if dy_ < 0 or dx_ < 0:
+        raise NotImplementedError("UpDS with a skip connection smaller than the upsampled map (negative pad)")
+    pt, pl = dy_ // 2, dx_ // 2
+    a2d = w.permute(2, 3, 1, 0).reshape(4 * co, c1)  # row (a*2+b)*Co + co = w[:, co, a, b]
+    t = _gemm_rows(x1, a2d, 4 * co)
+    _lib.check(L.smaat_pixel_shuffle2_fwd(_ptr(t), 4 * co * h * wd, _ptr(b), cat.data_ptr() + 4 * c_off * ho * wo,
+                                          ct * ho * wo, n, co, h, wd, ho, wo, pt, pl, _stream(x1)),
+               "smaat_pixel_shuffle2_fwd")
+    return (n, c1, h, wd, co, ct, ho, wo, pt, pl)
+
+
+def _upconv_backward(geom, x1, w, has_bias, dcat, c_off, need_dx):
+    L = _lib.get()
+    n, c1, h, wd, co, ct, ho, wo, pt, pl = geom
+    dcat = dcat.contiguous()
+    dslice = dcat[:, c_off:c_off + co]
+    dt = _new(dcat, n, 4 * co, h, wd)
+    _lib.check(L.smaat_pixel_shuffle2_bwd(dslice.data_ptr(), ct * ho * wo, _ptr(dt), 4 * co * h * wd, n, co, h, wd, ho,
+                                          wo, pt, pl, _stream(dcat)), "smaat_pixel_shuffle2_bwd")
+    a2d = w.permute(2, 3, 1, 0).reshape(4 * co, c1)
+    dx1 = _gemm_rows(dt, a2d.t(), c1) if need_dx else None          # dX = A^T dT
+    da = _pointwise_wgrad_raw(x1, dt, 4 * co).reshape(2, 2, co, c1)   # dA[(a,b,co)][ci]
+    dw = da.permute(3, 2, 0, 1).contiguous()
+    db = _channel_sum_raw(dt).view(4, co).sum(0) if has_bias else None   # over the un-padded image = over the four dt planes
+    return dx1, dw, db
+
+
+class _UpConvInto(torch.autograd.Function):
+    """cat[:, c_off:] = pad(conv_transpose2x2(x1)) in place; the first c_off channels already hold the skip"""
+
+    @staticmethod
+    def forward(ctx, cat, x1, w, b, c_off):
+        _check(cat, x1, w, b)
+        assert cat.is_contiguous() and cat.shape[1] == c_off + w.shape[1]
+        ctx.geom = _upconv_forward(x1, w, b, cat, c_off)
+        ctx.save_for_backward(x1, w)
+        ctx.c_off, ctx.has_bias = c_off, b is not None
+        ctx.mark_dirty(cat)
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        x1, w = ctx.saved_tensors
+        dx1, dw, db = _upconv_backward(ctx.geom, x1, w, ctx.has_bias, dcat, ctx.c_off, ctx.needs_input_grad[1])
+        return dcat, dx1, dw, db, None
+
+
+class _UpConvCat(torch.autograd.Function):
+    """cat([x2, pad(conv_transpose2x2(x1))], dim=1)"""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w, b):
+        _check(x1, x2, w, b)
+        L = _lib.get()
+        x2, x2_bs = _planes(x2)
+        n2, c2, ho, wo = x2.shape
+        co = w.shape[1]
+        cat = _new(x1, n2, c2 + co, ho, wo)
+        _lib.check(L.smaat_copy_planes(_ptr(x2), x2_bs, _ptr(cat), (c2 + co) * ho * wo, n2, c2 * ho * wo, 0,
+                                       _stream(x1)), "smaat_copy_planes")
+        ctx.geom = _upconv_forward(x1, w, b, cat, c2)
+        ctx.save_for_backward(x1, w)
+        ctx.c2, ctx.has_bias = c2, b is not None
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        L = _lib.get()
+        x1, w = ctx.saved_tensors
+        n, c1, h, wd, co, ct, ho, wo, pt, pl = ctx.geom
+        dcat = dcat.contiguous()
+        dx2 = None
+        if ctx.needs_input_grad[1]:
+            dx2 = _new(dcat, n, ctx.c2, ho, wo)
+            _lib.check(L.smaat_copy_planes(_ptr(dcat), ct * ho * wo, _ptr(dx2), ctx.c2 * ho * wo, n, ctx.c2 * ho * wo, 0,
+                                           _stream(dcat)), "smaat_copy_planes")
+        dx1, dw, db = _upconv_backward(ctx.geom, x1, w, ctx.has_bias, dcat, ctx.c2, ctx.needs_input_grad[0])
+        return dx1, dx2, dw, db
+
+
+def upconv_into(cat, x1, w, b, c_off):
+    return _UpConvInto.apply(cat, x1, w, b, c_off)
+
+
+def upconv_cat(x1, x2, w, b):
+    return _UpConvCat.apply(x1, x2, w, b)
+
+
 def cbam(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, use_ch=True, use_sp=True):
     return _CBAM.apply(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, use_ch, use_sp)
 

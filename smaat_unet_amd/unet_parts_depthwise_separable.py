@@ -60,26 +60,35 @@ class DownDS(nn.Module):
 
 
 class UpDS(nn.Module):
-    """Upscaling then double conv -- reference :56-86 (bilinear branch; the ConvTranspose2d
-    branch `bilinear=False` is never used by the reference scripts and is not accelerated)."""
+    """Upscaling then double conv -- reference :56-86.  bilinear=True: nn.Upsample(x2, bilinear, align_corners) and a
+    DoubleConvDS with mid = in/2 (:64-70); bilinear=False: nn.ConvTranspose2d(in, in/2, 2, stride=2) and a plain
+    DoubleConvDS (:72-73).  Either way the upsampled map is written straight into the concatenation buffer."""
 
     def __init__(self, in_channels, out_channels, bilinear=True, kernels_per_layer=1):
         super().__init__()
-        if not bilinear:
-            raise NotImplementedError("UpDS(bilinear=False) (ConvTranspose2d) is outside the accelerated hot path")
-        # `up` is kept as a (parameter-free) submodule for interface parity; the upsampling itself runs fused with
-        # the pad + concatenation in ops.upsample_cat / ops.upsample_into
-        self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
-        self.conv = DoubleConvDS(in_channels, out_channels, mid_channels=in_channels // 2,
-                                 kernels_per_layer=kernels_per_layer)
+        self.bilinear = bilinear
+        if bilinear:
+            # `up` is kept as a (parameter-free) submodule for interface parity; the upsampling itself runs fused
+            # with the pad + concatenation in ops.upsample_cat / ops.upsample_into
+            self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+            self.conv = DoubleConvDS(in_channels, out_channels, mid_channels=in_channels // 2,
+                                     kernels_per_layer=kernels_per_layer)
+        else:
+            self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)  # parameters only
+            self.conv = DoubleConvDS(in_channels, out_channels, kernels_per_layer=kernels_per_layer)
 
     def forward(self, x1, x2):
-        return self.conv(ops.upsample_cat(x1, x2))
+        if self.bilinear:
+            return self.conv(ops.upsample_cat(x1, x2))
+        return self.conv(ops.upconv_cat(x1, x2, self.up.weight, self.up.bias))
 
     def forward_into(self, x1, cat):
         """same as forward(x1, x2) when x2 already sits in channels [0, C2) of `cat`
-        ([N, C2 + C1, H2, W2]): the upsampled x1 is written behind it, no torch.cat copy."""
-        return self.conv(ops.upsample_into(cat, x1, cat.shape[1] - x1.shape[1]))
+        ([N, C2 + C1', H2, W2]): the upsampled x1 is written behind it, no torch.cat copy."""
+        if self.bilinear:
+            return self.conv(ops.upsample_into(cat, x1, cat.shape[1] - x1.shape[1]))
+        co = self.up.out_channels
+        return self.conv(ops.upconv_into(cat, x1, self.up.weight, self.up.bias, cat.shape[1] - co))
 
 
 class OutConv(nn.Module):

@@ -365,6 +365,29 @@ class EmuLib:
             d[:] = r
         return 0
 
+    def smaat_pixel_shuffle2_fwd(self, t, t_bs, bias, out, out_bs, N, Co, H, W, Ho, Wo, pad_t, pad_l, stream):
+        tv = np.array(planes(t, N, 4 * Co, H * W, t_bs)).reshape(N, 2, 2, Co, H, W)
+        img = np.zeros((N, Co, 2 * H, 2 * W), np.float32)
+        for a in range(2):
+            for b in range(2):
+                img[:, :, a::2, b::2] = tv[:, a, b]
+        if bias:
+            img += f32(bias, Co)[None, :, None, None]
+        full = np.zeros((N, Co, Ho, Wo), np.float32)
+        full[:, :, pad_t:pad_t + 2 * H, pad_l:pad_l + 2 * W] = img
+        planes(out, N, Co, Ho * Wo, out_bs)[:] = full.reshape(N, Co, -1)
+        return 0
+
+    def smaat_pixel_shuffle2_bwd(self, dout, dout_bs, dt, dt_bs, N, Co, H, W, Ho, Wo, pad_t, pad_l, stream):
+        g = np.array(planes(dout, N, Co, Ho * Wo, dout_bs)).reshape(N, Co, Ho, Wo)
+        img = g[:, :, pad_t:pad_t + 2 * H, pad_l:pad_l + 2 * W]
+        tv = np.zeros((N, 2, 2, Co, H, W), np.float32)
+        for a in range(2):
+            for b in range(2):
+                tv[:, a, b] = img[:, :, a::2, b::2]
+        planes(dt, N, 4 * Co, H * W, dt_bs)[:] = tv.reshape(N, 4 * Co, H * W)
+        return 0
+
     def smaat_upsample2x_fwd(self, x, x_bs, out, out_bs, N, C, H, W, Ho, Wo, pad_t, pad_l, stream):
         xv = np.array(planes(x, N, C, H * W, x_bs)).reshape(N, C, H, W)
         u = O.upsample2x_fwd(xv)

@@ -539,6 +539,28 @@ def test_pool_upsample(shape):
 
 
 # ----------------------------------------------------------------------------------------
+def case_pixel_shuffle(L, dev, N, Co, H, W, Ho, Wo, slice_pad=0):
+    """ConvTranspose2d(k=2, s=2) tail: 2x2 pixel shuffle + bias into a padded slice of a cat buffer, and its inverse"""
+    t = T(rnd(1, N, 4 * Co, H, W), dev)
+    bias = T(rnd(2, Co), dev)
+    cat = torch.full((N, Co + slice_pad, Ho, Wo), float("nan"), device=dev)
+    pt, pl = (Ho - 2 * H) // 2, (Wo - 2 * W) // 2
+    s = stream(dev)
+    assert L.smaat_pixel_shuffle2_fwd(P(t), 4 * Co * H * W, P(bias), cat.data_ptr() + 4 * slice_pad * Ho * Wo,
+                                      (Co + slice_pad) * Ho * Wo, N, Co, H, W, Ho, Wo, pt, pl, s) == 0
+    dcat = T(rnd(3, N, Co + slice_pad, Ho, Wo), dev)
+    dt = torch.full((N, 4 * Co, H, W), float("nan"), device=dev)
+    assert L.smaat_pixel_shuffle2_bwd(dcat.data_ptr() + 4 * slice_pad * Ho * Wo, (Co + slice_pad) * Ho * Wo, P(dt),
+                                      4 * Co * H * W, N, Co, H, W, Ho, Wo, pt, pl, s) == 0
+    return dict(out=cat[:, slice_pad:], dt=dt)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 5, 6, 10, 12), (2, 4, 5, 6, 11, 13), (1, 3, 1, 1, 2, 2), (2, 64, 36, 36, 72, 72)])
+def test_pixel_shuffle(shape):
+    both(case_pixel_shuffle, *shape, tol=0)
+    both(case_pixel_shuffle, *shape, slice_pad=5, tol=0)
+
+
 def case_cbam(L, dev, N, C, H, W, ks=7, rr=16):
     Pn, Cr = H * W, max(C // rr, 1)
     s = stream(dev)

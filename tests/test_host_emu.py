@@ -146,7 +146,8 @@ def test_unet(golden_dir, name, policy, monkeypatch):
 
 
 VARIANTS = ["strict_unetds_k2_n2_32", "strict_unetds_k1_n1_48x40", "strict_unetds_k4_n1_32",
-            "strict_unetds4cbam_k2_n2_32", "strict_unetds4cbam_k4_n1_32"]
+            "strict_unetds4cbam_k2_n2_32", "strict_unetds4cbam_k4_n1_32",
+            "strict_smaat_convt_k2_n2_32"]  # the last one: SmaAt_UNet(bilinear=False), ConvTranspose2d up path
 
 
 def run_variant(golden_dir, name, dev="cpu", hooked=False, report=None):
@@ -160,10 +161,14 @@ def run_variant(golden_dir, name, dev="cpu", hooked=False, report=None):
     error by the tie-free block fixtures (tests/test_strict_blocks.py)."""
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     meta = json.loads(str(g["meta"]))
-    cls = {0: S.UNetDS, 4: S.UNetDSAttention4CBAMs}[meta["cbams"]]
-    model = cls(n_channels=meta["n_channels"], n_classes=meta["n_classes"], kernels_per_layer=meta["kpl"])
-    P = oparams.fill(oparams.unetds_keys(meta["n_channels"], meta["n_classes"], meta["kpl"], 16, meta["cbams"]),
-                     meta["param_seed"])
+    if meta.get("convt"):
+        model = S.SmaAt_UNet(meta["n_channels"], meta["n_classes"], kernels_per_layer=meta["kpl"], bilinear=False)
+        keys = oparams.smaat_unet_keys(meta["n_channels"], meta["n_classes"], meta["kpl"], 16, bilinear=False)
+    else:
+        cls = {0: S.UNetDS, 4: S.UNetDSAttention4CBAMs}[meta["cbams"]]
+        model = cls(n_channels=meta["n_channels"], n_classes=meta["n_classes"], kernels_per_layer=meta["kpl"])
+        keys = oparams.unetds_keys(meta["n_channels"], meta["n_classes"], meta["kpl"], 16, meta["cbams"])
+    P = oparams.fill(keys, meta["param_seed"])
     assert list(model.state_dict().keys()) == list(P.keys())
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in P.items()})
     model.to(dev).train()

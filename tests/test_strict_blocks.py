@@ -30,6 +30,8 @@ BLOCKS = {
     "up_pad_k4": lambda: S.UpDS(8, 4, bilinear=True, kernels_per_layer=4),
     "cbam_32": lambda: S.CBAM(32, reduction_ratio=16),
     "cbam_64_rr8": lambda: S.CBAM(64, reduction_ratio=8),
+    "up_convt_k2": lambda: S.UpDS(16, 6, bilinear=False, kernels_per_layer=2),      # ConvTranspose2d up path
+    "up_convt_pad_k1": lambda: S.UpDS(8, 4, bilinear=False, kernels_per_layer=1),
 }
 
 
