@@ -529,6 +529,75 @@ def dsconv_bn_relu(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, running_mean, running
                                momentum, eps, kpl)
 
 
+# --------------------------------------------------------------------------------------
+# Inference fast path (reference call stack D: model.eval() forward, calc_metrics_test_set.py:119):
+# BatchNorm folded into the pointwise conv once per set of weights,
+#     w' = w * gamma / sqrt(running_var + eps),   b' = (b - running_mean) * gamma / sqrt(running_var + eps) + beta
+# (models/unet_parts_depthwise_separable.py:25,34 in eval mode is exactly this affine map), so a half block is ONE
+# fused depthwise -> pointwise launch; the ReLU is applied by the consumer on load (in_scale = 1, in_shift = 0) or by
+# one streaming pass for the block output.
+# --------------------------------------------------------------------------------------
+def fold_bn_into_pointwise(w_pw, b_pw, gamma, beta, rm, rv, eps):
+    """-> dict(w [Cout][K] folded, b [Cout] folded, wt [K][Cout] (f32 kernels), planes (split kernels))"""
+    cout = w_pw.shape[0]
+    with torch.no_grad():
+        s = torch.rsqrt(rv.double() + eps)
+        if gamma is not None:
+            s = s * gamma.double()
+        w2 = (w_pw.reshape(cout, -1).double() * s[:, None]).float().contiguous()
+        b0 = b_pw.double() if b_pw is not None else torch.zeros(cout, dtype=torch.float64, device=w_pw.device)
+        b2 = (b0 - rm.double()) * s
+        if beta is not None:
+            b2 = b2 + beta.double()
+        b2 = b2.float().contiguous()
+        fold = dict(w=w2, b=b2, wt=w2.t().contiguous())
+        fold["planes"] = _split_planes_raw(w2) if _split_on() else None
+    return fold
+
+
+_UNIT = {}
+
+
+def _unit_affine(c, ref):
+    key = (c, ref.device)
+    if key not in _UNIT:
+        _UNIT[key] = (torch.ones(c, dtype=torch.float32, device=ref.device),
+                      torch.zeros(c, dtype=torch.float32, device=ref.device))
+    return _UNIT[key]
+
+
+def dsconv_folded(x, w_dw, b_dw, fold, kpl, relu_in):
+    """z = pointwise'(depthwise(relu?(x))) with BatchNorm folded into the pointwise conv; no autograd (inference)"""
+    _check(x, w_dw, b_dw)
+    L = _lib.get()
+    x, x_bs = _planes(x)
+    n, cin, h, w = x.shape
+    cout = fold["w"].shape[0]
+    isc, ish = _unit_affine(cin, x) if relu_in else (None, None)
+    if fold["planes"] is not None and kpl == 2 and FUSE_DW_SPLIT != "off" and L.smaat_dsconv_split_num_slots(n, h, w) > 0:
+        z = _new(x, n, cout, h, w)
+        rc = L.smaat_dsconv_fwd_split(_ptr(x), x_bs, _ptr(isc), _ptr(ish), _ptr(w_dw), _ptr(b_dw), _ptr(fold["planes"]),
+                                      _ptr(fold["b"]), _ptr(z), cout * h * w, None, None, n, cin, kpl, cout, h, w,
+                                      _stream(x))
+        if rc == 0:
+            return z
+        if rc != -2:
+            _lib.check(rc, "smaat_dsconv_fwd_split")
+    z = _new(x, n, cout, h, w)
+    _lib.check(L.smaat_dsconv_fwd(_ptr(x), x_bs, _ptr(isc), _ptr(ish), _ptr(w_dw), _ptr(b_dw), _ptr(fold["wt"]),
+                                  _ptr(fold["b"]), _ptr(z), cout * h * w, None, None, n, cin, kpl, cout, h, w,
+                                  _stream(x)), "smaat_dsconv_fwd")
+    return z
+
+
+def double_conv_ds_eval(x, half1, half2, kpl):
+    """eval-mode DoubleConvDS under no_grad: half = (w_dw, b_dw, fold).  Three launches."""
+    z1 = dsconv_folded(x, half1[0], half1[1], half1[2], kpl, relu_in=False)
+    z2 = dsconv_folded(z1, half2[0], half2[1], half2[2], kpl, relu_in=True)   # relu(z1) applied on load
+    one, zero = _unit_affine(z2.shape[1], z2)
+    return _affine_act_raw(z2, one, zero, True, out=z2)                        # block output, in place
+
+
 class _DSConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_dw, b_dw, w_pw, b_pw, kpl):

@@ -28,9 +28,33 @@ class DoubleConvDS(nn.Module):
                                   conv.pointwise.bias, g, b, rm, rv, training, momentum, eps,
                                   conv.kernels_per_layer_)
 
+    # ---- inference fast path: BatchNorm folded into the pointwise weights, cached until a tensor changes ----
+    EVAL_FAST_PATH = True
+
+    def _folded_half(self, i):
+        conv, bn = self.double_conv[3 * i], self.double_conv[3 * i + 1]
+        src = (conv.pointwise.weight, conv.pointwise.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        key = tuple((t.data_ptr(), t._version) if t is not None else None for t in src) + (bn.eps,)
+        cache = self.__dict__.setdefault("_fold_cache", {})
+        if cache.get(i, (None,))[0] != key:
+            cache[i] = (key, ops.fold_bn_into_pointwise(*src, bn.eps))
+        return conv.depthwise.weight, conv.depthwise.bias, cache[i][1]
+
+    def _eval_fast_ok(self, hooked):
+        import torch
+        seq = self.double_conv
+        return (self.EVAL_FAST_PATH and not hooked and not self.training and not torch.is_grad_enabled()
+                and all(seq[j].track_running_stats and seq[j].running_mean is not None and not seq[j].training
+                        for j in (1, 4))
+                and seq[0].kernels_per_layer_ == seq[3].kernels_per_layer_)
+
     def forward(self, x):
         seq = self.double_conv
         hooked = any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks for m in seq.modules())
+        if self._eval_fast_ok(hooked):
+            for conv in (seq[0], seq[3]):
+                conv._check_geometry()
+            return ops.double_conv_ds_eval(x, self._folded_half(0), self._folded_half(1), seq[0].kernels_per_layer_)
         if hooked or seq[0].kernels_per_layer_ != seq[3].kernels_per_layer_:
             x = self._half(x, seq[0], seq[1])
             return self._half(x, seq[3], seq[4])

@@ -300,24 +300,37 @@ def _recorded_calls(fn):
 
 def test_matrix_path_policy_training_vs_inference():
     """training runs every supported layer on the split GEMMs (standalone depthwise kernel +
-    smaat_pointwise_fwd_split); inference keeps the fused f32 kernel for the narrow layers."""
+    smaat_pointwise_fwd_split, the depthwise output is kept for the streamed weight gradient); inference (eval mode
+    under no_grad) folds BatchNorm into the pointwise weights and runs ONE fused launch per half block."""
     from smaat_unet_amd import ops as _ops
-    assert _ops.SPLIT_POLICY == "auto"
+    assert _ops.SPLIT_POLICY == "auto" and _ops.FUSE_DW_SPLIT == "auto"
     mod = S.DoubleConvDS(8, 16, kernels_per_layer=2)  # K = 16 / 32, Cout = 16: "narrow"
     x = torch.randn(2, 8, 8, 8)
     mod.train()
     c = _recorded_calls(lambda: mod(x.clone().requires_grad_(True)).sum().backward())
     assert c.get("smaat_dw3x3_fwd", 0) == 2 and c.get("smaat_pointwise_fwd_split", 0) >= 2, c
-    assert c.get("smaat_dsconv_fwd", 0) == 0, c
+    assert c.get("smaat_dsconv_fwd", 0) == 0 and c.get("smaat_dsconv_fwd_split", 0) == 0, c
     mod.eval()
     with torch.no_grad():
         c = _recorded_calls(lambda: mod(x))
-    assert c.get("smaat_dsconv_fwd", 0) == 2 and c.get("smaat_pointwise_fwd_split", 0) == 0, c
-    wide = S.DoubleConvDS(64, 128, kernels_per_layer=2).eval()  # K = 128 / 256, Cout = 128: split also at inference
+        c2 = _recorded_calls(lambda: mod(x))
+    # 8 x 8 planes: the f32 fused kernel, twice, + one ReLU pass; BatchNorm folded (no coefficient kernels), and the
+    # folding (smaat_split_planes of the folded weights) is cached: the second call does not repeat it
+    assert c.get("smaat_dsconv_fwd", 0) == 2 and c.get("smaat_affine_act", 0) == 1, c
+    assert c.get("smaat_bn_eval_coefs", 0) == 0 and c.get("smaat_bn_finalize", 0) == 0, c
+    assert c.get("smaat_split_planes", 0) == 2 and c2.get("smaat_split_planes", 0) == 0, (c, c2)
+    with torch.no_grad():  # a parameter update invalidates the cache
+        mod.double_conv[1].weight.mul_(1.5)
+        c3 = _recorded_calls(lambda: mod(x))
+    assert c3.get("smaat_split_planes", 0) == 1, c3
+    # planes the fused split kernel takes (W % 16 == 0): one smaat_dsconv_fwd_split per half
     with torch.no_grad():
-        c = _recorded_calls(lambda: wide(torch.randn(1, 64, 8, 8)))
-    assert c.get("smaat_pointwise_fwd_split", 0) == 2, c
-    # a width the strip depthwise kernel does not take (W % 4 != 0) falls back to the fused kernel
+        c = _recorded_calls(lambda: mod(torch.randn(1, 8, 16, 16)))
+    assert c.get("smaat_dsconv_fwd_split", 0) == 2 and c.get("smaat_dsconv_fwd", 0) == 0, c
+    # eval mode WITH autograd keeps the unfolded path (BatchNorm as an affine map with its own backward)
+    c = _recorded_calls(lambda: mod(x.clone().requires_grad_(True)).sum().backward())
+    assert c.get("smaat_bn_eval_coefs", 0) == 2, c
+    # a width the strip depthwise kernel does not take (W % 4 != 0) falls back to the fused f32 kernel in training
     mod.train()
     c = _recorded_calls(lambda: mod(torch.randn(2, 8, 6, 6)))
     assert c.get("smaat_dsconv_fwd", 0) == 2, c
