@@ -219,6 +219,22 @@ int smaat_dsconv_fwd_split(const float* x, long x_bs, const float* in_scale, con
                            const float* b_dw, const void* planes, const float* b_pw, float* z, long z_bs, float* part,
                            float* y_out, int N, int Cin, int kpl, int Cout, int H, int W, void* stream);
 
+/* ---- inference forms (reference call stack D, calc_metrics_test_set.py:119): the same three
+ *      forward GEMM entry points without statistics / side outputs and with an optional fused ReLU epilogue
+ *      (relu_out != 0: out = max(acc + bias, 0)).  With BatchNorm folded into the pointwise weights by the host
+ *      (w' = w * gamma / sqrt(running_var + eps), b' = (b - running_mean) * gamma / sqrt(running_var + eps) + beta:
+ *      eval-mode BatchNorm2d, unet_parts_depthwise_separable.py:25,34) one launch is a whole
+ *      DepthwiseSeparableConv -> BatchNorm2d -> ReLU half block.
+ */
+int smaat_dsconv_fwd_act(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                         const float* b_dw, const float* wt_pw, const float* b_pw, float* z, long z_bs, int N, int Cin,
+                         int kpl, int Cout, int H, int W, int relu_out, void* stream);
+int smaat_dsconv_fwd_split_act(const float* x, long x_bs, const float* in_scale, const float* in_shift,
+                               const float* w_dw, const float* b_dw, const void* planes, const float* b_pw, float* z,
+                               long z_bs, int N, int Cin, int kpl, int Cout, int H, int W, int relu_out, void* stream);
+int smaat_pointwise_fwd_split_act(const float* x, long x_bs, const void* planes, const float* bias, float* out,
+                                  long out_bs, int N, int Cin, int M, int H, int W, int relu_out, void* stream);
+
 /* ---- on-device PrecipitationMetrics.update ---------------------------------------------
  * replaces metric/precipitation_metrics.py:37-95 (called every train/val/test step, models/regression_lightning.py:
  * 75,86,94): NaN check, sum (p-t)^2 / batch, sum (p*f - t*f)^2 / batch, and the 4-bin confusion counts of

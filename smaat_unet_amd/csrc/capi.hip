@@ -75,6 +75,7 @@ struct DsSplitArgs {  // dsconv_split.hip
     float* part;
     float* y_out;
     int N, Cin, Kdim, M, nco, H, W, P, tiles_x, tiles_per_img, T;
+    float out_floor;
 };
 int launch_dsconv_split(DsSplitArgs& a, int kpl, hipStream_t st);
 int dsconv_split_num_slots(int N, int H, int W);
@@ -102,15 +103,29 @@ int smaat_abi_version(void) { return 1; }
 
 int smaat_pw_num_slots(int N, int H, int W, int M) { return smaat_pw_num_slots_impl(N, H, W, M); }
 
-int smaat_dsconv_fwd(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
-                     const float* b_dw, const float* wt_pw, const float* b_pw, float* z, long z_bs, float* part,
-                     float* y_out, int N, int Cin, int kpl, int Cout, int H, int W, void* stream) {
+#define NEG_INF (-__builtin_huge_valf())
+static int dsconv_fwd_impl(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                           const float* b_dw, const float* wt_pw, const float* b_pw, float* z, long z_bs, float* part,
+                           float* y_out, int N, int Cin, int kpl, int Cout, int H, int W, int relu_out, void* stream) {
     if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return -1;
     PwArgs a{};
+    a.out_floor = relu_out ? 0.f : NEG_INF;
     a.x = x; a.x_bs = x_bs; a.in_scale = in_scale; a.in_shift = in_shift; a.w_dw = w_dw; a.b_dw = b_dw;
     a.wt = wt_pw; a.bias = b_pw; a.out = z; a.out_bs = z_bs; a.part = part; a.y_out = y_out;
     a.N = N; a.Cin = Cin; a.kpl = kpl; a.Kdim = Cin * kpl; a.M = Cout; a.g.H = H; a.g.W = W;
     return launch_pwgemm(a, true, ST);
+}
+int smaat_dsconv_fwd(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                     const float* b_dw, const float* wt_pw, const float* b_pw, float* z, long z_bs, float* part,
+                     float* y_out, int N, int Cin, int kpl, int Cout, int H, int W, void* stream) {
+    return dsconv_fwd_impl(x, x_bs, in_scale, in_shift, w_dw, b_dw, wt_pw, b_pw, z, z_bs, part, y_out, N, Cin, kpl, Cout,
+                           H, W, 0, stream);
+}
+int smaat_dsconv_fwd_act(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                         const float* b_dw, const float* wt_pw, const float* b_pw, float* z, long z_bs, int N, int Cin,
+                         int kpl, int Cout, int H, int W, int relu_out, void* stream) {
+    return dsconv_fwd_impl(x, x_bs, in_scale, in_shift, w_dw, b_dw, wt_pw, b_pw, z, z_bs, nullptr, nullptr, N, Cin, kpl,
+                           Cout, H, W, relu_out, stream);
 }
 
 int smaat_pointwise_fwd(const float* x, long x_bs, const float* wt, const float* bias, float* out, long out_bs,
@@ -119,6 +134,7 @@ int smaat_pointwise_fwd(const float* x, long x_bs, const float* wt, const float*
     PwArgs a{};
     a.x = x; a.x_bs = x_bs; a.wt = wt; a.bias = bias; a.out = out; a.out_bs = out_bs; a.part = part;
     a.N = N; a.Cin = Cin; a.kpl = 1; a.Kdim = Cin; a.M = M; a.g.H = H; a.g.W = W;
+    a.out_floor = NEG_INF;
     return launch_pwgemm(a, false, ST);
 }
 
@@ -311,25 +327,49 @@ int smaat_dw3x3_fwd(const float* x, long x_bs, const float* in_scale, const floa
     if (N < 1 || Cin < 1 || H < 1 || W < 1) return -1;
     return launch_dw3x3_fwd(x, x_bs, w_dw, b_dw, y, y_bs, N, Cin, kpl, H, W, ST, in_scale, in_shift);
 }
-int smaat_pointwise_fwd_split(const float* x, long x_bs, const void* planes, const float* bias, float* out,
-                              long out_bs, float* part, int N, int Cin, int M, int H, int W, void* stream) {
+static int pointwise_fwd_split_impl(const float* x, long x_bs, const void* planes, const float* bias, float* out,
+                                    long out_bs, float* part, int N, int Cin, int M, int H, int W, int relu_out,
+                                    void* stream) {
     if (N < 1 || Cin < 1 || M < 1 || H < 1 || W < 1) return -1;
     PwSplitArgs a{};
+    a.out_floor = relu_out ? 0.f : NEG_INF;
     a.x = x; a.x_bs = x_bs; a.planes = (const unsigned short*)planes; a.bias = bias; a.out = out; a.out_bs = out_bs;
     a.part = part; a.N = N; a.Cin = Cin; a.Cp = (Cin + 15) & ~15; a.M = M; a.P = H * W;
     return launch_pw_split(a, ST);
 }
+int smaat_pointwise_fwd_split(const float* x, long x_bs, const void* planes, const float* bias, float* out,
+                              long out_bs, float* part, int N, int Cin, int M, int H, int W, void* stream) {
+    return pointwise_fwd_split_impl(x, x_bs, planes, bias, out, out_bs, part, N, Cin, M, H, W, 0, stream);
+}
+int smaat_pointwise_fwd_split_act(const float* x, long x_bs, const void* planes, const float* bias, float* out,
+                                  long out_bs, int N, int Cin, int M, int H, int W, int relu_out, void* stream) {
+    return pointwise_fwd_split_impl(x, x_bs, planes, bias, out, out_bs, nullptr, N, Cin, M, H, W, relu_out, stream);
+}
 int smaat_dsconv_split_num_slots(int N, int H, int W) { return dsconv_split_num_slots(N, H, W); }
-int smaat_dsconv_fwd_split(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
-                           const float* b_dw, const void* planes, const float* b_pw, float* z, long z_bs, float* part,
-                           float* y_out, int N, int Cin, int kpl, int Cout, int H, int W, void* stream) {
+static int dsconv_fwd_split_impl(const float* x, long x_bs, const float* in_scale, const float* in_shift,
+                                 const float* w_dw, const float* b_dw, const void* planes, const float* b_pw, float* z,
+                                 long z_bs, float* part, float* y_out, int N, int Cin, int kpl, int Cout, int H, int W,
+                                 int relu_out, void* stream) {
     if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || !planes) return -1;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return -1;
     DsSplitArgs a{};
+    a.out_floor = relu_out ? 0.f : NEG_INF;
     a.x = x; a.x_bs = x_bs; a.in_scale = in_scale; a.in_shift = in_shift; a.w_dw = w_dw; a.b_dw = b_dw;
     a.planes = (const unsigned short*)planes; a.bias = b_pw; a.out = z; a.out_bs = z_bs; a.part = part; a.y_out = y_out;
     a.N = N; a.Cin = Cin; a.Kdim = Cin * kpl; a.M = Cout; a.H = H; a.W = W;
     return launch_dsconv_split(a, kpl, ST);
+}
+int smaat_dsconv_fwd_split(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                           const float* b_dw, const void* planes, const float* b_pw, float* z, long z_bs, float* part,
+                           float* y_out, int N, int Cin, int kpl, int Cout, int H, int W, void* stream) {
+    return dsconv_fwd_split_impl(x, x_bs, in_scale, in_shift, w_dw, b_dw, planes, b_pw, z, z_bs, part, y_out, N, Cin, kpl,
+                                 Cout, H, W, 0, stream);
+}
+int smaat_dsconv_fwd_split_act(const float* x, long x_bs, const float* in_scale, const float* in_shift,
+                               const float* w_dw, const float* b_dw, const void* planes, const float* b_pw, float* z,
+                               long z_bs, int N, int Cin, int kpl, int Cout, int H, int W, int relu_out, void* stream) {
+    return dsconv_fwd_split_impl(x, x_bs, in_scale, in_shift, w_dw, b_dw, planes, b_pw, z, z_bs, nullptr, nullptr, N, Cin,
+                                 kpl, Cout, H, W, relu_out, stream);
 }
 int smaat_precip_metrics_ws_bytes(long n) { return (int)precip_metrics_ws_bytes(n); }
 int smaat_precip_metrics_update(const float* preds, const float* target, long n, int batch, float factor,

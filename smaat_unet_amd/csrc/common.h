@@ -258,6 +258,7 @@ struct PwArgs {
     int N, Cin, kpl, Kdim, M, nco, sstride;
     TileGeom g;
     int dbg;  // timing ablations only (SMAAT_PW_ABLATE): 1 = consumers skip the MFMAs, 2 = producers idle
+    float out_floor;  // epilogue: out = max(acc + bias, out_floor); -inf = plain, 0 = fused ReLU (inference path)
 };
 
 struct Wg2Args {
@@ -293,6 +294,7 @@ struct PwSplitArgs {
     float* part;  // [2][T][M] or null
     int N, Cin, Cp, M, P, nco, tiles_per_img, T, slots;
     int dbg;  // reserved (0)
+    float out_floor;  // epilogue: out = max(acc + bias, out_floor); -inf = plain, 0 = fused ReLU (inference path)
 };
 
 #define HIP_RET(expr)                          \

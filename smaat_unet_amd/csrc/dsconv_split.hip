@@ -47,6 +47,7 @@ struct DsSplitArgs {
     float* part;   // [3][T][M] or null
     float* y_out;  // [N][K][P] or null (depthwise output as a side product)
     int N, Cin, Kdim, M, nco, H, W, P, tiles_x, tiles_per_img, T;
+    float out_floor;  // epilogue: out = max(acc + bias, out_floor); -inf = plain, 0 = fused ReLU
 };
 
 // TWL: log2 of the tile width (5: 4 x 32 tile, 4: 8 x 16 tile).  NT: 3 = exact split, 1 = plain bf16 operands.
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(512, 4) void k_dsconv_split(const DsSplitArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int col = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int m = co0 + col;
-                if (m < a.M && off >= 0) obase[(long)m * a.P + off] = acc[ct][0][r] + biasl[col];
+                if (m < a.M && off >= 0) obase[(long)m * a.P + off] = fmaxf(acc[ct][0][r] + biasl[col], a.out_floor);
             }
         }
         if (a.part) {

@@ -286,8 +286,10 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
                     for (int q = 0; q < 4; ++q) {
                         const int i0 = (wpx * PXT + pt) * 32 + 8 * q + 4 * half;
                         if (p0 + i0 < g.P)  // P % 4 == 0: a group of 4 is entirely inside or outside
-                            *(float4*)(rowp + i0) = make_float4(acc[ct][pt][4 * q] + bvv, acc[ct][pt][4 * q + 1] + bvv,
-                                                                acc[ct][pt][4 * q + 2] + bvv, acc[ct][pt][4 * q + 3] + bvv);
+                            *(float4*)(rowp + i0) = make_float4(fmaxf(acc[ct][pt][4 * q] + bvv, a.out_floor),
+                                                                fmaxf(acc[ct][pt][4 * q + 1] + bvv, a.out_floor),
+                                                                fmaxf(acc[ct][pt][4 * q + 2] + bvv, a.out_floor),
+                                                                fmaxf(acc[ct][pt][4 * q + 3] + bvv, a.out_floor));
                     }
             }
         }
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(SMAAT_THREADS, 2) void k_pwgemm(const PwArgs a) {
                 float* rowp = obase + (long)m * g.P;
 #pragma unroll
                 for (int pt = 0; pt < PXT; ++pt)
-                    if (off[pt] >= 0) rowp[off[pt]] = acc[ct][pt][r] + bvv;
+                    if (off[pt] >= 0) rowp[off[pt]] = fmaxf(acc[ct][pt][r] + bvv, a.out_floor);
             }
         }
     }
@@ -689,7 +691,7 @@ __global__ __launch_bounds__(256 + NPT) void k_pwgemm_ws(const PwArgs a) {
                     float* rowp = obase + (long)m * g.P;
 #pragma unroll
                     for (int pt = 0; pt < PXT; ++pt)
-                        if (off[pt] >= 0) rowp[off[pt]] = acc[ct][pt][r] + bvv;
+                        if (off[pt] >= 0) rowp[off[pt]] = fmaxf(acc[ct][pt][r] + bvv, a.out_floor);
                 }
             }
         }
@@ -995,7 +997,7 @@ __global__ __launch_bounds__(256 + NPT) void k_dsconv_strip(const PwArgs a) {
                     float* rowp = obase + (long)m * g.P;
 #pragma unroll
                     for (int pt = 0; pt < PXT; ++pt)
-                        if (off[pt] >= 0) rowp[off[pt]] = acc[ct][pt][r] + bvv;
+                        if (off[pt] >= 0) rowp[off[pt]] = fmaxf(acc[ct][pt][r] + bvv, a.out_floor);
                 }
             }
         }

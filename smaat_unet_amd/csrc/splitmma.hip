@@ -551,7 +551,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
                     float* rowp = obase + (long)m * a.P;
 #pragma unroll
                     for (int pt = 0; pt < PXT; ++pt)
-                        if (off[pt] >= 0) rowp[off[pt]] = acc[ct][pt][r] + bvv;
+                        if (off[pt] >= 0) rowp[off[pt]] = fmaxf(acc[ct][pt][r] + bvv, a.out_floor);
                 }
             }
         }
@@ -886,7 +886,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
                     const unsigned ro = rowb + (unsigned)rc * (unsigned)a.P * 4u;
 #pragma unroll
                     for (int pt = 0; pt < PXT; ++pt)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[ct][pt][r] + bvv), rs,
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(acc[ct][pt][r] + bvv, a.out_floor)), rs,
                                                               ro + pvo[pt], 0, 0);
                 }
             }

@@ -566,36 +566,42 @@ def _unit_affine(c, ref):
     return _UNIT[key]
 
 
-def dsconv_folded(x, w_dw, b_dw, fold, kpl, relu_in):
-    """z = pointwise'(depthwise(relu?(x))) with BatchNorm folded into the pointwise conv; no autograd (inference)"""
+def dsconv_folded(x, w_dw, b_dw, fold, kpl, relu_out=True):
+    """relu?(pointwise'(depthwise(x))) with BatchNorm folded into the pointwise conv and the ReLU fused into the GEMM
+    epilogue: a whole DepthwiseSeparableConv -> BatchNorm2d(eval) -> ReLU half block.  No autograd (inference)."""
     _check(x, w_dw, b_dw)
     L = _lib.get()
     x, x_bs = _planes(x)
     n, cin, h, w = x.shape
     cout = fold["w"].shape[0]
-    isc, ish = _unit_affine(cin, x) if relu_in else (None, None)
+    ro = 1 if relu_out else 0
+    z = _new(x, n, cout, h, w)
     if fold["planes"] is not None and kpl == 2 and FUSE_DW_SPLIT != "off" and L.smaat_dsconv_split_num_slots(n, h, w) > 0:
-        z = _new(x, n, cout, h, w)
-        rc = L.smaat_dsconv_fwd_split(_ptr(x), x_bs, _ptr(isc), _ptr(ish), _ptr(w_dw), _ptr(b_dw), _ptr(fold["planes"]),
-                                      _ptr(fold["b"]), _ptr(z), cout * h * w, None, None, n, cin, kpl, cout, h, w,
-                                      _stream(x))
+        rc = L.smaat_dsconv_fwd_split_act(_ptr(x), x_bs, None, None, _ptr(w_dw), _ptr(b_dw), _ptr(fold["planes"]),
+                                          _ptr(fold["b"]), _ptr(z), cout * h * w, n, cin, kpl, cout, h, w, ro, _stream(x))
         if rc == 0:
             return z
         if rc != -2:
-            _lib.check(rc, "smaat_dsconv_fwd_split")
-    z = _new(x, n, cout, h, w)
-    _lib.check(L.smaat_dsconv_fwd(_ptr(x), x_bs, _ptr(isc), _ptr(ish), _ptr(w_dw), _ptr(b_dw), _ptr(fold["wt"]),
-                                  _ptr(fold["b"]), _ptr(z), cout * h * w, None, None, n, cin, kpl, cout, h, w,
-                                  _stream(x)), "smaat_dsconv_fwd")
+            _lib.check(rc, "smaat_dsconv_fwd_split_act")
+    if fold["planes"] is not None and _split_fwd_ok(cin * kpl, cout, train=False):
+        # GEMM-sized layers: depthwise kernel + persistent split GEMM (2 launches) beat the f32-MFMA fused kernel
+        y = _dw3x3_fwd_raw(x, w_dw, b_dw, kpl)
+        if y is not None:
+            _lib.check(L.smaat_pointwise_fwd_split_act(_ptr(y), cin * kpl * h * w, _ptr(fold["planes"]), _ptr(fold["b"]),
+                                                       _ptr(z), cout * h * w, n, cin * kpl, cout, h, w, ro, _stream(x)),
+                       "smaat_pointwise_fwd_split_act")
+            return z
+    _lib.check(L.smaat_dsconv_fwd_act(_ptr(x), x_bs, None, None, _ptr(w_dw), _ptr(b_dw), _ptr(fold["wt"]),
+                                      _ptr(fold["b"]), _ptr(z), cout * h * w, n, cin, kpl, cout, h, w, ro, _stream(x)),
+               "smaat_dsconv_fwd_act")
     return z
 
 
 def double_conv_ds_eval(x, half1, half2, kpl):
-    """eval-mode DoubleConvDS under no_grad: half = (w_dw, b_dw, fold).  Three launches."""
-    z1 = dsconv_folded(x, half1[0], half1[1], half1[2], kpl, relu_in=False)
-    z2 = dsconv_folded(z1, half2[0], half2[1], half2[2], kpl, relu_in=True)   # relu(z1) applied on load
-    one, zero = _unit_affine(z2.shape[1], z2)
-    return _affine_act_raw(z2, one, zero, True, out=z2)                        # block output, in place
+    """eval-mode DoubleConvDS under no_grad: half = (w_dw, b_dw, fold).  One fused launch per half on the
+    plane-dominated layers, depthwise + GEMM on the deep ones; no BatchNorm / ReLU kernels at all."""
+    y1 = dsconv_folded(x, half1[0], half1[1], half1[2], kpl)
+    return dsconv_folded(y1, half2[0], half2[1], half2[2], kpl)
 
 
 class _DSConv(torch.autograd.Function):

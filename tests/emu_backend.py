@@ -161,6 +161,32 @@ class EmuLib:
             f32(y_out, N * K * P)[:] = y.reshape(-1)
         return 0
 
+    # ------------------------------------------------------------------ inference forms (fused ReLU epilogue)
+    def smaat_dsconv_fwd_act(self, x, x_bs, in_scale, in_shift, w_dw, b_dw, wt_pw, b_pw, z, z_bs, N, Cin, kpl, Cout, H, W,
+                             relu_out, stream):
+        rc = self.smaat_dsconv_fwd(x, x_bs, in_scale, in_shift, w_dw, b_dw, wt_pw, b_pw, z, z_bs, None, None, N, Cin, kpl,
+                                   Cout, H, W, stream)
+        if rc == 0 and relu_out:
+            zz = planes(z, N, Cout, H * W, z_bs)
+            zz[:] = np.maximum(zz, 0)
+        return rc
+
+    def smaat_dsconv_fwd_split_act(self, x, x_bs, in_scale, in_shift, w_dw, b_dw, pl, b_pw, z, z_bs, N, Cin, kpl, Cout, H,
+                                   W, relu_out, stream):
+        rc = self.smaat_dsconv_fwd_split(x, x_bs, in_scale, in_shift, w_dw, b_dw, pl, b_pw, z, z_bs, None, None, N, Cin,
+                                         kpl, Cout, H, W, stream)
+        if rc == 0 and relu_out:
+            zz = planes(z, N, Cout, H * W, z_bs)
+            zz[:] = np.maximum(zz, 0)
+        return rc
+
+    def smaat_pointwise_fwd_split_act(self, x, x_bs, pl, bias, out, out_bs, N, Cin, M, H, W, relu_out, stream):
+        rc = self.smaat_pointwise_fwd_split(x, x_bs, pl, bias, out, out_bs, None, N, Cin, M, H, W, stream)
+        if rc == 0 and relu_out:
+            oo = planes(out, N, M, H * W, out_bs)
+            oo[:] = np.maximum(oo, 0)
+        return rc
+
     def smaat_dw3x3_bwd_ws_rows(self, N, Cin, H, W):
         return N + 1
 

@@ -259,11 +259,12 @@ def test_bn_partials_keep_the_variance_under_a_large_mean(shape):
         ref_mean, ref_var = raw.mean(dim=(0, 2, 3)), raw.var(dim=(0, 2, 3), unbiased=False)
         assert ((mean - ref_mean).abs() / ref_mean.abs()).max().item() < 1e-6, name
         assert (ref_mean.abs() / ref_var.sqrt()).min().item() > 1e3, "the case must be offset-dominated"
-        # split family: the statistics are those of the stored values to the last digit.  f32 family on a 2 x 2 map
-        # (four values per channel): one of the four differs by one ulp OF THE MEAN between the accumulator the
-        # statistics see and the stored value (2e-3 of this variance; profiles/r2/bn_partials_probe.txt) -- bounded,
-        # not explained.
-        tol = 1e-5 if name == "split" else (5e-3 if H * W * N <= 4 else 1e-3)
+        # Tile means are stored as f32: with |mean| = 1e4 x the between-tile differences, their rounding moves the
+        # between-tile term (1/128 of the variance here) by ~1e-2 of itself -> 1e-4 of the variance.  One-tile cases
+        # of the split family reproduce the variance of the stored values to the last digit.  f32 family on a 2 x 2
+        # map (four values per channel): one of the four differs by one ulp OF THE MEAN between the accumulator the
+        # statistics see and the stored value (2e-3 of this variance) -- bounded, not explained.
+        tol = 5e-3 if (name == "f32" and H * W * N <= 4) else 2e-4
         assert ((var - ref_var).abs() / ref_var).max().item() < tol, (name, ((var - ref_var).abs() / ref_var).max())
 
 

@@ -314,10 +314,12 @@ def test_matrix_path_policy_training_vs_inference():
     with torch.no_grad():
         c = _recorded_calls(lambda: mod(x))
         c2 = _recorded_calls(lambda: mod(x))
-    # 8 x 8 planes: the f32 fused kernel, twice, + one ReLU pass; BatchNorm folded (no coefficient kernels), and the
-    # folding (smaat_split_planes of the folded weights) is cached: the second call does not repeat it
-    assert c.get("smaat_dsconv_fwd", 0) == 2 and c.get("smaat_affine_act", 0) == 1, c
-    assert c.get("smaat_bn_eval_coefs", 0) == 0 and c.get("smaat_bn_finalize", 0) == 0, c
+    # 8 x 8 planes: the f32 fused kernel with the ReLU in its epilogue, twice -- TWO launches for the block; BatchNorm
+    # folded (no coefficient / activation kernels), and the folding (smaat_split_planes of the folded weights) is
+    # cached: the second call does not repeat it
+    others = ("smaat_affine_act", "smaat_bn_eval_coefs", "smaat_dw3x3_fwd", "smaat_pointwise_fwd_split_act",
+              "smaat_dsconv_fwd_split_act", "smaat_bn_finalize")
+    assert c.get("smaat_dsconv_fwd_act", 0) == 2 and not any(c.get(k, 0) for k in others), c
     assert c.get("smaat_split_planes", 0) == 2 and c2.get("smaat_split_planes", 0) == 0, (c, c2)
     with torch.no_grad():  # a parameter update invalidates the cache
         mod.double_conv[1].weight.mul_(1.5)
@@ -326,7 +328,8 @@ def test_matrix_path_policy_training_vs_inference():
     # planes the fused split kernel takes (W % 16 == 0): one smaat_dsconv_fwd_split per half
     with torch.no_grad():
         c = _recorded_calls(lambda: mod(torch.randn(1, 8, 16, 16)))
-    assert c.get("smaat_dsconv_fwd_split", 0) == 2 and c.get("smaat_dsconv_fwd", 0) == 0, c
+    assert c.get("smaat_dsconv_fwd_split_act", 0) == 2 and c.get("smaat_dsconv_fwd_act", 0) == 0, c
+    assert not any(c.get(k, 0) for k in ("smaat_affine_act", "smaat_bn_eval_coefs", "smaat_dw3x3_fwd")), c
     # eval mode WITH autograd keeps the unfolded path (BatchNorm as an affine map with its own backward)
     c = _recorded_calls(lambda: mod(x.clone().requires_grad_(True)).sum().backward())
     assert c.get("smaat_bn_eval_coefs", 0) == 2, c
