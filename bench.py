@@ -157,6 +157,15 @@ def fwd_latency(model, size, dev, iters=50):
             return round(ts[len(ts) // 2], 4)
 
         res["eager_ms"] = timed(lambda: model(x1))
+        try:  # the module-owned graph (SmaAt_UNet.enable_eval_graph): input copy + replay + output clone
+            model.enable_eval_graph(True)
+            model(x1)
+            res["module_graph_ms"] = timed(lambda: model(x1))
+            res["launches_per_forward"] = "see profiles/: ~40 kernels in one hipGraph"
+        except Exception as e:  # noqa: BLE001
+            res["module_graph_error"] = str(e)[:160]
+        finally:
+            model.enable_eval_graph(False)
         try:  # the whole forward as ONE hipGraph launch (launch-bound at batch 1)
             g = torch.cuda.CUDAGraph()
             s = torch.cuda.Stream()

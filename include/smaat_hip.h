@@ -163,6 +163,18 @@ int smaat_cbam_spconv(const float* maps, const float* wc, int ks, int N, int H, 
 int smaat_cbam_gate(const float* conv, const float* scale, const float* shift, long total, float* gate, void* stream);
 int smaat_cbam_apply(const float* x, long x_bs, const float* s, const float* gate, float* out, long out_bs, int N,
                      int C, int P, void* stream);
+/* inference (eval mode, running statistics in the spatial attention's BatchNorm2d(1): a fixed affine map, no grid-wide
+ * reduction).  A whole CBAM -- and the MaxPool2d(2) that consumes the same tensor in SmaAt_UNet.forward -- is
+ *   smaat_cbam_chpool -> smaat_cbam_eval_pool (shared MLP + sigmoid -> s [N][C], mean/max over channels of x*s -> maps)
+ *   -> smaat_cbam_eval_apply (k x k conv on maps + BN(1) eval + sigmoid -> gate; out = x*s*gate; pooled (nullable) =
+ *   maxpool2(x) from the same loads).  reference: models/layers.py:105-111,122-129,138-141. */
+int smaat_cbam_eval_pool(const float* x, long x_bs, const float* avg, const float* mx, const float* w1, const float* b1,
+                         const float* w2, const float* b2, int N, int C, int Cr, int P, float* s_out, float* maps,
+                         void* stream);
+int smaat_cbam_eval_apply(const float* x, long x_bs, const float* s, const float* maps, const float* wc, int ks,
+                          const float* bn_gamma, const float* bn_beta, const float* bn_rm, const float* bn_rv, float eps,
+                          int N, int C, int H, int W, float* out, long out_bs, float* pooled, long pooled_bs,
+                          void* stream);
 int smaat_cbam_bwd_gate(const float* dout, long dout_bs, const float* x, long x_bs, const float* s,
                         const float* gate, const float* conv, const float* mean, const float* invstd, int N, int C,
                         int P, float* dbn, float* part, void* stream);

@@ -57,6 +57,8 @@ SIGNATURES = {
     "smaat_cbam_spconv": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
     "smaat_cbam_gate": [_P, _P, _P, _L, _P, _P],
     "smaat_cbam_apply": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _P],
+    "smaat_cbam_eval_pool": [_P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "smaat_cbam_eval_apply": [_P, _L, _P, _P, _P, _I, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P, _L, _P, _L, _P],
     "smaat_cbam_bwd_gate": [_P, _L, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "smaat_cbam_bwd_spconv": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "smaat_cbam_bwd_main": [_P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P, _P],

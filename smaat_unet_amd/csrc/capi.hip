@@ -50,6 +50,10 @@ int launch_cbam_sppool(const float*, long, const float*, int, int, int, float*, 
 int launch_cbam_spconv(const float*, const float*, int, int, int, int, float*, float*, hipStream_t);
 int launch_cbam_gate(const float*, const float*, const float*, long, float*, hipStream_t);
 int launch_cbam_apply(const float*, long, const float*, const float*, float*, long, int, int, int, hipStream_t);
+int launch_cbam_eval_pool(const float*, long, const float*, const float*, const float*, const float*, const float*,
+                          const float*, int, int, int, int, float*, float*, hipStream_t);
+int launch_cbam_eval_apply(const float*, long, const float*, const float*, const float*, int, const float*, const float*,
+                           const float*, const float*, float, int, int, int, int, float*, long, float*, long, hipStream_t);
 int launch_cbam_bwd_gate(const float*, long, const float*, long, const float*, const float*, const float*,
                          const float*, const float*, int, int, int, float*, float*, hipStream_t);
 int launch_cbam_bwd_spconv(const float*, const float*, const float*, const float*, const float*, const float*,
@@ -284,6 +288,20 @@ int smaat_cbam_gate(const float* conv, const float* scale, const float* shift, l
 int smaat_cbam_apply(const float* x, long x_bs, const float* s, const float* gate, float* out, long out_bs, int N,
                      int C, int P, void* stream) {
     return launch_cbam_apply(x, x_bs, s, gate, out, out_bs, N, C, P, ST);
+}
+int smaat_cbam_eval_pool(const float* x, long x_bs, const float* avg, const float* mx, const float* w1, const float* b1,
+                         const float* w2, const float* b2, int N, int C, int Cr, int P, float* s_out, float* maps,
+                         void* stream) {
+    if (N < 1 || C < 1 || Cr < 1 || P < 1) return -1;
+    return launch_cbam_eval_pool(x, x_bs, avg, mx, w1, b1, w2, b2, N, C, Cr, P, s_out, maps, ST);
+}
+int smaat_cbam_eval_apply(const float* x, long x_bs, const float* s, const float* maps, const float* wc, int ks,
+                          const float* bn_gamma, const float* bn_beta, const float* bn_rm, const float* bn_rv, float eps,
+                          int N, int C, int H, int W, float* out, long out_bs, float* pooled, long pooled_bs,
+                          void* stream) {
+    if (N < 1 || C < 1 || H < 1 || W < 1 || !bn_rm || !bn_rv) return -1;
+    return launch_cbam_eval_apply(x, x_bs, s, maps, wc, ks, bn_gamma, bn_beta, bn_rm, bn_rv, eps, N, C, H, W, out, out_bs,
+                                  pooled, pooled_bs, ST);
 }
 int smaat_cbam_bwd_gate(const float* dout, long dout_bs, const float* x, long x_bs, const float* s,
                         const float* gate, const float* conv, const float* mean, const float* invstd, int N, int C,

@@ -237,6 +237,200 @@ __global__ __launch_bounds__(256) void k_cbam_apply(const float* __restrict__ x,
     }
 }
 
+// ===================================== inference (eval mode) ======================================
+// Three launches for a whole CBAM (+ the MaxPool2d(2) that consumes the same tensor in SmaAt_UNet.forward):
+//   k_cbam_chpool          avg / max over H*W per (n, c)                                        (as in training)
+//   k_cbam_mlp_sppool      every block recomputes the tiny shared MLP -> s[C] in LDS, then mean / max over channels
+//                          of x*s for its 256 pixels; the four waves split the channels (4x shorter load chains)
+//   k_cbam_gate_apply      k x k conv on the 2-channel maps (halo tile in LDS) + BatchNorm(1) with RUNNING statistics
+//                          (a fixed affine map: no grid-wide reduction) + sigmoid -> gate, then
+//                          out = x * s * gate for the block's channel range, and pooled = maxpool2(x) from the same loads
+// reference: models/layers.py:105-111, 122-129, 138-141; unet_parts_depthwise_separable.py:48
+__global__ __launch_bounds__(256) void k_cbam_mlp_sppool(const float* __restrict__ x, long x_bs,
+                                                         const float* __restrict__ avg, const float* __restrict__ mx,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2, int C,
+                                                         int Cr, int P, float* __restrict__ s_out,
+                                                         float* __restrict__ maps) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* la = sm;            // [C]
+    float* lm = la + C;        // [C]
+    float* sl = lm + C;        // [C]
+    float* ha = sl + C;        // [Cr]
+    float* hm = ha + Cr;       // [Cr]
+    float4* red = (float4*)(sm + ((3 * C + 2 * Cr + 3) & ~3));  // [2][4 waves][64 lanes], 16-byte aligned
+    const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < C; c += 256) {
+        la[c] = avg[(long)n * C + c];
+        lm[c] = mx[(long)n * C + c];
+    }
+    __syncthreads();
+    for (int j = wave; j < Cr; j += 4) {
+        float pa = 0.f, pm = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float w = w1[(long)j * C + c];
+            pa = fmaf(w, la[c], pa);
+            pm = fmaf(w, lm[c], pm);
+        }
+        pa = wave_sum_all(pa);
+        pm = wave_sum_all(pm);
+        if (lane == 0) {
+            ha[j] = fmaxf(pa + b1[j], 0.f);
+            hm[j] = fmaxf(pm + b1[j], 0.f);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float oa = b2[c], om = b2[c];
+        for (int j = 0; j < Cr; ++j) {
+            const float w = w2[(long)c * Cr + j];
+            oa = fmaf(w, ha[j], oa);
+            om = fmaf(w, hm[j], om);
+        }
+        const float sv = sigmoidf_(oa + om);
+        sl[c] = sv;
+        if (blockIdx.x == 0) s_out[(long)n * C + c] = sv;
+    }
+    __syncthreads();
+    // pixels p .. p+3 of this lane; wave w takes channels w, w+4, ...
+    const int p = blockIdx.x * 256 + lane * 4;
+    const bool vec = ((P & 3) == 0) && ((x_bs & 3) == 0) && ((((uintptr_t)x) & 15) == 0);
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f), m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    if (p < P) {
+        const float* xp = x + (long)n * x_bs + p;
+        if (vec) {
+            int c = wave;
+            for (; c + 12 < C; c += 16) {  // four loads in flight
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(xp + (long)(c + 4 * u) * P);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float sv = sl[c + 4 * u];
+                    const float a = v[u].x * sv, b = v[u].y * sv, cc = v[u].z * sv, d = v[u].w * sv;
+                    sum.x += a; sum.y += b; sum.z += cc; sum.w += d;
+                    m.x = fmaxf(m.x, a); m.y = fmaxf(m.y, b); m.z = fmaxf(m.z, cc); m.w = fmaxf(m.w, d);
+                }
+            }
+            for (; c < C; c += 4) {
+                const float4 v = *(const float4*)(xp + (long)c * P);
+                const float sv = sl[c];
+                const float a = v.x * sv, b = v.y * sv, cc = v.z * sv, d = v.w * sv;
+                sum.x += a; sum.y += b; sum.z += cc; sum.w += d;
+                m.x = fmaxf(m.x, a); m.y = fmaxf(m.y, b); m.z = fmaxf(m.z, cc); m.w = fmaxf(m.w, d);
+            }
+        } else {
+            for (int c = wave; c < C; c += 4) {
+                const float sv = sl[c];
+                float e[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e[q] = (p + q < P) ? xp[(long)c * P + q] * sv : 0.f;
+                sum.x += e[0]; sum.y += e[1]; sum.z += e[2]; sum.w += e[3];
+                m.x = fmaxf(m.x, e[0]); m.y = fmaxf(m.y, e[1]); m.z = fmaxf(m.z, e[2]); m.w = fmaxf(m.w, e[3]);
+            }
+        }
+    }
+    red[wave * 64 + lane] = sum;
+    red[256 + wave * 64 + lane] = m;
+    __syncthreads();
+    if (wave == 0 && p < P) {
+        float4 ts = red[lane], tm = red[256 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float4 a = red[w * 64 + lane], b = red[256 + w * 64 + lane];
+            ts.x += a.x; ts.y += a.y; ts.z += a.z; ts.w += a.w;
+            tm.x = fmaxf(tm.x, b.x); tm.y = fmaxf(tm.y, b.y); tm.z = fmaxf(tm.z, b.z); tm.w = fmaxf(tm.w, b.w);
+        }
+        const float ic = 1.f / (float)C;
+        float* m0 = maps + ((long)n * 2 + 0) * P + p;
+        float* m1 = maps + ((long)n * 2 + 1) * P + p;
+        const float so[4] = {ts.x * ic, ts.y * ic, ts.z * ic, ts.w * ic}, mo[4] = {tm.x, tm.y, tm.z, tm.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (p + q < P) {
+                m0[q] = so[q];
+                m1[q] = mo[q];
+            }
+    }
+}
+
+#define GAT_TH 8
+#define GAT_TW 32
+__global__ __launch_bounds__(256) void k_cbam_gate_apply(const float* __restrict__ x, long x_bs,
+                                                         const float* __restrict__ s, const float* __restrict__ maps,
+                                                         const float* __restrict__ wc, int ks,
+                                                         const float* __restrict__ bn_g, const float* __restrict__ bn_b,
+                                                         const float* __restrict__ bn_rm, const float* __restrict__ bn_rv,
+                                                         float eps, int C, int H, int W, int csplit,
+                                                         float* __restrict__ out, long out_bs,
+                                                         float* __restrict__ pooled, long pooled_bs) {
+    __shared__ float tile[2][GAT_TH + 6][GAT_TW + 6 + 1];
+    __shared__ float wl[2 * 49];
+    const int n = blockIdx.z / csplit, cs = blockIdx.z - n * csplit;
+    const int P = H * W;
+    const int r0 = blockIdx.y * GAT_TH, c0 = blockIdx.x * GAT_TW;
+    const int pd = ks >> 1, RH = GAT_TH + 2 * pd, RW = GAT_TW + 2 * pd;
+    const int tid = threadIdx.x;
+    if (tid < 2 * ks * ks) wl[tid] = wc[tid];
+    for (int e = tid; e < 2 * RH * RW; e += 256) {
+        const int ch = e / (RH * RW), rem = e - ch * RH * RW;
+        const int sr = rem / RW, sc = rem - sr * RW;
+        const int gr = r0 - pd + sr, gc = c0 - pd + sc;
+        float v = 0.f;
+        if (gr >= 0 && gr < H && gc >= 0 && gc < W) v = maps[((long)n * 2 + ch) * P + gr * W + gc];
+        tile[ch][sr][sc] = v;
+    }
+    __syncthreads();
+    const int tr = tid >> 5, tc = tid & 31;
+    const int r = r0 + tr, c = c0 + tc;
+    const bool valid = r < H && c < W;
+    float acc = 0.f;
+    for (int ch = 0; ch < 2; ++ch)
+        for (int i = 0; i < ks; ++i)
+            for (int j = 0; j < ks; ++j) acc = fmaf(wl[(ch * ks + i) * ks + j], tile[ch][tr + i][tc + j], acc);
+    const float is = 1.f / sqrtf(bn_rv[0] + eps);
+    const float sc_ = (bn_g ? bn_g[0] : 1.f) * is;
+    const float sh_ = (bn_b ? bn_b[0] : 0.f) - bn_rm[0] * sc_;
+    const float g = sigmoidf_(fmaf(acc, sc_, sh_));
+    // channel range of this block
+    const int per = (C + csplit - 1) / csplit;
+    const int cb = cs * per;
+    int ce = cb + per;
+    if (ce > C) ce = C;
+    const long po = (long)r * W + c;
+    const float* xp = x + (long)n * x_bs + (valid ? po : 0);
+    float* op = out + (long)n * out_bs + po;
+    const float* sp = s + (long)n * C;
+    const int Hp = H >> 1, Wp = W >> 1;
+    const bool pw = pooled != nullptr && valid && !(tr & 1) && !(tc & 1) && (r >> 1) < Hp && (c >> 1) < Wp;
+    float* pp = pooled ? pooled + (long)n * pooled_bs + (long)(r >> 1) * Wp + (c >> 1) : nullptr;
+    int ch = cb;
+    for (; ch + 3 < ce; ch += 4) {  // four loads in flight
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = xp[(long)(ch + u) * P];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float xv = valid ? v[u] : -INFINITY;
+            if (valid) op[(long)(ch + u) * P] = xv * sp[ch + u] * g;
+            if (pooled) {  // uniform
+                float mxv = fmaxf(xv, __shfl_xor(xv, 1, 64));   // the column neighbour
+                mxv = fmaxf(mxv, __shfl_xor(mxv, 32, 64));      // the row below (tile rows are 32 lanes apart)
+                if (pw) pp[(long)(ch + u) * Hp * Wp] = mxv;
+            }
+        }
+    }
+    for (; ch < ce; ++ch) {
+        const float xv = valid ? xp[(long)ch * P] : -INFINITY;
+        if (valid) op[(long)ch * P] = xv * sp[ch] * g;
+        if (pooled) {
+            float mxv = fmaxf(xv, __shfl_xor(xv, 1, 64));
+            mxv = fmaxf(mxv, __shfl_xor(mxv, 32, 64));
+            if (pw) pp[(long)ch * Hp * Wp] = mxv;
+        }
+    }
+}
+
 // ===================================== backward ======================================
 // B1: dgate[n][p] = sum_c dout*x*s ; dbn = dgate * m * (1-m); BN(1) backward partials
 //     (sum dbn, sum dbn*xhat), xhat = (conv - mean) * invstd.   part[2][nblocks]
@@ -645,6 +839,27 @@ int launch_cbam_apply(const float* x, long x_bs, const float* s, const float* ga
     const int seg = seg_len_c(P);
     hipLaunchKernelGGL(k_cbam_apply, dim3(N * C, cdivc(P, seg)), dim3(256), 0, st, x, x_bs, s, gate, out, out_bs, C,
                        P, seg);
+    return (int)hipGetLastError();
+}
+int launch_cbam_eval_pool(const float* x, long x_bs, const float* avg, const float* mx, const float* w1, const float* b1,
+                          const float* w2, const float* b2, int N, int C, int Cr, int P, float* s_out, float* maps,
+                          hipStream_t st) {
+    const size_t lds = sizeof(float) * (size_t)((3 * C + 2 * Cr + 3) & ~3) + 2 * 256 * sizeof(float4);
+    hipLaunchKernelGGL(k_cbam_mlp_sppool, dim3(cdivc(P, 256), N), dim3(256), lds, st, x, x_bs, avg, mx, w1, b1, w2, b2, C,
+                       Cr, P, s_out, maps);
+    return (int)hipGetLastError();
+}
+int launch_cbam_eval_apply(const float* x, long x_bs, const float* s, const float* maps, const float* wc, int ks,
+                           const float* bn_g, const float* bn_b, const float* bn_rm, const float* bn_rv, float eps, int N,
+                           int C, int H, int W, float* out, long out_bs, float* pooled, long pooled_bs, hipStream_t st) {
+    if (ks != 3 && ks != 7) return -1;
+    const int tx = cdivc(W, GAT_TW), ty = cdivc(H, GAT_TH);
+    int csplit = 512 / (tx * ty * N);  // enough blocks to fill the chip on the small planes of the deep levels
+    if (csplit > C / 8) csplit = C / 8;
+    if (csplit < 1) csplit = 1;
+    if ((long)N * csplit > 65535) csplit = 1;
+    hipLaunchKernelGGL(k_cbam_gate_apply, dim3(tx, ty, N * csplit), dim3(256), 0, st, x, x_bs, s, maps, wc, ks, bn_g, bn_b,
+                       bn_rm, bn_rv, eps, C, H, W, csplit, out, out_bs, pooled, pooled_bs);
     return (int)hipGetLastError();
 }
 int launch_cbam_bwd_gate(const float* dout, long dout_bs, const float* x, long x_bs, const float* s,

@@ -102,9 +102,20 @@ class CBAM(nn.Module):
         self.channel_att = ChannelAttention(input_channels, reduction_ratio=reduction_ratio)
         self.spatial_att = SpatialAttention(kernel_size=kernel_size)
 
+    EVAL_FAST_PATH = True
+
+    def _eval_fast(self):
+        import torch
+        bn = self.spatial_att.bn
+        return (self.EVAL_FAST_PATH and not self.training and not bn.training and not torch.is_grad_enabled()
+                and bn.track_running_stats and bn.running_mean is not None)
+
     def forward(self, x):
         w1, b1, w2, b2 = self.channel_att._mlp_params()
         sp = self.spatial_att
+        if self._eval_fast():  # inference: three launches, BatchNorm(1) on the running statistics
+            return ops.cbam_eval(x, w1, b1, w2, b2, sp.conv.weight, sp.bn.weight, sp.bn.bias, sp.bn.running_mean,
+                                 sp.bn.running_var, sp.bn.eps)
         g, b, rm, rv, training, momentum, eps = _bn_args(sp.bn)
         return ops.cbam(x, w1, b1, w2, b2, sp.conv.weight, g, b, rm, rv, training, momentum, eps, True, True)
 
@@ -114,5 +125,12 @@ class CBAM(nn.Module):
         SmaAt_UNet.forward, sharing one backward pass over x."""
         w1, b1, w2, b2 = self.channel_att._mlp_params()
         sp = self.spatial_att
+        if self._eval_fast():
+            import torch
+            n, c, h, w = x.shape
+            cat = torch.empty((n, c + c_extra, h, w), dtype=x.dtype, device=x.device)
+            _, pooled = ops.cbam_eval(x, w1, b1, w2, b2, sp.conv.weight, sp.bn.weight, sp.bn.bias, sp.bn.running_mean,
+                                      sp.bn.running_var, sp.bn.eps, out=cat[:, :c], pool=True)
+            return cat, pooled
         g, b, rm, rv, training, momentum, eps = _bn_args(sp.bn)
         return ops.cbam_pool_cat(x, w1, b1, w2, b2, sp.conv.weight, g, b, rm, rv, training, momentum, eps, c_extra)

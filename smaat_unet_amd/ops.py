@@ -890,6 +890,36 @@ def _cbam_backward_impl(saved, flags, dout):
     return dx, dw1, db1, dw2, db2, dwconv, dgamma, dbeta
 
 
+def cbam_eval(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, eps, out=None, pool=False):
+    """Inference CBAM (eval mode, no autograd): three launches -- channel pooling, shared MLP + channel-wise
+    mean/max maps, spatial conv + BatchNorm(1) on the running statistics + sigmoid + the final product -- and,
+    with pool=True, MaxPool2d(2) of the un-attended input from the same loads.  Returns out or (out, pooled)."""
+    _check(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv)
+    L = _lib.get()
+    x, x_bs = _planes(x)
+    n, c, h, w = x.shape
+    p = h * w
+    cr = w1.shape[0]
+    s_ = _stream(x)
+    w1, w2, wconv = w1.contiguous(), w2.contiguous(), wconv.contiguous()
+    avg, mx = _new(x, n, c), _new(x, n, c)
+    amax = _new(x, n, c, dtype=torch.int32)
+    _lib.check(L.smaat_cbam_chpool(_ptr(x), x_bs, n, c, p, _ptr(avg), _ptr(mx), _ptr(amax), s_), "smaat_cbam_chpool")
+    sc = _new(x, n, c)
+    maps = _new(x, n, 2, h, w)
+    _lib.check(L.smaat_cbam_eval_pool(_ptr(x), x_bs, _ptr(avg), _ptr(mx), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), n, c,
+                                      cr, p, _ptr(sc), _ptr(maps), s_), "smaat_cbam_eval_pool")
+    if out is None:
+        out = _new(x, n, c, h, w)
+    out_t, o_bs = _planes(out)
+    assert out_t is out, "cbam: the output slice must have dense [C][H][W] planes"
+    pooled = _new(x, n, c, h // 2, w // 2) if pool else None
+    _lib.check(L.smaat_cbam_eval_apply(_ptr(x), x_bs, _ptr(sc), _ptr(maps), _ptr(wconv), wconv.shape[-1], _ptr(gamma),
+                                       _ptr(beta), _ptr(rm), _ptr(rv), float(eps), n, c, h, w, _ptr(out), o_bs,
+                                       _ptr(pooled), c * (h // 2) * (w // 2) if pool else 0, s_), "smaat_cbam_eval_apply")
+    return (out, pooled) if pool else out
+
+
 class _CBAM(torch.autograd.Function):
     """out = spatial_att(channel_att(x)); either half can be switched off (standalone
     ChannelAttention / SpatialAttention modules reuse the same kernels)."""

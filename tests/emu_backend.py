@@ -468,6 +468,28 @@ class EmuLib:
         pp[2, 1] = c64.size
         return 0
 
+    def smaat_cbam_eval_pool(self, x, x_bs, avg, mx, w1, b1, w2, b2, N, C, Cr, P, s_out, maps, stream):
+        ha = np.empty(N * Cr, np.float32)
+        hm = np.empty(N * Cr, np.float32)
+        self.smaat_cbam_mlp(avg, mx, w1, b1, w2, b2, N, C, Cr, ha.ctypes.data, hm.ctypes.data, s_out, stream)
+        return self.smaat_cbam_sppool(x, x_bs, s_out, N, C, P, maps, stream)
+
+    def smaat_cbam_eval_apply(self, x, x_bs, s, maps, wc, ks, bn_g, bn_b, bn_rm, bn_rv, eps, N, C, H, W, out, out_bs,
+                              pooled, pooled_bs, stream):
+        P = H * W
+        mp = f32(maps, N * 2 * P).reshape(N, 2, H, W)
+        cv = O.conv2d_same_fwd(mp, f32(wc, 2 * ks * ks).reshape(1, 2, ks, ks)).reshape(N, P)
+        isd = np.float32(1.0) / np.sqrt(f32(bn_rv, 1)[0] + np.float32(eps))
+        sc = (f32(bn_g, 1)[0] if bn_g else np.float32(1)) * isd
+        sh = (f32(bn_b, 1)[0] if bn_b else np.float32(0)) - f32(bn_rm, 1)[0] * sc
+        gate = O.sigmoid(cv * sc + sh).astype(np.float32)
+        xv = planes(x, N, C, P, x_bs)
+        planes(out, N, C, P, out_bs)[:] = (xv * f32(s, N * C).reshape(N, C)[:, :, None]) * gate[:, None, :]
+        if pooled:
+            yv, _ = O.maxpool2_fwd(np.array(xv).reshape(N, C, H, W))
+            planes(pooled, N, C, (H // 2) * (W // 2), pooled_bs)[:] = yv.reshape(N, C, -1)
+        return 0
+
     def smaat_cbam_gate(self, conv, scale, shift, total, gate, stream):
         f32(gate, total)[:] = O.sigmoid(f32(conv, total) * f32(scale, 1)[0] + f32(shift, 1)[0])
         return 0

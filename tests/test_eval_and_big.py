@@ -253,3 +253,37 @@ def test_big_cases_gpu(golden_dir, name, policy, monkeypatch):
         if os.path.isdir("gpurun_out"):
             with open(f"gpurun_out/big_case_{name}_{policy}.json", "w") as f:
                 json.dump(report, f, indent=1, default=float)
+
+
+@pytest.mark.gpu
+def test_module_owned_eval_graph(golden_dir):
+    """SmaAt_UNet.enable_eval_graph(): the inference forward as one hipGraph owned by the module -- replay equals the
+    eager fast path bit for bit and the reference fixture to 1e-4; a weight update rebuilds the graph."""
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(golden_dir, "unet_12x1_n3_64x48_eval.npz"))
+    meta = json.loads(str(g["meta"]))
+    (x, _), (xe, _) = big_inputs(meta)
+    P = oparams.make_smaat_params(12, 1, 2, 16, meta["param_seed"])
+    model = S.SmaAt_UNet(12, 1)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in P.items()})
+    model.to(dev).train()
+    with torch.no_grad():
+        model(torch.from_numpy(x).to(dev))  # the training step of the fixture (running statistics)
+    model.eval()
+    xb = torch.from_numpy(xe).to(dev)
+    with torch.no_grad():
+        eager = model(xb)
+        model.enable_eval_graph()
+        y1 = model(xb)
+        y2 = model(xb[:1])          # another shape: a second graph
+        y3 = model(xb)              # replay of the first
+    assert torch.equal(y1, eager) and torch.equal(y3, eager) and torch.equal(y2, eager[:1])
+    assert check_summary(g, "eval/logits", y1.cpu().numpy()) < 1e-4
+    assert len(model._graphs) == 2
+    with torch.no_grad():
+        model.outc.conv.bias.add_(1.0)
+        y4 = model(xb)
+    assert torch.allclose(y4, eager + 1.0, atol=1e-5)
+    model.train()                    # training mode never takes the graph
+    out = model(xb)
+    assert out.requires_grad

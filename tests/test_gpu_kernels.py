@@ -540,6 +540,40 @@ def test_pool_upsample(shape):
 
 
 # ----------------------------------------------------------------------------------------
+def case_cbam_eval(L, dev, N, C, H, W, ks=7, rr=16, pool=True, pad_c=0):
+    """inference CBAM: chpool -> eval_pool (MLP + channel-wise maps) -> eval_apply (conv + BN(1) running stats + sigmoid
+    + product, + maxpool2 of the input), output written into a channel slice of a larger buffer"""
+    Pn, Cr = H * W, max(C // rr, 1)
+    x = T(np.maximum(rnd(1, N, C, H, W), 0) + 0.01 * rnd(11, N, C, H, W), dev)
+    w1, b1 = T(rnd(2, Cr, C, scale=0.3), dev), T(rnd(3, Cr, scale=0.1), dev)
+    w2, b2 = T(rnd(4, C, Cr, scale=0.3), dev), T(rnd(5, C, scale=0.1), dev)
+    wc = T(rnd(6, 2, ks, ks, scale=0.2), dev)
+    g, b = T(np.array([1.3], np.float32), dev), T(np.array([-0.2], np.float32), dev)
+    rm, rv = T(np.array([0.15], np.float32), dev), T(np.array([0.7], np.float32), dev)
+    s = stream(dev)
+    avg, mx = torch.empty((N, C), device=dev), torch.empty((N, C), device=dev)
+    amax = torch.empty((N, C), dtype=torch.int32, device=dev)
+    assert L.smaat_cbam_chpool(P(x), C * Pn, N, C, Pn, P(avg), P(mx), P(amax), s) == 0
+    sc, maps = torch.full((N, C), float("nan"), device=dev), torch.full((N, 2, H, W), float("nan"), device=dev)
+    assert L.smaat_cbam_eval_pool(P(x), C * Pn, P(avg), P(mx), P(w1), P(b1), P(w2), P(b2), N, C, Cr, Pn, P(sc), P(maps),
+                                  s) == 0
+    cat = torch.full((N, C + pad_c, H, W), float("nan"), device=dev)
+    pooled = torch.full((N, C, H // 2, W // 2), float("nan"), device=dev) if pool else None
+    assert L.smaat_cbam_eval_apply(P(x), C * Pn, P(sc), P(maps), P(wc), ks, P(g), P(b), P(rm), P(rv), 1e-5, N, C, H, W,
+                                   P(cat), (C + pad_c) * Pn, P(pooled), C * (H // 2) * (W // 2) if pool else 0, s) == 0
+    r = dict(s=sc, maps=maps, out=cat[:, :C])
+    if pool:
+        r["pooled"] = pooled
+    return r
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 10, 10), (1, 64, 288, 288), (2, 512, 18, 18), (1, 128, 36, 36), (3, 10, 9, 12),
+                                   (2, 16, 7, 33), (1, 256, 72, 72)])
+def test_cbam_eval(shape):
+    both(case_cbam_eval, *shape, tol=2e-6)
+    both(case_cbam_eval, *shape, ks=3, rr=8, pool=False, pad_c=3, tol=2e-6)
+
+
 def case_pixel_shuffle(L, dev, N, Co, H, W, Ho, Wo, slice_pad=0):
     """ConvTranspose2d(k=2, s=2) tail: 2x2 pixel shuffle + bias into a padded slice of a cat buffer, and its inverse"""
     t = T(rnd(1, N, 4 * Co, H, W), dev)
