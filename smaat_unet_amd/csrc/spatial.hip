@@ -916,10 +916,108 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_strip(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Small planes (any H, W with H*W <= DWS_PMAX, e.g. the 18 x 18 maps of the deepest level whose rows are not
+// 16-byte aligned): whole planes are copied flat into LDS (no alignment requirement), PPB planes per workgroup so that
+// all 256 threads have work, and the 3x3 window is read with boundary predicates instead of a zero halo.
+// Workgroups walk over plane groups with the next group's loads in flight.
+// ---------------------------------------------------------------------------------
+#define DWS_PMAX 1600
+#define DWS_LDS_FLOATS 8192
+
+template <int KPL>
+__global__ __launch_bounds__(256) void k_dw3x3_fwd_small(const float* __restrict__ x, long x_bs,
+                                                         const float* __restrict__ w_dw, const float* __restrict__ b_dw,
+                                                         float* __restrict__ y, long y_bs, int NC, int Cin, int H, int W,
+                                                         int PPB, const float* __restrict__ in_scale,
+                                                         const float* __restrict__ in_shift) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const int P = H * W, tid = threadIdx.x;
+    const int ngroups = (NC + PPB - 1) / PPB;
+    const float invW = 1.0f / (float)W;
+    constexpr int NLD = DWS_LDS_FLOATS / 256;  // staged elements per thread (PPB * P <= DWS_LDS_FLOATS)
+    float sv[NLD];
+    auto prefetch = [&](int g) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = tid + 256 * k;
+            const int pl = e / P, p = e - pl * P;
+            const int pi = g * PPB + pl;
+            const bool ok = pl < PPB && pi < NC;
+            const int pic = ok ? pi : 0;
+            const int n = pic / Cin, ci = pic - n * Cin;
+            float v = x[(long)n * x_bs + (long)ci * P + (ok ? p : 0)];
+            if (in_scale) v = fmaxf(fmaf(v, in_scale[ci], in_shift[ci]), 0.f);
+            sv[k] = v;
+        }
+    };
+    int g = blockIdx.x;
+    if (g < ngroups) prefetch(g);
+    for (; g < ngroups; g += gridDim.x) {
+        __syncthreads();  // the previous group's reads are done
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = tid + 256 * k;
+            if (e < PPB * P) dsm[e] = sv[k];
+        }
+        __syncthreads();
+        {
+            const int gn = g + gridDim.x;
+            prefetch(gn < ngroups ? gn : g);
+        }
+        for (int e = tid; e < PPB * P; e += 256) {
+            const int pl = e / P, p = e - pl * P;
+            const int pi = g * PPB + pl;
+            if (pi >= NC) break;
+            const int r = (int)(((float)p + 0.5f) * invW), c = p - r * W;
+            const float* sp = dsm + pl * P + p;
+            float v[3][3];
+#pragma unroll
+            for (int dr = 0; dr < 3; ++dr)
+#pragma unroll
+                for (int dc = 0; dc < 3; ++dc) {
+                    const bool in = (r + dr - 1) >= 0 && (r + dr - 1) < H && (c + dc - 1) >= 0 && (c + dc - 1) < W;
+                    v[dr][dc] = in ? sp[(dr - 1) * W + (dc - 1)] : 0.f;
+                }
+            const int n = pi / Cin, ci = pi - n * Cin;
+            float* yp = y + (long)n * y_bs + (long)(ci * KPL) * P + p;
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                const float* wt = w_dw + (ci * KPL + j) * 9;
+                float acc = b_dw ? b_dw[ci * KPL + j] : 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc = fmaf(wt[t], v[t / 3][t % 3], acc);
+                yp[(long)j * P] = acc;
+            }
+        }
+    }
+}
+
+static int launch_dw3x3_fwd_small(const float* x, long x_bs, const float* w_dw, const float* b_dw, float* y, long y_bs,
+                                  int N, int Cin, int kpl, int H, int W, hipStream_t st, const float* in_scale,
+                                  const float* in_shift) {
+    const int P = H * W;
+    int PPB = DWS_LDS_FLOATS / P;
+    if (PPB > 16) PPB = 16;
+    const int NC = N * Cin;
+    int grid = (NC + PPB - 1) / PPB;
+    if (grid > 2048) grid = 2048;
+    const size_t lds = sizeof(float) * (size_t)PPB * P;
+#define DWS_LAUNCH(K) hipLaunchKernelGGL(k_dw3x3_fwd_small<K>, dim3(grid), dim3(256), lds, st, x, x_bs, w_dw, b_dw, y, y_bs, NC, Cin, H, W, PPB, in_scale, in_shift)
+    if (kpl == 1) DWS_LAUNCH(1);
+    else if (kpl == 2) DWS_LAUNCH(2);
+    else DWS_LAUNCH(4);
+#undef DWS_LAUNCH
+    return (int)hipGetLastError();
+}
+
 int launch_dw3x3_fwd(const float* x, long x_bs, const float* w_dw, const float* b_dw, float* y, long y_bs, int N,
                      int Cin, int kpl, int H, int W, hipStream_t st, const float* in_scale, const float* in_shift) {
     const bool aligned = ((W & 3) == 0) && ((x_bs & 3) == 0) && ((((uintptr_t)x) & 15) == 0) && H >= 1 &&
                          (kpl == 1 || kpl == 2 || kpl == 4);
+    if (!(kpl == 1 || kpl == 2 || kpl == 4)) return -2;
+    if (!aligned && H * W <= DWS_PMAX)  // small planes with unaligned rows (18 x 18 ...): the flat-copy kernel
+        return launch_dw3x3_fwd_small(x, x_bs, w_dw, b_dw, y, y_bs, N, Cin, kpl, H, W, st, in_scale, in_shift);
     if (!aligned) return -2;  // caller falls back to the fused f32 kernel
     const DwbGeom sg = strip_geom(H, W, 1);
     if (sg.nrow * sg.ncol4 > 1536) return -2;

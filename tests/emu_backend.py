@@ -113,7 +113,7 @@ class EmuLib:
         return 0
 
     def smaat_dw3x3_fwd(self, x, x_bs, in_scale, in_shift, w_dw, b_dw, y, y_bs, N, Cin, kpl, H, W, stream):
-        if W % 4:
+        if kpl not in (1, 2, 4) or (W % 4 and H * W > 1600):  # small planes take the flat-copy kernel, any width
             return -2
         P, K = H * W, Cin * kpl
         xv = np.array(planes(x, N, Cin, P, x_bs)).reshape(N, Cin, H, W)

@@ -342,7 +342,9 @@ def case_dw_fwd(L, dev, N, Cin, kpl, H, W, bias=True, pad_c=0, aff=False):
 @pytest.mark.parametrize("shape", [(2, 12, 2, 32, 32), (2, 5, 1, 8, 8), (2, 8, 2, 36, 36), (2, 4, 2, 144, 144),
                                    (2, 3, 2, 288, 288), (1, 4, 2, 100, 100), (2, 8, 2, 4, 4), (1, 3, 4, 8, 12),
                                    (2, 4, 2, 72, 72), (1, 5, 2, 10, 12), (1, 2, 2, 50, 64), (1, 2, 1, 21, 48),
-                                   (1, 2, 2, 3, 4), (1, 2, 2, 1, 8)])
+                                   (1, 2, 2, 3, 4), (1, 2, 2, 1, 8),
+                                   # rows that are not 16-byte aligned: the flat-copy small-plane kernel
+                                   (2, 20, 2, 18, 18), (3, 5, 1, 9, 11), (1, 3, 4, 7, 5), (2, 37, 2, 6, 6), (1, 2, 2, 39, 41)])
 def test_dw3x3_fwd(shape):
     both(case_dw_fwd, *shape)
     both(case_dw_fwd, *shape, bias=False, pad_c=4)

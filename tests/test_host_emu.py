@@ -333,9 +333,12 @@ def test_matrix_path_policy_training_vs_inference():
     # eval mode WITH autograd keeps the unfolded path (BatchNorm as an affine map with its own backward)
     c = _recorded_calls(lambda: mod(x.clone().requires_grad_(True)).sum().backward())
     assert c.get("smaat_bn_eval_coefs", 0) == 2, c
-    # a width the strip depthwise kernel does not take (W % 4 != 0) falls back to the fused f32 kernel in training
+    # small planes of any width run the flat-copy depthwise kernel + split GEMM; a LARGE plane whose rows are not
+    # 16-byte aligned (W % 4 != 0) falls back to the fused f32 kernel in training
     mod.train()
     c = _recorded_calls(lambda: mod(torch.randn(2, 8, 6, 6)))
+    assert c.get("smaat_dw3x3_fwd", 0) == 2 and c.get("smaat_dsconv_fwd", 0) == 0, c
+    c = _recorded_calls(lambda: mod(torch.randn(1, 8, 42, 42)))
     assert c.get("smaat_dsconv_fwd", 0) == 2, c
 
 
