@@ -924,6 +924,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_strip(const float* __restrict
 // ---------------------------------------------------------------------------------
 #define DWS_PMAX 1600
 #define DWS_LDS_FLOATS 8192
+#define DWS_NLD 24  // staged values per thread
 
 template <int KPL>
 __global__ __launch_bounds__(256) void k_dw3x3_fwd_small(const float* __restrict__ x, long x_bs,
@@ -931,63 +932,79 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_small(const float* __restrict
                                                          float* __restrict__ y, long y_bs, int NC, int Cin, int H, int W,
                                                          int PPB, const float* __restrict__ in_scale,
                                                          const float* __restrict__ in_shift) {
+    // PPB (a power of two <= 16) planes per group; the 256 / PPB threads of a plane keep its taps in registers
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     const int P = H * W, tid = threadIdx.x;
+    const int TPP = 256 / PPB, pl = tid / TPP, lt = tid - pl * TPP;
     const int ngroups = (NC + PPB - 1) / PPB;
     const float invW = 1.0f / (float)W;
-    constexpr int NLD = DWS_LDS_FLOATS / 256;  // staged elements per thread (PPB * P <= DWS_LDS_FLOATS)
-    float sv[NLD];
+    const int nld = (P + TPP - 1) / TPP;  // elements of its plane each thread stages (<= DWS_NLD)
+    float sv[DWS_NLD];
+    float wt[KPL][9], bs[KPL];
     auto prefetch = [&](int g) {
+        const int pi = g * PPB + pl;
+        const int pic = pi < NC ? pi : NC - 1;
+        const int n = pic / Cin, ci = pic - n * Cin;
+        const float* xp = x + (long)n * x_bs + (long)ci * P;
+        const float sc = in_scale ? in_scale[ci] : 1.f, sh = in_scale ? in_shift[ci] : 0.f;
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int e = tid + 256 * k;
-            const int pl = e / P, p = e - pl * P;
-            const int pi = g * PPB + pl;
-            const bool ok = pl < PPB && pi < NC;
-            const int pic = ok ? pi : 0;
-            const int n = pic / Cin, ci = pic - n * Cin;
-            float v = x[(long)n * x_bs + (long)ci * P + (ok ? p : 0)];
-            if (in_scale) v = fmaxf(fmaf(v, in_scale[ci], in_shift[ci]), 0.f);
+        for (int k = 0; k < DWS_NLD; ++k) {
+            const int p = lt + TPP * k;
+            float v = xp[p < P ? p : P - 1];
+            if (in_scale) v = fmaxf(fmaf(v, sc, sh), 0.f);
             sv[k] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wt[j][t] = w_dw[(ci * KPL + j) * 9 + t];
+            bs[j] = b_dw ? b_dw[ci * KPL + j] : 0.f;
         }
     };
     int g = blockIdx.x;
     if (g < ngroups) prefetch(g);
     for (; g < ngroups; g += gridDim.x) {
+        float w0[KPL][9], b0[KPL];
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) w0[j][t] = wt[j][t];
+            b0[j] = bs[j];
+        }
         __syncthreads();  // the previous group's reads are done
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int e = tid + 256 * k;
-            if (e < PPB * P) dsm[e] = sv[k];
+        for (int k = 0; k < DWS_NLD; ++k) {
+            const int p = lt + TPP * k;
+            if (k < nld && p < P) dsm[pl * P + p] = sv[k];
         }
         __syncthreads();
         {
             const int gn = g + gridDim.x;
-            prefetch(gn < ngroups ? gn : g);
+            prefetch(gn < ngroups ? gn : g);  // in flight during the compute below
         }
-        for (int e = tid; e < PPB * P; e += 256) {
-            const int pl = e / P, p = e - pl * P;
-            const int pi = g * PPB + pl;
-            if (pi >= NC) break;
-            const int r = (int)(((float)p + 0.5f) * invW), c = p - r * W;
-            const float* sp = dsm + pl * P + p;
-            float v[3][3];
-#pragma unroll
-            for (int dr = 0; dr < 3; ++dr)
-#pragma unroll
-                for (int dc = 0; dc < 3; ++dc) {
-                    const bool in = (r + dr - 1) >= 0 && (r + dr - 1) < H && (c + dc - 1) >= 0 && (c + dc - 1) < W;
-                    v[dr][dc] = in ? sp[(dr - 1) * W + (dc - 1)] : 0.f;
-                }
+        const int pi = g * PPB + pl;
+        if (pi < NC) {
             const int n = pi / Cin, ci = pi - n * Cin;
-            float* yp = y + (long)n * y_bs + (long)(ci * KPL) * P + p;
+            const float* sb = dsm + pl * P;
+            float* yb = y + (long)n * y_bs + (long)(ci * KPL) * P;
+            for (int p = lt; p < P; p += TPP) {
+                const int r = (int)(((float)p + 0.5f) * invW), c = p - r * W;
+                const float* sp = sb + p;
+                float v[3][3];
 #pragma unroll
-            for (int j = 0; j < KPL; ++j) {
-                const float* wt = w_dw + (ci * KPL + j) * 9;
-                float acc = b_dw ? b_dw[ci * KPL + j] : 0.f;
+                for (int dr = 0; dr < 3; ++dr)
 #pragma unroll
-                for (int t = 0; t < 9; ++t) acc = fmaf(wt[t], v[t / 3][t % 3], acc);
-                yp[(long)j * P] = acc;
+                    for (int dc = 0; dc < 3; ++dc) {
+                        const bool in = (r + dr - 1) >= 0 && (r + dr - 1) < H && (c + dc - 1) >= 0 && (c + dc - 1) < W;
+                        v[dr][dc] = in ? sp[(dr - 1) * W + (dc - 1)] : 0.f;
+                    }
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+                    float acc = b0[j];
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) acc = fmaf(w0[j][t], v[t / 3][t % 3], acc);
+                    yb[(long)j * P + p] = acc;
+                }
             }
         }
     }
@@ -997,8 +1014,9 @@ static int launch_dw3x3_fwd_small(const float* x, long x_bs, const float* w_dw, 
                                   int N, int Cin, int kpl, int H, int W, hipStream_t st, const float* in_scale,
                                   const float* in_shift) {
     const int P = H * W;
-    int PPB = DWS_LDS_FLOATS / P;
-    if (PPB > 16) PPB = 16;
+    int PPB = 16;  // planes per workgroup: a power of two, 256 / PPB threads per plane, <= DWS_NLD staged values per thread
+    while (PPB > 1 && ((P + 256 / PPB - 1) / (256 / PPB) > DWS_NLD || PPB * P > DWS_LDS_FLOATS)) PPB >>= 1;
+    if ((P + 256 / PPB - 1) / (256 / PPB) > DWS_NLD || PPB * P > DWS_LDS_FLOATS) return -2;
     const int NC = N * Cin;
     int grid = (NC + PPB - 1) / PPB;
     if (grid > 2048) grid = 2048;
