@@ -36,6 +36,8 @@ class DepthwiseSeparableConv(nn.Module):
         )
         self.pointwise = nn.Conv2d(in_channels * kernels_per_layer, output_channels, kernel_size=1)
         self.kernels_per_layer_ = kernels_per_layer
+        if kernels_per_layer not in (1, 2, 4):  # the reference accepts any integer; its scripts use 1, 2 and 4
+            raise NotImplementedError(f"kernels_per_layer={kernels_per_layer}: the gfx950 kernels are built for 1, 2, 4")
 
     def _check_geometry(self):
         dw = self.depthwise

@@ -8,8 +8,12 @@ update is one streaming HIP pass + a one-block finish that accumulates into pers
   * a batch containing a NaN is skipped on the device and counted; the reference's warning is printed by
     `compute()` (when the state is read back) instead of by `update()`;
   * the sums are accumulated in float64 (the reference adds float32 scalars);
-  * `torchmetrics` is not a dependency: cross-process reduction is `sync(group)` = one all-reduce of the 9 state
-    values (the reference's dist_reduce_fx="sum" on every state).
+  * `torchmetrics` is not a dependency: cross-process reduction follows its sync/unsync protocol -- when
+    `torch.distributed` is initialised, `compute()` all-reduces a COPY of the 9 state values
+    (dist_reduce_fx="sum" on every state) and leaves the local accumulators untouched, so repeated compute() /
+    update() cycles never double count; every rank takes part in the collective, also one that never called
+    `update()`.  `dist_sync_on_step=True` (per-step synchronisation of the forward value) is rejected: the
+    reference never sets it and this class has no per-step forward value.
 """
 from __future__ import annotations
 
@@ -22,10 +26,14 @@ _I64 = ("nan_batches", "total_tn", "total_fp", "total_fn", "total_tp", "total_sa
 
 
 class PrecipitationMetrics:
-    def __init__(self, threshold=0.5, denormalize=True, dist_sync_on_step=False):
+    def __init__(self, threshold=0.5, denormalize=True, dist_sync_on_step=False, process_group=None, device=None):
+        if dist_sync_on_step:
+            raise NotImplementedError("PrecipitationMetrics: dist_sync_on_step=True is not supported (see module docstring)")
         self.threshold = threshold
         self.denormalize = denormalize
-        self.dist_sync_on_step = dist_sync_on_step
+        self.dist_sync_on_step = False
+        self.process_group = process_group
+        self._device = torch.device(device) if device is not None else None
         self.factor = 47.83  # reference :23
         self._f64 = None
         self._i64 = None
@@ -48,19 +56,35 @@ class PrecipitationMetrics:
             self._f64.zero_()
             self._i64.zero_()
 
-    def state(self):
-        """name -> python number (synchronises)"""
+    def _local_state(self, device=None):
+        """the two state tensors, allocated (as zeros) when this rank has not seen an update yet"""
         if self._f64 is None:
-            return {**{k: 0.0 for k in _F64}, **{k: 0 for k in _I64}}
-        f, i = self._f64.tolist(), self._i64.tolist()
-        return {**dict(zip(_F64, f)), **dict(zip(_I64, i))}
+            dev = device or self._device or (torch.device("cuda", torch.cuda.current_device())
+                                             if torch.cuda.is_available() else torch.device("cpu"))
+            self._f64 = torch.zeros(len(_F64), dtype=torch.float64, device=dev)
+            self._i64 = torch.zeros(len(_I64), dtype=torch.int64, device=dev)
+        return self._f64, self._i64
+
+    def state(self, sync=True):
+        """name -> python number (synchronises the host).  With torch.distributed initialised and sync=True the values
+        are the totals over the ranks of `process_group`: the collective runs on COPIES (torchmetrics' sync/unsync), the
+        local accumulators keep counting from where they were."""
+        import torch.distributed as dist
+        f, i = self._local_state()
+        if sync and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
+            f, i = f.clone(), i.clone()
+            dist.all_reduce(f, group=self.process_group)
+            dist.all_reduce(i, group=self.process_group)
+        return {**dict(zip(_F64, f.tolist())), **dict(zip(_I64, i.tolist()))}
 
     def sync(self, group=None):
-        """sum the state over the ranks of `group` (torch.distributed); every rank ends with the totals"""
+        """explicitly REPLACE the local state by the totals over the ranks (every rank must call it; a rank without
+        updates contributes zeros).  Prefer compute(), which reduces copies; calling sync() twice double counts."""
         import torch.distributed as dist
-        if self._f64 is not None and dist.is_available() and dist.is_initialized():
-            dist.all_reduce(self._f64, group=group)
-            dist.all_reduce(self._i64, group=group)
+        f, i = self._local_state()
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(f, group=group if group is not None else self.process_group)
+            dist.all_reduce(i, group=group if group is not None else self.process_group)
 
     # -- reference API -------------------------------------------------------------------------------
     def update(self, preds, target):
@@ -86,8 +110,8 @@ class PrecipitationMetrics:
                                                  self._ws.data_ptr(), self._f64.data_ptr(), self._i64.data_ptr(),
                                                  stream), "smaat_precip_metrics_update")
 
-    def compute(self):
-        s = self.state()
+    def compute(self, sync=True):
+        s = self.state(sync=sync)
         if s["nan_batches"]:
             print(f"Warning: NaN values detected in predictions or targets ({s['nan_batches']} batch(es) skipped)")
         nan = float("nan")

@@ -45,6 +45,32 @@ def _check(*tensors):
             raise TypeError(f"smaat_unet_amd operators are float32-only (got {t.dtype})")
 
 
+def _expect(t, shape, name):
+    """argument validation at the operator boundary: a mismatching weight / activation shape must surface as a
+    Python exception naming the tensor, not as a wrong read inside a kernel (None = any size, optional tensors pass)"""
+    if t is None:
+        return
+    if t.dim() != len(shape) or any(e is not None and int(a) != int(e) for a, e in zip(t.shape, shape)):
+        raise ValueError(f"{name}: expected shape {tuple('*' if e is None else e for e in shape)}, got {tuple(t.shape)}")
+
+
+def _expect_dsconv(x, w_dw, b_dw, w_pw, b_pw, kpl, bn=()):
+    if x.dim() != 4:
+        raise ValueError(f"input: expected [N, C, H, W], got {tuple(x.shape)}")
+    if kpl not in (1, 2, 4):
+        raise NotImplementedError(f"kernels_per_layer={kpl}: the gfx950 kernels are built for 1, 2 and 4")
+    cin = x.shape[1]
+    k = cin * kpl
+    _expect(w_dw, (k, 1, 3, 3), "depthwise.weight")
+    _expect(b_dw, (k,), "depthwise.bias")
+    _expect(w_pw, (None, k, 1, 1), "pointwise.weight")
+    cout = w_pw.shape[0]
+    _expect(b_pw, (cout,), "pointwise.bias")
+    for name, t in bn:
+        _expect(t, (cout,), name)
+    return cout
+
+
 def _planes(t):
     """(tensor usable by the kernels, batch stride): NCHW with dense [C][H][W] planes; the
     batch stride may be larger than C*H*W (channel slice of a cat buffer)."""
@@ -456,6 +482,8 @@ class _DSConvBNReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, momentum, eps, kpl):
         _check(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv)
+        _expect_dsconv(x, w_dw, b_dw, w_pw, b_pw, kpl, (("bn.weight", gamma), ("bn.bias", beta), ("bn.running_mean", rm),
+                                                         ("bn.running_var", rv)))
         w_dw = w_dw.contiguous()
         w_pw = w_pw.contiguous()
         keep_y = KEEP_DEPTHWISE_OUTPUT and any(ctx.needs_input_grad[:4])  # forward runs under no_grad
@@ -485,6 +513,15 @@ class _DoubleConvDS(torch.autograd.Function):
     def forward(ctx, x, w_dw1, b_dw1, w_pw1, b_pw1, g1, be1, rm1, rv1, w_dw2, b_dw2, w_pw2, b_pw2, g2, be2, rm2, rv2,
                 tr1, mo1, eps1, tr2, mo2, eps2, kpl):
         _check(x, w_dw1, b_dw1, w_pw1, b_pw1, g1, be1, rm1, rv1, w_dw2, b_dw2, w_pw2, b_pw2, g2, be2, rm2, rv2)
+        c1 = _expect_dsconv(x, w_dw1, b_dw1, w_pw1, b_pw1, kpl, (("double_conv.1.weight", g1), ("double_conv.1.bias", be1),
+                                                                  ("double_conv.1.running_mean", rm1),
+                                                                  ("double_conv.1.running_var", rv1)))
+        _expect(w_dw2, (c1 * kpl, 1, 3, 3), "double_conv.3.depthwise.weight")
+        _expect(b_dw2, (c1 * kpl,), "double_conv.3.depthwise.bias")
+        _expect(w_pw2, (None, c1 * kpl, 1, 1), "double_conv.3.pointwise.weight")
+        for nm, t in (("pointwise.bias", b_pw2), ("double_conv.4.weight", g2), ("double_conv.4.bias", be2),
+                      ("double_conv.4.running_mean", rm2), ("double_conv.4.running_var", rv2)):
+            _expect(t, (w_pw2.shape[0],), "double_conv.3/4 " + nm)
         w_dw1, w_pw1, w_dw2, w_pw2 = (t.contiguous() for t in (w_dw1, w_pw1, w_dw2, w_pw2))
         keep_y = KEEP_DEPTHWISE_OUTPUT and any(ctx.needs_input_grad[:17])
         # the activation y1 = relu(bn1(z1)) is never written when every consumer can apply it on load:
@@ -608,6 +645,7 @@ class _DSConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_dw, b_dw, w_pw, b_pw, kpl):
         _check(x, w_dw, b_dw, w_pw, b_pw)
+        _expect_dsconv(x, w_dw, b_dw, w_pw, b_pw, kpl)
         w_dw = w_dw.contiguous()
         w_pw = w_pw.contiguous()
         keep_y = KEEP_DEPTHWISE_OUTPUT and any(ctx.needs_input_grad[:4])
@@ -646,6 +684,10 @@ class _Pointwise(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
         _check(x, w, b)
+        if x.dim() != 4:
+            raise ValueError(f"input: expected [N, C, H, W], got {tuple(x.shape)}")
+        _expect(w, (None, x.shape[1], 1, 1), "conv.weight")
+        _expect(b, (w.shape[0],), "conv.bias")
         w = w.contiguous()
         m, c = w.shape[0], w.shape[1]
         wt = w.reshape(m, c).t().contiguous()
@@ -760,6 +802,18 @@ def _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, 
     """out = spatial_att(channel_att(x)); `out` may be a channel slice of a larger buffer (dense
     planes, any batch stride).  Returns (out, saved tensors, flags)."""
     _check(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv)
+    if x.dim() != 4:
+        raise ValueError(f"input: expected [N, C, H, W], got {tuple(x.shape)}")
+    if use_ch:
+        _expect(w1, (None, x.shape[1]), "channel_att.MLP.1.weight")
+        _expect(b1, (w1.shape[0],), "channel_att.MLP.1.bias")
+        _expect(w2, (x.shape[1], w1.shape[0]), "channel_att.MLP.3.weight")
+        _expect(b2, (x.shape[1],), "channel_att.MLP.3.bias")
+    if use_sp:
+        if wconv.dim() != 4 or tuple(wconv.shape[:2]) != (1, 2) or wconv.shape[2] != wconv.shape[3] or wconv.shape[2] not in (3, 7):
+            raise ValueError(f"spatial_att.conv.weight: expected (1, 2, k, k) with k in (3, 7), got {tuple(wconv.shape)}")
+        for nm, t in (("bn.weight", gamma), ("bn.bias", beta), ("bn.running_mean", rm), ("bn.running_var", rv)):
+            _expect(t, (1,), "spatial_att." + nm)
     L = _lib.get()
     x, x_bs = _planes(x)
     n, c, h, w = x.shape

@@ -122,3 +122,45 @@ def test_gpu_kernel_vs_oracle(n, batch, denorm, thr, nan_at):
     assert [i[1], i[2], i[3], i[4]] == [ref["total_tn"], ref["total_fp"], ref["total_fn"], ref["total_tp"]]
     assert i[5] == ref["total_samples"] and i[6] == ref["total_pixels"]
     assert _close(f[0], ref["total_loss"], 1e-5) and _close(f[1], ref["total_loss_denorm"], 1e-5)
+
+
+def _metrics_worker(rank, world, port, out_dir):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import emu_backend
+    emu_backend.install()
+    from smaat_unet_amd import PrecipitationMetrics
+    m = PrecipitationMetrics(device="cpu")
+    if rank == 0:  # rank 1 never sees a batch: it must still take part in the collective, with zeros
+        g = torch.Generator().manual_seed(0)
+        t = torch.rand(2, 8, 8, generator=g) * 0.02
+        m.update(t + 0.001, t)
+    a = m.compute()
+    b = m.compute()      # a second compute must not double count (the reduction runs on copies)
+    local = m.state(sync=False)
+    torch.save(dict(a=a, b=b, local=local), os.path.join(out_dir, f"m{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_metrics_distributed_compute_reduces_copies(tmp_path):
+    """compute() under torch.distributed = totals over the ranks, from copies of the state; a rank without
+    updates joins the collective; repeated compute() calls agree"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_metrics_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "m0.pt"), torch.load(tmp_path / "m1.pt")
+    assert r0["a"] == r0["b"] or all((r0["a"][k] == r0["b"][k]) or (r0["a"][k] != r0["a"][k]) for k in r0["a"])
+    for k in r0["a"]:
+        x, y = r0["a"][k], r1["a"][k]
+        assert x == y or (x != x and y != y), k          # both ranks report the same totals
+    assert r0["local"]["total_samples"] == 2 and r1["local"]["total_samples"] == 0
+    assert r0["a"]["mse"] == r0["a"]["mse"]               # not NaN: the totals include rank 0's batch on both ranks
+    with pytest.raises(NotImplementedError):
+        from smaat_unet_amd import PrecipitationMetrics
+        PrecipitationMetrics(dist_sync_on_step=True)
