@@ -4,6 +4,8 @@ Hand-written HIP kernels (libsmaat_hip.so, C ABI in include/smaat_hip.h) behind 
 classes that mirror the reference's `models/` API.  There is no CPU fallback.
 """
 from . import _lib  # noqa: F401
+from . import ops as _ops  # noqa: F401
+from . import torch_ops  # noqa: F401  (registers torch.ops.smaat.* inference operators)
 from .SmaAt_UNet import SmaAt_UNet  # noqa: F401
 from .layers import CBAM, ChannelAttention, DepthwiseSeparableConv, SpatialAttention  # noqa: F401
 from .unet_parts_depthwise_separable import DoubleConvDS, DownDS, OutConv, UpDS  # noqa: F401

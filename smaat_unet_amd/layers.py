@@ -116,8 +116,9 @@ class CBAM(nn.Module):
         w1, b1, w2, b2 = self.channel_att._mlp_params()
         sp = self.spatial_att
         if self._eval_fast():  # inference: three launches, BatchNorm(1) on the running statistics
-            return ops.cbam_eval(x, w1, b1, w2, b2, sp.conv.weight, sp.bn.weight, sp.bn.bias, sp.bn.running_mean,
-                                 sp.bn.running_var, sp.bn.eps)
+            import torch
+            return torch.ops.smaat.cbam_infer(x, w1, b1, w2, b2, sp.conv.weight, sp.bn.weight, sp.bn.bias,
+                                              sp.bn.running_mean, sp.bn.running_var, sp.bn.eps)
         g, b, rm, rv, training, momentum, eps = _bn_args(sp.bn)
         return ops.cbam(x, w1, b1, w2, b2, sp.conv.weight, g, b, rm, rv, training, momentum, eps, True, True)
 
@@ -129,10 +130,7 @@ class CBAM(nn.Module):
         sp = self.spatial_att
         if self._eval_fast():
             import torch
-            n, c, h, w = x.shape
-            cat = torch.empty((n, c + c_extra, h, w), dtype=x.dtype, device=x.device)
-            _, pooled = ops.cbam_eval(x, w1, b1, w2, b2, sp.conv.weight, sp.bn.weight, sp.bn.bias, sp.bn.running_mean,
-                                      sp.bn.running_var, sp.bn.eps, out=cat[:, :c], pool=True)
-            return cat, pooled
+            return torch.ops.smaat.cbam_pool_cat_infer(x, w1, b1, w2, b2, sp.conv.weight, sp.bn.weight, sp.bn.bias,
+                                                       sp.bn.running_mean, sp.bn.running_var, sp.bn.eps, c_extra)
         g, b, rm, rv, training, momentum, eps = _bn_args(sp.bn)
         return ops.cbam_pool_cat(x, w1, b1, w2, b2, sp.conv.weight, g, b, rm, rv, training, momentum, eps, c_extra)

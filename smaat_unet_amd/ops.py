@@ -588,7 +588,7 @@ def fold_bn_into_pointwise(w_pw, b_pw, gamma, beta, rm, rv, eps):
             b2 = b2 + beta.double()
         b2 = b2.float().contiguous()
         fold = dict(w=w2, b=b2, wt=w2.t().contiguous())
-        fold["planes"] = _split_planes_raw(w2) if _split_on() else None
+        fold["planes"] = torch.ops.smaat.split_planes(w2) if _split_on() else None
     return fold
 
 
@@ -636,9 +636,11 @@ def dsconv_folded(x, w_dw, b_dw, fold, kpl, relu_out=True):
 
 def double_conv_ds_eval(x, half1, half2, kpl):
     """eval-mode DoubleConvDS under no_grad: half = (w_dw, b_dw, fold).  One fused launch per half on the
-    plane-dominated layers, depthwise + GEMM on the deep ones; no BatchNorm / ReLU kernels at all."""
-    y1 = dsconv_folded(x, half1[0], half1[1], half1[2], kpl)
-    return dsconv_folded(y1, half2[0], half2[1], half2[2], kpl)
+    plane-dominated layers, depthwise + GEMM on the deep ones; no BatchNorm / ReLU kernels at all.  Goes through
+    torch.ops.smaat.dsconv_folded (smaat_unet_amd/torch_ops.py) so that the inference graph is traceable."""
+    for w_dw, b_dw, f in (half1, half2):
+        x = torch.ops.smaat.dsconv_folded(x, w_dw, b_dw, f["w"], f["wt"], f["planes"], f["b"], kpl, True)
+    return x
 
 
 class _DSConv(torch.autograd.Function):

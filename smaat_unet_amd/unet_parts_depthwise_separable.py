@@ -34,7 +34,10 @@ class DoubleConvDS(nn.Module):
     def _folded_half(self, i):
         conv, bn = self.double_conv[3 * i], self.double_conv[3 * i + 1]
         src = (conv.pointwise.weight, conv.pointwise.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
-        key = tuple((t.data_ptr(), t._version) if t is not None else None for t in src) + (bn.eps,)
+        try:
+            key = tuple((t.data_ptr(), t._version) if t is not None else None for t in src) + (bn.eps,)
+        except Exception:  # noqa: BLE001  (FakeTensors under torch.export / compile: fold inside the traced graph)
+            return conv.depthwise.weight, conv.depthwise.bias, ops.fold_bn_into_pointwise(*src, bn.eps)
         cache = self.__dict__.setdefault("_fold_cache", {})
         if cache.get(i, (None,))[0] != key:
             cache[i] = (key, ops.fold_bn_into_pointwise(*src, bn.eps))
@@ -68,6 +71,9 @@ class DoubleConvDS(nn.Module):
 
 class _MaxPool2(nn.MaxPool2d):
     def forward(self, x):
+        import torch
+        if not torch.is_grad_enabled():
+            return torch.ops.smaat.maxpool2_infer(x)
         return ops.maxpool2(x)
 
 
@@ -102,7 +108,10 @@ class UpDS(nn.Module):
             self.conv = DoubleConvDS(in_channels, out_channels, kernels_per_layer=kernels_per_layer)
 
     def forward(self, x1, x2):
+        import torch
         if self.bilinear:
+            if not torch.is_grad_enabled():
+                return self.conv(torch.ops.smaat.upsample_cat_infer(x1, x2))
             return self.conv(ops.upsample_cat(x1, x2))
         return self.conv(ops.upconv_cat(x1, x2, self.up.weight, self.up.bias))
 
@@ -110,6 +119,10 @@ class UpDS(nn.Module):
         """same as forward(x1, x2) when x2 already sits in channels [0, C2) of `cat`
         ([N, C2 + C1', H2, W2]): the upsampled x1 is written behind it, no torch.cat copy."""
         if self.bilinear:
+            import torch
+            if not torch.is_grad_enabled():
+                torch.ops.smaat.upsample_into_(cat, x1, cat.shape[1] - x1.shape[1])
+                return self.conv(cat)
             return self.conv(ops.upsample_into(cat, x1, cat.shape[1] - x1.shape[1]))
         co = self.up.out_channels
         return self.conv(ops.upconv_into(cat, x1, self.up.weight, self.up.bias, cat.shape[1] - co))
@@ -123,4 +136,7 @@ class OutConv(nn.Module):
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=1)
 
     def forward(self, x):
+        import torch
+        if not torch.is_grad_enabled():
+            return torch.ops.smaat.pointwise_infer(x, self.conv.weight, self.conv.bias)
         return ops.pointwise(x, self.conv.weight, self.conv.bias)
