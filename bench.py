@@ -256,10 +256,14 @@ def main():
             loss = torch.nn.functional.cross_entropy(out, y)
         else:
             loss = torch.nn.functional.mse_loss(out.squeeze(1), y, reduction="sum") / y.size(0)
-        ddp.active = exchange
-        ddp.zero_grad()           # one memset of the flat buffer; every p.grad stays a view of it
-        loss.backward()           # post-accumulate hooks launch the bucket all-reduces (RCCL) behind the backward
-        ddp.finish()              # wait + average (no-op at world size 1)
+        if world > 1:
+            ddp.active = exchange
+            ddp.zero_grad()
+            loss.backward()
+            ddp.finish()          # pack into the persistent flat buffer, bucket all-reduces over RCCL, average
+        else:
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
         opt.step()
         return loss
 
@@ -425,10 +429,8 @@ def main():
                         t0 = time.perf_counter()
                     out = model(xb)
                     loss_f = torch.nn.functional.mse_loss(out.squeeze(1), yb, reduction="sum") / yb.size(0)
-                    ddp.active = False
-                    ddp.zero_grad()
+                    opt.zero_grad(set_to_none=True)
                     loss_f.backward()
-                    ddp.finish()
                     opt.step()
                     nstep += 1
             torch.cuda.synchronize()

@@ -7,6 +7,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -42,7 +43,7 @@ def _worker(rank, world, port, out_dir):
         model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in P.items()})
         with torch.no_grad():
             model.inc.double_conv[1].running_mean.fill_(0.25)  # buffers travel with the parameters
-    ddp = FlatGradAllReduce(model, buckets=2)
+    ddp = FlatGradAllReduce(model, buckets=2, overlap=(os.environ.get("SMAAT_TEST_DDP_OVERLAP") == "1"))
     assert ddp.world == world and ddp.numel == 4033537 and len(ddp._buckets) == 2
     ddp.broadcast_parameters(0)
     assert float(model.inc.double_conv[1].running_mean[0]) == 0.25
@@ -76,7 +77,11 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_flat_allreduce_world2(tmp_path):
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_flat_allreduce_world2(tmp_path, overlap, monkeypatch):
+    """default mode (fresh gradients packed by one multi-tensor copy, then the bucket all-reduces) and overlap mode
+    (.grad pre-set to views of the flat buffer, bucket all-reduces launched from post-accumulate hooks)"""
+    monkeypatch.setenv("SMAAT_TEST_DDP_OVERLAP", overlap)
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     f0, f1 = np.load(tmp_path / "flat0.npy"), np.load(tmp_path / "flat1.npy")

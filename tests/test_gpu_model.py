@@ -353,7 +353,7 @@ def test_ddp_rccl_single_rank(tmp_path):
         (torch.nn.functional.mse_loss(out.squeeze(1), y, reduction="sum") / 2).backward()
         ref = [p.grad.clone() for p in model.parameters()]
         model2, _ = _load_model(meta)
-        ddp = FlatGradAllReduce(model2, buckets=2, force_collectives=True)
+        ddp = FlatGradAllReduce(model2, buckets=2, overlap=True, force_collectives=True)
         for _ in range(2):
             ddp.zero_grad()
             out = model2(x)
