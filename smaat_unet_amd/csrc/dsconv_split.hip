@@ -13,19 +13,28 @@
 // Geometry: 64 output channels x 128 pixels per workgroup (2 workgroups per CU), pixel tile = 4 x 32 or 8 x 16
 // (template TWL), kernels_per_layer = 2, one barrier per chunk, every LDS buffer double buffered:
 //   iteration i:  consumers  M(i)     : A[i&1], B[i&1] -> MFMA
-//                 producers  Ac(i+1)  : weight-plane registers -> A[(i+1)&1];      issue loads A(i+2)
-//                            Sc(i+2)  : halo registers -> S[i&1] (act + zero pad); issue loads S(i+3)
+//                 producers  wait for load group i (issued PD = 3 iterations earlier: counted s_waitcnt)
+//                            Ac(i+1)  : weight-plane registers -> A[(i+1)&1]
+//                            Sc(i+2)  : halo registers -> S[i&1] (act + zero pad)
+//                            issue load group i + PD = {A(i+1+PD), S(i+2+PD)}
 //                            D(i+1)   : S[(i+1)&1] -> depthwise -> split -> B[(i+1)&1]
+// The producers' global loads go through inline asm with explicit counted waits: hipcc's own bookkeeping drains to
+// vmcnt(0) at every commit, which leaves ONE group in flight and makes an iteration last one memory latency (~1.5 us
+// measured: 31 us for a 16-chunk tile; profiles/r2).
 // Task map of the depthwise stage (one task per producer thread and chunk): lane -> (column c = lane & 7 + 8 wave,
 // channel cl = (lane >> 3) & 3 + 4 (lane >> 5)): the 32 lanes of a half-wave read 8 columns x 4 channels of the
 // staging buffer (channel stride = 8 mod 32 banks) and write 8 pixels x 4 channel pairs of the B image (pixel
 // stride 12 words) -- both conflict-free.
 #include "common.h"
+#include <cstdlib>
 #include <stdlib.h>
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 #define DSS_BROW 48  // bytes per LDS row of a [row][16 bf16] image (32 + 16 pad: conflict-free ds_read_b128)
-#define DSS_CSTRIDE 264  // staged floats per input channel: 240 used (6 x 40 or 10 x 24), = 8 mod 32 banks
+// staged floats per input channel (240 used: 6 x 40 or 10 x 24).  The stride decides the LDS banks of the depthwise
+// stage's reads: lane map 0 (8 columns x 8 channels per wave) wants = 8 mod 64, lane map 1 (a full tile row per half
+// wave, see ROWMAP) wants = 32 (4 x 32 tile) or = 16 (8 x 16 tile) mod 64.
+#define DSS_CSTRIDE_OF(TWL, ROWMAP) ((ROWMAP) ? ((TWL) == 5 ? 288 : 272) : 264)
 
 __device__ __forceinline__ unsigned dss_fbits(float x) { return __builtin_bit_cast(unsigned, x); }
 __device__ __forceinline__ float dss_bitsf(unsigned x) { return __builtin_bit_cast(float, x); }
@@ -51,8 +60,15 @@ struct DsSplitArgs {
 };
 
 // TWL: log2 of the tile width (5: 4 x 32 tile, 4: 8 x 16 tile).  NT: 3 = exact split, 1 = plain bf16 operands.
-template <int TWL, int NT, bool AFF>
+typedef float dss_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned dss_u32x4 __attribute__((ext_vector_type(4)));
+
+// ROWMAP: the depthwise stage's lane -> (column, channel) map.  0: a wave covers 8 columns x 8 channels (bank-conflict
+// free on both LDS sides).  1: a half wave covers one full tile row of one channel, so that the side output y_out is
+// written as whole 128-B (4 x 32 tile) / 64-B (8 x 16 tile) runs; the bf16 image writes then conflict 2-way.
+template <int TWL, int NT, bool AFF, bool YOUT, bool ROWMAP>
 __global__ __launch_bounds__(512, 4) void k_dsconv_split(const DsSplitArgs a) {
+    constexpr int DSS_CSTRIDE = DSS_CSTRIDE_OF(TWL, ROWMAP);
     constexpr int KPL = 2, KC = 16, KCI = KC / KPL;
     constexpr int CT = 2, WPX = 4, PXT = 1;
     constexpr int COT = 64, PT = 128, NPT = 256;
@@ -71,6 +87,7 @@ __global__ __launch_bounds__(512, 4) void k_dsconv_split(const DsSplitArgs a) {
     float* stat = DWl + 2 * 256;                  // BN_STAT_FLOATS(WPX, COT)
     int* pixoff = (int*)(stat + BN_STAT_FLOATS(WPX, COT));  // [PT]
     float* biasl = (float*)(pixoff + PT);         // [COT]
+    float* affl = biasl + COT;                    // AFF: [2][Cin] scale / shift of the activation applied on load
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -100,6 +117,13 @@ __global__ __launch_bounds__(512, 4) void k_dsconv_split(const DsSplitArgs a) {
         const int r = r0 + (i >> TWL), c = c0 + (i & (TW - 1));
         pixoff[i] = (r < a.H && c < a.W) ? r * a.W + c : -1;
     }
+    if (AFF) {
+        for (int i = tid; i < a.Cin; i += 512) {
+            affl[i] = a.in_scale[i];
+            affl[a.Cin + i] = a.in_shift[i];
+        }
+        __syncthreads();
+    }
 
     if (producer) {
         // ---- staging slots: (channel of the chunk, halo row, float4 column) ----
@@ -118,20 +142,27 @@ __global__ __launch_bounds__(512, 4) void k_dsconv_split(const DsSplitArgs a) {
             s_ok[j] = ok;
         }
         // ---- depthwise task of this thread: channel t_cl of the chunk, strip (t_rg, t_c) ----
-        const int t_cl = ((lane >> 3) & 3) + 4 * half;
-        int t_c, t_rg;
-        if (TWL == 5) {
-            t_c = (lane & 7) + 8 * pw;
-            t_rg = 0;
+        int t_cl, t_c, t_rg;
+        if (ROWMAP) {
+            t_cl = half + 2 * pw;
+            t_c = lane & (TW - 1);
+            t_rg = TWL == 5 ? 0 : (lane >> 4) & 1;
         } else {
-            t_c = (lane & 7) + 8 * (pw & 1);
-            t_rg = pw >> 1;
+            t_cl = ((lane >> 3) & 3) + 4 * half;
+            if (TWL == 5) {
+                t_c = (lane & 7) + 8 * pw;
+                t_rg = 0;
+            } else {
+                t_c = (lane & 7) + 8 * (pw & 1);
+                t_rg = pw >> 1;
+            }
         }
         const int t_sb = t_cl * DSS_CSTRIDE + (t_rg * 4) * STRIDE + t_c + 3;   // S index of (row - 1, col - 1)
         const int t_px = (t_rg * 4) * TW + t_c;                                // tile pixel of the strip's first row
         const int t_gr = r0 + t_rg * 4;
         const int t_go = t_gr * a.W + c0 + t_c;
         const bool t_cok = (c0 + t_c) < a.W;
+        const unsigned t_yo = (unsigned)(t_cl * 2 * a.P + t_go) * 4u;
         // ---- A-plane pieces ----
         int a_src[NAT], a_dst[NAT];
 #pragma unroll
@@ -147,39 +178,61 @@ __global__ __launch_bounds__(512, 4) void k_dsconv_split(const DsSplitArgs a) {
         const float* dwsrc = (dwt < 9) ? a.w_dw : (a.b_dw ? a.b_dw : a.w_dw);
         const int dwmul = (dwt < 9) ? 9 : 1, dwadd = (dwt < 9) ? dwt : 0;
         const bool dwvalid = (dwk < KC) && (dwt < 9 || (dwt == 9 && a.b_dw != nullptr));
-        float dwreg = 0.f;
-        float4 sreg[NSL];
-        float scr[NSL], shr[NSL];
-        uint4 areg[NAT];
-
+        // ---- load groups: PD register sets in flight, inline-asm loads, counted waits ----
+        constexpr int PD = 3;
+        constexpr int LPC = NSL + 1 + NAT;                       // loads per group
+        constexpr int SPC = YOUT ? 8 : 0;                        // side-output stores per iteration (also count in vmcnt)
+        constexpr int WAITN = SPC + (PD - 1) * (LPC + SPC);      // younger operations when a group is consumed
+        static_assert(WAITN <= 63, "vmcnt is a 6-bit counter");
+        dss_f32x4 sx[PD][NSL];
+        float sdw[PD];
+        dss_u32x4 sa[PD][NAT];
         auto clampc = [&](int ch) { return ch < nchunks ? ch : nchunks - 1; };
-        auto prefetch_b = [&](int ch_) {
-            const int ci0 = clampc(ch_) * KCI;
+        // group g = {weight planes of chunk g + 1, halo + taps of chunk g + 2}
+        auto issue = [&](int g, int set) __attribute__((always_inline)) {
+            const int cx = clampc(g + 2), ca = clampc(g + 1);
+            const int ci0 = cx * KCI;
 #pragma unroll
             for (int j = 0; j < NSL; ++j) {
                 const int ci = ci0 + s_cl[j];
-                const int cic = ci < a.Cin ? ci : a.Cin - 1;
-                sreg[j] = *(const float4*)(xn + (long)cic * a.P + s_in[j]);
-                if (AFF) {
-                    scr[j] = a.in_scale[cic];
-                    shr[j] = a.in_shift[cic];
-                }
+                const float* src = xn + (long)(ci < a.Cin ? ci : a.Cin - 1) * a.P + s_in[j];
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sx[set][j]) : "v"(src));
             }
-            const int kg = clampc(ch_) * KC + (dwk < KC ? dwk : 0);
-            dwreg = dwsrc[(kg < a.Kdim ? kg : a.Kdim - 1) * dwmul + dwadd];
+            {
+                const int kg = cx * KC + (dwk < KC ? dwk : 0);
+                const float* src = dwsrc + (kg < a.Kdim ? kg : a.Kdim - 1) * dwmul + dwadd;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(sdw[set]) : "v"(src));
+            }
+            const unsigned short* ab = a.planes + (long)ca * 3 * a.M * 16;
+#pragma unroll
+            for (int u = 0; u < NAT; ++u) {
+                const unsigned short* src = ab + a_src[u];
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sa[set][u]) : "v"(src));
+            }
         };
-        auto commit_b = [&](int ch_, int buf) {
+        auto wait_set = [&](int set) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+#pragma unroll
+            for (int j = 0; j < NSL; ++j) asm volatile("" : "+v"(sx[set][j]));  // uses stay behind the wait
+            asm volatile("" : "+v"(sdw[set]));
+#pragma unroll
+            for (int u = 0; u < NAT; ++u) asm volatile("" : "+v"(sa[set][u]));
+        };
+        auto store_b = [&](int ch_, int buf, const dss_f32x4 (&xr)[NSL], float dwv) __attribute__((always_inline)) {
             const int ci0 = clampc(ch_) * KCI;
             float* Sb = S + buf * (KCI * DSS_CSTRIDE);
 #pragma unroll
             for (int j = 0; j < NSL; ++j) {
-                const bool ok = s_ok[j] && (ci0 + s_cl[j]) < a.Cin;
-                float4 v = sreg[j];
+                const int ci = ci0 + s_cl[j];
+                const bool ok = s_ok[j] && ci < a.Cin;
+                float4 v = make_float4(xr[j][0], xr[j][1], xr[j][2], xr[j][3]);
                 if (AFF) {  // the previous BatchNorm + ReLU applied on load; the zero padding stays zero
-                    v.x = fmaxf(fmaf(v.x, scr[j], shr[j]), 0.f);
-                    v.y = fmaxf(fmaf(v.y, scr[j], shr[j]), 0.f);
-                    v.z = fmaxf(fmaf(v.z, scr[j], shr[j]), 0.f);
-                    v.w = fmaxf(fmaf(v.w, scr[j], shr[j]), 0.f);
+                    const int cic = ci < a.Cin ? ci : a.Cin - 1;
+                    const float sc = affl[cic], sh = affl[a.Cin + cic];
+                    v.x = fmaxf(fmaf(v.x, sc, sh), 0.f);
+                    v.y = fmaxf(fmaf(v.y, sc, sh), 0.f);
+                    v.z = fmaxf(fmaf(v.z, sc, sh), 0.f);
+                    v.w = fmaxf(fmaf(v.w, sc, sh), 0.f);
                 }
                 v.x = ok ? v.x : 0.f;
                 v.y = ok ? v.y : 0.f;
@@ -187,18 +240,16 @@ __global__ __launch_bounds__(512, 4) void k_dsconv_split(const DsSplitArgs a) {
                 v.w = ok ? v.w : 0.f;
                 *(float4*)(Sb + s_lo[j]) = v;
             }
-            DWl[buf * 256 + (ptid < 256 ? ptid : 0)] = (dwvalid && (clampc(ch_) * KC + dwk) < a.Kdim) ? dwreg : 0.f;
+            DWl[buf * 256 + ptid] = (dwvalid && (clampc(ch_) * KC + dwk) < a.Kdim) ? dwv : 0.f;
         };
-        auto prefetch_a = [&](int ch_) {
-            const long base = (long)clampc(ch_) * 3 * a.M * 16;
-#pragma unroll
-            for (int u = 0; u < NAT; ++u) areg[u] = *(const uint4*)(a.planes + base + a_src[u]);
-        };
-        auto commit_a = [&](int buf) {
+        auto store_a = [&](int buf, const dss_u32x4 (&ar)[NAT]) __attribute__((always_inline)) {
             unsigned char* base = lds + buf * BUFSZ;
 #pragma unroll
-            for (int u = 0; u < NAT; ++u) *(uint4*)(base + a_dst[u]) = areg[u];
+            for (int u = 0; u < NAT; ++u) *(dss_u32x4*)(base + a_dst[u]) = ar[u];
         };
+        // side output through a buffer descriptor: always issued (fixed operation count), dropped by the range check
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+            YOUT ? a.y_out + (long)n * a.Kdim * a.P : (float*)nullptr, 0, YOUT ? a.Kdim * a.P * 4 : 0, 0x00020000);
         auto dwstage = [&](int ch_, int buf) {
             const int k0 = ch_ * KC;
             const float* sp = S + buf * (KCI * DSS_CSTRIDE) + t_sb;
@@ -229,13 +280,18 @@ __global__ __launch_bounds__(512, 4) void k_dsconv_split(const DsSplitArgs a) {
                     y[j][i] = acc;
                 }
             }
-            if (a.y_out != nullptr && cot == 0) {
-                float* yo = a.y_out + ((long)n * a.Kdim + k0 + t_cl * 2) * a.P + t_go;
+            if (YOUT) {
+                // byte offset = per-thread part (channel pair, strip origin) + per-chunk / per-store scalar part
+                const bool pok = cot == 0 && t_cok && (k0 + t_cl * 2) < a.Kdim;  // Kdim is even: a pair is in or out
+                unsigned vo = pok ? t_yo : 0x80000000u;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if ((k0 + t_cl * 2 + j) < a.Kdim && t_cok && (t_gr + i) < a.H) yo[(long)j * a.P + i * a.W] = y[j][i];
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned voff = (t_gr + i) < a.H ? vo : 0x80000000u;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[j][i]), yrs, voff,
+                                                              ((k0 + j) * a.P + i * a.W) * 4, 0);
+                    }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -263,28 +319,49 @@ __global__ __launch_bounds__(512, 4) void k_dsconv_split(const DsSplitArgs a) {
             }
         };
 
-        prefetch_b(0);
-        prefetch_a(0);
-        commit_b(0, 0);
-        commit_a(0);
-        prefetch_b(1);
-        prefetch_a(1);
-        __syncthreads();
-        dwstage(0, 0);
-        commit_b(1, 1);
-        prefetch_b(2);
-        __syncthreads();
-        for (int i = 0; i < nchunks; ++i) {
-            if (i + 1 < nchunks) {
-                const int nb = (i + 1) & 1;
-                commit_a(nb);
-                commit_b(i + 2, i & 1);
-                prefetch_a(i + 2);
-                prefetch_b(i + 3);
-                dwstage(i + 1, nb);
+        // The PD groups that the loop consumes first are issued before the (compiler-tracked) prologue loads: the
+        // prologue's wait covers all of them, i.e. one memory latency for the whole start-up.
+#pragma unroll
+        for (int g = 0; g < PD; ++g) issue(g, g);
+        {
+            dss_f32x4 x0[NSL], x1[NSL];
+            dss_u32x4 a0[NAT];
+#pragma unroll
+            for (int j = 0; j < NSL; ++j) {
+                const int c0_ = s_cl[j], c1_ = clampc(1) * KCI + s_cl[j];
+                x0[j] = *(const dss_f32x4*)(xn + (long)(c0_ < a.Cin ? c0_ : a.Cin - 1) * a.P + s_in[j]);
+                x1[j] = *(const dss_f32x4*)(xn + (long)(c1_ < a.Cin ? c1_ : a.Cin - 1) * a.P + s_in[j]);
             }
+            const int kg0 = dwk < KC ? dwk : 0, kg1 = clampc(1) * KC + kg0;
+            const float d0 = dwsrc[(kg0 < a.Kdim ? kg0 : a.Kdim - 1) * dwmul + dwadd];
+            const float d1 = dwsrc[(kg1 < a.Kdim ? kg1 : a.Kdim - 1) * dwmul + dwadd];
+#pragma unroll
+            for (int u = 0; u < NAT; ++u) a0[u] = *(const dss_u32x4*)(a.planes + a_src[u]);
+            store_b(0, 0, x0, d0);
+            store_a(0, a0);
+            __syncthreads();
+            dwstage(0, 0);
+            store_b(1, 1, x1, d1);
             __syncthreads();
         }
+        for (int i0 = 0; i0 < nchunks; i0 += PD) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                const int i = i0 + u;
+                if (i < nchunks) {
+                    if (i + 1 < nchunks) {
+                        const int nb = (i + 1) & 1;
+                        wait_set(u);                       // group i: its loads were issued PD iterations ago
+                        store_a(nb, sa[u]);                // A(i + 1)
+                        store_b(i + 2, i & 1, sx[u], sdw[u]);  // S(i + 2)
+                        issue(i + PD, u);
+                        dwstage(i + 1, nb);
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus groups of the tail still target live registers
     } else {
         f32x16 acc[CT][PXT];
 #pragma unroll
@@ -370,12 +447,13 @@ int dsconv_split_num_slots(int N, int H, int W) {
     return N * ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
 }
 
-template <int TWL, int NT, bool AFF>
+template <int TWL, int NT, bool AFF, bool YOUT, bool ROWMAP>
 static int launch_dss_cfg(DsSplitArgs& a, hipStream_t st) {
-    constexpr int COT = 64, PT = 128, KCI = 8;
+    constexpr int COT = 64, PT = 128, KCI = 8, DSS_CSTRIDE = DSS_CSTRIDE_OF(TWL, ROWMAP);
     const size_t lds = (size_t)2 * NT * (COT + PT) * DSS_BROW +
-                       sizeof(float) * (size_t)(2 * KCI * DSS_CSTRIDE + 2 * 256 + BN_STAT_FLOATS(4, COT) + PT + COT);
-    constexpr auto kern = k_dsconv_split<TWL, NT, AFF>;
+                       sizeof(float) * (size_t)(2 * KCI * DSS_CSTRIDE + 2 * 256 + BN_STAT_FLOATS(4, COT) + PT + COT +
+                                                (AFF ? 2 * a.Cin : 0));
+    constexpr auto kern = k_dsconv_split<TWL, NT, AFF, YOUT, ROWMAP>;
     static size_t granted = 0;
     if (lds > granted) {
         HIP_RET(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -384,6 +462,25 @@ static int launch_dss_cfg(DsSplitArgs& a, hipStream_t st) {
     const int grid = ((a.T + 7) / 8) * 8 * a.nco;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
     return (int)hipGetLastError();
+}
+
+static int dss_rowmap_noy() {  // experiment switch: lane map 1 also without the side output
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("SMAAT_DSS_ROWMAP");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v;
+}
+
+template <int TWL, int NT>
+static int launch_dss_sel(DsSplitArgs& a, hipStream_t st) {
+    const bool aff = a.in_scale != nullptr, yo = a.y_out != nullptr;
+    if (yo)
+        return aff ? launch_dss_cfg<TWL, NT, true, true, true>(a, st) : launch_dss_cfg<TWL, NT, false, true, true>(a, st);
+    if (dss_rowmap_noy())
+        return aff ? launch_dss_cfg<TWL, NT, true, false, true>(a, st) : launch_dss_cfg<TWL, NT, false, false, true>(a, st);
+    return aff ? launch_dss_cfg<TWL, NT, true, false, false>(a, st) : launch_dss_cfg<TWL, NT, false, false, false>(a, st);
 }
 
 // returns -2 when the shape / alignment is not handled (kernels_per_layer != 2, W % 16 != 0, unaligned planes)
@@ -397,12 +494,8 @@ int launch_dsconv_split(DsSplitArgs& a, int kpl, hipStream_t st) {
     a.tiles_per_img = a.tiles_x * ((a.H + TH - 1) / TH);
     a.T = a.N * a.tiles_per_img;
     a.nco = (a.M + 63) / 64;
-    const bool aff = a.in_scale != nullptr;
+    if (a.in_scale != nullptr && a.Cin > 1024) return -2;  // (the activation table lives in LDS)
     const int nt = split_mode() == 1 ? 1 : 3;
-    if (twl == 5) {
-        if (nt == 1) return aff ? launch_dss_cfg<5, 1, true>(a, st) : launch_dss_cfg<5, 1, false>(a, st);
-        return aff ? launch_dss_cfg<5, 3, true>(a, st) : launch_dss_cfg<5, 3, false>(a, st);
-    }
-    if (nt == 1) return aff ? launch_dss_cfg<4, 1, true>(a, st) : launch_dss_cfg<4, 1, false>(a, st);
-    return aff ? launch_dss_cfg<4, 3, true>(a, st) : launch_dss_cfg<4, 3, false>(a, st);
+    if (twl == 5) return nt == 1 ? launch_dss_sel<5, 1>(a, st) : launch_dss_sel<5, 3>(a, st);
+    return nt == 1 ? launch_dss_sel<4, 1>(a, st) : launch_dss_sel<4, 3>(a, st);
 }

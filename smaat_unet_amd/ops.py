@@ -227,14 +227,20 @@ def _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None,
 FUSE_DW_SPLIT = os.environ.get("SMAAT_FUSE_DW", "auto")
 
 
-def _fused_dw_ok(n, h, w, kpl, cout, keep_y):
+def _fused_dw_ok(n, h, w, kpl, cout, keep_y, cin=0):
     if FUSE_DW_SPLIT == "off" or kpl != 2 or not _split_on():
         return False
     if _lib.get().smaat_dsconv_split_num_slots(n, h, w) <= 0:
         return False
     if FUSE_DW_SPLIT == "all":
         return True
-    return cout <= 128 and (not keep_y or FUSE_DW_SPLIT == "train")
+    if not keep_y or FUSE_DW_SPLIT == "train":
+        return cout <= 128
+    # training keeps the depthwise tensor for the weight gradient: the kernel then writes it as a side output.
+    # Measured per layer on MI355X (profiles/r2/layer_bench_fused_r2l.txt): that wins where one 64-row output tile
+    # covers Cout and the reduction is long enough to amortise the tile prologue (288^2: 1.50 vs 1.80 ms at K = 256,
+    # 0.94 vs 0.99 ms at K = 128) and loses where the depthwise stage is recomputed per output tile (Cout = 128).
+    return cout <= 64 and cin * kpl >= 128 and h * w >= 65536
 
 
 def _dsconv_fwd_fused(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, in_shift=None, want_y=False):
@@ -427,7 +433,7 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
     y_dw = None
     isc, ish = in_aff if in_aff is not None else (None, None)
     rs = None
-    if _split_on() and _fused_dw_ok(n, h, w, kpl, cout, keep_y):
+    if _split_on() and _fused_dw_ok(n, h, w, kpl, cout, keep_y, cin):
         rs = _dsconv_fwd_fused(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish, want_y=keep_y)
     if rs is None and _split_fwd_ok(cin * kpl, cout, use_batch_stats):
         rs = _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish)
