@@ -1,0 +1,411 @@
+// Depthwise 3x3 forward / backward as register row-streaming kernels (gfx950).
+//
+// reference: models/layers.py:38-44,48 (nn.Conv2d(in, in * kernels_per_layer, 3, padding=1, groups=in)) and its ATen
+// backward (input gradient = transposed depthwise convolution summed over the kernels_per_layer outputs of a group,
+// weight gradient = correlation of the input with dY, bias gradient = sum of dY).
+//
+// The strip kernels of spatial.hip stage a halo tile through LDS between two barriers and give one thread a 1 x 4
+// pixel strip: dword global accesses, 18 ds_read_b32 per strip and channel, 133 VGPRs in the backward (3 waves per
+// SIMD) with the loads of x exposed inside the tile loop -- 3.5 TB/s (backward) and 4.3 TB/s (forward) of algorithmic
+// traffic on MI355X (profiles/r2).  These kernels need no LDS staging and no barrier in the main loop:
+//   * a thread owns FOUR adjacent columns (one float4) of a band of BH rows of one plane and walks down the band;
+//   * the 3 x 6 window it needs (its float4 and the two neighbouring columns, three rows) lives in registers and
+//     slides by one row per step: per row one global_load_dwordx4 + two edge dwords (L1 hits: the neighbour lane's
+//     float4) per channel, one global_store_dwordx4 per output channel;
+//   * forward: the row after next is always in flight (rotating register windows, manual unroll by 4);
+//   * a wave never straddles two planes, so the per-channel weights live in SGPRs; workgroups are just four
+//     consecutive waves of the (plane, wave-in-plane) list -- no LDS, no barrier anywhere;
+//   * the weight / bias gradient partials reduce with DPP wave sums: one partial row per (image, wave of the plane),
+//     part[n * wpp + w][Cdw][10], rpart[2][n * wpp + w][Cin]  (dw_bwd_groups() == wpp).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+
+#include "common.h"
+
+struct DwrGeom {
+    int H, W, P, ncol4, nbands, BH, wpp;
+};
+
+// band / wave decomposition of a plane: maximise lane utilisation x (BH / (BH + 2)) x chip fill
+DwrGeom dw_rows_geom(long planes, int H, int W) {
+    DwrGeom g;
+    g.H = H;
+    g.W = W;
+    g.P = H * W;
+    g.ncol4 = W / 4;
+    double best = -1.0;
+    g.nbands = 1;
+    g.BH = H;
+    g.wpp = 0;
+    for (int nb = 1; nb <= H && (long)nb * g.ncol4 <= 64 * 64; ++nb) {
+        const int bh = (H + nb - 1) / nb;
+        if ((nb - 1) * bh >= H) continue;  // an empty trailing band: a smaller nb gives the same BH
+        if (bh < 4 && nb > 1) break;
+        const int T = g.ncol4 * nb;
+        const int wpp = (T + 63) / 64;
+        const double util = (double)T / (64.0 * wpp);
+        const double halo = (double)bh / (bh + 2.0);
+        double fill = (double)planes * wpp / 8192.0;
+        if (fill > 1.0) fill = 1.0;
+        const double score = util * halo * (0.25 + 0.75 * fill);
+        if (score > best) {
+            best = score;
+            g.nbands = nb;
+            g.BH = bh;
+            g.wpp = wpp;
+        }
+    }
+    return g;
+}
+
+int dw_rows_wpp(int N, int Cin, int H, int W) { return dw_rows_geom((long)N * Cin, H, W).wpp; }
+
+__device__ __forceinline__ float dwr_act(float v, bool aff, float sc, float sh) {
+    return aff ? fmaxf(fmaf(v, sc, sh), 0.f) : v;
+}
+
+// One row of the 6-wide window of a float4 column group: cols 4q-1 .. 4q+4 (zero outside the plane).
+// The two edge columns are the neighbour lanes' float4 ends (DPP wave shifts by one lane: the neighbour lane holds
+// the neighbour column group of the SAME band, hence the same row); only lane 0 / lane 63 read theirs from memory,
+// both with one dword load whose per-thread offset `eo` (-1, +4 or 0) is fixed.
+struct DwrLane {
+    int eo;         // edge element offset of this lane's extra load
+    bool l0, l63;   // lane 0 / lane 63 of the wave
+    bool lok, rok;  // a column exists to the left / right of the group
+};
+__device__ __forceinline__ DwrLane dwr_lane(int lane, int q, int ncol4) {
+    DwrLane ln;
+    ln.l0 = lane == 0;
+    ln.l63 = lane == 63;
+    ln.lok = q > 0;
+    ln.rok = q < ncol4 - 1;
+    ln.eo = (ln.l0 && ln.lok) ? -1 : ((ln.l63 && ln.rok) ? 4 : 0);
+    return ln;
+}
+struct DwrRaw {
+    float4 m;
+    float e;
+};
+// issue the two loads of a window row (p = plane + 4q; nothing waits here)
+__device__ __forceinline__ DwrRaw dwr_issue(const float* __restrict__ p, int r, int H, int W, const DwrLane& ln) {
+    const int rc = min(max(r, 0), H - 1);
+    const float* pr = p + (long)rc * W;
+    DwrRaw v;
+    v.m = *(const float4*)pr;
+    v.e = pr[ln.eo];
+    return v;
+}
+__device__ __forceinline__ float4 dwr_issue4(const float* __restrict__ p, int r, int H, int W) {
+    const int rc = min(max(r, 0), H - 1);
+    return *(const float4*)(p + (long)rc * W);
+}
+// pin the loaded registers: keeps hipcc from sinking parts of a 16-byte load into the row-validity select (it splits
+// the load into dword loads plus a branch otherwise).  Call after ALL loads of a step have been issued.
+__device__ __forceinline__ void dwr_pin(DwrRaw& v) {
+    asm volatile("" : "+v"(v.m.x), "+v"(v.m.y), "+v"(v.m.z), "+v"(v.m.w), "+v"(v.e));
+}
+__device__ __forceinline__ void dwr_pin(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+// raw row -> window row: edge exchange, activation (previous BatchNorm + ReLU) on load, zero padding
+__device__ __forceinline__ void dwr_finish(float (&w)[6], const DwrRaw& v, int r, int H, const DwrLane& ln, bool aff,
+                                           float sc, float sh) {
+    const bool rv = r >= 0 && r < H;
+    float l = dpp_src<0x138, 0xF>(v.m.w);   // wave_shr:1  (lane i <- lane i - 1)
+    float rr = dpp_src<0x130, 0xF>(v.m.x);  // wave_shl:1  (lane i <- lane i + 1)
+    l = ln.l0 ? v.e : l;
+    rr = ln.l63 ? v.e : rr;
+    w[0] = (rv && ln.lok) ? dwr_act(l, aff, sc, sh) : 0.f;
+    w[1] = rv ? dwr_act(v.m.x, aff, sc, sh) : 0.f;
+    w[2] = rv ? dwr_act(v.m.y, aff, sc, sh) : 0.f;
+    w[3] = rv ? dwr_act(v.m.z, aff, sc, sh) : 0.f;
+    w[4] = rv ? dwr_act(v.m.w, aff, sc, sh) : 0.f;
+    w[5] = (rv && ln.rok) ? dwr_act(rr, aff, sc, sh) : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward:  y[ci*KPL + j][r][c] = b[j] + sum_{tr,tc} w[j][tr][tc] * act(x)[ci][r + tr - 1][c + tc - 1]
+// ---------------------------------------------------------------------------------------------------------------
+template <int KPL>
+__global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const float* __restrict__ x, long x_bs,
+                                                         const float* __restrict__ w_dw,
+                                                         const float* __restrict__ b_dw, float* __restrict__ y,
+                                                         long y_bs, int Cin, int nplanes, const DwrGeom g,
+                                                         const float* __restrict__ in_scale,
+                                                         const float* __restrict__ in_shift) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (tid >> 6));  // (plane, wave of the plane) list
+    const int plane = gw / g.wpp, wip = gw - plane * g.wpp;
+    if (plane >= nplanes) return;  // (whole wave)
+    const int n = plane / Cin, ci = plane - n * Cin;
+    const int t = wip * 64 + lane;
+    const int band_ = t / g.ncol4, q = t - band_ * g.ncol4;
+    const bool active = band_ < g.nbands;  // surplus lanes of the last wave walk the last band again (stores masked)
+    const int band = active ? band_ : g.nbands - 1;
+    const int r0 = band * g.BH;
+    const float* xp = x + (long)n * x_bs + (long)ci * g.P + 4 * q;
+    float* yp = y + (long)n * y_bs + (long)(ci * KPL) * g.P + 4 * q;
+    float wt[KPL][9], bs[KPL];
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wt[j][k] = w_dw[(ci * KPL + j) * 9 + k];
+        bs[j] = b_dw ? b_dw[ci * KPL + j] : 0.f;
+    }
+    const bool aff = in_scale != nullptr;
+    const float asc = aff ? in_scale[ci] : 1.f, ash = aff ? in_shift[ci] : 0.f;
+    const DwrLane ln = dwr_lane(lane, q, g.ncol4);
+
+    // before step r (u = (r - r0) % 4): Wn[u] = row r - 1, Wn[u + 1] = row r, raw[u & 1] = row r + 1 in flight; the
+    // step issues row r + 2, then finishes row r + 1 into Wn[u + 2]   (indices mod 4 / mod 2)
+    float Wn[4][6];
+    DwrRaw raw[2];
+    auto compute = [&](int r, const float (&R0)[6], const float (&R1)[6], const float (&R2)[6]) {
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            float o[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float acc = bs[j];
+#pragma unroll
+                for (int tc = 0; tc < 3; ++tc) {
+                    acc = fmaf(wt[j][tc], R0[c + tc], acc);
+                    acc = fmaf(wt[j][3 + tc], R1[c + tc], acc);
+                    acc = fmaf(wt[j][6 + tc], R2[c + tc], acc);
+                }
+                o[c] = acc;
+            }
+            if (active && r < g.H) *(float4*)(yp + (long)j * g.P + (long)r * g.W) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    };
+    {
+        DwrRaw a = dwr_issue(xp, r0 - 1, g.H, g.W, ln), b = dwr_issue(xp, r0, g.H, g.W, ln);
+        raw[0] = dwr_issue(xp, r0 + 1, g.H, g.W, ln);
+        dwr_pin(a);
+        dwr_pin(b);
+        dwr_finish(Wn[0], a, r0 - 1, g.H, ln, aff, asc, ash);
+        dwr_finish(Wn[1], b, r0, g.H, ln, aff, asc, ash);
+    }
+    for (int i = 0; i < g.BH; i += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i + u < g.BH) {
+                const int r = r0 + i + u;
+                raw[(u + 1) & 1] = dwr_issue(xp, r + 2, g.H, g.W, ln);
+                dwr_pin(raw[u & 1]);  // row r + 1 (issued one step ago)
+                dwr_finish(Wn[(u + 2) & 3], raw[u & 1], r + 1, g.H, ln, aff, asc, ash);
+                compute(r, Wn[u], Wn[(u + 1) & 3], Wn[(u + 2) & 3]);
+            }
+        }
+    }
+    dwr_pin(raw[0]);  // (loads still in flight target live registers)
+    dwr_pin(raw[1]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward:
+//   dX[ci][q]        = sum_j sum_tap w[j][tap] * dY[ci*KPL + j][q - off(tap)]
+//   part[n][k][tap]  = sum_q xact[ci][q] * dY[k][q - off(tap)]      (tap < 9),   part[n][k][9] = sum_q dY[k][q]
+//   rpart (nullable; needs in_scale / in_shift, x = the PRE-BatchNorm tensor z of the previous half-block):
+//     rpart[0][n][ci] = sum g,  rpart[1][n][ci] = sum g * (z - mean) * invstd,  g = dX * [xact > 0]
+// Scatter form: the dY row rho that arrives at a step contributes to the dX rows rho - 1, rho, rho + 1 (tap rows 0, 1,
+// 2) and, with the x rows of the same three lines, to the weight gradient.  Live state: three dX accumulator rows,
+// three activated x rows (zero outside the band, so that neighbouring bands do not count a product twice), ONE dY
+// window row per channel.  A dX row is complete after the step of the row below it.
+// The loads of a step are issued at its start and consumed in the same step: the latency is covered by occupancy (a
+// variant that kept the next row in flight needed 128 VGPRs + spills and ran 1.4x slower; profiles/r2/dw_bench_r2m).
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef DWR_BWD_WAVES
+#define DWR_BWD_WAVES 4  // 5 needs spills (18 VGPRs) and runs 1.3x slower; profiles/r2/dw_bench_r2n
+#endif
+template <int KPL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAVES, DWR_BWD_WAVES))) void k_dw3x3_bwd_rows(const float* __restrict__ x, long x_bs,
+                                                         const float* __restrict__ dy, long dy_bs,
+                                                         const float* __restrict__ w_dw, float* __restrict__ dx,
+                                                         long dx_bs, float* __restrict__ part, int Cin, int nplanes,
+                                                         int N, const DwrGeom g, const float* __restrict__ bn_mean,
+                                                         const float* __restrict__ bn_invstd,
+                                                         float* __restrict__ rpart,
+                                                         const float* __restrict__ in_scale,
+                                                         const float* __restrict__ in_shift) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (tid >> 6));  // (plane, wave of the plane) list
+    const int plane = gw / g.wpp, wip = gw - plane * g.wpp;
+    if (plane >= nplanes) return;  // (whole wave; no barrier below)
+    const bool pvalid = true;
+    const int n = plane / Cin, ci = plane - n * Cin;
+    const int t = wip * 64 + lane;
+    const int band_ = t / g.ncol4, q = t - band_ * g.ncol4;
+    const bool active = pvalid && band_ < g.nbands;  // the other lanes walk a valid band with every output masked
+    const int band = band_ < g.nbands ? band_ : g.nbands - 1;
+    const int r0 = band * g.BH;
+    const float* xp = x + (long)n * x_bs + (long)ci * g.P + 4 * q;
+    const float* dyp = dy + (long)n * dy_bs + (long)(ci * KPL) * g.P + 4 * q;
+    float* dxp = dx ? dx + (long)n * dx_bs + (long)ci * g.P + 4 * q : nullptr;
+    float wt[KPL][9];
+#pragma unroll
+    for (int j = 0; j < KPL; ++j)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wt[j][k] = w_dw[(ci * KPL + j) * 9 + k];
+    const bool aff = in_scale != nullptr;
+    const float asc = aff ? in_scale[ci] : 1.f, ash = aff ? in_shift[ci] : 0.f;
+    const float rmean = rpart ? bn_mean[ci] : 0.f, rinvstd = rpart ? bn_invstd[ci] : 0.f;
+    const DwrLane ln = dwr_lane(lane, q, g.ncol4);
+
+    float accw[KPL][10];
+#pragma unroll
+    for (int j = 0; j < KPL; ++j)
+#pragma unroll
+        for (int k = 0; k < 10; ++k) accw[j][k] = 0.f;
+    float r1s = 0.f, r2s = 0.f;
+    {
+        const int r1 = !active ? r0 : ((r0 + g.BH < g.H) ? r0 + g.BH : g.H);  // band = rows [r0, r1); empty when masked
+        float dxa[3][4], xc[3][4];
+        float d[KPL][6];
+        DwrRaw raw[KPL];
+        float4 xn;
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dxa[s_][c] = xc[s_][c] = 0.f;
+        // step k: rho = r0 - 1 + k;  rows rho - 1, rho, rho + 1 live in slots k % 3, (k + 1) % 3, (k + 2) % 3
+        constexpr int UN = 3;
+        for (int k0 = 0; k0 < g.BH + 2; k0 += UN) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int k = k0 + u;
+                if (k < g.BH + 2) {
+                    const int rho = r0 - 1 + k;
+                    const int sa = u % 3, sb = (u + 1) % 3, sc_ = (u + 2) % 3;
+                    // issue: dY row rho, x row rho + 1
+#pragma unroll
+                    for (int j = 0; j < KPL; ++j) raw[j] = dwr_issue(dyp + (long)j * g.P, rho, g.H, g.W, ln);
+                    xn = dwr_issue4(xp, rho + 1, g.H, g.W);
+#pragma unroll
+                    for (int j = 0; j < KPL; ++j) dwr_pin(raw[j]);
+                    dwr_pin(xn);
+#pragma unroll
+                    for (int j = 0; j < KPL; ++j) dwr_finish(d[j], raw[j], rho, g.H, ln, false, 1.f, 0.f);
+                    {  // open the slot of row rho + 1
+                        const bool in = (rho + 1) >= r0 && (rho + 1) < r1;
+                        const float4 zv = xn;
+                        xc[sc_][0] = in ? dwr_act(zv.x, aff, asc, ash) : 0.f;
+                        xc[sc_][1] = in ? dwr_act(zv.y, aff, asc, ash) : 0.f;
+                        xc[sc_][2] = in ? dwr_act(zv.z, aff, asc, ash) : 0.f;
+                        xc[sc_][3] = in ? dwr_act(zv.w, aff, asc, ash) : 0.f;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) dxa[sc_][c] = 0.f;
+                    }
+                    const bool inb = rho >= r0 && rho < r1;
+#pragma unroll
+                    for (int j = 0; j < KPL; ++j) {
+                        const float(&dv)[6] = d[j];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                            for (int tc = 0; tc < 3; ++tc) {
+                                const float e = dv[c + 2 - tc];
+                                dxa[sa][c] = fmaf(wt[j][tc], e, dxa[sa][c]);        // row rho - 1: tap row 0
+                                dxa[sb][c] = fmaf(wt[j][3 + tc], e, dxa[sb][c]);    // row rho    : tap row 1
+                                dxa[sc_][c] = fmaf(wt[j][6 + tc], e, dxa[sc_][c]);  // row rho + 1: tap row 2
+                                accw[j][tc] = fmaf(xc[sa][c], e, accw[j][tc]);
+                                accw[j][3 + tc] = fmaf(xc[sb][c], e, accw[j][3 + tc]);
+                                accw[j][6 + tc] = fmaf(xc[sc_][c], e, accw[j][6 + tc]);
+                            }
+                        }
+                        const float bsum = (dv[1] + dv[2]) + (dv[3] + dv[4]);
+                        accw[j][9] += inb ? bsum : 0.f;
+                    }
+                    // row rho - 1 is complete
+                    const int rd = rho - 1;
+                    const bool fin = rd >= r0 && rd < r1;
+                    if (dxp && fin)
+                        *(float4*)(dxp + (long)rd * g.W) = make_float4(dxa[sa][0], dxa[sa][1], dxa[sa][2], dxa[sa][3]);
+                    if (rpart) {
+                        // the pre-BatchNorm values of the completed row again (L1 / L2 resident; loaded here, not at
+                        // the start of the step, to keep four registers free during the accumulation)
+                        const float4 zfin = dwr_issue4(xp, rd, g.H, g.W);
+                        const float zr[4] = {zfin.x, zfin.y, zfin.z, zfin.w};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float gg = (fin && xc[sa][c] > 0.f) ? dxa[sa][c] : 0.f;
+                            r1s += gg;
+                            r2s = fmaf(gg, (zr[c] - rmean) * rinvstd, r2s);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // wave sums -> one partial row per (image, wave of the plane)
+    const long row = (long)n * g.wpp + wip;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j)
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const float v = wave_sum_l63(accw[j][k]);
+            if (lane == 63) part[(row * Cin * KPL + ci * KPL + j) * 10 + k] = v;
+        }
+    if (rpart) {
+        const float v1 = wave_sum_l63(r1s), v2 = wave_sum_l63(r2s);
+        const long rows = (long)N * g.wpp;
+        if (lane == 63) {
+            rpart[row * Cin + ci] = v1;
+            rpart[(rows + row) * Cin + ci] = v2;
+        }
+    }
+}
+
+static int dwr_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("SMAAT_DW_ROWS");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
+// 1 when the row kernels take this shape (W % 4 == 0; the caller checks pointer / stride alignment)
+int dw_rows_ok(int kpl, int H, int W) {
+    return dwr_enabled() && (kpl == 1 || kpl == 2 || kpl == 4) && (W & 3) == 0 && W >= 4 && W <= 4096 && H >= 1;
+}
+
+int launch_dw3x3_fwd_rows(const float* x, long x_bs, const float* w_dw, const float* b_dw, float* y, long y_bs, int N,
+                          int Cin, int kpl, int H, int W, hipStream_t st, const float* in_scale,
+                          const float* in_shift) {
+    const int nplanes = N * Cin;
+    const DwrGeom g = dw_rows_geom(nplanes, H, W);
+    if (g.wpp == 0) return -2;
+    const dim3 grid((unsigned)(((long)nplanes * g.wpp + 3) / 4)), blk(256);
+    if (kpl == 1)
+        hipLaunchKernelGGL(k_dw3x3_fwd_rows<1>, grid, blk, 0, st, x, x_bs, w_dw, b_dw, y, y_bs, Cin, nplanes, g, in_scale,
+                           in_shift);
+    else if (kpl == 2)
+        hipLaunchKernelGGL(k_dw3x3_fwd_rows<2>, grid, blk, 0, st, x, x_bs, w_dw, b_dw, y, y_bs, Cin, nplanes, g, in_scale,
+                           in_shift);
+    else
+        hipLaunchKernelGGL(k_dw3x3_fwd_rows<4>, grid, blk, 0, st, x, x_bs, w_dw, b_dw, y, y_bs, Cin, nplanes, g, in_scale,
+                           in_shift);
+    return (int)hipGetLastError();
+}
+
+int launch_dw3x3_bwd_rows(const float* x, long x_bs, const float* dy, long dy_bs, const float* w_dw, float* dx,
+                          long dx_bs, float* part, int N, int Cin, int kpl, int H, int W, hipStream_t st,
+                          const float* bn_mean, const float* bn_invstd, float* rpart, const float* in_scale,
+                          const float* in_shift) {
+    const int nplanes = N * Cin;
+    const DwrGeom g = dw_rows_geom(nplanes, H, W);
+    if (g.wpp == 0) return -2;
+    const dim3 grid((unsigned)(((long)nplanes * g.wpp + 3) / 4)), blk(256);
+#define DWR_GO(K)                                                                                                     \
+    hipLaunchKernelGGL(k_dw3x3_bwd_rows<K>, grid, blk, 0, st, x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, part, Cin, nplanes, N, \
+                       g, bn_mean, bn_invstd, rpart, in_scale, in_shift)
+    if (kpl == 1)
+        DWR_GO(1);
+    else if (kpl == 2)
+        DWR_GO(2);
+    else
+        return -2;
+#undef DWR_GO
+    return (int)hipGetLastError();
+}

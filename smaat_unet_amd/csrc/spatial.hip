@@ -501,8 +501,11 @@ struct DwbGeom {
     int H, W, P, TH, TW, tiles_x, tiles, stride, nrow, ncol4, ssz;
 };
 
+#ifndef DWB_MINW
+#define DWB_MINW 1
+#endif
 template <int KPL>
-__global__ __launch_bounds__(256) void k_dw3x3_bwd_strip(const float* __restrict__ x, long x_bs,
+__global__ __launch_bounds__(256, DWB_MINW) void k_dw3x3_bwd_strip(const float* __restrict__ x, long x_bs,
                                                          const float* __restrict__ dy, long dy_bs,
                                                          const float* __restrict__ w_dw, float* __restrict__ dx,
                                                          long dx_bs, float* __restrict__ part, int Cin,
@@ -1029,6 +1032,14 @@ static int launch_dw3x3_fwd_small(const float* x, long x_bs, const float* w_dw, 
     return (int)hipGetLastError();
 }
 
+// dwrows.hip: register row-streaming kernels (W % 4 == 0)
+int dw_rows_ok(int kpl, int H, int W);
+int dw_rows_wpp(int N, int Cin, int H, int W);
+int launch_dw3x3_fwd_rows(const float*, long, const float*, const float*, float*, long, int, int, int, int, int,
+                          hipStream_t, const float*, const float*);
+int launch_dw3x3_bwd_rows(const float*, long, const float*, long, const float*, float*, long, float*, int, int, int, int,
+                          int, hipStream_t, const float*, const float*, float*, const float*, const float*);
+
 int launch_dw3x3_fwd(const float* x, long x_bs, const float* w_dw, const float* b_dw, float* y, long y_bs, int N,
                      int Cin, int kpl, int H, int W, hipStream_t st, const float* in_scale, const float* in_shift) {
     const bool aligned = ((W & 3) == 0) && ((x_bs & 3) == 0) && ((((uintptr_t)x) & 15) == 0) && H >= 1 &&
@@ -1037,6 +1048,8 @@ int launch_dw3x3_fwd(const float* x, long x_bs, const float* w_dw, const float* 
     if (!aligned && H * W <= DWS_PMAX)  // small planes with unaligned rows (18 x 18 ...): the flat-copy kernel
         return launch_dw3x3_fwd_small(x, x_bs, w_dw, b_dw, y, y_bs, N, Cin, kpl, H, W, st, in_scale, in_shift);
     if (!aligned) return -2;  // caller falls back to the fused f32 kernel
+    if (dw_rows_ok(kpl, H, W) && (y_bs & 3) == 0 && ((((uintptr_t)y) & 15) == 0))
+        return launch_dw3x3_fwd_rows(x, x_bs, w_dw, b_dw, y, y_bs, N, Cin, kpl, H, W, st, in_scale, in_shift);
     const DwbGeom sg = strip_geom(H, W, 1);
     if (sg.nrow * sg.ncol4 > 1536) return -2;
     long planes = (long)N * Cin;
@@ -1060,6 +1073,7 @@ int launch_dw3x3_fwd(const float* x, long x_bs, const float* w_dw, const float* 
 
 // tile groups per plane: enough workgroups to fill the chip, few enough to keep the partials small
 int dw_bwd_groups(int N, int Cin, int H, int W) {
+    if (dw_rows_ok(1, H, W)) return dw_rows_wpp(N, Cin, H, W);  // the row kernels: one partial row per wave of a plane
     TileGeom g;
     choose_geom_pub(N, H, W, 256, DWB_SMAX, &g);
     long planes = (long)N * Cin;
@@ -1084,6 +1098,9 @@ int launch_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, con
                          ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)dy) & 15) == 0) &&
                          ((((uintptr_t)dx) & 15) == 0) && (kpl == 1 || kpl == 2 || kpl == 4) && H >= 4;
     if (rpart && !in_scale) return -2;  // the fused reduction needs the pre-BatchNorm tensor (zhat = (z - mean) * invstd)
+    if (aligned && kpl <= 2 && dw_rows_ok(kpl, H, W))
+        return launch_dw3x3_bwd_rows(x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, part, N, Cin, kpl, H, W, st, bn_g, bn_b, rpart,
+                                     in_scale, in_shift);
     if (use_strip && aligned) {
         const DwbGeom sg = strip_geom(H, W, kpl);
         if (kpl * sg.nrow * sg.ncol4 <= 1536) {
