@@ -166,13 +166,13 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const float* __restrict_
             float o[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float acc = bs[j];
+                float acc = bs[j];  // tap order = the strip kernel's and the oracle's (row-major): same rounding
 #pragma unroll
-                for (int tc = 0; tc < 3; ++tc) {
-                    acc = fmaf(wt[j][tc], R0[c + tc], acc);
-                    acc = fmaf(wt[j][3 + tc], R1[c + tc], acc);
-                    acc = fmaf(wt[j][6 + tc], R2[c + tc], acc);
-                }
+                for (int tc = 0; tc < 3; ++tc) acc = fmaf(wt[j][tc], R0[c + tc], acc);
+#pragma unroll
+                for (int tc = 0; tc < 3; ++tc) acc = fmaf(wt[j][3 + tc], R1[c + tc], acc);
+#pragma unroll
+                for (int tc = 0; tc < 3; ++tc) acc = fmaf(wt[j][6 + tc], R2[c + tc], acc);
                 o[c] = acc;
             }
             if (active && r < g.H) *(float4*)(yp + (long)j * g.P + (long)r * g.W) = make_float4(o[0], o[1], o[2], o[3]);
