@@ -9,6 +9,11 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- bilinear blend, one fixed evaluation order for every upsample kernel (element-per-thread and row-walking forms
+// give bit-identical results):  v = a0 * (b0 * tl + b1 * tr) + a1 * (b0 * bl + b1 * br)
+__device__ __forceinline__ float bilerp_h(float b0, float l, float b1, float r) { return fmaf(b0, l, b1 * r); }
+__device__ __forceinline__ float bilerp_v(float a0, float top, float a1, float bot) { return fmaf(a0, top, a1 * bot); }
+
 // ---- DPP cross-lane adds (pure VALU, no LDS crossbar) -------------------------
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_src(float v) {

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_upsample2x_fwd(const float* __restrict_
             ac_coef(uc, sw, W, c0, c1, b0, b1);
             const float tl = xp[r0 * W + c0], tr = xp[r0 * W + c1];
             const float bl = xp[r1 * W + c0], br = xp[r1 * W + c1];
-            v = a0 * (b0 * tl + b1 * tr) + a1 * (b0 * bl + b1 * br);
+            v = bilerp_v(a0, bilerp_h(b0, tl, b1, tr), a1, bilerp_h(b0, bl, b1, br));
         }
         op[o] = v;
     }
@@ -722,8 +722,16 @@ int launch_maxpool2_bwd(const float* x, long x_bs, const float* dy, long dy_bs, 
     return (int)hipGetLastError();
 }
 
+// uprows.hip: row-walking kernels (float4 rows); -2 = shape / alignment not handled there
+int launch_upsample2x_fwd_rows(const float*, long, float*, long, int, int, int, int, int, int, int, int, hipStream_t);
+int launch_upsample2x_bwd_rows(const float*, long, float*, long, int, int, int, int, int, int, int, int, hipStream_t);
+
 int launch_upsample2x_fwd(const float* x, long x_bs, float* out, long out_bs, int N, int C, int H, int W, int Ho,
                           int Wo, int pad_t, int pad_l, hipStream_t st) {
+    {
+        const int rc = launch_upsample2x_fwd_rows(x, x_bs, out, out_bs, N, C, H, W, Ho, Wo, pad_t, pad_l, st);
+        if (rc != -2) return rc;
+    }
     int gy = cdivs((long)Ho * Wo, 2048);
     if (gy > 64) gy = 64;
     dim3 grid(N * C, gy);
@@ -733,6 +741,10 @@ int launch_upsample2x_fwd(const float* x, long x_bs, float* out, long out_bs, in
 
 int launch_upsample2x_bwd(const float* dout, long dout_bs, float* dx, long dx_bs, int N, int C, int H, int W, int Ho,
                           int Wo, int pad_t, int pad_l, hipStream_t st) {
+    {
+        const int rc = launch_upsample2x_bwd_rows(dout, dout_bs, dx, dx_bs, N, C, H, W, Ho, Wo, pad_t, pad_l, st);
+        if (rc != -2) return rc;
+    }
     if (W <= 256) {
         const int PB = 256 / W;
         const int NC = N * C;

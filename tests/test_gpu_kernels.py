@@ -539,7 +539,10 @@ def case_pool_up(L, dev, N, C, H, W, Ho, Wo):
 
 @pytest.mark.parametrize("shape", [(2, 3, 8, 8, 16, 16), (2, 4, 5, 6, 11, 13), (1, 2, 11, 13, 22, 26),
                                    (2, 8, 18, 18, 36, 36), (1, 2, 144, 144, 288, 288), (2, 3, 2, 2, 4, 4),
-                                   (1, 2, 2, 3, 5, 7)])
+                                   (1, 2, 2, 3, 5, 7),
+                                   # row-walking upsample kernels: padded (pad_l % 4 == 0), unpadded, many bands
+                                   (2, 4, 6, 8, 16, 24), (2, 5, 10, 12, 20, 24), (1, 3, 72, 72, 144, 144),
+                                   (1, 2, 7, 10, 16, 28), (3, 70, 4, 4, 8, 8), (1, 2, 36, 36, 72, 72)])
 def test_pool_upsample(shape):
     both(case_pool_up, *shape)
 
