@@ -189,6 +189,12 @@ int smaat_cbam_bwd_mlp(const float* ds, const float* s, const float* avg, const 
                        float* davg, float* dmx, void* stream);
 int smaat_cbam_bwd_final(float* dx, long dx_bs, const float* davg, const float* dmx, const int* amax, int N, int C,
                          int P, void* stream);
+/* smaat_cbam_bwd_final + the backward of the MaxPool2d(2) that reads the same tensor (encoder levels, reference
+ * models/SmaAt_UNet.py:43-50: x -> CBAM(x) for the skip, x -> DownDS -> next level), in one read-modify-write pass:
+ *   dx += davg/P + [p == amax] dmx + maxpool2_backward(x, dpool).   Returns -2 when the shape / alignment is not taken
+ *   (W % 4 != 0, unaligned planes): the caller then runs smaat_cbam_bwd_final and smaat_maxpool2_bwd(accum = 1). */
+int smaat_cbam_bwd_final_pool(float* dx, long dx_bs, const float* davg, const float* dmx, const int* amax, const float* x,
+                              long x_bs, const float* dpool, long dp_bs, int N, int C, int H, int W, void* stream);
 
 /* ---- bf16-split matrix path (f32 operands split exactly into three bf16 terms, six bf16 MFMAs per
  *      product, f32 accumulation: f32-class error at 2.7x the f32-MFMA rate).  Same reference call

@@ -64,6 +64,7 @@ SIGNATURES = {
     "smaat_cbam_bwd_main": [_P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P, _P],
     "smaat_cbam_bwd_mlp": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "smaat_cbam_bwd_final": [_P, _L, _P, _P, _P, _I, _I, _I, _P],
+    "smaat_cbam_bwd_final_pool": [_P, _L, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P],
     "smaat_split_enabled": [],
     "smaat_split_mode": [],
     "smaat_set_split_mode": [_I],

@@ -63,6 +63,8 @@ int launch_cbam_bwd_main(const float*, long, const float*, long, const float*, c
 int launch_cbam_bwd_mlp(const float*, const float*, const float*, const float*, const float*, const float*,
                         const float*, const float*, int, int, int, float*, float*, float*, hipStream_t);
 int launch_cbam_bwd_final(float*, long, const float*, const float*, const int*, int, int, int, hipStream_t);
+int launch_cbam_final_pool_bwd(float*, long, const float*, const float*, const int*, const float*, long, const float*, long,
+                               int, int, int, int, hipStream_t);
 
 
 struct DsSplitArgs {  // dsconv_split.hip
@@ -326,6 +328,11 @@ int smaat_cbam_bwd_mlp(const float* ds, const float* s, const float* avg, const 
 int smaat_cbam_bwd_final(float* dx, long dx_bs, const float* davg, const float* dmx, const int* amax, int N, int C,
                          int P, void* stream) {
     return launch_cbam_bwd_final(dx, dx_bs, davg, dmx, amax, N, C, P, ST);
+}
+int smaat_cbam_bwd_final_pool(float* dx, long dx_bs, const float* davg, const float* dmx, const int* amax, const float* x,
+                              long x_bs, const float* dpool, long dp_bs, int N, int C, int H, int W, void* stream) {
+    if (!dx || !davg || !dmx || !amax || !x || !dpool || N < 1 || C < 1 || H < 1 || W < 1) return -1;
+    return launch_cbam_final_pool_bwd(dx, dx_bs, davg, dmx, amax, x, x_bs, dpool, dp_bs, N, C, H, W, ST);
 }
 
 

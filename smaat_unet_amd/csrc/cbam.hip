@@ -796,6 +796,67 @@ __global__ __launch_bounds__(256) void k_cbam_bwd_final(float* __restrict__ dx, 
     }
 }
 
+// B5 + the backward of the MaxPool2d(2) that reads the same tensor (encoder levels: x -> CBAM(x) for the skip and
+// x -> maxpool -> next block; reference SmaAt_UNet.py:43-50), in ONE read-modify-write pass over dX:
+//   dx[n][c][p] += davg[n][c]/P + [p == amax[n][c]] * dmx[n][c] + [p is the first maximum of its 2x2 window] * dpool
+// instead of two passes (k_cbam_bwd_final, k_maxpool2_bwd with accum = 1).  A thread owns a 2 x 4 patch (two windows):
+// float4 accesses, the window maximum taken in the scan order of k_maxpool2_bwd.  W % 4 == 0; a last odd row has no
+// window (floor mode) and only receives the channel-attention terms.
+__global__ __launch_bounds__(256) void k_cbam_final_pool_bwd(float* __restrict__ dx, long dx_bs,
+                                                             const float* __restrict__ davg,
+                                                             const float* __restrict__ dmx,
+                                                             const int* __restrict__ amax,
+                                                             const float* __restrict__ x, long x_bs,
+                                                             const float* __restrict__ dpool, long dp_bs, int C, int H,
+                                                             int W, long total) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int ncol4 = W >> 2, npair = (H + 1) >> 1;
+    const int per = ncol4 * npair;
+    const int plane = (int)(gid / per), rem = (int)(gid - (long)plane * per);
+    const int i = rem / ncol4, q = rem - i * ncol4;
+    const int n = plane / C, c = plane - n * C;
+    const int P = H * W, Wo = W >> 1, Ho = H >> 1;
+    const float add = davg[plane] / (float)P;
+    const float dm = dmx[plane];
+    const int am = amax[plane];
+    const float* xp = x + (long)n * x_bs + (long)c * P;
+    float* dp = dx + (long)n * dx_bs + (long)c * P;
+    const int r0 = 2 * i, p0 = r0 * W + 4 * q;
+    const bool two = r0 + 1 < H;  // (i < Ho)
+    float4 d0 = *(const float4*)(dp + p0);
+    float a0[4] = {d0.x + add, d0.y + add, d0.z + add, d0.w + add};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (p0 + k == am) a0[k] += dm;
+    if (two) {
+        const float4 x0 = *(const float4*)(xp + p0), x1 = *(const float4*)(xp + p0 + W);
+        float4 d1 = *(const float4*)(dp + p0 + W);
+        const float2 g = *(const float2*)(dpool + (long)n * dp_bs + (long)c * Ho * Wo + (long)i * Wo + 2 * q);
+        float a1[4] = {d1.x + add, d1.y + add, d1.z + add, d1.w + add};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (p0 + W + k == am) a1[k] += dm;
+        const float xa[4] = {x0.x, x0.y, x0.z, x0.w}, xb[4] = {x1.x, x1.y, x1.z, x1.w};
+        const float gg[2] = {g.x, g.y};
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const float v0 = xa[2 * w], v1 = xa[2 * w + 1], v2 = xb[2 * w], v3 = xb[2 * w + 1];
+            int sel = 0;
+            float m = v0;
+            if (v1 > m) { m = v1; sel = 1; }
+            if (v2 > m) { m = v2; sel = 2; }
+            if (v3 > m) { m = v3; sel = 3; }
+            a0[2 * w] += sel == 0 ? gg[w] : 0.f;
+            a0[2 * w + 1] += sel == 1 ? gg[w] : 0.f;
+            a1[2 * w] += sel == 2 ? gg[w] : 0.f;
+            a1[2 * w + 1] += sel == 3 ? gg[w] : 0.f;
+        }
+        *(float4*)(dp + p0 + W) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+    }
+    *(float4*)(dp + p0) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+}
+
 // =====================================================================================
 static inline int cdivc(long a, long b) { return (int)((a + b - 1) / b); }
 static int seg_len_c(int P) { return P <= 8192 ? ((P + 1023) / 1024) * 1024 : 8192; }
@@ -917,5 +978,18 @@ int launch_cbam_bwd_final(float* dx, long dx_bs, const float* davg, const float*
     const int seg = seg_len_c(P);
     hipLaunchKernelGGL(k_cbam_bwd_final, dim3(N * C, cdivc(P, seg)), dim3(256), 0, st, dx, dx_bs, davg, dmx, amax, C,
                        P, seg);
+    return (int)hipGetLastError();
+}
+
+// -2: shape / alignment not handled (the caller runs smaat_cbam_bwd_final + smaat_maxpool2_bwd)
+int launch_cbam_final_pool_bwd(float* dx, long dx_bs, const float* davg, const float* dmx, const int* amax,
+                               const float* x, long x_bs, const float* dpool, long dp_bs, int N, int C, int H, int W,
+                               hipStream_t st) {
+    if ((W & 3) != 0 || (dx_bs & 3) != 0 || (x_bs & 3) != 0 || (dp_bs & 1) != 0 || ((((uintptr_t)dx) & 15) != 0) ||
+        ((((uintptr_t)x) & 15) != 0) || ((((uintptr_t)dpool) & 7) != 0) || H < 2)
+        return -2;
+    const long total = (long)N * C * (W >> 2) * ((H + 1) >> 1);
+    hipLaunchKernelGGL(k_cbam_final_pool_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dx, dx_bs, davg, dmx,
+                       amax, x, x_bs, dpool, dp_bs, C, H, W, total);
     return (int)hipGetLastError();
 }

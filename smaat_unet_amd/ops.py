@@ -879,9 +879,11 @@ def _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, 
     return out, saved, (use_ch, use_sp, use_batch_stats)
 
 
-def _cbam_backward_impl(saved, flags, dout):
+def _cbam_backward_impl(saved, flags, dout, pooled=None):
     """-> dx, dw1, db1, dw2, db2, dwconv, dgamma, dbeta.  `dout` may be a channel slice of a larger
-    gradient buffer (dense planes, any batch stride)."""
+    gradient buffer (dense planes, any batch stride).  pooled = (d maxpool2(x), batch stride): the gradient of the
+    MaxPool2d that reads x as well is added to dx (in the same pass as the channel-attention terms when the shape
+    allows)."""
     L = _lib.get()
     x, w1, w2, wconv, gamma, avg, mx, amax, ha, hm, sc, maps, conv, st, gate = saved
     use_ch, use_sp, train_stats = flags
@@ -928,6 +930,7 @@ def _cbam_backward_impl(saved, flags, dout):
                                      _ptr(dmaps), n, c, p, _ptr(dx), c * p, _ptr(dspart), s_),
                "smaat_cbam_bwd_main")
     dw1 = db1 = dw2 = db2 = None
+    pool_done = False
     if use_ch:
         cr = w1.shape[0]
         per = nbp // n
@@ -947,8 +950,21 @@ def _cbam_backward_impl(saved, flags, dout):
         db2 = pgr[c * cr:c * cr + c]
         dw1 = pgr[c * cr + c:c * cr + c + cr * c].view(cr, c)
         db1 = pgr[c * cr + c + cr * c:]
-        _lib.check(L.smaat_cbam_bwd_final(_ptr(dx), c * p, _ptr(davg), _ptr(dmx), _ptr(amax), n, c, p, s_),
-                   "smaat_cbam_bwd_final")
+        rc = -2
+        if pooled is not None:  # + the backward of the MaxPool2d that reads x too, in the same pass over dx
+            dpl, dp_bs = pooled
+            rc = L.smaat_cbam_bwd_final_pool(_ptr(dx), c * p, _ptr(davg), _ptr(dmx), _ptr(amax), _ptr(x), x_bs, _ptr(dpl),
+                                             dp_bs, n, c, h, w, s_)
+            if rc not in (0, -2):
+                _lib.check(rc, "smaat_cbam_bwd_final_pool")
+        if rc == -2:
+            _lib.check(L.smaat_cbam_bwd_final(_ptr(dx), c * p, _ptr(davg), _ptr(dmx), _ptr(amax), n, c, p, s_),
+                       "smaat_cbam_bwd_final")
+        pool_done = rc == 0
+    if pooled is not None and not pool_done:
+        dpl, dp_bs = pooled
+        _lib.check(L.smaat_maxpool2_bwd(_ptr(x), x_bs, _ptr(dpl), dp_bs, _ptr(dx), c * p, n, c, h, w, 1, s_),
+                   "smaat_maxpool2_bwd")
     return dx, dw1, db1, dw2, db2, dwconv, dgamma, dbeta
 
 
@@ -1031,16 +1047,17 @@ class _CBAMPoolCat(torch.autograd.Function):
         x = saved[0]
         n, c, h, w = x.shape
         if dcat is not None:
-            g = _cbam_backward_impl(saved, ctx.flags, dcat[:, :c])
+            pooled = _planes(dpooled) if dpooled is not None else None
+            g = _cbam_backward_impl(saved, ctx.flags, dcat[:, :c], pooled=pooled)
             dx = g[0]
         else:
             g = (None,) * 8
             dx = torch.zeros_like(x)
-        if dpooled is not None:
-            xx, x_bs = _planes(x)
-            dpooled, dp_bs = _planes(dpooled)
-            _lib.check(L.smaat_maxpool2_bwd(_ptr(xx), x_bs, _ptr(dpooled), dp_bs, _ptr(dx), c * h * w, n, c, h, w, 1,
-                                            _stream(x)), "smaat_maxpool2_bwd")
+            if dpooled is not None:
+                xx, x_bs = _planes(x)
+                dpooled, dp_bs = _planes(dpooled)
+                _lib.check(L.smaat_maxpool2_bwd(_ptr(xx), x_bs, _ptr(dpooled), dp_bs, _ptr(dx), c * h * w, n, c, h, w, 1,
+                                                _stream(x)), "smaat_maxpool2_bwd")
         return (dx,) + tuple(g[1:]) + (None,) * 6
 
 

@@ -565,6 +565,12 @@ class EmuLib:
         f32(dmx, N * C).reshape(N, C)[:] = dhm @ W1
         return 0
 
+    def smaat_cbam_bwd_final_pool(self, dx, dx_bs, davg, dmx, amax, x, x_bs, dpool, dp_bs, N, C, H, W, stream):
+        if W % 4 != 0 or H < 2:
+            return -2
+        self.smaat_cbam_bwd_final(dx, dx_bs, davg, dmx, amax, N, C, H * W, stream)
+        return self.smaat_maxpool2_bwd(x, x_bs, dpool, dp_bs, dx, dx_bs, N, C, H, W, 1, stream)
+
     def smaat_cbam_bwd_final(self, dx, dx_bs, davg, dmx, amax, N, C, P, stream):
         d = planes(dx, N, C, P, dx_bs)
         d += (f32(davg, N * C).reshape(N, C) / np.float32(P))[:, :, None]

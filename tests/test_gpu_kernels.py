@@ -547,6 +547,38 @@ def test_pool_upsample(shape):
     both(case_pool_up, *shape)
 
 
+def case_final_pool(L, dev, N, C, H, W, pad_c=0):
+    """cbam_bwd_final + maxpool2 backward in one pass == the two separate kernels (bit for bit: same adds, same order)"""
+    Pn = H * W
+    x = T(np.maximum(rnd(1, N, C + pad_c, H, W), 0), dev)  # relu-like: ties at 0 inside windows
+    dpool = T(rnd(2, N, C, H // 2, W // 2), dev)
+    davg, dmx = T(rnd(3, N, C), dev), T(rnd(4, N, C), dev)
+    amax = torch.from_numpy(np.random.default_rng(5).integers(0, Pn, (N, C)).astype(np.int32)).to(dev)
+    dx0 = T(rnd(6, N, C, H, W), dev)
+    s = stream(dev)
+    dx = dx0.clone()
+    rc = L.smaat_cbam_bwd_final_pool(P(dx), C * Pn, P(davg), P(dmx), P(amax), P(x), (C + pad_c) * Pn, P(dpool),
+                                     C * (H // 2) * (W // 2), N, C, H, W, s)
+    ref = dx0.clone()
+    assert L.smaat_cbam_bwd_final(P(ref), C * Pn, P(davg), P(dmx), P(amax), N, C, Pn, s) == 0
+    assert L.smaat_maxpool2_bwd(P(x), (C + pad_c) * Pn, P(dpool), C * (H // 2) * (W // 2), P(ref), C * Pn, N, C, H, W, 1,
+                                s) == 0
+    if W % 4 == 0 and H >= 2:
+        assert rc == 0
+        assert torch.equal(dx, ref)
+    else:
+        assert rc == -2
+        dx = ref
+    return dict(dx=dx)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 8, 8), (2, 5, 9, 12), (1, 2, 288, 288), (3, 70, 4, 4), (2, 4, 6, 10),
+                                   (2, 64, 36, 36), (1, 3, 2, 4)])
+def test_cbam_final_pool(shape):
+    both(case_final_pool, *shape)
+    both(case_final_pool, *shape, pad_c=2)
+
+
 # ----------------------------------------------------------------------------------------
 def case_cbam_eval(L, dev, N, C, H, W, ks=7, rr=16, pool=True, pad_c=0):
     """inference CBAM: chpool -> eval_pool (MLP + channel-wise maps) -> eval_apply (conv + BN(1) running stats + sigmoid
