@@ -217,6 +217,9 @@ int smaat_split_enabled(void);
 int smaat_split_mode(void);
 int smaat_set_split_mode(int mode);
 int smaat_split_planes(const float* w, int R, int C, void* planes, void* stream);
+/* planes of the TRANSPOSE of a matrix stored [C][R] (same output layout as smaat_split_planes(w^T, R, C)): the data
+ * gradient of a pointwise conv takes A = pointwise.weight^T without a transposed copy of the weight */
+int smaat_split_planes_t(const float* w, int R, int C, void* planes, void* stream);
 int smaat_pw_split_num_slots(int N, int H, int W);
 int smaat_dw3x3_fwd(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
                     const float* b_dw, float* y, long y_bs, int N, int Cin, int kpl, int H, int W, void* stream);

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 from torch import nn
 
-from .layers import CBAM
+from .layers import CBAM, batched_counters
 from .unet_parts import OutConv
 from .unet_parts_depthwise_separable import DoubleConvDS, DownDS, UpDS
 
@@ -102,7 +102,8 @@ class UNetDSFamily(nn.Module):
         if (getattr(self, "_graph_enabled", False) and not self.training and not torch.is_grad_enabled() and x.is_cuda
                 and not torch.cuda.is_current_stream_capturing()):
             return self._graph_forward(x)
-        return self._forward_impl(x)
+        with batched_counters():  # one add for all num_batches_tracked counters of the step
+            return self._forward_impl(x)
 
     def _forward_impl(self, x):
         # NB (reference SmaAt_UNet.py:41-57): the encoder continues from the UN-attended x_i; the CBAM

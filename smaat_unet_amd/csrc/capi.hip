@@ -39,6 +39,7 @@ int launch_dw3x3_bwd(const float*, long, const float*, long, const float*, float
                      int, hipStream_t, const float*, const float*, float*, const float*, const float*);
 int launch_dw_split(const float*, int, float*, float*, hipStream_t);
 int dw_bwd_groups(int N, int Cin, int H, int W);
+int launch_dw_reduce_split(const float* part, int rows, int Cdw, float* dw, float* db, hipStream_t st);
 int dw3x3_strip_ok(int kpl, int H, int W);
 
 int smaat_cbam_spconv_blocks_impl(int N, int H, int W);
@@ -87,7 +88,7 @@ int launch_dsconv_split(DsSplitArgs& a, int kpl, hipStream_t st);
 int dsconv_split_num_slots(int N, int H, int W);
 int split_mode();
 int set_split_mode(int m);
-int launch_split_planes(const float* w, int R, int C, unsigned short* out, hipStream_t st);
+int launch_split_planes(const float* w, int R, int C, unsigned short* out, hipStream_t st, int src_t = 0);
 int pw_split_num_slots(int N, int P);
 long precip_metrics_ws_bytes(long n);                                                    // metrics.hip
 int launch_precip_metrics_update(const float* preds, const float* target, long n, int batch, float factor, float thr,
@@ -181,9 +182,7 @@ int smaat_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, cons
     hipStream_t st = ST;
     const int rows = N * dw_bwd_groups(N, Cin, H, W);
     CHK(launch_dw3x3_bwd(x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, ws, N, Cin, kpl, H, W, st, nullptr, nullptr, nullptr, nullptr, nullptr));
-    float* tmp = ws + (long)rows * Cdw * 10;
-    CHK(launch_reduce_rows(ws, rows, (long)Cdw * 10, tmp, 1.f, st));
-    return launch_dw_split(tmp, Cdw, dw_out, db_out, st);
+    return launch_dw_reduce_split(ws, rows, Cdw, dw_out, db_out, st);
 }
 
 int smaat_dw3x3_bwd_bnred(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* dy,
@@ -196,9 +195,7 @@ int smaat_dw3x3_bwd_bnred(const float* x, long x_bs, const float* in_scale, cons
     hipStream_t st = ST;
     const int rows = N * dw_bwd_groups(N, Cin, H, W);
     CHK(launch_dw3x3_bwd(x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, ws, N, Cin, kpl, H, W, st, bn_mean, bn_invstd, rpart, in_scale, in_shift));
-    float* tmp = ws + (long)rows * Cdw * 10;
-    CHK(launch_reduce_rows(ws, rows, (long)Cdw * 10, tmp, 1.f, st));
-    return launch_dw_split(tmp, Cdw, dw_out, db_out, st);
+    return launch_dw_reduce_split(ws, rows, Cdw, dw_out, db_out, st);
 }
 
 int smaat_bn_finalize(const float* part, int T, int C, double count, const float* bias_shift, const float* gamma,
@@ -345,6 +342,10 @@ int smaat_set_split_mode(int mode) {
 int smaat_split_planes(const float* w, int R, int C, void* planes, void* stream) {
     if (R < 1 || C < 1) return -1;
     return launch_split_planes(w, R, C, (unsigned short*)planes, ST);
+}
+int smaat_split_planes_t(const float* w, int R, int C, void* planes, void* stream) {
+    if (R < 1 || C < 1) return -1;
+    return launch_split_planes(w, R, C, (unsigned short*)planes, ST, 1);
 }
 int smaat_pw_split_num_slots(int N, int H, int W) { return pw_split_num_slots(N, H * W); }
 int smaat_dw3x3_fwd(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,

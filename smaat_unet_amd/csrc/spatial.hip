@@ -1150,6 +1150,39 @@ int dw3x3_strip_ok(int kpl, int H, int W) {
     return (f.nrow * f.ncol4 <= 1536 && kpl * b.nrow * b.ncol4 <= 1536) ? 1 : 0;
 }
 
+// part[rows][Cdw][10] -> dW[Cdw][9], db[Cdw]: the fixed-order fp64 row sum and the split in one launch.
+// A block owns 64 consecutive columns; its 16 row groups sum rows rg, rg + 16, ... (independent coalesced loads) and
+// are then added in a fixed order.
+__global__ __launch_bounds__(1024) void k_dw_reduce_split(const float* __restrict__ part, int rows, int Cdw,
+                                                          float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ double red[16][64];
+    const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int len = Cdw * 10;
+    const int i = blockIdx.x * 64 + col;
+    double s = 0.0;
+    if (i < len) {
+#pragma unroll 4
+        for (int r = rg; r < rows; r += 16) s += (double)part[(long)r * len + i];
+    }
+    red[rg][col] = s;
+    __syncthreads();
+    if (rg == 0 && i < len) {
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][col];
+        const int k = i / 10, tt = i - k * 10;
+        if (tt < 9)
+            dw[k * 9 + tt] = (float)t;
+        else
+            db[k] = (float)t;
+    }
+}
+
+int launch_dw_reduce_split(const float* part, int rows, int Cdw, float* dw, float* db, hipStream_t st) {
+    hipLaunchKernelGGL(k_dw_reduce_split, dim3(cdivs((long)Cdw * 10, 64)), dim3(1024), 0, st, part, rows, Cdw, dw, db);
+    return (int)hipGetLastError();
+}
+
 int launch_dw_split(const float* tmp, int Cdw, float* dw, float* db, hipStream_t st) {
     hipLaunchKernelGGL(k_dw_split, dim3(cdivs((long)Cdw * 10, 256)), dim3(256), 0, st, tmp, Cdw, dw, db);
     return (int)hipGetLastError();

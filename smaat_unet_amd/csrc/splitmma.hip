@@ -312,12 +312,16 @@ int launch_wgrad_split(Wg2Args& a, int nt, hipStream_t st) {
 // vector L1 spent ~70% of the short-contraction GEMMs stalled on pending lines.)  Run once per weight
 // tensor per step.
 // =====================================================================================
+// src_t: the planes of the TRANSPOSE are wanted, w is stored [C][R] (the data gradient dY = W^T dZ takes the planes of
+// pointwise.weight^T straight from the weight, without a transposed copy)
 __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ w, int R, int C, int Cp,
-                                                      unsigned short* __restrict__ out, int bf16_only) {
+                                                      unsigned short* __restrict__ out, int bf16_only, int src_t) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)R * Cp) return;
-    const int r = (int)(i / Cp), c = (int)(i - (long)r * Cp);
-    const float x = c < C ? w[(long)r * C + c] : 0.f;
+    // consecutive threads walk the CONTIGUOUS dimension of the source (coalesced reads; the 2-byte scattered writes of
+    // the transposed case go to a tensor of at most a few MB)
+    const int r = src_t ? (int)(i % R) : (int)(i / Cp), c = src_t ? (int)(i / R) : (int)(i - (long)r * Cp);
+    const float x = c < C ? (src_t ? w[(long)c * R + r] : w[(long)r * C + c]) : 0.f;
     const float p1 = bf16_only ? rne_bf16(x) : bitsf(fbits(x) & 0xFFFF0000u);
     const float r1 = bf16_only ? 0.f : x - p1;
     const float p2 = bitsf(fbits(r1) & 0xFFFF0000u);
@@ -330,11 +334,11 @@ __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ 
     out[o + 2 * plane] = (unsigned short)(fbits(p3) >> 16);
 }
 
-int launch_split_planes(const float* w, int R, int C, unsigned short* out, hipStream_t st) {
+int launch_split_planes(const float* w, int R, int C, unsigned short* out, hipStream_t st, int src_t) {
     const int Cp = (C + 15) & ~15;
     const long n = (long)R * Cp;
     hipLaunchKernelGGL(k_split_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, R, C, Cp, out,
-                       split_mode() == 1 ? 1 : 0);
+                       split_mode() == 1 ? 1 : 0, src_t);
     return (int)hipGetLastError();
 }
 

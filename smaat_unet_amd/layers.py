@@ -3,9 +3,34 @@ hot path): same constructor signatures, attribute names and state_dict keys; `fo
 dispatches to the gfx950 kernels (smaat_unet_amd.ops).  No CPU path."""
 from __future__ import annotations
 
+import contextlib
+import threading
+
+import torch
 from torch import nn
 
 from . import ops
+
+_TLS = threading.local()
+
+
+@contextlib.contextmanager
+def batched_counters():
+    """Inside this context the `num_batches_tracked += 1` of every train-mode BatchNorm that runs (reference:
+    torch.nn.BatchNorm2d.forward) is deferred and applied on exit with ONE multi-tensor add instead of one tiny
+    kernel per layer (23 per SmaAt_UNet step).  The network's forward wraps itself in it; a BatchNorm with
+    momentum=None needs the counter's value and increments immediately."""
+    if getattr(_TLS, "pending", None) is not None:  # nested: the outermost context flushes
+        yield
+        return
+    _TLS.pending = []
+    try:
+        yield
+    finally:
+        pend, _TLS.pending = _TLS.pending, None
+        if pend:
+            with torch.no_grad():
+                torch._foreach_add_(pend, 1)
 
 
 def _bn_args(bn: nn.BatchNorm2d):
@@ -14,7 +39,11 @@ def _bn_args(bn: nn.BatchNorm2d):
     momentum = bn.momentum
     if bn.training and bn.track_running_stats:
         if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+            pend = getattr(_TLS, "pending", None)
+            if pend is not None and bn.momentum is not None:
+                pend.append(bn.num_batches_tracked)
+            else:
+                bn.num_batches_tracked.add_(1)
             if bn.momentum is None:
                 momentum = 1.0 / float(bn.num_batches_tracked)
     training = bn.training or (bn.running_mean is None and bn.running_var is None)

@@ -166,13 +166,15 @@ def set_matrix_mode(mode):
     return {0: "f32", 1: "bf16", 2: "f32_split2", 3: "f32_split"}[prev]
 
 
-def _split_planes_raw(w2d):
-    """w2d [R][C] f32 contiguous -> int16 bf16 planes, 3 * R * ceil16(C) elements (chunk-major [ceil16(C)/16][3][R][16])"""
+def _split_planes_raw(w2d, transpose=False):
+    """w2d [R][C] f32 contiguous -> int16 bf16 planes, 3 * R * ceil16(C) elements (chunk-major [ceil16(C)/16][3][R][16]).
+    transpose=True: the planes of w2d^T (w2d is [C][R]), read straight from w2d"""
     L = _lib.get()
-    r, c = w2d.shape
+    r, c = (w2d.shape[1], w2d.shape[0]) if transpose else w2d.shape
     cp = (c + 15) // 16 * 16
     planes = torch.empty((3, r, cp), dtype=torch.int16, device=w2d.device)
-    _lib.check(L.smaat_split_planes(_ptr(w2d), r, c, _ptr(planes), _stream(w2d)), "smaat_split_planes")
+    fn = L.smaat_split_planes_t if transpose else L.smaat_split_planes
+    _lib.check(fn(_ptr(w2d), r, c, _ptr(planes), _stream(w2d)), "smaat_split_planes")
     return planes
 
 
@@ -376,7 +378,7 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None, i
     # data gradient of the pointwise conv: dY = W^T dZ  (wt := w_pw in its natural [Cout][K] layout)
     if _split_dgrad_ok(cout, k):
         # A[m' = k][c = co] = w_pw[co][k]: planes of the transposed weight
-        planes_t = _split_planes_raw(w_pw.reshape(cout, k).t().contiguous())
+        planes_t = _split_planes_raw(w_pw.reshape(cout, k), transpose=True)
         dy, _, _ = _pointwise_split_raw(dz, planes_t, None, k)
     else:
         dy = _new(x, n, k, h, w)

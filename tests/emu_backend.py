@@ -112,6 +112,10 @@ class EmuLib:
         assert not rem.any(), "three bf16 terms must represent an f32 exactly"
         return 0
 
+    def smaat_split_planes_t(self, w, R, C, out, stream):
+        wt = np.ascontiguousarray(f32(w, R * C).reshape(C, R).T)
+        return self.smaat_split_planes(wt.ctypes.data, R, C, out, stream)
+
     def smaat_dw3x3_fwd(self, x, x_bs, in_scale, in_shift, w_dw, b_dw, y, y_bs, N, Cin, kpl, H, W, stream):
         if kpl not in (1, 2, 4) or (W % 4 and H * W > 1600):  # small planes take the flat-copy kernel, any width
             return -2

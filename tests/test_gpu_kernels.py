@@ -547,6 +547,22 @@ def test_pool_upsample(shape):
     both(case_pool_up, *shape)
 
 
+@pytest.mark.parametrize("shape", [(64, 256), (37, 19), (512, 1024), (1, 5)])
+def test_split_planes_transposed(shape):
+    """smaat_split_planes_t(w [C][R]) == smaat_split_planes(w^T): the data gradient takes the planes of the transposed
+    pointwise weight without a transposed copy"""
+    L, dev = _lib.get(), torch.device("cuda:0")
+    C, R = shape
+    w = T(rnd(1, C, R), dev)
+    Cp = (C + 15) // 16 * 16
+    a = torch.full((3, R, Cp), -1, dtype=torch.int16, device=dev)
+    b = torch.full((3, R, Cp), -2, dtype=torch.int16, device=dev)
+    wt = w.t().contiguous()
+    assert L.smaat_split_planes(P(wt), R, C, P(a), stream(dev)) == 0
+    assert L.smaat_split_planes_t(P(w), R, C, P(b), stream(dev)) == 0
+    assert torch.equal(a, b)
+
+
 def case_final_pool(L, dev, N, C, H, W, pad_c=0):
     """cbam_bwd_final + maxpool2 backward in one pass == the two separate kernels (bit for bit: same adds, same order)"""
     Pn = H * W
