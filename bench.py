@@ -364,19 +364,25 @@ def main():
         HBM = "HBM3E 8000 GB/s"
         nt = 6.0 if _lib.get().smaat_split_mode() == 3 else (3.0 if _lib.get().smaat_split_mode() == 2 else 1.0)
         classes = [
-            klass(["smaat_pointwise_fwd_split", "smaat_dsconv_fwd_split"], "mfma", PEAK_BF16_MFMA_TFLOPS, "TFLOP/s", nt,
-                  "k_pw_split_p / k_dsconv_split: persistent wave-specialised GEMMs (v_mfma_f32_32x32x16_bf16, exact "
-                  "3-term operand split)", pmc=("k_pw_split", "k_dsconv_split"), peak_name=BF16),
+            klass(["smaat_pointwise_fwd_split"], "mfma", PEAK_BF16_MFMA_TFLOPS, "TFLOP/s", nt,
+                  "k_pw_split_p: persistent wave-specialised GEMM (v_mfma_f32_32x32x16_bf16, exact 3-term operand "
+                  "split): pointwise forward of the GEMM-sized layers + every data gradient", pmc=("k_pw_split",),
+                  peak_name=BF16),
+            klass(["smaat_dsconv_fwd_split"], "mfma", PEAK_BF16_MFMA_TFLOPS, "TFLOP/s", nt,
+                  "k_dsconv_split: fused depthwise 3x3 -> split GEMM forward of the 288^2 layers (depthwise tensor written "
+                  "once as a side output for the weight gradient, never re-read by the forward)", pmc=("k_dsconv_split",),
+                  peak_name=BF16),
             klass(["smaat_pointwise_wgrad"], "mfma", PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
                   nt if split else 1.0, "k_wgrad_split" if split else "k_wgrad2 (v_mfma_f32_32x32x2_f32)",
                   pmc=("k_wgrad_split",) if split else ("k_wgrad2",), peak_name=BF16 if split else F32),
             klass(["smaat_dsconv_fwd", "smaat_pointwise_fwd"], "mfma", PEAK_F32_MFMA_TFLOPS, "TFLOP/s", 1.0,
                   "k_pwgemm_ws / k_dsconv_strip / k_pwgemm (v_mfma_f32_32x32x2_f32)", pmc=("k_pwgemm", "k_dsconv_strip"),
                   peak_name=F32),
-            klass(["smaat_dw3x3_bwd", "smaat_dw3x3_bwd_bnred"], "hbm", PEAK_HBM_GBS, "GB/s", 1.0, "k_dw3x3_bwd_strip",
+            klass(["smaat_dw3x3_bwd", "smaat_dw3x3_bwd_bnred"], "hbm", PEAK_HBM_GBS, "GB/s", 1.0,
+                  "k_dw3x3_bwd_rows (register row-streaming depthwise backward, + the fused BatchNorm reduction)",
                   pmc=("k_dw3x3_bwd",), peak_name=HBM),
-            klass(["smaat_dw3x3_fwd"], "hbm", PEAK_HBM_GBS, "GB/s", 1.0, "k_dw3x3_fwd_strip", pmc=("k_dw3x3_fwd",),
-                  peak_name=HBM),
+            klass(["smaat_dw3x3_fwd"], "hbm", PEAK_HBM_GBS, "GB/s", 1.0, "k_dw3x3_fwd_rows (register row-streaming "
+                  "depthwise forward)", pmc=("k_dw3x3_fwd",), peak_name=HBM),
             klass(["smaat_bn_bwd_apply", "smaat_bn_bwd_reduce", "smaat_affine_act"], "hbm", PEAK_HBM_GBS, "GB/s", 1.0,
                   "BatchNorm/ReLU streaming kernels", pmc=("k_bn_bwd_apply", "k_bn_bwd_reduce", "k_affine_act"),
                   peak_name=HBM),
