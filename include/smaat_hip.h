@@ -99,7 +99,8 @@ int smaat_dw3x3_bwd_bnred(const float* x, long x_bs, const float* in_scale, cons
  *   bwd: g = dy*[y>0]; part [2][slots][C] with slots = smaat_plane_num_slots(N,P);
  *        finalize -> dgamma, dbeta, coef[3][C]; apply -> dz.
  */
-int smaat_bn_finalize(const float* part, int T, int C, double count, const float* bias_shift, const float* gamma,
+/* part is SCRATCH: with T >= 2048 tiles the rows are first merged in place (64 slabs, head rows overwritten) */
+int smaat_bn_finalize(float* part, int T, int C, double count, const float* bias_shift, const float* gamma,
                       const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                       float* mean, float* invstd, float* scale, float* shift, void* stream);
 /* eval mode: st[4][C] = running_mean, 1/sqrt(running_var+eps), gamma*invstd, beta - mean*gamma*invstd */

@@ -10,10 +10,11 @@
 // update  M2 = sum_t M2_t + n_t (mean_t - mean)^2, evaluated in one pass about a shift taken from the data: no
 // E[z^2] - E[z]^2 of raw values anywhere, so the variance keeps its accuracy when |mean| >> std.
 // ---------------------------------------------------------------------------------
+template <int NTH>
 __device__ __forceinline__ double block_sum_f64(double v, double* red) {
     red[threadIdx.x] = v;
     __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
+    for (int st = NTH / 2; st > 0; st >>= 1) {
         if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
         __syncthreads();
     }
@@ -22,28 +23,80 @@ __device__ __forceinline__ double block_sum_f64(double v, double* red) {
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ part, int T, int C, double count,
+// NTH threads per channel: 1024 for the layers with thousands of tiles (the reads of one channel are strided by C
+// floats, so the time is set by the number of loads in flight), 256 otherwise.
+// Level 1 for layers with thousands of tiles: merge the tiles of a slab of R rows into ONE partial of the same form,
+// written over the slab's head row (the partial buffer is scratch once the GEMM has finished; same convention as
+// k_reduce_rows_l1).  A block owns 16 adjacent channels (64-byte runs: full sectors) and 16 row lanes; fp64 one-pass
+// sums about the head row's mean, row lanes added in a fixed order.  k_bn_finalize then reads the head rows only.
+__global__ __launch_bounds__(256) void k_bn_merge_slabs(float* __restrict__ part, int T, int C, int R) {
+    __shared__ double red[3][16][17];
+    const int ch = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + ch;
+    const int t0 = blockIdx.y * R;
+    const int t1 = t0 + R < T ? t0 + R : T;
+    const bool cv = c < C;
+    const int cc = cv ? c : C - 1;
+    float* pm = part + cc;
+    float* pq = part + (long)T * C + cc;
+    float* pn = part + 2L * T * C + cc;
+    const double K = (double)pm[(long)t0 * C];
+    double n = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
+    for (int t = t0 + rl; t < t1; t += 16) {
+        const double nt = (double)pn[(long)t * C];
+        const double d = (double)pm[(long)t * C] - K;
+        n += nt;
+        s1 += nt * d;
+        s2 += (double)pq[(long)t * C] + nt * d * d;
+    }
+    red[0][ch][rl] = n;
+    red[1][ch][rl] = s1;
+    red[2][ch][rl] = s2;
+    __syncthreads();  // (also: every read of the head row is done before it is overwritten)
+    if (rl == 0 && cv) {
+        double nn = 0.0, a = 0.0, b = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            nn += red[0][ch][j];
+            a += red[1][ch][j];
+            b += red[2][ch][j];
+        }
+        const double mean = nn > 0.0 ? K + a / nn : 0.0;
+        double m2 = nn > 0.0 ? b - a * a / nn : 0.0;
+        if (m2 < 0.0) m2 = 0.0;
+        pm[(long)t0 * C] = (float)mean;
+        pq[(long)t0 * C] = (float)m2;
+        pn[(long)t0 * C] = (float)nn;
+    }
+}
+
+// RS: row stride (1, or the slab size after k_bn_merge_slabs: only the head rows are read)
+template <int NTH>
+__global__ __launch_bounds__(NTH) void k_bn_finalize(const float* __restrict__ part, int T, int RS, int C, double count,
                                                      const float* __restrict__ bias_shift,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, float momentum, float* running_mean,
                                                      float* running_var, float* mean_out, float* invstd_out,
                                                      float* scale_out, float* shift_out) {
-    __shared__ double red[256];
+    __shared__ double red[NTH];
     const int c = blockIdx.x;
+    const long RC = (long)RS * C;  // distance between the rows that are read
     const float* pm = part + c;
     const float* pq = part + (long)T * C + c;
     const float* pn = part + 2L * T * C + c;
+    const int TR = (T + RS - 1) / RS;  // rows read
     // ONE pass, in fp64, about the shift K = mean of tile 0 (a value inside the data range, so the final
     // s2 - s1^2 / N has no cancellation beyond the spread of the tile means):
     //   N = sum n_t,  s1 = sum n_t (m_t - K),  s2 = sum [M2_t + n_t (m_t - K)^2]
     const double K = (double)pm[0];
     double n = 0.0, s1 = 0.0, s2 = 0.0;
     int t = threadIdx.x;
-    for (; t + 768 < T; t += 1024) {  // four independent loads of each row in flight
+    for (; t + 3 * NTH < TR; t += 4 * NTH) {  // four independent loads of each row in flight
         double nn[4], dd[4], qq[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const long o = (long)(t + 256 * u) * C;
+            const long o = (long)(t + NTH * u) * RC;
             nn[u] = (double)pn[o];
             dd[u] = (double)pm[o] - K;
             qq[u] = (double)pq[o];
@@ -55,16 +108,16 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ p
             s2 += qq[u] + nn[u] * dd[u] * dd[u];
         }
     }
-    for (; t < T; t += 256) {
-        const double nt = (double)pn[(long)t * C];
-        const double d = (double)pm[(long)t * C] - K;
+    for (; t < TR; t += NTH) {
+        const double nt = (double)pn[(long)t * RC];
+        const double d = (double)pm[(long)t * RC] - K;
         n += nt;
         s1 += nt * d;
-        s2 += (double)pq[(long)t * C] + nt * d * d;
+        s2 += (double)pq[(long)t * RC] + nt * d * d;
     }
-    const double ntot = block_sum_f64(n, red);
-    const double s1t = block_sum_f64(s1, red);
-    const double s2t = block_sum_f64(s2, red);
+    const double ntot = block_sum_f64<NTH>(n, red);
+    const double s1t = block_sum_f64<NTH>(s1, red);
+    const double s2t = block_sum_f64<NTH>(s2, red);
     const double m0 = ntot > 0.0 ? K + s1t / ntot : 0.0;
     const double qtot = ntot > 0.0 ? s2t - s1t * s1t / ntot : 0.0;
     if (threadIdx.x == 0) {
@@ -352,10 +405,16 @@ static int plane_seg_len(int P) {
 
 int smaat_bn_bwd_num_slots_impl(int N, int P) { return N * cdiv(P, plane_seg_len(P)); }
 
-int launch_bn_finalize(const float* part, int T, int C, double count, const float* bias_shift, const float* gamma,
+int launch_bn_finalize(float* part, int T, int C, double count, const float* bias_shift, const float* gamma,
                        const float* beta, float eps, float momentum, float* rm, float* rv, float* mean, float* invstd,
                        float* scale, float* shift, hipStream_t st) {
-    hipLaunchKernelGGL(k_bn_finalize, dim3(C), dim3(256), 0, st, part, T, C, count, bias_shift, gamma, beta, eps,
+    int RS = 1;
+    if (T >= 2048) {  // two levels: 64 slabs merged in place, then the head rows
+        RS = (T + 63) / 64;
+        const int ns = (T + RS - 1) / RS;
+        hipLaunchKernelGGL(k_bn_merge_slabs, dim3((C + 15) / 16, ns), dim3(256), 0, st, (float*)part, T, C, RS);
+    }
+    hipLaunchKernelGGL(k_bn_finalize<256>, dim3(C), dim3(256), 0, st, part, T, RS, C, count, bias_shift, gamma, beta, eps,
                        momentum, rm, rv, mean, invstd, scale, shift);
     return (int)hipGetLastError();
 }

@@ -13,7 +13,7 @@ int launch_wgrad(WgArgs& a, bool dw, hipStream_t st);
 int smaat_pw_num_slots_impl(int N, int H, int W, int M);
 int smaat_wgrad_num_splits_impl(int N, int P, int M, int K);
 
-int launch_bn_finalize(const float*, int, int, double, const float*, const float*, const float*, float, float, float*,
+int launch_bn_finalize(float*, int, int, double, const float*, const float*, const float*, float, float, float*,
                        float*, float*, float*, float*, float*, hipStream_t);
 int launch_bn_eval_coefs(const float*, const float*, const float*, const float*, float, int, float*, hipStream_t);
 int launch_affine_act(const float*, long, const float*, const float*, float*, long, int, int, int, int, hipStream_t);
@@ -198,7 +198,7 @@ int smaat_dw3x3_bwd_bnred(const float* x, long x_bs, const float* in_scale, cons
     return launch_dw_reduce_split(ws, rows, Cdw, dw_out, db_out, st);
 }
 
-int smaat_bn_finalize(const float* part, int T, int C, double count, const float* bias_shift, const float* gamma,
+int smaat_bn_finalize(float* part, int T, int C, double count, const float* bias_shift, const float* gamma,
                       const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                       float* mean, float* invstd, float* scale, float* shift, void* stream) {
     return launch_bn_finalize(part, T, C, count, bias_shift, gamma, beta, eps, momentum, running_mean, running_var,
