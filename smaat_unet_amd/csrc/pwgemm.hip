@@ -14,6 +14,7 @@
 // (cols), so that for a fixed accumulator register the 32 lanes of a half-wave hold 32
 // consecutive pixels of one output channel -> every global store is a full 128 B row.
 #include "common.h"
+#include <cstdlib>
 #include <stdlib.h>
 
 #define KC 16       // contraction rows staged per chunk
@@ -1628,7 +1629,18 @@ int smaat_wgrad_num_splits_impl(int N, int P, int M, int K) {
     const int total = N * ceil_div(P, 64);
     const int mt = (M > 64) ? 128 : 64;
     const int ntile = ceil_div(M, mt) * ceil_div(K, 128);
-    int ns = ceil_div(1024, ntile);
+    // Workgroups per launch = ns * ntile; every workgroup writes one partial tile (32-64 KB) that the row reduction reads
+    // back, so fewer, longer workgroups are cheaper as long as the chip stays full: one workgroup per CU (256), and at
+    // least 8 pixel splits per tile (measured per layer, profiles/r2/wgrad_splits_r2u.txt: 5.73 -> 5.10 ms per step
+    // against the round-1 target of 1024 workgroups).
+    static int target = -1;
+    if (target < 0) {
+        const char* e = getenv("SMAAT_WGRAD_WGS");
+        target = e ? atoi(e) : 256;
+        if (target < 8) target = 8;
+    }
+    int ns = ceil_div(target, ntile);
+    if (ns < 8) ns = 8;
     if (ns > total) ns = total;
     if (ns < 1) ns = 1;
     return ns;
