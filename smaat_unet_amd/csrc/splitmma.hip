@@ -612,9 +612,13 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
     static_assert(NCW == 4 || NCW == 8, "4 or 8 consumer waves");
     static_assert((PT * 2) % NPT == 0, "producer mapping");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int STSZ = BN_STAT_FLOATS(WPX, COT);
-    float* stat = (float*)(lds + 2 * BUFSZ);  // [2][STSZ]: per item parity, [WPX][3][COT] wave partials + [8] wave pixel counts
-    float* biasl = stat + 2 * STSZ;  // [4][COT]: bias of the channel tile of item k in slot k & 3
+    // LDS budget: two workgroups per CU need <= 80 KB each.  The 128 x 128 configuration is at 73.7 KB of operand
+    // buffers + 2 KB of bias slots; the statistics area is [2][WPX][3][COT] floats = 6 KB and nothing else (the wave
+    // pixel counts are recomputed from the tile index instead of being exchanged through LDS: with them the block
+    // was 64 bytes over the limit and ran alone on its CU), and it is only allocated when partials are requested.
+    constexpr int STSZ = WPX * 3 * COT;
+    float* stat = (float*)(lds + 2 * BUFSZ);  // [2][STSZ]: per item parity, [WPX][3][COT] wave partials
+    float* biasl = stat + (a.part ? 2 * STSZ : 0);  // [4][COT]: bias of the channel tile of item k in slot k & 3
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -810,9 +814,18 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
         const int boff = NT * APL + ((wpx * PXT) * 32 + l31) * BROW + half * 16;
         auto flush = [&](int par, int ptg, int co0) __attribute__((always_inline)) {  // merge the WPX waves' partials of a finished item
             const float* sp = stat + par * STSZ;
+            int nwv[WPX];  // valid pixels per wave column of that tile (flattened tiles: a prefix)
+            {
+                const int tl_ = ptg % a.tiles_per_img;
+#pragma unroll
+                for (int w = 0; w < WPX; ++w) {
+                    const int v = a.P - (tl_ * PT + w * PXT * 32);
+                    nwv[w] = v < 0 ? 0 : (v > PXT * 32 ? PXT * 32 : v);
+                }
+            }
             for (int col = tid; col < COT; col += NCT) {
                 float mean, m2, cnt;
-                bn_tile_combine<WPX>(sp, (const int*)(sp + WPX * 3 * COT), COT, col, mean, m2, cnt);
+                bn_tile_combine<WPX>(sp, nwv, COT, col, mean, m2, cnt);
                 const int m = co0 + col;
                 if (m < a.M) {
                     a.part[((long)0 * a.slots + ptg) * a.M + m] = mean;
@@ -896,10 +909,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
             }
             if (a.part) {
                 float* sb = stat + (k & 1) * STSZ;
-                int nw = a.P - (p0 + wpx * PXT * 32);  // flattened tiles: the valid pixels are a prefix
-                nw = nw < 0 ? 0 : (nw > PXT * 32 ? PXT * 32 : nw);
                 bn_wave_partials<CT, PXT>(acc, pval, l31, half, sb + wpx * 3 * COT + wco * CT * 32, COT, 0);
-                if (lane == 0) ((int*)(sb + WPX * 3 * COT))[wpx] = nw;
                 prev_ptg = ptg;
                 prev_co0 = co0;
             }
@@ -930,7 +940,7 @@ static int launch_pw_split_cfg(PwSplitArgs& a, hipStream_t st) {
     // 32-bit buffer offset with bit 31 as the "dropped" marker: images of 2 GiB and more (and SMAAT_PWS_CFG=16,
     // for A/B timing) take the one-tile-per-workgroup kernel.
     if (!(pws_cfg() & 16) && (long)(a.M + COT) * a.P * 4 < (1L << 31)) {
-        const size_t lds = (size_t)2 * NT * (COT + PT) * BROW + sizeof(float) * (2 * BN_STAT_FLOATS(WPX, COT) + 4 * COT);
+        const size_t lds = (size_t)2 * NT * (COT + PT) * BROW + sizeof(float) * ((a.part ? 2 * WPX * 3 * COT : 0) + 4 * COT);
         constexpr auto kern = k_pw_split_p<WCO, CT, WPX, PXT, NPT, NT>;
         int rc = ensure_lds_s<kern>(lds);
         if (rc) return rc;
