@@ -239,10 +239,10 @@ def _fused_dw_ok(n, h, w, kpl, cout, keep_y, cin=0):
     if not keep_y or FUSE_DW_SPLIT == "train":
         return cout <= 128
     # training keeps the depthwise tensor for the weight gradient: the kernel then writes it as a side output.
-    # Measured per layer on MI355X (profiles/r2/layer_bench_fused_r2l.txt): that wins where one 64-row output tile
-    # covers Cout and the reduction is long enough to amortise the tile prologue (288^2: 1.50 vs 1.80 ms at K = 256,
-    # 0.94 vs 0.99 ms at K = 128) and loses where the depthwise stage is recomputed per output tile (Cout = 128).
-    return cout <= 64 and cin * kpl >= 128 and h * w >= 65536
+    # Measured per layer on MI355X (profiles/r2/layer_bench_r2v.txt): that wins where one 64-row output tile covers
+    # Cout and the reduction is long enough to amortise the tile prologue (288^2, K = 256: 1.52 vs 1.73 ms), is a tie
+    # at K = 128 (0.99 vs 0.97 ms) and loses where the depthwise stage is recomputed per output tile (Cout = 128).
+    return cout <= 64 and cin * kpl >= 256 and h * w >= 65536
 
 
 def _dsconv_fwd_fused(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, in_shift=None, want_y=False):
