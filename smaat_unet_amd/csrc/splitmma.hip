@@ -940,6 +940,8 @@ static int launch_pw_split_cfg(PwSplitArgs& a, hipStream_t st) {
     // 32-bit buffer offset with bit 31 as the "dropped" marker: images of 2 GiB and more (and SMAAT_PWS_CFG=16,
     // for A/B timing) take the one-tile-per-workgroup kernel.
     if (!(pws_cfg() & 16) && (long)(a.M + COT) * a.P * 4 < (1L << 31)) {
+        static_assert((size_t)2 * NT * (COT + PT) * BROW + sizeof(float) * (2 * WPX * 3 * COT + 4 * COT) <= 80 * 1024,
+                      "k_pw_split_p: two workgroups per CU (160 KB of LDS) -- round 2 lost 1.5 ms per step to 64 bytes");
         const size_t lds = (size_t)2 * NT * (COT + PT) * BROW + sizeof(float) * ((a.part ? 2 * WPX * 3 * COT : 0) + 4 * COT);
         constexpr auto kern = k_pw_split_p<WCO, CT, WPX, PXT, NPT, NT>;
         int rc = ensure_lds_s<kern>(lds);
