@@ -218,7 +218,9 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const float* __restrict_
 #ifndef DWR_BWD_WAVES
 #define DWR_BWD_WAVES 4  // 5 needs spills (18 VGPRs) and runs 1.3x slower; profiles/r2/dw_bench_r2n
 #endif
-template <int KPL>
+// RP: the variant that also emits rpart keeps the raw (pre-BatchNorm) rows of the three open lines in registers: the
+// counter passes showed the re-load of the completed row as +25 % HBM fetch (it had left the L2 two steps later).
+template <int KPL, bool RP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAVES, DWR_BWD_WAVES))) void k_dw3x3_bwd_rows(const float* __restrict__ x, long x_bs,
                                                          const float* __restrict__ dy, long dy_bs,
                                                          const float* __restrict__ w_dw, float* __restrict__ dx,
@@ -261,13 +263,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAV
     {
         const int r1 = !active ? r0 : ((r0 + g.BH < g.H) ? r0 + g.BH : g.H);  // band = rows [r0, r1); empty when masked
         float dxa[3][4], xc[3][4];
+        float zraw[RP ? 3 : 1][4];
         float d[KPL][6];
         DwrRaw raw[KPL];
         float4 xn;
 #pragma unroll
         for (int s_ = 0; s_ < 3; ++s_)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) dxa[s_][c] = xc[s_][c] = 0.f;
+            for (int c = 0; c < 4; ++c) {
+                dxa[s_][c] = xc[s_][c] = 0.f;
+                if (RP) zraw[s_][c] = 0.f;  // (a slot that was never opened still enters 0 * (z - mean) * invstd)
+            }
         // step k: rho = r0 - 1 + k;  rows rho - 1, rho, rho + 1 live in slots k % 3, (k + 1) % 3, (k + 2) % 3
         constexpr int UN = 3;
         for (int k0 = 0; k0 < g.BH + 2; k0 += UN) {
@@ -293,6 +299,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAV
                         xc[sc_][1] = in ? dwr_act(zv.y, aff, asc, ash) : 0.f;
                         xc[sc_][2] = in ? dwr_act(zv.z, aff, asc, ash) : 0.f;
                         xc[sc_][3] = in ? dwr_act(zv.w, aff, asc, ash) : 0.f;
+                        if (RP) {
+                            zraw[sc_][0] = zv.x;
+                            zraw[sc_][1] = zv.y;
+                            zraw[sc_][2] = zv.z;
+                            zraw[sc_][3] = zv.w;
+                        }
 #pragma unroll
                         for (int c = 0; c < 4; ++c) dxa[sc_][c] = 0.f;
                     }
@@ -321,16 +333,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAV
                     const bool fin = rd >= r0 && rd < r1;
                     if (dxp && fin)
                         *(float4*)(dxp + (long)rd * g.W) = make_float4(dxa[sa][0], dxa[sa][1], dxa[sa][2], dxa[sa][3]);
-                    if (rpart) {
-                        // the pre-BatchNorm values of the completed row again (L1 / L2 resident; loaded here, not at
-                        // the start of the step, to keep four registers free during the accumulation)
-                        const float4 zfin = dwr_issue4(xp, rd, g.H, g.W);
-                        const float zr[4] = {zfin.x, zfin.y, zfin.z, zfin.w};
+                    if (RP) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             const float gg = (fin && xc[sa][c] > 0.f) ? dxa[sa][c] : 0.f;
                             r1s += gg;
-                            r2s = fmaf(gg, (zr[c] - rmean) * rinvstd, r2s);
+                            r2s = fmaf(gg, (zraw[sa][c] - rmean) * rinvstd, r2s);
                         }
                     }
                 }
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAV
             const float v = wave_sum_l63(accw[j][k]);
             if (lane == 63) part[(row * Cin * KPL + ci * KPL + j) * 10 + k] = v;
         }
-    if (rpart) {
+    if (RP) {
         const float v1 = wave_sum_l63(r1s), v2 = wave_sum_l63(r2s);
         const long rows = (long)N * g.wpp;
         if (lane == 63) {
@@ -397,15 +405,16 @@ int launch_dw3x3_bwd_rows(const float* x, long x_bs, const float* dy, long dy_bs
     const DwrGeom g = dw_rows_geom(nplanes, H, W);
     if (g.wpp == 0) return -2;
     const dim3 grid((unsigned)(((long)nplanes * g.wpp + 3) / 4)), blk(256);
-#define DWR_GO(K)                                                                                                     \
-    hipLaunchKernelGGL(k_dw3x3_bwd_rows<K>, grid, blk, 0, st, x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, part, Cin, nplanes, N, \
-                       g, bn_mean, bn_invstd, rpart, in_scale, in_shift)
-    if (kpl == 1)
-        DWR_GO(1);
-    else if (kpl == 2)
-        DWR_GO(2);
-    else
+#define DWR_GO(K, R)                                                                                                 \
+    hipLaunchKernelGGL((k_dw3x3_bwd_rows<K, R>), grid, blk, 0, st, x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, part, Cin, nplanes, \
+                       N, g, bn_mean, bn_invstd, rpart, in_scale, in_shift)
+    if (kpl == 1) {
+        if (rpart) DWR_GO(1, true); else DWR_GO(1, false);
+    } else if (kpl == 2) {
+        if (rpart) DWR_GO(2, true); else DWR_GO(2, false);
+    } else {
         return -2;
+    }
 #undef DWR_GO
     return (int)hipGetLastError();
 }
