@@ -236,6 +236,15 @@ int smaat_pointwise_fwd_split(const float* x, long x_bs, const void* planes, con
  *      weight gradient).  Returns -2 when the shape is not handled (kernels_per_layer != 2, W % 16 != 0, H < 4 ...):
  *      run smaat_dw3x3_fwd + smaat_pointwise_fwd_split instead.  smaat_dsconv_split_num_slots returns 0 for such shapes.
  */
+/* smaat_pointwise_fwd_split_act with the contraction cut into K slices when the problem has too few tiles to fill the
+ * chip (inference at batch 1: the deep layers are a few dozen serial chunk chains): the slices run as virtual images of
+ * the same kernel into ws [N][S][M][P] and a second kernel adds them in a fixed order, the bias and the ReLU.
+ * ws: smaat_pointwise_splitk_ws_floats(...) floats (0 = no split for this shape; ws may then be null).  Needs dense x
+ * (x_bs == Cin*H*W); otherwise, and without ws, it is smaat_pointwise_fwd_split_act. */
+int smaat_pointwise_splitk_ws_floats(int N, int Cin, int M, int H, int W);
+int smaat_pointwise_fwd_split_act_k(const float* x, long x_bs, const void* planes, const float* bias, float* out,
+                                    long out_bs, float* ws, int N, int Cin, int M, int H, int W, int relu_out,
+                                    void* stream);
 int smaat_dsconv_split_num_slots(int N, int H, int W);
 int smaat_dsconv_fwd_split(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
                            const float* b_dw, const void* planes, const float* b_pw, float* z, long z_bs, float* part,

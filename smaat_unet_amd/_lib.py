@@ -78,6 +78,8 @@ SIGNATURES = {
     "smaat_dsconv_fwd_act": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P],
     "smaat_dsconv_fwd_split_act": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P],
     "smaat_pointwise_fwd_split_act": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "smaat_pointwise_splitk_ws_floats": [_I, _I, _I, _I, _I],
+    "smaat_pointwise_fwd_split_act_k": [_P, _L, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P],
     "smaat_precip_metrics_ws_bytes": [_L],
     "smaat_precip_metrics_update": [_P, _P, _L, _I, _F, _F, _I, _P, _P, _P, _P],
 }

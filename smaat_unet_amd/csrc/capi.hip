@@ -89,6 +89,9 @@ int dsconv_split_num_slots(int N, int H, int W);
 int split_mode();
 int set_split_mode(int m);
 int launch_split_planes(const float* w, int R, int C, unsigned short* out, hipStream_t st, int src_t = 0);
+int pw_splitk_slices(int N, int Cin, int M, int P);
+int launch_pw_split_k(PwSplitArgs& a, float* ws, int S, hipStream_t st);
+int pws_persistent_ok(int M, int P);
 int pw_split_num_slots(int N, int P);
 long precip_metrics_ws_bytes(long n);                                                    // metrics.hip
 int launch_precip_metrics_update(const float* preds, const float* target, long n, int batch, float factor, float thr,
@@ -370,6 +373,25 @@ int smaat_pointwise_fwd_split(const float* x, long x_bs, const void* planes, con
 int smaat_pointwise_fwd_split_act(const float* x, long x_bs, const void* planes, const float* bias, float* out,
                                   long out_bs, int N, int Cin, int M, int H, int W, int relu_out, void* stream) {
     return pointwise_fwd_split_impl(x, x_bs, planes, bias, out, out_bs, nullptr, N, Cin, M, H, W, relu_out, stream);
+}
+int smaat_pointwise_splitk_ws_floats(int N, int Cin, int M, int H, int W) {
+    const int S = pw_splitk_slices(N, Cin, M, H * W);
+    return S > 1 ? (int)((long)N * S * M * H * W) : 0;
+}
+int smaat_pointwise_fwd_split_act_k(const float* x, long x_bs, const void* planes, const float* bias, float* out,
+                                    long out_bs, float* ws, int N, int Cin, int M, int H, int W, int relu_out,
+                                    void* stream) {
+    if (N < 1 || Cin < 1 || M < 1 || H < 1 || W < 1) return -1;
+    const int S = (ws && x_bs == (long)Cin * H * W && (out_bs & 3) == 0 && ((((uintptr_t)out) & 15) == 0) &&
+                   ((((uintptr_t)ws) & 15) == 0) && pws_persistent_ok(M, H * W))
+                      ? pw_splitk_slices(N, Cin, M, H * W)
+                      : 1;
+    if (S == 1) return pointwise_fwd_split_impl(x, x_bs, planes, bias, out, out_bs, nullptr, N, Cin, M, H, W, relu_out, stream);
+    PwSplitArgs a{};
+    a.out_floor = relu_out ? 0.f : NEG_INF;
+    a.x = x; a.x_bs = x_bs; a.planes = (const unsigned short*)planes; a.bias = bias; a.out = out; a.out_bs = out_bs;
+    a.part = nullptr; a.N = N; a.Cin = Cin; a.Cp = (Cin + 15) & ~15; a.M = M; a.P = H * W;
+    return launch_pw_split_k(a, ws, S, ST);
 }
 int smaat_dsconv_split_num_slots(int N, int H, int W) { return dsconv_split_num_slots(N, H, W); }
 static int dsconv_fwd_split_impl(const float* x, long x_bs, const float* in_scale, const float* in_shift,

@@ -300,6 +300,11 @@ struct PwSplitArgs {
     int N, Cin, Cp, M, P, nco, tiles_per_img, T, slots;
     int dbg;  // reserved (0)
     float out_floor;  // epilogue: out = max(acc + bias, out_floor); -inf = plain, 0 = fused ReLU (inference path)
+    // split-K (inference at small batch): image v = n * ksplit + s reads the s-th slice of Cin channels of x (x_bs = slice
+    // stride) and of the weight planes (planes_bs elements per slice) and writes partial image v; ksplit = 1, planes_bs = 0
+    // otherwise
+    int ksplit;
+    long planes_bs;
 };
 
 #define HIP_RET(expr)                          \

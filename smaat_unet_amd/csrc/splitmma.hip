@@ -670,6 +670,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
         // prefetch cursor: (item, chunk) + the per-item address bases
         int pf_item = 0, pf_ch = 0;
         const float* pf_x = a.x;
+        const unsigned short* pf_pl = a.planes;  // weight planes of the item's K slice
         int pf_bp[NBT], pf_bidx = 0;
         unsigned pf_bvo[NBT], pf_avo[NAT];  // per-lane byte offsets of the scalar-base (saddr) loads
         long pf_as[NAT];
@@ -680,6 +681,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
             const int ptg = xcd * tpx + j;
             const int n = ptg / a.tiles_per_img, tl = ptg - n * a.tiles_per_img;
             pf_x = a.x + (long)n * a.x_bs;
+            pf_pl = a.planes + (a.ksplit > 1 ? (long)(n % a.ksplit) * a.planes_bs : 0L);
             pf_bidx = cot * COT + ptid % COT;
             pf_bidx = pf_bidx < a.M ? pf_bidx : a.M - 1;
 #pragma unroll
@@ -728,7 +730,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
                     }
             }
             {
-                const unsigned short* sa = a.planes + (long)k0 * 3 * a.M;
+                const unsigned short* sa = pf_pl + (long)k0 * 3 * a.M;
 #pragma unroll
                 for (int u = 0; u < NAT; ++u) {
                     const unsigned short* sau = sa + (ASIMPLE ? u * aplane : 0);
@@ -971,6 +973,12 @@ static int pws_cfg() {  // SMAAT_PWS_CFG: tuning experiments (0 = default)
     return v;
 }
 
+// 1 when launch_pw_split takes the persistent kernel for this shape (the only one that knows about K slices)
+int pws_persistent_ok(int M, int P) {
+    const int COT = M > 64 ? 128 : 64;
+    return (!(pws_cfg() & 16) && (long)(M + COT) * P * 4 < (1L << 31)) ? 1 : 0;
+}
+
 int launch_pw_split(PwSplitArgs& a, hipStream_t st) {
     // 128-pixel tiles everywhere: two workgroups per CU overlap each other's fill/drain and barriers
     // (measured faster than 256-pixel tiles with one workgroup per CU, than 256 x 128 tiles with eight
@@ -981,4 +989,73 @@ int launch_pw_split(PwSplitArgs& a, hipStream_t st) {
     }
     if (a.M > 64) return launch_pw_split_cfg<2, 2, 2, 2, 256>(a, st);  // 128 x 128
     return launch_pw_split_cfg<1, 2, 4, 1, 256>(a, st);                // 64 x 128
+}
+
+// ---- split-K for the inference GEMMs at small batch --------------------------------------------------------------
+// A deep layer at batch 1 has a few dozen (pixel tile, channel tile) items, each a serial chain of up to 128
+// contraction chunks: the chip idles and the kernel time is the chain's latency (batch-1 trace: 10 launches of 37 us).
+// The contraction is cut into S slices that run as S "virtual images" of the same persistent kernel (x slice = a
+// channel offset, weight-plane slice = planes_bs) into a partial buffer [N][S][M][P]; this kernel adds the slices in a
+// fixed order, the bias and the ReLU.
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ ws, int S, const float* __restrict__ bias,
+                                                       float* __restrict__ out, long out_bs, int M, int P, float out_floor,
+                                                       long total4) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const long per_img = (long)M * P / 4;
+    const int n = (int)(i / per_img);
+    const long e = (i - (long)n * per_img) * 4;  // element of the [M][P] image
+    const int m = (int)(e / P);
+    const float* w0 = ws + ((long)n * S) * M * P + e;
+    float4 acc = *(const float4*)w0;
+    for (int s = 1; s < S; ++s) {
+        const float4 v = *(const float4*)(w0 + (long)s * M * P);
+        acc.x += v.x;
+        acc.y += v.y;
+        acc.z += v.z;
+        acc.w += v.w;
+    }
+    const float b = bias ? bias[m] : 0.f;
+    acc.x = fmaxf(acc.x + b, out_floor);
+    acc.y = fmaxf(acc.y + b, out_floor);
+    acc.z = fmaxf(acc.z + b, out_floor);
+    acc.w = fmaxf(acc.w + b, out_floor);
+    *(float4*)(out + (long)n * out_bs + e) = acc;
+}
+
+// number of K slices for a [N][Cin][P] -> [N][M][P] GEMM (1 = no split): fill ~512 workgroup slots, keep >= 8 chunks of
+// 16 channels per slice, at most 8 slices
+int pw_splitk_slices(int N, int Cin, int M, int P) {
+    if ((Cin & 15) != 0 || (P & 3) != 0) return 1;
+    const int cot = M > 64 ? 128 : 64;
+    const long items = (long)N * ((P + 127) / 128) * ((M + cot - 1) / cot);
+    int s = 1;
+    while (s < 8 && items * (s * 2) <= 512 && (Cin / 16) % (s * 2) == 0 && Cin / 16 / (s * 2) >= 8) s *= 2;
+    return s;
+}
+
+int launch_pw_split_k(PwSplitArgs& a, float* ws, int S, hipStream_t st) {
+    // a: the un-split problem (N, Cin, dense x: x_bs == Cin * P); out / out_bs / bias / out_floor of the final result
+    float* out = a.out;
+    const long out_bs = a.out_bs;
+    const float* bias = a.bias;
+    const float floor_ = a.out_floor;
+    const int N = a.N;
+    a.ksplit = S;
+    a.planes_bs = (long)(a.Cin / S / 16) * 3 * a.M * 16;
+    a.x_bs = (long)(a.Cin / S) * a.P;
+    a.Cin = a.Cin / S;
+    a.Cp = a.Cin;
+    a.N = N * S;
+    a.out = ws;
+    a.out_bs = (long)a.M * a.P;
+    a.bias = nullptr;
+    a.part = nullptr;
+    a.out_floor = -__builtin_inff();
+    int rc = launch_pw_split(a, st);
+    if (rc) return rc;
+    const long total4 = (long)N * a.M * a.P / 4;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, ws, S, bias, out, out_bs,
+                       a.M, a.P, floor_, total4);
+    return (int)hipGetLastError();
 }

@@ -632,9 +632,12 @@ def dsconv_folded(x, w_dw, b_dw, fold, kpl, relu_out=True):
         # GEMM-sized layers: depthwise kernel + persistent split GEMM (2 launches) beat the f32-MFMA fused kernel
         y = _dw3x3_fwd_raw(x, w_dw, b_dw, kpl)
         if y is not None:
-            _lib.check(L.smaat_pointwise_fwd_split_act(_ptr(y), cin * kpl * h * w, _ptr(fold["planes"]), _ptr(fold["b"]),
-                                                       _ptr(z), cout * h * w, n, cin * kpl, cout, h, w, ro, _stream(x)),
-                       "smaat_pointwise_fwd_split_act")
+            # (few tiles, long contraction -- batch 1 on the deep levels: the library cuts the contraction into slices)
+            wsn = L.smaat_pointwise_splitk_ws_floats(n, cin * kpl, cout, h, w)
+            ws = _new(x, wsn) if wsn > 0 else None
+            _lib.check(L.smaat_pointwise_fwd_split_act_k(_ptr(y), cin * kpl * h * w, _ptr(fold["planes"]), _ptr(fold["b"]),
+                                                         _ptr(z), cout * h * w, _ptr(ws), n, cin * kpl, cout, h, w, ro,
+                                                         _stream(x)), "smaat_pointwise_fwd_split_act_k")
             return z
     _lib.check(L.smaat_dsconv_fwd_act(_ptr(x), x_bs, None, None, _ptr(w_dw), _ptr(b_dw), _ptr(fold["wt"]),
                                       _ptr(fold["b"]), _ptr(z), cout * h * w, n, cin, kpl, cout, h, w, ro, _stream(x)),

@@ -184,6 +184,12 @@ class EmuLib:
             zz[:] = np.maximum(zz, 0)
         return rc
 
+    def smaat_pointwise_splitk_ws_floats(self, N, Cin, M, H, W):
+        return 0
+
+    def smaat_pointwise_fwd_split_act_k(self, x, x_bs, planes, bias, out, out_bs, ws, N, Cin, M, H, W, relu_out, stream):
+        return self.smaat_pointwise_fwd_split_act(x, x_bs, planes, bias, out, out_bs, N, Cin, M, H, W, relu_out, stream)
+
     def smaat_pointwise_fwd_split_act(self, x, x_bs, pl, bias, out, out_bs, N, Cin, M, H, W, relu_out, stream):
         rc = self.smaat_pointwise_fwd_split(x, x_bs, pl, bias, out, out_bs, None, N, Cin, M, H, W, stream)
         if rc == 0 and relu_out:

@@ -563,6 +563,33 @@ def test_split_planes_transposed(shape):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("shape", [(1, 512, 256, 36, 36), (1, 1024, 512, 18, 18), (2, 256, 256, 36, 36),
+                                   (1, 2048, 512, 36, 36), (1, 64, 64, 32, 32), (1, 256, 128, 72, 72)])
+def test_pointwise_split_k_slices(shape):
+    """inference GEMM with the contraction cut into K slices == the un-split kernel (same products, another order of
+    the f32 sums) on the shapes where the library splits, identical where it does not"""
+    L, dev = _lib.get(), torch.device("cuda:0")
+    N, C, M, H, W = shape
+    x = T(np.maximum(rnd(1, N, C, H, W), 0), dev)
+    w, b = T(rnd(2, M, C, scale=0.1), dev), T(rnd(3, M), dev)
+    pl = torch.empty((3, M, (C + 15) // 16 * 16), dtype=torch.int16, device=dev)
+    assert L.smaat_split_planes(P(w), M, C, P(pl), stream(dev)) == 0
+    ref = torch.full((N, M, H, W), float("nan"), device=dev)
+    assert L.smaat_pointwise_fwd_split_act(P(x), C * H * W, P(pl), P(b), P(ref), M * H * W, N, C, M, H, W, 1,
+                                           stream(dev)) == 0
+    nws = L.smaat_pointwise_splitk_ws_floats(N, C, M, H, W)
+    ws = torch.full((max(nws, 1),), float("nan"), device=dev)
+    out = torch.full((N, M, H, W), float("nan"), device=dev)
+    assert L.smaat_pointwise_fwd_split_act_k(P(x), C * H * W, P(pl), P(b), P(out), M * H * W, P(ws) if nws else None, N, C,
+                                             M, H, W, 1, stream(dev)) == 0
+    if nws == 0:
+        assert torch.equal(out, ref)
+    else:
+        assert rel(out.cpu().numpy(), ref.cpu().numpy()) < 1e-6
+    if shape[1] >= 512:
+        assert nws > 0  # the deep batch-1 layers are the ones this exists for
+
+
 def case_final_pool(L, dev, N, C, H, W, pad_c=0):
     """cbam_bwd_final + maxpool2 backward in one pass == the two separate kernels (bit for bit: same adds, same order)"""
     Pn = H * W
