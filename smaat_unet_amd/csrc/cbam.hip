@@ -265,25 +265,36 @@ __global__ __launch_bounds__(256) void k_cbam_mlp_sppool(const float* __restrict
         lm[c] = mx[(long)n * C + c];
     }
     __syncthreads();
-    for (int j = wave; j < Cr; j += 4) {
-        float pa = 0.f, pm = 0.f;
-        for (int c = lane; c < C; c += 64) {
-            const float w = w1[(long)j * C + c];
-            pa = fmaf(w, la[c], pa);
-            pm = fmaf(w, lm[c], pm);
-        }
-        pa = wave_sum_all(pa);
-        pm = wave_sum_all(pm);
-        if (lane == 0) {
-            ha[j] = fmaxf(pa + b1[j], 0.f);
-            hm[j] = fmaxf(pm + b1[j], 0.f);
+    // Shared MLP, recomputed by every block: at batch 1 its latency chains ARE the kernel on the deep levels (C = 512,
+    // Cr = 32: 128 KB of weights), so both layers are laid out for independent loads: a hidden unit is a dot product
+    // spread over 16 lanes (quarter wave) with all its loads issued before the DPP row sum, an output channel reads its
+    // Cr contiguous weights with the loop unrolled.
+    {
+        const int q16 = tid >> 4, l16 = tid & 15;  // 16 groups of 16 lanes
+        for (int j = q16; j < Cr; j += 16) {
+            float pa = 0.f, pm = 0.f;
+            const float* wr = w1 + (long)j * C;
+#pragma unroll 4
+            for (int c = l16; c < C; c += 16) {
+                const float w = wr[c];
+                pa = fmaf(w, la[c], pa);
+                pm = fmaf(w, lm[c], pm);
+            }
+            pa = row16_sum(pa);
+            pm = row16_sum(pm);
+            if (l16 == 0) {
+                ha[j] = fmaxf(pa + b1[j], 0.f);
+                hm[j] = fmaxf(pm + b1[j], 0.f);
+            }
         }
     }
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
         float oa = b2[c], om = b2[c];
+        const float* wr = w2 + (long)c * Cr;
+#pragma unroll 8
         for (int j = 0; j < Cr; ++j) {
-            const float w = w2[(long)c * Cr + j];
+            const float w = wr[j];
             oa = fmaf(w, ha[j], oa);
             om = fmaf(w, hm[j], om);
         }
