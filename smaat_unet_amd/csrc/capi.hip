@@ -37,7 +37,6 @@ int launch_pixel_shuffle2_fwd(const float*, long, const float*, float*, long, in
 int launch_pixel_shuffle2_bwd(const float*, long, float*, long, int, int, int, int, int, int, int, int, hipStream_t);
 int launch_dw3x3_bwd(const float*, long, const float*, long, const float*, float*, long, float*, int, int, int, int,
                      int, hipStream_t, const float*, const float*, float*, const float*, const float*);
-int launch_dw_split(const float*, int, float*, float*, hipStream_t);
 int dw_bwd_groups(int N, int Cin, int H, int W);
 int launch_dw_reduce_split(const float* part, int rows, int Cdw, float* dw, float* db, hipStream_t st);
 int dw3x3_strip_ok(int kpl, int H, int W);

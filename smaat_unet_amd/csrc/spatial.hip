@@ -685,19 +685,6 @@ __global__ __launch_bounds__(256, DWB_MINW) void k_dw3x3_bwd_strip(const float* 
     }
 }
 
-// split part[N][Cdw][10] (already reduced over N into tmp[Cdw][10]) into dW[Cdw][9], db[Cdw]
-__global__ __launch_bounds__(256) void k_dw_split(const float* __restrict__ tmp, int Cdw, float* __restrict__ dw,
-                                                  float* __restrict__ db) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= Cdw * 10) return;
-    const int o = i / 10, t = i - o * 10;
-    if (t < 9)
-        dw[o * 9 + t] = tmp[i];
-    else if (db)
-        db[o] = tmp[i];
-}
-
-// =====================================================================================
 static inline int cdivs(long a, long b) { return (int)((a + b - 1) / b); }
 
 int launch_maxpool2_fwd(const float* x, long x_bs, float* y, long y_bs, int N, int C, int H, int W, hipStream_t st) {
@@ -1183,7 +1170,3 @@ int launch_dw_reduce_split(const float* part, int rows, int Cdw, float* dw, floa
     return (int)hipGetLastError();
 }
 
-int launch_dw_split(const float* tmp, int Cdw, float* dw, float* db, hipStream_t st) {
-    hipLaunchKernelGGL(k_dw_split, dim3(cdivs((long)Cdw * 10, 256)), dim3(256), 0, st, tmp, Cdw, dw, db);
-    return (int)hipGetLastError();
-}
