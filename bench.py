@@ -242,7 +242,10 @@ def main():
     model = (S.SmaAt_UNet(3, 21) if voc else S.SmaAt_UNet(12, 1)).to(dev).train()
     ddp = FlatGradAllReduce(model, world_size=world)  # persistent flat gradient buffer, bucketed async all-reduce
     ddp.broadcast_parameters()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, foreach=True)
+    # stock torch Adam; "fused" = torch's single-kernel multi-tensor implementation of the same update
+    adam_impl = os.environ.get("SMAAT_ADAM", "foreach")
+    opt = (torch.optim.Adam(model.parameters(), lr=1e-3, fused=True) if adam_impl == "fused"
+           else torch.optim.Adam(model.parameters(), lr=1e-3, foreach=True))
     if voc:  # ImageNet-normalised-like images, integer class maps
         g = torch.Generator().manual_seed(1234 + rank)
         x = torch.randn(args.batch, 3, args.size, args.size, generator=g).to(dev)
