@@ -192,7 +192,8 @@ def case_dw_bwd(L, dev, N, Cin, kpl, H, W, need_dx=True):
                                    (2, 8, 2, 4, 4), (1, 8, 2, 2, 2), (1, 3, 4, 8, 12), (2, 4, 2, 72, 72),
                                    (1, 5, 2, 10, 12), (1, 2, 2, 50, 64), (1, 2, 1, 21, 48),
                                    # row-streaming kernels: 4 / 6 / 40 float4 columns, planes over several waves and blocks
-                                   (3, 64, 2, 16, 16), (2, 96, 2, 32, 24), (1, 3, 2, 64, 160), (3, 130, 1, 16, 12)])
+                                   (3, 64, 2, 16, 16), (2, 96, 2, 32, 24), (1, 3, 2, 64, 160), (3, 130, 1, 16, 12),
+                                   (1, 2, 2, 1, 8), (1, 3, 2, 3, 4), (2, 3, 1, 2, 12)])
 def test_dw3x3_bwd(shape):
     both(case_dw_bwd, *shape, tol=2e-5)
     both(case_dw_bwd, *shape, need_dx=False, tol=2e-5)
@@ -310,6 +311,8 @@ def case_dsconv_fwd_split(L, dev, N, Cin, Cout, H, W, aff=False, pad_c=0, bias=T
     (2, 12, 64, 288, 288),    # inc.0
     (1, 128, 64, 288, 288),   # up4.0: 16 chunks
     (2, 64, 128, 144, 144),   # down1.0: W = 144 -> 8 x 16 tiles, two channel tiles
+    (1, 40, 64, 32, 32),      # 5 chunks: the 3-deep load groups wrap with a tail
+    (1, 2, 3, 4, 32),         # ONE partial chunk, one tile
 ])
 def test_dsconv_fwd_split(shape):
     both(case_dsconv_fwd_split, *shape, tol=2e-6)

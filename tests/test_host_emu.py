@@ -342,6 +342,43 @@ def test_matrix_path_policy_training_vs_inference():
     assert c.get("smaat_dsconv_fwd", 0) == 2, c
 
 
+def test_batchnorm_counters_batched_per_forward():
+    """num_batches_tracked of every train-mode BatchNorm goes up by exactly one per forward (reference:
+    torch.nn.BatchNorm2d.forward); inside the network's forward the 23 increments are ONE multi-tensor add; a
+    BatchNorm with momentum=None (cumulative average) needs the value at once and is not deferred; eval does not count"""
+    from smaat_unet_amd import layers
+    torch.manual_seed(0)
+    m = S.SmaAt_UNet(3, 2).train()
+    m.inc.double_conv[1].momentum = None  # cumulative moving average for one layer
+    x = torch.rand(1, 3, 16, 16)
+    calls = []
+    orig = torch._foreach_add_
+
+    def spy(tensors, *a, **k):
+        calls.append(len(tensors))
+        return orig(tensors, *a, **k)
+
+    torch._foreach_add_ = spy
+    try:
+        for step in range(1, 4):
+            m(x)
+            counts = {int(b) for n, b in m.named_buffers() if n.endswith("num_batches_tracked")}
+            assert counts == {step}, counts
+    finally:
+        torch._foreach_add_ = orig
+    nbn = sum(1 for n, _ in m.named_buffers() if n.endswith("num_batches_tracked"))
+    assert calls == [nbn - 1] * 3  # one launch per forward; the momentum=None layer incremented on its own
+    # cumulative average: running_mean after 3 steps of the same batch == that batch's mean (factor 1/k each step)
+    m.eval()
+    with torch.no_grad():
+        m(x)
+    assert {int(b) for n, b in m.named_buffers() if n.endswith("num_batches_tracked")} == {3}
+    # a block used on its own (no network forward around it) still counts
+    blk = S.DoubleConvDS(3, 8).train()
+    blk(x)
+    assert int(blk.double_conv[1].num_batches_tracked) == 1 and getattr(layers._TLS, "pending", None) is None
+
+
 def test_no_cpu_fallback():
     emu_backend.uninstall()
     m = S.OutConv(4, 2)
