@@ -109,6 +109,22 @@ int smaat_bn_eval_coefs(const float* running_mean, const float* running_var, con
 int smaat_affine_act(const float* z, long z_bs, const float* scale, const float* shift, float* y, long y_bs, int N,
                      int C, int P, int relu, void* stream);
 int smaat_plane_num_slots(int N, int P);
+/* ---- OutConv with ONE output channel fused with the BatchNorm2d + ReLU in front of it: the head of SmaAt_UNet(12, 1)
+ *      (reference models/SmaAt_UNet.py:38,56: self.outc = OutConv(64, n_classes) on the output of up4, whose last two
+ *      layers are unet_parts_depthwise_separable.py:34-35).  The 64-channel block output and its gradient are never
+ *      materialised:
+ *   smaat_outconv1_fwd        out[n][p] = b + sum_c w[c] * relu(z[n][c][p] * scale[c] + shift[c])      (out_bs = P)
+ *   smaat_bn_bwd_reduce_head  like smaat_bn_bwd_reduce with dy[n][c][p] = w[c] * dlog[n][p] formed on the fly, plus the
+ *                             convolution's weight gradient: part [3][slots][C], part[2] = sum dlog * relu(bn(z))
+ *   smaat_bn_bwd_apply_head   like smaat_bn_bwd_apply with the same on-the-fly dy                                   */
+int smaat_outconv1_fwd(const float* z, long z_bs, const float* scale, const float* shift, const float* w, const float* b,
+                       float* out, long out_bs, int N, int C, int P, void* stream);
+int smaat_bn_bwd_reduce_head(const float* dlog, long dlog_bs, const float* w, const float* z, long z_bs,
+                             const float* scale, const float* shift, const float* mean, const float* invstd, float* part,
+                             int N, int C, int P, void* stream);
+int smaat_bn_bwd_apply_head(const float* dlog, long dlog_bs, const float* w, const float* z, long z_bs,
+                            const float* scale, const float* shift, const float* mean, const float* invstd,
+                            const float* coef, float* dz, long dz_bs, int N, int C, int P, void* stream);
 int smaat_bn_bwd_reduce(const float* dy, long dy_bs, const float* z, long z_bs, const float* scale,
                         const float* shift, const float* mean, const float* invstd, float* part, int N, int C, int P,
                         int relu, void* stream);

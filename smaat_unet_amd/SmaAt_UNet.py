@@ -121,9 +121,24 @@ class UNetDSFamily(nn.Module):
             h = downs[lvl].maxpool_conv[1](pooled)
         if cbams[4] is not None:
             h = cbams[4](h)
-        for up, cat in zip(ups, reversed(cats)):
+        head = self._fused_head()
+        for i, (up, cat) in enumerate(zip(ups, reversed(cats))):
+            if head is not None and i == len(ups) - 1:
+                return up.forward_into(h, cat, head=head)  # last decoder block + OutConv as one node
             h = up.forward_into(h, cat)
         return self.outc(h)
+
+    FUSE_HEAD = True
+
+    def _fused_head(self):
+        """the OutConv's nn.Conv2d when it has ONE output channel and can be fused with the BatchNorm + ReLU in front of
+        it (training path: the 64-channel block output and its gradient are never materialised), else None"""
+        import torch
+        conv = self.outc.conv
+        if (not self.FUSE_HEAD or not torch.is_grad_enabled() or conv.out_channels != 1 or conv.kernel_size != (1, 1)
+                or any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks for m in self.outc.modules())):
+            return None
+        return conv
 
     def _forward_modular(self, x):
         """module-by-module wiring (what the reference spells out statement by statement)"""

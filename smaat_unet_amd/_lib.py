@@ -40,6 +40,9 @@ SIGNATURES = {
     "smaat_bn_bwd_reduce": [_P, _L, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "smaat_bn_bwd_finalize": [_P, _I, _I, _D, _P, _P, _P, _P, _P, _P],
     "smaat_bn_bwd_apply": [_P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "smaat_outconv1_fwd": [_P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "smaat_bn_bwd_reduce_head": [_P, _L, _P, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "smaat_bn_bwd_apply_head": [_P, _L, _P, _P, _L, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "smaat_reduce_rows": [_P, _I, _L, _P, _F, _P],
     "smaat_channel_sum": [_P, _L, _I, _I, _I, _P, _P, _P],
     "smaat_copy_planes": [_P, _L, _P, _L, _I, _L, _I, _P],

@@ -186,23 +186,29 @@ __global__ __launch_bounds__(256) void k_affine_act(const float* __restrict__ z,
 //   g = dy * [z*scale+shift > 0] (RELU) or dy;  xhat = (z - mean) * invstd
 // part[2][slots][C], slot = n * nseg + seg
 // ---------------------------------------------------------------------------------
-template <bool RELU>
+// HEAD (hw != null): the consumer of y = relu(bn(z)) is a 1x1 convolution to ONE channel (OutConv with n_classes = 1,
+// reference models/unet_parts.py:67-73) whose gradient dlog [N][P] is given instead of dy: dy[n][c][p] = hw[c] *
+// dlog[n][p] is formed on the fly (the same single product ATen's conv backward stores), and the kernel also emits that
+// convolution's weight gradient, part[2][slot][c] = sum dlog * y.  The 64-channel dy tensor is never written or read.
+template <bool RELU, bool HEAD>
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__ dy, long dy_bs,
                                                        const float* __restrict__ z, long z_bs,
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, float* __restrict__ part,
-                                                       int C, int P, int seg_len, int slots) {
-    __shared__ float red[8];
+                                                       int C, int P, int seg_len, int slots,
+                                                       const float* __restrict__ hw) {
+    __shared__ float red[12];
     const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
     const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+    const float wc = HEAD ? hw[c] : 1.f;
     const float* zp = z + (long)n * z_bs + (long)c * P;
-    const float* gp = dy + (long)n * dy_bs + (long)c * P;
+    const float* gp = dy + (long)n * dy_bs + (HEAD ? 0L : (long)c * P);
     const int p0 = blockIdx.y * seg_len;
     int p1 = p0 + seg_len;
     if (p1 > P) p1 = P;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
     const bool vec = ((P & 3) == 0) && ((z_bs & 3) == 0) && ((dy_bs & 3) == 0) && ((seg_len & 3) == 0) &&
                      ((((uintptr_t)z) & 15) == 0) && ((((uintptr_t)dy) & 15) == 0);
     if (vec) {
@@ -213,27 +219,34 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
             const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float g = gg[j];
-                if (RELU && !(fmaf(zz[j], sc, sh) > 0.f)) g = 0.f;
+                const float a = fmaf(zz[j], sc, sh);
+                float g = HEAD ? wc * gg[j] : gg[j];
+                if (RELU && !(a > 0.f)) g = 0.f;
                 s1 += g;
                 s2 = fmaf(g, (zz[j] - mu) * is, s2);
+                if (HEAD) s3 = fmaf(gg[j], RELU ? fmaxf(a, 0.f) : a, s3);
             }
         }
     } else {
         for (int p = p0 + threadIdx.x; p < p1; p += 256) {
             const float zz = zp[p];
-            float g = gp[p];
-            if (RELU && !(fmaf(zz, sc, sh) > 0.f)) g = 0.f;
+            const float a = fmaf(zz, sc, sh);
+            const float g0 = gp[p];
+            float g = HEAD ? wc * g0 : g0;
+            if (RELU && !(a > 0.f)) g = 0.f;
             s1 += g;
             s2 = fmaf(g, (zz - mu) * is, s2);
+            if (HEAD) s3 = fmaf(g0, RELU ? fmaxf(a, 0.f) : a, s3);
         }
     }
     const float t1 = block_sum_t0(s1, red);
     const float t2 = block_sum_t0(s2, red + 4);
+    const float t3 = HEAD ? block_sum_t0(s3, red + 8) : 0.f;
     if (threadIdx.x == 0) {
         const int slot = n * gridDim.y + blockIdx.y;
         part[(long)slot * C + c] = t1;
         part[((long)slots + slot) * C + c] = t2;
+        if (HEAD) part[(2L * slots + slot) * C + c] = t3;
     }
 }
 
@@ -270,7 +283,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict
 }
 
 // backward pass 2: dz = c1 * (g - c2 - xhat * c3)
-template <bool RELU>
+template <bool RELU, bool HEAD>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dy, long dy_bs,
                                                       const float* __restrict__ z, long z_bs,
                                                       const float* __restrict__ scale,
@@ -278,12 +291,14 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                       const float* __restrict__ mean,
                                                       const float* __restrict__ invstd,
                                                       const float* __restrict__ coef, float* __restrict__ dz,
-                                                      long dz_bs, int C, int P, int seg_len) {
+                                                      long dz_bs, int C, int P, int seg_len,
+                                                      const float* __restrict__ hw) {
     const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
     const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
     const float c1 = coef[c], c2 = coef[C + c], c3 = coef[2 * C + c];
+    const float wc = HEAD ? hw[c] : 1.f;  // HEAD: dy[n][c][p] = hw[c] * dlog[n][p], see k_bn_bwd_reduce
     const float* zp = z + (long)n * z_bs + (long)c * P;
-    const float* gp = dy + (long)n * dy_bs + (long)c * P;
+    const float* gp = dy + (long)n * dy_bs + (HEAD ? 0L : (long)c * P);
     float* op = dz + (long)n * dz_bs + (long)c * P;
     const int p0 = blockIdx.y * seg_len;
     int p1 = p0 + seg_len;
@@ -300,7 +315,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
             float o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float g = gg[j];
+                float g = HEAD ? wc * gg[j] : gg[j];
                 if (RELU && !(fmaf(zz[j], sc, sh) > 0.f)) g = 0.f;
                 o[j] = c1 * (g - c2 - (zz[j] - mu) * is * c3);
             }
@@ -309,7 +324,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     } else {
         for (int p = p0 + threadIdx.x; p < p1; p += 256) {
             const float zz = zp[p];
-            float g = gp[p];
+            float g = HEAD ? wc * gp[p] : gp[p];
             if (RELU && !(fmaf(zz, sc, sh) > 0.f)) g = 0.f;
             op[p] = c1 * (g - c2 - (zz - mu) * is * c3);
         }
@@ -432,16 +447,19 @@ int launch_affine_act(const float* z, long z_bs, const float* scale, const float
 
 int launch_bn_bwd_reduce(const float* dy, long dy_bs, const float* z, long z_bs, const float* scale,
                          const float* shift, const float* mean, const float* invstd, float* part, int N, int C, int P,
-                         int relu, hipStream_t st) {
+                         int relu, hipStream_t st, const float* hw) {
     const int seg = plane_seg_len(P);
     dim3 grid(N * C, cdiv(P, seg));
     const int slots = N * grid.y;
-    if (relu)
-        hipLaunchKernelGGL(k_bn_bwd_reduce<true>, grid, dim3(256), 0, st, dy, dy_bs, z, z_bs, scale, shift, mean,
-                           invstd, part, C, P, seg, slots);
-    else
-        hipLaunchKernelGGL(k_bn_bwd_reduce<false>, grid, dim3(256), 0, st, dy, dy_bs, z, z_bs, scale, shift, mean,
-                           invstd, part, C, P, seg, slots);
+#define BNR_GO(R, H)                                                                                                  \
+    hipLaunchKernelGGL((k_bn_bwd_reduce<R, H>), grid, dim3(256), 0, st, dy, dy_bs, z, z_bs, scale, shift, mean, invstd, \
+                       part, C, P, seg, slots, hw)
+    if (hw) {
+        if (relu) BNR_GO(true, true); else BNR_GO(false, true);
+    } else {
+        if (relu) BNR_GO(true, false); else BNR_GO(false, false);
+    }
+#undef BNR_GO
     return (int)hipGetLastError();
 }
 
@@ -454,15 +472,81 @@ int launch_bn_bwd_finalize(const float* part, int slots, int C, double count, co
 
 int launch_bn_bwd_apply(const float* dy, long dy_bs, const float* z, long z_bs, const float* scale,
                         const float* shift, const float* mean, const float* invstd, const float* coef, float* dz,
-                        long dz_bs, int N, int C, int P, int relu, hipStream_t st) {
+                        long dz_bs, int N, int C, int P, int relu, hipStream_t st, const float* hw) {
     const int seg = plane_seg_len(P);
     dim3 grid(N * C, cdiv(P, seg));
-    if (relu)
-        hipLaunchKernelGGL(k_bn_bwd_apply<true>, grid, dim3(256), 0, st, dy, dy_bs, z, z_bs, scale, shift, mean,
-                           invstd, coef, dz, dz_bs, C, P, seg);
-    else
-        hipLaunchKernelGGL(k_bn_bwd_apply<false>, grid, dim3(256), 0, st, dy, dy_bs, z, z_bs, scale, shift, mean,
-                           invstd, coef, dz, dz_bs, C, P, seg);
+#define BNA_GO(R, H)                                                                                                 \
+    hipLaunchKernelGGL((k_bn_bwd_apply<R, H>), grid, dim3(256), 0, st, dy, dy_bs, z, z_bs, scale, shift, mean, invstd, \
+                       coef, dz, dz_bs, C, P, seg, hw)
+    if (hw) {
+        if (relu) BNA_GO(true, true); else BNA_GO(false, true);
+    } else {
+        if (relu) BNA_GO(true, false); else BNA_GO(false, false);
+    }
+#undef BNA_GO
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// OutConv with ONE output channel on an un-materialised activation (reference models/unet_parts.py:67-73 after
+// unet_parts_depthwise_separable.py:34-35):  out[n][p] = b + sum_c w[c] * relu(z[n][c][p] * scale[c] + shift[c]).
+// A thread owns four pixels and walks the channels (coalesced float4 rows); the block output of the last decoder level
+// is never written.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_outconv1_fwd(const float* __restrict__ z, long z_bs,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      const float* __restrict__ w, const float* __restrict__ b,
+                                                      float* __restrict__ out, long out_bs, int C, int P) {
+    const int n = blockIdx.y;
+    const long p = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p >= P) return;
+    const float* zp = z + (long)n * z_bs + p;
+    const float b0 = b ? b[0] : 0.f;
+    float4 acc = make_float4(b0, b0, b0, b0);
+    const bool vec = ((P & 3) == 0) && ((z_bs & 3) == 0) && ((out_bs & 3) == 0) && ((((uintptr_t)z) & 15) == 0) &&
+                     ((((uintptr_t)out) & 15) == 0);
+    if (vec) {
+        int c = 0;
+        for (; c + 3 < C; c += 4) {  // four rows in flight
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(zp + (long)(c + u) * P);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float sc = scale[c + u], sh = shift[c + u], wc = w[c + u];
+                acc.x = fmaf(wc, fmaxf(fmaf(v[u].x, sc, sh), 0.f), acc.x);
+                acc.y = fmaf(wc, fmaxf(fmaf(v[u].y, sc, sh), 0.f), acc.y);
+                acc.z = fmaf(wc, fmaxf(fmaf(v[u].z, sc, sh), 0.f), acc.z);
+                acc.w = fmaf(wc, fmaxf(fmaf(v[u].w, sc, sh), 0.f), acc.w);
+            }
+        }
+        for (; c < C; ++c) {
+            const float4 v = *(const float4*)(zp + (long)c * P);
+            const float sc = scale[c], sh = shift[c], wc = w[c];
+            acc.x = fmaf(wc, fmaxf(fmaf(v.x, sc, sh), 0.f), acc.x);
+            acc.y = fmaf(wc, fmaxf(fmaf(v.y, sc, sh), 0.f), acc.y);
+            acc.z = fmaf(wc, fmaxf(fmaf(v.z, sc, sh), 0.f), acc.z);
+            acc.w = fmaf(wc, fmaxf(fmaf(v.w, sc, sh), 0.f), acc.w);
+        }
+        *(float4*)(out + (long)n * out_bs + p) = acc;
+    } else {
+        float a[4] = {b0, b0, b0, b0};
+        for (int c = 0; c < C; ++c) {
+            const float sc = scale[c], sh = shift[c], wc = w[c];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (p + q < P) a[q] = fmaf(wc, fmaxf(fmaf(zp[(long)c * P + q], sc, sh), 0.f), a[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (p + q < P) out[(long)n * out_bs + p + q] = a[q];
+    }
+}
+
+int launch_outconv1_fwd(const float* z, long z_bs, const float* scale, const float* shift, const float* w, const float* b,
+                        float* out, long out_bs, int N, int C, int P, hipStream_t st) {
+    hipLaunchKernelGGL(k_outconv1_fwd, dim3(cdiv(P, 1024), N), dim3(256), 0, st, z, z_bs, scale, shift, w, b, out, out_bs, C,
+                       P);
     return (int)hipGetLastError();
 }
 

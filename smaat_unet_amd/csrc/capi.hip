@@ -19,11 +19,13 @@ int launch_bn_eval_coefs(const float*, const float*, const float*, const float*,
 int launch_affine_act(const float*, long, const float*, const float*, float*, long, int, int, int, int, hipStream_t);
 int smaat_bn_bwd_num_slots_impl(int N, int P);
 int launch_bn_bwd_reduce(const float*, long, const float*, long, const float*, const float*, const float*, const float*,
-                         float*, int, int, int, int, hipStream_t);
+                         float*, int, int, int, int, hipStream_t, const float* hw = nullptr);
 int launch_bn_bwd_finalize(const float*, int, int, double, const float*, const float*, float*, float*, float*,
                            hipStream_t);
 int launch_bn_bwd_apply(const float*, long, const float*, long, const float*, const float*, const float*, const float*,
-                        const float*, float*, long, int, int, int, int, hipStream_t);
+                        const float*, float*, long, int, int, int, int, hipStream_t, const float* hw = nullptr);
+int launch_outconv1_fwd(const float*, long, const float*, const float*, const float*, const float*, float*, long, int, int,
+                        int, hipStream_t);
 int launch_reduce_rows(const float*, int, long, float*, float, hipStream_t);
 int launch_channel_sum(const float*, long, int, int, int, float*, float*, hipStream_t);
 int launch_copy_planes(const float*, long, float*, long, int, long, int, hipStream_t);
@@ -229,6 +231,24 @@ int smaat_bn_bwd_apply(const float* dy, long dy_bs, const float* z, long z_bs, c
                        const float* shift, const float* mean, const float* invstd, const float* coef, float* dz,
                        long dz_bs, int N, int C, int P, int relu, void* stream) {
     return launch_bn_bwd_apply(dy, dy_bs, z, z_bs, scale, shift, mean, invstd, coef, dz, dz_bs, N, C, P, relu, ST);
+}
+/* ---- OutConv with one output channel fused with the BatchNorm + ReLU in front of it (see include/smaat_hip.h) */
+int smaat_outconv1_fwd(const float* z, long z_bs, const float* scale, const float* shift, const float* w, const float* b,
+                       float* out, long out_bs, int N, int C, int P, void* stream) {
+    if (!z || !scale || !shift || !w || !out || N < 1 || C < 1 || P < 1) return -1;
+    return launch_outconv1_fwd(z, z_bs, scale, shift, w, b, out, out_bs, N, C, P, ST);
+}
+int smaat_bn_bwd_reduce_head(const float* dlog, long dlog_bs, const float* hw, const float* z, long z_bs,
+                             const float* scale, const float* shift, const float* mean, const float* invstd, float* part,
+                             int N, int C, int P, void* stream) {
+    if (!dlog || !hw || !part) return -1;
+    return launch_bn_bwd_reduce(dlog, dlog_bs, z, z_bs, scale, shift, mean, invstd, part, N, C, P, 1, ST, hw);
+}
+int smaat_bn_bwd_apply_head(const float* dlog, long dlog_bs, const float* hw, const float* z, long z_bs,
+                            const float* scale, const float* shift, const float* mean, const float* invstd,
+                            const float* coef, float* dz, long dz_bs, int N, int C, int P, void* stream) {
+    if (!dlog || !hw || !dz) return -1;
+    return launch_bn_bwd_apply(dlog, dlog_bs, z, z_bs, scale, shift, mean, invstd, coef, dz, dz_bs, N, C, P, 1, ST, hw);
 }
 int smaat_reduce_rows(const float* part, int rows, long len, float* out, float alpha, void* stream) {
     return launch_reduce_rows(part, rows, len, out, alpha, ST);

@@ -331,6 +331,47 @@ def _bn_bwd_raw(dy, z, st, gamma, relu, train, pre_part=None):
     return dz, dgamma, dbeta
 
 
+def _bn_bwd_head_raw(dlog, w_out, z, st, gamma, train):
+    """BatchNorm + ReLU backward when the consumer of y = relu(bn(z)) is a 1x1 convolution to ONE channel whose output
+    gradient is dlog [N][1][H][W]: dy = w_out[c] * dlog is formed on the fly (smaat_bn_bwd_*_head), never stored.
+    -> dz, dgamma, dbeta, dw_out [1][C][1][1]"""
+    L = _lib.get()
+    dlog, dl_bs = _planes(dlog)
+    z, z_bs = _planes(z)
+    n, c, h, w = z.shape
+    p = h * w
+    s = _stream(z)
+    wv = w_out.reshape(-1).contiguous()
+    slots = L.smaat_plane_num_slots(n, p)
+    part = _new(z, 3, slots, c)
+    _lib.check(L.smaat_bn_bwd_reduce_head(_ptr(dlog), dl_bs, _ptr(wv), _ptr(z), z_bs, _ptr(st[2]), _ptr(st[3]),
+                                          _ptr(st[0]), _ptr(st[1]), _ptr(part), n, c, p, s), "smaat_bn_bwd_reduce_head")
+    dgamma, dbeta, coef = _new(z, c), _new(z, c), _new(z, 3, c)
+    _lib.check(L.smaat_bn_bwd_finalize(_ptr(part), slots, c, float(n * p), _ptr(gamma), _ptr(st[1]), _ptr(dgamma),
+                                       _ptr(dbeta), _ptr(coef), s), "smaat_bn_bwd_finalize")
+    if not train:
+        coef[1:].zero_()
+    dz = _new(z, n, c, h, w)
+    _lib.check(L.smaat_bn_bwd_apply_head(_ptr(dlog), dl_bs, _ptr(wv), _ptr(z), z_bs, _ptr(st[2]), _ptr(st[3]),
+                                         _ptr(st[0]), _ptr(st[1]), _ptr(coef), _ptr(dz), c * p, n, c, p, s),
+               "smaat_bn_bwd_apply_head")
+    dw_out = _new(z, c)
+    _lib.check(L.smaat_reduce_rows(_ptr(part[2]), slots, c, _ptr(dw_out), 1.0, s), "smaat_reduce_rows")
+    return dz, dgamma, dbeta, dw_out.view(1, c, 1, 1)
+
+
+def _outconv1_fwd_raw(z, scale, shift, w_out, b_out):
+    """logits [N][1][H][W] = OutConv(relu(z * scale + shift)) for ONE output channel, the activation never written"""
+    L = _lib.get()
+    z, z_bs = _planes(z)
+    n, c, h, w = z.shape
+    out = _new(z, n, 1, h, w)
+    wv = w_out.reshape(-1).contiguous()
+    _lib.check(L.smaat_outconv1_fwd(_ptr(z), z_bs, _ptr(scale), _ptr(shift), _ptr(wv), _ptr(b_out), _ptr(out), h * w, n, c,
+                                    h * w, _stream(z)), "smaat_outconv1_fwd")
+    return out
+
+
 def _channel_sum_raw(x):
     L = _lib.get()
     x, x_bs = _planes(x)
@@ -466,11 +507,14 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
 
 
 def _half_backward(x, w_dw, b_dw, w_pw, gamma, z, st, y_dw, dy, kpl, train_stats, has_bias, need_dx, pre_part=None,
-                   bnred=None, in_aff=None):
+                   bnred=None, in_aff=None, head=None):
     """-> (dx, dw_dw, db_dw, dw_pw, db_pw, dgamma, dbeta), red.  pre_part: this BatchNorm's backward sums
     (from the following block's depthwise backward); in_aff=(scale, shift) + bnred=(mean, invstd) of the PREVIOUS
     BatchNorm: x is its input, the activation is applied on load and its backward sums are emitted (`red`)."""
-    dz, dgamma, dbeta = _bn_bwd_raw(dy, z, st, gamma, True, train_stats, pre_part=pre_part)
+    if head is not None:  # dy is w_out (x) dlog, formed on the fly; head["dw"] receives the 1x1 conv's weight gradient
+        dz, dgamma, dbeta, head["dw"] = _bn_bwd_head_raw(head["dlog"], head["w"], z, st, gamma, train_stats)
+    else:
+        dz, dgamma, dbeta = _bn_bwd_raw(dy, z, st, gamma, True, train_stats, pre_part=pre_part)
     r = _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=y_dw, bnred=bnred, in_aff=in_aff)
     dx, dw_dw, db_dw, dw_pw = r[:4]
     red = r[4] if bnred is not None else None
@@ -519,8 +563,9 @@ class _DoubleConvDS(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_dw1, b_dw1, w_pw1, b_pw1, g1, be1, rm1, rv1, w_dw2, b_dw2, w_pw2, b_pw2, g2, be2, rm2, rv2,
-                tr1, mo1, eps1, tr2, mo2, eps2, kpl):
-        _check(x, w_dw1, b_dw1, w_pw1, b_pw1, g1, be1, rm1, rv1, w_dw2, b_dw2, w_pw2, b_pw2, g2, be2, rm2, rv2)
+                tr1, mo1, eps1, tr2, mo2, eps2, kpl, w_out=None, b_out=None):
+        _check(x, w_dw1, b_dw1, w_pw1, b_pw1, g1, be1, rm1, rv1, w_dw2, b_dw2, w_pw2, b_pw2, g2, be2, rm2, rv2, w_out,
+               b_out)
         c1 = _expect_dsconv(x, w_dw1, b_dw1, w_pw1, b_pw1, kpl, (("double_conv.1.weight", g1), ("double_conv.1.bias", be1),
                                                                   ("double_conv.1.running_mean", rm1),
                                                                   ("double_conv.1.running_var", rv1)))
@@ -540,32 +585,52 @@ class _DoubleConvDS(torch.autograd.Function):
                 and bool(_lib.get().smaat_dw3x3_strip_ok(kpl, h, w)))
         y1, z1, st1, ydw1, ubs1 = _half_forward(x, w_dw1, b_dw1, w_pw1, b_pw1, g1, be1, rm1, rv1, tr1, mo1, eps1, kpl,
                                                 keep_y, want_act=not fuse)
+        # head: an OutConv with ONE output channel consumes the block (w_out [1][C][1][1]): the block output is not
+        # written, the logits come from the pre-BatchNorm tensor with the activation applied on load
+        head = w_out is not None
+        if head:
+            _expect(w_out, (1, w_pw2.shape[0], 1, 1), "outc.conv.weight")
+            _expect(b_out, (1,), "outc.conv.bias")
         y2, z2, st2, ydw2, ubs2 = _half_forward(z1 if fuse else y1, w_dw2, b_dw2, w_pw2, b_pw2, g2, be2, rm2, rv2, tr2,
-                                                mo2, eps2, kpl, keep_y, in_aff=(st1[2], st1[3]) if fuse else None)
+                                                mo2, eps2, kpl, keep_y, in_aff=(st1[2], st1[3]) if fuse else None,
+                                                want_act=not head)
         ctx.save_for_backward(x, w_dw1, b_dw1, w_pw1, g1, be1, z1, st1, ydw1, y1, w_dw2, b_dw2, w_pw2, g2, z2, st2,
-                              ydw2)
+                              ydw2, w_out)
         ctx.fuse = fuse
         ctx.kpl = kpl
         ctx.train_stats = (ubs1, ubs2)
         ctx.has_bias = ((b_dw1 is not None, b_pw1 is not None), (b_dw2 is not None, b_pw2 is not None))
+        ctx.head = (True, b_out is not None) if head else None
+        if head:
+            return _outconv1_fwd_raw(z2, st2[2], st2[3], w_out, b_out)
         return y2
 
     @staticmethod
     def backward(ctx, dy2):
         (x, w_dw1, b_dw1, w_pw1, g1, be1, z1, st1, ydw1, y1, w_dw2, b_dw2, w_pw2, g2, z2, st2,
-         ydw2) = ctx.saved_tensors
+         ydw2, w_out) = ctx.saved_tensors
+        head = None
+        if ctx.head is not None:  # dy2 is the gradient of the logits [N][1][H][W]
+            head = dict(dlog=dy2.contiguous(), w=w_out, dw=None)
         gr2, red = _half_backward(z1 if ctx.fuse else y1, w_dw2, b_dw2, w_pw2, g2, z2, st2, ydw2, dy2, ctx.kpl,
                                   ctx.train_stats[1], ctx.has_bias[1], True,
                                   bnred=(st1[0], st1[1]) if ctx.fuse else None,
-                                  in_aff=(st1[2], st1[3]) if ctx.fuse else None)
+                                  in_aff=(st1[2], st1[3]) if ctx.fuse else None, head=head)
         gr1, _ = _half_backward(x, w_dw1, b_dw1, w_pw1, g1, z1, st1, ydw1, gr2[0], ctx.kpl, ctx.train_stats[0],
                                 ctx.has_bias[0], ctx.needs_input_grad[0], pre_part=red)
-        return gr1 + (None, None) + gr2[1:] + (None, None) + (None,) * 7
+        ghead = (None, None)
+        if head is not None:
+            ghead = (head["dw"], _channel_sum_raw(head["dlog"]) if ctx.head[1] else None)
+        return gr1 + (None, None) + gr2[1:] + (None, None) + (None,) * 7 + ghead
 
 
-def double_conv_ds(x, half1, half2, kpl):
-    """half = (w_dw, b_dw, w_pw, b_pw, gamma, beta, running_mean, running_var, training, momentum, eps)"""
+def double_conv_ds(x, half1, half2, kpl, head=None):
+    """half = (w_dw, b_dw, w_pw, b_pw, gamma, beta, running_mean, running_var, training, momentum, eps).
+    head = (w_out [1][C][1][1], b_out [1] or None): returns OutConv(block(x)) for an OutConv with ONE output channel,
+    with the block output and its gradient never materialised (see _DoubleConvDS)."""
     a, b = half1, half2
+    if head is not None:
+        return _DoubleConvDS.apply(x, *a[:8], *b[:8], a[8], a[9], a[10], b[8], b[9], b[10], kpl, head[0], head[1])
     return _DoubleConvDS.apply(x, *a[:8], *b[:8], a[8], a[9], a[10], b[8], b[9], b[10], kpl)
 
 

@@ -51,9 +51,23 @@ class DoubleConvDS(nn.Module):
                         for j in (1, 4))
                 and seq[0].kernels_per_layer_ == seq[3].kernels_per_layer_)
 
-    def forward(self, x):
+    def forward(self, x, head=None):
+        """head (internal, set by the network's fused wiring): the nn.Conv2d(C, 1, 1) of the OutConv that consumes this
+        block; the call then returns OutConv(block(x)) as one autograd node (ops.double_conv_ds(..., head=...))."""
         seq = self.double_conv
         hooked = any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks for m in seq.modules())
+        if head is not None:
+            import torch
+            if hooked or not torch.is_grad_enabled() or seq[0].kernels_per_layer_ != seq[3].kernels_per_layer_:
+                y = self.forward(x)  # the plain block, then the OutConv on its own
+                if not torch.is_grad_enabled():
+                    return torch.ops.smaat.pointwise_infer(y, head.weight, head.bias)
+                return ops.pointwise(y, head.weight, head.bias)
+            for conv in (seq[0], seq[3]):
+                conv._check_geometry()
+            halves = [(seq[i].depthwise.weight, seq[i].depthwise.bias, seq[i].pointwise.weight, seq[i].pointwise.bias)
+                      + _bn_args(seq[i + 1]) for i in (0, 3)]
+            return ops.double_conv_ds(x, halves[0], halves[1], seq[0].kernels_per_layer_, head=(head.weight, head.bias))
         if self._eval_fast_ok(hooked):
             for conv in (seq[0], seq[3]):
                 conv._check_geometry()
@@ -115,17 +129,19 @@ class UpDS(nn.Module):
             return self.conv(ops.upsample_cat(x1, x2))
         return self.conv(ops.upconv_cat(x1, x2, self.up.weight, self.up.bias))
 
-    def forward_into(self, x1, cat):
+    def forward_into(self, x1, cat, head=None):
         """same as forward(x1, x2) when x2 already sits in channels [0, C2) of `cat`
-        ([N, C2 + C1', H2, W2]): the upsampled x1 is written behind it, no torch.cat copy."""
+        ([N, C2 + C1', H2, W2]): the upsampled x1 is written behind it, no torch.cat copy.
+        head: see DoubleConvDS.forward."""
+        kw = {} if head is None else {"head": head}
         if self.bilinear:
             import torch
             if not torch.is_grad_enabled():
                 torch.ops.smaat.upsample_into_(cat, x1, cat.shape[1] - x1.shape[1])
-                return self.conv(cat)
-            return self.conv(ops.upsample_into(cat, x1, cat.shape[1] - x1.shape[1]))
+                return self.conv(cat, **kw)
+            return self.conv(ops.upsample_into(cat, x1, cat.shape[1] - x1.shape[1]), **kw)
         co = self.up.out_channels
-        return self.conv(ops.upconv_into(cat, x1, self.up.weight, self.up.bias, cat.shape[1] - co))
+        return self.conv(ops.upconv_into(cat, x1, self.up.weight, self.up.bias, cat.shape[1] - co), **kw)
 
 
 class OutConv(nn.Module):

@@ -364,6 +364,39 @@ class EmuLib:
         planes(dz, N, C, P, dz_bs)[:] = cf[0][None, :, None] * (g - cf[1][None, :, None] - xhat * cf[2][None, :, None])
         return 0
 
+    # ---- OutConv (one output channel) fused with the BatchNorm + ReLU in front of it
+    def _head_dy(self, dlog, dlog_bs, w, N, C, P):
+        d = np.array(planes(dlog, N, 1, P, dlog_bs))  # [N][1][P]
+        return (f32(w, C)[None, :, None] * d).astype(np.float32)  # the single product ATen's conv backward stores
+
+    def smaat_outconv1_fwd(self, z, z_bs, scale, shift, w, b, out, out_bs, N, C, P, stream):
+        zz = np.array(planes(z, N, C, P, z_bs))
+        y = np.maximum(zz * f32(scale, C)[None, :, None] + f32(shift, C)[None, :, None], 0).astype(np.float32)
+        o = (y.astype(np.float64) * f32(w, C)[None, :, None]).sum(1) + (float(f32(b, 1)[0]) if b else 0.0)
+        planes(out, N, 1, P, out_bs)[:] = o[:, None, :].astype(np.float32)
+        return 0
+
+    def smaat_bn_bwd_reduce_head(self, dlog, dlog_bs, w, z, z_bs, scale, shift, mean, invstd, part, N, C, P, stream):
+        dy = self._head_dy(dlog, dlog_bs, w, N, C, P)
+        zz = np.array(planes(z, N, C, P, z_bs))
+        a = zz * f32(scale, C)[None, :, None] + f32(shift, C)[None, :, None]
+        g = dy * (a > 0)
+        xhat = (zz - f32(mean, C)[None, :, None]) * f32(invstd, C)[None, :, None]
+        slots = PLANE_SLOTS * N
+        pp = f32(part, 3 * slots * C).reshape(3, slots, C)
+        pp[:] = 0
+        pp[0, 0] = g.astype(np.float64).sum(axis=(0, 2))
+        pp[1, 0] = (g.astype(np.float64) * xhat).sum(axis=(0, 2))
+        d = np.array(planes(dlog, N, 1, P, dlog_bs)).astype(np.float64)
+        pp[2, 0] = (d * np.maximum(a, 0)).sum(axis=(0, 2))
+        return 0
+
+    def smaat_bn_bwd_apply_head(self, dlog, dlog_bs, w, z, z_bs, scale, shift, mean, invstd, coef, dz, dz_bs, N, C, P,
+                                stream):
+        dy = np.ascontiguousarray(self._head_dy(dlog, dlog_bs, w, N, C, P))
+        return self.smaat_bn_bwd_apply(dy.ctypes.data, C * P, z, z_bs, scale, shift, mean, invstd, coef, dz, dz_bs, N, C,
+                                       P, 1, stream)
+
     # ------------------------------------------------------------------ helpers
     def smaat_reduce_rows(self, part, rows, length, out, alpha, stream):
         f32(out, length)[:] = f32(part, rows * length).reshape(rows, length).astype(np.float64).sum(0) * alpha

@@ -593,6 +593,41 @@ def test_pointwise_split_k_slices(shape):
         assert nws > 0  # the deep batch-1 layers are the ones this exists for
 
 
+def case_head(L, dev, N, C, H, W, pad_c=0):
+    """OutConv with one output channel fused with the BatchNorm + ReLU in front of it: forward, backward reduction
+    (+ the conv's weight gradient), backward apply"""
+    Pn = H * W
+    zf = T(rnd(1, N, C + pad_c, H, W) * 1.5 + 0.3, dev)
+    z_bs = (C + pad_c) * Pn
+    mean = zf[:, :C].mean(dim=(0, 2, 3)).contiguous()
+    invstd = (1.0 / torch.sqrt(zf[:, :C].var(dim=(0, 2, 3), unbiased=False) + 1e-5)).contiguous()
+    gam = T(np.random.default_rng(2).uniform(0.5, 1.5, C).astype(np.float32), dev)
+    bet = T(rnd(3, C, scale=0.3), dev)
+    sc = (gam * invstd).contiguous()
+    sh = (bet - mean * sc).contiguous()
+    w, b = T(rnd(4, C, scale=0.4), dev), T(rnd(5, 1), dev)
+    s = stream(dev)
+    out = torch.full((N, 1, H, W), float("nan"), device=dev)
+    assert L.smaat_outconv1_fwd(P(zf), z_bs, P(sc), P(sh), P(w), P(b), P(out), Pn, N, C, Pn, s) == 0
+    dlog = T(rnd(6, N, 1, H, W), dev)
+    slots = L.smaat_plane_num_slots(N, Pn)
+    part = torch.full((3, slots, C), float("nan"), device=dev)
+    assert L.smaat_bn_bwd_reduce_head(P(dlog), Pn, P(w), P(zf), z_bs, P(sc), P(sh), P(mean), P(invstd), P(part), N, C, Pn,
+                                      s) == 0
+    dgamma, dbeta, coef = (torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(3, C, device=dev))
+    assert L.smaat_bn_bwd_finalize(P(part), slots, C, float(N * Pn), P(gam), P(invstd), P(dgamma), P(dbeta), P(coef), s) == 0
+    dz = torch.full((N, C, H, W), float("nan"), device=dev)
+    assert L.smaat_bn_bwd_apply_head(P(dlog), Pn, P(w), P(zf), z_bs, P(sc), P(sh), P(mean), P(invstd), P(coef), P(dz),
+                                     C * Pn, N, C, Pn, s) == 0
+    return dict(out=out, dgamma=dgamma, dbeta=dbeta, dw=part[2].double().sum(0), dz=dz)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 32, 32), (1, 5, 7, 9), (2, 64, 288, 288), (3, 16, 20, 12)])
+def test_outconv1_head(shape):
+    both(case_head, *shape, tol=2e-5)
+    both(case_head, *shape, pad_c=3, tol=2e-5)
+
+
 def case_final_pool(L, dev, N, C, H, W, pad_c=0):
     """cbam_bwd_final + maxpool2 backward in one pass == the two separate kernels (bit for bit: same adds, same order)"""
     Pn = H * W
