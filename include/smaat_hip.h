@@ -172,6 +172,11 @@ int smaat_pixel_shuffle2_bwd(const float* dout, long dout_bs, float* dt, long dt
 int smaat_cbam_spconv_blocks(int N, int H, int W);
 int smaat_cbam_pix_blocks(int N, int P);
 int smaat_cbam_chpool(const float* x, long x_bs, int N, int C, int P, float* avg, float* mx, int* amax, void* stream);
+/* the same pooling over y = relu(z * scale[c] + shift[c]) formed on load from the PRE-BatchNorm tensor z of the block in
+ * front of the attention (unet_parts_depthwise_separable.py:34-35), with y written out: the block output is
+ * materialised by its first consumer instead of by a BatchNorm-apply pass of its own */
+int smaat_cbam_chpool_act(const float* z, long z_bs, const float* scale, const float* shift, float* y, long y_bs, int N,
+                          int C, int P, float* avg, float* mx, int* amax, void* stream);
 int smaat_cbam_mlp(const float* avg, const float* mx, const float* w1, const float* b1, const float* w2,
                    const float* b2, int N, int C, int Cr, float* ha, float* hm, float* s, void* stream);
 int smaat_cbam_sppool(const float* x, long x_bs, const float* s, int N, int C, int P, float* maps, void* stream);

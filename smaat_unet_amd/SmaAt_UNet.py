@@ -9,6 +9,8 @@ outc), which is what fixes the `state_dict` key order.
 """
 from __future__ import annotations
 
+import os
+
 from torch import nn
 
 from .layers import CBAM, batched_counters
@@ -112,13 +114,20 @@ class UNetDSFamily(nn.Module):
             return self._forward_modular(x)
         downs, ups, cbams = self._levels()
         cats = []
-        h = self.inc(x)
+        import torch
+        # deferred activation (training path): an encoder block hands out its pre-BatchNorm tensor + coefficients and
+        # the attention block that consumes it applies BatchNorm + ReLU inside its channel-pooling kernel, which also
+        # writes the activated tensor -- the separate pass over every encoder output disappears
+        defer = self.FUSE_ENCODER_ACT and torch.is_grad_enabled()
+        h = self.inc(x, defer=True) if defer else self.inc(x)
         for lvl in range(4):
             up = ups[3 - lvl]  # the decoder level that consumes this skip
-            c_extra = up.conv.double_conv[0].depthwise.in_channels - h.shape[1]
+            ch = (h[0] if isinstance(h, tuple) else h).shape[1]
+            c_extra = up.conv.double_conv[0].depthwise.in_channels - ch
             cat, pooled = cbams[lvl].forward_pool_cat(h, c_extra)  # skip written straight into the decoder's cat buffer
             cats.append(cat)
-            h = downs[lvl].maxpool_conv[1](pooled)
+            last = downs[lvl].maxpool_conv[1]
+            h = last(pooled, defer=True) if (defer and cbams[4] is not None or defer and lvl < 3) else last(pooled)
         if cbams[4] is not None:
             h = cbams[4](h)
         head = self._fused_head()
@@ -128,7 +137,9 @@ class UNetDSFamily(nn.Module):
             h = up.forward_into(h, cat)
         return self.outc(h)
 
-    FUSE_HEAD = True
+    # class-level switches of the two cross-module fusions of the training path (environment overrides for A/B runs)
+    FUSE_HEAD = os.environ.get("SMAAT_FUSE_HEAD", "1") != "0"
+    FUSE_ENCODER_ACT = os.environ.get("SMAAT_FUSE_ENC", "1") != "0"
 
     def _fused_head(self):
         """the OutConv's nn.Conv2d when it has ONE output channel and can be fused with the BatchNorm + ReLU in front of

@@ -55,6 +55,7 @@ SIGNATURES = {
     "smaat_cbam_spconv_blocks": [_I, _I, _I],
     "smaat_cbam_pix_blocks": [_I, _I],
     "smaat_cbam_chpool": [_P, _L, _I, _I, _I, _P, _P, _P, _P],
+    "smaat_cbam_chpool_act": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P],
     "smaat_cbam_mlp": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "smaat_cbam_sppool": [_P, _L, _P, _I, _I, _I, _P, _P],
     "smaat_cbam_spconv": [_P, _P, _I, _I, _I, _I, _P, _P, _P],

@@ -45,7 +45,8 @@ int dw3x3_strip_ok(int kpl, int H, int W);
 
 int smaat_cbam_spconv_blocks_impl(int N, int H, int W);
 int smaat_cbam_pix_blocks_impl(int N, int P);
-int launch_cbam_chpool(const float*, long, int, int, int, float*, float*, int*, hipStream_t);
+int launch_cbam_chpool(const float*, long, int, int, int, float*, float*, int*, hipStream_t, const float* = nullptr,
+                       const float* = nullptr, float* = nullptr, long = 0);
 int launch_cbam_mlp(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int,
                     float*, float*, float*, hipStream_t);
 int launch_cbam_sppool(const float*, long, const float*, int, int, int, float*, hipStream_t);
@@ -290,6 +291,11 @@ int smaat_cbam_pix_blocks(int N, int P) { return smaat_cbam_pix_blocks_impl(N, P
 int smaat_cbam_chpool(const float* x, long x_bs, int N, int C, int P, float* avg, float* mx, int* amax,
                       void* stream) {
     return launch_cbam_chpool(x, x_bs, N, C, P, avg, mx, amax, ST);
+}
+int smaat_cbam_chpool_act(const float* z, long z_bs, const float* scale, const float* shift, float* y, long y_bs, int N,
+                          int C, int P, float* avg, float* mx, int* amax, void* stream) {
+    if (!z || !scale || !shift || !y) return -1;
+    return launch_cbam_chpool(z, z_bs, N, C, P, avg, mx, amax, ST, scale, shift, y, y_bs);
 }
 int smaat_cbam_mlp(const float* avg, const float* mx, const float* w1, const float* b1, const float* w2,
                    const float* b2, int N, int C, int Cr, float* ha, float* hm, float* s, void* stream) {

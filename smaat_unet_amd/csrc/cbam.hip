@@ -13,13 +13,31 @@
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
 
 // ---------------------------------------------------------------------------------
+// ACT: x is the PRE-BatchNorm tensor of the block that feeds the attention (reference
+// unet_parts_depthwise_separable.py:34-35 in front of layers.py:107-108): y = relu(x * scale[c] + shift[c]) is formed on
+// load, pooled, and WRITTEN to y_out -- the block output is materialised by its first consumer, the separate
+// BatchNorm-apply + ReLU pass over it disappears.
+template <bool ACT>
 __global__ __launch_bounds__(256) void k_cbam_chpool(const float* __restrict__ x, long x_bs, int C, int P,
                                                      float* __restrict__ avg, float* __restrict__ mx,
-                                                     int* __restrict__ amax) {
+                                                     int* __restrict__ amax, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, float* __restrict__ y_out,
+                                                     long y_bs) {
     __shared__ float rf[8];
     __shared__ int ri[4];
     const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
     const float* xp = x + (long)n * x_bs + (long)c * P;
+    float* yp = ACT ? y_out + (long)n * y_bs + (long)c * P : nullptr;
+    const float asc = ACT ? scale[c] : 1.f, ash = ACT ? shift[c] : 0.f;
+    auto act4 = [&](float4 v) {
+        if (ACT) {  // the expression of k_affine_act: identical bits
+            v.x = fmaxf(fmaf(v.x, asc, ash), 0.f);
+            v.y = fmaxf(fmaf(v.y, asc, ash), 0.f);
+            v.z = fmaxf(fmaf(v.z, asc, ash), 0.f);
+            v.w = fmaxf(fmaf(v.w, asc, ash), 0.f);
+        }
+        return v;
+    };
     float s = 0.f, m = -INFINITY;
     int mi = 0x7fffffff;
     // branch-free running maximum (strictly greater: the first index wins, positions are visited in increasing
@@ -31,7 +49,8 @@ __global__ __launch_bounds__(256) void k_cbam_chpool(const float* __restrict__ x
         m = gt ? v : m;
         mi = gt ? p : mi;
     };
-    if ((P & 3) == 0 && (x_bs & 3) == 0 && ((((uintptr_t)x) & 15) == 0)) {
+    if ((P & 3) == 0 && (x_bs & 3) == 0 && ((((uintptr_t)x) & 15) == 0) &&
+        (!ACT || ((y_bs & 3) == 0 && ((((uintptr_t)y_out) & 15) == 0)))) {
         const int P4 = P >> 2;
         int q = threadIdx.x;
         for (; q + 768 < P4; q += 1024) {
@@ -41,6 +60,8 @@ __global__ __launch_bounds__(256) void k_cbam_chpool(const float* __restrict__ x
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int p = 4 * (q + 256 * u);
+                v[u] = act4(v[u]);
+                if (ACT) *(float4*)(yp + p) = v[u];
                 upd(v[u].x, p);
                 upd(v[u].y, p + 1);
                 upd(v[u].z, p + 2);
@@ -48,14 +69,22 @@ __global__ __launch_bounds__(256) void k_cbam_chpool(const float* __restrict__ x
             }
         }
         for (; q < P4; q += 256) {
-            const float4 v = *(const float4*)(xp + 4 * q);
+            const float4 v = act4(*(const float4*)(xp + 4 * q));
+            if (ACT) *(float4*)(yp + 4 * q) = v;
             upd(v.x, 4 * q);
             upd(v.y, 4 * q + 1);
             upd(v.z, 4 * q + 2);
             upd(v.w, 4 * q + 3);
         }
     } else {
-        for (int p = threadIdx.x; p < P; p += 256) upd(xp[p], p);
+        for (int p = threadIdx.x; p < P; p += 256) {
+            float v = xp[p];
+            if (ACT) {
+                v = fmaxf(fmaf(v, asc, ash), 0.f);
+                yp[p] = v;
+            }
+            upd(v, p);
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float ws = wave_sum_all(s);
@@ -876,8 +905,13 @@ int smaat_cbam_spconv_blocks_impl(int N, int H, int W) { return N * cdivc(H, SPT
 int smaat_cbam_pix_blocks_impl(int N, int P) { return N * cdivc(P, 256); }
 
 int launch_cbam_chpool(const float* x, long x_bs, int N, int C, int P, float* avg, float* mx, int* amax,
-                       hipStream_t st) {
-    hipLaunchKernelGGL(k_cbam_chpool, dim3(N * C), dim3(256), 0, st, x, x_bs, C, P, avg, mx, amax);
+                       hipStream_t st, const float* scale, const float* shift, float* y_out, long y_bs) {
+    if (scale)
+        hipLaunchKernelGGL(k_cbam_chpool<true>, dim3(N * C), dim3(256), 0, st, x, x_bs, C, P, avg, mx, amax, scale, shift,
+                           y_out, y_bs);
+    else
+        hipLaunchKernelGGL(k_cbam_chpool<false>, dim3(N * C), dim3(256), 0, st, x, x_bs, C, P, avg, mx, amax, nullptr,
+                           nullptr, nullptr, 0L);
     return (int)hipGetLastError();
 }
 int launch_cbam_mlp(const float* avg, const float* mx, const float* w1, const float* b1, const float* w2,

@@ -141,9 +141,22 @@ class CBAM(nn.Module):
         return (self.EVAL_FAST_PATH and not self.training and not bn.training and not torch.is_grad_enabled()
                 and bn.track_running_stats and bn.running_mean is not None)
 
+    @staticmethod
+    def _split_lazy(x):
+        """x is a tensor, or (z, st) from a block whose last BatchNorm + ReLU is deferred to this consumer (st rows:
+        mean, invstd, scale, shift)"""
+        if isinstance(x, tuple):
+            return x[0], (x[1][2], x[1][3])
+        return x, None
+
     def forward(self, x):
+        x, lazy = self._split_lazy(x)
         w1, b1, w2, b2 = self.channel_att._mlp_params()
         sp = self.spatial_att
+        if lazy is not None:
+            g, b, rm, rv, training, momentum, eps = _bn_args(sp.bn)
+            return ops.cbam(x, w1, b1, w2, b2, sp.conv.weight, g, b, rm, rv, training, momentum, eps, True, True,
+                            lazy=lazy)
         if self._eval_fast():  # inference: three launches, BatchNorm(1) on the running statistics
             import torch
             return torch.ops.smaat.cbam_infer(x, w1, b1, w2, b2, sp.conv.weight, sp.bn.weight, sp.bn.bias,
@@ -155,8 +168,13 @@ class CBAM(nn.Module):
         """(cat, pooled): CBAM(x) written into channels [0, C) of a fresh [N, C + c_extra, H, W]
         concatenation buffer, and maxpool2(x) -- the two consumers of an encoder level in
         SmaAt_UNet.forward, sharing one backward pass over x."""
+        x, lazy = self._split_lazy(x)
         w1, b1, w2, b2 = self.channel_att._mlp_params()
         sp = self.spatial_att
+        if lazy is not None:
+            g, b, rm, rv, training, momentum, eps = _bn_args(sp.bn)
+            return ops.cbam_pool_cat(x, w1, b1, w2, b2, sp.conv.weight, g, b, rm, rv, training, momentum, eps, c_extra,
+                                     lazy=lazy)
         if self._eval_fast():
             import torch
             return torch.ops.smaat.cbam_pool_cat_infer(x, w1, b1, w2, b2, sp.conv.weight, sp.bn.weight, sp.bn.bias,

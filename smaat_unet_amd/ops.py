@@ -563,7 +563,7 @@ class _DoubleConvDS(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_dw1, b_dw1, w_pw1, b_pw1, g1, be1, rm1, rv1, w_dw2, b_dw2, w_pw2, b_pw2, g2, be2, rm2, rv2,
-                tr1, mo1, eps1, tr2, mo2, eps2, kpl, w_out=None, b_out=None):
+                tr1, mo1, eps1, tr2, mo2, eps2, kpl, w_out=None, b_out=None, defer=False):
         _check(x, w_dw1, b_dw1, w_pw1, b_pw1, g1, be1, rm1, rv1, w_dw2, b_dw2, w_pw2, b_pw2, g2, be2, rm2, rv2, w_out,
                b_out)
         c1 = _expect_dsconv(x, w_dw1, b_dw1, w_pw1, b_pw1, kpl, (("double_conv.1.weight", g1), ("double_conv.1.bias", be1),
@@ -593,7 +593,7 @@ class _DoubleConvDS(torch.autograd.Function):
             _expect(b_out, (1,), "outc.conv.bias")
         y2, z2, st2, ydw2, ubs2 = _half_forward(z1 if fuse else y1, w_dw2, b_dw2, w_pw2, b_pw2, g2, be2, rm2, rv2, tr2,
                                                 mo2, eps2, kpl, keep_y, in_aff=(st1[2], st1[3]) if fuse else None,
-                                                want_act=not head)
+                                                want_act=not (head or defer))
         ctx.save_for_backward(x, w_dw1, b_dw1, w_pw1, g1, be1, z1, st1, ydw1, y1, w_dw2, b_dw2, w_pw2, g2, z2, st2,
                               ydw2, w_out)
         ctx.fuse = fuse
@@ -603,10 +603,17 @@ class _DoubleConvDS(torch.autograd.Function):
         ctx.head = (True, b_out is not None) if head else None
         if head:
             return _outconv1_fwd_raw(z2, st2[2], st2[3], w_out, b_out)
+        if defer:
+            # Deferred activation: the node hands out the PRE-BatchNorm tensor z2 with the coefficients of
+            # y2 = relu(z2 * scale + shift); its consumer (the attention block of the fused encoder wiring) applies and
+            # materialises the activation inside its first kernel and returns, as the gradient of this output, the
+            # gradient with respect to y2 -- which is what backward() below expects in every mode.
+            ctx.mark_non_differentiable(st2)
+            return z2, st2  # st2 rows: mean, invstd, scale, shift
         return y2
 
     @staticmethod
-    def backward(ctx, dy2):
+    def backward(ctx, dy2, *_unused):
         (x, w_dw1, b_dw1, w_pw1, g1, be1, z1, st1, ydw1, y1, w_dw2, b_dw2, w_pw2, g2, z2, st2,
          ydw2, w_out) = ctx.saved_tensors
         head = None
@@ -621,16 +628,18 @@ class _DoubleConvDS(torch.autograd.Function):
         ghead = (None, None)
         if head is not None:
             ghead = (head["dw"], _channel_sum_raw(head["dlog"]) if ctx.head[1] else None)
-        return gr1 + (None, None) + gr2[1:] + (None, None) + (None,) * 7 + ghead
+        return gr1 + (None, None) + gr2[1:] + (None, None) + (None,) * 7 + ghead + (None,)
 
 
-def double_conv_ds(x, half1, half2, kpl, head=None):
+def double_conv_ds(x, half1, half2, kpl, head=None, defer=False):
     """half = (w_dw, b_dw, w_pw, b_pw, gamma, beta, running_mean, running_var, training, momentum, eps).
     head = (w_out [1][C][1][1], b_out [1] or None): returns OutConv(block(x)) for an OutConv with ONE output channel,
     with the block output and its gradient never materialised (see _DoubleConvDS)."""
     a, b = half1, half2
     if head is not None:
         return _DoubleConvDS.apply(x, *a[:8], *b[:8], a[8], a[9], a[10], b[8], b[9], b[10], kpl, head[0], head[1])
+    if defer:  # -> (z2, st2): the consumer applies relu(z2 * st2[2] + st2[3]), see _DoubleConvDS.forward
+        return _DoubleConvDS.apply(x, *a[:8], *b[:8], a[8], a[9], a[10], b[8], b[9], b[10], kpl, None, None, True)
     return _DoubleConvDS.apply(x, *a[:8], *b[:8], a[8], a[9], a[10], b[8], b[9], b[10], kpl)
 
 
@@ -876,10 +885,16 @@ def upsample_cat(x1, x2):
 # CBAM (channel attention and/or spatial attention)
 # --------------------------------------------------------------------------------------
 def _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, use_ch, use_sp,
-                       out=None):
+                       out=None, lazy=None):
     """out = spatial_att(channel_att(x)); `out` may be a channel slice of a larger buffer (dense
-    planes, any batch stride).  Returns (out, saved tensors, flags)."""
+    planes, any batch stride).  Returns (out, saved tensors, flags).
+    lazy = (scale, shift): x is the PRE-BatchNorm tensor of the block in front (deferred activation, see
+    _DoubleConvDS): relu(x * scale + shift) is formed and written by the channel pooling kernel; saved[0] is that
+    activated tensor."""
     _check(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv)
+    if lazy is not None and not use_ch:  # no pooling kernel to fuse with: materialise up front
+        x = _affine_act_raw(x, lazy[0], lazy[1], True)
+        lazy = None
     if x.dim() != 4:
         raise ValueError(f"input: expected [N, C, H, W], got {tuple(x.shape)}")
     if use_ch:
@@ -905,8 +920,14 @@ def _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, 
         avg = _new(dev, n, c)
         mx = _new(dev, n, c)
         amax = _new(dev, n, c, dtype=torch.int32)
-        _lib.check(L.smaat_cbam_chpool(_ptr(x), x_bs, n, c, p, _ptr(avg), _ptr(mx), _ptr(amax), s_),
-                   "smaat_cbam_chpool")
+        if lazy is not None:
+            y = _new(dev, n, c, h, w)
+            _lib.check(L.smaat_cbam_chpool_act(_ptr(x), x_bs, _ptr(lazy[0]), _ptr(lazy[1]), _ptr(y), c * p, n, c, p,
+                                               _ptr(avg), _ptr(mx), _ptr(amax), s_), "smaat_cbam_chpool_act")
+            x, x_bs = y, c * p
+        else:
+            _lib.check(L.smaat_cbam_chpool(_ptr(x), x_bs, n, c, p, _ptr(avg), _ptr(mx), _ptr(amax), s_),
+                       "smaat_cbam_chpool")
         ha = _new(dev, n, cr)
         hm = _new(dev, n, cr)
         sc = _new(dev, n, c)
@@ -1073,9 +1094,11 @@ class _CBAM(torch.autograd.Function):
     ChannelAttention / SpatialAttention modules reuse the same kernels)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, use_ch, use_sp):
+    def forward(ctx, x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, use_ch, use_sp,
+                lazy_scale=None, lazy_shift=None):
+        lazy = (lazy_scale, lazy_shift) if lazy_scale is not None else None
         out, saved, flags = _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum,
-                                               eps, use_ch, use_sp)
+                                               eps, use_ch, use_sp, lazy=lazy)
         ctx.save_for_backward(*saved)
         ctx.flags = flags
         return out
@@ -1083,7 +1106,7 @@ class _CBAM(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         g = _cbam_backward_impl(ctx.saved_tensors, ctx.flags, dout)
-        return g + (None,) * 7
+        return g + (None,) * 9
 
 
 class _CBAMPoolCat(torch.autograd.Function):
@@ -1096,13 +1119,16 @@ class _CBAMPoolCat(torch.autograd.Function):
     gradient-accumulation add."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, c_extra):
+    def forward(ctx, x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, c_extra,
+                lazy_scale=None, lazy_shift=None):
         L = _lib.get()
         x, x_bs = _planes(x)
         n, c, h, w = x.shape
         cat = _new(x, n, c + c_extra, h, w)
+        lazy = (lazy_scale, lazy_shift) if lazy_scale is not None else None
         _, saved, flags = _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps,
-                                             True, True, out=cat[:, :c])
+                                             True, True, out=cat[:, :c], lazy=lazy)
+        x, x_bs = _planes(saved[0])  # (the activated tensor when the activation was deferred)
         pooled = _new(x, n, c, h // 2, w // 2)
         _lib.check(L.smaat_maxpool2_fwd(_ptr(x), x_bs, _ptr(pooled), c * (h // 2) * (w // 2), n, c, h, w,
                                         _stream(x)), "smaat_maxpool2_fwd")
@@ -1128,10 +1154,14 @@ class _CBAMPoolCat(torch.autograd.Function):
                 dpooled, dp_bs = _planes(dpooled)
                 _lib.check(L.smaat_maxpool2_bwd(_ptr(xx), x_bs, _ptr(dpooled), dp_bs, _ptr(dx), c * h * w, n, c, h, w, 1,
                                                 _stream(x)), "smaat_maxpool2_bwd")
-        return (dx,) + tuple(g[1:]) + (None,) * 6
+        return (dx,) + tuple(g[1:]) + (None,) * 8
 
 
-def cbam_pool_cat(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, c_extra):
+def cbam_pool_cat(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, c_extra, lazy=None):
+    """lazy = (scale, shift): x is a deferred-activation block output (see double_conv_ds(..., defer=True))"""
+    if lazy is not None:
+        return _CBAMPoolCat.apply(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, c_extra,
+                                  lazy[0], lazy[1])
     return _CBAMPoolCat.apply(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, c_extra)
 
 
@@ -1286,7 +1316,10 @@ def upconv_cat(x1, x2, w, b):
     return _UpConvCat.apply(x1, x2, w, b)
 
 
-def cbam(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, use_ch=True, use_sp=True):
+def cbam(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, use_ch=True, use_sp=True, lazy=None):
+    if lazy is not None:
+        return _CBAM.apply(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, use_ch, use_sp,
+                           lazy[0], lazy[1])
     return _CBAM.apply(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, use_ch, use_sp)
 
 

@@ -51,11 +51,22 @@ class DoubleConvDS(nn.Module):
                         for j in (1, 4))
                 and seq[0].kernels_per_layer_ == seq[3].kernels_per_layer_)
 
-    def forward(self, x, head=None):
+    def forward(self, x, head=None, defer=False):
         """head (internal, set by the network's fused wiring): the nn.Conv2d(C, 1, 1) of the OutConv that consumes this
-        block; the call then returns OutConv(block(x)) as one autograd node (ops.double_conv_ds(..., head=...))."""
+        block; the call then returns OutConv(block(x)) as one autograd node (ops.double_conv_ds(..., head=...)).
+        defer (internal, same wiring): return (z2, st2) -- the block output with its last BatchNorm + ReLU (coefficient
+        rows st2[2], st2[3]) left to the consumer -- when the block runs as the fused training node; a plain tensor otherwise."""
         seq = self.double_conv
         hooked = any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks for m in seq.modules())
+        if defer:
+            import torch
+            if (not hooked and torch.is_grad_enabled() and seq[0].kernels_per_layer_ == seq[3].kernels_per_layer_
+                    and seq[4].affine):
+                for conv in (seq[0], seq[3]):
+                    conv._check_geometry()
+                halves = [(seq[i].depthwise.weight, seq[i].depthwise.bias, seq[i].pointwise.weight,
+                           seq[i].pointwise.bias) + _bn_args(seq[i + 1]) for i in (0, 3)]
+                return ops.double_conv_ds(x, halves[0], halves[1], seq[0].kernels_per_layer_, defer=True)
         if head is not None:
             import torch
             if hooked or not torch.is_grad_enabled() or seq[0].kernels_per_layer_ != seq[3].kernels_per_layer_:

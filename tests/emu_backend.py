@@ -480,6 +480,10 @@ class EmuLib:
         f32(mx, N * C).reshape(N, C)[:] = np.take_along_axis(xv, am[..., None], axis=2)[..., 0]
         return 0
 
+    def smaat_cbam_chpool_act(self, z, z_bs, scale, shift, y, y_bs, N, C, P, avg, mx, amax, stream):
+        self.smaat_affine_act(z, z_bs, scale, shift, y, y_bs, N, C, P, 1, stream)
+        return self.smaat_cbam_chpool(y, y_bs, N, C, P, avg, mx, amax, stream)
+
     def smaat_cbam_mlp(self, avg, mx, w1, b1, w2, b2, N, C, Cr, ha, hm, s, stream):
         a, m = f32(avg, N * C).reshape(N, C), f32(mx, N * C).reshape(N, C)
         W1, B1 = f32(w1, Cr * C).reshape(Cr, C), f32(b1, Cr)

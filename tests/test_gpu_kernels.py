@@ -593,6 +593,33 @@ def test_pointwise_split_k_slices(shape):
         assert nws > 0  # the deep batch-1 layers are the ones this exists for
 
 
+def case_chpool_act(L, dev, N, C, H, W, pad_c=0):
+    """channel pooling with the BatchNorm + ReLU of the block in front applied on load and the activated tensor written
+    out: y bit-identical to smaat_affine_act, pools identical to pooling that y"""
+    Pn = H * W
+    zf = T(rnd(1, N, C + pad_c, H, W) * 1.2 - 0.1, dev)
+    z_bs = (C + pad_c) * Pn
+    sc, sh = T(np.random.default_rng(2).uniform(0.5, 1.5, C).astype(np.float32), dev), T(rnd(3, C, scale=0.3), dev)
+    s = stream(dev)
+    y = torch.full((N, C, H, W), float("nan"), device=dev)
+    avg, mx = torch.empty(N, C, device=dev), torch.empty(N, C, device=dev)
+    amax = torch.empty(N, C, dtype=torch.int32, device=dev)
+    assert L.smaat_cbam_chpool_act(P(zf), z_bs, P(sc), P(sh), P(y), C * Pn, N, C, Pn, P(avg), P(mx), P(amax), s) == 0
+    y2 = torch.empty_like(y)
+    assert L.smaat_affine_act(P(zf), z_bs, P(sc), P(sh), P(y2), C * Pn, N, C, Pn, 1, s) == 0
+    a2, m2 = torch.empty_like(avg), torch.empty_like(mx)
+    am2 = torch.empty_like(amax)
+    assert L.smaat_cbam_chpool(P(y2), C * Pn, N, C, Pn, P(a2), P(m2), P(am2), s) == 0
+    assert torch.equal(y, y2) and torch.equal(avg, a2) and torch.equal(mx, m2) and torch.equal(amax, am2)
+    return dict(y=y, avg=avg, mx=mx, amax=amax.float())
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 16, 16), (1, 3, 5, 7), (2, 64, 144, 144), (3, 5, 9, 12)])
+def test_cbam_chpool_act(shape):
+    both(case_chpool_act, *shape)
+    both(case_chpool_act, *shape, pad_c=2)
+
+
 def case_head(L, dev, N, C, H, W, pad_c=0):
     """OutConv with one output channel fused with the BatchNorm + ReLU in front of it: forward, backward reduction
     (+ the conv's weight gradient), backward apply"""
