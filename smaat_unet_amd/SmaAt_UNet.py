@@ -59,7 +59,9 @@ class UNetDSFamily(nn.Module):
         if self.cbam_levels < 4:
             return False
         downs, ups, cbams = self._levels()
-        for top in downs + ups + [c for c in cbams[:4] if c is not None]:
+        # (inc, outc and the bottleneck attention are called as modules, but with internal keyword arguments / tuple
+        # values of the deferred-activation and head fusions: a hook on them gets the module-by-module path as well)
+        for top in downs + ups + [c for c in cbams if c is not None] + [self.inc, self.outc]:
             for mm in top.modules():
                 if mm._forward_hooks or mm._forward_pre_hooks or mm._backward_hooks:
                     return False
