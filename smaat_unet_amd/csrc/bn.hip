@@ -158,8 +158,7 @@ __global__ __launch_bounds__(256) void k_affine_act(const float* __restrict__ z,
     const bool vec = ((P & 3) == 0) && ((z_bs & 3) == 0) && ((y_bs & 3) == 0) && ((seg_len & 3) == 0) &&
                      ((((uintptr_t)z) & 15) == 0) && ((((uintptr_t)y) & 15) == 0);
     if (vec) {
-        for (int p = p0 + threadIdx.x * 4; p < p1; p += 1024) {
-            float4 v = *(const float4*)(zp + p);
+        auto one = [&](float4 v, int p) {
             v.x = fmaf(v.x, sc, sh);
             v.y = fmaf(v.y, sc, sh);
             v.z = fmaf(v.z, sc, sh);
@@ -171,7 +170,14 @@ __global__ __launch_bounds__(256) void k_affine_act(const float* __restrict__ z,
                 v.w = fmaxf(v.w, 0.f);
             }
             *(float4*)(yp + p) = v;
+        };
+        int p = p0 + threadIdx.x * 4;  // two positions per trip: both loads issued before the first store
+        for (; p + 1024 < p1; p += 2048) {
+            const float4 a = *(const float4*)(zp + p), b = *(const float4*)(zp + p + 1024);
+            one(a, p);
+            one(b, p + 1024);
         }
+        if (p < p1) one(*(const float4*)(zp + p), p);
     } else {
         for (int p = p0 + threadIdx.x; p < p1; p += 256) {
             float v = fmaf(zp[p], sc, sh);
@@ -212,9 +218,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
     const bool vec = ((P & 3) == 0) && ((z_bs & 3) == 0) && ((dy_bs & 3) == 0) && ((seg_len & 3) == 0) &&
                      ((((uintptr_t)z) & 15) == 0) && ((((uintptr_t)dy) & 15) == 0);
     if (vec) {
-        for (int p = p0 + threadIdx.x * 4; p < p1; p += 1024) {
-            const float4 zv = *(const float4*)(zp + p);
-            const float4 gv = *(const float4*)(gp + p);
+        auto one = [&](const float4 zv, const float4 gv) {
             const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
             const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
@@ -226,7 +230,15 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
                 s2 = fmaf(g, (zz[j] - mu) * is, s2);
                 if (HEAD) s3 = fmaf(gg[j], RELU ? fmaxf(a, 0.f) : a, s3);
             }
+        };
+        int p = p0 + threadIdx.x * 4;  // two positions per trip: four loads in flight (same summation order)
+        for (; p + 1024 < p1; p += 2048) {
+            const float4 za = *(const float4*)(zp + p), ga = *(const float4*)(gp + p);
+            const float4 zb = *(const float4*)(zp + p + 1024), gb = *(const float4*)(gp + p + 1024);
+            one(za, ga);
+            one(zb, gb);
         }
+        if (p < p1) one(*(const float4*)(zp + p), *(const float4*)(gp + p));
     } else {
         for (int p = p0 + threadIdx.x; p < p1; p += 256) {
             const float zz = zp[p];
@@ -307,9 +319,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                      ((seg_len & 3) == 0) && ((((uintptr_t)z) & 15) == 0) && ((((uintptr_t)dy) & 15) == 0) &&
                      ((((uintptr_t)dz) & 15) == 0);
     if (vec) {
-        for (int p = p0 + threadIdx.x * 4; p < p1; p += 1024) {
-            const float4 zv = *(const float4*)(zp + p);
-            const float4 gv = *(const float4*)(gp + p);
+        auto one = [&](const float4 zv, const float4 gv, int p) {
             const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
             const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
             float o[4];
@@ -320,7 +330,17 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                 o[j] = c1 * (g - c2 - (zz[j] - mu) * is * c3);
             }
             *(float4*)(op + p) = make_float4(o[0], o[1], o[2], o[3]);
+        };
+        // two positions per trip, their four loads issued together (one position per trip waits for its two loads
+        // with nothing else in flight: scripts/asm_lint.py DRAIN)
+        int p = p0 + threadIdx.x * 4;
+        for (; p + 1024 < p1; p += 2048) {
+            const float4 za = *(const float4*)(zp + p), ga = *(const float4*)(gp + p);
+            const float4 zb = *(const float4*)(zp + p + 1024), gb = *(const float4*)(gp + p + 1024);
+            one(za, ga, p);
+            one(zb, gb, p + 1024);
         }
+        if (p < p1) one(*(const float4*)(zp + p), *(const float4*)(gp + p), p);
     } else {
         for (int p = p0 + threadIdx.x; p < p1; p += 256) {
             const float zz = zp[p];
