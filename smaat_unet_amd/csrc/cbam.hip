@@ -252,15 +252,21 @@ __global__ __launch_bounds__(256) void k_cbam_apply(const float* __restrict__ x,
                      ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)out) & 15) == 0) &&
                      ((((uintptr_t)gate) & 15) == 0);
     if (vec) {
-        for (int p = p0 + threadIdx.x * 4; p < p1; p += 1024) {
-            float4 v = *(const float4*)(xp + p);
-            const float4 g = *(const float4*)(gp + p);
+        auto one = [&](float4 v, const float4 g, int p) {
             v.x = v.x * sv * g.x;
             v.y = v.y * sv * g.y;
             v.z = v.z * sv * g.z;
             v.w = v.w * sv * g.w;
             *(float4*)(op + p) = v;
+        };
+        int p = p0 + threadIdx.x * 4;  // two positions per trip: four loads in flight
+        for (; p + 1024 < p1; p += 2048) {
+            const float4 xa = *(const float4*)(xp + p), ga = *(const float4*)(gp + p);
+            const float4 xb = *(const float4*)(xp + p + 1024), gb = *(const float4*)(gp + p + 1024);
+            one(xa, ga, p);
+            one(xb, gb, p + 1024);
         }
+        if (p < p1) one(*(const float4*)(xp + p), *(const float4*)(gp + p), p);
     } else {
         for (int p = p0 + threadIdx.x; p < p1; p += 256) op[p] = xp[p] * sv * gp[p];
     }
@@ -724,16 +730,15 @@ __global__ __launch_bounds__(64) void k_cbam_bwd_main_v4(const float* __restrict
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(dsrow, 0, C * 4, 0x00020000);
     const unsigned dvo = valid ? (unsigned)pp * 4u : 0x80000000u;
     const unsigned svo = threadIdx.x == 63 ? 0u : 0x80000000u;
-    float4 xn = *(const float4*)(xp);
-    float4 gn = *(const float4*)(gp);
-    float sn = sp[0];
-    for (int c = 0; c < C; ++c) {
-        const float4 xv = xn, gv = gn;
-        const float sv = sn;
-        const int cn = c + 1 < C ? c + 1 : c;
-        xn = *(const float4*)(xp + (long)cn * P);
-        gn = *(const float4*)(gp + (long)cn * P);
-        sn = sp[cn];
+    // two channels per trip, the loads of the NEXT two in flight meanwhile (four 16-byte loads per lane); a channel
+    // index beyond C reads clamped addresses and its stores fall outside the buffer ranges (dropped by the hardware)
+    auto ld = [&](int c, float4& xv, float4& gv, float& sv) {
+        const int cc = c < C ? c : C - 1;
+        xv = *(const float4*)(xp + (long)cc * P);
+        gv = *(const float4*)(gp + (long)cc * P);
+        sv = sp[cc];
+    };
+    auto process = [&](const float4 xv, const float4 gv, const float sv, int c) {
         float4 dxs;
         dxs.x = fmaf(gv.x, g.x, da.x);
         dxs.y = fmaf(gv.y, g.y, da.y);
@@ -758,6 +763,20 @@ __global__ __launch_bounds__(64) void k_cbam_bwd_main_v4(const float* __restrict
         float r = valid ? (dxs.x * xv.x + dxs.y * xv.y) + (dxs.z * xv.z + dxs.w * xv.w) : 0.f;
         r = wave_sum_l63(r);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r), srs, svo + (unsigned)c * 4u, 0, 0);
+    };
+    float4 xa, ga, xb, gb;
+    float sa, sb;
+    ld(0, xa, ga, sa);
+    ld(1, xb, gb, sb);
+    for (int c = 0; c < C; c += 2) {
+        const float4 x0 = xa, g0 = ga, x1 = xb, g1 = gb;
+        const float s0 = sa, s1 = sb;
+        ld(c + 2, xa, ga, sa);
+        ld(c + 3, xb, gb, sb);
+        process(x0, g0, s0, c);
+        // (c + 1 == C for an odd channel count: a clamped duplicate of the last channel whose stores are dropped; the
+        // first-maximum flags it may set are not read again)
+        process(x1, g1, s1, c + 1 < C ? c + 1 : C);
     }
 }
 
