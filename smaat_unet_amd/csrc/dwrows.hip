@@ -12,7 +12,7 @@
 //   * the 3 x 6 window it needs (its float4 and the two neighbouring columns, three rows) lives in registers and
 //     slides by one row per step: per row one global_load_dwordx4 + two edge dwords (L1 hits: the neighbour lane's
 //     float4) per channel, one global_store_dwordx4 per output channel;
-//   * forward: the row after next is always in flight (rotating register windows, manual unroll by 4);
+//   * forward: the two rows after next are always in flight (three rotating windows + three raw load sets, unroll by 3);
 //   * a wave never straddles two planes, so the per-channel weights live in SGPRs; workgroups are just four
 //     consecutive waves of the (plane, wave-in-plane) list -- no LDS, no barrier anywhere;
 //   * the weight / bias gradient partials reduce with DPP wave sums: one partial row per (image, wave of the plane),
@@ -156,10 +156,11 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const float* __restrict_
     const float asc = aff ? in_scale[ci] : 1.f, ash = aff ? in_shift[ci] : 0.f;
     const DwrLane ln = dwr_lane(lane, q, g.ncol4);
 
-    // before step r (u = (r - r0) % 4): Wn[u] = row r - 1, Wn[u + 1] = row r, raw[u & 1] = row r + 1 in flight; the
-    // step issues row r + 2, then finishes row r + 1 into Wn[u + 2]   (indices mod 4 / mod 2)
-    float Wn[4][6];
-    DwrRaw raw[2];
+    // before step r (u = (r - r0) % 3): Wn[u] = row r - 1, Wn[u + 1] = row r, raw[u] = row r + 1 and raw[u + 1] = row
+    // r + 2 in flight; the step issues row r + 3 into raw[u + 2], then finishes row r + 1 into Wn[u + 2] (the slot of the
+    // dead row r - 2)   (indices mod 3: two rows of loads stay in flight behind the one being consumed)
+    float Wn[3][6];
+    DwrRaw raw[3];
     auto compute = [&](int r, const float (&R0)[6], const float (&R1)[6], const float (&R2)[6]) {
 #pragma unroll
         for (int j = 0; j < KPL; ++j) {
@@ -181,25 +182,27 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const float* __restrict_
     {
         DwrRaw a = dwr_issue(xp, r0 - 1, g.H, g.W, ln), b = dwr_issue(xp, r0, g.H, g.W, ln);
         raw[0] = dwr_issue(xp, r0 + 1, g.H, g.W, ln);
+        raw[1] = dwr_issue(xp, r0 + 2, g.H, g.W, ln);
         dwr_pin(a);
         dwr_pin(b);
         dwr_finish(Wn[0], a, r0 - 1, g.H, ln, aff, asc, ash);
         dwr_finish(Wn[1], b, r0, g.H, ln, aff, asc, ash);
     }
-    for (int i = 0; i < g.BH; i += 4) {
+    for (int i = 0; i < g.BH; i += 3) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 3; ++u) {
             if (i + u < g.BH) {
                 const int r = r0 + i + u;
-                raw[(u + 1) & 1] = dwr_issue(xp, r + 2, g.H, g.W, ln);
-                dwr_pin(raw[u & 1]);  // row r + 1 (issued one step ago)
-                dwr_finish(Wn[(u + 2) & 3], raw[u & 1], r + 1, g.H, ln, aff, asc, ash);
-                compute(r, Wn[u], Wn[(u + 1) & 3], Wn[(u + 2) & 3]);
+                raw[(u + 2) % 3] = dwr_issue(xp, r + 3, g.H, g.W, ln);
+                dwr_pin(raw[u]);  // row r + 1 (issued two steps ago)
+                dwr_finish(Wn[(u + 2) % 3], raw[u], r + 1, g.H, ln, aff, asc, ash);
+                compute(r, Wn[u], Wn[(u + 1) % 3], Wn[(u + 2) % 3]);
             }
         }
     }
     dwr_pin(raw[0]);  // (loads still in flight target live registers)
     dwr_pin(raw[1]);
+    dwr_pin(raw[2]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
