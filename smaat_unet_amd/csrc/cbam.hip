@@ -281,7 +281,9 @@ __global__ __launch_bounds__(256) void k_cbam_apply(const float* __restrict__ x,
 //                          (a fixed affine map: no grid-wide reduction) + sigmoid -> gate, then
 //                          out = x * s * gate for the block's channel range, and pooled = maxpool2(x) from the same loads
 // reference: models/layers.py:105-111, 122-129, 138-141; unet_parts_depthwise_separable.py:48
-__global__ __launch_bounds__(256) void k_cbam_mlp_sppool(const float* __restrict__ x, long x_bs,
+// NWV waves per block (4, or 16 when the plane gives too few blocks: the channel loop of a wave is then 4x shorter)
+template <int NWV>
+__global__ __launch_bounds__(NWV * 64) void k_cbam_mlp_sppool(const float* __restrict__ x, long x_bs,
                                                          const float* __restrict__ avg, const float* __restrict__ mx,
                                                          const float* __restrict__ w1, const float* __restrict__ b1,
                                                          const float* __restrict__ w2, const float* __restrict__ b2, int C,
@@ -293,9 +295,10 @@ __global__ __launch_bounds__(256) void k_cbam_mlp_sppool(const float* __restrict
     float* sl = lm + C;        // [C]
     float* ha = sl + C;        // [Cr]
     float* hm = ha + Cr;       // [Cr]
-    float4* red = (float4*)(sm + ((3 * C + 2 * Cr + 3) & ~3));  // [2][4 waves][64 lanes], 16-byte aligned
+    constexpr int NT = NWV * 64;
+    float4* red = (float4*)(sm + ((3 * C + 2 * Cr + 3) & ~3));  // [2][NWV waves][64 lanes], 16-byte aligned
     const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += NT) {
         la[c] = avg[(long)n * C + c];
         lm[c] = mx[(long)n * C + c];
     }
@@ -305,8 +308,8 @@ __global__ __launch_bounds__(256) void k_cbam_mlp_sppool(const float* __restrict
     // spread over 16 lanes (quarter wave) with all its loads issued before the DPP row sum, an output channel reads its
     // Cr contiguous weights with the loop unrolled.
     {
-        const int q16 = tid >> 4, l16 = tid & 15;  // 16 groups of 16 lanes
-        for (int j = q16; j < Cr; j += 16) {
+        const int q16 = tid >> 4, l16 = tid & 15;  // NT / 16 groups of 16 lanes
+        for (int j = q16; j < Cr; j += NT / 16) {
             float pa = 0.f, pm = 0.f;
             const float* wr = w1 + (long)j * C;
 #pragma unroll 4
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(256) void k_cbam_mlp_sppool(const float* __restrict
         }
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += NT) {
         float oa = b2[c], om = b2[c];
         const float* wr = w2 + (long)c * Cr;
 #pragma unroll 8
@@ -346,19 +349,19 @@ __global__ __launch_bounds__(256) void k_cbam_mlp_sppool(const float* __restrict
         const float* xp = x + (long)n * x_bs + p;
         if (vec) {
             int c = wave;
-            for (; c + 12 < C; c += 16) {  // four loads in flight
+            for (; c + 3 * NWV < C; c += 4 * NWV) {  // four loads in flight
                 float4 v[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(xp + (long)(c + 4 * u) * P);
+                for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(xp + (long)(c + NWV * u) * P);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const float sv = sl[c + 4 * u];
+                    const float sv = sl[c + NWV * u];
                     const float a = v[u].x * sv, b = v[u].y * sv, cc = v[u].z * sv, d = v[u].w * sv;
                     sum.x += a; sum.y += b; sum.z += cc; sum.w += d;
                     m.x = fmaxf(m.x, a); m.y = fmaxf(m.y, b); m.z = fmaxf(m.z, cc); m.w = fmaxf(m.w, d);
                 }
             }
-            for (; c < C; c += 4) {
+            for (; c < C; c += NWV) {
                 const float4 v = *(const float4*)(xp + (long)c * P);
                 const float sv = sl[c];
                 const float a = v.x * sv, b = v.y * sv, cc = v.z * sv, d = v.w * sv;
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(256) void k_cbam_mlp_sppool(const float* __restrict
                 m.x = fmaxf(m.x, a); m.y = fmaxf(m.y, b); m.z = fmaxf(m.z, cc); m.w = fmaxf(m.w, d);
             }
         } else {
-            for (int c = wave; c < C; c += 4) {
+            for (int c = wave; c < C; c += NWV) {
                 const float sv = sl[c];
                 float e[4];
 #pragma unroll
@@ -377,13 +380,13 @@ __global__ __launch_bounds__(256) void k_cbam_mlp_sppool(const float* __restrict
         }
     }
     red[wave * 64 + lane] = sum;
-    red[256 + wave * 64 + lane] = m;
+    red[NT + wave * 64 + lane] = m;
     __syncthreads();
     if (wave == 0 && p < P) {
-        float4 ts = red[lane], tm = red[256 + lane];
+        float4 ts = red[lane], tm = red[NT + lane];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            const float4 a = red[w * 64 + lane], b = red[256 + w * 64 + lane];
+        for (int w = 1; w < NWV; ++w) {
+            const float4 a = red[w * 64 + lane], b = red[NT + w * 64 + lane];
             ts.x += a.x; ts.y += a.y; ts.z += a.z; ts.w += a.w;
             tm.x = fmaxf(tm.x, b.x); tm.y = fmaxf(tm.y, b.y); tm.z = fmaxf(tm.z, b.z); tm.w = fmaxf(tm.w, b.w);
         }
@@ -969,9 +972,16 @@ int launch_cbam_apply(const float* x, long x_bs, const float* s, const float* ga
 int launch_cbam_eval_pool(const float* x, long x_bs, const float* avg, const float* mx, const float* w1, const float* b1,
                           const float* w2, const float* b2, int N, int C, int Cr, int P, float* s_out, float* maps,
                           hipStream_t st) {
-    const size_t lds = sizeof(float) * (size_t)((3 * C + 2 * Cr + 3) & ~3) + 2 * 256 * sizeof(float4);
-    hipLaunchKernelGGL(k_cbam_mlp_sppool, dim3(cdivc(P, 256), N), dim3(256), lds, st, x, x_bs, avg, mx, w1, b1, w2, b2, C,
-                       Cr, P, s_out, maps);
+    const int blocks = cdivc(P, 256) * N;
+    if (blocks < 128 && C >= 64) {  // deep levels at small batch: 16 waves share the channels of a 256-pixel block
+        const size_t lds = sizeof(float) * (size_t)((3 * C + 2 * Cr + 3) & ~3) + 2 * 1024 * sizeof(float4);
+        hipLaunchKernelGGL(k_cbam_mlp_sppool<16>, dim3(cdivc(P, 256), N), dim3(1024), lds, st, x, x_bs, avg, mx, w1, b1, w2,
+                           b2, C, Cr, P, s_out, maps);
+    } else {
+        const size_t lds = sizeof(float) * (size_t)((3 * C + 2 * Cr + 3) & ~3) + 2 * 256 * sizeof(float4);
+        hipLaunchKernelGGL(k_cbam_mlp_sppool<4>, dim3(cdivc(P, 256), N), dim3(256), lds, st, x, x_bs, avg, mx, w1, b1, w2, b2,
+                           C, Cr, P, s_out, maps);
+    }
     return (int)hipGetLastError();
 }
 int launch_cbam_eval_apply(const float* x, long x_bs, const float* s, const float* maps, const float* wc, int ks,
@@ -979,7 +989,9 @@ int launch_cbam_eval_apply(const float* x, long x_bs, const float* s, const floa
                            int C, int H, int W, float* out, long out_bs, float* pooled, long pooled_bs, hipStream_t st) {
     if (ks != 3 && ks != 7) return -1;
     const int tx = cdivc(W, GAT_TW), ty = cdivc(H, GAT_TH);
-    int csplit = 512 / (tx * ty * N);  // enough blocks to fill the chip on the small planes of the deep levels
+    // enough blocks to fill the chip AND to keep a block's channel loop short: at batch 1 a block that walks all 64
+    // channels of a 288^2 tile is a 64-step load chain (19 us); the gate is cheap to recompute per channel slice
+    int csplit = 2048 / (tx * ty * N);
     if (csplit > C / 8) csplit = C / 8;
     if (csplit < 1) csplit = 1;
     if ((long)N * csplit > 65535) csplit = 1;
