@@ -8,7 +8,7 @@
  * signatures and state_dict keys.
  *
  * Conventions
- *  - all tensors are float32, NCHW, device pointers; "plane" = H*W contiguous floats;
+ *  - all tensors are float32 (bf16 storage: the "mixed precision" section), NCHW, device pointers; "plane" = H*W contiguous floats;
  *    channel stride = H*W; batch stride is passed explicitly (`*_bs`, in elements) so
  *    that a tensor may be a channel slice of a larger concatenation buffer.
  *  - no allocation, no synchronisation, no global state inside: workspaces are passed in,
@@ -286,6 +286,92 @@ int smaat_dsconv_fwd_split_act(const float* x, long x_bs, const float* in_scale,
                                long z_bs, int N, int Cin, int kpl, int Cout, int H, int W, int relu_out, void* stream);
 int smaat_pointwise_fwd_split_act(const float* x, long x_bs, const void* planes, const float* bias, float* out,
                                   long out_bs, int N, int Cin, int M, int H, int W, int relu_out, void* stream);
+
+/* ================= mixed precision: bf16 activation storage (BASELINE.json configs[3]) =================================
+ * The reference has no AMP switch (train_precip_lightning.py:71-72 leaves set_float32_matmul_precision commented out);
+ * what a maintainer would turn on is Lightning's precision="bf16-mixed" = torch.autocast around the nn.Modules of
+ * models/SmaAt_UNet.py:41-57.  This section is that mode built natively: every activation tensor of the network and its
+ * gradient is stored as bf16 (2 bytes per element in HBM -- in bf16 every layer is HBM-bound), all arithmetic
+ * is f32 in registers, the pointwise GEMMs run ONE v_mfma_f32_32x32x16_bf16 per product with f32 accumulation, weights
+ * (f32 masters), weight gradients, BatchNorm statistics / partial sums and the small attention maps stay f32.
+ *
+ * Conventions: a tensor argument of variable element type is a `const void*` / `void*` followed (or described) by a dtype
+ * code: SMAAT_DT_F32 = 0, SMAAT_DT_BF16 = 1; strides stay in ELEMENTS.  "-2" = this combination of shape / alignment /
+ * dtypes is not built (the f32 entry points above cover everything in f32).  Entry points named *_t are the typed forms of
+ * the f32 entry points of the same name: same arithmetic, same argument meaning, same reference call sites.
+ */
+#define SMAAT_DT_F32 0
+#define SMAAT_DT_BF16 1
+
+/* pointwise.weight (f32 master, [R][C] row-major; transposed != 0: the image of the TRANSPOSE of a matrix stored [C][R]) ->
+ * bf16 image [ceil32(C)/16][R][16] (contraction chunk major, zero padded): the A operand of smaat_pointwise_fwd_bf16.
+ * reference: the weight of nn.Conv2d(K, Cout, 1), models/layers.py:45 (forward: R x C = Cout x K; data gradient: K x Cout). */
+int smaat_bf16_planes(const float* w, int R, int C, void* planes, int transposed, void* stream);
+/* out[n][m][p] = sum_c A[m][c] x[n][c][p] + bias[m]  (x bf16 [N][Cin][P], out bf16 or f32 per out_dt; bias, part f32):
+ * the pointwise conv of DepthwiseSeparableConv.forward (models/layers.py:49) on the depthwise output, and its data
+ * gradient dY = W^T dZ (A = transposed image, bias = null).  part: nullable [3][smaat_pw_split_num_slots(N,H,W)][M]
+ * BatchNorm partials (mean, M2, count per 128-pixel tile) of the f32 accumulators; relu_out: max(., 0) in the epilogue.
+ * LDS-DMA operand staging + ds_read_b64_tr_b16 transposed fragment reads (csrc/bf16gemm.hip).  -2: odd H*W. */
+int smaat_pointwise_fwd_bf16(const void* x, long x_bs, const void* planes, const float* bias, void* out, long out_bs,
+                             int out_dt, float* part, int N, int Cin, int M, int H, int W, int relu_out, void* stream);
+/* dW[m][k] = sum_{n,p} dz[n][m][p] * y[n][k][p] with bf16 dz, y and f32 accumulation / output (autograd of the same
+ * nn.Conv2d); ws: [smaat_wgrad_num_splits(N,H,W,M,Cin)][M][Cin] floats, dw_out [M][Cin]. */
+int smaat_pointwise_wgrad_bf16(const void* y, long y_bs, const void* dz, long dz_bs, float* ws, float* dw_out, int N,
+                               int Cin, int M, int H, int W, void* stream);
+/* typed smaat_dw3x3_fwd (models/layers.py:38-44,48): (x_dt, y_dt) in {(f32,f32), (f32,bf16), (bf16,bf16)} */
+int smaat_dw3x3_fwd_t(const void* x, int x_dt, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                      const float* b_dw, void* y, int y_dt, long y_bs, int N, int Cin, int kpl, int H, int W,
+                      void* stream);
+/* typed smaat_dw3x3_bwd / smaat_dw3x3_bwd_bnred (rpart != null selects the fused BatchNorm reduction, which then needs
+ * in_scale / in_shift / bn_mean / bn_invstd / dx): (x_dt, dy_dt, dx_dt) in {(f32,f32,f32), (bf16,bf16,bf16), (f32,bf16,f32)} */
+int smaat_dw3x3_bwd_t(const void* x, int x_dt, long x_bs, const float* in_scale, const float* in_shift, const void* dy,
+                      int dy_dt, long dy_bs, const float* w_dw, void* dx, int dx_dt, long dx_bs, float* ws, float* dw_out,
+                      float* db_out, const float* bn_mean, const float* bn_invstd, float* rpart, int N, int Cin, int kpl,
+                      int H, int W, void* stream);
+/* typed smaat_affine_act (nn.BatchNorm2d + nn.ReLU apply, unet_parts_depthwise_separable.py:25-26,34-35) */
+int smaat_affine_act_t(const void* z, int z_dt, long z_bs, const float* scale, const float* shift, void* y, int y_dt,
+                       long y_bs, int N, int C, int P, int relu, void* stream);
+/* typed smaat_bn_bwd_reduce / _apply; head_w != null: the *_head forms (dy is dlog [N][1][P], f32), see above.
+ * (dy_dt, z_dt[, dz_dt]) in {all f32, all bf16, (f32, bf16[, bf16])} */
+int smaat_bn_bwd_reduce_t(const void* dy, int dy_dt, long dy_bs, const void* z, int z_dt, long z_bs, const float* scale,
+                          const float* shift, const float* mean, const float* invstd, float* part, int N, int C, int P,
+                          int relu, const float* head_w, void* stream);
+int smaat_bn_bwd_apply_t(const void* dy, int dy_dt, long dy_bs, const void* z, int z_dt, long z_bs, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, const float* coef, void* dz,
+                         int dz_dt, long dz_bs, int N, int C, int P, int relu, const float* head_w, void* stream);
+/* typed smaat_outconv1_fwd (logits stay f32) and smaat_channel_sum */
+int smaat_outconv1_fwd_t(const void* z, int z_dt, long z_bs, const float* scale, const float* shift, const float* w,
+                         const float* b, float* out, long out_bs, int N, int C, int P, void* stream);
+int smaat_channel_sum_t(const void* x, int x_dt, long x_bs, int N, int C, int P, float* ws, float* out, void* stream);
+/* typed MaxPool2d(2) and bilinear Upsample + pad (unet_parts_depthwise_separable.py:48,64,76-85): one dtype `dt` for
+ * every tensor argument.  The upsample forms exist for the row-walking kernels only (-2 otherwise in bf16). */
+int smaat_maxpool2_fwd_t(const void* x, long x_bs, void* y, long y_bs, int N, int C, int H, int W, int dt, void* stream);
+int smaat_maxpool2_bwd_t(const void* x, long x_bs, const void* dy, long dy_bs, void* dx, long dx_bs, int N, int C, int H,
+                         int W, int accum, int dt, void* stream);
+int smaat_upsample2x_fwd_t(const void* x, long x_bs, void* out, long out_bs, int N, int C, int H, int W, int Ho, int Wo,
+                           int pad_t, int pad_l, int dt, void* stream);
+int smaat_upsample2x_bwd_t(const void* dout, long dout_bs, void* dx, long dx_bs, int N, int C, int H, int W, int Ho,
+                           int Wo, int pad_t, int pad_l, int dt, void* stream);
+/* typed CBAM passes over the activation-sized tensors (models/layers.py:105-141); x / y / out / dout / dx / dpool all have
+ * element type `dt`, the per-(n, c) vectors, the 2-channel maps and the gate stay f32.  smaat_cbam_chpool_t with
+ * scale != null is smaat_cbam_chpool_act (pools taken over the values as stored). */
+int smaat_cbam_chpool_t(const void* x, long x_bs, const float* scale, const float* shift, void* y, long y_bs, int N,
+                        int C, int P, float* avg, float* mx, int* amax, int dt, void* stream);
+int smaat_cbam_sppool_t(const void* x, long x_bs, const float* s, int N, int C, int P, float* maps, int dt,
+                        void* stream);
+int smaat_cbam_apply_t(const void* x, long x_bs, const float* s, const float* gate, void* out, long out_bs, int N, int C,
+                       int P, int dt, void* stream);
+int smaat_cbam_bwd_gate_t(const void* dout, long dout_bs, const void* x, long x_bs, const float* s, const float* gate,
+                          const float* conv, const float* mean, const float* invstd, int N, int C, int P, float* dbn,
+                          float* part, int dt, void* stream);
+int smaat_cbam_bwd_main_t(const void* dout, long dout_bs, const void* x, long x_bs, const float* s, const float* gate,
+                          const float* maps, const float* dmaps, int N, int C, int P, void* dx, long dx_bs,
+                          float* dspart, int dt, void* stream);
+int smaat_cbam_bwd_final_t(void* dx, long dx_bs, const float* davg, const float* dmx, const int* amax, int N, int C,
+                           int P, int dt, void* stream);
+int smaat_cbam_bwd_final_pool_t(void* dx, long dx_bs, const float* davg, const float* dmx, const int* amax, const void* x,
+                                long x_bs, const void* dpool, long dp_bs, int N, int C, int H, int W, int dt,
+                                void* stream);
 
 /* ---- on-device PrecipitationMetrics.update ---------------------------------------------
  * replaces metric/precipitation_metrics.py:37-95 (called every train/val/test step, models/regression_lightning.py:

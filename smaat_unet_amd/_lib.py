@@ -84,6 +84,28 @@ SIGNATURES = {
     "smaat_pointwise_fwd_split_act": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "smaat_pointwise_splitk_ws_floats": [_I, _I, _I, _I, _I],
     "smaat_pointwise_fwd_split_act_k": [_P, _L, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P],
+    # ---- mixed precision (bf16 activation storage) ----
+    "smaat_bf16_planes": [_P, _I, _I, _P, _I, _P],
+    "smaat_pointwise_fwd_bf16": [_P, _L, _P, _P, _P, _L, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "smaat_pointwise_wgrad_bf16": [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _P],
+    "smaat_dw3x3_fwd_t": [_P, _I, _L, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P],
+    "smaat_dw3x3_bwd_t": [_P, _I, _L, _P, _P, _P, _I, _L, _P, _P, _I, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "smaat_affine_act_t": [_P, _I, _L, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P],
+    "smaat_bn_bwd_reduce_t": [_P, _I, _L, _P, _I, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "smaat_bn_bwd_apply_t": [_P, _I, _L, _P, _I, _L, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P, _P],
+    "smaat_outconv1_fwd_t": [_P, _I, _L, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "smaat_channel_sum_t": [_P, _I, _L, _I, _I, _I, _P, _P, _P],
+    "smaat_maxpool2_fwd_t": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _P],
+    "smaat_maxpool2_bwd_t": [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "smaat_upsample2x_fwd_t": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "smaat_upsample2x_bwd_t": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "smaat_cbam_chpool_t": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _I, _P],
+    "smaat_cbam_sppool_t": [_P, _L, _P, _I, _I, _I, _P, _I, _P],
+    "smaat_cbam_apply_t": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "smaat_cbam_bwd_gate_t": [_P, _L, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P],
+    "smaat_cbam_bwd_main_t": [_P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P, _I, _P],
+    "smaat_cbam_bwd_final_t": [_P, _L, _P, _P, _P, _I, _I, _I, _I, _P],
+    "smaat_cbam_bwd_final_pool_t": [_P, _L, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P],
     "smaat_precip_metrics_ws_bytes": [_L],
     "smaat_precip_metrics_update": [_P, _P, _L, _I, _F, _F, _I, _P, _P, _P, _P],
 }

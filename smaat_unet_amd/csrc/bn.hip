@@ -144,19 +144,20 @@ __global__ __launch_bounds__(NTH) void k_bn_finalize(const float* __restrict__ p
 // y = [relu](z * scale[c] + shift[c]) over [N][C][P] planes with batch strides
 // grid: (N*C planes, segments)
 // ---------------------------------------------------------------------------------
-template <bool RELU>
-__global__ __launch_bounds__(256) void k_affine_act(const float* __restrict__ z, long z_bs,
+// TZ / TY: element types of z and y (f32 | bf16 storage, common.h)
+template <bool RELU, typename TZ, typename TY>
+__global__ __launch_bounds__(256) void k_affine_act(const TZ* __restrict__ z, long z_bs,
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
-                                                    float* __restrict__ y, long y_bs, int C, int P, int seg_len) {
+                                                    TY* __restrict__ y, long y_bs, int C, int P, int seg_len) {
     const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
     const float sc = scale[c], sh = shift[c];
-    const float* zp = z + (long)n * z_bs + (long)c * P;
-    float* yp = y + (long)n * y_bs + (long)c * P;
+    const TZ* zp = z + (long)n * z_bs + (long)c * P;
+    TY* yp = y + (long)n * y_bs + (long)c * P;
     const int p0 = blockIdx.y * seg_len;
     int p1 = p0 + seg_len;
     if (p1 > P) p1 = P;
     const bool vec = ((P & 3) == 0) && ((z_bs & 3) == 0) && ((y_bs & 3) == 0) && ((seg_len & 3) == 0) &&
-                     ((((uintptr_t)z) & 15) == 0) && ((((uintptr_t)y) & 15) == 0);
+                     ((((uintptr_t)z) & Elem<TZ>::vmask) == 0) && ((((uintptr_t)y) & Elem<TY>::vmask) == 0);
     if (vec) {
         auto one = [&](float4 v, int p) {
             v.x = fmaf(v.x, sc, sh);
@@ -169,20 +170,20 @@ __global__ __launch_bounds__(256) void k_affine_act(const float* __restrict__ z,
                 v.z = fmaxf(v.z, 0.f);
                 v.w = fmaxf(v.w, 0.f);
             }
-            *(float4*)(yp + p) = v;
+            st4(yp + p, v);
         };
         int p = p0 + threadIdx.x * 4;  // two positions per trip: both loads issued before the first store
         for (; p + 1024 < p1; p += 2048) {
-            const float4 a = *(const float4*)(zp + p), b = *(const float4*)(zp + p + 1024);
-            one(a, p);
-            one(b, p + 1024);
+            const auto a = ldraw4(zp + p), b = ldraw4(zp + p + 1024);
+            one(cvt4(a), p);
+            one(cvt4(b), p + 1024);
         }
-        if (p < p1) one(*(const float4*)(zp + p), p);
+        if (p < p1) one(ld4(zp + p), p);
     } else {
         for (int p = p0 + threadIdx.x; p < p1; p += 256) {
-            float v = fmaf(zp[p], sc, sh);
+            float v = fmaf(ld1(zp + p), sc, sh);
             if (RELU) v = fmaxf(v, 0.f);
-            yp[p] = v;
+            st1(yp + p, v);
         }
     }
 }
@@ -196,9 +197,10 @@ __global__ __launch_bounds__(256) void k_affine_act(const float* __restrict__ z,
 // reference models/unet_parts.py:67-73) whose gradient dlog [N][P] is given instead of dy: dy[n][c][p] = hw[c] *
 // dlog[n][p] is formed on the fly (the same single product ATen's conv backward stores), and the kernel also emits that
 // convolution's weight gradient, part[2][slot][c] = sum dlog * y.  The 64-channel dy tensor is never written or read.
-template <bool RELU, bool HEAD>
-__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__ dy, long dy_bs,
-                                                       const float* __restrict__ z, long z_bs,
+// TG / TZ: element types of dy (HEAD: of dlog) and z
+template <bool RELU, bool HEAD, typename TG, typename TZ>
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const TG* __restrict__ dy, long dy_bs,
+                                                       const TZ* __restrict__ z, long z_bs,
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
                                                        const float* __restrict__ mean,
@@ -209,14 +211,14 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
     const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
     const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
     const float wc = HEAD ? hw[c] : 1.f;
-    const float* zp = z + (long)n * z_bs + (long)c * P;
-    const float* gp = dy + (long)n * dy_bs + (HEAD ? 0L : (long)c * P);
+    const TZ* zp = z + (long)n * z_bs + (long)c * P;
+    const TG* gp = dy + (long)n * dy_bs + (HEAD ? 0L : (long)c * P);
     const int p0 = blockIdx.y * seg_len;
     int p1 = p0 + seg_len;
     if (p1 > P) p1 = P;
     float s1 = 0.f, s2 = 0.f, s3 = 0.f;
     const bool vec = ((P & 3) == 0) && ((z_bs & 3) == 0) && ((dy_bs & 3) == 0) && ((seg_len & 3) == 0) &&
-                     ((((uintptr_t)z) & 15) == 0) && ((((uintptr_t)dy) & 15) == 0);
+                     ((((uintptr_t)z) & Elem<TZ>::vmask) == 0) && ((((uintptr_t)dy) & Elem<TG>::vmask) == 0);
     if (vec) {
         auto one = [&](const float4 zv, const float4 gv) {
             const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
@@ -233,17 +235,19 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
         };
         int p = p0 + threadIdx.x * 4;  // two positions per trip: four loads in flight (same summation order)
         for (; p + 1024 < p1; p += 2048) {
-            const float4 za = *(const float4*)(zp + p), ga = *(const float4*)(gp + p);
-            const float4 zb = *(const float4*)(zp + p + 1024), gb = *(const float4*)(gp + p + 1024);
-            one(za, ga);
-            one(zb, gb);
+            const auto za = ldraw4(zp + p);
+            const auto ga = ldraw4(gp + p);
+            const auto zb = ldraw4(zp + p + 1024);
+            const auto gb = ldraw4(gp + p + 1024);
+            one(cvt4(za), cvt4(ga));
+            one(cvt4(zb), cvt4(gb));
         }
-        if (p < p1) one(*(const float4*)(zp + p), *(const float4*)(gp + p));
+        if (p < p1) one(ld4(zp + p), ld4(gp + p));
     } else {
         for (int p = p0 + threadIdx.x; p < p1; p += 256) {
-            const float zz = zp[p];
+            const float zz = ld1(zp + p);
             const float a = fmaf(zz, sc, sh);
-            const float g0 = gp[p];
+            const float g0 = ld1(gp + p);
             float g = HEAD ? wc * g0 : g0;
             if (RELU && !(a > 0.f)) g = 0.f;
             s1 += g;
@@ -295,29 +299,29 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict
 }
 
 // backward pass 2: dz = c1 * (g - c2 - xhat * c3)
-template <bool RELU, bool HEAD>
-__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dy, long dy_bs,
-                                                      const float* __restrict__ z, long z_bs,
+template <bool RELU, bool HEAD, typename TG, typename TZ, typename TD>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const TG* __restrict__ dy, long dy_bs,
+                                                      const TZ* __restrict__ z, long z_bs,
                                                       const float* __restrict__ scale,
                                                       const float* __restrict__ shift,
                                                       const float* __restrict__ mean,
                                                       const float* __restrict__ invstd,
-                                                      const float* __restrict__ coef, float* __restrict__ dz,
+                                                      const float* __restrict__ coef, TD* __restrict__ dz,
                                                       long dz_bs, int C, int P, int seg_len,
                                                       const float* __restrict__ hw) {
     const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
     const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
     const float c1 = coef[c], c2 = coef[C + c], c3 = coef[2 * C + c];
     const float wc = HEAD ? hw[c] : 1.f;  // HEAD: dy[n][c][p] = hw[c] * dlog[n][p], see k_bn_bwd_reduce
-    const float* zp = z + (long)n * z_bs + (long)c * P;
-    const float* gp = dy + (long)n * dy_bs + (HEAD ? 0L : (long)c * P);
-    float* op = dz + (long)n * dz_bs + (long)c * P;
+    const TZ* zp = z + (long)n * z_bs + (long)c * P;
+    const TG* gp = dy + (long)n * dy_bs + (HEAD ? 0L : (long)c * P);
+    TD* op = dz + (long)n * dz_bs + (long)c * P;
     const int p0 = blockIdx.y * seg_len;
     int p1 = p0 + seg_len;
     if (p1 > P) p1 = P;
     const bool vec = ((P & 3) == 0) && ((z_bs & 3) == 0) && ((dy_bs & 3) == 0) && ((dz_bs & 3) == 0) &&
-                     ((seg_len & 3) == 0) && ((((uintptr_t)z) & 15) == 0) && ((((uintptr_t)dy) & 15) == 0) &&
-                     ((((uintptr_t)dz) & 15) == 0);
+                     ((seg_len & 3) == 0) && ((((uintptr_t)z) & Elem<TZ>::vmask) == 0) &&
+                     ((((uintptr_t)dy) & Elem<TG>::vmask) == 0) && ((((uintptr_t)dz) & Elem<TD>::vmask) == 0);
     if (vec) {
         auto one = [&](const float4 zv, const float4 gv, int p) {
             const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
@@ -329,24 +333,26 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                 if (RELU && !(fmaf(zz[j], sc, sh) > 0.f)) g = 0.f;
                 o[j] = c1 * (g - c2 - (zz[j] - mu) * is * c3);
             }
-            *(float4*)(op + p) = make_float4(o[0], o[1], o[2], o[3]);
+            st4(op + p, make_float4(o[0], o[1], o[2], o[3]));
         };
         // two positions per trip, their four loads issued together (one position per trip waits for its two loads
         // with nothing else in flight: scripts/asm_lint.py DRAIN)
         int p = p0 + threadIdx.x * 4;
         for (; p + 1024 < p1; p += 2048) {
-            const float4 za = *(const float4*)(zp + p), ga = *(const float4*)(gp + p);
-            const float4 zb = *(const float4*)(zp + p + 1024), gb = *(const float4*)(gp + p + 1024);
-            one(za, ga, p);
-            one(zb, gb, p + 1024);
+            const auto za = ldraw4(zp + p);
+            const auto ga = ldraw4(gp + p);
+            const auto zb = ldraw4(zp + p + 1024);
+            const auto gb = ldraw4(gp + p + 1024);
+            one(cvt4(za), cvt4(ga), p);
+            one(cvt4(zb), cvt4(gb), p + 1024);
         }
-        if (p < p1) one(*(const float4*)(zp + p), *(const float4*)(gp + p), p);
+        if (p < p1) one(ld4(zp + p), ld4(gp + p), p);
     } else {
         for (int p = p0 + threadIdx.x; p < p1; p += 256) {
-            const float zz = zp[p];
-            float g = HEAD ? wc * gp[p] : gp[p];
+            const float zz = ld1(zp + p);
+            float g = HEAD ? wc * ld1(gp + p) : ld1(gp + p);
             if (RELU && !(fmaf(zz, sc, sh) > 0.f)) g = 0.f;
-            op[p] = c1 * (g - c2 - (zz - mu) * is * c3);
+            st1(op + p, c1 * (g - c2 - (zz - mu) * is * c3));
         }
     }
 }
@@ -387,16 +393,17 @@ __global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ p
 }
 
 // part[slot][c] = sum over one plane segment of x[n][c][:]   (bias gradients; finished by k_reduce_rows)
-__global__ __launch_bounds__(256) void k_plane_sum(const float* __restrict__ x, long x_bs, int C, int P, int seg_len,
+template <typename T>
+__global__ __launch_bounds__(256) void k_plane_sum(const T* __restrict__ x, long x_bs, int C, int P, int seg_len,
                                                    float* __restrict__ part) {
     __shared__ float red[4];
     const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
-    const float* xp = x + (long)n * x_bs + (long)c * P;
+    const T* xp = x + (long)n * x_bs + (long)c * P;
     const int p0 = blockIdx.y * seg_len;
     int p1 = p0 + seg_len;
     if (p1 > P) p1 = P;
     float ls = 0.f;
-    for (int p = p0 + threadIdx.x; p < p1; p += 256) ls += xp[p];
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) ls += ld1(xp + p);
     const float t = block_sum_t0(ls, red);
     if (threadIdx.x == 0) part[(long)(n * gridDim.y + blockIdx.y) * C + c] = t;
 }
@@ -454,31 +461,51 @@ int launch_bn_finalize(float* part, int T, int C, double count, const float* bia
     return (int)hipGetLastError();
 }
 
-int launch_affine_act(const float* z, long z_bs, const float* scale, const float* shift, float* y, long y_bs, int N,
-                      int C, int P, int relu, hipStream_t st) {
+// *_dt: SMAAT_F32 | SMAAT_BF16 element type of the tensor argument in front of it.  Built combinations: all f32; all
+// bf16; (HEAD) f32 dlog with bf16 z / dz.  -2 otherwise.
+int launch_affine_act(const void* z, int z_dt, long z_bs, const float* scale, const float* shift, void* y, int y_dt,
+                      long y_bs, int N, int C, int P, int relu, hipStream_t st) {
     const int seg = plane_seg_len(P);
     dim3 grid(N * C, cdiv(P, seg));
-    if (relu)
-        hipLaunchKernelGGL(k_affine_act<true>, grid, dim3(256), 0, st, z, z_bs, scale, shift, y, y_bs, C, P, seg);
-    else
-        hipLaunchKernelGGL(k_affine_act<false>, grid, dim3(256), 0, st, z, z_bs, scale, shift, y, y_bs, C, P, seg);
+#define AFF_GO(R, TZ, TY)                                                                                          \
+    hipLaunchKernelGGL((k_affine_act<R, TZ, TY>), grid, dim3(256), 0, st, (const TZ*)z, z_bs, scale, shift, (TY*)y, y_bs, C, \
+                       P, seg)
+#define AFF_T(TZ, TY)                              \
+    do {                                           \
+        if (relu) AFF_GO(true, TZ, TY); else AFF_GO(false, TZ, TY); \
+    } while (0)
+    if (z_dt == SMAAT_F32 && y_dt == SMAAT_F32) AFF_T(float, float);
+    else if (z_dt == SMAAT_BF16 && y_dt == SMAAT_BF16) AFF_T(bf16_t, bf16_t);
+    else if (z_dt == SMAAT_BF16 && y_dt == SMAAT_F32) AFF_T(bf16_t, float);
+    else if (z_dt == SMAAT_F32 && y_dt == SMAAT_BF16) AFF_T(float, bf16_t);
+    else return -2;
+#undef AFF_T
+#undef AFF_GO
     return (int)hipGetLastError();
 }
 
-int launch_bn_bwd_reduce(const float* dy, long dy_bs, const float* z, long z_bs, const float* scale,
+int launch_bn_bwd_reduce(const void* dy, int dy_dt, long dy_bs, const void* z, int z_dt, long z_bs, const float* scale,
                          const float* shift, const float* mean, const float* invstd, float* part, int N, int C, int P,
                          int relu, hipStream_t st, const float* hw) {
     const int seg = plane_seg_len(P);
     dim3 grid(N * C, cdiv(P, seg));
     const int slots = N * grid.y;
-#define BNR_GO(R, H)                                                                                                  \
-    hipLaunchKernelGGL((k_bn_bwd_reduce<R, H>), grid, dim3(256), 0, st, dy, dy_bs, z, z_bs, scale, shift, mean, invstd, \
-                       part, C, P, seg, slots, hw)
-    if (hw) {
-        if (relu) BNR_GO(true, true); else BNR_GO(false, true);
-    } else {
-        if (relu) BNR_GO(true, false); else BNR_GO(false, false);
-    }
+#define BNR_GO(R, H, TG, TZ)                                                                                         \
+    hipLaunchKernelGGL((k_bn_bwd_reduce<R, H, TG, TZ>), grid, dim3(256), 0, st, (const TG*)dy, dy_bs, (const TZ*)z, z_bs,  \
+                       scale, shift, mean, invstd, part, C, P, seg, slots, hw)
+#define BNR_T(TG, TZ)                                                          \
+    do {                                                                       \
+        if (hw) {                                                              \
+            if (relu) BNR_GO(true, true, TG, TZ); else BNR_GO(false, true, TG, TZ);   \
+        } else {                                                               \
+            if (relu) BNR_GO(true, false, TG, TZ); else BNR_GO(false, false, TG, TZ); \
+        }                                                                      \
+    } while (0)
+    if (dy_dt == SMAAT_F32 && z_dt == SMAAT_F32) BNR_T(float, float);
+    else if (dy_dt == SMAAT_BF16 && z_dt == SMAAT_BF16) BNR_T(bf16_t, bf16_t);
+    else if (dy_dt == SMAAT_F32 && z_dt == SMAAT_BF16) BNR_T(float, bf16_t);
+    else return -2;
+#undef BNR_T
 #undef BNR_GO
     return (int)hipGetLastError();
 }
@@ -490,19 +517,27 @@ int launch_bn_bwd_finalize(const float* part, int slots, int C, double count, co
     return (int)hipGetLastError();
 }
 
-int launch_bn_bwd_apply(const float* dy, long dy_bs, const float* z, long z_bs, const float* scale,
-                        const float* shift, const float* mean, const float* invstd, const float* coef, float* dz,
+int launch_bn_bwd_apply(const void* dy, int dy_dt, long dy_bs, const void* z, int z_dt, long z_bs, const float* scale,
+                        const float* shift, const float* mean, const float* invstd, const float* coef, void* dz, int dz_dt,
                         long dz_bs, int N, int C, int P, int relu, hipStream_t st, const float* hw) {
     const int seg = plane_seg_len(P);
     dim3 grid(N * C, cdiv(P, seg));
-#define BNA_GO(R, H)                                                                                                 \
-    hipLaunchKernelGGL((k_bn_bwd_apply<R, H>), grid, dim3(256), 0, st, dy, dy_bs, z, z_bs, scale, shift, mean, invstd, \
-                       coef, dz, dz_bs, C, P, seg, hw)
-    if (hw) {
-        if (relu) BNA_GO(true, true); else BNA_GO(false, true);
-    } else {
-        if (relu) BNA_GO(true, false); else BNA_GO(false, false);
-    }
+#define BNA_GO(R, H, TG, TZ, TD)                                                                                        \
+    hipLaunchKernelGGL((k_bn_bwd_apply<R, H, TG, TZ, TD>), grid, dim3(256), 0, st, (const TG*)dy, dy_bs, (const TZ*)z, z_bs,  \
+                       scale, shift, mean, invstd, coef, (TD*)dz, dz_bs, C, P, seg, hw)
+#define BNA_T(TG, TZ, TD)                                                              \
+    do {                                                                               \
+        if (hw) {                                                                      \
+            if (relu) BNA_GO(true, true, TG, TZ, TD); else BNA_GO(false, true, TG, TZ, TD);   \
+        } else {                                                                       \
+            if (relu) BNA_GO(true, false, TG, TZ, TD); else BNA_GO(false, false, TG, TZ, TD); \
+        }                                                                              \
+    } while (0)
+    if (dy_dt == SMAAT_F32 && z_dt == SMAAT_F32 && dz_dt == SMAAT_F32) BNA_T(float, float, float);
+    else if (dy_dt == SMAAT_BF16 && z_dt == SMAAT_BF16 && dz_dt == SMAAT_BF16) BNA_T(bf16_t, bf16_t, bf16_t);
+    else if (dy_dt == SMAAT_F32 && z_dt == SMAAT_BF16 && dz_dt == SMAAT_BF16) BNA_T(float, bf16_t, bf16_t);
+    else return -2;
+#undef BNA_T
 #undef BNA_GO
     return (int)hipGetLastError();
 }
@@ -513,24 +548,28 @@ int launch_bn_bwd_apply(const float* dy, long dy_bs, const float* z, long z_bs, 
 // A thread owns four pixels and walks the channels (coalesced float4 rows); the block output of the last decoder level
 // is never written.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_outconv1_fwd(const float* __restrict__ z, long z_bs,
+template <typename TZ>
+__global__ __launch_bounds__(256) void k_outconv1_fwd(const TZ* __restrict__ z, long z_bs,
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
                                                       const float* __restrict__ w, const float* __restrict__ b,
                                                       float* __restrict__ out, long out_bs, int C, int P) {
     const int n = blockIdx.y;
     const long p = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (p >= P) return;
-    const float* zp = z + (long)n * z_bs + p;
+    const TZ* zp = z + (long)n * z_bs + p;
     const float b0 = b ? b[0] : 0.f;
     float4 acc = make_float4(b0, b0, b0, b0);
-    const bool vec = ((P & 3) == 0) && ((z_bs & 3) == 0) && ((out_bs & 3) == 0) && ((((uintptr_t)z) & 15) == 0) &&
-                     ((((uintptr_t)out) & 15) == 0);
+    const bool vec = ((P & 3) == 0) && ((z_bs & 3) == 0) && ((out_bs & 3) == 0) &&
+                     ((((uintptr_t)z) & Elem<TZ>::vmask) == 0) && ((((uintptr_t)out) & 15) == 0);
     if (vec) {
         int c = 0;
         for (; c + 3 < C; c += 4) {  // four rows in flight
+            typename Elem<TZ>::raw4 vr[4];
             float4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(zp + (long)(c + u) * P);
+            for (int u = 0; u < 4; ++u) vr[u] = ldraw4(zp + (long)(c + u) * P);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = cvt4(vr[u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float sc = scale[c + u], sh = shift[c + u], wc = w[c + u];
@@ -541,7 +580,7 @@ __global__ __launch_bounds__(256) void k_outconv1_fwd(const float* __restrict__ 
             }
         }
         for (; c < C; ++c) {
-            const float4 v = *(const float4*)(zp + (long)c * P);
+            const float4 v = ld4(zp + (long)c * P);
             const float sc = scale[c], sh = shift[c], wc = w[c];
             acc.x = fmaf(wc, fmaxf(fmaf(v.x, sc, sh), 0.f), acc.x);
             acc.y = fmaf(wc, fmaxf(fmaf(v.y, sc, sh), 0.f), acc.y);
@@ -555,7 +594,7 @@ __global__ __launch_bounds__(256) void k_outconv1_fwd(const float* __restrict__ 
             const float sc = scale[c], sh = shift[c], wc = w[c];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (p + q < P) a[q] = fmaf(wc, fmaxf(fmaf(zp[(long)c * P + q], sc, sh), 0.f), a[q]);
+                if (p + q < P) a[q] = fmaf(wc, fmaxf(fmaf(ld1(zp + (long)c * P + q), sc, sh), 0.f), a[q]);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -563,10 +602,11 @@ __global__ __launch_bounds__(256) void k_outconv1_fwd(const float* __restrict__ 
     }
 }
 
-int launch_outconv1_fwd(const float* z, long z_bs, const float* scale, const float* shift, const float* w, const float* b,
-                        float* out, long out_bs, int N, int C, int P, hipStream_t st) {
-    hipLaunchKernelGGL(k_outconv1_fwd, dim3(cdiv(P, 1024), N), dim3(256), 0, st, z, z_bs, scale, shift, w, b, out, out_bs, C,
-                       P);
+int launch_outconv1_fwd(const void* z, int z_dt, long z_bs, const float* scale, const float* shift, const float* w,
+                        const float* b, float* out, long out_bs, int N, int C, int P, hipStream_t st) {
+    SMAAT_DISPATCH_ET(z_dt, TZ,
+        hipLaunchKernelGGL(k_outconv1_fwd<TZ>, dim3(cdiv(P, 1024), N), dim3(256), 0, st, (const TZ*)z, z_bs, scale, shift, w,
+                           b, out, out_bs, C, P););
     return (int)hipGetLastError();
 }
 
@@ -588,10 +628,10 @@ int launch_reduce_rows(const float* part, int rows, long len, float* out, float 
     return (int)hipGetLastError();
 }
 
-int launch_channel_sum(const float* x, long x_bs, int N, int C, int P, float* ws, float* out, hipStream_t st) {
+int launch_channel_sum(const void* x, int x_dt, long x_bs, int N, int C, int P, float* ws, float* out, hipStream_t st) {
     const int seg = plane_seg_len(P);
     dim3 grid(N * C, cdiv(P, seg));
-    hipLaunchKernelGGL(k_plane_sum, grid, dim3(256), 0, st, x, x_bs, C, P, seg, ws);
+    SMAAT_DISPATCH_ET(x_dt, T, hipLaunchKernelGGL(k_plane_sum<T>, grid, dim3(256), 0, st, (const T*)x, x_bs, C, P, seg, ws););
     const int slots = N * grid.y;
     hipLaunchKernelGGL(k_reduce_rows, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)ws, slots, (long)C, 1, out, 1.f);
     return (int)hipGetLastError();

@@ -16,58 +16,64 @@ int smaat_wgrad_num_splits_impl(int N, int P, int M, int K);
 int launch_bn_finalize(float*, int, int, double, const float*, const float*, const float*, float, float, float*,
                        float*, float*, float*, float*, float*, hipStream_t);
 int launch_bn_eval_coefs(const float*, const float*, const float*, const float*, float, int, float*, hipStream_t);
-int launch_affine_act(const float*, long, const float*, const float*, float*, long, int, int, int, int, hipStream_t);
+int launch_affine_act(const void*, int, long, const float*, const float*, void*, int, long, int, int, int, int, hipStream_t);
 int smaat_bn_bwd_num_slots_impl(int N, int P);
-int launch_bn_bwd_reduce(const float*, long, const float*, long, const float*, const float*, const float*, const float*,
-                         float*, int, int, int, int, hipStream_t, const float* hw = nullptr);
+int launch_bn_bwd_reduce(const void*, int, long, const void*, int, long, const float*, const float*, const float*,
+                         const float*, float*, int, int, int, int, hipStream_t, const float* hw = nullptr);
 int launch_bn_bwd_finalize(const float*, int, int, double, const float*, const float*, float*, float*, float*,
                            hipStream_t);
-int launch_bn_bwd_apply(const float*, long, const float*, long, const float*, const float*, const float*, const float*,
-                        const float*, float*, long, int, int, int, int, hipStream_t, const float* hw = nullptr);
-int launch_outconv1_fwd(const float*, long, const float*, const float*, const float*, const float*, float*, long, int, int,
-                        int, hipStream_t);
+int launch_bn_bwd_apply(const void*, int, long, const void*, int, long, const float*, const float*, const float*,
+                        const float*, const float*, void*, int, long, int, int, int, int, hipStream_t,
+                        const float* hw = nullptr);
+int launch_outconv1_fwd(const void*, int, long, const float*, const float*, const float*, const float*, float*, long, int,
+                        int, int, hipStream_t);
 int launch_reduce_rows(const float*, int, long, float*, float, hipStream_t);
-int launch_channel_sum(const float*, long, int, int, int, float*, float*, hipStream_t);
+int launch_channel_sum(const void*, int, long, int, int, int, float*, float*, hipStream_t);
 int launch_copy_planes(const float*, long, float*, long, int, long, int, hipStream_t);
 
-int launch_maxpool2_fwd(const float*, long, float*, long, int, int, int, int, hipStream_t);
-int launch_maxpool2_bwd(const float*, long, const float*, long, float*, long, int, int, int, int, int, hipStream_t);
-int launch_upsample2x_fwd(const float*, long, float*, long, int, int, int, int, int, int, int, int, hipStream_t);
-int launch_upsample2x_bwd(const float*, long, float*, long, int, int, int, int, int, int, int, int, hipStream_t);
+int launch_maxpool2_fwd(const void*, long, void*, long, int, int, int, int, hipStream_t, int dt = SMAAT_F32);
+int launch_maxpool2_bwd(const void*, long, const void*, long, void*, long, int, int, int, int, int, hipStream_t,
+                        int dt = SMAAT_F32);
+int launch_upsample2x_fwd(const void*, long, void*, long, int, int, int, int, int, int, int, int, hipStream_t,
+                          int dt = SMAAT_F32);
+int launch_upsample2x_bwd(const void*, long, void*, long, int, int, int, int, int, int, int, int, hipStream_t,
+                          int dt = SMAAT_F32);
 int launch_pixel_shuffle2_fwd(const float*, long, const float*, float*, long, int, int, int, int, int, int, int, int,
                               hipStream_t);
 int launch_pixel_shuffle2_bwd(const float*, long, float*, long, int, int, int, int, int, int, int, int, hipStream_t);
-int launch_dw3x3_bwd(const float*, long, const float*, long, const float*, float*, long, float*, int, int, int, int,
-                     int, hipStream_t, const float*, const float*, float*, const float*, const float*);
+int launch_dw3x3_bwd(const void*, int, long, const void*, int, long, const float*, void*, int, long, float*, int, int, int,
+                     int, int, hipStream_t, const float*, const float*, float*, const float*, const float*);
 int dw_bwd_groups(int N, int Cin, int H, int W);
 int launch_dw_reduce_split(const float* part, int rows, int Cdw, float* dw, float* db, hipStream_t st);
 int dw3x3_strip_ok(int kpl, int H, int W);
 
 int smaat_cbam_spconv_blocks_impl(int N, int H, int W);
 int smaat_cbam_pix_blocks_impl(int N, int P);
-int launch_cbam_chpool(const float*, long, int, int, int, float*, float*, int*, hipStream_t, const float* = nullptr,
-                       const float* = nullptr, float* = nullptr, long = 0);
+int launch_cbam_chpool(const void*, long, int, int, int, float*, float*, int*, hipStream_t, const float* = nullptr,
+                       const float* = nullptr, void* = nullptr, long = 0, int dt = SMAAT_F32);
 int launch_cbam_mlp(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int,
                     float*, float*, float*, hipStream_t);
-int launch_cbam_sppool(const float*, long, const float*, int, int, int, float*, hipStream_t);
+int launch_cbam_sppool(const void*, long, const float*, int, int, int, float*, hipStream_t, int dt = SMAAT_F32);
 int launch_cbam_spconv(const float*, const float*, int, int, int, int, float*, float*, hipStream_t);
 int launch_cbam_gate(const float*, const float*, const float*, long, float*, hipStream_t);
-int launch_cbam_apply(const float*, long, const float*, const float*, float*, long, int, int, int, hipStream_t);
+int launch_cbam_apply(const void*, long, const float*, const float*, void*, long, int, int, int, hipStream_t,
+                      int dt = SMAAT_F32);
 int launch_cbam_eval_pool(const float*, long, const float*, const float*, const float*, const float*, const float*,
                           const float*, int, int, int, int, float*, float*, hipStream_t);
 int launch_cbam_eval_apply(const float*, long, const float*, const float*, const float*, int, const float*, const float*,
                            const float*, const float*, float, int, int, int, int, float*, long, float*, long, hipStream_t);
-int launch_cbam_bwd_gate(const float*, long, const float*, long, const float*, const float*, const float*,
-                         const float*, const float*, int, int, int, float*, float*, hipStream_t);
+int launch_cbam_bwd_gate(const void*, long, const void*, long, const float*, const float*, const float*,
+                         const float*, const float*, int, int, int, float*, float*, hipStream_t, int dt = SMAAT_F32);
 int launch_cbam_bwd_spconv(const float*, const float*, const float*, const float*, const float*, const float*,
                            const float*, int, int, int, int, float*, float*, hipStream_t);
-int launch_cbam_bwd_main(const float*, long, const float*, long, const float*, const float*, const float*,
-                         const float*, int, int, int, float*, long, float*, hipStream_t);
+int launch_cbam_bwd_main(const void*, long, const void*, long, const float*, const float*, const float*,
+                         const float*, int, int, int, void*, long, float*, hipStream_t, int dt = SMAAT_F32);
 int launch_cbam_bwd_mlp(const float*, const float*, const float*, const float*, const float*, const float*,
                         const float*, const float*, int, int, int, float*, float*, float*, hipStream_t);
-int launch_cbam_bwd_final(float*, long, const float*, const float*, const int*, int, int, int, hipStream_t);
-int launch_cbam_final_pool_bwd(float*, long, const float*, const float*, const int*, const float*, long, const float*, long,
-                               int, int, int, int, hipStream_t);
+int launch_cbam_bwd_final(void*, long, const float*, const float*, const int*, int, int, int, hipStream_t,
+                          int dt = SMAAT_F32);
+int launch_cbam_final_pool_bwd(void*, long, const float*, const float*, const int*, const void*, long, const void*, long,
+                               int, int, int, int, hipStream_t, int dt = SMAAT_F32);
 
 
 struct DsSplitArgs {  // dsconv_split.hip
@@ -99,8 +105,13 @@ long precip_metrics_ws_bytes(long n);                                           
 int launch_precip_metrics_update(const float* preds, const float* target, long n, int batch, float factor, float thr,
                                  int denorm, void* ws, double* state_f64, long long* state_i64, hipStream_t st);
 int launch_pw_split(PwSplitArgs& a, hipStream_t st);
-int launch_dw3x3_fwd(const float*, long, const float*, const float*, float*, long, int, int, int, int, int, hipStream_t,
-                     const float*, const float*);
+int launch_dw3x3_fwd(const void*, int, long, const float*, const float*, void*, int, long, int, int, int, int, int,
+                     hipStream_t, const float*, const float*);
+
+// bf16gemm.hip (mixed precision)
+int launch_bf16_planes(const float* w, int R, int C, bf16_t* out, int src_t, hipStream_t st);
+int launch_pw_bf16(PwBfArgs& a, int out_dt, hipStream_t st);
+int launch_wgrad_bf16(WgBfArgs& a, hipStream_t st);
 
 #define ST ((hipStream_t)(((void)hipGetLastError()), stream))
 #define CHK(e)              \
@@ -186,7 +197,8 @@ int smaat_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, cons
     const int Cdw = Cin * kpl;
     hipStream_t st = ST;
     const int rows = N * dw_bwd_groups(N, Cin, H, W);
-    CHK(launch_dw3x3_bwd(x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, ws, N, Cin, kpl, H, W, st, nullptr, nullptr, nullptr, nullptr, nullptr));
+    CHK(launch_dw3x3_bwd(x, SMAAT_F32, x_bs, dy, SMAAT_F32, dy_bs, w_dw, dx, SMAAT_F32, dx_bs, ws, N, Cin, kpl, H, W, st, nullptr,
+                         nullptr, nullptr, nullptr, nullptr));
     return launch_dw_reduce_split(ws, rows, Cdw, dw_out, db_out, st);
 }
 
@@ -199,7 +211,8 @@ int smaat_dw3x3_bwd_bnred(const float* x, long x_bs, const float* in_scale, cons
     const int Cdw = Cin * kpl;
     hipStream_t st = ST;
     const int rows = N * dw_bwd_groups(N, Cin, H, W);
-    CHK(launch_dw3x3_bwd(x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, ws, N, Cin, kpl, H, W, st, bn_mean, bn_invstd, rpart, in_scale, in_shift));
+    CHK(launch_dw3x3_bwd(x, SMAAT_F32, x_bs, dy, SMAAT_F32, dy_bs, w_dw, dx, SMAAT_F32, dx_bs, ws, N, Cin, kpl, H, W, st, bn_mean,
+                         bn_invstd, rpart, in_scale, in_shift));
     return launch_dw_reduce_split(ws, rows, Cdw, dw_out, db_out, st);
 }
 
@@ -216,13 +229,13 @@ int smaat_bn_eval_coefs(const float* running_mean, const float* running_var, con
 }
 int smaat_affine_act(const float* z, long z_bs, const float* scale, const float* shift, float* y, long y_bs, int N,
                      int C, int P, int relu, void* stream) {
-    return launch_affine_act(z, z_bs, scale, shift, y, y_bs, N, C, P, relu, ST);
+    return launch_affine_act(z, SMAAT_F32, z_bs, scale, shift, y, SMAAT_F32, y_bs, N, C, P, relu, ST);
 }
 int smaat_plane_num_slots(int N, int P) { return smaat_bn_bwd_num_slots_impl(N, P); }
 int smaat_bn_bwd_reduce(const float* dy, long dy_bs, const float* z, long z_bs, const float* scale,
                         const float* shift, const float* mean, const float* invstd, float* part, int N, int C, int P,
                         int relu, void* stream) {
-    return launch_bn_bwd_reduce(dy, dy_bs, z, z_bs, scale, shift, mean, invstd, part, N, C, P, relu, ST);
+    return launch_bn_bwd_reduce(dy, SMAAT_F32, dy_bs, z, SMAAT_F32, z_bs, scale, shift, mean, invstd, part, N, C, P, relu, ST);
 }
 int smaat_bn_bwd_finalize(const float* part, int slots, int C, double count, const float* gamma, const float* invstd,
                           float* dgamma, float* dbeta, float* coef, void* stream) {
@@ -231,31 +244,34 @@ int smaat_bn_bwd_finalize(const float* part, int slots, int C, double count, con
 int smaat_bn_bwd_apply(const float* dy, long dy_bs, const float* z, long z_bs, const float* scale,
                        const float* shift, const float* mean, const float* invstd, const float* coef, float* dz,
                        long dz_bs, int N, int C, int P, int relu, void* stream) {
-    return launch_bn_bwd_apply(dy, dy_bs, z, z_bs, scale, shift, mean, invstd, coef, dz, dz_bs, N, C, P, relu, ST);
+    return launch_bn_bwd_apply(dy, SMAAT_F32, dy_bs, z, SMAAT_F32, z_bs, scale, shift, mean, invstd, coef, dz, SMAAT_F32, dz_bs,
+                               N, C, P, relu, ST);
 }
 /* ---- OutConv with one output channel fused with the BatchNorm + ReLU in front of it (see include/smaat_hip.h) */
 int smaat_outconv1_fwd(const float* z, long z_bs, const float* scale, const float* shift, const float* w, const float* b,
                        float* out, long out_bs, int N, int C, int P, void* stream) {
     if (!z || !scale || !shift || !w || !out || N < 1 || C < 1 || P < 1) return -1;
-    return launch_outconv1_fwd(z, z_bs, scale, shift, w, b, out, out_bs, N, C, P, ST);
+    return launch_outconv1_fwd(z, SMAAT_F32, z_bs, scale, shift, w, b, out, out_bs, N, C, P, ST);
 }
 int smaat_bn_bwd_reduce_head(const float* dlog, long dlog_bs, const float* hw, const float* z, long z_bs,
                              const float* scale, const float* shift, const float* mean, const float* invstd, float* part,
                              int N, int C, int P, void* stream) {
     if (!dlog || !hw || !part) return -1;
-    return launch_bn_bwd_reduce(dlog, dlog_bs, z, z_bs, scale, shift, mean, invstd, part, N, C, P, 1, ST, hw);
+    return launch_bn_bwd_reduce(dlog, SMAAT_F32, dlog_bs, z, SMAAT_F32, z_bs, scale, shift, mean, invstd, part, N, C, P, 1, ST,
+                                hw);
 }
 int smaat_bn_bwd_apply_head(const float* dlog, long dlog_bs, const float* hw, const float* z, long z_bs,
                             const float* scale, const float* shift, const float* mean, const float* invstd,
                             const float* coef, float* dz, long dz_bs, int N, int C, int P, void* stream) {
     if (!dlog || !hw || !dz) return -1;
-    return launch_bn_bwd_apply(dlog, dlog_bs, z, z_bs, scale, shift, mean, invstd, coef, dz, dz_bs, N, C, P, 1, ST, hw);
+    return launch_bn_bwd_apply(dlog, SMAAT_F32, dlog_bs, z, SMAAT_F32, z_bs, scale, shift, mean, invstd, coef, dz, SMAAT_F32,
+                               dz_bs, N, C, P, 1, ST, hw);
 }
 int smaat_reduce_rows(const float* part, int rows, long len, float* out, float alpha, void* stream) {
     return launch_reduce_rows(part, rows, len, out, alpha, ST);
 }
 int smaat_channel_sum(const float* x, long x_bs, int N, int C, int P, float* ws, float* out, void* stream) {
-    return launch_channel_sum(x, x_bs, N, C, P, ws, out, ST);
+    return launch_channel_sum(x, SMAAT_F32, x_bs, N, C, P, ws, out, ST);
 }
 int smaat_copy_planes(const float* src, long s_bs, float* dst, long d_bs, int N, long plane_len, int accum,
                       void* stream) {
@@ -379,7 +395,7 @@ int smaat_pw_split_num_slots(int N, int H, int W) { return pw_split_num_slots(N,
 int smaat_dw3x3_fwd(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
                     const float* b_dw, float* y, long y_bs, int N, int Cin, int kpl, int H, int W, void* stream) {
     if (N < 1 || Cin < 1 || H < 1 || W < 1) return -1;
-    return launch_dw3x3_fwd(x, x_bs, w_dw, b_dw, y, y_bs, N, Cin, kpl, H, W, ST, in_scale, in_shift);
+    return launch_dw3x3_fwd(x, SMAAT_F32, x_bs, w_dw, b_dw, y, SMAAT_F32, y_bs, N, Cin, kpl, H, W, ST, in_scale, in_shift);
 }
 static int pointwise_fwd_split_impl(const float* x, long x_bs, const void* planes, const float* bias, float* out,
                                     long out_bs, float* part, int N, int Cin, int M, int H, int W, int relu_out,
@@ -444,6 +460,138 @@ int smaat_dsconv_fwd_split_act(const float* x, long x_bs, const float* in_scale,
     return dsconv_fwd_split_impl(x, x_bs, in_scale, in_shift, w_dw, b_dw, planes, b_pw, z, z_bs, nullptr, nullptr, N, Cin,
                                  kpl, Cout, H, W, relu_out, stream);
 }
+/* ================= mixed precision (bf16 activation storage): include/smaat_hip.h "mixed precision" ================= */
+static inline bool dt_ok(int dt) { return dt == SMAAT_F32 || dt == SMAAT_BF16; }
+
+int smaat_bf16_planes(const float* w, int R, int C, void* planes, int transposed, void* stream) {
+    if (R < 1 || C < 1 || !w || !planes) return -1;
+    return launch_bf16_planes(w, R, C, (bf16_t*)planes, transposed ? 1 : 0, ST);
+}
+int smaat_pointwise_fwd_bf16(const void* x, long x_bs, const void* planes, const float* bias, void* out, long out_bs,
+                             int out_dt, float* part, int N, int Cin, int M, int H, int W, int relu_out, void* stream) {
+    if (N < 1 || Cin < 1 || M < 1 || H < 1 || W < 1 || !x || !planes || !out || !dt_ok(out_dt)) return -1;
+    PwBfArgs a{};
+    a.out_floor = relu_out ? 0.f : NEG_INF;
+    a.x = (const bf16_t*)x; a.x_bs = x_bs; a.planes = (const bf16_t*)planes; a.bias = bias; a.out = out; a.out_bs = out_bs;
+    a.part = part; a.N = N; a.Cin = Cin; a.M = M; a.P = H * W;
+    return launch_pw_bf16(a, out_dt, ST);
+}
+int smaat_pointwise_wgrad_bf16(const void* y, long y_bs, const void* dz, long dz_bs, float* ws, float* dw_out, int N,
+                               int Cin, int M, int H, int W, void* stream) {
+    if (N < 1 || Cin < 1 || M < 1 || H < 1 || W < 1 || !y || !dz || !ws || !dw_out) return -1;
+    WgBfArgs a{};
+    a.dz = (const bf16_t*)dz; a.dz_bs = dz_bs; a.y = (const bf16_t*)y; a.y_bs = y_bs; a.part = ws;
+    a.N = N; a.M = M; a.K = Cin; a.P = H * W;
+    a.nsplit = smaat_wgrad_num_splits_impl(N, H * W, M, Cin);
+    hipStream_t st = ST;
+    CHK(launch_wgrad_bf16(a, st));
+    return launch_reduce_rows(ws, a.nsplit, (long)M * Cin, dw_out, 1.f, st);
+}
+int smaat_dw3x3_fwd_t(const void* x, int x_dt, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                      const float* b_dw, void* y, int y_dt, long y_bs, int N, int Cin, int kpl, int H, int W,
+                      void* stream) {
+    if (N < 1 || Cin < 1 || H < 1 || W < 1 || !dt_ok(x_dt) || !dt_ok(y_dt)) return -1;
+    return launch_dw3x3_fwd(x, x_dt, x_bs, w_dw, b_dw, y, y_dt, y_bs, N, Cin, kpl, H, W, ST, in_scale, in_shift);
+}
+int smaat_dw3x3_bwd_t(const void* x, int x_dt, long x_bs, const float* in_scale, const float* in_shift, const void* dy,
+                      int dy_dt, long dy_bs, const float* w_dw, void* dx, int dx_dt, long dx_bs, float* ws, float* dw_out,
+                      float* db_out, const float* bn_mean, const float* bn_invstd, float* rpart, int N, int Cin, int kpl,
+                      int H, int W, void* stream) {
+    if (!dt_ok(x_dt) || !dt_ok(dy_dt) || !dt_ok(dx_dt)) return -1;
+    if (rpart && (!dx || !bn_mean || !bn_invstd)) return -1;
+    if ((in_scale == nullptr) != (in_shift == nullptr)) return -1;
+    const int Cdw = Cin * kpl;
+    hipStream_t st = ST;
+    const int rows = N * dw_bwd_groups(N, Cin, H, W);
+    CHK(launch_dw3x3_bwd(x, x_dt, x_bs, dy, dy_dt, dy_bs, w_dw, dx, dx_dt, dx_bs, ws, N, Cin, kpl, H, W, st, bn_mean, bn_invstd,
+                         rpart, in_scale, in_shift));
+    return launch_dw_reduce_split(ws, rows, Cdw, dw_out, db_out, st);
+}
+int smaat_affine_act_t(const void* z, int z_dt, long z_bs, const float* scale, const float* shift, void* y, int y_dt,
+                       long y_bs, int N, int C, int P, int relu, void* stream) {
+    if (!dt_ok(z_dt) || !dt_ok(y_dt)) return -1;
+    return launch_affine_act(z, z_dt, z_bs, scale, shift, y, y_dt, y_bs, N, C, P, relu, ST);
+}
+int smaat_bn_bwd_reduce_t(const void* dy, int dy_dt, long dy_bs, const void* z, int z_dt, long z_bs, const float* scale,
+                          const float* shift, const float* mean, const float* invstd, float* part, int N, int C, int P,
+                          int relu, const float* head_w, void* stream) {
+    if (!dt_ok(dy_dt) || !dt_ok(z_dt) || !dy || !z || !part) return -1;
+    return launch_bn_bwd_reduce(dy, dy_dt, dy_bs, z, z_dt, z_bs, scale, shift, mean, invstd, part, N, C, P, relu, ST, head_w);
+}
+int smaat_bn_bwd_apply_t(const void* dy, int dy_dt, long dy_bs, const void* z, int z_dt, long z_bs, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, const float* coef, void* dz,
+                         int dz_dt, long dz_bs, int N, int C, int P, int relu, const float* head_w, void* stream) {
+    if (!dt_ok(dy_dt) || !dt_ok(z_dt) || !dt_ok(dz_dt) || !dy || !z || !dz) return -1;
+    return launch_bn_bwd_apply(dy, dy_dt, dy_bs, z, z_dt, z_bs, scale, shift, mean, invstd, coef, dz, dz_dt, dz_bs, N, C, P,
+                               relu, ST, head_w);
+}
+int smaat_outconv1_fwd_t(const void* z, int z_dt, long z_bs, const float* scale, const float* shift, const float* w,
+                         const float* b, float* out, long out_bs, int N, int C, int P, void* stream) {
+    if (!z || !scale || !shift || !w || !out || N < 1 || C < 1 || P < 1 || !dt_ok(z_dt)) return -1;
+    return launch_outconv1_fwd(z, z_dt, z_bs, scale, shift, w, b, out, out_bs, N, C, P, ST);
+}
+int smaat_channel_sum_t(const void* x, int x_dt, long x_bs, int N, int C, int P, float* ws, float* out, void* stream) {
+    if (!dt_ok(x_dt)) return -1;
+    return launch_channel_sum(x, x_dt, x_bs, N, C, P, ws, out, ST);
+}
+int smaat_maxpool2_fwd_t(const void* x, long x_bs, void* y, long y_bs, int N, int C, int H, int W, int dt, void* stream) {
+    if (!dt_ok(dt)) return -1;
+    return launch_maxpool2_fwd(x, x_bs, y, y_bs, N, C, H, W, ST, dt);
+}
+int smaat_maxpool2_bwd_t(const void* x, long x_bs, const void* dy, long dy_bs, void* dx, long dx_bs, int N, int C, int H,
+                         int W, int accum, int dt, void* stream) {
+    if (!dt_ok(dt)) return -1;
+    return launch_maxpool2_bwd(x, x_bs, dy, dy_bs, dx, dx_bs, N, C, H, W, accum, ST, dt);
+}
+int smaat_upsample2x_fwd_t(const void* x, long x_bs, void* out, long out_bs, int N, int C, int H, int W, int Ho, int Wo,
+                           int pad_t, int pad_l, int dt, void* stream) {
+    if (!dt_ok(dt)) return -1;
+    return launch_upsample2x_fwd(x, x_bs, out, out_bs, N, C, H, W, Ho, Wo, pad_t, pad_l, ST, dt);
+}
+int smaat_upsample2x_bwd_t(const void* dout, long dout_bs, void* dx, long dx_bs, int N, int C, int H, int W, int Ho,
+                           int Wo, int pad_t, int pad_l, int dt, void* stream) {
+    if (!dt_ok(dt)) return -1;
+    return launch_upsample2x_bwd(dout, dout_bs, dx, dx_bs, N, C, H, W, Ho, Wo, pad_t, pad_l, ST, dt);
+}
+int smaat_cbam_chpool_t(const void* x, long x_bs, const float* scale, const float* shift, void* y, long y_bs, int N,
+                        int C, int P, float* avg, float* mx, int* amax, int dt, void* stream) {
+    if (!dt_ok(dt) || !x || (scale && (!shift || !y))) return -1;
+    return launch_cbam_chpool(x, x_bs, N, C, P, avg, mx, amax, ST, scale, shift, y, y_bs, dt);
+}
+int smaat_cbam_sppool_t(const void* x, long x_bs, const float* s, int N, int C, int P, float* maps, int dt,
+                        void* stream) {
+    if (!dt_ok(dt)) return -1;
+    return launch_cbam_sppool(x, x_bs, s, N, C, P, maps, ST, dt);
+}
+int smaat_cbam_apply_t(const void* x, long x_bs, const float* s, const float* gate, void* out, long out_bs, int N, int C,
+                       int P, int dt, void* stream) {
+    if (!dt_ok(dt)) return -1;
+    return launch_cbam_apply(x, x_bs, s, gate, out, out_bs, N, C, P, ST, dt);
+}
+int smaat_cbam_bwd_gate_t(const void* dout, long dout_bs, const void* x, long x_bs, const float* s, const float* gate,
+                          const float* conv, const float* mean, const float* invstd, int N, int C, int P, float* dbn,
+                          float* part, int dt, void* stream) {
+    if (!dt_ok(dt)) return -1;
+    return launch_cbam_bwd_gate(dout, dout_bs, x, x_bs, s, gate, conv, mean, invstd, N, C, P, dbn, part, ST, dt);
+}
+int smaat_cbam_bwd_main_t(const void* dout, long dout_bs, const void* x, long x_bs, const float* s, const float* gate,
+                          const float* maps, const float* dmaps, int N, int C, int P, void* dx, long dx_bs,
+                          float* dspart, int dt, void* stream) {
+    if (!dt_ok(dt)) return -1;
+    return launch_cbam_bwd_main(dout, dout_bs, x, x_bs, s, gate, maps, dmaps, N, C, P, dx, dx_bs, dspart, ST, dt);
+}
+int smaat_cbam_bwd_final_t(void* dx, long dx_bs, const float* davg, const float* dmx, const int* amax, int N, int C,
+                           int P, int dt, void* stream) {
+    if (!dt_ok(dt)) return -1;
+    return launch_cbam_bwd_final(dx, dx_bs, davg, dmx, amax, N, C, P, ST, dt);
+}
+int smaat_cbam_bwd_final_pool_t(void* dx, long dx_bs, const float* davg, const float* dmx, const int* amax, const void* x,
+                                long x_bs, const void* dpool, long dp_bs, int N, int C, int H, int W, int dt,
+                                void* stream) {
+    if (!dx || !davg || !dmx || !amax || !x || !dpool || N < 1 || C < 1 || H < 1 || W < 1 || !dt_ok(dt)) return -1;
+    return launch_cbam_final_pool_bwd(dx, dx_bs, davg, dmx, amax, x, x_bs, dpool, dp_bs, N, C, H, W, ST, dt);
+}
+
 int smaat_precip_metrics_ws_bytes(long n) { return (int)precip_metrics_ws_bytes(n); }
 int smaat_precip_metrics_update(const float* preds, const float* target, long n, int batch, float factor,
                                 float threshold, int denormalize, void* ws, double* state_f64, long long* state_i64,

@@ -17,24 +17,26 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf
 // unet_parts_depthwise_separable.py:34-35 in front of layers.py:107-108): y = relu(x * scale[c] + shift[c]) is formed on
 // load, pooled, and WRITTEN to y_out -- the block output is materialised by its first consumer, the separate
 // BatchNorm-apply + ReLU pass over it disappears.
-template <bool ACT>
-__global__ __launch_bounds__(256) void k_cbam_chpool(const float* __restrict__ x, long x_bs, int C, int P,
+// T: element type of x and y_out (f32 | bf16 storage).  With bf16 storage the pools are taken over the values AS STORED
+// (rounded to bf16), i.e. over the tensor every later consumer reads -- the argmax index stays exact.
+template <bool ACT, typename T>
+__global__ __launch_bounds__(256) void k_cbam_chpool(const T* __restrict__ x, long x_bs, int C, int P,
                                                      float* __restrict__ avg, float* __restrict__ mx,
                                                      int* __restrict__ amax, const float* __restrict__ scale,
-                                                     const float* __restrict__ shift, float* __restrict__ y_out,
+                                                     const float* __restrict__ shift, T* __restrict__ y_out,
                                                      long y_bs) {
     __shared__ float rf[8];
     __shared__ int ri[4];
     const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
-    const float* xp = x + (long)n * x_bs + (long)c * P;
-    float* yp = ACT ? y_out + (long)n * y_bs + (long)c * P : nullptr;
+    const T* xp = x + (long)n * x_bs + (long)c * P;
+    T* yp = ACT ? y_out + (long)n * y_bs + (long)c * P : nullptr;
     const float asc = ACT ? scale[c] : 1.f, ash = ACT ? shift[c] : 0.f;
     auto act4 = [&](float4 v) {
         if (ACT) {  // the expression of k_affine_act: identical bits
-            v.x = fmaxf(fmaf(v.x, asc, ash), 0.f);
-            v.y = fmaxf(fmaf(v.y, asc, ash), 0.f);
-            v.z = fmaxf(fmaf(v.z, asc, ash), 0.f);
-            v.w = fmaxf(fmaf(v.w, asc, ash), 0.f);
+            v.x = as_stored(yp, fmaxf(fmaf(v.x, asc, ash), 0.f));
+            v.y = as_stored(yp, fmaxf(fmaf(v.y, asc, ash), 0.f));
+            v.z = as_stored(yp, fmaxf(fmaf(v.z, asc, ash), 0.f));
+            v.w = as_stored(yp, fmaxf(fmaf(v.w, asc, ash), 0.f));
         }
         return v;
     };
@@ -49,19 +51,20 @@ __global__ __launch_bounds__(256) void k_cbam_chpool(const float* __restrict__ x
         m = gt ? v : m;
         mi = gt ? p : mi;
     };
-    if ((P & 3) == 0 && (x_bs & 3) == 0 && ((((uintptr_t)x) & 15) == 0) &&
-        (!ACT || ((y_bs & 3) == 0 && ((((uintptr_t)y_out) & 15) == 0)))) {
+    if ((P & 3) == 0 && (x_bs & 3) == 0 && ((((uintptr_t)x) & Elem<T>::vmask) == 0) &&
+        (!ACT || ((y_bs & 3) == 0 && ((((uintptr_t)y_out) & Elem<T>::vmask) == 0)))) {
         const int P4 = P >> 2;
         int q = threadIdx.x;
         for (; q + 768 < P4; q += 1024) {
+            typename Elem<T>::raw4 vr[4];
             float4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(xp + 4 * (q + 256 * u));
+            for (int u = 0; u < 4; ++u) vr[u] = ldraw4(xp + 4 * (q + 256 * u));
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int p = 4 * (q + 256 * u);
-                v[u] = act4(v[u]);
-                if (ACT) *(float4*)(yp + p) = v[u];
+                v[u] = act4(cvt4(vr[u]));
+                if (ACT) st4(yp + p, v[u]);
                 upd(v[u].x, p);
                 upd(v[u].y, p + 1);
                 upd(v[u].z, p + 2);
@@ -69,8 +72,8 @@ __global__ __launch_bounds__(256) void k_cbam_chpool(const float* __restrict__ x
             }
         }
         for (; q < P4; q += 256) {
-            const float4 v = act4(*(const float4*)(xp + 4 * q));
-            if (ACT) *(float4*)(yp + 4 * q) = v;
+            const float4 v = act4(ld4(xp + 4 * q));
+            if (ACT) st4(yp + 4 * q, v);
             upd(v.x, 4 * q);
             upd(v.y, 4 * q + 1);
             upd(v.z, 4 * q + 2);
@@ -78,10 +81,10 @@ __global__ __launch_bounds__(256) void k_cbam_chpool(const float* __restrict__ x
         }
     } else {
         for (int p = threadIdx.x; p < P; p += 256) {
-            float v = xp[p];
+            float v = ld1(xp + p);
             if (ACT) {
-                v = fmaxf(fmaf(v, asc, ash), 0.f);
-                yp[p] = v;
+                v = as_stored(yp, fmaxf(fmaf(v, asc, ash), 0.f));
+                st1(yp + p, v);
             }
             upd(v, p);
         }
@@ -162,17 +165,18 @@ __global__ __launch_bounds__(256) void k_cbam_mlp(const float* __restrict__ avg,
 }
 
 // thread per pixel, loop over channels.  maps[n][0][p] = mean_c(x*s), maps[n][1][p] = max_c(x*s)
-__global__ __launch_bounds__(256) void k_cbam_sppool(const float* __restrict__ x, long x_bs,
+template <typename T>
+__global__ __launch_bounds__(256) void k_cbam_sppool(const T* __restrict__ x, long x_bs,
                                                      const float* __restrict__ s, int C, int P,
                                                      float* __restrict__ maps) {
     const int n = blockIdx.y;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= P) return;
-    const float* xp = x + (long)n * x_bs + p;
+    const T* xp = x + (long)n * x_bs + p;
     const float* sp = s + (long)n * C;
     float sum = 0.f, m = -INFINITY;
     for (int c = 0; c < C; ++c) {
-        const float v = xp[(long)c * P] * sp[c];
+        const float v = ld1(xp + (long)c * P) * sp[c];
         sum += v;
         m = fmaxf(m, v);
     }
@@ -237,19 +241,20 @@ __global__ __launch_bounds__(256) void k_cbam_gate(const float* __restrict__ con
 }
 
 // out[n][c][p] = x[n][c][p] * s[n][c] * gate[n][p];  grid (N*C planes, segments)
-__global__ __launch_bounds__(256) void k_cbam_apply(const float* __restrict__ x, long x_bs,
+template <typename T>
+__global__ __launch_bounds__(256) void k_cbam_apply(const T* __restrict__ x, long x_bs,
                                                     const float* __restrict__ s, const float* __restrict__ gate,
-                                                    float* __restrict__ out, long out_bs, int C, int P, int seg_len) {
+                                                    T* __restrict__ out, long out_bs, int C, int P, int seg_len) {
     const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
     const float sv = s[plane];
-    const float* xp = x + (long)n * x_bs + (long)c * P;
+    const T* xp = x + (long)n * x_bs + (long)c * P;
     const float* gp = gate + (long)n * P;
-    float* op = out + (long)n * out_bs + (long)c * P;
+    T* op = out + (long)n * out_bs + (long)c * P;
     const int p0 = blockIdx.y * seg_len;
     int p1 = p0 + seg_len;
     if (p1 > P) p1 = P;
     const bool vec = ((P & 3) == 0) && ((x_bs & 3) == 0) && ((out_bs & 3) == 0) && ((seg_len & 3) == 0) &&
-                     ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)out) & 15) == 0) &&
+                     ((((uintptr_t)x) & Elem<T>::vmask) == 0) && ((((uintptr_t)out) & Elem<T>::vmask) == 0) &&
                      ((((uintptr_t)gate) & 15) == 0);
     if (vec) {
         auto one = [&](float4 v, const float4 g, int p) {
@@ -257,18 +262,20 @@ __global__ __launch_bounds__(256) void k_cbam_apply(const float* __restrict__ x,
             v.y = v.y * sv * g.y;
             v.z = v.z * sv * g.z;
             v.w = v.w * sv * g.w;
-            *(float4*)(op + p) = v;
+            st4(op + p, v);
         };
         int p = p0 + threadIdx.x * 4;  // two positions per trip: four loads in flight
         for (; p + 1024 < p1; p += 2048) {
-            const float4 xa = *(const float4*)(xp + p), ga = *(const float4*)(gp + p);
-            const float4 xb = *(const float4*)(xp + p + 1024), gb = *(const float4*)(gp + p + 1024);
-            one(xa, ga, p);
-            one(xb, gb, p + 1024);
+            const auto xa = ldraw4(xp + p);
+            const float4 ga = *(const float4*)(gp + p);
+            const auto xb = ldraw4(xp + p + 1024);
+            const float4 gb = *(const float4*)(gp + p + 1024);
+            one(cvt4(xa), ga, p);
+            one(cvt4(xb), gb, p + 1024);
         }
-        if (p < p1) one(*(const float4*)(xp + p), *(const float4*)(gp + p), p);
+        if (p < p1) one(ld4(xp + p), *(const float4*)(gp + p), p);
     } else {
-        for (int p = p0 + threadIdx.x; p < p1; p += 256) op[p] = xp[p] * sv * gp[p];
+        for (int p = p0 + threadIdx.x; p < p1; p += 256) st1(op + p, ld1(xp + p) * sv * gp[p]);
     }
 }
 
@@ -483,8 +490,9 @@ __global__ __launch_bounds__(256) void k_cbam_gate_apply(const float* __restrict
 // ===================================== backward ======================================
 // B1: dgate[n][p] = sum_c dout*x*s ; dbn = dgate * m * (1-m); BN(1) backward partials
 //     (sum dbn, sum dbn*xhat), xhat = (conv - mean) * invstd.   part[2][nblocks]
-__global__ __launch_bounds__(256) void k_cbam_bwd_gate(const float* __restrict__ dout, long dout_bs,
-                                                       const float* __restrict__ x, long x_bs,
+template <typename T>
+__global__ __launch_bounds__(256) void k_cbam_bwd_gate(const T* __restrict__ dout, long dout_bs,
+                                                       const T* __restrict__ x, long x_bs,
                                                        const float* __restrict__ s, const float* __restrict__ gate,
                                                        const float* __restrict__ conv,
                                                        const float* __restrict__ mean,
@@ -496,11 +504,11 @@ __global__ __launch_bounds__(256) void k_cbam_bwd_gate(const float* __restrict__
     const int p = blockIdx.x * 256 + threadIdx.x;
     float d = 0.f, dx = 0.f;
     if (p < P) {
-        const float* xp = x + (long)n * x_bs + p;
-        const float* gp = dout + (long)n * dout_bs + p;
+        const T* xp = x + (long)n * x_bs + p;
+        const T* gp = dout + (long)n * dout_bs + p;
         const float* sp = s + (long)n * C;
         float acc = 0.f;
-        for (int c = 0; c < C; ++c) acc = fmaf(gp[(long)c * P] * xp[(long)c * P], sp[c], acc);
+        for (int c = 0; c < C; ++c) acc = fmaf(ld1(gp + (long)c * P) * ld1(xp + (long)c * P), sp[c], acc);
         const float m = gate[(long)n * P + p];
         d = acc * m * (1.f - m);
         dbn[(long)n * P + p] = d;
@@ -586,12 +594,13 @@ __global__ __launch_bounds__(256) void k_cbam_bwd_spconv(const float* __restrict
 //     xs = x*s ; dxs = dout*gate + dmaps0/C + [c == first argmax_c xs] * dmaps1
 //     t[n][c][p] = dxs * s         (main part of dx, written to dx)
 //     dspart[blk][n][c] = sum_p dxs * x          (-> ds[n][c] after k_reduce_rows over blk)
-__global__ __launch_bounds__(256) void k_cbam_bwd_main(const float* __restrict__ dout, long dout_bs,
-                                                       const float* __restrict__ x, long x_bs,
+template <typename T>
+__global__ __launch_bounds__(256) void k_cbam_bwd_main(const T* __restrict__ dout, long dout_bs,
+                                                       const T* __restrict__ x, long x_bs,
                                                        const float* __restrict__ s, const float* __restrict__ gate,
                                                        const float* __restrict__ maps,
                                                        const float* __restrict__ dmaps, int C, int P,
-                                                       float* __restrict__ dx, long dx_bs,
+                                                       T* __restrict__ dx, long dx_bs,
                                                        float* __restrict__ dspart) {
     extern __shared__ float red[];  // [4][C]
     const int n = blockIdx.y, N = gridDim.y;
@@ -599,9 +608,9 @@ __global__ __launch_bounds__(256) void k_cbam_bwd_main(const float* __restrict__
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool valid = p < P;
     const int pp = valid ? p : P - 1;
-    const float* xp = x + (long)n * x_bs + pp;
-    const float* gp = dout + (long)n * dout_bs + pp;
-    float* dp = dx + (long)n * dx_bs + pp;
+    const T* xp = x + (long)n * x_bs + pp;
+    const T* gp = dout + (long)n * dout_bs + pp;
+    T* dp = dx + (long)n * dx_bs + pp;
     const float* sp = s + (long)n * C;
     const float g = gate[(long)n * P + pp];
     const float mxv = maps[((long)n * 2 + 1) * P + pp];
@@ -609,14 +618,14 @@ __global__ __launch_bounds__(256) void k_cbam_bwd_main(const float* __restrict__
     const float dm = dmaps[((long)n * 2 + 1) * P + pp];
     bool found = false;
     for (int c = 0; c < C; ++c) {
-        const float xv = xp[(long)c * P], sv = sp[c];
+        const float xv = ld1(xp + (long)c * P), sv = sp[c];
         const float xs = xv * sv;
-        float dxs = fmaf(gp[(long)c * P], g, da);
+        float dxs = fmaf(ld1(gp + (long)c * P), g, da);
         if (!found && xs == mxv) {
             dxs += dm;
             found = true;
         }
-        if (valid) dp[(long)c * P] = dxs * sv;
+        if (valid) st1(dp + (long)c * P, dxs * sv);
         const float r = wave_sum_l63(valid ? dxs * xv : 0.f);
         if (lane == 63) red[wave * C + c] = r;
     }
@@ -631,18 +640,19 @@ __global__ __launch_bounds__(256) void k_cbam_bwd_main(const float* __restrict__
 // slots), each lane owns 4 consecutive pixels: 16-byte loads/stores and one wave reduction per channel
 // instead of four.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_cbam_sppool_v4(const float* __restrict__ x, long x_bs,
+template <typename T>
+__global__ __launch_bounds__(64) void k_cbam_sppool_v4(const T* __restrict__ x, long x_bs,
                                                        const float* __restrict__ s, int C, int P,
                                                        float* __restrict__ maps) {
     const int n = blockIdx.y;
     const int p = blockIdx.x * 256 + threadIdx.x * 4;
     if (p >= P) return;
-    const float* xp = x + (long)n * x_bs + p;
+    const T* xp = x + (long)n * x_bs + p;
     const float* sp = s + (long)n * C;
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f), m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll 4
     for (int c = 0; c < C; ++c) {
-        const float4 v = *(const float4*)(xp + (long)c * P);
+        const float4 v = ld4(xp + (long)c * P);
         const float sv = sp[c];
         const float a = v.x * sv, b = v.y * sv, cc = v.z * sv, d = v.w * sv;
         sum.x += a; sum.y += b; sum.z += cc; sum.w += d;
@@ -653,8 +663,9 @@ __global__ __launch_bounds__(64) void k_cbam_sppool_v4(const float* __restrict__
     *(float4*)(maps + ((long)n * 2 + 1) * P + p) = m;
 }
 
-__global__ __launch_bounds__(64) void k_cbam_bwd_gate_v4(const float* __restrict__ dout, long dout_bs,
-                                                         const float* __restrict__ x, long x_bs,
+template <typename T>
+__global__ __launch_bounds__(64) void k_cbam_bwd_gate_v4(const T* __restrict__ dout, long dout_bs,
+                                                         const T* __restrict__ x, long x_bs,
                                                          const float* __restrict__ s, const float* __restrict__ gate,
                                                          const float* __restrict__ conv,
                                                          const float* __restrict__ mean,
@@ -665,14 +676,14 @@ __global__ __launch_bounds__(64) void k_cbam_bwd_gate_v4(const float* __restrict
     const int p = blockIdx.x * 256 + threadIdx.x * 4;
     float t1 = 0.f, t2 = 0.f;
     if (p < P) {
-        const float* xp = x + (long)n * x_bs + p;
-        const float* gp = dout + (long)n * dout_bs + p;
+        const T* xp = x + (long)n * x_bs + p;
+        const T* gp = dout + (long)n * dout_bs + p;
         const float* sp = s + (long)n * C;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
         for (int c = 0; c < C; ++c) {
-            const float4 g = *(const float4*)(gp + (long)c * P);
-            const float4 v = *(const float4*)(xp + (long)c * P);
+            const float4 g = ld4(gp + (long)c * P);
+            const float4 v = ld4(xp + (long)c * P);
             const float sv = sp[c];
             acc.x = fmaf(g.x * v.x, sv, acc.x);
             acc.y = fmaf(g.y * v.y, sv, acc.y);
@@ -700,19 +711,21 @@ __global__ __launch_bounds__(64) void k_cbam_bwd_gate_v4(const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(64) void k_cbam_bwd_main_v4(const float* __restrict__ dout, long dout_bs,
-                                                         const float* __restrict__ x, long x_bs,
+template <typename T>
+__global__ __launch_bounds__(64) void k_cbam_bwd_main_v4(const T* __restrict__ dout, long dout_bs,
+                                                         const T* __restrict__ x, long x_bs,
                                                          const float* __restrict__ s, const float* __restrict__ gate,
                                                          const float* __restrict__ maps,
                                                          const float* __restrict__ dmaps, int C, int P,
-                                                         float* __restrict__ dx, long dx_bs,
+                                                         T* __restrict__ dx, long dx_bs,
                                                          float* __restrict__ dspart) {
     const int n = blockIdx.y, N = gridDim.y;
     const int p = blockIdx.x * 256 + threadIdx.x * 4;
     const bool valid = p < P;
     const int pp = valid ? p : 0;
-    const float* xp = x + (long)n * x_bs + pp;
-    const float* gp = dout + (long)n * dout_bs + pp;
+    constexpr unsigned EB = Elem<T>::bytes;
+    const T* xp = x + (long)n * x_bs + pp;
+    const T* gp = dout + (long)n * dout_bs + pp;
     const float* sp = s + (long)n * C;
     const float4 g = *(const float4*)(gate + (long)n * P + pp);
     const float4 mxv = *(const float4*)(maps + ((long)n * 2 + 1) * P + pp);
@@ -729,19 +742,21 @@ __global__ __launch_bounds__(64) void k_cbam_bwd_main_v4(const float* __restrict
     // whose range check drops the lanes that must not write) -- a divergent branch or a load between the
     // stores makes hipcc drain the prefetch with vmcnt(0).
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
-    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(dx + (long)n * dx_bs, 0, C * P * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(dx + (long)n * dx_bs, 0, C * P * (int)EB, 0x00020000);
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(dsrow, 0, C * 4, 0x00020000);
-    const unsigned dvo = valid ? (unsigned)pp * 4u : 0x80000000u;
+    const unsigned dvo = valid ? (unsigned)pp * EB : 0x80000000u;
     const unsigned svo = threadIdx.x == 63 ? 0u : 0x80000000u;
     // two channels per trip, the loads of the NEXT two in flight meanwhile (four 16-byte loads per lane); a channel
     // index beyond C reads clamped addresses and its stores fall outside the buffer ranges (dropped by the hardware)
-    auto ld = [&](int c, float4& xv, float4& gv, float& sv) {
+    typedef typename Elem<T>::raw4 R4;
+    auto ld = [&](int c, R4& xv, R4& gv, float& sv) {
         const int cc = c < C ? c : C - 1;
-        xv = *(const float4*)(xp + (long)cc * P);
-        gv = *(const float4*)(gp + (long)cc * P);
+        xv = ldraw4(xp + (long)cc * P);
+        gv = ldraw4(gp + (long)cc * P);
         sv = sp[cc];
     };
-    auto process = [&](const float4 xv, const float4 gv, const float sv, int c) {
+    auto process = [&](const R4 xr, const R4 gr, const float sv, int c) {
+        const float4 xv = cvt4(xr), gv = cvt4(gr);
         float4 dxs;
         dxs.x = fmaf(gv.x, g.x, da.x);
         dxs.y = fmaf(gv.y, g.y, da.y);
@@ -757,22 +772,30 @@ __global__ __launch_bounds__(64) void k_cbam_bwd_main_v4(const float* __restrict
         f1 |= h1;
         f2 |= h2;
         f3 |= h3;
-        u4 o;
-        o.x = __builtin_bit_cast(unsigned, dxs.x * sv);
-        o.y = __builtin_bit_cast(unsigned, dxs.y * sv);
-        o.z = __builtin_bit_cast(unsigned, dxs.z * sv);
-        o.w = __builtin_bit_cast(unsigned, dxs.w * sv);
-        __builtin_amdgcn_raw_buffer_store_b128(o, drs, dvo + (unsigned)c * (unsigned)P * 4u, 0, 0);
+        if constexpr (EB == 4) {
+            u4 o;
+            o.x = __builtin_bit_cast(unsigned, dxs.x * sv);
+            o.y = __builtin_bit_cast(unsigned, dxs.y * sv);
+            o.z = __builtin_bit_cast(unsigned, dxs.z * sv);
+            o.w = __builtin_bit_cast(unsigned, dxs.w * sv);
+            __builtin_amdgcn_raw_buffer_store_b128(o, drs, dvo + (unsigned)c * (unsigned)P * 4u, 0, 0);
+        } else {
+            typedef unsigned u2 __attribute__((ext_vector_type(2)));
+            u2 o;
+            o.x = pack_bf16x2(dxs.x * sv, dxs.y * sv);
+            o.y = pack_bf16x2(dxs.z * sv, dxs.w * sv);
+            __builtin_amdgcn_raw_buffer_store_b64(o, drs, dvo + (unsigned)c * (unsigned)P * 2u, 0, 0);
+        }
         float r = valid ? (dxs.x * xv.x + dxs.y * xv.y) + (dxs.z * xv.z + dxs.w * xv.w) : 0.f;
         r = wave_sum_l63(r);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r), srs, svo + (unsigned)c * 4u, 0, 0);
     };
-    float4 xa, ga, xb, gb;
+    R4 xa, ga, xb, gb;
     float sa, sb;
     ld(0, xa, ga, sa);
     ld(1, xb, gb, sb);
     for (int c = 0; c < C; c += 2) {
-        const float4 x0 = xa, g0 = ga, x1 = xb, g1 = gb;
+        const R4 x0 = xa, g0 = ga, x1 = xb, g1 = gb;
         const float s0 = sa, s1 = sb;
         ld(c + 2, xa, ga, sa);
         ld(c + 3, xb, gb, sb);
@@ -839,7 +862,8 @@ __global__ __launch_bounds__(256) void k_cbam_bwd_mlp(const float* __restrict__ 
 }
 
 // B5: dx[n][c][p] += davg[n][c]/P ; dx[n][c][amax[n][c]] += dmx[n][c]     (in place)
-__global__ __launch_bounds__(256) void k_cbam_bwd_final(float* __restrict__ dx, long dx_bs,
+template <typename T>
+__global__ __launch_bounds__(256) void k_cbam_bwd_final(T* __restrict__ dx, long dx_bs,
                                                         const float* __restrict__ davg,
                                                         const float* __restrict__ dmx, const int* __restrict__ amax,
                                                         int C, int P, int seg_len) {
@@ -847,14 +871,14 @@ __global__ __launch_bounds__(256) void k_cbam_bwd_final(float* __restrict__ dx, 
     const float add = davg[plane] / (float)P;
     const float dm = dmx[plane];
     const int am = amax[plane];
-    float* dp = dx + (long)n * dx_bs + (long)c * P;
+    T* dp = dx + (long)n * dx_bs + (long)c * P;
     const int p0 = blockIdx.y * seg_len;
     int p1 = p0 + seg_len;
     if (p1 > P) p1 = P;
     for (int p = p0 + threadIdx.x; p < p1; p += 256) {
-        float v = dp[p] + add;
+        float v = ld1(dp + p) + add;
         if (p == am) v += dm;
-        dp[p] = v;
+        st1(dp + p, v);
     }
 }
 
@@ -864,12 +888,13 @@ __global__ __launch_bounds__(256) void k_cbam_bwd_final(float* __restrict__ dx, 
 // instead of two passes (k_cbam_bwd_final, k_maxpool2_bwd with accum = 1).  A thread owns a 2 x 4 patch (two windows):
 // float4 accesses, the window maximum taken in the scan order of k_maxpool2_bwd.  W % 4 == 0; a last odd row has no
 // window (floor mode) and only receives the channel-attention terms.
-__global__ __launch_bounds__(256) void k_cbam_final_pool_bwd(float* __restrict__ dx, long dx_bs,
+template <typename T>
+__global__ __launch_bounds__(256) void k_cbam_final_pool_bwd(T* __restrict__ dx, long dx_bs,
                                                              const float* __restrict__ davg,
                                                              const float* __restrict__ dmx,
                                                              const int* __restrict__ amax,
-                                                             const float* __restrict__ x, long x_bs,
-                                                             const float* __restrict__ dpool, long dp_bs, int C, int H,
+                                                             const T* __restrict__ x, long x_bs,
+                                                             const T* __restrict__ dpool, long dp_bs, int C, int H,
                                                              int W, long total) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= total) return;
@@ -882,19 +907,19 @@ __global__ __launch_bounds__(256) void k_cbam_final_pool_bwd(float* __restrict__
     const float add = davg[plane] / (float)P;
     const float dm = dmx[plane];
     const int am = amax[plane];
-    const float* xp = x + (long)n * x_bs + (long)c * P;
-    float* dp = dx + (long)n * dx_bs + (long)c * P;
+    const T* xp = x + (long)n * x_bs + (long)c * P;
+    T* dp = dx + (long)n * dx_bs + (long)c * P;
     const int r0 = 2 * i, p0 = r0 * W + 4 * q;
     const bool two = r0 + 1 < H;  // (i < Ho)
-    float4 d0 = *(const float4*)(dp + p0);
+    float4 d0 = ld4(dp + p0);
     float a0[4] = {d0.x + add, d0.y + add, d0.z + add, d0.w + add};
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (p0 + k == am) a0[k] += dm;
     if (two) {
-        const float4 x0 = *(const float4*)(xp + p0), x1 = *(const float4*)(xp + p0 + W);
-        float4 d1 = *(const float4*)(dp + p0 + W);
-        const float2 g = *(const float2*)(dpool + (long)n * dp_bs + (long)c * Ho * Wo + (long)i * Wo + 2 * q);
+        const float4 x0 = ld4(xp + p0), x1 = ld4(xp + p0 + W);
+        float4 d1 = ld4(dp + p0 + W);
+        const float2 g = ld2(dpool + (long)n * dp_bs + (long)c * Ho * Wo + (long)i * Wo + 2 * q);
         float a1[4] = {d1.x + add, d1.y + add, d1.z + add, d1.w + add};
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -914,9 +939,9 @@ __global__ __launch_bounds__(256) void k_cbam_final_pool_bwd(float* __restrict__
             a1[2 * w] += sel == 2 ? gg[w] : 0.f;
             a1[2 * w + 1] += sel == 3 ? gg[w] : 0.f;
         }
-        *(float4*)(dp + p0 + W) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+        st4(dp + p0 + W, make_float4(a1[0], a1[1], a1[2], a1[3]));
     }
-    *(float4*)(dp + p0) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+    st4(dp + p0, make_float4(a0[0], a0[1], a0[2], a0[3]));
 }
 
 // =====================================================================================
@@ -926,14 +951,16 @@ static int seg_len_c(int P) { return P <= 8192 ? ((P + 1023) / 1024) * 1024 : 81
 int smaat_cbam_spconv_blocks_impl(int N, int H, int W) { return N * cdivc(H, SPT) * cdivc(W, SPT); }
 int smaat_cbam_pix_blocks_impl(int N, int P) { return N * cdivc(P, 256); }
 
-int launch_cbam_chpool(const float* x, long x_bs, int N, int C, int P, float* avg, float* mx, int* amax,
-                       hipStream_t st, const float* scale, const float* shift, float* y_out, long y_bs) {
-    if (scale)
-        hipLaunchKernelGGL(k_cbam_chpool<true>, dim3(N * C), dim3(256), 0, st, x, x_bs, C, P, avg, mx, amax, scale, shift,
-                           y_out, y_bs);
-    else
-        hipLaunchKernelGGL(k_cbam_chpool<false>, dim3(N * C), dim3(256), 0, st, x, x_bs, C, P, avg, mx, amax, nullptr,
-                           nullptr, nullptr, 0L);
+// dt (here and below): SMAAT_F32 | SMAAT_BF16 element type of the activation-sized tensors (x, out, dout, dx, pooled)
+int launch_cbam_chpool(const void* x, long x_bs, int N, int C, int P, float* avg, float* mx, int* amax,
+                       hipStream_t st, const float* scale, const float* shift, void* y_out, long y_bs, int dt) {
+    SMAAT_DISPATCH_ET(dt, T,
+        if (scale)
+            hipLaunchKernelGGL((k_cbam_chpool<true, T>), dim3(N * C), dim3(256), 0, st, (const T*)x, x_bs, C, P, avg, mx, amax,
+                               scale, shift, (T*)y_out, y_bs);
+        else
+            hipLaunchKernelGGL((k_cbam_chpool<false, T>), dim3(N * C), dim3(256), 0, st, (const T*)x, x_bs, C, P, avg, mx, amax,
+                               nullptr, nullptr, (T*)nullptr, 0L););
     return (int)hipGetLastError();
 }
 int launch_cbam_mlp(const float* avg, const float* mx, const float* w1, const float* b1, const float* w2,
@@ -942,11 +969,12 @@ int launch_cbam_mlp(const float* avg, const float* mx, const float* w1, const fl
     hipLaunchKernelGGL(k_cbam_mlp, dim3(N), dim3(256), lds, st, avg, mx, w1, b1, w2, b2, C, Cr, ha, hm, s);
     return (int)hipGetLastError();
 }
-int launch_cbam_sppool(const float* x, long x_bs, const float* s, int N, int C, int P, float* maps, hipStream_t st) {
-    if (((P & 3) == 0) && ((x_bs & 3) == 0) && ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)maps) & 15) == 0))
-        hipLaunchKernelGGL(k_cbam_sppool_v4, dim3(cdivc(P, 256), N), dim3(64), 0, st, x, x_bs, s, C, P, maps);
-    else
-        hipLaunchKernelGGL(k_cbam_sppool, dim3(cdivc(P, 256), N), dim3(256), 0, st, x, x_bs, s, C, P, maps);
+int launch_cbam_sppool(const void* x, long x_bs, const float* s, int N, int C, int P, float* maps, hipStream_t st, int dt) {
+    SMAAT_DISPATCH_ET(dt, T,
+        if (((P & 3) == 0) && ((x_bs & 3) == 0) && ((((uintptr_t)x) & Elem<T>::vmask) == 0) && ((((uintptr_t)maps) & 15) == 0))
+            hipLaunchKernelGGL(k_cbam_sppool_v4<T>, dim3(cdivc(P, 256), N), dim3(64), 0, st, (const T*)x, x_bs, s, C, P, maps);
+        else
+            hipLaunchKernelGGL(k_cbam_sppool<T>, dim3(cdivc(P, 256), N), dim3(256), 0, st, (const T*)x, x_bs, s, C, P, maps););
     return (int)hipGetLastError();
 }
 int launch_cbam_spconv(const float* maps, const float* wc, int ks, int N, int H, int W, float* conv, float* part,
@@ -962,11 +990,12 @@ int launch_cbam_gate(const float* conv, const float* scale, const float* shift, 
     hipLaunchKernelGGL(k_cbam_gate, dim3(cdivc(total, 256)), dim3(256), 0, st, conv, scale, shift, total, gate);
     return (int)hipGetLastError();
 }
-int launch_cbam_apply(const float* x, long x_bs, const float* s, const float* gate, float* out, long out_bs, int N,
-                      int C, int P, hipStream_t st) {
+int launch_cbam_apply(const void* x, long x_bs, const float* s, const float* gate, void* out, long out_bs, int N,
+                      int C, int P, hipStream_t st, int dt) {
     const int seg = seg_len_c(P);
-    hipLaunchKernelGGL(k_cbam_apply, dim3(N * C, cdivc(P, seg)), dim3(256), 0, st, x, x_bs, s, gate, out, out_bs, C,
-                       P, seg);
+    SMAAT_DISPATCH_ET(dt, T,
+        hipLaunchKernelGGL(k_cbam_apply<T>, dim3(N * C, cdivc(P, seg)), dim3(256), 0, st, (const T*)x, x_bs, s, gate, (T*)out,
+                           out_bs, C, P, seg););
     return (int)hipGetLastError();
 }
 int launch_cbam_eval_pool(const float* x, long x_bs, const float* avg, const float* mx, const float* w1, const float* b1,
@@ -999,19 +1028,21 @@ int launch_cbam_eval_apply(const float* x, long x_bs, const float* s, const floa
                        bn_rm, bn_rv, eps, C, H, W, csplit, out, out_bs, pooled, pooled_bs);
     return (int)hipGetLastError();
 }
-int launch_cbam_bwd_gate(const float* dout, long dout_bs, const float* x, long x_bs, const float* s,
+int launch_cbam_bwd_gate(const void* dout, long dout_bs, const void* x, long x_bs, const float* s,
                          const float* gate, const float* conv, const float* mean, const float* invstd, int N, int C,
-                         int P, float* dbn, float* part, hipStream_t st) {
+                         int P, float* dbn, float* part, hipStream_t st, int dt) {
     dim3 grid(cdivc(P, 256), N);
-    const bool v4 = ((P & 3) == 0) && ((x_bs & 3) == 0) && ((dout_bs & 3) == 0) && ((((uintptr_t)x) & 15) == 0) &&
-                    ((((uintptr_t)dout) & 15) == 0) && ((((uintptr_t)gate) & 15) == 0) &&
+    const unsigned am = dt == SMAAT_BF16 ? 7u : 15u;
+    const bool v4 = ((P & 3) == 0) && ((x_bs & 3) == 0) && ((dout_bs & 3) == 0) && ((((uintptr_t)x) & am) == 0) &&
+                    ((((uintptr_t)dout) & am) == 0) && ((((uintptr_t)gate) & 15) == 0) &&
                     ((((uintptr_t)conv) & 15) == 0) && ((((uintptr_t)dbn) & 15) == 0);
-    if (v4)
-        hipLaunchKernelGGL(k_cbam_bwd_gate_v4, grid, dim3(64), 0, st, dout, dout_bs, x, x_bs, s, gate, conv, mean,
-                           invstd, C, P, dbn, part, (int)(grid.x * grid.y));
-    else
-        hipLaunchKernelGGL(k_cbam_bwd_gate, grid, dim3(256), 0, st, dout, dout_bs, x, x_bs, s, gate, conv, mean,
-                           invstd, C, P, dbn, part, (int)(grid.x * grid.y));
+    SMAAT_DISPATCH_ET(dt, T,
+        if (v4)
+            hipLaunchKernelGGL(k_cbam_bwd_gate_v4<T>, grid, dim3(64), 0, st, (const T*)dout, dout_bs, (const T*)x, x_bs, s, gate,
+                               conv, mean, invstd, C, P, dbn, part, (int)(grid.x * grid.y));
+        else
+            hipLaunchKernelGGL(k_cbam_bwd_gate<T>, grid, dim3(256), 0, st, (const T*)dout, dout_bs, (const T*)x, x_bs, s, gate,
+                               conv, mean, invstd, C, P, dbn, part, (int)(grid.x * grid.y)););
     return (int)hipGetLastError();
 }
 int launch_cbam_bwd_spconv(const float* dbn, const float* conv, const float* mean, const float* invstd,
@@ -1023,22 +1054,24 @@ int launch_cbam_bwd_spconv(const float* dbn, const float* conv, const float* mea
                        dmaps, wpart);
     return (int)hipGetLastError();
 }
-int launch_cbam_bwd_main(const float* dout, long dout_bs, const float* x, long x_bs, const float* s,
-                         const float* gate, const float* maps, const float* dmaps, int N, int C, int P, float* dx,
-                         long dx_bs, float* dspart, hipStream_t st) {
+int launch_cbam_bwd_main(const void* dout, long dout_bs, const void* x, long x_bs, const float* s,
+                         const float* gate, const float* maps, const float* dmaps, int N, int C, int P, void* dx,
+                         long dx_bs, float* dspart, hipStream_t st, int dt) {
+    const unsigned am = dt == SMAAT_BF16 ? 7u : 15u;
     const bool v4 = ((P & 3) == 0) && ((x_bs & 3) == 0) && ((dout_bs & 3) == 0) && ((dx_bs & 3) == 0) &&
-                    ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)dout) & 15) == 0) &&
-                    ((((uintptr_t)dx) & 15) == 0) && ((((uintptr_t)gate) & 15) == 0) &&
+                    ((((uintptr_t)x) & am) == 0) && ((((uintptr_t)dout) & am) == 0) &&
+                    ((((uintptr_t)dx) & am) == 0) && ((((uintptr_t)gate) & 15) == 0) &&
                     ((((uintptr_t)maps) & 15) == 0) && ((((uintptr_t)dmaps) & 15) == 0) &&
                     ((long)C * P * 4 < (1L << 31));  // dX goes through a 32-bit buffer offset (bit 31 = dropped)
-    if (v4) {
-        hipLaunchKernelGGL(k_cbam_bwd_main_v4, dim3(cdivc(P, 256), N), dim3(64), 0, st, dout, dout_bs, x, x_bs, s, gate,
-                           maps, dmaps, C, P, dx, dx_bs, dspart);
-        return (int)hipGetLastError();
-    }
-    const size_t lds = sizeof(float) * (size_t)(4 * C);
-    hipLaunchKernelGGL(k_cbam_bwd_main, dim3(cdivc(P, 256), N), dim3(256), lds, st, dout, dout_bs, x, x_bs, s, gate,
-                       maps, dmaps, C, P, dx, dx_bs, dspart);
+    SMAAT_DISPATCH_ET(dt, T,
+        if (v4) {
+            hipLaunchKernelGGL(k_cbam_bwd_main_v4<T>, dim3(cdivc(P, 256), N), dim3(64), 0, st, (const T*)dout, dout_bs,
+                               (const T*)x, x_bs, s, gate, maps, dmaps, C, P, (T*)dx, dx_bs, dspart);
+        } else {
+            const size_t lds = sizeof(float) * (size_t)(4 * C);
+            hipLaunchKernelGGL(k_cbam_bwd_main<T>, dim3(cdivc(P, 256), N), dim3(256), lds, st, (const T*)dout, dout_bs,
+                               (const T*)x, x_bs, s, gate, maps, dmaps, C, P, (T*)dx, dx_bs, dspart);
+        });
     return (int)hipGetLastError();
 }
 int launch_cbam_bwd_mlp(const float* ds, const float* s, const float* avg, const float* mx, const float* ha,
@@ -1049,23 +1082,26 @@ int launch_cbam_bwd_mlp(const float* ds, const float* s, const float* avg, const
                        dmx);
     return (int)hipGetLastError();
 }
-int launch_cbam_bwd_final(float* dx, long dx_bs, const float* davg, const float* dmx, const int* amax, int N, int C,
-                          int P, hipStream_t st) {
+int launch_cbam_bwd_final(void* dx, long dx_bs, const float* davg, const float* dmx, const int* amax, int N, int C,
+                          int P, hipStream_t st, int dt) {
     const int seg = seg_len_c(P);
-    hipLaunchKernelGGL(k_cbam_bwd_final, dim3(N * C, cdivc(P, seg)), dim3(256), 0, st, dx, dx_bs, davg, dmx, amax, C,
-                       P, seg);
+    SMAAT_DISPATCH_ET(dt, T,
+        hipLaunchKernelGGL(k_cbam_bwd_final<T>, dim3(N * C, cdivc(P, seg)), dim3(256), 0, st, (T*)dx, dx_bs, davg, dmx, amax,
+                           C, P, seg););
     return (int)hipGetLastError();
 }
 
 // -2: shape / alignment not handled (the caller runs smaat_cbam_bwd_final + smaat_maxpool2_bwd)
-int launch_cbam_final_pool_bwd(float* dx, long dx_bs, const float* davg, const float* dmx, const int* amax,
-                               const float* x, long x_bs, const float* dpool, long dp_bs, int N, int C, int H, int W,
-                               hipStream_t st) {
-    if ((W & 3) != 0 || (dx_bs & 3) != 0 || (x_bs & 3) != 0 || (dp_bs & 1) != 0 || ((((uintptr_t)dx) & 15) != 0) ||
-        ((((uintptr_t)x) & 15) != 0) || ((((uintptr_t)dpool) & 7) != 0) || H < 2)
+int launch_cbam_final_pool_bwd(void* dx, long dx_bs, const float* davg, const float* dmx, const int* amax,
+                               const void* x, long x_bs, const void* dpool, long dp_bs, int N, int C, int H, int W,
+                               hipStream_t st, int dt) {
+    const unsigned am = dt == SMAAT_BF16 ? 7u : 15u;
+    if ((W & 3) != 0 || (dx_bs & 3) != 0 || (x_bs & 3) != 0 || (dp_bs & 1) != 0 || ((((uintptr_t)dx) & am) != 0) ||
+        ((((uintptr_t)x) & am) != 0) || ((((uintptr_t)dpool) & (am >> 1)) != 0) || H < 2)
         return -2;
     const long total = (long)N * C * (W >> 2) * ((H + 1) >> 1);
-    hipLaunchKernelGGL(k_cbam_final_pool_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dx, dx_bs, davg, dmx,
-                       amax, x, x_bs, dpool, dp_bs, C, H, W, total);
+    SMAAT_DISPATCH_ET(dt, T,
+        hipLaunchKernelGGL(k_cbam_final_pool_bwd<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (T*)dx, dx_bs, davg,
+                           dmx, amax, (const T*)x, x_bs, (const T*)dpool, dp_bs, C, H, W, total););
     return (int)hipGetLastError();
 }

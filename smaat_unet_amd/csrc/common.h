@@ -9,6 +9,75 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- element types of the activation tensors ------------------------------------------------------------------
+// f32 (default) or bf16 storage (mixed precision: BASELINE configs[3] -- activations and their gradients 2 bytes per
+// element in HBM, f32 arithmetic / accumulation / BatchNorm statistics in registers, f32 master weights).  A kernel
+// that exists for both is a template over the element type of each tensor and touches memory only through these
+// accessors, so the f32 instantiation is the code it was before.  SMAAT_F32 / SMAAT_BF16 are the dtype codes of the C ABI.
+#define SMAAT_F32 0
+#define SMAAT_BF16 1
+typedef unsigned short bf16_t;  // bit pattern of a bf16 value
+typedef __bf16 bf16x2_native __attribute__((ext_vector_type(2)));
+typedef float f32x2_native __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {  // one v_cvt_pk_bf16_f32 (round to nearest even)
+    const f32x2_native v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_native));
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    typedef float4 raw4;    // registers of one 4-element load
+    typedef float raw1;
+    static constexpr int code = SMAAT_F32;
+    static constexpr unsigned vmask = 15;  // byte alignment mask of a 4-element access
+    static constexpr int bytes = 4;
+};
+template <> struct Elem<bf16_t> {
+    typedef uint2 raw4;
+    typedef unsigned raw1;
+    static constexpr int code = SMAAT_BF16;
+    static constexpr unsigned vmask = 7;
+    static constexpr int bytes = 2;
+};
+__device__ __forceinline__ float4 ldraw4(const float* p) { return *(const float4*)p; }
+__device__ __forceinline__ uint2 ldraw4(const bf16_t* p) { return *(const uint2*)p; }
+__device__ __forceinline__ float ldraw1(const float* p) { return *p; }
+__device__ __forceinline__ unsigned ldraw1(const bf16_t* p) { return *p; }
+__device__ __forceinline__ float4 cvt4(const float4 v) { return v; }
+__device__ __forceinline__ float4 cvt4(const uint2 v) { return make_float4(bf16_lo(v.x), bf16_hi(v.x), bf16_lo(v.y), bf16_hi(v.y)); }
+__device__ __forceinline__ float cvt1(const float v) { return v; }
+__device__ __forceinline__ float cvt1(const unsigned v) { return bf16_lo(v); }
+template <typename T> __device__ __forceinline__ float4 ld4(const T* p) { return cvt4(ldraw4(p)); }
+template <typename T> __device__ __forceinline__ float ld1(const T* p) { return cvt1(ldraw1(p)); }
+__device__ __forceinline__ void st4(float* p, const float4 v) { *(float4*)p = v; }
+__device__ __forceinline__ void st4(bf16_t* p, const float4 v) { *(uint2*)p = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)); }
+__device__ __forceinline__ void st1(float* p, const float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16_t* p, const float v) { *p = (bf16_t)(pack_bf16x2(v, 0.f) & 0xFFFFu); }
+__device__ __forceinline__ void st2(float* p, const float a, const float b) { *(float2*)p = make_float2(a, b); }
+__device__ __forceinline__ void st2(bf16_t* p, const float a, const float b) { *(unsigned*)p = pack_bf16x2(a, b); }
+__device__ __forceinline__ float2 ld2(const float* p) { return *(const float2*)p; }
+__device__ __forceinline__ float2 ld2(const bf16_t* p) {
+    const unsigned u = *(const unsigned*)p;
+    return make_float2(bf16_lo(u), bf16_hi(u));
+}
+// the value a store of v to a tensor of type T leaves there (so that a kernel which both stores and keeps using a value
+// -- deferred activation + pooling -- sees what its consumers will read)
+__device__ __forceinline__ float as_stored(const float*, float v) { return v; }
+__device__ __forceinline__ float as_stored(const bf16_t*, float v) { return bf16_lo(pack_bf16x2(v, 0.f)); }
+// host side: run `body` with ET bound to the element type of dtype code `dt`
+#define SMAAT_DISPATCH_ET(dt, ET, ...)                     \
+    do {                                                   \
+        if ((dt) == SMAAT_BF16) {                          \
+            typedef bf16_t ET;                             \
+            __VA_ARGS__                                    \
+        } else {                                           \
+            typedef float ET;                              \
+            __VA_ARGS__                                    \
+        }                                                  \
+    } while (0)
+
 // ---- bilinear blend, one fixed evaluation order for every upsample kernel (element-per-thread and row-walking forms
 // give bit-identical results):  v = a0 * (b0 * tl + b1 * tr) + a1 * (b0 * bl + b1 * br)
 __device__ __forceinline__ float bilerp_h(float b0, float l, float b1, float r) { return fmaf(b0, l, b1 * r); }
@@ -305,6 +374,27 @@ struct PwSplitArgs {
     // otherwise
     int ksplit;
     long planes_bs;
+};
+
+// mixed-precision GEMMs (bf16gemm.hip)
+struct PwBfArgs {
+    const bf16_t* x;       // [N][Cin][P]
+    long x_bs;
+    const bf16_t* planes;  // [Cp/16][M][16], Cp = Cin rounded up to 32 (smaat_bf16_planes)
+    const float* bias;     // [M] or null
+    void* out;             // [N][M][P], f32 or bf16
+    long out_bs;
+    float* part;  // [3][slots][M] or null
+    int N, Cin, Cp, M, P, nco, tiles_per_img, T, slots;
+    float out_floor;
+};
+struct WgBfArgs {
+    const bf16_t* dz;  // [N][M][P]
+    long dz_bs;
+    const bf16_t* y;  // [N][K][P]
+    long y_bs;
+    float* part;  // [nsplit][M][K]
+    int N, M, K, P, nmt, nkt, nsplit, nchunk_img, total_chunks;
 };
 
 #define HIP_RET(expr)                          \

@@ -84,52 +84,63 @@ __device__ __forceinline__ DwrLane dwr_lane(int lane, int q, int ncol4) {
     ln.eo = (ln.l0 && ln.lok) ? -1 : ((ln.l63 && ln.rok) ? 4 : 0);
     return ln;
 }
+// T = element type of the streamed tensor (float or bf16_t, common.h "element types"): a row is ONE 16- or 8-byte load
+// per lane plus the edge element; the raw registers are converted to f32 in dwr_finish, after the pin.
+template <typename T>
 struct DwrRaw {
-    float4 m;
-    float e;
+    typename Elem<T>::raw4 m;
+    typename Elem<T>::raw1 e;
 };
 // issue the two loads of a window row (p = plane + 4q; nothing waits here)
-__device__ __forceinline__ DwrRaw dwr_issue(const float* __restrict__ p, int r, int H, int W, const DwrLane& ln) {
+template <typename T>
+__device__ __forceinline__ DwrRaw<T> dwr_issue(const T* __restrict__ p, int r, int H, int W, const DwrLane& ln) {
     const int rc = min(max(r, 0), H - 1);
-    const float* pr = p + (long)rc * W;
-    DwrRaw v;
-    v.m = *(const float4*)pr;
-    v.e = pr[ln.eo];
+    const T* pr = p + (long)rc * W;
+    DwrRaw<T> v;
+    v.m = ldraw4(pr);
+    v.e = ldraw1(pr + ln.eo);
     return v;
 }
-__device__ __forceinline__ float4 dwr_issue4(const float* __restrict__ p, int r, int H, int W) {
+template <typename T>
+__device__ __forceinline__ typename Elem<T>::raw4 dwr_issue4(const T* __restrict__ p, int r, int H, int W) {
     const int rc = min(max(r, 0), H - 1);
-    return *(const float4*)(p + (long)rc * W);
+    return ldraw4(p + (long)rc * W);
 }
 // pin the loaded registers: keeps hipcc from sinking parts of a 16-byte load into the row-validity select (it splits
 // the load into dword loads plus a branch otherwise).  Call after ALL loads of a step have been issued.
-__device__ __forceinline__ void dwr_pin(DwrRaw& v) {
+__device__ __forceinline__ void dwr_pin(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void dwr_pin(uint2& v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
+__device__ __forceinline__ void dwr_pin(DwrRaw<float>& v) {
     asm volatile("" : "+v"(v.m.x), "+v"(v.m.y), "+v"(v.m.z), "+v"(v.m.w), "+v"(v.e));
 }
-__device__ __forceinline__ void dwr_pin(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void dwr_pin(DwrRaw<bf16_t>& v) { asm volatile("" : "+v"(v.m.x), "+v"(v.m.y), "+v"(v.e)); }
 // raw row -> window row: edge exchange, activation (previous BatchNorm + ReLU) on load, zero padding
-__device__ __forceinline__ void dwr_finish(float (&w)[6], const DwrRaw& v, int r, int H, const DwrLane& ln, bool aff,
+template <typename T>
+__device__ __forceinline__ void dwr_finish(float (&w)[6], const DwrRaw<T>& vr, int r, int H, const DwrLane& ln, bool aff,
                                            float sc, float sh) {
     const bool rv = r >= 0 && r < H;
-    float l = dpp_src<0x138, 0xF>(v.m.w);   // wave_shr:1  (lane i <- lane i - 1)
-    float rr = dpp_src<0x130, 0xF>(v.m.x);  // wave_shl:1  (lane i <- lane i + 1)
-    l = ln.l0 ? v.e : l;
-    rr = ln.l63 ? v.e : rr;
+    const float4 m = cvt4(vr.m);
+    const float e = cvt1(vr.e);
+    float l = dpp_src<0x138, 0xF>(m.w);   // wave_shr:1  (lane i <- lane i - 1)
+    float rr = dpp_src<0x130, 0xF>(m.x);  // wave_shl:1  (lane i <- lane i + 1)
+    l = ln.l0 ? e : l;
+    rr = ln.l63 ? e : rr;
     w[0] = (rv && ln.lok) ? dwr_act(l, aff, sc, sh) : 0.f;
-    w[1] = rv ? dwr_act(v.m.x, aff, sc, sh) : 0.f;
-    w[2] = rv ? dwr_act(v.m.y, aff, sc, sh) : 0.f;
-    w[3] = rv ? dwr_act(v.m.z, aff, sc, sh) : 0.f;
-    w[4] = rv ? dwr_act(v.m.w, aff, sc, sh) : 0.f;
+    w[1] = rv ? dwr_act(m.x, aff, sc, sh) : 0.f;
+    w[2] = rv ? dwr_act(m.y, aff, sc, sh) : 0.f;
+    w[3] = rv ? dwr_act(m.z, aff, sc, sh) : 0.f;
+    w[4] = rv ? dwr_act(m.w, aff, sc, sh) : 0.f;
     w[5] = (rv && ln.rok) ? dwr_act(rr, aff, sc, sh) : 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // forward:  y[ci*KPL + j][r][c] = b[j] + sum_{tr,tc} w[j][tr][tc] * act(x)[ci][r + tr - 1][c + tc - 1]
 // ---------------------------------------------------------------------------------------------------------------
-template <int KPL>
-__global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const float* __restrict__ x, long x_bs,
+// TX / TY: element types of x and y (f32 | bf16 storage; the arithmetic is f32 either way)
+template <int KPL, typename TX, typename TY>
+__global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const TX* __restrict__ x, long x_bs,
                                                          const float* __restrict__ w_dw,
-                                                         const float* __restrict__ b_dw, float* __restrict__ y,
+                                                         const float* __restrict__ b_dw, TY* __restrict__ y,
                                                          long y_bs, int Cin, int nplanes, const DwrGeom g,
                                                          const float* __restrict__ in_scale,
                                                          const float* __restrict__ in_shift) {
@@ -143,8 +154,8 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const float* __restrict_
     const bool active = band_ < g.nbands;  // surplus lanes of the last wave walk the last band again (stores masked)
     const int band = active ? band_ : g.nbands - 1;
     const int r0 = band * g.BH;
-    const float* xp = x + (long)n * x_bs + (long)ci * g.P + 4 * q;
-    float* yp = y + (long)n * y_bs + (long)(ci * KPL) * g.P + 4 * q;
+    const TX* xp = x + (long)n * x_bs + (long)ci * g.P + 4 * q;
+    TY* yp = y + (long)n * y_bs + (long)(ci * KPL) * g.P + 4 * q;
     float wt[KPL][9], bs[KPL];
 #pragma unroll
     for (int j = 0; j < KPL; ++j) {
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const float* __restrict_
     // r + 2 in flight; the step issues row r + 3 into raw[u + 2], then finishes row r + 1 into Wn[u + 2] (the slot of the
     // dead row r - 2)   (indices mod 3: two rows of loads stay in flight behind the one being consumed)
     float Wn[3][6];
-    DwrRaw raw[3];
+    DwrRaw<TX> raw[3];
     auto compute = [&](int r, const float (&R0)[6], const float (&R1)[6], const float (&R2)[6]) {
 #pragma unroll
         for (int j = 0; j < KPL; ++j) {
@@ -176,11 +187,11 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const float* __restrict_
                 for (int tc = 0; tc < 3; ++tc) acc = fmaf(wt[j][6 + tc], R2[c + tc], acc);
                 o[c] = acc;
             }
-            if (active && r < g.H) *(float4*)(yp + (long)j * g.P + (long)r * g.W) = make_float4(o[0], o[1], o[2], o[3]);
+            if (active && r < g.H) st4(yp + (long)j * g.P + (long)r * g.W, make_float4(o[0], o[1], o[2], o[3]));
         }
     };
     {
-        DwrRaw a = dwr_issue(xp, r0 - 1, g.H, g.W, ln), b = dwr_issue(xp, r0, g.H, g.W, ln);
+        DwrRaw<TX> a = dwr_issue(xp, r0 - 1, g.H, g.W, ln), b = dwr_issue(xp, r0, g.H, g.W, ln);
         raw[0] = dwr_issue(xp, r0 + 1, g.H, g.W, ln);
         raw[1] = dwr_issue(xp, r0 + 2, g.H, g.W, ln);
         dwr_pin(a);
@@ -223,10 +234,11 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const float* __restrict_
 #endif
 // RP: the variant that also emits rpart keeps the raw (pre-BatchNorm) rows of the three open lines in registers: the
 // counter passes showed the re-load of the completed row as +25 % HBM fetch (it had left the L2 two steps later).
-template <int KPL, bool RP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAVES, DWR_BWD_WAVES))) void k_dw3x3_bwd_rows(const float* __restrict__ x, long x_bs,
-                                                         const float* __restrict__ dy, long dy_bs,
-                                                         const float* __restrict__ w_dw, float* __restrict__ dx,
+// TX / TG / TD: element types of x (or z), dY and dX
+template <int KPL, bool RP, typename TX, typename TG, typename TD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAVES, DWR_BWD_WAVES))) void k_dw3x3_bwd_rows(const TX* __restrict__ x, long x_bs,
+                                                         const TG* __restrict__ dy, long dy_bs,
+                                                         const float* __restrict__ w_dw, TD* __restrict__ dx,
                                                          long dx_bs, float* __restrict__ part, int Cin, int nplanes,
                                                          int N, const DwrGeom g, const float* __restrict__ bn_mean,
                                                          const float* __restrict__ bn_invstd,
@@ -244,9 +256,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAV
     const bool active = pvalid && band_ < g.nbands;  // the other lanes walk a valid band with every output masked
     const int band = band_ < g.nbands ? band_ : g.nbands - 1;
     const int r0 = band * g.BH;
-    const float* xp = x + (long)n * x_bs + (long)ci * g.P + 4 * q;
-    const float* dyp = dy + (long)n * dy_bs + (long)(ci * KPL) * g.P + 4 * q;
-    float* dxp = dx ? dx + (long)n * dx_bs + (long)ci * g.P + 4 * q : nullptr;
+    const TX* xp = x + (long)n * x_bs + (long)ci * g.P + 4 * q;
+    const TG* dyp = dy + (long)n * dy_bs + (long)(ci * KPL) * g.P + 4 * q;
+    TD* dxp = dx ? dx + (long)n * dx_bs + (long)ci * g.P + 4 * q : nullptr;
     float wt[KPL][9];
 #pragma unroll
     for (int j = 0; j < KPL; ++j)
@@ -268,8 +280,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAV
         float dxa[3][4], xc[3][4];
         float zraw[RP ? 3 : 1][4];
         float d[KPL][6];
-        DwrRaw raw[KPL];
-        float4 xn;
+        DwrRaw<TG> raw[KPL];
+        typename Elem<TX>::raw4 xn;
 #pragma unroll
         for (int s_ = 0; s_ < 3; ++s_)
 #pragma unroll
@@ -297,7 +309,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAV
                     for (int j = 0; j < KPL; ++j) dwr_finish(d[j], raw[j], rho, g.H, ln, false, 1.f, 0.f);
                     {  // open the slot of row rho + 1
                         const bool in = (rho + 1) >= r0 && (rho + 1) < r1;
-                        const float4 zv = xn;
+                        const float4 zv = cvt4(xn);
                         xc[sc_][0] = in ? dwr_act(zv.x, aff, asc, ash) : 0.f;
                         xc[sc_][1] = in ? dwr_act(zv.y, aff, asc, ash) : 0.f;
                         xc[sc_][2] = in ? dwr_act(zv.z, aff, asc, ash) : 0.f;
@@ -335,11 +347,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAV
                     const int rd = rho - 1;
                     const bool fin = rd >= r0 && rd < r1;
                     if (dxp && fin)
-                        *(float4*)(dxp + (long)rd * g.W) = make_float4(dxa[sa][0], dxa[sa][1], dxa[sa][2], dxa[sa][3]);
+                        st4(dxp + (long)rd * g.W, make_float4(dxa[sa][0], dxa[sa][1], dxa[sa][2], dxa[sa][3]));
                     if (RP) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
-                            const float gg = (fin && xc[sa][c] > 0.f) ? dxa[sa][c] : 0.f;
+                            // (the value the BatchNorm backward will read back from dX)
+                            const float gg = (fin && xc[sa][c] > 0.f) ? as_stored(dxp, dxa[sa][c]) : 0.f;
                             r1s += gg;
                             r2s = fmaf(gg, (zraw[sa][c] - rmean) * rinvstd, r2s);
                         }
@@ -381,43 +394,58 @@ int dw_rows_ok(int kpl, int H, int W) {
     return dwr_enabled() && (kpl == 1 || kpl == 2 || kpl == 4) && (W & 3) == 0 && W >= 4 && W <= 4096 && H >= 1;
 }
 
-int launch_dw3x3_fwd_rows(const float* x, long x_bs, const float* w_dw, const float* b_dw, float* y, long y_bs, int N,
-                          int Cin, int kpl, int H, int W, hipStream_t st, const float* in_scale,
+// x_dt / y_dt (/ dy_dt / dx_dt): SMAAT_F32 or SMAAT_BF16.  Built combinations: everything f32; bf16 outputs from an f32
+// or bf16 input (forward), bf16 dY with x and dX both f32 or both bf16 (backward).  -2 otherwise.
+int launch_dw3x3_fwd_rows(const void* x, int x_dt, long x_bs, const float* w_dw, const float* b_dw, void* y, int y_dt,
+                          long y_bs, int N, int Cin, int kpl, int H, int W, hipStream_t st, const float* in_scale,
                           const float* in_shift) {
     const int nplanes = N * Cin;
     const DwrGeom g = dw_rows_geom(nplanes, H, W);
     if (g.wpp == 0) return -2;
     const dim3 grid((unsigned)(((long)nplanes * g.wpp + 3) / 4)), blk(256);
-    if (kpl == 1)
-        hipLaunchKernelGGL(k_dw3x3_fwd_rows<1>, grid, blk, 0, st, x, x_bs, w_dw, b_dw, y, y_bs, Cin, nplanes, g, in_scale,
-                           in_shift);
-    else if (kpl == 2)
-        hipLaunchKernelGGL(k_dw3x3_fwd_rows<2>, grid, blk, 0, st, x, x_bs, w_dw, b_dw, y, y_bs, Cin, nplanes, g, in_scale,
-                           in_shift);
-    else
-        hipLaunchKernelGGL(k_dw3x3_fwd_rows<4>, grid, blk, 0, st, x, x_bs, w_dw, b_dw, y, y_bs, Cin, nplanes, g, in_scale,
-                           in_shift);
+#define DWF_GO(K, TX, TY)                                                                                              \
+    hipLaunchKernelGGL((k_dw3x3_fwd_rows<K, TX, TY>), grid, blk, 0, st, (const TX*)x, x_bs, w_dw, b_dw, (TY*)y, y_bs, Cin, \
+                       nplanes, g, in_scale, in_shift)
+#define DWF_K(TX, TY)                        \
+    do {                                     \
+        if (kpl == 1) DWF_GO(1, TX, TY);     \
+        else if (kpl == 2) DWF_GO(2, TX, TY); \
+        else DWF_GO(4, TX, TY);              \
+    } while (0)
+    if (x_dt == SMAAT_F32 && y_dt == SMAAT_F32) DWF_K(float, float);
+    else if (x_dt == SMAAT_F32 && y_dt == SMAAT_BF16) DWF_K(float, bf16_t);
+    else if (x_dt == SMAAT_BF16 && y_dt == SMAAT_BF16) DWF_K(bf16_t, bf16_t);
+    else return -2;
+#undef DWF_K
+#undef DWF_GO
     return (int)hipGetLastError();
 }
 
-int launch_dw3x3_bwd_rows(const float* x, long x_bs, const float* dy, long dy_bs, const float* w_dw, float* dx,
-                          long dx_bs, float* part, int N, int Cin, int kpl, int H, int W, hipStream_t st,
-                          const float* bn_mean, const float* bn_invstd, float* rpart, const float* in_scale,
-                          const float* in_shift) {
+int launch_dw3x3_bwd_rows(const void* x, int x_dt, long x_bs, const void* dy, int dy_dt, long dy_bs, const float* w_dw,
+                          void* dx, int dx_dt, long dx_bs, float* part, int N, int Cin, int kpl, int H, int W,
+                          hipStream_t st, const float* bn_mean, const float* bn_invstd, float* rpart,
+                          const float* in_scale, const float* in_shift) {
     const int nplanes = N * Cin;
     const DwrGeom g = dw_rows_geom(nplanes, H, W);
     if (g.wpp == 0) return -2;
+    if (kpl != 1 && kpl != 2) return -2;
     const dim3 grid((unsigned)(((long)nplanes * g.wpp + 3) / 4)), blk(256);
-#define DWR_GO(K, R)                                                                                                 \
-    hipLaunchKernelGGL((k_dw3x3_bwd_rows<K, R>), grid, blk, 0, st, x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, part, Cin, nplanes, \
-                       N, g, bn_mean, bn_invstd, rpart, in_scale, in_shift)
-    if (kpl == 1) {
-        if (rpart) DWR_GO(1, true); else DWR_GO(1, false);
-    } else if (kpl == 2) {
-        if (rpart) DWR_GO(2, true); else DWR_GO(2, false);
-    } else {
-        return -2;
-    }
+#define DWR_GO(K, R, TX, TG, TD)                                                                                       \
+    hipLaunchKernelGGL((k_dw3x3_bwd_rows<K, R, TX, TG, TD>), grid, blk, 0, st, (const TX*)x, x_bs, (const TG*)dy, dy_bs,   \
+                       w_dw, (TD*)dx, dx_bs, part, Cin, nplanes, N, g, bn_mean, bn_invstd, rpart, in_scale, in_shift)
+#define DWR_K(TX, TG, TD)                                                  \
+    do {                                                                   \
+        if (kpl == 1) {                                                    \
+            if (rpart) DWR_GO(1, true, TX, TG, TD); else DWR_GO(1, false, TX, TG, TD); \
+        } else {                                                           \
+            if (rpart) DWR_GO(2, true, TX, TG, TD); else DWR_GO(2, false, TX, TG, TD); \
+        }                                                                  \
+    } while (0)
+    if (x_dt == SMAAT_F32 && dy_dt == SMAAT_F32 && dx_dt == SMAAT_F32) DWR_K(float, float, float);
+    else if (x_dt == SMAAT_BF16 && dy_dt == SMAAT_BF16 && dx_dt == SMAAT_BF16) DWR_K(bf16_t, bf16_t, bf16_t);
+    else if (x_dt == SMAAT_F32 && dy_dt == SMAAT_BF16 && dx_dt == SMAAT_F32) DWR_K(float, bf16_t, float);
+    else return -2;
+#undef DWR_K
 #undef DWR_GO
     return (int)hipGetLastError();
 }

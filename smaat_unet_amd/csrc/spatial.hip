@@ -8,64 +8,68 @@
 // ---------------------------------------------------------------------------------
 // MaxPool 2x2 (floor mode).  grid: (N*C planes, segments of output pixels)
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_maxpool2_fwd(const float* __restrict__ x, long x_bs, float* __restrict__ y,
+// T: element type of x, y (and of dy, dx in the backward): f32 or bf16 storage
+template <typename T>
+__global__ __launch_bounds__(256) void k_maxpool2_fwd(const T* __restrict__ x, long x_bs, T* __restrict__ y,
                                                       long y_bs, int C, int H, int W) {
     const int Ho = H >> 1, Wo = W >> 1;
     const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
-    const float* xp = x + (long)n * x_bs + (long)c * H * W;
-    float* yp = y + (long)n * y_bs + (long)c * Ho * Wo;
+    const T* xp = x + (long)n * x_bs + (long)c * H * W;
+    T* yp = y + (long)n * y_bs + (long)c * Ho * Wo;
     const int Po = Ho * Wo;
     for (int o = blockIdx.y * 256 + threadIdx.x; o < Po; o += gridDim.y * 256) {
         const int i = o / Wo, j = o - i * Wo;
-        const float* p = xp + (long)(2 * i) * W + 2 * j;
-        const float2 a = *(const float2*)p;  // 2*j even; row start parity handled below
-        const float2 b2 = *(const float2*)(p + W);
-        yp[o] = fmaxf(fmaxf(a.x, a.y), fmaxf(b2.x, b2.y));
+        const T* p = xp + (long)(2 * i) * W + 2 * j;
+        const float2 a = ld2(p);  // 2*j even; row start parity handled below
+        const float2 b2 = ld2(p + W);
+        st1(yp + o, fmaxf(fmaxf(a.x, a.y), fmaxf(b2.x, b2.y)));
     }
 }
-// scalar variant for odd W (float2 loads would be misaligned)
-__global__ __launch_bounds__(256) void k_maxpool2_fwd_s(const float* __restrict__ x, long x_bs, float* __restrict__ y,
+// scalar variant for odd W (two-element loads would be misaligned)
+template <typename T>
+__global__ __launch_bounds__(256) void k_maxpool2_fwd_s(const T* __restrict__ x, long x_bs, T* __restrict__ y,
                                                         long y_bs, int C, int H, int W) {
     const int Ho = H >> 1, Wo = W >> 1;
     const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
-    const float* xp = x + (long)n * x_bs + (long)c * H * W;
-    float* yp = y + (long)n * y_bs + (long)c * Ho * Wo;
+    const T* xp = x + (long)n * x_bs + (long)c * H * W;
+    T* yp = y + (long)n * y_bs + (long)c * Ho * Wo;
     const int Po = Ho * Wo;
     for (int o = blockIdx.y * 256 + threadIdx.x; o < Po; o += gridDim.y * 256) {
         const int i = o / Wo, j = o - i * Wo;
-        const float* p = xp + (long)(2 * i) * W + 2 * j;
-        yp[o] = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[W], p[W + 1]));
+        const T* p = xp + (long)(2 * i) * W + 2 * j;
+        st1(yp + o, fmaxf(fmaxf(ld1(p), ld1(p + 1)), fmaxf(ld1(p + W), ld1(p + W + 1))));
     }
 }
 
 // dx: gradient goes to the FIRST maximum in scan order (0,0),(0,1),(1,0),(1,1); rows/cols
 // dropped by floor mode get zero.  One thread per INPUT pixel pair row -> full coverage.
-__global__ __launch_bounds__(256) void k_maxpool2_bwd(const float* __restrict__ x, long x_bs,
-                                                      const float* __restrict__ dy, long dy_bs,
-                                                      float* __restrict__ dx, long dx_bs, int C, int H, int W,
+template <typename T>
+__global__ __launch_bounds__(256) void k_maxpool2_bwd(const T* __restrict__ x, long x_bs,
+                                                      const T* __restrict__ dy, long dy_bs,
+                                                      T* __restrict__ dx, long dx_bs, int C, int H, int W,
                                                       int accum) {
     const int Ho = H >> 1, Wo = W >> 1;
     const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
-    const float* xp = x + (long)n * x_bs + (long)c * H * W;
-    const float* gp = dy + (long)n * dy_bs + (long)c * Ho * Wo;
-    float* dp = dx + (long)n * dx_bs + (long)c * H * W;
+    const T* xp = x + (long)n * x_bs + (long)c * H * W;
+    const T* gp = dy + (long)n * dy_bs + (long)c * Ho * Wo;
+    T* dp = dx + (long)n * dx_bs + (long)c * H * W;
     const int P = H * W;
     for (int p = blockIdx.y * 256 + threadIdx.x; p < P; p += gridDim.y * 256) {
         const int r = p / W, cc = p - r * W;
         const int i = r >> 1, j = cc >> 1;
         float g = 0.f;
         if (i < Ho && j < Wo) {
-            const float* q = xp + (long)(2 * i) * W + 2 * j;
-            const float v0 = q[0], v1 = q[1], v2 = q[W], v3 = q[W + 1];
+            const T* q = xp + (long)(2 * i) * W + 2 * j;
+            const float v0 = ld1(q), v1 = ld1(q + 1), v2 = ld1(q + W), v3 = ld1(q + W + 1);
             int am = 0;
             float m = v0;
             if (v1 > m) { m = v1; am = 1; }
             if (v2 > m) { m = v2; am = 2; }
             if (v3 > m) { m = v3; am = 3; }
             const int me = ((r & 1) << 1) | (cc & 1);
-            if (me == am) g = gp[i * Wo + j];
+            if (me == am) g = ld1(gp + i * Wo + j);
         }
-        dp[p] = accum ? dp[p] + g : g;
+        st1(dp + p, accum ? ld1(dp + p) + g : g);
     }
 }
 
@@ -332,9 +336,11 @@ __global__ __launch_bounds__(256) void k_upsample2x_bwd_sep(const float* __restr
 #define DWB_SMAX 768
 #define DWB_KPL_MAX 4
 
-__global__ __launch_bounds__(256) void k_dw3x3_bwd(const float* __restrict__ x, long x_bs,
-                                                   const float* __restrict__ dy, long dy_bs,
-                                                   const float* __restrict__ w_dw, float* __restrict__ dx,
+// TX / TG / TD: element types of x, dY, dX (f32 | bf16 storage)
+template <typename TX, typename TG, typename TD>
+__global__ __launch_bounds__(256) void k_dw3x3_bwd(const TX* __restrict__ x, long x_bs,
+                                                   const TG* __restrict__ dy, long dy_bs,
+                                                   const float* __restrict__ w_dw, TD* __restrict__ dx,
                                                    long dx_bs, float* __restrict__ part, int Cin, int kpl,
                                                    TileGeom g) {
     // grid: (N*Cin planes, tile groups).  part: [N*groups][Cdw][10]
@@ -343,9 +349,9 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd(const float* __restrict__ x, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int plane = blockIdx.x, n = plane / Cin, ci = plane - n * Cin;
     const int Cdw = Cin * kpl;
-    const float* xp = x + (long)n * x_bs + (long)ci * g.P;
-    const float* dyp = dy + (long)n * dy_bs + (long)(ci * kpl) * g.P;
-    float* dxp = dx ? dx + (long)n * dx_bs + (long)ci * g.P : nullptr;
+    const TX* xp = x + (long)n * x_bs + (long)ci * g.P;
+    const TG* dyp = dy + (long)n * dy_bs + (long)(ci * kpl) * g.P;
+    TD* dxp = dx ? dx + (long)n * dx_bs + (long)ci * g.P : nullptr;
 
     float accw[DWB_KPL_MAX][10];
 #pragma unroll
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd(const float* __restrict__ x, 
             sin[jj] = (e < rsize) && (gr >= 0 && gr < g.H && gc >= 0 && gc < g.W);
             const int go = sin[jj] ? gr * g.W + gc : 0;
 #pragma unroll
-            for (int j = 0; j < DWB_KPL_MAX; ++j) sv[jj][j] = dyp[(long)(j < kpl ? j : 0) * g.P + go];
+            for (int j = 0; j < DWB_KPL_MAX; ++j) sv[jj][j] = ld1(dyp + (long)(j < kpl ? j : 0) * g.P + go);
         }
         int r, c;
         if (g.mode == 1) {
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd(const float* __restrict__ x, 
             pvnext = tile_pixel(g, tl, tid, r, c);
         }
         pnext = pvnext ? r * g.W + c : 0;
-        xnext = xp[pnext];
+        xnext = ld1(xp + pnext);
     };
 
     int tl = blockIdx.y;
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_bwd(const float* __restrict__ x, 
                     accw[j][9] += d11;
                 }
             }
-            if (dxp) dxp[po] = dxa;
+            if (dxp) st1(dxp + po, dxa);
         }
     }
     // block reduction of the (kpl x 10) accumulators
@@ -687,38 +693,44 @@ __global__ __launch_bounds__(256, DWB_MINW) void k_dw3x3_bwd_strip(const float* 
 
 static inline int cdivs(long a, long b) { return (int)((a + b - 1) / b); }
 
-int launch_maxpool2_fwd(const float* x, long x_bs, float* y, long y_bs, int N, int C, int H, int W, hipStream_t st) {
+int launch_maxpool2_fwd(const void* x, long x_bs, void* y, long y_bs, int N, int C, int H, int W, hipStream_t st, int dt) {
     const int Po = (H / 2) * (W / 2);
     if (Po == 0) return -1;
     int gy = cdivs(Po, 1024);
     if (gy > 64) gy = 64;
     dim3 grid(N * C, gy);
-    if ((W & 1) == 0 && (x_bs & 1) == 0 && ((((uintptr_t)x) & 7) == 0))
-        hipLaunchKernelGGL(k_maxpool2_fwd, grid, dim3(256), 0, st, x, x_bs, y, y_bs, C, H, W);
-    else
-        hipLaunchKernelGGL(k_maxpool2_fwd_s, grid, dim3(256), 0, st, x, x_bs, y, y_bs, C, H, W);
+    SMAAT_DISPATCH_ET(dt, T,
+        if ((W & 1) == 0 && (x_bs & 1) == 0 && ((((uintptr_t)x) & (2 * sizeof(T) - 1)) == 0))
+            hipLaunchKernelGGL(k_maxpool2_fwd<T>, grid, dim3(256), 0, st, (const T*)x, x_bs, (T*)y, y_bs, C, H, W);
+        else
+            hipLaunchKernelGGL(k_maxpool2_fwd_s<T>, grid, dim3(256), 0, st, (const T*)x, x_bs, (T*)y, y_bs, C, H, W););
     return (int)hipGetLastError();
 }
 
-int launch_maxpool2_bwd(const float* x, long x_bs, const float* dy, long dy_bs, float* dx, long dx_bs, int N, int C,
-                        int H, int W, int accum, hipStream_t st) {
+int launch_maxpool2_bwd(const void* x, long x_bs, const void* dy, long dy_bs, void* dx, long dx_bs, int N, int C,
+                        int H, int W, int accum, hipStream_t st, int dt) {
     int gy = cdivs((long)H * W, 2048);
     if (gy > 64) gy = 64;
     dim3 grid(N * C, gy);
-    hipLaunchKernelGGL(k_maxpool2_bwd, grid, dim3(256), 0, st, x, x_bs, dy, dy_bs, dx, dx_bs, C, H, W, accum);
+    SMAAT_DISPATCH_ET(dt, T,
+        hipLaunchKernelGGL(k_maxpool2_bwd<T>, grid, dim3(256), 0, st, (const T*)x, x_bs, (const T*)dy, dy_bs, (T*)dx, dx_bs, C,
+                           H, W, accum););
     return (int)hipGetLastError();
 }
 
 // uprows.hip: row-walking kernels (float4 rows); -2 = shape / alignment not handled there
-int launch_upsample2x_fwd_rows(const float*, long, float*, long, int, int, int, int, int, int, int, int, hipStream_t);
-int launch_upsample2x_bwd_rows(const float*, long, float*, long, int, int, int, int, int, int, int, int, hipStream_t);
+int launch_upsample2x_fwd_rows(const void*, long, void*, long, int, int, int, int, int, int, int, int, hipStream_t, int);
+int launch_upsample2x_bwd_rows(const void*, long, void*, long, int, int, int, int, int, int, int, int, hipStream_t, int);
 
-int launch_upsample2x_fwd(const float* x, long x_bs, float* out, long out_bs, int N, int C, int H, int W, int Ho,
-                          int Wo, int pad_t, int pad_l, hipStream_t st) {
+// dt: SMAAT_F32 | SMAAT_BF16 (bf16 storage: the row-walking kernels only, -2 when they do not take the shape)
+int launch_upsample2x_fwd(const void* xv, long x_bs, void* outv, long out_bs, int N, int C, int H, int W, int Ho,
+                          int Wo, int pad_t, int pad_l, hipStream_t st, int dt) {
     {
-        const int rc = launch_upsample2x_fwd_rows(x, x_bs, out, out_bs, N, C, H, W, Ho, Wo, pad_t, pad_l, st);
-        if (rc != -2) return rc;
+        const int rc = launch_upsample2x_fwd_rows(xv, x_bs, outv, out_bs, N, C, H, W, Ho, Wo, pad_t, pad_l, st, dt);
+        if (rc != -2 || dt != SMAAT_F32) return rc;
     }
+    const float* x = (const float*)xv;
+    float* out = (float*)outv;
     int gy = cdivs((long)Ho * Wo, 2048);
     if (gy > 64) gy = 64;
     dim3 grid(N * C, gy);
@@ -726,12 +738,14 @@ int launch_upsample2x_fwd(const float* x, long x_bs, float* out, long out_bs, in
     return (int)hipGetLastError();
 }
 
-int launch_upsample2x_bwd(const float* dout, long dout_bs, float* dx, long dx_bs, int N, int C, int H, int W, int Ho,
-                          int Wo, int pad_t, int pad_l, hipStream_t st) {
+int launch_upsample2x_bwd(const void* doutv, long dout_bs, void* dxv, long dx_bs, int N, int C, int H, int W, int Ho,
+                          int Wo, int pad_t, int pad_l, hipStream_t st, int dt) {
     {
-        const int rc = launch_upsample2x_bwd_rows(dout, dout_bs, dx, dx_bs, N, C, H, W, Ho, Wo, pad_t, pad_l, st);
-        if (rc != -2) return rc;
+        const int rc = launch_upsample2x_bwd_rows(doutv, dout_bs, dxv, dx_bs, N, C, H, W, Ho, Wo, pad_t, pad_l, st, dt);
+        if (rc != -2 || dt != SMAAT_F32) return rc;
     }
+    const float* dout = (const float*)doutv;
+    float* dx = (float*)dxv;
     if (W <= 256) {
         const int PB = 256 / W;
         const int NC = N * C;
@@ -928,10 +942,10 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_strip(const float* __restrict
 #define DWS_LDS_FLOATS 8192
 #define DWS_NLD 24  // staged values per thread
 
-template <int KPL>
-__global__ __launch_bounds__(256) void k_dw3x3_fwd_small(const float* __restrict__ x, long x_bs,
+template <int KPL, typename TX, typename TY>
+__global__ __launch_bounds__(256) void k_dw3x3_fwd_small(const TX* __restrict__ x, long x_bs,
                                                          const float* __restrict__ w_dw, const float* __restrict__ b_dw,
-                                                         float* __restrict__ y, long y_bs, int NC, int Cin, int H, int W,
+                                                         TY* __restrict__ y, long y_bs, int NC, int Cin, int H, int W,
                                                          int PPB, const float* __restrict__ in_scale,
                                                          const float* __restrict__ in_shift) {
     // PPB (a power of two <= 16) planes per group; the 256 / PPB threads of a plane keep its taps in registers
@@ -947,12 +961,12 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_small(const float* __restrict
         const int pi = g * PPB + pl;
         const int pic = pi < NC ? pi : NC - 1;
         const int n = pic / Cin, ci = pic - n * Cin;
-        const float* xp = x + (long)n * x_bs + (long)ci * P;
+        const TX* xp = x + (long)n * x_bs + (long)ci * P;
         const float sc = in_scale ? in_scale[ci] : 1.f, sh = in_scale ? in_shift[ci] : 0.f;
 #pragma unroll
         for (int k = 0; k < DWS_NLD; ++k) {
             const int p = lt + TPP * k;
-            float v = xp[p < P ? p : P - 1];
+            float v = ld1(xp + (p < P ? p : P - 1));
             if (in_scale) v = fmaxf(fmaf(v, sc, sh), 0.f);
             sv[k] = v;
         }
@@ -988,7 +1002,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_small(const float* __restrict
         if (pi < NC) {
             const int n = pi / Cin, ci = pi - n * Cin;
             const float* sb = dsm + pl * P;
-            float* yb = y + (long)n * y_bs + (long)(ci * KPL) * P;
+            TY* yb = y + (long)n * y_bs + (long)(ci * KPL) * P;
             for (int p = lt; p < P; p += TPP) {
                 const int r = (int)(((float)p + 0.5f) * invW), c = p - r * W;
                 const float* sp = sb + p;
@@ -1005,16 +1019,16 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_small(const float* __restrict
                     float acc = b0[j];
 #pragma unroll
                     for (int t = 0; t < 9; ++t) acc = fmaf(w0[j][t], v[t / 3][t % 3], acc);
-                    yb[(long)j * P + p] = acc;
+                    st1(yb + (long)j * P + p, acc);
                 }
             }
         }
     }
 }
 
-static int launch_dw3x3_fwd_small(const float* x, long x_bs, const float* w_dw, const float* b_dw, float* y, long y_bs,
-                                  int N, int Cin, int kpl, int H, int W, hipStream_t st, const float* in_scale,
-                                  const float* in_shift) {
+static int launch_dw3x3_fwd_small(const void* x, int x_dt, long x_bs, const float* w_dw, const float* b_dw, void* y,
+                                  int y_dt, long y_bs, int N, int Cin, int kpl, int H, int W, hipStream_t st,
+                                  const float* in_scale, const float* in_shift) {
     const int P = H * W;
     int PPB = 16;  // planes per workgroup: a power of two, 256 / PPB threads per plane, <= DWS_NLD staged values per thread
     while (PPB > 1 && ((P + 256 / PPB - 1) / (256 / PPB) > DWS_NLD || PPB * P > DWS_LDS_FLOATS)) PPB >>= 1;
@@ -1023,10 +1037,20 @@ static int launch_dw3x3_fwd_small(const float* x, long x_bs, const float* w_dw, 
     int grid = (NC + PPB - 1) / PPB;
     if (grid > 2048) grid = 2048;
     const size_t lds = sizeof(float) * (size_t)PPB * P;
-#define DWS_LAUNCH(K) hipLaunchKernelGGL(k_dw3x3_fwd_small<K>, dim3(grid), dim3(256), lds, st, x, x_bs, w_dw, b_dw, y, y_bs, NC, Cin, H, W, PPB, in_scale, in_shift)
-    if (kpl == 1) DWS_LAUNCH(1);
-    else if (kpl == 2) DWS_LAUNCH(2);
-    else DWS_LAUNCH(4);
+#define DWS_LAUNCH(K, TX, TY)                                                                                          \
+    hipLaunchKernelGGL((k_dw3x3_fwd_small<K, TX, TY>), dim3(grid), dim3(256), lds, st, (const TX*)x, x_bs, w_dw, b_dw,  \
+                       (TY*)y, y_bs, NC, Cin, H, W, PPB, in_scale, in_shift)
+#define DWS_K(TX, TY)                          \
+    do {                                       \
+        if (kpl == 1) DWS_LAUNCH(1, TX, TY);   \
+        else if (kpl == 2) DWS_LAUNCH(2, TX, TY); \
+        else DWS_LAUNCH(4, TX, TY);            \
+    } while (0)
+    if (x_dt == SMAAT_F32 && y_dt == SMAAT_F32) DWS_K(float, float);
+    else if (x_dt == SMAAT_F32 && y_dt == SMAAT_BF16) DWS_K(float, bf16_t);
+    else if (x_dt == SMAAT_BF16 && y_dt == SMAAT_BF16) DWS_K(bf16_t, bf16_t);
+    else return -2;
+#undef DWS_K
 #undef DWS_LAUNCH
     return (int)hipGetLastError();
 }
@@ -1034,21 +1058,27 @@ static int launch_dw3x3_fwd_small(const float* x, long x_bs, const float* w_dw, 
 // dwrows.hip: register row-streaming kernels (W % 4 == 0)
 int dw_rows_ok(int kpl, int H, int W);
 int dw_rows_wpp(int N, int Cin, int H, int W);
-int launch_dw3x3_fwd_rows(const float*, long, const float*, const float*, float*, long, int, int, int, int, int,
+int launch_dw3x3_fwd_rows(const void*, int, long, const float*, const float*, void*, int, long, int, int, int, int, int,
                           hipStream_t, const float*, const float*);
-int launch_dw3x3_bwd_rows(const float*, long, const float*, long, const float*, float*, long, float*, int, int, int, int,
-                          int, hipStream_t, const float*, const float*, float*, const float*, const float*);
+int launch_dw3x3_bwd_rows(const void*, int, long, const void*, int, long, const float*, void*, int, long, float*, int, int,
+                          int, int, int, hipStream_t, const float*, const float*, float*, const float*, const float*);
 
-int launch_dw3x3_fwd(const float* x, long x_bs, const float* w_dw, const float* b_dw, float* y, long y_bs, int N,
-                     int Cin, int kpl, int H, int W, hipStream_t st, const float* in_scale, const float* in_shift) {
-    const bool aligned = ((W & 3) == 0) && ((x_bs & 3) == 0) && ((((uintptr_t)x) & 15) == 0) && H >= 1 &&
+// x_dt / y_dt: SMAAT_F32 | SMAAT_BF16 (bf16 storage: the row-streaming and the small-plane kernels only)
+int launch_dw3x3_fwd(const void* xv, int x_dt, long x_bs, const float* w_dw, const float* b_dw, void* yv, int y_dt,
+                     long y_bs, int N, int Cin, int kpl, int H, int W, hipStream_t st, const float* in_scale,
+                     const float* in_shift) {
+    const unsigned xm = x_dt == SMAAT_BF16 ? 7u : 15u, ym = y_dt == SMAAT_BF16 ? 7u : 15u;
+    const bool aligned = ((W & 3) == 0) && ((x_bs & 3) == 0) && ((((uintptr_t)xv) & xm) == 0) && H >= 1 &&
                          (kpl == 1 || kpl == 2 || kpl == 4);
     if (!(kpl == 1 || kpl == 2 || kpl == 4)) return -2;
     if (!aligned && H * W <= DWS_PMAX)  // small planes with unaligned rows (18 x 18 ...): the flat-copy kernel
-        return launch_dw3x3_fwd_small(x, x_bs, w_dw, b_dw, y, y_bs, N, Cin, kpl, H, W, st, in_scale, in_shift);
+        return launch_dw3x3_fwd_small(xv, x_dt, x_bs, w_dw, b_dw, yv, y_dt, y_bs, N, Cin, kpl, H, W, st, in_scale, in_shift);
     if (!aligned) return -2;  // caller falls back to the fused f32 kernel
-    if (dw_rows_ok(kpl, H, W) && (y_bs & 3) == 0 && ((((uintptr_t)y) & 15) == 0))
-        return launch_dw3x3_fwd_rows(x, x_bs, w_dw, b_dw, y, y_bs, N, Cin, kpl, H, W, st, in_scale, in_shift);
+    if (dw_rows_ok(kpl, H, W) && (y_bs & 3) == 0 && ((((uintptr_t)yv) & ym) == 0))
+        return launch_dw3x3_fwd_rows(xv, x_dt, x_bs, w_dw, b_dw, yv, y_dt, y_bs, N, Cin, kpl, H, W, st, in_scale, in_shift);
+    if (x_dt != SMAAT_F32 || y_dt != SMAAT_F32) return -2;
+    const float* x = (const float*)xv;
+    float* y = (float*)yv;
     const DwbGeom sg = strip_geom(H, W, 1);
     if (sg.nrow * sg.ncol4 > 1536) return -2;
     long planes = (long)N * Cin;
@@ -1083,9 +1113,10 @@ int dw_bwd_groups(int N, int Cin, int H, int W) {
     return groups;
 }
 
-int launch_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, const float* w_dw, float* dx, long dx_bs,
-                     float* part, int N, int Cin, int kpl, int H, int W, hipStream_t st, const float* bn_g,
-                     const float* bn_b, float* rpart, const float* in_scale, const float* in_shift) {
+// x_dt / dy_dt / dx_dt: SMAAT_F32 | SMAAT_BF16 (bf16 storage: the row-streaming and the generic kernels only)
+int launch_dw3x3_bwd(const void* xv, int x_dt, long x_bs, const void* dyv, int dy_dt, long dy_bs, const float* w_dw,
+                     void* dxv, int dx_dt, long dx_bs, float* part, int N, int Cin, int kpl, int H, int W, hipStream_t st,
+                     const float* bn_g, const float* bn_b, float* rpart, const float* in_scale, const float* in_shift) {
     if (kpl < 1 || kpl > DWB_KPL_MAX) return -1;
     const int groups = dw_bwd_groups(N, Cin, H, W);
     static int use_strip = -1;
@@ -1093,14 +1124,19 @@ int launch_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, con
         const char* e = getenv("SMAAT_DWB_STRIP");
         use_strip = e ? atoi(e) : 1;
     }
+    const bool all32 = x_dt == SMAAT_F32 && dy_dt == SMAAT_F32 && dx_dt == SMAAT_F32;
+    const unsigned xm = x_dt == SMAAT_BF16 ? 7u : 15u, gm = dy_dt == SMAAT_BF16 ? 7u : 15u, dm = dx_dt == SMAAT_BF16 ? 7u : 15u;
     const bool aligned = ((W & 3) == 0) && ((x_bs & 3) == 0) && ((dy_bs & 3) == 0) && ((dx_bs & 3) == 0) &&
-                         ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)dy) & 15) == 0) &&
-                         ((((uintptr_t)dx) & 15) == 0) && (kpl == 1 || kpl == 2 || kpl == 4) && H >= 4;
+                         ((((uintptr_t)xv) & xm) == 0) && ((((uintptr_t)dyv) & gm) == 0) &&
+                         ((((uintptr_t)dxv) & dm) == 0) && (kpl == 1 || kpl == 2 || kpl == 4) && H >= 4;
     if (rpart && !in_scale) return -2;  // the fused reduction needs the pre-BatchNorm tensor (zhat = (z - mean) * invstd)
     if (aligned && kpl <= 2 && dw_rows_ok(kpl, H, W))
-        return launch_dw3x3_bwd_rows(x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, part, N, Cin, kpl, H, W, st, bn_g, bn_b, rpart,
-                                     in_scale, in_shift);
-    if (use_strip && aligned) {
+        return launch_dw3x3_bwd_rows(xv, x_dt, x_bs, dyv, dy_dt, dy_bs, w_dw, dxv, dx_dt, dx_bs, part, N, Cin, kpl, H, W, st,
+                                     bn_g, bn_b, rpart, in_scale, in_shift);
+    if (use_strip && aligned && all32) {
+        const float* x = (const float*)xv;
+        const float* dy = (const float*)dyv;
+        float* dx = (float*)dxv;
         const DwbGeom sg = strip_geom(H, W, kpl);
         if (kpl * sg.nrow * sg.ncol4 <= 1536) {
             const size_t lds = sizeof(float) * ((size_t)kpl * sg.ssz + 4 * kpl * 10 + 8);
@@ -1117,12 +1153,18 @@ int launch_dw3x3_bwd(const float* x, long x_bs, const float* dy, long dy_bs, con
             return (int)hipGetLastError();
         }
     }
-    if (rpart || in_scale) return -2;  // the fused BatchNorm pieces exist in the strip kernel only
+    if (rpart || in_scale) return -2;  // the fused BatchNorm pieces exist in the row / strip kernels only
     TileGeom g;
     choose_geom_pub(N, H, W, 256, DWB_SMAX, &g);
     if (g.mode < 0) return -1;
-    hipLaunchKernelGGL(k_dw3x3_bwd, dim3(N * Cin, groups), dim3(256), 0, st, x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, part,
-                       Cin, kpl, g);
+#define DWG_GO(TX, TG, TD)                                                                                               \
+    hipLaunchKernelGGL((k_dw3x3_bwd<TX, TG, TD>), dim3(N * Cin, groups), dim3(256), 0, st, (const TX*)xv, x_bs, (const TG*)dyv, \
+                       dy_bs, w_dw, (TD*)dxv, dx_bs, part, Cin, kpl, g)
+    if (all32) DWG_GO(float, float, float);
+    else if (x_dt == SMAAT_BF16 && dy_dt == SMAAT_BF16 && dx_dt == SMAAT_BF16) DWG_GO(bf16_t, bf16_t, bf16_t);
+    else if (x_dt == SMAAT_F32 && dy_dt == SMAAT_BF16 && dx_dt == SMAAT_F32) DWG_GO(float, bf16_t, float);
+    else return -2;
+#undef DWG_GO
     return (int)hipGetLastError();
 }
 

@@ -40,16 +40,18 @@ struct UprGeom {
 // ---------------------------------------------------------------------------------------------------------------
 // forward (Wo % 4 == 0, 16-byte aligned output planes)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_upsample2x_fwd_rows(const float* __restrict__ x, long x_bs,
-                                                             float* __restrict__ out, long out_bs, const UprGeom g) {
+// T: element type of x and out (f32 | bf16 storage)
+template <typename T>
+__global__ __launch_bounds__(256) void k_upsample2x_fwd_rows(const T* __restrict__ x, long x_bs,
+                                                             T* __restrict__ out, long out_bs, const UprGeom g) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= g.total) return;
     const int per = g.nbands * g.ntr;
     const int plane = (int)(gid / per), rem = (int)(gid - (long)plane * per);
     const int band = rem / g.ntr, q = rem - band * g.ntr;
     const int n = plane / g.C, c = plane - n * g.C;
-    const float* xp = x + (long)n * x_bs + (long)c * g.H * g.W;
-    float* op = out + (long)n * out_bs + (long)c * g.Ho * g.Wo + 4 * q;
+    const T* xp = x + (long)n * x_bs + (long)c * g.H * g.W;
+    T* op = out + (long)n * out_bs + (long)c * g.Ho * g.Wo + 4 * q;
     const int H2 = 2 * g.H, W2 = 2 * g.W;
     const float sh = H2 > 1 ? (float)(g.H - 1) / (float)(H2 - 1) : 0.f;
     const float sw = W2 > 1 ? (float)(g.W - 1) / (float)(W2 - 1) : 0.f;
@@ -70,9 +72,9 @@ __global__ __launch_bounds__(256) void k_upsample2x_fwd_rows(const float* __rest
     float htop[4], hbot[4];
     int cur = -2;
     auto hrow = [&](int row, float (&hv)[4]) {
-        const float* p = xp + (long)(row < g.H - 1 ? row : g.H - 1) * g.W;
+        const T* p = xp + (long)(row < g.H - 1 ? row : g.H - 1) * g.W;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) hv[i] = bilerp_h(b0[i], p[c0[i]], b1[i], p[c1[i]]);
+        for (int i = 0; i < 4; ++i) hv[i] = bilerp_h(b0[i], ld1(p + c0[i]), b1[i], ld1(p + c1[i]));
     };
     for (int r = ro0; r < ro1; ++r) {
         const int ur = r - g.pad_t;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void k_upsample2x_fwd_rows(const float* __rest
             for (int i = 0; i < 4; ++i) v[i] = cv[i] ? bilerp_v(a0, htop[i], a1, hbot[i]) : 0.f;
             o = make_float4(v[0], v[1], v[2], v[3]);
         }
-        *(float4*)(op + (long)r * g.Wo) = o;
+        st4(op + (long)r * g.Wo, o);
     }
 }
 
@@ -104,8 +106,9 @@ __global__ __launch_bounds__(256) void k_upsample2x_fwd_rows(const float* __rest
 // backward (W even, Wo % 4 == 0, pad_l % 4 == 0, 16-byte aligned gradient planes)
 // thread mm = m + 1 of a band row owns the input columns wA = 2m + 1 and wB = 2m + 2, m = -1 .. W/2 - 1
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_upsample2x_bwd_rows(const float* __restrict__ dout, long dout_bs,
-                                                             float* __restrict__ dx, long dx_bs, const UprGeom g) {
+template <typename T>
+__global__ __launch_bounds__(256) void k_upsample2x_bwd_rows(const T* __restrict__ dout, long dout_bs,
+                                                             T* __restrict__ dx, long dx_bs, const UprGeom g) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= g.total) return;
     const int per = g.nbands * g.ntr;
@@ -113,8 +116,8 @@ __global__ __launch_bounds__(256) void k_upsample2x_bwd_rows(const float* __rest
     const int band = rem / g.ntr, mm = rem - band * g.ntr;
     const int m = mm - 1;
     const int n = plane / g.C, c = plane - n * g.C;
-    const float* gp = dout + (long)n * dout_bs + (long)c * g.Ho * g.Wo;
-    float* dp = dx + (long)n * dx_bs + (long)c * g.H * g.W;
+    const T* gp = dout + (long)n * dout_bs + (long)c * g.Ho * g.Wo;
+    T* dp = dx + (long)n * dx_bs + (long)c * g.H * g.W;
     const int H2 = 2 * g.H, W2 = 2 * g.W;
     const float sh = H2 > 1 ? (float)(g.H - 1) / (float)(H2 - 1) : 0.f;
     const float sw = W2 > 1 ? (float)(g.W - 1) / (float)(W2 - 1) : 0.f;
@@ -156,8 +159,8 @@ __global__ __launch_bounds__(256) void k_upsample2x_bwd_rows(const float* __rest
     }
     auto flush = [&](int row, float a, float b) {
         if (row >= h0 && row < h1) {
-            if (vA) dp[(long)row * g.W + wA] = a;
-            if (vB) dp[(long)row * g.W + wB] = b;
+            if (vA) st1(dp + (long)row * g.W + wA, a);
+            if (vB) st1(dp + (long)row * g.W + wB, b);
         }
     };
     for (int orow = olo; orow <= ohi; ++orow) {
@@ -172,8 +175,8 @@ __global__ __launch_bounds__(256) void k_upsample2x_bwd_rows(const float* __rest
             cur = r0;
         }
         const int gr = orow + g.pad_t;  // pad_t >= 0 and 2H + pad_t <= Ho: always inside the gradient plane
-        const float* grow = gp + (long)gr * g.Wo;
-        const float4 f0 = *(const float4*)(grow + o0), f1 = *(const float4*)(grow + o1);
+        const T* grow = gp + (long)gr * g.Wo;
+        const float4 f0 = ld4(grow + o0), f1 = ld4(grow + o1);
         const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
         float cA = 0.f, cB = 0.f;
 #pragma unroll
@@ -226,24 +229,29 @@ static UprGeom upr_geom(int N, int C, int H, int W, int Ho, int Wo, int pad_t, i
 }
 
 // return -2: shape / alignment not handled here (the caller uses the element-per-thread kernels)
-int launch_upsample2x_fwd_rows(const float* x, long x_bs, float* out, long out_bs, int N, int C, int H, int W, int Ho,
-                               int Wo, int pad_t, int pad_l, hipStream_t st) {
-    if (!upr_enabled() || (Wo & 3) != 0 || (out_bs & 3) != 0 || ((((uintptr_t)out) & 15) != 0) || H < 1 || W < 1)
+// dt: SMAAT_F32 | SMAAT_BF16 element type of both tensors
+int launch_upsample2x_fwd_rows(const void* x, long x_bs, void* out, long out_bs, int N, int C, int H, int W, int Ho,
+                               int Wo, int pad_t, int pad_l, hipStream_t st, int dt) {
+    const unsigned am = dt == SMAAT_BF16 ? 7u : 15u;
+    if (!upr_enabled() || (Wo & 3) != 0 || (out_bs & 3) != 0 || ((((uintptr_t)out) & am) != 0) || H < 1 || W < 1)
         return -2;
     const UprGeom g = upr_geom(N, C, H, W, Ho, Wo, pad_t, pad_l, Wo / 4, Ho, 32);
     if (g.total > (1L << 31) * 256L) return -2;
-    hipLaunchKernelGGL(k_upsample2x_fwd_rows, dim3((unsigned)((g.total + 255) / 256)), dim3(256), 0, st, x, x_bs, out,
-                       out_bs, g);
+    SMAAT_DISPATCH_ET(dt, T,
+        hipLaunchKernelGGL(k_upsample2x_fwd_rows<T>, dim3((unsigned)((g.total + 255) / 256)), dim3(256), 0, st, (const T*)x,
+                           x_bs, (T*)out, out_bs, g););
     return (int)hipGetLastError();
 }
 
-int launch_upsample2x_bwd_rows(const float* dout, long dout_bs, float* dx, long dx_bs, int N, int C, int H, int W,
-                               int Ho, int Wo, int pad_t, int pad_l, hipStream_t st) {
+int launch_upsample2x_bwd_rows(const void* dout, long dout_bs, void* dx, long dx_bs, int N, int C, int H, int W,
+                               int Ho, int Wo, int pad_t, int pad_l, hipStream_t st, int dt) {
+    const unsigned am = dt == SMAAT_BF16 ? 7u : 15u;
     if (!upr_enabled() || (W & 1) != 0 || (Wo & 3) != 0 || (pad_l & 3) != 0 || (dout_bs & 3) != 0 ||
-        ((((uintptr_t)dout) & 15) != 0) || pad_t < 0 || pad_l < 0 || 2 * H + pad_t > Ho || 2 * W + pad_l > Wo)
+        ((((uintptr_t)dout) & am) != 0) || pad_t < 0 || pad_l < 0 || 2 * H + pad_t > Ho || 2 * W + pad_l > Wo)
         return -2;
     const UprGeom g = upr_geom(N, C, H, W, Ho, Wo, pad_t, pad_l, W / 2 + 1, H, 16);
-    hipLaunchKernelGGL(k_upsample2x_bwd_rows, dim3((unsigned)((g.total + 255) / 256)), dim3(256), 0, st, dout, dout_bs,
-                       dx, dx_bs, g);
+    SMAAT_DISPATCH_ET(dt, T,
+        hipLaunchKernelGGL(k_upsample2x_bwd_rows<T>, dim3((unsigned)((g.total + 255) / 256)), dim3(256), 0, st, (const T*)dout,
+                           dout_bs, (T*)dx, dx_bs, g););
     return (int)hipGetLastError();
 }
