@@ -13,6 +13,7 @@ import os
 
 from torch import nn
 
+from . import ops
 from .layers import CBAM, batched_counters
 from .unet_parts import OutConv
 from .unet_parts_depthwise_separable import DoubleConvDS, DownDS, UpDS
@@ -46,6 +47,21 @@ class UNetDSFamily(nn.Module):
             cat_channels //= 2
         self.outc = OutConv(64, n_classes)
 
+    # -- precision -----------------------------------------------------------------------------------------
+    def set_precision(self, mode):
+        """"f32" (default) or "bf16" = mixed precision (BASELINE configs[3]): activations and their gradients are stored as
+        bfloat16, pointwise GEMMs run on the bf16 matrix pipe with f32 accumulation, parameters / gradients of parameters
+        / BatchNorm statistics stay f32.  The reference has no such switch; the equivalent there is Lightning's
+        precision="bf16-mixed" (torch.autocast around models/SmaAt_UNet.py:41-57), which this module honours too: under
+        torch.autocast(device_type="cuda", dtype=torch.bfloat16) the forward runs in mixed precision without this call.
+        Inputs and logits stay float32.  Applies to the training / grad-enabled path; the eval fast path is f32.
+        None = follow the surrounding `smaat_unet_amd.precision(...)` context / autocast."""
+        if mode not in (None, "f32", "bf16"):
+            raise ValueError("precision must be 'f32', 'bf16' or None")
+        self._precision = mode
+        self.__dict__["_graphs"] = {}
+        return self
+
     # -- pieces ------------------------------------------------------------------------------------------
     def _levels(self):
         downs = [getattr(self, f"down{l}") for l in range(1, 5)]
@@ -68,25 +84,71 @@ class UNetDSFamily(nn.Module):
         return True
 
     # ---- inference: the whole forward as ONE captured hipGraph, owned by the module -----------------------------
+    MAX_EVAL_GRAPHS = 8  # captured input shapes kept per module (least recently used one dropped beyond that)
+
     def enable_eval_graph(self, enabled=True, clone_output=True):
         """Inference (eval mode under no_grad, reference call stack D): capture the forward for every input shape
         seen into a hipGraph and replay it -- ~40 kernel launches become one graph launch.  The graph is rebuilt when
-        any parameter / buffer changes (tensor versions) or the shape changes.  clone_output=False returns the graph's
-        static output buffer (overwritten by the next call) and saves one copy."""
+        a parameter / buffer changes or the shape changes.  clone_output=False returns the graph's static output buffer
+        (overwritten by the next call) and saves one copy.
+
+        Change detection is cheap by construction (it runs on every call of a 0.6 ms forward): the sum of the autograd
+        version counters of the parameters and buffers -- every in-place torch operation, optimizer step and
+        load_state_dict bumps one -- plus a dirty flag raised by train(), .to() / .half() / ... (`_apply`),
+        load_state_dict, set_precision and invalidate_eval_cache().  Writes through `.data` (EMA / SWA weight swaps,
+        `.data`-based clamping) bypass the version counters: call `invalidate_eval_cache()` after them."""
         self._graph_enabled = bool(enabled)
         self._graph_clone = bool(clone_output)
         self._graphs = {}
+        self._sig_tensors = None
         return self
 
+    def invalidate_eval_cache(self):
+        """Drop everything the inference fast path derived from the weights: captured hipGraphs, BatchNorm folded into
+        the pointwise weights and their operand images (DoubleConvDS._fold_cache).  Needed after weight updates that
+        bypass torch's version counters (writes through `.data`); everything else is detected automatically."""
+        self._graphs = {}
+        self._sig_tensors = None
+        for m in self.modules():
+            if "_fold_cache" in m.__dict__:
+                m.__dict__["_fold_cache"] = {}
+        return self
+
+    def train(self, mode=True):
+        if mode:  # weights are about to change: captured inference state is stale from here on
+            self.__dict__["_graphs"] = {}
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **kw):
+        self.__dict__["_graphs"] = {}
+        self.__dict__["_sig_tensors"] = None
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        r = super().load_state_dict(*a, **kw)
+        self.invalidate_eval_cache()
+        return r
+
     def _weights_signature(self):
-        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        ts = self.__dict__.get("_sig_tensors")
+        if ts is None:  # (the flat tensor list is rebuilt after _apply / load_state_dict / invalidate_eval_cache)
+            ts = self.__dict__["_sig_tensors"] = list(self.parameters()) + list(self.buffers())
+        v = 0
+        for t in ts:
+            v += t._version
+        return v
 
     def _graph_forward(self, x):
         import torch
         key = (tuple(x.shape), x.dtype, x.device)
         sig = self._weights_signature()
         ent = self._graphs.get(key)
-        if ent is None or ent["sig"] != sig:
+        if ent is not None and ent["sig"] != sig:
+            self.invalidate_eval_cache()  # (the folded weights are stale as well)
+            ent = None
+        if ent is None:
+            while len(self._graphs) >= self.MAX_EVAL_GRAPHS:
+                self._graphs.pop(next(iter(self._graphs)))
             static_in = x.detach().clone()
             side = torch.cuda.Stream(device=x.device)
             side.wait_stream(torch.cuda.current_stream(x.device))
@@ -96,7 +158,9 @@ class UNetDSFamily(nn.Module):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 static_out = self._forward_impl(static_in)
-            ent = self._graphs[key] = dict(sig=sig, graph=g, x=static_in, y=static_out)
+            ent = self._graphs[key] = dict(sig=self._weights_signature(), graph=g, x=static_in, y=static_out)
+        else:
+            self._graphs[key] = self._graphs.pop(key)  # most recently used last
         ent["x"].copy_(x)
         ent["graph"].replay()
         return ent["y"].clone() if self._graph_clone else ent["y"]
@@ -106,8 +170,10 @@ class UNetDSFamily(nn.Module):
         if (getattr(self, "_graph_enabled", False) and not self.training and not torch.is_grad_enabled() and x.is_cuda
                 and not torch.cuda.is_current_stream_capturing()):
             return self._graph_forward(x)
-        with batched_counters():  # one add for all num_batches_tracked counters of the step
-            return self._forward_impl(x)
+        with batched_counters(), ops.precision(getattr(self, "_precision", None)):
+            # (batched_counters: one add for all num_batches_tracked counters of the step)
+            out = self._forward_impl(x)
+        return out.float() if out.dtype != x.dtype and x.dtype.is_floating_point else out
 
     def _forward_impl(self, x):
         # NB (reference SmaAt_UNet.py:41-57): the encoder continues from the UN-attended x_i; the CBAM

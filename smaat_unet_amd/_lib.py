@@ -194,7 +194,24 @@ def _w_pw_split(a):
     return 2.0 * n * cin * m * h * w, 4.0 * n * (cin + m) * h * w
 
 
+def _es(dt):
+    return 2.0 if dt == 1 else 4.0
+
+
 WORK_MODELS = {
+    # mixed precision: algorithmic bytes with the element sizes actually passed
+    "smaat_pointwise_fwd_bf16": lambda a: (2.0 * a[8] * a[9] * a[10] * a[11] * a[12],
+                                           a[8] * (2.0 * a[9] + _es(a[6]) * a[10]) * a[11] * a[12]),
+    "smaat_pointwise_wgrad_bf16": lambda a: (2.0 * a[6] * a[7] * a[8] * a[9] * a[10], 2.0 * a[6] * (a[7] + a[8]) * a[9] * a[10]),
+    "smaat_dw3x3_fwd_t": lambda a: (18.0 * a[10] * a[11] * a[12] * a[13] * a[14],
+                                    a[10] * a[11] * (_es(a[1]) + _es(a[8]) * a[12]) * a[13] * a[14]),
+    "smaat_dw3x3_bwd_t": lambda a: (38.0 * a[18] * a[19] * a[20] * a[21] * a[22],
+                                    a[18] * a[19] * (_es(a[6]) * a[20] + _es(a[1]) + (_es(a[10]) if a[9] else 0.0)) * a[21] * a[22]),
+    "smaat_affine_act_t": lambda a: (2.0 * a[8] * a[9] * a[10], (_es(a[1]) + _es(a[6])) * a[8] * a[9] * a[10]),
+    "smaat_bn_bwd_reduce_t": lambda a: (6.0 * a[11] * a[12] * a[13],
+                                        (_es(a[4]) * a[12] + _es(a[1]) * (1 if a[15] else a[12])) * a[11] * a[13]),
+    "smaat_bn_bwd_apply_t": lambda a: (8.0 * a[14] * a[15] * a[16],
+                                       ((_es(a[4]) + _es(a[12])) * a[15] + _es(a[1]) * (1 if a[18] else a[15])) * a[14] * a[16]),
     "smaat_dw3x3_bwd_bnred": lambda a: (38.0 * a[15] * a[16] * a[17] * a[18] * a[19],
                                         4.0 * a[15] * (a[16] * a[17] + 2 * a[16]) * a[18] * a[19]),
     "smaat_pointwise_fwd_split": _w_pw_split,

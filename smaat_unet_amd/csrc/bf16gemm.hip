@@ -52,6 +52,12 @@ __device__ __forceinline__ s16x4 lds_rd_tr(unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
 }
+template <int OFF>
+__device__ __forceinline__ float2 lds_rd64(unsigned addr) {
+    float2 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
 template <int GW>
 __device__ __forceinline__ void glds(const void* src, void* lds_dst) {
     static_assert(GW == 16 || GW == 4, "LDS-DMA width");
@@ -90,8 +96,16 @@ int launch_bf16_planes(const float* w, int R, int C, bf16_t* out, int src_t, hip
 #define BF_NST 3  // LDS stages
 
 // GW: bytes per lane of an activation LDS-DMA (16: P % 8 == 0; 4: P % 2 == 0 -- the 18 x 18 planes)
+//
+// PERSISTENT over (pixel tile, channel tile) items: a workgroup walks the items idx0, idx0 + gstep, ... of its XCD and
+// issues its LDS-DMA as ONE flattened chunk stream across item boundaries -- the first two chunks of the next tile are in
+// flight while the store epilogue of the current tile runs.  The short-contraction GEMMs (data gradients of the 288^2 /
+// 144^2 layers: two to four chunks per tile, then 32-64 KB of output) would otherwise serialise load latency, MFMAs and
+// stores per workgroup.  Everything between the first DMA and the last store touches LDS through inline asm only (bias
+// slots included): a compiler-visible LDS access would be preceded by s_waitcnt vmcnt(0) and drain the prefetch.  The
+// BatchNorm partials (forward GEMMs only) use the shared helpers and accept that drain once per tile, after the stores.
 template <int WCO, int CT, int WPX, int PXT, int GW, typename TO>
-__global__ __launch_bounds__(WCO * WPX * 64) void k_pw_bf16(const PwBfArgs a) {
+__global__ __launch_bounds__(WCO * WPX * 64, 3) void k_pw_bf16(const PwBfArgs a) {
     constexpr int COT = WCO * CT * 32, PT = WPX * PXT * 32, NW = WCO * WPX, NTH = NW * 64;
     static_assert(PT == 128 && NW == 4, "128-pixel tiles (256-byte LDS rows), four waves");
     constexpr int XB = BF_KC * PT * 2;          // X stage: [KC][PT] bf16
@@ -101,65 +115,73 @@ __global__ __launch_bounds__(WCO * WPX * 64) void k_pw_bf16(const PwBfArgs a) {
     constexpr int NAP = AB / 1024;
     static_assert(NXP % NW == 0 && NAP % NW == 0, "pieces divide evenly among the waves");
     constexpr int XPW = NXP / NW, APW = NAP / NW, PPW = XPW + APW;
+    static_assert(2 * PPW <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)lds;  // asm reads take LDS byte addresses
-    float* stat = (float*)(lds + BF_NST * STG);       // [WPX][3][COT] + [8]
-    float* biasl = stat + BN_STAT_FLOATS(WPX, COT);  // [COT]
+    float* stat = (float*)(lds + BF_NST * STG);            // [WPX][3][COT] + [8]
+    constexpr int BIAS_OFF = BF_NST * STG + 4 * BN_STAT_FLOATS(WPX, COT);  // [2][COT] floats: bias of the item, by item parity
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wco = wv % WCO, wpx = wv / WCO;
     const int l31 = lane & 31, half = lane >> 5;
 
-    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
-    const int cot = idx % a.nco;
-    const int ptg = xcd * ((a.T + 7) >> 3) + idx / a.nco;  // contiguous tile range per XCD (all channel tiles of a pixel tile share an L2)
-    if (ptg >= a.T) return;
-    const int n = ptg / a.tiles_per_img, tl = ptg - n * a.tiles_per_img;
-    const int co0 = cot * COT, p0 = tl * PT;
+    // items of this workgroup: idx = idx0 + k * gstep within the XCD's range; idx -> (pixel tile idx / nco, channel tile idx % nco)
+    const int b = blockIdx.x, xcd = b & 7, idx0 = b >> 3;
+    const int gstep = gridDim.x >> 3;
+    const int tpx = (a.T + 7) >> 3;  // contiguous tile range per XCD (all channel tiles of a pixel tile share an L2)
+    int lim_t = a.T - xcd * tpx;
+    lim_t = lim_t < tpx ? lim_t : tpx;
+    const int lim = lim_t > 0 ? lim_t * a.nco : 0;
+    if (idx0 >= lim) return;
+    const int nitems = (lim - 1 - idx0) / gstep + 1;
     const int nchunks = a.Cp / BF_KC;
-    const unsigned char* xn = (const unsigned char*)(a.x + (long)n * a.x_bs);
-    if (tid < COT) {
-        const int m = co0 + tid;
-        biasl[tid] = (a.bias && m < a.M) ? a.bias[m] : 0.f;
-    }
-
-    // ---- LDS-DMA source offsets (bytes within the image / the weight image), fixed per lane --------------------------
-    unsigned xrow0, xcol;  // first row of this lane's X pieces; byte offset of its pixels within a row
-    if (GW == 16) {
-        const int r = lane >> 4;                          // row within a 4-row piece
-        const int c = (lane & 15) ^ (4 * (r & 3));        // source chunk of LDS chunk (lane & 15)
-        const int px = p0 + 8 * c;
-        xrow0 = 4 * wv + r;                               // piece q = wv + NW * u covers rows 4q .. 4q + 3
-        xcol = (unsigned)(px < a.P ? px : 0) * 2u;
-    } else {
-        const int c = (lane >> 2) ^ (4 * (wv & 3));       // piece q = wv + NW * u is row q; q & 3 == wv & 3
-        const int px = p0 + 8 * c + 2 * (lane & 3);
-        xrow0 = wv;
-        xcol = (unsigned)(px < a.P ? px : 0) * 2u;
-    }
     const unsigned rowbytes = (unsigned)a.P * 2u;
-    // A pieces: piece q' = wv + NW * u' -> (k sub-chunk j, 32-row block rb); lane -> (row lane >> 1, k half)
+
+    // ---- LDS-DMA cursor: (item, chunk) + the per-item source addresses, fixed per lane within an item ---------------
+    int pf_item = 0, pf_ch = 0;
+    const unsigned char* pf_x = nullptr;  // image base
+    unsigned pf_xcol = 0;                 // byte offset of this lane's pixels within a row
+    int pf_co0 = 0;
+    const int xr = lane >> 4;                                    // GW 16: row within a 4-row piece
+    const int xc16 = (lane & 15) ^ (4 * (xr & 3));               // GW 16: source chunk of LDS chunk (lane & 15)
+    const int xc4 = (lane >> 2) ^ (4 * (wv & 3));                // GW 4: piece q = wv + NW * u is row q; q & 3 == wv & 3
+    const unsigned xrow0 = GW == 16 ? (unsigned)(4 * wv + xr) : (unsigned)wv;
     const int arow = lane >> 1, ah = (lane & 1) ^ ((lane >> 4) & 1);
-    auto issue = [&](int ch_, int stage) __attribute__((always_inline)) {
-        const int ch = ch_ < nchunks ? ch_ : nchunks - 1;  // surplus issues re-load the last chunk into a dead stage
-        const int k0 = ch * BF_KC;
+    auto pf_setup = [&]() __attribute__((always_inline)) {
+        const int it = pf_item < nitems ? pf_item : nitems - 1;  // surplus issues re-load the last item into a dead stage
+        const int idx = idx0 + it * gstep;
+        const int j = idx / a.nco, cot = idx - j * a.nco;
+        const int ptg = xcd * tpx + j;
+        const int n = ptg / a.tiles_per_img, tl = ptg - n * a.tiles_per_img;
+        pf_x = (const unsigned char*)(a.x + (long)n * a.x_bs);
+        const int px = tl * PT + (GW == 16 ? 8 * xc16 : 8 * xc4 + 2 * (lane & 3));
+        pf_xcol = (unsigned)(px < a.P ? px : 0) * 2u;
+        pf_co0 = cot * COT;
+    };
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+        const int k0 = pf_ch * BF_KC;
         unsigned char* sb = lds + stage * STG;
 #pragma unroll
         for (int u = 0; u < XPW; ++u) {
             const int q = wv + NW * u;
             int row = k0 + (GW == 16 ? (int)xrow0 + 16 * u : q);
             row = row < a.Cin ? row : a.Cin - 1;  // (the weight image is zero there)
-            glds<GW>(xn + (unsigned)row * rowbytes + xcol, sb + q * (GW == 16 ? 1024 : 256));
+            glds<GW>(pf_x + (unsigned)row * rowbytes + pf_xcol, sb + q * (GW == 16 ? 1024 : 256));
         }
 #pragma unroll
         for (int u = 0; u < APW; ++u) {
             const int q = wv + NW * u;
             const int j = q / (COT / 32), rb = q - j * (COT / 32);
-            int m = co0 + rb * 32 + arow;
+            int m = pf_co0 + rb * 32 + arow;
             m = m < a.M ? m : a.M - 1;
             const bf16_t* src = a.planes + ((long)((k0 >> 4) + j) * a.M + m) * 16 + ah * 8;
             glds<16>(src, sb + XB + (j * COT + rb * 32) * 32);
+        }
+        if (++pf_ch == nchunks) {
+            pf_ch = 0;
+            ++pf_item;
+            pf_setup();
         }
     };
 
@@ -178,131 +200,157 @@ __global__ __launch_bounds__(WCO * WPX * 64) void k_pw_bf16(const PwBfArgs a) {
             b_addr[pt] = lds0 + (unsigned)((8 * half + (i >> 2)) * 256 + chunk * 16 + (i & 1) * 8);
         }
     }
+    // bias slot addresses: the pair (col, col + 1) of register pair (r, r + 1), r even
+    const unsigned bias_rd = lds0 + (unsigned)(BIAS_OFF + (wco * CT * 32 + 4 * half) * 4);
 
-    f32x16 acc[CT][PXT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int pt = 0; pt < PXT; ++pt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
-
-    issue(0, 0);
-    issue(1, 1);
+    pf_setup();
+    issue(0);
+    issue(1);
     int stage = 0;
-    for (int i = 0; i < nchunks; ++i) {
-        // chunk i has landed once at most the PPW loads of chunk i + 1 are outstanding (this wave's pieces); the barrier
-        // extends that to every wave's pieces and says that everybody is done reading stage (i - 1) % 3
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        int s2 = stage + 2;
-        s2 = s2 >= BF_NST ? s2 - BF_NST : s2;
-        issue(i + 2, s2);
-        const unsigned sbase = (unsigned)(stage * STG);
-        bf16x8 af[BF_KC / 16][CT];
-        s16x4 bq[BF_KC / 16][PXT][2];
-        static_for<BF_KC / 16>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            static_for<CT>([&](auto cc) {
-                constexpr int ct = decltype(cc)::value;
-                af[j][ct] = lds_rd128<(j * COT + ct * 32) * 32>(sbase + a_addr);
-            });
-            static_for<PXT>([&](auto pc) {
-                constexpr int pt = decltype(pc)::value;
-                bq[j][pt][0] = lds_rd_tr<j * 16 * 256>(sbase + b_addr[pt]);
-                bq[j][pt][1] = lds_rd_tr<j * 16 * 256 + 4 * 256>(sbase + b_addr[pt]);
-            });
-        });
-        if constexpr (CT == 2 && PXT == 2) {
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(bq[0][0][0]), "+v"(bq[0][0][1]),
-                           "+v"(bq[0][1][0]), "+v"(bq[0][1][1]), "+v"(bq[1][0][0]), "+v"(bq[1][0][1]), "+v"(bq[1][1][0]),
-                           "+v"(bq[1][1][1])::"memory");
-        } else {
-            static_assert(CT == 2 && PXT == 1, "tile configurations: 2x2 or 2x1 MFMA tiles per wave");
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(bq[0][0][0]), "+v"(bq[0][0][1]),
-                           "+v"(bq[1][0][0]), "+v"(bq[1][0][1])::"memory");
+    for (int k = 0; k < nitems; ++k) {
+        const int idx = idx0 + k * gstep;
+        const int jt = idx / a.nco, cot = idx - jt * a.nco;
+        const int ptg = xcd * tpx + jt;
+        const int n = ptg / a.tiles_per_img, tl = ptg - n * a.tiles_per_img;
+        const int co0 = cot * COT, p0 = tl * PT;
+        if (tid < COT) {  // (read two barriers later at the earliest; slot k & 1 was last read two items ago)
+            const int m = co0 + tid;
+            const float bv = (a.bias && m < a.M) ? a.bias[m] : 0.f;
+            asm volatile("ds_write_b32 %0, %1" ::"v"(lds0 + (unsigned)(BIAS_OFF + ((k & 1) * COT + tid) * 4)), "v"(bv) : "memory");
         }
-#pragma unroll
-        for (int j = 0; j < BF_KC / 16; ++j)
-#pragma unroll
-            for (int pt = 0; pt < PXT; ++pt) {
-                bf16x8 bf;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    bf[e] = bq[j][pt][0][e];
-                    bf[4 + e] = bq[j][pt][1][e];
-                }
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j][ct], bf, acc[ct][pt], 0, 0, 0);
-            }
-        stage = stage + 1 >= BF_NST ? 0 : stage + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus DMA of the tail must not outlive the workgroup's LDS
-    __syncthreads();                                   // (also: biasl is visible)
-
-    // ---- epilogue: bias, floor, stores; BatchNorm partials of the raw accumulators ----
-    TO* obase = (TO*)a.out + (long)n * a.out_bs;
-    bool pval[PXT];
-#pragma unroll
-    for (int pt = 0; pt < PXT; ++pt) pval[pt] = p0 + (wpx * PXT + pt) * 32 + l31 < a.P;
-    if constexpr (sizeof(TO) == 4) {
+        f32x16 acc[CT][PXT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int col = (wco * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int m = co0 + col;
-                if (m < a.M) {
-                    const float bvv = biasl[col];
+            for (int pt = 0; pt < PXT; ++pt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
+        for (int i = 0; i < nchunks; ++i) {
+            // the chunk at the head of the stream has landed once at most the PPW loads of the chunk after it are outstanding
+            // (this wave's pieces); the barrier extends that to every wave's pieces and says that everybody is done
+            // reading the stage that the next issue overwrites
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            int s2 = stage + 2;
+            s2 = s2 >= BF_NST ? s2 - BF_NST : s2;
+            issue(s2);
+            const unsigned sbase = (unsigned)(stage * STG);
+            bf16x8 af[BF_KC / 16][CT];
+            s16x4 bq[BF_KC / 16][PXT][2];
+            static_for<BF_KC / 16>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                static_for<CT>([&](auto cc) {
+                    constexpr int ct = decltype(cc)::value;
+                    af[j][ct] = lds_rd128<(j * COT + ct * 32) * 32>(sbase + a_addr);
+                });
+                static_for<PXT>([&](auto pc) {
+                    constexpr int pt = decltype(pc)::value;
+                    bq[j][pt][0] = lds_rd_tr<j * 16 * 256>(sbase + b_addr[pt]);
+                    bq[j][pt][1] = lds_rd_tr<j * 16 * 256 + 4 * 256>(sbase + b_addr[pt]);
+                });
+            });
+            if constexpr (CT == 2 && PXT == 2) {
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(bq[0][0][0]), "+v"(bq[0][0][1]),
+                               "+v"(bq[0][1][0]), "+v"(bq[0][1][1]), "+v"(bq[1][0][0]), "+v"(bq[1][0][1]), "+v"(bq[1][1][0]),
+                               "+v"(bq[1][1][1])::"memory");
+            } else {
+                static_assert(CT == 2 && PXT == 1, "tile configurations: 2x2 or 2x1 MFMA tiles per wave");
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(bq[0][0][0]), "+v"(bq[0][0][1]),
+                               "+v"(bq[1][0][0]), "+v"(bq[1][0][1])::"memory");
+            }
+#pragma unroll
+            for (int j = 0; j < BF_KC / 16; ++j)
+#pragma unroll
+                for (int pt = 0; pt < PXT; ++pt) {
+                    bf16x8 bf;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        bf[e] = bq[j][pt][0][e];
+                        bf[4 + e] = bq[j][pt][1][e];
+                    }
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j][ct], bf, acc[ct][pt], 0, 0, 0);
+                }
+            stage = stage + 1 >= BF_NST ? 0 : stage + 1;
+        }
+
+        // ---- epilogue: bias, floor, stores (the DMA of the next item's first chunks is in flight) ----
+        float2 bia[CT][8];
+        const unsigned badr = bias_rd + (unsigned)((k & 1) * COT * 4);
+        static_for<CT * 8>([&](auto ic) {
+            constexpr int ct = decltype(ic)::value / 8, e = decltype(ic)::value % 8;
+            // register pair (2e, 2e + 1): rows ct * 32 + (2e & 3) + 8 * (2e >> 2) (+ 4 * half) and the next one
+            constexpr int col = ct * 32 + ((2 * e) & 3) + 8 * ((2 * e) >> 2);
+            bia[ct][e] = lds_rd64<col * 4>(badr);
+        });
+        if constexpr (CT == 2) {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(bia[0][0]), "+v"(bia[0][1]), "+v"(bia[0][2]), "+v"(bia[0][3]), "+v"(bia[0][4]), "+v"(bia[0][5]),
+                           "+v"(bia[0][6]), "+v"(bia[0][7]), "+v"(bia[1][0]), "+v"(bia[1][1]), "+v"(bia[1][2]), "+v"(bia[1][3]),
+                           "+v"(bia[1][4]), "+v"(bia[1][5]), "+v"(bia[1][6]), "+v"(bia[1][7])::"memory");
+        }
+        TO* obase = (TO*)a.out + (long)n * a.out_bs;
+        bool pval[PXT];
+#pragma unroll
+        for (int pt = 0; pt < PXT; ++pt) pval[pt] = p0 + (wpx * PXT + pt) * 32 + l31 < a.P;
+        if constexpr (sizeof(TO) == 4) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int col = (wco * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int m = co0 + col;
+                    const float bvv = (r & 1) ? bia[ct][r >> 1].y : bia[ct][r >> 1].x;
                     float* rowp = (float*)obase + (long)m * a.P + p0 + wpx * PXT * 32 + l31;
 #pragma unroll
                     for (int pt = 0; pt < PXT; ++pt)
-                        if (pval[pt]) rowp[pt * 32] = fmaxf(acc[ct][pt][r] + bvv, a.out_floor);
+                        if (pval[pt] && m < a.M) rowp[pt * 32] = fmaxf(acc[ct][pt][r] + bvv, a.out_floor);
                 }
-            }
-    } else {
-        // bf16 rows: lanes (2e, 2e + 1) hold adjacent pixels; for the register pair (r, r + 1) = rows (m, m + 1) the even
-        // lane stores row m, the odd lane row m + 1, each ONE dword = two pixels (one DPP exchange per pair)
-        const bool odd = lane & 1;
+        } else {
+            // bf16 rows: lanes (2e, 2e + 1) hold adjacent pixels; for the register pair (r, r + 1) = rows (m, m + 1) the even
+            // lane stores row m, the odd lane row m + 1, each ONE dword = two pixels (one DPP exchange per pair)
+            const bool odd = lane & 1;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+            for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const int col = (wco * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;  // row of register r
-                const float b0 = biasl[col], b1 = biasl[col + 1];
-                const int m = co0 + col + (odd ? 1 : 0);
-                bf16_t* rowp = (bf16_t*)obase + (long)m * a.P + p0 + wpx * PXT * 32 + (l31 & ~1);
+                for (int r = 0; r < 16; r += 2) {
+                    const int col = (wco * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;  // row of register r
+                    const float b0 = bia[ct][r >> 1].x, b1 = bia[ct][r >> 1].y;
+                    const int m = co0 + col + (odd ? 1 : 0);
+                    bf16_t* rowp = (bf16_t*)obase + (long)m * a.P + p0 + wpx * PXT * 32 + (l31 & ~1);
 #pragma unroll
-                for (int pt = 0; pt < PXT; ++pt) {
-                    const float v0 = fmaxf(acc[ct][pt][r] + b0, a.out_floor), v1 = fmaxf(acc[ct][pt][r + 1] + b1, a.out_floor);
-                    const float send = odd ? v0 : v1;
-                    const float recv = dpp_src<0xB1, 0xF>(send);  // quad_perm [1,0,3,2]: the neighbour lane of the pair
-                    const unsigned pk = odd ? pack_bf16x2(recv, v1) : pack_bf16x2(v0, recv);
-                    if (pval[pt] && m < a.M) *(unsigned*)(rowp + pt * 32) = pk;  // P is even: a pair is valid or not as a whole
+                    for (int pt = 0; pt < PXT; ++pt) {
+                        const float v0 = fmaxf(acc[ct][pt][r] + b0, a.out_floor), v1 = fmaxf(acc[ct][pt][r + 1] + b1, a.out_floor);
+                        const float send = odd ? v0 : v1;
+                        const float recv = dpp_src<0xB1, 0xF>(send);  // quad_perm [1,0,3,2]: the neighbour lane of the pair
+                        const unsigned pk = odd ? pack_bf16x2(recv, v1) : pack_bf16x2(v0, recv);
+                        if (pval[pt] && m < a.M) *(unsigned*)(rowp + pt * 32) = pk;  // P is even: a pair is valid or not as a whole
+                    }
                 }
-            }
-    }
-    if (a.part) {
-        int nw = a.P - (p0 + wpx * PXT * 32);
-        nw = nw < 0 ? 0 : (nw > PXT * 32 ? PXT * 32 : nw);
-        bn_wave_partials<CT, PXT>(acc, pval, l31, half, stat + wpx * 3 * COT + wco * CT * 32, COT, 0);
-        if (lane == 0) ((int*)(stat + WPX * 3 * COT))[wpx] = nw;
-        __syncthreads();
-        for (int col = tid; col < COT; col += NTH) {
-            float mean, m2, cnt;
-            bn_tile_combine<WPX>(stat, (const int*)(stat + WPX * 3 * COT), COT, col, mean, m2, cnt);
-            const int m = co0 + col;
-            if (m < a.M) {
-                a.part[((long)0 * a.slots + ptg) * a.M + m] = mean;
-                a.part[((long)1 * a.slots + ptg) * a.M + m] = m2;
-                a.part[((long)2 * a.slots + ptg) * a.M + m] = cnt;
+        }
+        if (a.part) {  // BatchNorm partials of the raw accumulators (compiler-visible LDS: waits for the DMA in flight)
+            int nw = a.P - (p0 + wpx * PXT * 32);
+            nw = nw < 0 ? 0 : (nw > PXT * 32 ? PXT * 32 : nw);
+            bn_wave_partials<CT, PXT>(acc, pval, l31, half, stat + wpx * 3 * COT + wco * CT * 32, COT, 0);
+            if (lane == 0) ((int*)(stat + WPX * 3 * COT))[wpx] = nw;
+            __syncthreads();
+            for (int col = tid; col < COT; col += NTH) {
+                float mean, m2, cnt;
+                bn_tile_combine<WPX>(stat, (const int*)(stat + WPX * 3 * COT), COT, col, mean, m2, cnt);
+                const int m = co0 + col;
+                if (m < a.M) {
+                    a.part[((long)0 * a.slots + ptg) * a.M + m] = mean;
+                    a.part[((long)1 * a.slots + ptg) * a.M + m] = m2;
+                    a.part[((long)2 * a.slots + ptg) * a.M + m] = cnt;
+                }
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus DMA of the tail must not outlive the workgroup's LDS
 }
 
 template <auto KERN>
@@ -325,11 +373,14 @@ static int launch_pw_bf16_cfg(PwBfArgs& a, hipStream_t st) {
     a.T = a.N * a.tiles_per_img;
     a.slots = pw_split_num_slots(a.N, a.P);
     const int items = ((a.T + 7) / 8) * 8 * a.nco;
-    const size_t lds = (size_t)BF_NST * (BF_KC * PT * 2 + (BF_KC / 16) * COT * 32) + sizeof(float) * (BN_STAT_FLOATS(WPX, COT) + COT);
+    const size_t lds = (size_t)BF_NST * (BF_KC * PT * 2 + (BF_KC / 16) * COT * 32) + sizeof(float) * (BN_STAT_FLOATS(WPX, COT) + 2 * COT);
     constexpr auto kern = k_pw_bf16<WCO, CT, WPX, PXT, GW, TO>;
     int rc = ensure_lds_b<kern>(lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(items), dim3(WCO * WPX * 64), lds, st, a);
+    static_assert((size_t)BF_NST * (BF_KC * PT * 2 + (BF_KC / 16) * COT * 32) + sizeof(float) * (BN_STAT_FLOATS(WPX, COT) + 2 * COT) <=
+                      160 * 1024 / 3, "k_pw_bf16: three workgroups per CU");
+    const int grid = items < 768 ? items : 768;  // persistent: 3 workgroups per CU walk the items of their XCD
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WCO * WPX * 64), lds, st, a);
     return (int)hipGetLastError();
 }
 
@@ -381,8 +432,13 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(const WgBfArgs a) {
     if (split >= a.nsplit) return;
     const int mt = rest % a.nmt, kt = rest / a.nmt;
     const int m0 = mt * MT, k0 = kt * KT;
-    const int c_begin = split, c_step = a.nsplit;
-    const int nit = c_begin < a.total_chunks ? (a.total_chunks - c_begin + c_step - 1) / c_step : 0;
+    // A 32-pixel chunk of a bf16 row is HALF a 128-byte line: a workgroup takes chunk PAIRS (2j, 2j + 1), j = split,
+    // split + nsplit, ... so that the second half of every line it touches is an L2 hit on its own XCD a moment later
+    // (with single chunks strided over the splits the two halves were fetched by workgroups on two different XCDs).
+    const int npairs = (a.total_chunks + 1) >> 1;
+    const int np_mine = split < npairs ? (npairs - split + a.nsplit - 1) / a.nsplit : 0;
+    int nit = 2 * np_mine;
+    if (nit > 0 && 2 * (split + (np_mine - 1) * a.nsplit) + 1 >= a.total_chunks) --nit;  // (odd total: the last pair is half)
 
     // lane -> (row within a piece, source pixel offset within the chunk); LDS chunk c' of a row holds source chunk
     // c' ^ ((row >> 2) & 3)
@@ -396,7 +452,7 @@ __global__ __launch_bounds__(256) void k_wgrad_bf16(const WgBfArgs a) {
     }
     auto issue = [&](int it_, int stage) __attribute__((always_inline)) {
         const int it = it_ < nit ? it_ : nit - 1;
-        const int c = c_begin + it * c_step;
+        const int c = 2 * (split + (it >> 1) * a.nsplit) + (it & 1);
         const int n = c / a.nchunk_img;
         const int pc0 = (c - n * a.nchunk_img) * WB_SPS;
         unsigned char* sb = lds + stage * STG;

@@ -34,7 +34,7 @@ DwrGeom dw_rows_geom(long planes, int H, int W) {
     g.H = H;
     g.W = W;
     g.P = H * W;
-    g.ncol4 = W / 4;
+    g.ncol4 = (W + 3) / 4;  // W % 4 == 2: the last column group of a row holds two columns (DwrLane::part)
     double best = -1.0;
     g.nbands = 1;
     g.BH = H;
@@ -70,19 +70,32 @@ __device__ __forceinline__ float dwr_act(float v, bool aff, float sc, float sh) 
 // The two edge columns are the neighbour lanes' float4 ends (DPP wave shifts by one lane: the neighbour lane holds
 // the neighbour column group of the SAME band, hence the same row); only lane 0 / lane 63 read theirs from memory,
 // both with one dword load whose per-thread offset `eo` (-1, +4 or 0) is fixed.
+// W % 4 == 2 (the 18 x 18 planes of the bottleneck): the LAST group of a row has only the columns 4q, 4q + 1.  Its
+// 4-element access is shifted two columns to the left (cols 4q - 2 .. 4q + 1: never beyond the row, hence never beyond the
+// tensor), the two valid values are moved to positions 0, 1 of the group and positions 2, 3 are the zero padding right of
+// the plane; its store writes two elements.  Rows are then only 8-byte (f32) / 4-byte (bf16) aligned: the hardware takes
+// unaligned dwordx4 / dwordx2 global accesses.
 struct DwrLane {
     int eo;         // edge element offset of this lane's extra load
     bool l0, l63;   // lane 0 / lane 63 of the wave
     bool lok, rok;  // a column exists to the left / right of the group
+    bool part;      // the two-column last group of a row (W % 4 == 2)
+    int lo;         // element offset of the group's 4-element access: -2 for a partial group, else 0
 };
-__device__ __forceinline__ DwrLane dwr_lane(int lane, int q, int ncol4) {
+__device__ __forceinline__ DwrLane dwr_lane(int lane, int q, int ncol4, int W) {
     DwrLane ln;
     ln.l0 = lane == 0;
     ln.l63 = lane == 63;
     ln.lok = q > 0;
     ln.rok = q < ncol4 - 1;
+    ln.part = (W & 3) != 0 && q == ncol4 - 1;
+    ln.lo = ln.part ? -2 : 0;
     ln.eo = (ln.l0 && ln.lok) ? -1 : ((ln.l63 && ln.rok) ? 4 : 0);
     return ln;
+}
+// the four values of a group from its (possibly shifted) access: partial group -> (v.z, v.w, 0, 0)
+__device__ __forceinline__ float4 dwr_group(const float4 v, const DwrLane& ln) {
+    return ln.part ? make_float4(v.z, v.w, 0.f, 0.f) : v;
 }
 // T = element type of the streamed tensor (float or bf16_t, common.h "element types"): a row is ONE 16- or 8-byte load
 // per lane plus the edge element; the raw registers are converted to f32 in dwr_finish, after the pin.
@@ -97,14 +110,22 @@ __device__ __forceinline__ DwrRaw<T> dwr_issue(const T* __restrict__ p, int r, i
     const int rc = min(max(r, 0), H - 1);
     const T* pr = p + (long)rc * W;
     DwrRaw<T> v;
-    v.m = ldraw4(pr);
+    v.m = ldraw4(pr + ln.lo);
     v.e = ldraw1(pr + ln.eo);
     return v;
 }
 template <typename T>
-__device__ __forceinline__ typename Elem<T>::raw4 dwr_issue4(const T* __restrict__ p, int r, int H, int W) {
+__device__ __forceinline__ typename Elem<T>::raw4 dwr_issue4(const T* __restrict__ p, int r, int H, int W, const DwrLane& ln) {
     const int rc = min(max(r, 0), H - 1);
-    return ldraw4(p + (long)rc * W);
+    return ldraw4(p + (long)rc * W + ln.lo);
+}
+// store the group's values of one row (two of them for a partial group)
+template <typename T>
+__device__ __forceinline__ void dwr_store(T* p, const float4 v, const DwrLane& ln) {
+    if (ln.part)
+        st2(p, v.x, v.y);
+    else
+        st4(p, v);
 }
 // pin the loaded registers: keeps hipcc from sinking parts of a 16-byte load into the row-validity select (it splits
 // the load into dword loads plus a branch otherwise).  Call after ALL loads of a step have been issued.
@@ -119,7 +140,7 @@ template <typename T>
 __device__ __forceinline__ void dwr_finish(float (&w)[6], const DwrRaw<T>& vr, int r, int H, const DwrLane& ln, bool aff,
                                            float sc, float sh) {
     const bool rv = r >= 0 && r < H;
-    const float4 m = cvt4(vr.m);
+    const float4 m = dwr_group(cvt4(vr.m), ln);
     const float e = cvt1(vr.e);
     float l = dpp_src<0x138, 0xF>(m.w);   // wave_shr:1  (lane i <- lane i - 1)
     float rr = dpp_src<0x130, 0xF>(m.x);  // wave_shl:1  (lane i <- lane i + 1)
@@ -128,8 +149,8 @@ __device__ __forceinline__ void dwr_finish(float (&w)[6], const DwrRaw<T>& vr, i
     w[0] = (rv && ln.lok) ? dwr_act(l, aff, sc, sh) : 0.f;
     w[1] = rv ? dwr_act(m.x, aff, sc, sh) : 0.f;
     w[2] = rv ? dwr_act(m.y, aff, sc, sh) : 0.f;
-    w[3] = rv ? dwr_act(m.z, aff, sc, sh) : 0.f;
-    w[4] = rv ? dwr_act(m.w, aff, sc, sh) : 0.f;
+    w[3] = (rv && !ln.part) ? dwr_act(m.z, aff, sc, sh) : 0.f;  // (zero padding right of the plane: after the activation)
+    w[4] = (rv && !ln.part) ? dwr_act(m.w, aff, sc, sh) : 0.f;
     w[5] = (rv && ln.rok) ? dwr_act(rr, aff, sc, sh) : 0.f;
 }
 
@@ -165,7 +186,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const TX* __restrict__ x
     }
     const bool aff = in_scale != nullptr;
     const float asc = aff ? in_scale[ci] : 1.f, ash = aff ? in_shift[ci] : 0.f;
-    const DwrLane ln = dwr_lane(lane, q, g.ncol4);
+    const DwrLane ln = dwr_lane(lane, q, g.ncol4, g.W);
 
     // before step r (u = (r - r0) % 3): Wn[u] = row r - 1, Wn[u + 1] = row r, raw[u] = row r + 1 and raw[u + 1] = row
     // r + 2 in flight; the step issues row r + 3 into raw[u + 2], then finishes row r + 1 into Wn[u + 2] (the slot of the
@@ -187,7 +208,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const TX* __restrict__ x
                 for (int tc = 0; tc < 3; ++tc) acc = fmaf(wt[j][6 + tc], R2[c + tc], acc);
                 o[c] = acc;
             }
-            if (active && r < g.H) st4(yp + (long)j * g.P + (long)r * g.W, make_float4(o[0], o[1], o[2], o[3]));
+            if (active && r < g.H) dwr_store(yp + (long)j * g.P + (long)r * g.W, make_float4(o[0], o[1], o[2], o[3]), ln);
         }
     };
     {
@@ -267,7 +288,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAV
     const bool aff = in_scale != nullptr;
     const float asc = aff ? in_scale[ci] : 1.f, ash = aff ? in_shift[ci] : 0.f;
     const float rmean = rpart ? bn_mean[ci] : 0.f, rinvstd = rpart ? bn_invstd[ci] : 0.f;
-    const DwrLane ln = dwr_lane(lane, q, g.ncol4);
+    const DwrLane ln = dwr_lane(lane, q, g.ncol4, g.W);
 
     float accw[KPL][10];
 #pragma unroll
@@ -301,7 +322,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAV
                     // issue: dY row rho, x row rho + 1
 #pragma unroll
                     for (int j = 0; j < KPL; ++j) raw[j] = dwr_issue(dyp + (long)j * g.P, rho, g.H, g.W, ln);
-                    xn = dwr_issue4(xp, rho + 1, g.H, g.W);
+                    xn = dwr_issue4(xp, rho + 1, g.H, g.W, ln);
 #pragma unroll
                     for (int j = 0; j < KPL; ++j) dwr_pin(raw[j]);
                     dwr_pin(xn);
@@ -309,11 +330,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAV
                     for (int j = 0; j < KPL; ++j) dwr_finish(d[j], raw[j], rho, g.H, ln, false, 1.f, 0.f);
                     {  // open the slot of row rho + 1
                         const bool in = (rho + 1) >= r0 && (rho + 1) < r1;
-                        const float4 zv = cvt4(xn);
+                        const float4 zv = dwr_group(cvt4(xn), ln);
                         xc[sc_][0] = in ? dwr_act(zv.x, aff, asc, ash) : 0.f;
                         xc[sc_][1] = in ? dwr_act(zv.y, aff, asc, ash) : 0.f;
-                        xc[sc_][2] = in ? dwr_act(zv.z, aff, asc, ash) : 0.f;
-                        xc[sc_][3] = in ? dwr_act(zv.w, aff, asc, ash) : 0.f;
+                        xc[sc_][2] = (in && !ln.part) ? dwr_act(zv.z, aff, asc, ash) : 0.f;  // (columns beyond the plane)
+                        xc[sc_][3] = (in && !ln.part) ? dwr_act(zv.w, aff, asc, ash) : 0.f;
                         if (RP) {
                             zraw[sc_][0] = zv.x;
                             zraw[sc_][1] = zv.y;
@@ -347,7 +368,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAV
                     const int rd = rho - 1;
                     const bool fin = rd >= r0 && rd < r1;
                     if (dxp && fin)
-                        st4(dxp + (long)rd * g.W, make_float4(dxa[sa][0], dxa[sa][1], dxa[sa][2], dxa[sa][3]));
+                        dwr_store(dxp + (long)rd * g.W, make_float4(dxa[sa][0], dxa[sa][1], dxa[sa][2], dxa[sa][3]), ln);
                     if (RP) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
@@ -389,9 +410,10 @@ static int dwr_enabled() {
     return v;
 }
 
-// 1 when the row kernels take this shape (W % 4 == 0; the caller checks pointer / stride alignment)
+// 1 when the row kernels take this shape (W even: W % 4 == 2 runs with a two-column last group; the caller checks pointer /
+// stride alignment)
 int dw_rows_ok(int kpl, int H, int W) {
-    return dwr_enabled() && (kpl == 1 || kpl == 2 || kpl == 4) && (W & 3) == 0 && W >= 4 && W <= 4096 && H >= 1;
+    return dwr_enabled() && (kpl == 1 || kpl == 2 || kpl == 4) && (W & 1) == 0 && W >= 4 && W <= 4096 && H >= 1;
 }
 
 // x_dt / y_dt (/ dy_dt / dx_dt): SMAAT_F32 or SMAAT_BF16.  Built combinations: everything f32; bf16 outputs from an f32

@@ -1071,6 +1071,10 @@ int launch_dw3x3_fwd(const void* xv, int x_dt, long x_bs, const float* w_dw, con
     const bool aligned = ((W & 3) == 0) && ((x_bs & 3) == 0) && ((((uintptr_t)xv) & xm) == 0) && H >= 1 &&
                          (kpl == 1 || kpl == 2 || kpl == 4);
     if (!(kpl == 1 || kpl == 2 || kpl == 4)) return -2;
+    // W % 4 == 2 (18 x 18 ...): the row kernels with a two-column last group; rows are 8- (f32) / 4-byte (bf16) aligned
+    if (!aligned && (W & 3) == 2 && dw_rows_ok(kpl, H, W) && (x_bs & 1) == 0 && (y_bs & 1) == 0 &&
+        ((((uintptr_t)xv) & (xm >> 1)) == 0) && ((((uintptr_t)yv) & (ym >> 1)) == 0))
+        return launch_dw3x3_fwd_rows(xv, x_dt, x_bs, w_dw, b_dw, yv, y_dt, y_bs, N, Cin, kpl, H, W, st, in_scale, in_shift);
     if (!aligned && H * W <= DWS_PMAX)  // small planes with unaligned rows (18 x 18 ...): the flat-copy kernel
         return launch_dw3x3_fwd_small(xv, x_dt, x_bs, w_dw, b_dw, yv, y_dt, y_bs, N, Cin, kpl, H, W, st, in_scale, in_shift);
     if (!aligned) return -2;  // caller falls back to the fused f32 kernel
@@ -1130,7 +1134,10 @@ int launch_dw3x3_bwd(const void* xv, int x_dt, long x_bs, const void* dyv, int d
                          ((((uintptr_t)xv) & xm) == 0) && ((((uintptr_t)dyv) & gm) == 0) &&
                          ((((uintptr_t)dxv) & dm) == 0) && (kpl == 1 || kpl == 2 || kpl == 4) && H >= 4;
     if (rpart && !in_scale) return -2;  // the fused reduction needs the pre-BatchNorm tensor (zhat = (z - mean) * invstd)
-    if (aligned && kpl <= 2 && dw_rows_ok(kpl, H, W))
+    const bool aligned2 = ((W & 3) == 2) && ((x_bs & 1) == 0) && ((dy_bs & 1) == 0) && ((dx_bs & 1) == 0) &&
+                          ((((uintptr_t)xv) & (xm >> 1)) == 0) && ((((uintptr_t)dyv) & (gm >> 1)) == 0) &&
+                          ((((uintptr_t)dxv) & (dm >> 1)) == 0) && H >= 4;  // two-column last group, see dwrows.hip
+    if ((aligned || aligned2) && kpl <= 2 && dw_rows_ok(kpl, H, W))
         return launch_dw3x3_bwd_rows(xv, x_dt, x_bs, dyv, dy_dt, dy_bs, w_dw, dxv, dx_dt, dx_bs, part, N, Cin, kpl, H, W, st,
                                      bn_g, bn_b, rpart, in_scale, in_shift);
     if (use_strip && aligned && all32) {

@@ -68,10 +68,20 @@ class PrefetchLoader:
 
     depth      ring size (pinned host buffers = device buffers): batches in flight
     workers    gather threads (numpy releases the GIL while copying)
+    rank / world_size   data-parallel sharding: every rank draws the SAME seeded permutation and takes the samples
+               rank, rank + world_size, ... of it (torch.utils.data.DistributedSampler's rule, drop_last semantics), so
+               that the replicas of smaat_unet_amd.ddp.FlatGradAllReduce see disjoint batches
     The tensors of one iteration stay valid until `depth - 1` further batches have been requested.
+    An exception in a gather thread, in the dataset's transform or in the copy is re-raised in the consuming loop (as
+    torch's DataLoader re-raises worker errors); no batch is delivered after it.  close() releases the pinned and device
+    rings (the loader is unusable afterwards).
     """
 
-    def __init__(self, source, batch_size, device="cuda", depth=3, workers=4, shuffle=True, seed=0, drop_last=True):
+    def __init__(self, source, batch_size, device="cuda", depth=3, workers=4, shuffle=True, seed=0, drop_last=True,
+                 rank=0, world_size=1):
+        if not 0 <= int(rank) < int(world_size):
+            raise ValueError("rank must be in [0, world_size)")
+        self.rank, self.world = int(rank), int(world_size)
         self.source, self.batch, self.depth = source, int(batch_size), max(2, int(depth))
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
@@ -86,15 +96,24 @@ class PrefetchLoader:
             if self.cuda else self.host
         self.copy_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
 
+    def _shard_len(self):
+        return len(self.source) // self.world  # every rank the same count (the tail of the permutation is dropped)
+
     def __len__(self):
-        n = len(self.source)
+        n = self._shard_len()
         return n // self.batch if self.drop_last else (n + self.batch - 1) // self.batch
+
+    def close(self):
+        """release the pinned host ring and the device ring"""
+        self.host, self.host_np, self.dev = [], [], []
 
     def _batches(self):
         n = len(self.source)
         order = np.arange(n)
         if self.shuffle:
             np.random.default_rng(self.seed + self.epoch).shuffle(order)
+        order = order[self.rank:self._shard_len() * self.world:self.world]
+        n = len(order)
         stop = n - n % self.batch if self.drop_last else n
         return [order[i:i + self.batch] for i in range(0, stop, self.batch)]
 
@@ -104,13 +123,22 @@ class PrefetchLoader:
         if self.workers == 1 or nb < 2 * self.workers:
             self.source.gather_into(idx, dst)
             return
-        parts = np.array_split(np.arange(nb), self.workers)
-        ths = [threading.Thread(target=lambda p=p: self.source.gather_into(idx[p], dst[p[0]:p[-1] + 1])) for p in parts
-               if len(p)]
+        parts = [p for p in np.array_split(np.arange(nb), self.workers) if len(p)]
+        errors = []
+
+        def work(p):
+            try:
+                self.source.gather_into(idx[p], dst[p[0]:p[-1] + 1])
+            except BaseException as e:  # noqa: BLE001  (handed to the consumer, never swallowed)
+                errors.append(e)
+
+        ths = [threading.Thread(target=work, args=(p,)) for p in parts]
         for t in ths:
             t.start()
         for t in ths:
             t.join()
+        if errors:
+            raise errors[0]
 
     def __iter__(self):
         batches = self._batches()
@@ -123,6 +151,9 @@ class PrefetchLoader:
         stop = threading.Event()
 
         def producer():
+            if not self.host:
+                ready.put(RuntimeError("PrefetchLoader.close() was called"))
+                return
             try:
                 for idx in batches:
                     slot, reuse_ev = free.get()
@@ -138,8 +169,10 @@ class PrefetchLoader:
                             ev = torch.cuda.Event()
                             ev.record(self.copy_stream)
                     ready.put((slot, len(idx), ev))
-            finally:
-                ready.put(None)
+            except BaseException as e:  # noqa: BLE001  (gather / transform / copy failed: the consumer re-raises it)
+                ready.put(e)
+                return
+            ready.put(None)
 
         th = threading.Thread(target=producer, daemon=True)
         th.start()
@@ -149,6 +182,8 @@ class PrefetchLoader:
                 item = ready.get()
                 if item is None:
                     break
+                if isinstance(item, BaseException):
+                    raise RuntimeError(f"PrefetchLoader: the producer thread failed: {item!r}") from item
                 slot, nb, ev = item
                 if ev is not None:
                     torch.cuda.current_stream(self.device).wait_event(ev)

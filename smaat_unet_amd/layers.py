@@ -29,8 +29,15 @@ def batched_counters():
     finally:
         pend, _TLS.pending = _TLS.pending, None
         if pend:
+            # a BatchNorm module called k times inside the context appears k times: add k ONCE per tensor (duplicate
+            # tensors in one multi-tensor apply are not guaranteed to accumulate)
+            counts = {}
+            for t in pend:
+                e = counts.setdefault(id(t), [t, 0])
+                e[1] += 1
             with torch.no_grad():
-                torch._foreach_add_(pend, 1)
+                for k in sorted({n for _, n in counts.values()}):
+                    torch._foreach_add_([t for t, n in counts.values() if n == k], k)
 
 
 def _bn_args(bn: nn.BatchNorm2d):

@@ -15,11 +15,16 @@ Mapping to the reference (HansBambel/SmaAt-UNet):
 """
 from __future__ import annotations
 
+import contextlib
 import os
+import threading
 
 import torch
 
 from . import _lib
+
+BF16 = torch.bfloat16
+F32 = torch.float32
 
 
 # --------------------------------------------------------------------------------------
@@ -41,8 +46,51 @@ def _check(*tensors):
             continue
         if not t.is_cuda and not _lib._ALLOW_HOST_POINTERS:
             raise _lib.SmaatHipError("smaat_unet_amd operators need ROCm (cuda) tensors: there is no CPU fallback")
-        if t.dtype not in (torch.float32, torch.int32):
-            raise TypeError(f"smaat_unet_amd operators are float32-only (got {t.dtype})")
+        if t.dtype not in (torch.float32, torch.int32, torch.bfloat16):
+            raise TypeError(f"smaat_unet_amd operators take float32 (and bfloat16 activations in mixed precision), got {t.dtype}")
+
+
+def _dt(t):
+    """dtype code of the C ABI (include/smaat_hip.h: SMAAT_DT_F32 = 0, SMAAT_DT_BF16 = 1)"""
+    return 1 if t.dtype == torch.bfloat16 else 0
+
+
+def _is_bf(t):
+    return t is not None and t.dtype == torch.bfloat16
+
+
+# ---- precision policy ----------------------------------------------------------------------------------------------
+# "bf16" = mixed precision (BASELINE configs[3]): every activation tensor and its gradient is STORED as bfloat16, the
+# pointwise GEMMs run one bf16 MFMA per product, accumulation / BatchNorm statistics / weights / weight gradients stay
+# f32.  It is selected per call tree, not per process: `with precision("bf16"):` around a forward (the networks do this
+# for themselves after `model.set_precision("bf16")`), or torch.autocast(device_type="cuda", dtype=torch.bfloat16) -- what
+# Lightning's precision="bf16-mixed" wraps the reference's modules in.  Only the blocks that receive an f32 tensor (the
+# stem) consult it; everything downstream follows the dtype of its input, and the backward follows the saved tensors.
+_PREC = threading.local()
+
+
+@contextlib.contextmanager
+def precision(mode):
+    """mode: "f32" | "bf16" | None (None = leave the surrounding setting)"""
+    if mode not in (None, "f32", "bf16"):
+        raise ValueError("precision must be 'f32' or 'bf16'")
+    prev = getattr(_PREC, "mode", None)
+    if mode is not None:
+        _PREC.mode = mode
+    try:
+        yield
+    finally:
+        _PREC.mode = prev
+
+
+def mixed_precision_active():
+    mode = getattr(_PREC, "mode", None)
+    if mode is not None:
+        return mode == "bf16"
+    try:
+        return torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+    except Exception:  # noqa: BLE001  (older torch signatures)
+        return False
 
 
 def _expect(t, shape, name):
@@ -193,13 +241,22 @@ def _pointwise_split_raw(x, planes, bias, m, want_stats=False):
     return out, part, slots
 
 
-def _dw3x3_fwd_raw(x, w_dw, b_dw, kpl, in_scale=None, in_shift=None):
-    """standalone depthwise 3x3 forward; None when the library does not handle the shape"""
+def _dw3x3_fwd_raw(x, w_dw, b_dw, kpl, in_scale=None, in_shift=None, out_dtype=None):
+    """standalone depthwise 3x3 forward; None when the library does not handle the shape.  out_dtype: torch.float32
+    (default: the dtype of x) or torch.bfloat16 (mixed precision: x may be f32 -- the stem -- or bf16)"""
     L = _lib.get()
     x, x_bs = _planes(x)
     n, cin, h, w = x.shape
     k = cin * kpl
-    y = _new(x, n, k, h, w)
+    out_dtype = out_dtype or x.dtype
+    y = _new(x, n, k, h, w, dtype=out_dtype)
+    if _is_bf(x) or out_dtype == BF16:
+        rc = L.smaat_dw3x3_fwd_t(_ptr(x), _dt(x), x_bs, _ptr(in_scale), _ptr(in_shift), _ptr(w_dw), _ptr(b_dw), _ptr(y),
+                                 _dt(y), k * h * w, n, cin, kpl, h, w, _stream(x))
+        if rc == -2:
+            raise NotImplementedError(f"depthwise 3x3 with bf16 storage: shape [{n},{cin},{h},{w}] kpl={kpl} not built")
+        _lib.check(rc, "smaat_dw3x3_fwd_t")
+        return y
     rc = L.smaat_dw3x3_fwd(_ptr(x), x_bs, _ptr(in_scale), _ptr(in_shift), _ptr(w_dw), _ptr(b_dw), _ptr(y), k * h * w,
                            n, cin, kpl, h, w, _stream(x))
     if rc == -2:
@@ -216,6 +273,44 @@ def _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None,
     cout = w_pw.shape[0]
     planes = _split_planes_raw(w_pw.reshape(cout, -1))
     z, part, slots = _pointwise_split_raw(y, planes, b_pw, cout, want_stats)
+    return z, part, slots, y
+
+
+# ---- mixed precision (bf16 storage): depthwise kernel (bf16 out) + bf16 GEMM fed by LDS-DMA (csrc/bf16gemm.hip) ----
+def _bf16_planes_raw(w2d, transpose=False):
+    """w2d [R][C] f32 -> bf16 image [ceil32(C)/16][R][16]; transpose=True: the image of w2d^T (w2d stored [C][R])"""
+    L = _lib.get()
+    r, c = (w2d.shape[1], w2d.shape[0]) if transpose else w2d.shape
+    planes = torch.empty(((c + 31) // 32 * 2, r, 16), dtype=torch.int16, device=w2d.device)
+    _lib.check(L.smaat_bf16_planes(_ptr(w2d), r, c, _ptr(planes), 1 if transpose else 0, _stream(w2d)), "smaat_bf16_planes")
+    return planes
+
+
+def _pointwise_bf16_raw(x, planes, bias, m, want_stats=False, out_dtype=BF16, relu=False):
+    """out[n][m][p] = sum_c A[m][c] x[n][c][p] + bias[m]; x bf16, A a bf16 image, f32 accumulation, out bf16 | f32"""
+    L = _lib.get()
+    x, x_bs = _planes(x)
+    assert x.dtype == BF16
+    n, c, h, w = x.shape
+    out = _new(x, n, m, h, w, dtype=out_dtype)
+    part, slots = None, 0
+    if want_stats:
+        slots = L.smaat_pw_split_num_slots(n, h, w)
+        part = _new(x, 3, slots, m)
+    rc = L.smaat_pointwise_fwd_bf16(_ptr(x), x_bs, _ptr(planes), _ptr(bias), _ptr(out), m * h * w, _dt(out), _ptr(part), n, c,
+                                    m, h, w, 1 if relu else 0, _stream(x))
+    if rc == -2:
+        raise NotImplementedError(f"bf16 pointwise GEMM: [{n},{c},{h},{w}] -> {m} channels not built (odd plane size?)")
+    _lib.check(rc, "smaat_pointwise_fwd_bf16")
+    return out, part, slots
+
+
+def _dsconv_fwd_bf16(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, in_shift=None):
+    """mixed-precision DepthwiseSeparableConv forward: (z bf16, part, slots, y_dw bf16); x f32 (stem) or bf16"""
+    y = _dw3x3_fwd_raw(x, w_dw, b_dw, kpl, in_scale, in_shift, out_dtype=BF16)
+    cout = w_pw.shape[0]
+    planes = _bf16_planes_raw(w_pw.reshape(cout, -1))
+    z, part, slots = _pointwise_bf16_raw(y, planes, b_pw, cout, want_stats)
     return z, part, slots, y
 
 
@@ -292,9 +387,13 @@ def _affine_act_raw(z, scale, shift, relu, out=None):
     z, z_bs = _planes(z)
     n, c, h, w = z.shape
     if out is None:
-        out = _new(z, n, c, h, w)
+        out = _new(z, n, c, h, w, dtype=z.dtype)
     out_t, o_bs = _planes(out)
     assert out_t is out
+    if _is_bf(z) or _is_bf(out):
+        _lib.check(L.smaat_affine_act_t(_ptr(z), _dt(z), z_bs, _ptr(scale), _ptr(shift), _ptr(out), _dt(out), o_bs, n, c,
+                                        h * w, 1 if relu else 0, _stream(z)), "smaat_affine_act_t")
+        return out
     _lib.check(L.smaat_affine_act(_ptr(z), z_bs, _ptr(scale), _ptr(shift), _ptr(out), o_bs, n, c, h * w,
                                   1 if relu else 0, _stream(z)), "smaat_affine_act")
     return out
@@ -309,14 +408,22 @@ def _bn_bwd_raw(dy, z, st, gamma, relu, train, pre_part=None):
     n, c, h, w = z.shape
     p = h * w
     s = _stream(z)
+    typed = _is_bf(z) or _is_bf(dy)
+    if typed and dy.dtype != z.dtype:  # (a gradient that autograd handed over in another dtype)
+        dy = dy.to(z.dtype)
     if pre_part is not None:
         part, slots = pre_part
     else:
         slots = L.smaat_plane_num_slots(n, p)
         part = _new(z, 2, slots, c)
-        _lib.check(L.smaat_bn_bwd_reduce(_ptr(dy), dy_bs, _ptr(z), z_bs, _ptr(st[2]), _ptr(st[3]), _ptr(st[0]),
-                                         _ptr(st[1]), _ptr(part), n, c, p, 1 if relu else 0, s),
-                   "smaat_bn_bwd_reduce")
+        if typed:
+            _lib.check(L.smaat_bn_bwd_reduce_t(_ptr(dy), _dt(dy), dy_bs, _ptr(z), _dt(z), z_bs, _ptr(st[2]), _ptr(st[3]),
+                                               _ptr(st[0]), _ptr(st[1]), _ptr(part), n, c, p, 1 if relu else 0, None, s),
+                       "smaat_bn_bwd_reduce_t")
+        else:
+            _lib.check(L.smaat_bn_bwd_reduce(_ptr(dy), dy_bs, _ptr(z), z_bs, _ptr(st[2]), _ptr(st[3]), _ptr(st[0]),
+                                             _ptr(st[1]), _ptr(part), n, c, p, 1 if relu else 0, s),
+                       "smaat_bn_bwd_reduce")
     dgamma = _new(z, c)
     dbeta = _new(z, c)
     coef = _new(z, 3, c)
@@ -324,7 +431,12 @@ def _bn_bwd_raw(dy, z, st, gamma, relu, train, pre_part=None):
                                        _ptr(dbeta), _ptr(coef), s), "smaat_bn_bwd_finalize")
     if not train:  # eval mode: statistics are constants -> no mean/var terms
         coef[1:].zero_()
-    dz = _new(z, n, c, h, w)
+    dz = _new(z, n, c, h, w, dtype=z.dtype)
+    if typed:
+        _lib.check(L.smaat_bn_bwd_apply_t(_ptr(dy), _dt(dy), dy_bs, _ptr(z), _dt(z), z_bs, _ptr(st[2]), _ptr(st[3]),
+                                          _ptr(st[0]), _ptr(st[1]), _ptr(coef), _ptr(dz), _dt(dz), c * p, n, c, p,
+                                          1 if relu else 0, None, s), "smaat_bn_bwd_apply_t")
+        return dz, dgamma, dbeta
     _lib.check(L.smaat_bn_bwd_apply(_ptr(dy), dy_bs, _ptr(z), z_bs, _ptr(st[2]), _ptr(st[3]), _ptr(st[0]),
                                     _ptr(st[1]), _ptr(coef), _ptr(dz), c * p, n, c, p, 1 if relu else 0, s),
                "smaat_bn_bwd_apply")
@@ -344,17 +456,28 @@ def _bn_bwd_head_raw(dlog, w_out, z, st, gamma, train):
     wv = w_out.reshape(-1).contiguous()
     slots = L.smaat_plane_num_slots(n, p)
     part = _new(z, 3, slots, c)
-    _lib.check(L.smaat_bn_bwd_reduce_head(_ptr(dlog), dl_bs, _ptr(wv), _ptr(z), z_bs, _ptr(st[2]), _ptr(st[3]),
-                                          _ptr(st[0]), _ptr(st[1]), _ptr(part), n, c, p, s), "smaat_bn_bwd_reduce_head")
+    typed = _is_bf(z)
+    if typed:
+        dlog = dlog.float() if dlog.dtype != F32 else dlog
+        _lib.check(L.smaat_bn_bwd_reduce_t(_ptr(dlog), 0, dl_bs, _ptr(z), _dt(z), z_bs, _ptr(st[2]), _ptr(st[3]), _ptr(st[0]),
+                                           _ptr(st[1]), _ptr(part), n, c, p, 1, _ptr(wv), s), "smaat_bn_bwd_reduce_t(head)")
+    else:
+        _lib.check(L.smaat_bn_bwd_reduce_head(_ptr(dlog), dl_bs, _ptr(wv), _ptr(z), z_bs, _ptr(st[2]), _ptr(st[3]),
+                                              _ptr(st[0]), _ptr(st[1]), _ptr(part), n, c, p, s), "smaat_bn_bwd_reduce_head")
     dgamma, dbeta, coef = _new(z, c), _new(z, c), _new(z, 3, c)
     _lib.check(L.smaat_bn_bwd_finalize(_ptr(part), slots, c, float(n * p), _ptr(gamma), _ptr(st[1]), _ptr(dgamma),
                                        _ptr(dbeta), _ptr(coef), s), "smaat_bn_bwd_finalize")
     if not train:
         coef[1:].zero_()
-    dz = _new(z, n, c, h, w)
-    _lib.check(L.smaat_bn_bwd_apply_head(_ptr(dlog), dl_bs, _ptr(wv), _ptr(z), z_bs, _ptr(st[2]), _ptr(st[3]),
-                                         _ptr(st[0]), _ptr(st[1]), _ptr(coef), _ptr(dz), c * p, n, c, p, s),
-               "smaat_bn_bwd_apply_head")
+    dz = _new(z, n, c, h, w, dtype=z.dtype)
+    if typed:
+        _lib.check(L.smaat_bn_bwd_apply_t(_ptr(dlog), 0, dl_bs, _ptr(z), _dt(z), z_bs, _ptr(st[2]), _ptr(st[3]), _ptr(st[0]),
+                                          _ptr(st[1]), _ptr(coef), _ptr(dz), _dt(dz), c * p, n, c, p, 1, _ptr(wv), s),
+                   "smaat_bn_bwd_apply_t(head)")
+    else:
+        _lib.check(L.smaat_bn_bwd_apply_head(_ptr(dlog), dl_bs, _ptr(wv), _ptr(z), z_bs, _ptr(st[2]), _ptr(st[3]),
+                                             _ptr(st[0]), _ptr(st[1]), _ptr(coef), _ptr(dz), c * p, n, c, p, s),
+                   "smaat_bn_bwd_apply_head")
     dw_out = _new(z, c)
     _lib.check(L.smaat_reduce_rows(_ptr(part[2]), slots, c, _ptr(dw_out), 1.0, s), "smaat_reduce_rows")
     return dz, dgamma, dbeta, dw_out.view(1, c, 1, 1)
@@ -367,6 +490,10 @@ def _outconv1_fwd_raw(z, scale, shift, w_out, b_out):
     n, c, h, w = z.shape
     out = _new(z, n, 1, h, w)
     wv = w_out.reshape(-1).contiguous()
+    if _is_bf(z):
+        _lib.check(L.smaat_outconv1_fwd_t(_ptr(z), _dt(z), z_bs, _ptr(scale), _ptr(shift), _ptr(wv), _ptr(b_out), _ptr(out),
+                                          h * w, n, c, h * w, _stream(z)), "smaat_outconv1_fwd_t")
+        return out
     _lib.check(L.smaat_outconv1_fwd(_ptr(z), z_bs, _ptr(scale), _ptr(shift), _ptr(wv), _ptr(b_out), _ptr(out), h * w, n, c,
                                     h * w, _stream(z)), "smaat_outconv1_fwd")
     return out
@@ -378,6 +505,10 @@ def _channel_sum_raw(x):
     n, c, h, w = x.shape
     ws = _new(x, L.smaat_plane_num_slots(n, h * w), c)
     out = _new(x, c)
+    if _is_bf(x):
+        _lib.check(L.smaat_channel_sum_t(_ptr(x), _dt(x), x_bs, n, c, h * w, _ptr(ws), _ptr(out), _stream(x)),
+                   "smaat_channel_sum_t")
+        return out
     _lib.check(L.smaat_channel_sum(_ptr(x), x_bs, n, c, h * w, _ptr(ws), _ptr(out), _stream(x)), "smaat_channel_sum")
     return out
 
@@ -391,6 +522,16 @@ def _pointwise_wgrad_raw(y, dz, m):
     ns = L.smaat_wgrad_num_splits(n, h, w, m, k)
     ws = _new(y, ns, m, k)
     dw = _new(y, m, k, 1, 1)
+    if _is_bf(y) or _is_bf(dz):  # mixed precision: bf16 operands straight from HBM, f32 accumulation and result
+        if y.dtype != BF16:
+            y, y_bs = _planes(y.to(BF16))
+        if dz.dtype != BF16:
+            dz, dz_bs = _planes(dz.to(BF16))
+        rc = L.smaat_pointwise_wgrad_bf16(_ptr(y), y_bs, _ptr(dz), dz_bs, _ptr(ws), _ptr(dw), n, k, m, h, w, _stream(y))
+        if rc == -2:
+            raise NotImplementedError(f"bf16 pointwise weight gradient: [{n},{k},{h},{w}] x {m} not built (odd plane size?)")
+        _lib.check(rc, "smaat_pointwise_wgrad_bf16")
+        return dw
     _lib.check(L.smaat_pointwise_wgrad(_ptr(y), y_bs, _ptr(dz), dz_bs, _ptr(ws), _ptr(dw), n, k, m, h, w,
                                        _stream(y)), "smaat_pointwise_wgrad")
     return dw
@@ -407,6 +548,8 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None, i
     cout = w_pw.shape[0]
     k = cin * kpl
     s = _stream(x)
+    if _is_bf(dz):
+        return _dsconv_bwd_bf16(x, x_bs, w_dw, w_pw, dz, kpl, need_dx, y, bnred, in_aff)
     if y is not None:
         dw_pw = _pointwise_wgrad_raw(y, dz, cout)
     else:
@@ -457,6 +600,46 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None, i
     return dx, dw_dw, db_dw, dw_pw
 
 
+def _dsconv_bwd_bf16(x, x_bs, w_dw, w_pw, dz, kpl, need_dx, y, bnred, in_aff):
+    """mixed-precision form of _dsconv_bwd_raw: dz, y (the kept depthwise output) and the depthwise-output gradient are
+    bf16; x is bf16, or f32 for the stem (then dx, if wanted, is f32 too).  Same return convention."""
+    L = _lib.get()
+    n, cin, h, w = x.shape
+    cout = w_pw.shape[0]
+    k = cin * kpl
+    s = _stream(x)
+    if y is None:
+        raise _lib.SmaatHipError("mixed precision keeps the depthwise output for the weight gradient "
+                                 "(ops.KEEP_DEPTHWISE_OUTPUT = False is an f32-only option)")
+    dw_pw = _pointwise_wgrad_raw(y, dz, cout)
+    planes_t = _bf16_planes_raw(w_pw.reshape(cout, k), transpose=True)  # A[k][co] = w_pw[co][k]
+    dy, _, _ = _pointwise_bf16_raw(dz, planes_t, None, k)
+    dx = _new(x, n, cin, h, w, dtype=x.dtype) if need_dx else None
+    rows = L.smaat_dw3x3_bwd_ws_rows(n, cin, h, w)
+    ws2 = _new(x, rows, k, 10)
+    dw_dw = _new(x, k, 1, 3, 3)
+    db_dw = _new(x, k)
+    rpart = None
+    isc = ish = mean = invstd = None
+    if in_aff is not None:
+        if bnred is None or not need_dx:
+            raise _lib.SmaatHipError("depthwise backward with an on-load activation needs bnred=(mean, invstd) and dx")
+        mean, invstd = bnred
+        isc, ish = in_aff
+        rpart = _new(x, 2, rows - 1, cin)
+    rc = L.smaat_dw3x3_bwd_t(_ptr(x), _dt(x), x_bs, _ptr(isc), _ptr(ish), _ptr(dy), _dt(dy), k * h * w, _ptr(w_dw), _ptr(dx),
+                             _dt(dx) if dx is not None else _dt(x), cin * h * w, _ptr(ws2), _ptr(dw_dw), _ptr(db_dw),
+                             _ptr(mean), _ptr(invstd), _ptr(rpart), n, cin, kpl, h, w, s)
+    if rc == -2:
+        raise NotImplementedError(f"depthwise 3x3 backward with bf16 storage: [{n},{cin},{h},{w}] kpl={kpl} not built")
+    _lib.check(rc, "smaat_dw3x3_bwd_t")
+    if in_aff is not None:
+        return dx, dw_dw, db_dw, dw_pw, (rpart, rows - 1)
+    if bnred is not None:
+        return dx, dw_dw, db_dw, dw_pw, None
+    return dx, dw_dw, db_dw, dw_pw
+
+
 # keep the depthwise output of the forward for the backward (streamed weight gradient).  Set to
 # False to trade speed for memory: the backward then recomputes it inside the wgrad kernel.
 KEEP_DEPTHWISE_OUTPUT = True
@@ -476,9 +659,12 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
     y_dw = None
     isc, ish = in_aff if in_aff is not None else (None, None)
     rs = None
-    if _split_on() and _fused_dw_ok(n, h, w, kpl, cout, keep_y, cin):
+    bf = _is_bf(x) or mixed_precision_active()
+    if bf:  # mixed precision: bf16 depthwise output, bf16 GEMM, bf16 z (the f32 kernel families are not involved)
+        rs = _dsconv_fwd_bf16(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish)
+    elif _split_on() and _fused_dw_ok(n, h, w, kpl, cout, keep_y, cin):
         rs = _dsconv_fwd_fused(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish, want_y=keep_y)
-    if rs is None and _split_fwd_ok(cin * kpl, cout, use_batch_stats):
+    if rs is None and not bf and _split_fwd_ok(cin * kpl, cout, use_batch_stats):
         rs = _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish)
     if rs is not None and use_batch_stats:
         z, part, slots, y_dw = rs
@@ -538,7 +724,8 @@ class _DSConvBNReLU(torch.autograd.Function):
                                                          ("bn.running_var", rv)))
         w_dw = w_dw.contiguous()
         w_pw = w_pw.contiguous()
-        keep_y = KEEP_DEPTHWISE_OUTPUT and any(ctx.needs_input_grad[:4])  # forward runs under no_grad
+        keep_y = ((KEEP_DEPTHWISE_OUTPUT or _is_bf(x) or mixed_precision_active())
+                  and any(ctx.needs_input_grad[:4]))  # forward runs under no_grad
         y, z, st, y_dw, ubs = _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, momentum, eps,
                                             kpl, keep_y)
         ctx.save_for_backward(x, w_dw, b_dw, w_pw, gamma, z, st, y_dw)
@@ -576,13 +763,15 @@ class _DoubleConvDS(torch.autograd.Function):
                       ("double_conv.4.running_mean", rm2), ("double_conv.4.running_var", rv2)):
             _expect(t, (w_pw2.shape[0],), "double_conv.3/4 " + nm)
         w_dw1, w_pw1, w_dw2, w_pw2 = (t.contiguous() for t in (w_dw1, w_pw1, w_dw2, w_pw2))
-        keep_y = KEEP_DEPTHWISE_OUTPUT and any(ctx.needs_input_grad[:17])
+        keep_y = (KEEP_DEPTHWISE_OUTPUT or _is_bf(x) or mixed_precision_active()) and any(ctx.needs_input_grad[:17])
         # the activation y1 = relu(bn1(z1)) is never written when every consumer can apply it on load:
         # the second half's forward (depthwise stage) and its depthwise backward (strip kernel: W % 4 == 0),
         # and the weight gradient reads the kept depthwise output, not y1
         n, _, h, w = x.shape
+        bf = _is_bf(x) or mixed_precision_active()
         fuse = (FUSE_FIRST_ACTIVATION and keep_y and g1 is not None
-                and bool(_lib.get().smaat_dw3x3_strip_ok(kpl, h, w)))
+                and bool(_lib.get().smaat_dw3x3_strip_ok(kpl, h, w))
+                and (not bf or kpl <= 2))  # (bf16 storage: the row-streaming backward, kernels_per_layer <= 2)
         y1, z1, st1, ydw1, ubs1 = _half_forward(x, w_dw1, b_dw1, w_pw1, b_pw1, g1, be1, rm1, rv1, tr1, mo1, eps1, kpl,
                                                 keep_y, want_act=not fuse)
         # head: an OutConv with ONE output channel consumes the block (w_out [1][C][1][1]): the block output is not
@@ -777,8 +966,11 @@ class _Pointwise(torch.autograd.Function):
         _expect(b, (w.shape[0],), "conv.bias")
         w = w.contiguous()
         m, c = w.shape[0], w.shape[1]
-        wt = w.reshape(m, c).t().contiguous()
-        out = _pointwise_raw(x, wt, b, m)
+        if _is_bf(x):  # mixed precision: bf16 activations in, f32 logits out
+            out, _, _ = _pointwise_bf16_raw(x, _bf16_planes_raw(w.reshape(m, c)), b, m, out_dtype=F32)
+        else:
+            wt = w.reshape(m, c).t().contiguous()
+            out = _pointwise_raw(x, wt, b, m)
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         return out
@@ -788,6 +980,13 @@ class _Pointwise(torch.autograd.Function):
         x, w = ctx.saved_tensors
         m, c = w.shape[0], w.shape[1]
         dx = None
+        if _is_bf(x):
+            dzb = dz.to(BF16)  # (n_classes channels: a small tensor) -- the bf16 GEMMs take bf16 operands
+            if ctx.needs_input_grad[0]:
+                dx, _, _ = _pointwise_bf16_raw(dzb, _bf16_planes_raw(w.reshape(m, c), transpose=True), None, c)
+            dw = _pointwise_wgrad_raw(x, dzb, m)
+            db = _channel_sum_raw(dz) if ctx.has_bias else None
+            return dx, dw, db
         if ctx.needs_input_grad[0]:
             dx = _pointwise_raw(dz, w.reshape(m, c), None, c)  # wt[c'=m][m'=c] = w natural
         dw = _pointwise_wgrad_raw(x, dz, m)
@@ -809,9 +1008,7 @@ class _MaxPool2(torch.autograd.Function):
         L = _lib.get()
         x, x_bs = _planes(x)
         n, c, h, w = x.shape
-        y = _new(x, n, c, h // 2, w // 2)
-        _lib.check(L.smaat_maxpool2_fwd(_ptr(x), x_bs, _ptr(y), c * (h // 2) * (w // 2), n, c, h, w, _stream(x)),
-                   "smaat_maxpool2_fwd")
+        y = _maxpool2_fwd_raw(x, x_bs)
         ctx.save_for_backward(x)
         return y
 
@@ -822,10 +1019,36 @@ class _MaxPool2(torch.autograd.Function):
         x, x_bs = _planes(x)
         dy, dy_bs = _planes(dy)
         n, c, h, w = x.shape
-        dx = _new(x, n, c, h, w)
-        _lib.check(L.smaat_maxpool2_bwd(_ptr(x), x_bs, _ptr(dy), dy_bs, _ptr(dx), c * h * w, n, c, h, w, 0,
-                                        _stream(x)), "smaat_maxpool2_bwd")
+        dx = _new(x, n, c, h, w, dtype=x.dtype)
+        _maxpool2_bwd_raw(x, x_bs, dy, dy_bs, dx, 0)
         return dx
+
+
+def _maxpool2_fwd_raw(x, x_bs):
+    L = _lib.get()
+    n, c, h, w = x.shape
+    y = _new(x, n, c, h // 2, w // 2, dtype=x.dtype)
+    if _is_bf(x):
+        _lib.check(L.smaat_maxpool2_fwd_t(_ptr(x), x_bs, _ptr(y), c * (h // 2) * (w // 2), n, c, h, w, 1, _stream(x)),
+                   "smaat_maxpool2_fwd_t")
+    else:
+        _lib.check(L.smaat_maxpool2_fwd(_ptr(x), x_bs, _ptr(y), c * (h // 2) * (w // 2), n, c, h, w, _stream(x)),
+                   "smaat_maxpool2_fwd")
+    return y
+
+
+def _maxpool2_bwd_raw(x, x_bs, dy, dy_bs, dx, accum):
+    """dx (+)= maxpool2 backward; x, dy, dx share one dtype"""
+    L = _lib.get()
+    n, c, h, w = x.shape
+    if _is_bf(x):
+        if dy.dtype != BF16:
+            dy, dy_bs = _planes(dy.to(BF16))
+        _lib.check(L.smaat_maxpool2_bwd_t(_ptr(x), x_bs, _ptr(dy), dy_bs, _ptr(dx), c * h * w, n, c, h, w, accum, 1,
+                                          _stream(x)), "smaat_maxpool2_bwd_t")
+    else:
+        _lib.check(L.smaat_maxpool2_bwd(_ptr(x), x_bs, _ptr(dy), dy_bs, _ptr(dx), c * h * w, n, c, h, w, accum,
+                                        _stream(x)), "smaat_maxpool2_bwd")
 
 
 def maxpool2(x):
@@ -835,6 +1058,41 @@ def maxpool2(x):
 # --------------------------------------------------------------------------------------
 # Upsample(x2, bilinear, align_corners=True) + F.pad + cat([x2, x1_up], dim=1)
 # --------------------------------------------------------------------------------------
+def _upsample_fwd_raw(x1, x1_bs, dst_ptr, dst_bs, n, c1, h, w, ho, wo, pt, pl, s):
+    L = _lib.get()
+    if _is_bf(x1):
+        rc = L.smaat_upsample2x_fwd_t(_ptr(x1), x1_bs, dst_ptr, dst_bs, n, c1, h, w, ho, wo, pt, pl, 1, s)
+        if rc == -2:
+            raise NotImplementedError(f"bilinear upsample with bf16 storage: [{n},{c1},{h},{w}] -> {ho}x{wo} not built "
+                                      "(output width must be a multiple of 4)")
+        _lib.check(rc, "smaat_upsample2x_fwd_t")
+    else:
+        _lib.check(L.smaat_upsample2x_fwd(_ptr(x1), x1_bs, dst_ptr, dst_bs, n, c1, h, w, ho, wo, pt, pl, s),
+                   "smaat_upsample2x_fwd")
+
+
+def _upsample_bwd_raw(src_ptr, src_bs, dx1, n, c1, h, w, ho, wo, pt, pl, s):
+    L = _lib.get()
+    if _is_bf(dx1):
+        rc = L.smaat_upsample2x_bwd_t(src_ptr, src_bs, _ptr(dx1), c1 * h * w, n, c1, h, w, ho, wo, pt, pl, 1, s)
+        if rc == -2:
+            raise NotImplementedError(f"bilinear upsample backward with bf16 storage: [{n},{c1},{h},{w}] <- {ho}x{wo} not built")
+        _lib.check(rc, "smaat_upsample2x_bwd_t")
+    else:
+        _lib.check(L.smaat_upsample2x_bwd(src_ptr, src_bs, _ptr(dx1), c1 * h * w, n, c1, h, w, ho, wo, pt, pl, s),
+                   "smaat_upsample2x_bwd")
+
+
+def _copy_planes_raw(src_ptr, s_bs, dst_ptr, d_bs, n, plane_len, esize, s):
+    """dst[n][:plane_len] = src[n][:plane_len] for tensors of `esize`-byte elements (strides in elements)"""
+    L = _lib.get()
+    if esize == 2:  # bf16: move pairs of elements as floats
+        if (plane_len | s_bs | d_bs) & 1:
+            raise NotImplementedError("plane copy of bf16 tensors with an odd element count")
+        plane_len, s_bs, d_bs = plane_len // 2, s_bs // 2, d_bs // 2
+    _lib.check(L.smaat_copy_planes(src_ptr, s_bs, dst_ptr, d_bs, n, plane_len, 0, s), "smaat_copy_planes")
+
+
 class _UpsampleCat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, x2):
@@ -849,12 +1107,14 @@ class _UpsampleCat(torch.autograd.Function):
         if dy_ < 0 or dx_ < 0:
             raise NotImplementedError("UpDS with a skip connection smaller than the upsampled map (negative pad)")
         pt, pl = dy_ // 2, dx_ // 2
-        cat = _new(x1, n, c2 + c1, ho, wo)
+        if x2.dtype != x1.dtype:
+            x2, x2_bs = _planes(x2.to(x1.dtype))
+        cat = _new(x1, n, c2 + c1, ho, wo, dtype=x1.dtype)
+        es = cat.element_size()
         cbs = (c1 + c2) * ho * wo
         s = _stream(x1)
-        _lib.check(L.smaat_copy_planes(_ptr(x2), x2_bs, _ptr(cat), cbs, n, c2 * ho * wo, 0, s), "smaat_copy_planes")
-        _lib.check(L.smaat_upsample2x_fwd(_ptr(x1), x1_bs, cat.data_ptr() + 4 * c2 * ho * wo, cbs, n, c1, h, w, ho,
-                                          wo, pt, pl, s), "smaat_upsample2x_fwd")
+        _copy_planes_raw(_ptr(x2), x2_bs, _ptr(cat), cbs, n, c2 * ho * wo, es, s)
+        _upsample_fwd_raw(x1, x1_bs, cat.data_ptr() + es * c2 * ho * wo, cbs, n, c1, h, w, ho, wo, pt, pl, s)
         ctx.geom = (n, c1, h, w, c2, ho, wo, pt, pl)
         return cat
 
@@ -863,17 +1123,16 @@ class _UpsampleCat(torch.autograd.Function):
         L = _lib.get()
         n, c1, h, w, c2, ho, wo, pt, pl = ctx.geom
         dcat = dcat.contiguous()
+        es = dcat.element_size()
         cbs = (c1 + c2) * ho * wo
         s = _stream(dcat)
         dx1 = dx2 = None
         if ctx.needs_input_grad[1]:
-            dx2 = _new(dcat, n, c2, ho, wo)
-            _lib.check(L.smaat_copy_planes(_ptr(dcat), cbs, _ptr(dx2), c2 * ho * wo, n, c2 * ho * wo, 0, s),
-                       "smaat_copy_planes")
+            dx2 = _new(dcat, n, c2, ho, wo, dtype=dcat.dtype)
+            _copy_planes_raw(_ptr(dcat), cbs, _ptr(dx2), c2 * ho * wo, n, c2 * ho * wo, es, s)
         if ctx.needs_input_grad[0]:
-            dx1 = _new(dcat, n, c1, h, w)
-            _lib.check(L.smaat_upsample2x_bwd(dcat.data_ptr() + 4 * c2 * ho * wo, cbs, _ptr(dx1), c1 * h * w, n, c1,
-                                              h, w, ho, wo, pt, pl, s), "smaat_upsample2x_bwd")
+            dx1 = _new(dcat, n, c1, h, w, dtype=dcat.dtype)
+            _upsample_bwd_raw(dcat.data_ptr() + es * c2 * ho * wo, cbs, dx1, n, c1, h, w, ho, wo, pt, pl, s)
         return dx1, dx2
 
 
@@ -913,6 +1172,7 @@ def _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, 
     p = h * w
     s_ = _stream(x)
     dev = x
+    bf = _is_bf(x)  # mixed precision: x / out are bf16; the per-(n, c) vectors, maps and the gate stay f32
     if use_ch:
         cr = w1.shape[0]
         w1 = w1.contiguous()
@@ -921,10 +1181,17 @@ def _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, 
         mx = _new(dev, n, c)
         amax = _new(dev, n, c, dtype=torch.int32)
         if lazy is not None:
-            y = _new(dev, n, c, h, w)
-            _lib.check(L.smaat_cbam_chpool_act(_ptr(x), x_bs, _ptr(lazy[0]), _ptr(lazy[1]), _ptr(y), c * p, n, c, p,
-                                               _ptr(avg), _ptr(mx), _ptr(amax), s_), "smaat_cbam_chpool_act")
+            y = _new(dev, n, c, h, w, dtype=x.dtype)
+            if bf:
+                _lib.check(L.smaat_cbam_chpool_t(_ptr(x), x_bs, _ptr(lazy[0]), _ptr(lazy[1]), _ptr(y), c * p, n, c, p,
+                                                 _ptr(avg), _ptr(mx), _ptr(amax), 1, s_), "smaat_cbam_chpool_t")
+            else:
+                _lib.check(L.smaat_cbam_chpool_act(_ptr(x), x_bs, _ptr(lazy[0]), _ptr(lazy[1]), _ptr(y), c * p, n, c, p,
+                                                   _ptr(avg), _ptr(mx), _ptr(amax), s_), "smaat_cbam_chpool_act")
             x, x_bs = y, c * p
+        elif bf:
+            _lib.check(L.smaat_cbam_chpool_t(_ptr(x), x_bs, None, None, None, 0, n, c, p, _ptr(avg), _ptr(mx), _ptr(amax), 1,
+                                             s_), "smaat_cbam_chpool_t")
         else:
             _lib.check(L.smaat_cbam_chpool(_ptr(x), x_bs, n, c, p, _ptr(avg), _ptr(mx), _ptr(amax), s_),
                        "smaat_cbam_chpool")
@@ -935,12 +1202,15 @@ def _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, 
                                     _ptr(ha), _ptr(hm), _ptr(sc), s_), "smaat_cbam_mlp")
     else:
         avg = mx = amax = ha = hm = None
-        sc = torch.ones(n, c, dtype=torch.float32, device=x.device)
+        sc = torch.ones(n, c, dtype=torch.float32, device=x.device)  # (f32 in every precision)
     if use_sp:
         wconv = wconv.contiguous()
         ks = wconv.shape[-1]
         maps = _new(dev, n, 2, h, w)
-        _lib.check(L.smaat_cbam_sppool(_ptr(x), x_bs, _ptr(sc), n, c, p, _ptr(maps), s_), "smaat_cbam_sppool")
+        if bf:
+            _lib.check(L.smaat_cbam_sppool_t(_ptr(x), x_bs, _ptr(sc), n, c, p, _ptr(maps), 1, s_), "smaat_cbam_sppool_t")
+        else:
+            _lib.check(L.smaat_cbam_sppool(_ptr(x), x_bs, _ptr(sc), n, c, p, _ptr(maps), s_), "smaat_cbam_sppool")
         nb = L.smaat_cbam_spconv_blocks(n, h, w)
         conv = _new(dev, n, 1, h, w)
         use_batch_stats = training or rm is None
@@ -961,11 +1231,16 @@ def _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, 
         use_batch_stats = False
         gate = torch.ones(n, 1, h, w, dtype=torch.float32, device=x.device)
     if out is None:
-        out = _new(dev, n, c, h, w)
+        out = _new(dev, n, c, h, w, dtype=x.dtype)
     out_t, o_bs = _planes(out)
     assert out_t is out, "cbam: the output slice must have dense [C][H][W] planes"
-    _lib.check(L.smaat_cbam_apply(_ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(out), o_bs, n, c, p, s_),
-               "smaat_cbam_apply")
+    assert out.dtype == x.dtype
+    if bf:
+        _lib.check(L.smaat_cbam_apply_t(_ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(out), o_bs, n, c, p, 1, s_),
+                   "smaat_cbam_apply_t")
+    else:
+        _lib.check(L.smaat_cbam_apply(_ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(out), o_bs, n, c, p, s_),
+                   "smaat_cbam_apply")
     saved = (x, w1, w2, wconv, gamma, avg, mx, amax, ha, hm, sc, maps, conv, st, gate)
     return out, saved, (use_ch, use_sp, use_batch_stats)
 
@@ -979,6 +1254,9 @@ def _cbam_backward_impl(saved, flags, dout, pooled=None):
     x, w1, w2, wconv, gamma, avg, mx, amax, ha, hm, sc, maps, conv, st, gate = saved
     use_ch, use_sp, train_stats = flags
     x, x_bs = _planes(x)
+    bf = _is_bf(x)
+    if dout.dtype != x.dtype:
+        dout = dout.to(x.dtype)
     dout, do_bs = _planes(dout)
     n, c, h, w = x.shape
     p = h * w
@@ -990,9 +1268,14 @@ def _cbam_backward_impl(saved, flags, dout, pooled=None):
         nbp = L.smaat_cbam_pix_blocks(n, p)
         dbn = _new(dev, n, p)
         part = _new(dev, 2, nbp, 1)
-        _lib.check(L.smaat_cbam_bwd_gate(_ptr(dout), do_bs, _ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(conv),
-                                         _ptr(st[0]), _ptr(st[1]), n, c, p, _ptr(dbn), _ptr(part), s_),
-                   "smaat_cbam_bwd_gate")
+        if bf:
+            _lib.check(L.smaat_cbam_bwd_gate_t(_ptr(dout), do_bs, _ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(conv),
+                                               _ptr(st[0]), _ptr(st[1]), n, c, p, _ptr(dbn), _ptr(part), 1, s_),
+                       "smaat_cbam_bwd_gate_t")
+        else:
+            _lib.check(L.smaat_cbam_bwd_gate(_ptr(dout), do_bs, _ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(conv),
+                                             _ptr(st[0]), _ptr(st[1]), n, c, p, _ptr(dbn), _ptr(part), s_),
+                       "smaat_cbam_bwd_gate")
         dgamma = _new(dev, 1)
         dbeta = _new(dev, 1)
         coef = _new(dev, 3, 1)
@@ -1015,11 +1298,16 @@ def _cbam_backward_impl(saved, flags, dout, pooled=None):
         maps = torch.full((n, 2, h, w), float("inf"), dtype=torch.float32, device=x.device)
         dmaps = torch.zeros(n, 2, h, w, dtype=torch.float32, device=x.device)
     nbp = L.smaat_cbam_pix_blocks(n, p)
-    dx = _new(dev, n, c, h, w)
+    dx = _new(dev, n, c, h, w, dtype=x.dtype)
     dspart = _new(dev, nbp, c)
-    _lib.check(L.smaat_cbam_bwd_main(_ptr(dout), do_bs, _ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(maps),
-                                     _ptr(dmaps), n, c, p, _ptr(dx), c * p, _ptr(dspart), s_),
-               "smaat_cbam_bwd_main")
+    if bf:
+        _lib.check(L.smaat_cbam_bwd_main_t(_ptr(dout), do_bs, _ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(maps),
+                                           _ptr(dmaps), n, c, p, _ptr(dx), c * p, _ptr(dspart), 1, s_),
+                   "smaat_cbam_bwd_main_t")
+    else:
+        _lib.check(L.smaat_cbam_bwd_main(_ptr(dout), do_bs, _ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(maps),
+                                         _ptr(dmaps), n, c, p, _ptr(dx), c * p, _ptr(dspart), s_),
+                   "smaat_cbam_bwd_main")
     dw1 = db1 = dw2 = db2 = None
     pool_done = False
     if use_ch:
@@ -1044,18 +1332,28 @@ def _cbam_backward_impl(saved, flags, dout, pooled=None):
         rc = -2
         if pooled is not None:  # + the backward of the MaxPool2d that reads x too, in the same pass over dx
             dpl, dp_bs = pooled
-            rc = L.smaat_cbam_bwd_final_pool(_ptr(dx), c * p, _ptr(davg), _ptr(dmx), _ptr(amax), _ptr(x), x_bs, _ptr(dpl),
-                                             dp_bs, n, c, h, w, s_)
+            if dpl.dtype != x.dtype:
+                dpl, dp_bs = _planes(dpl.to(x.dtype))
+                pooled = (dpl, dp_bs)
+            if bf:
+                rc = L.smaat_cbam_bwd_final_pool_t(_ptr(dx), c * p, _ptr(davg), _ptr(dmx), _ptr(amax), _ptr(x), x_bs,
+                                                   _ptr(dpl), dp_bs, n, c, h, w, 1, s_)
+            else:
+                rc = L.smaat_cbam_bwd_final_pool(_ptr(dx), c * p, _ptr(davg), _ptr(dmx), _ptr(amax), _ptr(x), x_bs, _ptr(dpl),
+                                                 dp_bs, n, c, h, w, s_)
             if rc not in (0, -2):
                 _lib.check(rc, "smaat_cbam_bwd_final_pool")
         if rc == -2:
-            _lib.check(L.smaat_cbam_bwd_final(_ptr(dx), c * p, _ptr(davg), _ptr(dmx), _ptr(amax), n, c, p, s_),
-                       "smaat_cbam_bwd_final")
+            if bf:
+                _lib.check(L.smaat_cbam_bwd_final_t(_ptr(dx), c * p, _ptr(davg), _ptr(dmx), _ptr(amax), n, c, p, 1, s_),
+                           "smaat_cbam_bwd_final_t")
+            else:
+                _lib.check(L.smaat_cbam_bwd_final(_ptr(dx), c * p, _ptr(davg), _ptr(dmx), _ptr(amax), n, c, p, s_),
+                           "smaat_cbam_bwd_final")
         pool_done = rc == 0
     if pooled is not None and not pool_done:
         dpl, dp_bs = pooled
-        _lib.check(L.smaat_maxpool2_bwd(_ptr(x), x_bs, _ptr(dpl), dp_bs, _ptr(dx), c * p, n, c, h, w, 1, s_),
-                   "smaat_maxpool2_bwd")
+        _maxpool2_bwd_raw(x, x_bs, dpl, dp_bs, dx, 1)
     return dx, dw1, db1, dw2, db2, dwconv, dgamma, dbeta
 
 
@@ -1124,14 +1422,12 @@ class _CBAMPoolCat(torch.autograd.Function):
         L = _lib.get()
         x, x_bs = _planes(x)
         n, c, h, w = x.shape
-        cat = _new(x, n, c + c_extra, h, w)
+        cat = _new(x, n, c + c_extra, h, w, dtype=x.dtype)
         lazy = (lazy_scale, lazy_shift) if lazy_scale is not None else None
         _, saved, flags = _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps,
                                              True, True, out=cat[:, :c], lazy=lazy)
         x, x_bs = _planes(saved[0])  # (the activated tensor when the activation was deferred)
-        pooled = _new(x, n, c, h // 2, w // 2)
-        _lib.check(L.smaat_maxpool2_fwd(_ptr(x), x_bs, _ptr(pooled), c * (h // 2) * (w // 2), n, c, h, w,
-                                        _stream(x)), "smaat_maxpool2_fwd")
+        pooled = _maxpool2_fwd_raw(x, x_bs)
         ctx.save_for_backward(*saved)
         ctx.flags = flags
         return cat, pooled
@@ -1152,8 +1448,7 @@ class _CBAMPoolCat(torch.autograd.Function):
             if dpooled is not None:
                 xx, x_bs = _planes(x)
                 dpooled, dp_bs = _planes(dpooled)
-                _lib.check(L.smaat_maxpool2_bwd(_ptr(xx), x_bs, _ptr(dpooled), dp_bs, _ptr(dx), c * h * w, n, c, h, w, 1,
-                                                _stream(x)), "smaat_maxpool2_bwd")
+                _maxpool2_bwd_raw(xx, x_bs, dpooled, dp_bs, dx, 1)
         return (dx,) + tuple(g[1:]) + (None,) * 8
 
 
@@ -1181,8 +1476,10 @@ class _UpsampleInto(torch.autograd.Function):
         if dy_ < 0 or dx_ < 0:
             raise NotImplementedError("UpDS with a skip connection smaller than the upsampled map (negative pad)")
         pt, pl = dy_ // 2, dx_ // 2
-        _lib.check(L.smaat_upsample2x_fwd(_ptr(x1), x1_bs, cat.data_ptr() + 4 * c_off * ho * wo, ct * ho * wo, n, c1,
-                                          h, w, ho, wo, pt, pl, _stream(x1)), "smaat_upsample2x_fwd")
+        if x1.dtype != cat.dtype:
+            raise TypeError(f"upsample_into: the concatenation buffer is {cat.dtype}, the upsampled tensor {x1.dtype}")
+        _upsample_fwd_raw(x1, x1_bs, cat.data_ptr() + cat.element_size() * c_off * ho * wo, ct * ho * wo, n, c1, h, w, ho, wo,
+                          pt, pl, _stream(x1))
         ctx.geom = (n, c1, h, w, c_off, ho, wo, pt, pl)
         ctx.mark_dirty(cat)
         return cat
@@ -1194,10 +1491,9 @@ class _UpsampleInto(torch.autograd.Function):
         dcat = dcat.contiguous()
         dx1 = None
         if ctx.needs_input_grad[1]:
-            dx1 = _new(dcat, n, c1, h, w)
-            _lib.check(L.smaat_upsample2x_bwd(dcat.data_ptr() + 4 * c_off * ho * wo, (c_off + c1) * ho * wo, _ptr(dx1),
-                                              c1 * h * w, n, c1, h, w, ho, wo, pt, pl, _stream(dcat)),
-                       "smaat_upsample2x_bwd")
+            dx1 = _new(dcat, n, c1, h, w, dtype=dcat.dtype)
+            _upsample_bwd_raw(dcat.data_ptr() + dcat.element_size() * c_off * ho * wo, (c_off + c1) * ho * wo, dx1, n, c1, h,
+                              w, ho, wo, pt, pl, _stream(dcat))
         return dcat, dx1, None
 
 
@@ -1220,6 +1516,9 @@ def _gemm_rows(x, a2d, m):
 
 def _upconv_forward(x1, w, b, cat, c_off):
     L = _lib.get()
+    if _is_bf(x1) or _is_bf(cat):
+        raise NotImplementedError("UpDS(bilinear=False) (ConvTranspose2d up path) is built for f32 storage only; "
+                                  "mixed precision takes the bilinear up path")
     x1, _ = _planes(x1)
     x1 = x1.contiguous()
     n, c1, h, wd = x1.shape

@@ -35,13 +35,22 @@ class DoubleConvDS(nn.Module):
         conv, bn = self.double_conv[3 * i], self.double_conv[3 * i + 1]
         src = (conv.pointwise.weight, conv.pointwise.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
         try:
-            key = tuple((t.data_ptr(), t._version) if t is not None else None for t in src) + (bn.eps,)
+            # (data pointer, version counter) of every tensor that enters the fold + the matrix mode the operand images
+            # were built for.  Writes through `.data` do not bump the version counters: after such updates call the
+            # network's invalidate_eval_cache() (or DoubleConvDS.invalidate_eval_cache()).
+            key = (tuple((t.data_ptr(), t._version) if t is not None else None for t in src)
+                   + (bn.eps, ops._lib.get().smaat_split_mode()))
         except Exception:  # noqa: BLE001  (FakeTensors under torch.export / compile: fold inside the traced graph)
             return conv.depthwise.weight, conv.depthwise.bias, ops.fold_bn_into_pointwise(*src, bn.eps)
         cache = self.__dict__.setdefault("_fold_cache", {})
         if cache.get(i, (None,))[0] != key:
             cache[i] = (key, ops.fold_bn_into_pointwise(*src, bn.eps))
         return conv.depthwise.weight, conv.depthwise.bias, cache[i][1]
+
+    def invalidate_eval_cache(self):
+        """forget the BatchNorm-folded weights (see UNetDSFamily.invalidate_eval_cache)"""
+        self.__dict__["_fold_cache"] = {}
+        return self
 
     def _eval_fast_ok(self, hooked):
         import torch
@@ -71,7 +80,7 @@ class DoubleConvDS(nn.Module):
             import torch
             if hooked or not torch.is_grad_enabled() or seq[0].kernels_per_layer_ != seq[3].kernels_per_layer_:
                 y = self.forward(x)  # the plain block, then the OutConv on its own
-                if not torch.is_grad_enabled():
+                if not torch.is_grad_enabled() and y.dtype == torch.float32:
                     return torch.ops.smaat.pointwise_infer(y, head.weight, head.bias)
                 return ops.pointwise(y, head.weight, head.bias)
             for conv in (seq[0], seq[3]):
@@ -97,7 +106,7 @@ class DoubleConvDS(nn.Module):
 class _MaxPool2(nn.MaxPool2d):
     def forward(self, x):
         import torch
-        if not torch.is_grad_enabled():
+        if not torch.is_grad_enabled() and x.dtype == torch.float32:  # (the inference operator set is f32)
             return torch.ops.smaat.maxpool2_infer(x)
         return ops.maxpool2(x)
 
@@ -135,7 +144,7 @@ class UpDS(nn.Module):
     def forward(self, x1, x2):
         import torch
         if self.bilinear:
-            if not torch.is_grad_enabled():
+            if not torch.is_grad_enabled() and x1.dtype == torch.float32 and x2.dtype == torch.float32:
                 return self.conv(torch.ops.smaat.upsample_cat_infer(x1, x2))
             return self.conv(ops.upsample_cat(x1, x2))
         return self.conv(ops.upconv_cat(x1, x2, self.up.weight, self.up.bias))
@@ -147,7 +156,7 @@ class UpDS(nn.Module):
         kw = {} if head is None else {"head": head}
         if self.bilinear:
             import torch
-            if not torch.is_grad_enabled():
+            if not torch.is_grad_enabled() and x1.dtype == torch.float32:
                 torch.ops.smaat.upsample_into_(cat, x1, cat.shape[1] - x1.shape[1])
                 return self.conv(cat, **kw)
             return self.conv(ops.upsample_into(cat, x1, cat.shape[1] - x1.shape[1]), **kw)
@@ -164,6 +173,6 @@ class OutConv(nn.Module):
 
     def forward(self, x):
         import torch
-        if not torch.is_grad_enabled():
+        if not torch.is_grad_enabled() and x.dtype == torch.float32:
             return torch.ops.smaat.pointwise_infer(x, self.conv.weight, self.conv.bias)
         return ops.pointwise(x, self.conv.weight, self.conv.bias)

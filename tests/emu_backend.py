@@ -663,6 +663,286 @@ def _emu_precip_metrics_update(self, preds, target, n, batch, factor, threshold,
 EmuLib.smaat_precip_metrics_ws_bytes = _emu_precip_metrics_ws_bytes
 EmuLib.smaat_precip_metrics_update = _emu_precip_metrics_update
 
+# ---------------------------------------------------------------------------------------------------------------------
+# mixed precision (include/smaat_hip.h "mixed precision"): every typed entry point is emulated by its f32 twin run on f32
+# copies of the typed tensors; a bf16 output is the round-to-nearest-even of the f32 result -- which is exactly what the
+# kernels do (f32 arithmetic in registers, one rounding at the store).
+# ---------------------------------------------------------------------------------------------------------------------
+def bf16_to_f32(u16):
+    return (u16.astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+
+def f32_to_bf16(x):
+    b = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    return ((b + np.uint32(0x7FFF) + ((b >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
+
+
+def tplanes(ptr, dt, n, c, p, bs):
+    """typed [n][c][p] view (batch stride bs elements): float32 or uint16 (bf16 bits)"""
+    if ptr is None or ptr == 0:
+        return None
+    if dt == 0:
+        return planes(ptr, n, c, p, bs)
+    total = (n - 1) * bs + c * p
+    flat = np.ctypeslib.as_array((ctypes.c_uint16 * int(total)).from_address(int(ptr)))
+    return np.lib.stride_tricks.as_strided(flat, shape=(n, c, p), strides=(bs * 2, p * 2, 2))
+
+
+class _TIn:
+    """f32 copy of a typed input tensor, dense [n][c][p]"""
+
+    def __init__(self, ptr, dt, n, c, p, bs):
+        v = tplanes(ptr, dt, n, c, p, bs)
+        self.a = None if v is None else np.ascontiguousarray(bf16_to_f32(np.array(v)) if dt else np.array(v), np.float32)
+        self.ptr = None if v is None else self.a.ctypes.data
+        self.bs = c * p
+
+
+class _TOut:
+    """f32 staging buffer of a typed output tensor; commit() stores it (rounded when the tensor is bf16).  rmw: the
+    buffer starts with the tensor's current contents (read-modify-write kernels)"""
+
+    def __init__(self, ptr, dt, n, c, p, bs, rmw=False):
+        self.view = tplanes(ptr, dt, n, c, p, bs)
+        self.dt = dt
+        if self.view is None:
+            self.a, self.ptr = None, None
+        else:
+            self.a = np.zeros((n, c, p), np.float32)
+            if rmw:
+                self.a[:] = bf16_to_f32(np.array(self.view)) if dt else self.view
+            self.ptr = self.a.ctypes.data
+        self.bs = c * p
+
+    def commit(self):
+        if self.view is not None:
+            self.view[:] = f32_to_bf16(self.a).reshape(self.a.shape) if self.dt else self.a
+
+
+def _t_bf16_planes(self, w, R, C, out, transposed, stream):
+    wv = f32(w, R * C).reshape((C, R) if transposed else (R, C))
+    wv = wv.T if transposed else wv
+    Cp = (C + 31) // 32 * 32
+    full = np.zeros((R, Cp), np.float32)
+    full[:, :C] = wv
+    o = np.ctypeslib.as_array((ctypes.c_uint16 * (R * Cp)).from_address(int(out))).reshape(Cp // 16, R, 16)
+    o[:] = f32_to_bf16(full).reshape(R, Cp // 16, 16).transpose(1, 0, 2)
+    return 0
+
+
+def _t_pointwise_fwd_bf16(self, x, x_bs, pl, bias, out, out_bs, out_dt, part, N, Cin, M, H, W, relu_out, stream):
+    P = H * W
+    if P % 2:
+        return -2
+    Cp = (Cin + 31) // 32 * 32
+    u = np.ctypeslib.as_array((ctypes.c_uint16 * (M * Cp)).from_address(int(pl))).reshape(Cp // 16, M, 16)
+    a = bf16_to_f32(np.ascontiguousarray(u.transpose(1, 0, 2)).reshape(M, Cp))[:, :Cin]
+    xi = _TIn(x, 1, N, Cin, P, x_bs)
+    acc = np.einsum("mc,ncp->nmp", a.astype(np.float64), xi.a.astype(np.float64)).astype(np.float32)
+    o = _TOut(out, out_dt, N, M, P, out_bs)
+    o.a[:] = acc + (f32(bias, M)[None, :, None] if bias else 0)
+    if relu_out:
+        o.a[:] = np.maximum(o.a, 0)
+    o.commit()
+    self._write_part(part, PW_SLOTS + 1, M, acc)
+    return 0
+
+
+def _t_pointwise_wgrad_bf16(self, y, y_bs, dz, dz_bs, ws, dw_out, N, Cin, M, H, W, stream):
+    P = H * W
+    if P % 2:
+        return -2
+    yi, di = _TIn(y, 1, N, Cin, P, y_bs), _TIn(dz, 1, N, M, P, dz_bs)
+    f32(dw_out, M * Cin).reshape(M, Cin)[:] = np.einsum("nmp,nkp->mk", di.a.astype(np.float64), yi.a.astype(np.float64))
+    return 0
+
+
+def _t_dw3x3_fwd(self, x, x_dt, x_bs, in_scale, in_shift, w_dw, b_dw, y, y_dt, y_bs, N, Cin, kpl, H, W, stream):
+    if (x_dt, y_dt) not in ((0, 0), (0, 1), (1, 1)):
+        return -2
+    xi = _TIn(x, x_dt, N, Cin, H * W, x_bs)
+    o = _TOut(y, y_dt, N, Cin * kpl, H * W, y_bs)
+    rc = self.smaat_dw3x3_fwd(xi.ptr, xi.bs, in_scale, in_shift, w_dw, b_dw, o.ptr, o.bs, N, Cin, kpl, H, W, stream)
+    if rc == 0:
+        o.commit()
+    return rc
+
+
+def _t_dw3x3_bwd(self, x, x_dt, x_bs, in_scale, in_shift, dy, dy_dt, dy_bs, w_dw, dx, dx_dt, dx_bs, ws, dw_out, db_out, bn_mean,
+                 bn_invstd, rpart, N, Cin, kpl, H, W, stream):
+    if (x_dt, dy_dt, dx_dt) not in ((0, 0, 0), (1, 1, 1), (0, 1, 0)):
+        return -2
+    P, K = H * W, Cin * kpl
+    xi, gi = _TIn(x, x_dt, N, Cin, P, x_bs), _TIn(dy, dy_dt, N, K, P, dy_bs)
+    o = _TOut(dx, dx_dt, N, Cin, P, dx_bs)
+    if rpart:
+        if not (kpl <= 2 and W % 4 == 0 and H >= 4):
+            return -2
+        rc = self.smaat_dw3x3_bwd_bnred(xi.ptr, xi.bs, in_scale, in_shift, gi.ptr, gi.bs, w_dw, o.ptr, o.bs, ws, dw_out, db_out,
+                                        bn_mean, bn_invstd, rpart, N, Cin, kpl, H, W, stream)
+        if rc == 0 and dx_dt:  # the reduction is taken over dX as stored
+            o.a[:] = bf16_to_f32(f32_to_bf16(o.a)).reshape(o.a.shape)
+            sc, sh = f32(in_scale, Cin), f32(in_shift, Cin)
+            act = np.maximum(xi.a * sc[None, :, None] + sh[None, :, None], 0)
+            g = o.a.astype(np.float64) * (act > 0)
+            zhat = (xi.a.astype(np.float64) - f32(bn_mean, Cin)[None, :, None]) * f32(bn_invstd, Cin)[None, :, None].astype(np.float64)
+            rp = f32(rpart, 2 * N * Cin).reshape(2, N, Cin)
+            rp[:] = 0
+            rp[0, N - 1] = g.sum(axis=(0, 2))
+            rp[1, N - 1] = (g * zhat).sum(axis=(0, 2))
+    else:
+        if in_scale:
+            if not (kpl <= 2 and W % 4 == 0):
+                return -2
+            sc, sh = f32(in_scale, Cin), f32(in_shift, Cin)
+            xi.a[:] = np.maximum(xi.a * sc[None, :, None] + sh[None, :, None], 0)
+        rc = self.smaat_dw3x3_bwd(xi.ptr, xi.bs, gi.ptr, gi.bs, w_dw, o.ptr, o.bs, ws, dw_out, db_out, N, Cin, kpl, H, W, stream)
+    if rc == 0:
+        o.commit()
+    return rc
+
+
+def _t_affine_act(self, z, z_dt, z_bs, scale, shift, y, y_dt, y_bs, N, C, P, relu, stream):
+    zi, o = _TIn(z, z_dt, N, C, P, z_bs), _TOut(y, y_dt, N, C, P, y_bs)
+    rc = self.smaat_affine_act(zi.ptr, zi.bs, scale, shift, o.ptr, o.bs, N, C, P, relu, stream)
+    o.commit()
+    return rc
+
+
+def _t_bn_bwd_reduce(self, dy, dy_dt, dy_bs, z, z_dt, z_bs, scale, shift, mean, invstd, part, N, C, P, relu, head_w, stream):
+    zi = _TIn(z, z_dt, N, C, P, z_bs)
+    if head_w:
+        gi = _TIn(dy, dy_dt, N, 1, P, dy_bs)
+        return self.smaat_bn_bwd_reduce_head(gi.ptr, gi.bs, head_w, zi.ptr, zi.bs, scale, shift, mean, invstd, part, N, C, P, stream)
+    gi = _TIn(dy, dy_dt, N, C, P, dy_bs)
+    return self.smaat_bn_bwd_reduce(gi.ptr, gi.bs, zi.ptr, zi.bs, scale, shift, mean, invstd, part, N, C, P, relu, stream)
+
+
+def _t_bn_bwd_apply(self, dy, dy_dt, dy_bs, z, z_dt, z_bs, scale, shift, mean, invstd, coef, dz, dz_dt, dz_bs, N, C, P, relu,
+                    head_w, stream):
+    zi, o = _TIn(z, z_dt, N, C, P, z_bs), _TOut(dz, dz_dt, N, C, P, dz_bs)
+    if head_w:
+        gi = _TIn(dy, dy_dt, N, 1, P, dy_bs)
+        rc = self.smaat_bn_bwd_apply_head(gi.ptr, gi.bs, head_w, zi.ptr, zi.bs, scale, shift, mean, invstd, coef, o.ptr, o.bs, N,
+                                          C, P, stream)
+    else:
+        gi = _TIn(dy, dy_dt, N, C, P, dy_bs)
+        rc = self.smaat_bn_bwd_apply(gi.ptr, gi.bs, zi.ptr, zi.bs, scale, shift, mean, invstd, coef, o.ptr, o.bs, N, C, P, relu,
+                                     stream)
+    o.commit()
+    return rc
+
+
+def _t_outconv1_fwd(self, z, z_dt, z_bs, scale, shift, w, b, out, out_bs, N, C, P, stream):
+    zi = _TIn(z, z_dt, N, C, P, z_bs)
+    return self.smaat_outconv1_fwd(zi.ptr, zi.bs, scale, shift, w, b, out, out_bs, N, C, P, stream)
+
+
+def _t_channel_sum(self, x, x_dt, x_bs, N, C, P, ws, out, stream):
+    xi = _TIn(x, x_dt, N, C, P, x_bs)
+    return self.smaat_channel_sum(xi.ptr, xi.bs, N, C, P, ws, out, stream)
+
+
+def _t_maxpool2_fwd(self, x, x_bs, y, y_bs, N, C, H, W, dt, stream):
+    xi, o = _TIn(x, dt, N, C, H * W, x_bs), _TOut(y, dt, N, C, (H // 2) * (W // 2), y_bs)
+    rc = self.smaat_maxpool2_fwd(xi.ptr, xi.bs, o.ptr, o.bs, N, C, H, W, stream)
+    o.commit()
+    return rc
+
+
+def _t_maxpool2_bwd(self, x, x_bs, dy, dy_bs, dx, dx_bs, N, C, H, W, accum, dt, stream):
+    xi, gi = _TIn(x, dt, N, C, H * W, x_bs), _TIn(dy, dt, N, C, (H // 2) * (W // 2), dy_bs)
+    o = _TOut(dx, dt, N, C, H * W, dx_bs, rmw=bool(accum))
+    rc = self.smaat_maxpool2_bwd(xi.ptr, xi.bs, gi.ptr, gi.bs, o.ptr, o.bs, N, C, H, W, accum, stream)
+    o.commit()
+    return rc
+
+
+def _t_upsample2x_fwd(self, x, x_bs, out, out_bs, N, C, H, W, Ho, Wo, pad_t, pad_l, dt, stream):
+    if dt and Wo % 4:
+        return -2
+    xi, o = _TIn(x, dt, N, C, H * W, x_bs), _TOut(out, dt, N, C, Ho * Wo, out_bs)
+    rc = self.smaat_upsample2x_fwd(xi.ptr, xi.bs, o.ptr, o.bs, N, C, H, W, Ho, Wo, pad_t, pad_l, stream)
+    o.commit()
+    return rc
+
+
+def _t_upsample2x_bwd(self, dout, dout_bs, dx, dx_bs, N, C, H, W, Ho, Wo, pad_t, pad_l, dt, stream):
+    if dt and (W % 2 or Wo % 4 or pad_l % 4):
+        return -2
+    gi, o = _TIn(dout, dt, N, C, Ho * Wo, dout_bs), _TOut(dx, dt, N, C, H * W, dx_bs)
+    rc = self.smaat_upsample2x_bwd(gi.ptr, gi.bs, o.ptr, o.bs, N, C, H, W, Ho, Wo, pad_t, pad_l, stream)
+    o.commit()
+    return rc
+
+
+def _t_cbam_chpool(self, x, x_bs, scale, shift, y, y_bs, N, C, P, avg, mx, amax, dt, stream):
+    xi = _TIn(x, dt, N, C, P, x_bs)
+    if scale:
+        o = _TOut(y, dt, N, C, P, y_bs)
+        self.smaat_affine_act(xi.ptr, xi.bs, scale, shift, o.ptr, o.bs, N, C, P, 1, stream)
+        o.commit()
+        yi = _TIn(y, dt, N, C, P, y_bs)  # pools over the values as stored
+        return self.smaat_cbam_chpool(yi.ptr, yi.bs, N, C, P, avg, mx, amax, stream)
+    return self.smaat_cbam_chpool(xi.ptr, xi.bs, N, C, P, avg, mx, amax, stream)
+
+
+def _t_cbam_sppool(self, x, x_bs, s, N, C, P, maps, dt, stream):
+    xi = _TIn(x, dt, N, C, P, x_bs)
+    return self.smaat_cbam_sppool(xi.ptr, xi.bs, s, N, C, P, maps, stream)
+
+
+def _t_cbam_apply(self, x, x_bs, s, gate, out, out_bs, N, C, P, dt, stream):
+    xi, o = _TIn(x, dt, N, C, P, x_bs), _TOut(out, dt, N, C, P, out_bs)
+    rc = self.smaat_cbam_apply(xi.ptr, xi.bs, s, gate, o.ptr, o.bs, N, C, P, stream)
+    o.commit()
+    return rc
+
+
+def _t_cbam_bwd_gate(self, dout, dout_bs, x, x_bs, s, gate, conv, mean, invstd, N, C, P, dbn, part, dt, stream):
+    gi, xi = _TIn(dout, dt, N, C, P, dout_bs), _TIn(x, dt, N, C, P, x_bs)
+    return self.smaat_cbam_bwd_gate(gi.ptr, gi.bs, xi.ptr, xi.bs, s, gate, conv, mean, invstd, N, C, P, dbn, part, stream)
+
+
+def _t_cbam_bwd_main(self, dout, dout_bs, x, x_bs, s, gate, maps, dmaps, N, C, P, dx, dx_bs, dspart, dt, stream):
+    gi, xi = _TIn(dout, dt, N, C, P, dout_bs), _TIn(x, dt, N, C, P, x_bs)
+    o = _TOut(dx, dt, N, C, P, dx_bs)
+    rc = self.smaat_cbam_bwd_main(gi.ptr, gi.bs, xi.ptr, xi.bs, s, gate, maps, dmaps, N, C, P, o.ptr, o.bs, dspart, stream)
+    o.commit()
+    return rc
+
+
+def _t_cbam_bwd_final(self, dx, dx_bs, davg, dmx, amax, N, C, P, dt, stream):
+    o = _TOut(dx, dt, N, C, P, dx_bs, rmw=True)
+    rc = self.smaat_cbam_bwd_final(o.ptr, o.bs, davg, dmx, amax, N, C, P, stream)
+    o.commit()
+    return rc
+
+
+def _t_cbam_bwd_final_pool(self, dx, dx_bs, davg, dmx, amax, x, x_bs, dpool, dp_bs, N, C, H, W, dt, stream):
+    if W % 4 or H < 2:
+        return -2
+    o = _TOut(dx, dt, N, C, H * W, dx_bs, rmw=True)
+    xi, pi = _TIn(x, dt, N, C, H * W, x_bs), _TIn(dpool, dt, N, C, (H // 2) * (W // 2), dp_bs)
+    rc = self.smaat_cbam_bwd_final_pool(o.ptr, o.bs, davg, dmx, amax, xi.ptr, xi.bs, pi.ptr, pi.bs, N, C, H, W, stream)
+    if rc == 0:
+        o.commit()
+    return rc
+
+
+for _name, _fn in (("smaat_bf16_planes", _t_bf16_planes), ("smaat_pointwise_fwd_bf16", _t_pointwise_fwd_bf16),
+                   ("smaat_pointwise_wgrad_bf16", _t_pointwise_wgrad_bf16), ("smaat_dw3x3_fwd_t", _t_dw3x3_fwd),
+                   ("smaat_dw3x3_bwd_t", _t_dw3x3_bwd), ("smaat_affine_act_t", _t_affine_act),
+                   ("smaat_bn_bwd_reduce_t", _t_bn_bwd_reduce), ("smaat_bn_bwd_apply_t", _t_bn_bwd_apply),
+                   ("smaat_outconv1_fwd_t", _t_outconv1_fwd), ("smaat_channel_sum_t", _t_channel_sum),
+                   ("smaat_maxpool2_fwd_t", _t_maxpool2_fwd), ("smaat_maxpool2_bwd_t", _t_maxpool2_bwd),
+                   ("smaat_upsample2x_fwd_t", _t_upsample2x_fwd), ("smaat_upsample2x_bwd_t", _t_upsample2x_bwd),
+                   ("smaat_cbam_chpool_t", _t_cbam_chpool), ("smaat_cbam_sppool_t", _t_cbam_sppool),
+                   ("smaat_cbam_apply_t", _t_cbam_apply), ("smaat_cbam_bwd_gate_t", _t_cbam_bwd_gate),
+                   ("smaat_cbam_bwd_main_t", _t_cbam_bwd_main), ("smaat_cbam_bwd_final_t", _t_cbam_bwd_final),
+                   ("smaat_cbam_bwd_final_pool_t", _t_cbam_bwd_final_pool)):
+    setattr(EmuLib, _name, _fn)
+
 
 def install():
     """Swap the emulation in for libsmaat_hip.so (CPU tests only)."""

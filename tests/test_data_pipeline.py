@@ -88,3 +88,42 @@ def test_prefetch_loader_feeds_the_model_on_gpu(tmp_path):
         assert torch.equal(out, ref)
         k += 1
     assert k == 6
+
+
+@pytest.mark.parametrize("workers", [1, 3])
+def test_prefetch_loader_propagates_worker_errors(workers):
+    """an exception in the gather threads / the transform must surface in the consuming loop (torch's DataLoader
+    re-raises worker errors); round-2 behaviour was a silently truncated epoch (workers=1) or stale pinned-buffer
+    contents delivered as a batch (workers>1)"""
+    a = _array(s=12)
+
+    def bad(imgs):
+        if imgs[0, 0, 0] >= 6 * 6 * 64:  # samples 6 and up
+            raise ValueError("corrupt sample")
+        return imgs
+
+    src = NpySampleSource(a, 4, transform=bad)
+    ld = PrefetchLoader(src, 6, device="cpu", depth=2, workers=workers, shuffle=False)
+    got = 0
+    with pytest.raises(RuntimeError, match="corrupt sample"):
+        for _x, _y in ld:
+            got += 1
+    assert got == 1  # the first batch (samples 0..5) is fine, the second never arrives
+
+
+def test_prefetch_loader_rank_sharding_and_close():
+    a = _array(s=13)
+    src = NpySampleSource(a, 4)
+    seen = []
+    for r in range(2):
+        ld = PrefetchLoader(src, 3, device="cpu", shuffle=True, seed=7, rank=r, world_size=2)
+        assert len(ld) == 2
+        ids = [int(x[b, 0, 0, 0].item()) // (6 * 64) for x, _ in ld for b in range(x.shape[0])]
+        assert len(ids) == 6
+        seen.append(ids)
+    assert not set(seen[0]) & set(seen[1])  # disjoint shards of one permutation
+    ld.close()
+    with pytest.raises(RuntimeError, match="close"):
+        next(iter(ld))
+    with pytest.raises(ValueError):
+        PrefetchLoader(src, 3, device="cpu", rank=2, world_size=2)

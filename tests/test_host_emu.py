@@ -409,3 +409,84 @@ def test_argument_validation_at_the_operator_boundary():
     bad.double_conv[4] = torch.nn.BatchNorm2d(8)
     with pytest.raises(ValueError, match="double_conv.3/4"):
         bad(x)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# mixed precision (bf16 activation storage): the host wiring -- dtype plumbing through every autograd node, buffer
+# element sizes, the typed entry points chosen -- against the f32 run of the same network.  bf16 keeps 8 significant
+# bits: a network output within a few per cent of the f32 one and finite, well-correlated gradients are what the mode
+# promises (the GPU suite pins the kernels themselves bit for bit, tests/test_gpu_bf16.py).
+# ---------------------------------------------------------------------------------------------------------------------
+def _bf16_vs_f32(make_model, x, target_fn, setter):
+    torch.manual_seed(0)
+    m = make_model()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    res = []
+    for mode in ("f32", "bf16"):
+        m.load_state_dict(sd)
+        m.train()
+        m.zero_grad(set_to_none=True)
+        setter(m, mode)
+        out = m(x)
+        assert out.dtype == torch.float32
+        loss = target_fn(out)
+        loss.backward()
+        res.append((out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                    {k: v.clone() for k, v in m.state_dict().items() if "running" in k}))
+    (o0, g0, r0), (o1, g1, r1) = res
+    # stock torch.autocast(bfloat16) around the REFERENCE modules moves the logits of this random-init network by 0.16
+    # (rel-L2, measured with /root/reference on CPU): pre-BatchNorm tensors with |mean| >> std
+    # lose bits when stored in 8 significant bits, and the tiny batch statistics of the deep levels amplify it
+    e_out = rel(o1.numpy(), o0.numpy())
+    assert e_out < 0.25, e_out
+    for k in r0:
+        assert rel(r1[k].numpy(), r0[k].numpy()) < 5e-2, k
+    flat0 = torch.cat([g.flatten() for g in g0.values()])
+    flat1 = torch.cat([g1[k].flatten() for k in g0])
+    assert bool(torch.isfinite(flat1).all())
+    cos = float((flat0 * flat1).sum() / (flat0.norm() * flat1.norm()))
+    print(f"bf16 vs f32: logits rel-L2 {e_out:.3f}, flat-gradient cosine {cos:.4f}")
+    # (stock autocast on the reference, same network / input / loss: cosine 0.816, flat-gradient rel-L2 0.61 -- the early
+    # layers' gradients pass through ~40 bf16 roundings and 23 tiny-batch BatchNorm backward passes)
+    assert cos > 0.7, cos
+    return g0, g1
+
+
+def test_bf16_mixed_precision_smaat_unet():
+    x = torch.from_numpy(O_precip(2, 12, 64, 64))
+    y = torch.rand(2, 64, 64) * 0.3
+
+    def loss(out):
+        return torch.nn.functional.mse_loss(out.squeeze(1), y, reduction="sum") / 2
+
+    g0, g1 = _bf16_vs_f32(lambda: S.SmaAt_UNet(12, 1), x, loss, lambda m, mode: m.set_precision(mode))
+    k = "outc.conv.weight"
+    assert rel(g1[k].numpy(), g0[k].numpy()) < 0.3
+
+
+def test_bf16_mixed_precision_voc_head_and_context_manager():
+    """21-class head (OutConv as its own GEMM: bf16 in, f32 logits), precision chosen by the context manager instead of
+    the module attribute, kernels_per_layer = 1 sibling without attention"""
+    torch.manual_seed(1)
+    x = torch.randn(2, 3, 32, 32)
+    t = torch.randint(0, 21, (2, 32, 32))
+
+    class Wrap(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.net = S.SmaAt_UNet(3, 21)
+            self.mode = "f32"
+
+        def forward(self, inp):
+            with S.precision(self.mode):
+                return self.net(inp)
+
+    def setter(m, mode):
+        m.mode = mode
+
+    _bf16_vs_f32(Wrap, x, lambda out: torch.nn.functional.cross_entropy(out, t), setter)
+
+
+def O_precip(n, c, h, w):
+    from oracle import smaat_oracle as O
+    return O.synthetic_precip(n, c, h, w, seed=3)[0]
