@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from smaat_unet_amd import _lib  # noqa: E402
 
 SHAPES = [(12, 288), (64, 288), (128, 288), (64, 144), (128, 144), (256, 144), (128, 72), (256, 72), (512, 72),
-          (256, 36), (512, 36), (1024, 36)]
+          (256, 36), (512, 36), (1024, 36), (512, 18)]
 
 
 def timeit(fn, iters=10):

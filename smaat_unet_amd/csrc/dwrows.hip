@@ -82,19 +82,25 @@ struct DwrLane {
     bool part;      // the two-column last group of a row (W % 4 == 2)
     int lo;         // element offset of the group's 4-element access: -2 for a partial group, else 0
 };
-__device__ __forceinline__ DwrLane dwr_lane(int lane, int q, int ncol4, int W) {
+// PART (template parameter of the kernels): W % 4 == 2.  The W % 4 == 0 instantiations contain none of the partial-group
+// selects and no branch around their stores (a divergent store makes hipcc drain the loads in flight with vmcnt(0): the
+// forward kernel lost a third of its bandwidth to that when the distinction was a run-time flag).
+template <bool PART>
+__device__ __forceinline__ DwrLane dwr_lane(int lane, int q, int ncol4) {
     DwrLane ln;
     ln.l0 = lane == 0;
     ln.l63 = lane == 63;
     ln.lok = q > 0;
     ln.rok = q < ncol4 - 1;
-    ln.part = (W & 3) != 0 && q == ncol4 - 1;
-    ln.lo = ln.part ? -2 : 0;
+    ln.part = PART && q == ncol4 - 1;
+    ln.lo = (PART && ln.part) ? -2 : 0;
     ln.eo = (ln.l0 && ln.lok) ? -1 : ((ln.l63 && ln.rok) ? 4 : 0);
     return ln;
 }
 // the four values of a group from its (possibly shifted) access: partial group -> (v.z, v.w, 0, 0)
+template <bool PART>
 __device__ __forceinline__ float4 dwr_group(const float4 v, const DwrLane& ln) {
+    if (!PART) return v;
     return ln.part ? make_float4(v.z, v.w, 0.f, 0.f) : v;
 }
 // T = element type of the streamed tensor (float or bf16_t, common.h "element types"): a row is ONE 16- or 8-byte load
@@ -120,9 +126,9 @@ __device__ __forceinline__ typename Elem<T>::raw4 dwr_issue4(const T* __restrict
     return ldraw4(p + (long)rc * W + ln.lo);
 }
 // store the group's values of one row (two of them for a partial group)
-template <typename T>
+template <bool PART, typename T>
 __device__ __forceinline__ void dwr_store(T* p, const float4 v, const DwrLane& ln) {
-    if (ln.part)
+    if (PART && ln.part)
         st2(p, v.x, v.y);
     else
         st4(p, v);
@@ -136,11 +142,11 @@ __device__ __forceinline__ void dwr_pin(DwrRaw<float>& v) {
 }
 __device__ __forceinline__ void dwr_pin(DwrRaw<bf16_t>& v) { asm volatile("" : "+v"(v.m.x), "+v"(v.m.y), "+v"(v.e)); }
 // raw row -> window row: edge exchange, activation (previous BatchNorm + ReLU) on load, zero padding
-template <typename T>
+template <bool PART, typename T>
 __device__ __forceinline__ void dwr_finish(float (&w)[6], const DwrRaw<T>& vr, int r, int H, const DwrLane& ln, bool aff,
                                            float sc, float sh) {
     const bool rv = r >= 0 && r < H;
-    const float4 m = dwr_group(cvt4(vr.m), ln);
+    const float4 m = dwr_group<PART>(cvt4(vr.m), ln);
     const float e = cvt1(vr.e);
     float l = dpp_src<0x138, 0xF>(m.w);   // wave_shr:1  (lane i <- lane i - 1)
     float rr = dpp_src<0x130, 0xF>(m.x);  // wave_shl:1  (lane i <- lane i + 1)
@@ -149,8 +155,9 @@ __device__ __forceinline__ void dwr_finish(float (&w)[6], const DwrRaw<T>& vr, i
     w[0] = (rv && ln.lok) ? dwr_act(l, aff, sc, sh) : 0.f;
     w[1] = rv ? dwr_act(m.x, aff, sc, sh) : 0.f;
     w[2] = rv ? dwr_act(m.y, aff, sc, sh) : 0.f;
-    w[3] = (rv && !ln.part) ? dwr_act(m.z, aff, sc, sh) : 0.f;  // (zero padding right of the plane: after the activation)
-    w[4] = (rv && !ln.part) ? dwr_act(m.w, aff, sc, sh) : 0.f;
+    const bool rv2 = PART ? (rv && !ln.part) : rv;  // (zero padding right of the plane: after the activation)
+    w[3] = rv2 ? dwr_act(m.z, aff, sc, sh) : 0.f;
+    w[4] = rv2 ? dwr_act(m.w, aff, sc, sh) : 0.f;
     w[5] = (rv && ln.rok) ? dwr_act(rr, aff, sc, sh) : 0.f;
 }
 
@@ -158,7 +165,7 @@ __device__ __forceinline__ void dwr_finish(float (&w)[6], const DwrRaw<T>& vr, i
 // forward:  y[ci*KPL + j][r][c] = b[j] + sum_{tr,tc} w[j][tr][tc] * act(x)[ci][r + tr - 1][c + tc - 1]
 // ---------------------------------------------------------------------------------------------------------------
 // TX / TY: element types of x and y (f32 | bf16 storage; the arithmetic is f32 either way)
-template <int KPL, typename TX, typename TY>
+template <int KPL, typename TX, typename TY, bool PART>
 __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const TX* __restrict__ x, long x_bs,
                                                          const float* __restrict__ w_dw,
                                                          const float* __restrict__ b_dw, TY* __restrict__ y,
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const TX* __restrict__ x
     }
     const bool aff = in_scale != nullptr;
     const float asc = aff ? in_scale[ci] : 1.f, ash = aff ? in_shift[ci] : 0.f;
-    const DwrLane ln = dwr_lane(lane, q, g.ncol4, g.W);
+    const DwrLane ln = dwr_lane<PART>(lane, q, g.ncol4);
 
     // before step r (u = (r - r0) % 3): Wn[u] = row r - 1, Wn[u + 1] = row r, raw[u] = row r + 1 and raw[u + 1] = row
     // r + 2 in flight; the step issues row r + 3 into raw[u + 2], then finishes row r + 1 into Wn[u + 2] (the slot of the
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const TX* __restrict__ x
                 for (int tc = 0; tc < 3; ++tc) acc = fmaf(wt[j][6 + tc], R2[c + tc], acc);
                 o[c] = acc;
             }
-            if (active && r < g.H) dwr_store(yp + (long)j * g.P + (long)r * g.W, make_float4(o[0], o[1], o[2], o[3]), ln);
+            if (active && r < g.H) dwr_store<PART>(yp + (long)j * g.P + (long)r * g.W, make_float4(o[0], o[1], o[2], o[3]), ln);
         }
     };
     {
@@ -217,8 +224,8 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const TX* __restrict__ x
         raw[1] = dwr_issue(xp, r0 + 2, g.H, g.W, ln);
         dwr_pin(a);
         dwr_pin(b);
-        dwr_finish(Wn[0], a, r0 - 1, g.H, ln, aff, asc, ash);
-        dwr_finish(Wn[1], b, r0, g.H, ln, aff, asc, ash);
+        dwr_finish<PART>(Wn[0], a, r0 - 1, g.H, ln, aff, asc, ash);
+        dwr_finish<PART>(Wn[1], b, r0, g.H, ln, aff, asc, ash);
     }
     for (int i = 0; i < g.BH; i += 3) {
 #pragma unroll
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const TX* __restrict__ x
                 const int r = r0 + i + u;
                 raw[(u + 2) % 3] = dwr_issue(xp, r + 3, g.H, g.W, ln);
                 dwr_pin(raw[u]);  // row r + 1 (issued two steps ago)
-                dwr_finish(Wn[(u + 2) % 3], raw[u], r + 1, g.H, ln, aff, asc, ash);
+                dwr_finish<PART>(Wn[(u + 2) % 3], raw[u], r + 1, g.H, ln, aff, asc, ash);
                 compute(r, Wn[u], Wn[(u + 1) % 3], Wn[(u + 2) % 3]);
             }
         }
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const TX* __restrict__ x
 // RP: the variant that also emits rpart keeps the raw (pre-BatchNorm) rows of the three open lines in registers: the
 // counter passes showed the re-load of the completed row as +25 % HBM fetch (it had left the L2 two steps later).
 // TX / TG / TD: element types of x (or z), dY and dX
-template <int KPL, bool RP, typename TX, typename TG, typename TD>
+template <int KPL, bool RP, typename TX, typename TG, typename TD, bool PART>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAVES, DWR_BWD_WAVES))) void k_dw3x3_bwd_rows(const TX* __restrict__ x, long x_bs,
                                                          const TG* __restrict__ dy, long dy_bs,
                                                          const float* __restrict__ w_dw, TD* __restrict__ dx,
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAV
     const bool aff = in_scale != nullptr;
     const float asc = aff ? in_scale[ci] : 1.f, ash = aff ? in_shift[ci] : 0.f;
     const float rmean = rpart ? bn_mean[ci] : 0.f, rinvstd = rpart ? bn_invstd[ci] : 0.f;
-    const DwrLane ln = dwr_lane(lane, q, g.ncol4, g.W);
+    const DwrLane ln = dwr_lane<PART>(lane, q, g.ncol4);
 
     float accw[KPL][10];
 #pragma unroll
@@ -327,14 +334,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAV
                     for (int j = 0; j < KPL; ++j) dwr_pin(raw[j]);
                     dwr_pin(xn);
 #pragma unroll
-                    for (int j = 0; j < KPL; ++j) dwr_finish(d[j], raw[j], rho, g.H, ln, false, 1.f, 0.f);
+                    for (int j = 0; j < KPL; ++j) dwr_finish<PART>(d[j], raw[j], rho, g.H, ln, false, 1.f, 0.f);
                     {  // open the slot of row rho + 1
                         const bool in = (rho + 1) >= r0 && (rho + 1) < r1;
-                        const float4 zv = dwr_group(cvt4(xn), ln);
+                        const float4 zv = dwr_group<PART>(cvt4(xn), ln);
+                        const bool in2 = PART ? (in && !ln.part) : in;  // (columns beyond the plane)
                         xc[sc_][0] = in ? dwr_act(zv.x, aff, asc, ash) : 0.f;
                         xc[sc_][1] = in ? dwr_act(zv.y, aff, asc, ash) : 0.f;
-                        xc[sc_][2] = (in && !ln.part) ? dwr_act(zv.z, aff, asc, ash) : 0.f;  // (columns beyond the plane)
-                        xc[sc_][3] = (in && !ln.part) ? dwr_act(zv.w, aff, asc, ash) : 0.f;
+                        xc[sc_][2] = in2 ? dwr_act(zv.z, aff, asc, ash) : 0.f;
+                        xc[sc_][3] = in2 ? dwr_act(zv.w, aff, asc, ash) : 0.f;
                         if (RP) {
                             zraw[sc_][0] = zv.x;
                             zraw[sc_][1] = zv.y;
@@ -368,7 +376,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAV
                     const int rd = rho - 1;
                     const bool fin = rd >= r0 && rd < r1;
                     if (dxp && fin)
-                        dwr_store(dxp + (long)rd * g.W, make_float4(dxa[sa][0], dxa[sa][1], dxa[sa][2], dxa[sa][3]), ln);
+                        dwr_store<PART>(dxp + (long)rd * g.W, make_float4(dxa[sa][0], dxa[sa][1], dxa[sa][2], dxa[sa][3]), ln);
                     if (RP) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
@@ -425,9 +433,15 @@ int launch_dw3x3_fwd_rows(const void* x, int x_dt, long x_bs, const float* w_dw,
     const DwrGeom g = dw_rows_geom(nplanes, H, W);
     if (g.wpp == 0) return -2;
     const dim3 grid((unsigned)(((long)nplanes * g.wpp + 3) / 4)), blk(256);
-#define DWF_GO(K, TX, TY)                                                                                              \
-    hipLaunchKernelGGL((k_dw3x3_fwd_rows<K, TX, TY>), grid, blk, 0, st, (const TX*)x, x_bs, w_dw, b_dw, (TY*)y, y_bs, Cin, \
-                       nplanes, g, in_scale, in_shift)
+    const bool part = (W & 3) != 0;
+#define DWF_GO1(K, TX, TY, PT)                                                                                            \
+    hipLaunchKernelGGL((k_dw3x3_fwd_rows<K, TX, TY, PT>), grid, blk, 0, st, (const TX*)x, x_bs, w_dw, b_dw, (TY*)y, y_bs,   \
+                       Cin, nplanes, g, in_scale, in_shift)
+#define DWF_GO(K, TX, TY)                  \
+    do {                                   \
+        if (part) DWF_GO1(K, TX, TY, true); \
+        else DWF_GO1(K, TX, TY, false);    \
+    } while (0)
 #define DWF_K(TX, TY)                        \
     do {                                     \
         if (kpl == 1) DWF_GO(1, TX, TY);     \
@@ -440,6 +454,7 @@ int launch_dw3x3_fwd_rows(const void* x, int x_dt, long x_bs, const float* w_dw,
     else return -2;
 #undef DWF_K
 #undef DWF_GO
+#undef DWF_GO1
     return (int)hipGetLastError();
 }
 
@@ -452,9 +467,15 @@ int launch_dw3x3_bwd_rows(const void* x, int x_dt, long x_bs, const void* dy, in
     if (g.wpp == 0) return -2;
     if (kpl != 1 && kpl != 2) return -2;
     const dim3 grid((unsigned)(((long)nplanes * g.wpp + 3) / 4)), blk(256);
-#define DWR_GO(K, R, TX, TG, TD)                                                                                       \
-    hipLaunchKernelGGL((k_dw3x3_bwd_rows<K, R, TX, TG, TD>), grid, blk, 0, st, (const TX*)x, x_bs, (const TG*)dy, dy_bs,   \
+    const bool pgrp = (W & 3) != 0;
+#define DWR_GO1(K, R, TX, TG, TD, PT)                                                                                      \
+    hipLaunchKernelGGL((k_dw3x3_bwd_rows<K, R, TX, TG, TD, PT>), grid, blk, 0, st, (const TX*)x, x_bs, (const TG*)dy, dy_bs, \
                        w_dw, (TD*)dx, dx_bs, part, Cin, nplanes, N, g, bn_mean, bn_invstd, rpart, in_scale, in_shift)
+#define DWR_GO(K, R, TX, TG, TD)                     \
+    do {                                             \
+        if (pgrp) DWR_GO1(K, R, TX, TG, TD, true);   \
+        else DWR_GO1(K, R, TX, TG, TD, false);       \
+    } while (0)
 #define DWR_K(TX, TG, TD)                                                  \
     do {                                                                   \
         if (kpl == 1) {                                                    \
@@ -469,5 +490,6 @@ int launch_dw3x3_bwd_rows(const void* x, int x_dt, long x_bs, const void* dy, in
     else return -2;
 #undef DWR_K
 #undef DWR_GO
+#undef DWR_GO1
     return (int)hipGetLastError();
 }

@@ -1181,6 +1181,8 @@ int launch_dw3x3_bwd(const void* xv, int x_dt, long x_bs, const void* dyv, int d
 int dw3x3_strip_ok(int kpl, int H, int W) {
     const char* e = getenv("SMAAT_DWB_STRIP");
     if (e && atoi(e) == 0) return 0;
+    if ((W & 3) == 2)  // the row-streaming kernels with a two-column last group (18 x 18 ...): kernels_per_layer 1, 2
+        return ((kpl == 1 || kpl == 2) && H >= 4 && dw_rows_ok(kpl, H, W)) ? 1 : 0;
     if (!(kpl == 1 || kpl == 2 || kpl == 4) || (W & 3) != 0 || H < 4) return 0;
     const DwbGeom f = strip_geom(H, W, 1), b = strip_geom(H, W, kpl);
     return (f.nrow * f.ncol4 <= 1536 && kpl * b.nrow * b.ncol4 <= 1536) ? 1 : 0;

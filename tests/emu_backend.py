@@ -260,7 +260,7 @@ class EmuLib:
         return 0
 
     def smaat_dw3x3_strip_ok(self, kpl, H, W):
-        return 1 if (kpl in (1, 2, 4) and W % 4 == 0 and H >= 4) else 0
+        return 1 if (H >= 4 and ((kpl in (1, 2, 4) and W % 4 == 0) or (kpl in (1, 2) and W % 4 == 2))) else 0
 
     def smaat_dw3x3_bwd_bnred(self, x, x_bs, in_scale, in_shift, dy, dy_bs, w_dw, dx, dx_bs, ws, dw_out, db_out,
                               bn_mean, bn_invstd, rpart, N, Cin, kpl, H, W, stream):
@@ -776,7 +776,7 @@ def _t_dw3x3_bwd(self, x, x_dt, x_bs, in_scale, in_shift, dy, dy_dt, dy_bs, w_dw
     xi, gi = _TIn(x, x_dt, N, Cin, P, x_bs), _TIn(dy, dy_dt, N, K, P, dy_bs)
     o = _TOut(dx, dx_dt, N, Cin, P, dx_bs)
     if rpart:
-        if not (kpl <= 2 and W % 4 == 0 and H >= 4):
+        if not (kpl <= 2 and W % 2 == 0 and H >= 4):
             return -2
         rc = self.smaat_dw3x3_bwd_bnred(xi.ptr, xi.bs, in_scale, in_shift, gi.ptr, gi.bs, w_dw, o.ptr, o.bs, ws, dw_out, db_out,
                                         bn_mean, bn_invstd, rpart, N, Cin, kpl, H, W, stream)
@@ -792,7 +792,7 @@ def _t_dw3x3_bwd(self, x, x_dt, x_bs, in_scale, in_shift, dy, dy_dt, dy_bs, w_dw
             rp[1, N - 1] = (g * zhat).sum(axis=(0, 2))
     else:
         if in_scale:
-            if not (kpl <= 2 and W % 4 == 0):
+            if not (kpl <= 2 and W % 2 == 0):
                 return -2
             sc, sh = f32(in_scale, Cin), f32(in_shift, Cin)
             xi.a[:] = np.maximum(xi.a * sc[None, :, None] + sh[None, :, None], 0)
