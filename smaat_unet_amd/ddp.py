@@ -3,13 +3,18 @@ identical replicas, per-replica BatchNorm statistics (stock DistributedDataParal
 is single-GPU, train_precip_lightning.py:53-55), gradients AVERAGED over ranks through `torch.distributed`
 (backend "nccl" = RCCL over xGMI on ROCm, "gloo" on CPU for the unit tests).
 
-Layout: ONE persistent flat fp32 buffer (4,033,537 elements = 16.1 MB for SmaAt_UNet(12, 1)); every `p.grad` is a
-view into it for the whole run, so there is no per-step concatenation and no copy back.  The buffer is ordered by
-REVERSE registration order (outc, up4, ... , inc): the gradients of the decoder are complete first, and the buffer is
-cut into `buckets` contiguous ranges that are all-reduced asynchronously as soon as their last gradient has been
-accumulated (post-accumulate hooks), overlapping the exchange of the decoder's gradients with the encoder's
-backward.  With xGMI's point-to-point links a ring all-reduce of 16 MB costs ~0.2 ms against a ~40 ms step, so two
-buckets are plenty; more only add launch overhead.
+Layout: ONE persistent flat fp32 buffer (4,033,537 elements = 16.1 MB for SmaAt_UNet(12, 1)), ordered by REVERSE
+registration order (outc, up4, ... , inc: the gradients of the decoder are complete first) and cut into `buckets`
+contiguous ranges, each all-reduced with one collective.  What happens per step depends on the mode:
+  * default (`overlap=False`): `zero_grad()` sets every `p.grad` to None, autograd hands over fresh gradient tensors,
+    `finish()` PACKS them into the flat buffer with one multi-tensor copy (`torch._foreach_copy_`, 16 MB), all-reduces the
+    buckets, averages, and re-points every `p.grad` at its view of the reduced buffer (no copy back: the optimizer reads
+    the views).  One 16 MB pack per step, nothing overlapped with the backward.
+  * `overlap=True`: every `p.grad` IS a view of the flat buffer for the whole run (no pack, no copy back); autograd
+    accumulates into the views and post-accumulate hooks launch a bucket's all-reduce as soon as its last gradient has
+    been accumulated, overlapping the exchange of the decoder's gradients with the encoder's backward.
+With xGMI's point-to-point links a ring all-reduce of 16 MB costs ~0.2 ms against a ~35 ms step, so two buckets are
+plenty; more only add launch overhead.  Neither mode has been timed on more than one GPU (the build box has one).
 
     ddp = FlatGradAllReduce(model)        # module or iterable of parameters
     ddp.broadcast_parameters()            # identical replicas (parameters AND buffers from rank 0)

@@ -111,15 +111,18 @@ def test_unet_vs_reference_golden(golden_dir, name, policy, monkeypatch):
     else:
         loss = (logits * tgt).sum()
     loss.backward()
-    worst = ("", 0.0)
+    # per tensor against the fp64 anchor of the reference: no worse than 3 x the reference's own fp32 error on that
+    # tensor (floor 5e-3: one ReLU flip at forward round-off level), the rule of the benchmark-size fixtures
+    # (tests/test_eval_and_big.py run_big) -- not one flat 2e-2 for every tensor
+    bad = []
     for k, p in model.named_parameters():
         if ".double_conv." in k and (k.endswith("depthwise.bias") or k.endswith("pointwise.bias")):
             continue
-        e = check_summary(g, "grad/" + k, p.grad.cpu().numpy())
-        if e > worst[1]:
-            worst = (k, e)
-    assert worst[1] < 2e-2, worst
-    assert check_summary(g, "dx", x.grad.cpu().numpy()) < 2e-2
+        e, noise = check_summary(g, "grad64/" + k, p.grad.cpu().numpy()), float(g["noise/" + k])
+        if e > max(3.0 * noise, 5e-3):
+            bad.append((k, e, noise))
+    assert not bad, sorted(bad, key=lambda t: -t[1])[:6]
+    assert check_summary(g, "dx64", x.grad.cpu().numpy()) < max(3.0 * float(g["noise/dx"]), 5e-3)
     sd = model.state_dict()
     for k in g.files:
         if k.startswith("after/"):
@@ -455,3 +458,23 @@ def test_ddp_rccl_single_rank(tmp_path):
             assert torch.equal(p.grad, g)
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_two_ranks_share_the_gpu_over_gloo():
+    """bench.py's multi-rank control flow (rank-0-only profiling legs, barriers, max-over-ranks timing, one JSON line) with
+    two ranks on the ONE GPU of the test box: SMAAT_BENCH_BACKEND=gloo lets both ranks use cuda:0 (RCCL needs one device per
+    rank).  The driver's multi-GPU runs use the same code path with backend nccl; no scaling number is claimed from this."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMAAT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+           "--size", "64", "--no-cpu-baseline", "--no-alt", "--no-latency", "--no-eager-baseline", "--no-input-pipeline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2"
+    assert rec["kernels"]  # the rank-0 per-kernel leg ran while rank 1 waited at the final barrier

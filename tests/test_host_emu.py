@@ -136,8 +136,10 @@ def test_unet(golden_dir, name, policy, monkeypatch):
     for k, p in model.named_parameters():
         if ".double_conv." in k and (k.endswith("depthwise.bias") or k.endswith("pointwise.bias")):
             continue
-        assert check_summary(g, "grad/" + k, p.grad.numpy()) < 2e-2, k
-    assert check_summary(g, "dx", x.grad.numpy()) < 2e-2
+        # against the reference's fp64 anchor, per tensor: 3 x the reference's own fp32 error on it (floor 5e-3)
+        e, noise = check_summary(g, "grad64/" + k, p.grad.numpy()), float(g["noise/" + k])
+        assert e <= max(3.0 * noise, 5e-3), (k, e, noise)
+    assert check_summary(g, "dx64", x.grad.numpy()) <= max(3.0 * float(g["noise/dx"]), 5e-3)
     sd = model.state_dict()
     for k in g.files:
         if k.startswith("after/"):
@@ -156,9 +158,11 @@ def run_variant(golden_dir, name, dev="cpu", hooked=False, report=None):
     (oracle/gen_golden.py gen_variant_strict).  These networks flip individual ReLU / max selections under any
     perturbation of the size of fp32 forward round-off, the reference included, and one flip moves a gradient
     tensor by up to `sens_global` (1e-3 .. 1e-2, recorded per fixture from eight perturbed fp64 runs of the
-    reference).  Criterion: EVERY gradient tensor within 2 x sens_global of the fp64 anchor -- no percentile, no
-    minimum over references; kernel arithmetic itself is held to 2 x the reference's own fp32
-    error by the tie-free block fixtures (tests/test_strict_blocks.py)."""
+    reference).  Criterion (round 3): EVERY gradient tensor within max(2 x noise[k], 2 x sens[k]) of
+    the fp64 anchor, both recorded PER TENSOR in the fixture -- a 1e-2 regression on a tensor whose own sensitivity is
+    1e-5 no longer hides behind the most sensitive tensor of the network; the input gradient within 2 x sens_global.
+    Kernel arithmetic itself is held to 2 x the reference's own fp32 error by the tie-free block fixtures
+    (tests/test_strict_blocks.py)."""
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     meta = json.loads(str(g["meta"]))
     if meta.get("convt"):
@@ -191,8 +195,10 @@ def run_variant(golden_dir, name, dev="cpu", hooked=False, report=None):
             continue
         ours, noise = check_summary(g, "grad64/" + k, gk), float(g["noise/" + k])
         table[k] = (ours, noise, float(g["sens/" + k]))
-        if ours > 2.0 * bound:
-            bad.append((k, ours, noise))
+        # per tensor: 2 x what the reference itself shows ON THIS TENSOR (its fp32-vs-fp64 error, and how far its fp64
+        # gradient moves under 1e-6 input perturbations) -- not 2 x the worst tensor's sensitivity for everybody
+        if ours > max(2.0 * noise, 2.0 * float(g["sens/" + k])):
+            bad.append((k, ours, noise, float(g["sens/" + k])))
     if report is not None:
         report.update(per_tensor=table, worst=max(table.items(), key=lambda kv: kv[1][0]), sens_global=bound)
     assert not bad, (bound, sorted(bad, key=lambda t: -t[1])[:6])
