@@ -373,22 +373,6 @@ int smaat_cbam_bwd_final_pool_t(void* dx, long dx_bs, const float* davg, const f
                                 long x_bs, const void* dpool, long dp_bs, int N, int C, int H, int W, int dt,
                                 void* stream);
 
-/* ================= pre-split planes: the exact-f32 matrix path of the MFMA-bound deep layers (K >= 512) =================
- * Same arithmetic and same reference call sites as the bf16-split matrix path above (six bf16 MFMAs per f32 product, f32
- * accumulation, f32-class error) -- bit-identical results --, but the operand split is done ONCE by the kernel that
- * produces a tensor instead of by the GEMM's producer waves on every read: an activation tensor is handed over as three
- * bf16 planes x = p1 + p2 + p3 (plane t at planes + t * p_ps elements, each plane laid out like the f32 tensor), the GEMM
- * stages them by LDS-DMA and has no producer waves at all (csrc/bf16gemm.hip, NT = 3).  6 bytes per element instead of 4:
- * used where the GEMM is bound by the matrix pipe, not by HBM.
- *   smaat_split_act3            stand-alone splitter: x [N][C][P] f32 -> planes (the depthwise forward and the BatchNorm
- *                               backward write planes themselves where their consumer takes them)
- *   smaat_pointwise_fwd_planes3 out[n][m][p] = sum_c A[m][c] x[n][c][p] + bias[m], x as planes, A = smaat_split_planes(...)
- *                               image; part / relu_out as smaat_pointwise_fwd_split.  -2: M <= 64 or odd H * W.
- */
-int smaat_split_act3(const float* x, long x_bs, void* planes, long p_bs, long p_ps, int N, int C, int P, void* stream);
-int smaat_pointwise_fwd_planes3(const void* xplanes, long x_bs, long x_ps, const void* wplanes, const float* bias, float* out,
-                                long out_bs, float* part, int N, int Cin, int M, int H, int W, int relu_out, void* stream);
-
 /* ---- on-device PrecipitationMetrics.update ---------------------------------------------
  * replaces metric/precipitation_metrics.py:37-95 (called every train/val/test step, models/regression_lightning.py:
  * 75,86,94): NaN check, sum (p-t)^2 / batch, sum (p*f - t*f)^2 / batch, and the 4-bin confusion counts of

@@ -106,9 +106,6 @@ SIGNATURES = {
     "smaat_cbam_bwd_main_t": [_P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P, _I, _P],
     "smaat_cbam_bwd_final_t": [_P, _L, _P, _P, _P, _I, _I, _I, _I, _P],
     "smaat_cbam_bwd_final_pool_t": [_P, _L, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P],
-    # ---- pre-split planes (exact-f32 GEMMs of the deep layers) ----
-    "smaat_split_act3": [_P, _L, _P, _L, _L, _I, _I, _I, _P],
-    "smaat_pointwise_fwd_planes3": [_P, _L, _L, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P],
     "smaat_precip_metrics_ws_bytes": [_L],
     "smaat_precip_metrics_update": [_P, _P, _L, _I, _F, _F, _I, _P, _P, _P, _P],
 }

@@ -90,53 +90,9 @@ int launch_bf16_planes(const float* w, int R, int C, bf16_t* out, int src_t, hip
 }
 
 // =====================================================================================
-// k_split3: f32 activations [N][C][P] -> the exact three-plane bf16 split x = p1 + p2 + p3 (truncation splits, the
-// expression of splitmma.hip split4), plane t at out + t * ps.  Stand-alone form of what the producing kernels of the deep
-// layers do in their epilogue; used where the producer of a tensor cannot write planes itself.
-// =====================================================================================
-__device__ __forceinline__ void split3_bits(float x, unsigned& h1, unsigned& h2, unsigned& h3) {
-    const unsigned b = __builtin_bit_cast(unsigned, x);
-    const float p1 = __builtin_bit_cast(float, b & 0xFFFF0000u);
-    const float r1 = x - p1;  // exact
-    const float p2 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u);
-    const float p3 = r1 - p2;  // exact, <= 8 significant bits
-    h1 = b >> 16;
-    h2 = __builtin_bit_cast(unsigned, p2) >> 16;
-    h3 = __builtin_bit_cast(unsigned, p3) >> 16;
-}
-// store 4 consecutive values as three planes
-__device__ __forceinline__ void st4_split3(bf16_t* p, long ps, const float4 v) {
-    unsigned a[4], b[4], c[4];
-    split3_bits(v.x, a[0], b[0], c[0]);
-    split3_bits(v.y, a[1], b[1], c[1]);
-    split3_bits(v.z, a[2], b[2], c[2]);
-    split3_bits(v.w, a[3], b[3], c[3]);
-    *(uint2*)p = make_uint2(a[0] | (a[1] << 16), a[2] | (a[3] << 16));
-    *(uint2*)(p + ps) = make_uint2(b[0] | (b[1] << 16), b[2] | (b[3] << 16));
-    *(uint2*)(p + 2 * ps) = make_uint2(c[0] | (c[1] << 16), c[2] | (c[3] << 16));
-}
-
-__global__ __launch_bounds__(256) void k_split3(const float* __restrict__ x, long x_bs, bf16_t* __restrict__ out, long o_bs,
-                                                long o_ps, long per_img4, long total4) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total4) return;
-    const long n = i / per_img4, e = (i - n * per_img4) * 4;
-    st4_split3(out + n * o_bs + e, o_ps, *(const float4*)(x + n * x_bs + e));
-}
-
-// x: [N] images of `len` contiguous floats (C * P) at stride x_bs; out planes at stride o_ps, images at o_bs
-int launch_split3(const float* x, long x_bs, bf16_t* out, long o_bs, long o_ps, int N, long len, hipStream_t st) {
-    if ((len & 3) != 0 || (x_bs & 3) != 0 || (o_bs & 3) != 0 || (o_ps & 3) != 0 || ((((uintptr_t)x) & 15) != 0) ||
-        ((((uintptr_t)out) & 7) != 0))
-        return -2;
-    const long per = len / 4, total = per * N;
-    hipLaunchKernelGGL(k_split3, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, x_bs, out, o_bs, o_ps, per, total);
-    return (int)hipGetLastError();
-}
-
-// =====================================================================================
 // k_pw_bf16
 // =====================================================================================
+#define BF_KC 32  // channels per stage
 #define BF_NST 3  // LDS stages
 
 // GW: bytes per lane of an activation LDS-DMA (16: P % 8 == 0; 4: P % 2 == 0 -- the 18 x 18 planes)
@@ -148,26 +104,14 @@ int launch_split3(const float* x, long x_bs, bf16_t* out, long o_bs, long o_ps, 
 // stores per workgroup.  Everything between the first DMA and the last store touches LDS through inline asm only (bias
 // slots included): a compiler-visible LDS access would be preceded by s_waitcnt vmcnt(0) and drain the prefetch.  The
 // BatchNorm partials (forward GEMMs only) use the shared helpers and accept that drain once per tile, after the stores.
-//
-// NT = 3: the EXACT-f32 form of the same kernel ("pre-split planes").  x and A are given as three bf16
-// planes each (x = x1 + x2 + x3 exactly, written by the kernel that produced x; A from smaat_split_planes) and a product is
-// the six terms a1 b3 + a3 b1 + a2 b2 + a1 b2 + a2 b1 + a1 b1 of k_pw_split_p, in the same order per 16-deep chunk, so the
-// two kernels agree bit for bit.  What changes is who does the work: k_pw_split_p's four producer waves split every f32
-// value of x on the fly (~8 VALU per element + ds_write_b128) and the matrix pipe idled 55 % of the time behind them; here
-// there are no producers -- the planes arrive by LDS-DMA -- and a 16-deep stage is 24 MFMAs per wave between two barriers.
-// Used for the MFMA-bound deep layers only (K >= 512): the planes are 6 bytes per element instead of 4.
-template <int WCO, int CT, int WPX, int PXT, int GW, typename TO, int NT>
-__global__ __launch_bounds__(WCO * WPX * 64, NT == 1 ? 3 : 2) void k_pw_bf16(const PwBfArgs a) {
+template <int WCO, int CT, int WPX, int PXT, int GW, typename TO>
+__global__ __launch_bounds__(WCO * WPX * 64, 3) void k_pw_bf16(const PwBfArgs a) {
     constexpr int COT = WCO * CT * 32, PT = WPX * PXT * 32, NW = WCO * WPX, NTH = NW * 64;
     static_assert(PT == 128 && NW == 4, "128-pixel tiles (256-byte LDS rows), four waves");
-    static_assert(NT == 1 || NT == 3, "one bf16 plane (mixed precision) or the exact three-plane split");
-    constexpr int BF_KC = NT == 1 ? 32 : 16;     // channels per stage
-    constexpr int NSUB = BF_KC / 16;
-    constexpr int XPL = BF_KC * PT * 2;          // bytes of one X plane of a stage: [KC][PT] bf16
-    constexpr int APL = NSUB * COT * 32;         // bytes of one A plane of a stage: [KC/16][COT][16] bf16
-    constexpr int XB = NT * XPL, AB = NT * APL;
+    constexpr int XB = BF_KC * PT * 2;          // X stage: [KC][PT] bf16
+    constexpr int AB = (BF_KC / 16) * COT * 32;  // A stage: [KC/16][COT][16] bf16
     constexpr int STG = XB + AB;
-    constexpr int NXP = GW == 16 ? XB / 1024 : NT * BF_KC;  // X pieces (one wave-instruction each) per stage
+    constexpr int NXP = GW == 16 ? XB / 1024 : BF_KC;  // X pieces (one wave-instruction each) per stage
     constexpr int NAP = AB / 1024;
     static_assert(NXP % NW == 0 && NAP % NW == 0, "pieces divide evenly among the waves");
     constexpr int XPW = NXP / NW, APW = NAP / NW, PPW = XPW + APW;
@@ -202,6 +146,7 @@ __global__ __launch_bounds__(WCO * WPX * 64, NT == 1 ? 3 : 2) void k_pw_bf16(con
     const int xr = lane >> 4;                                    // GW 16: row within a 4-row piece
     const int xc16 = (lane & 15) ^ (4 * (xr & 3));               // GW 16: source chunk of LDS chunk (lane & 15)
     const int xc4 = (lane >> 2) ^ (4 * (wv & 3));                // GW 4: piece q = wv + NW * u is row q; q & 3 == wv & 3
+    const unsigned xrow0 = GW == 16 ? (unsigned)(4 * wv + xr) : (unsigned)wv;
     const int arow = lane >> 1, ah = (lane & 1) ^ ((lane >> 4) & 1);
     auto pf_setup = [&]() __attribute__((always_inline)) {
         const int it = pf_item < nitems ? pf_item : nitems - 1;  // surplus issues re-load the last item into a dead stage
@@ -214,39 +159,30 @@ __global__ __launch_bounds__(WCO * WPX * 64, NT == 1 ? 3 : 2) void k_pw_bf16(con
         pf_xcol = (unsigned)(px < a.P ? px : 0) * 2u;
         pf_co0 = cot * COT;
     };
-    // piece u (0 .. PPW - 1) of this wave for the chunk at the cursor: X pieces first, then A pieces
-    auto issue_piece = [&](int u, int stage) __attribute__((always_inline)) {
+    auto issue = [&](int stage) __attribute__((always_inline)) {
         const int k0 = pf_ch * BF_KC;
         unsigned char* sb = lds + stage * STG;
-        if (u < XPW) {
-            const int q = wv + NW * u;  // piece q of the stage: plane q / PPP, then rows (GW 16: four per piece)
-            constexpr int PPP = GW == 16 ? XPL / 1024 : BF_KC;  // pieces per plane (a multiple of NW, or NW a multiple of it)
-            const int t = q / PPP, qq = q - t * PPP;
-            int row = k0 + (GW == 16 ? 4 * qq + xr : qq);
+#pragma unroll
+        for (int u = 0; u < XPW; ++u) {
+            const int q = wv + NW * u;
+            int row = k0 + (GW == 16 ? (int)xrow0 + 16 * u : q);
             row = row < a.Cin ? row : a.Cin - 1;  // (the weight image is zero there)
-            glds<GW>(pf_x + (long)t * a.x_ps * 2 + (unsigned)row * rowbytes + pf_xcol, sb + q * (GW == 16 ? 1024 : 256));
-        } else {
-            const int q = wv + NW * (u - XPW);
-            constexpr int PA = APL / 1024;  // pieces per plane
-            const int t = q / PA, rem = q - t * PA;
-            const int j = rem / (COT / 32), rb = rem - j * (COT / 32);
+            glds<GW>(pf_x + (unsigned)row * rowbytes + pf_xcol, sb + q * (GW == 16 ? 1024 : 256));
+        }
+#pragma unroll
+        for (int u = 0; u < APW; ++u) {
+            const int q = wv + NW * u;
+            const int j = q / (COT / 32), rb = q - j * (COT / 32);
             int m = pf_co0 + rb * 32 + arow;
             m = m < a.M ? m : a.M - 1;
-            const bf16_t* src = a.planes + ((long)(((k0 >> 4) + j) * NT + t) * a.M + m) * 16 + ah * 8;
-            glds<16>(src, sb + XB + q * 1024);
+            const bf16_t* src = a.planes + ((long)((k0 >> 4) + j) * a.M + m) * 16 + ah * 8;
+            glds<16>(src, sb + XB + (j * COT + rb * 32) * 32);
         }
-    };
-    auto issue_advance = [&]() __attribute__((always_inline)) {
         if (++pf_ch == nchunks) {
             pf_ch = 0;
             ++pf_item;
             pf_setup();
         }
-    };
-    auto issue = [&](int stage) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < PPW; ++u) issue_piece(u, stage);
-        issue_advance();
     };
 
     // ---- fragment addresses -------------------------------------------------------------------------------------------
@@ -267,76 +203,17 @@ __global__ __launch_bounds__(WCO * WPX * 64, NT == 1 ? 3 : 2) void k_pw_bf16(con
     // bias slot addresses: the pair (col, col + 1) of register pair (r, r + 1), r even
     const unsigned bias_rd = lds0 + (unsigned)(BIAS_OFF + (wco * CT * 32 + 4 * half) * 4);
 
-    // ---- fragment reads of one stage (asm: not tracked by the compiler's waitcnt insertion) and the wait that ends them
-    auto read_frags = [&](bf16x8 (&af)[NT][NSUB][CT], s16x4 (&bq)[NT][NSUB][PXT][2], int stg) __attribute__((always_inline)) {
-        const unsigned sbase = (unsigned)(stg * STG);
-        static_for<NT * NSUB>([&](auto tc) {
-            constexpr int t = decltype(tc)::value / NSUB, j = decltype(tc)::value % NSUB;
-            static_for<CT>([&](auto cc) {
-                constexpr int ct = decltype(cc)::value;
-                af[t][j][ct] = lds_rd128<t * APL + (j * COT + ct * 32) * 32>(sbase + a_addr);
-            });
-            static_for<PXT>([&](auto pc) {
-                constexpr int pt = decltype(pc)::value;
-                bq[t][j][pt][0] = lds_rd_tr<t * XPL + j * 16 * 256>(sbase + b_addr[pt]);
-                bq[t][j][pt][1] = lds_rd_tr<t * XPL + j * 16 * 256 + 4 * 256>(sbase + b_addr[pt]);
-            });
-        });
-    };
-    auto wait_frags = [&](bf16x8 (&af)[NT][NSUB][CT], s16x4 (&bq)[NT][NSUB][PXT][2]) __attribute__((always_inline)) {
-        if constexpr (NT == 3) {
-            static_assert(NT == 1 || (CT == 2 && PXT == 2 && NSUB == 1), "three-plane form: 128 x 128 tiles, 16-deep stages");
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(af[0][0][0]), "+v"(af[0][0][1]), "+v"(af[1][0][0]), "+v"(af[1][0][1]), "+v"(af[2][0][0]),
-                           "+v"(af[2][0][1]), "+v"(bq[0][0][0][0]), "+v"(bq[0][0][0][1]), "+v"(bq[0][0][1][0]),
-                           "+v"(bq[0][0][1][1]), "+v"(bq[1][0][0][0]), "+v"(bq[1][0][0][1]), "+v"(bq[1][0][1][0]),
-                           "+v"(bq[1][0][1][1]), "+v"(bq[2][0][0][0]), "+v"(bq[2][0][0][1]), "+v"(bq[2][0][1][0]),
-                           "+v"(bq[2][0][1][1])::"memory");
-        } else if constexpr (CT == 2 && PXT == 2) {
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(af[0][0][0]), "+v"(af[0][0][1]), "+v"(af[0][1][0]), "+v"(af[0][1][1]), "+v"(bq[0][0][0][0]),
-                           "+v"(bq[0][0][0][1]), "+v"(bq[0][0][1][0]), "+v"(bq[0][0][1][1]), "+v"(bq[0][1][0][0]),
-                           "+v"(bq[0][1][0][1]), "+v"(bq[0][1][1][0]), "+v"(bq[0][1][1][1])::"memory");
-        } else {
-            static_assert(NT == 3 || (CT == 2 && PXT == 1), "tile configurations: 2x2 or 2x1 MFMA tiles per wave");
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(af[0][0][0]), "+v"(af[0][0][1]), "+v"(af[0][1][0]), "+v"(af[0][1][1]), "+v"(bq[0][0][0][0]),
-                           "+v"(bq[0][0][0][1]), "+v"(bq[0][1][0][0]), "+v"(bq[0][1][0][1])::"memory");
-        }
-    };
-
-    // ---- the pipeline: DMA two chunks ahead of the chunk being multiplied, fragment reads one chunk ahead ------------
-    // At the top of the step of chunk g (flattened over the items): its fragments are in registers (read during the MFMAs
-    // of chunk g - 1), the DMA of chunks g + 1 and g + 2 is outstanding.  The step waits for chunk g + 1, passes the barrier
-    // (all waves have finished READING stage g % 3 a step ago), refills that stage with chunk g + 3, issues the fragment
-    // reads of chunk g + 1 and only then runs the MFMAs of chunk g: LDS latency, DMA issue and the barrier skew of the
-    // next chunk hide under 8 - 24 MFMAs of this one.
-    // PIPE (the three-plane form: matrix-pipe bound, 256 registers per lane available at two workgroups per CU); the
-    // one-plane form is HBM-bound and register-capped at three workgroups per CU: it reads its fragments in the step that
-    // uses them.
-    constexpr bool PIPE = NT == 3;
-    const int G = nitems * nchunks;
-    bf16x8 af[NT][NSUB][CT], afn[PIPE ? NT : 1][NSUB][CT];
-    s16x4 bq[NT][NSUB][PXT][2], bqn[PIPE ? NT : 1][NSUB][PXT][2];
     pf_setup();
     issue(0);
     issue(1);
-    if constexpr (PIPE) {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        issue(2);
-        read_frags(af, bq, 0);
-        wait_frags(af, bq);
-    }
-    int stage = 0, g = 0;
+    int stage = 0;
     for (int k = 0; k < nitems; ++k) {
         const int idx = idx0 + k * gstep;
         const int jt = idx / a.nco, cot = idx - jt * a.nco;
         const int ptg = xcd * tpx + jt;
         const int n = ptg / a.tiles_per_img, tl = ptg - n * a.tiles_per_img;
         const int co0 = cot * COT, p0 = tl * PT;
-        if (tid < COT) {  // (read after the chunk loop of this item: at least one barrier later; slot k & 1 was last read two items ago)
+        if (tid < COT) {  // (read two barriers later at the earliest; slot k & 1 was last read two items ago)
             const int m = co0 + tid;
             const float bv = (a.bias && m < a.M) ? a.bias[m] : 0.f;
             asm volatile("ds_write_b32 %0, %1" ::"v"(lds0 + (unsigned)(BIAS_OFF + ((k & 1) * COT + tid) * 4)), "v"(bv) : "memory");
@@ -348,93 +225,57 @@ __global__ __launch_bounds__(WCO * WPX * 64, NT == 1 ? 3 : 2) void k_pw_bf16(con
             for (int pt = 0; pt < PXT; ++pt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
-        for (int i = 0; i < nchunks; ++i, ++g) {
-            const bool has_next = PIPE && g + 1 < G;  // (wave-uniform)
-            int s1 = stage + 1;
-            s1 = s1 >= BF_NST ? s1 - BF_NST : s1;
-            if constexpr (PIPE) {
-                if (has_next) {
-                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                    read_frags(afn, bqn, s1);
-                    __builtin_amdgcn_sched_barrier(0);  // keep the reads in front of the MFMAs they are meant to hide under
-                }
+        for (int i = 0; i < nchunks; ++i) {
+            // the chunk at the head of the stream has landed once at most the PPW loads of the chunk after it are outstanding
+            // (this wave's pieces); the barrier extends that to every wave's pieces and says that everybody is done
+            // reading the stage that the next issue overwrites
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            int s2 = stage + 2;
+            s2 = s2 >= BF_NST ? s2 - BF_NST : s2;
+            issue(s2);
+            const unsigned sbase = (unsigned)(stage * STG);
+            bf16x8 af[BF_KC / 16][CT];
+            s16x4 bq[BF_KC / 16][PXT][2];
+            static_for<BF_KC / 16>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                static_for<CT>([&](auto cc) {
+                    constexpr int ct = decltype(cc)::value;
+                    af[j][ct] = lds_rd128<(j * COT + ct * 32) * 32>(sbase + a_addr);
+                });
+                static_for<PXT>([&](auto pc) {
+                    constexpr int pt = decltype(pc)::value;
+                    bq[j][pt][0] = lds_rd_tr<j * 16 * 256>(sbase + b_addr[pt]);
+                    bq[j][pt][1] = lds_rd_tr<j * 16 * 256 + 4 * 256>(sbase + b_addr[pt]);
+                });
+            });
+            if constexpr (CT == 2 && PXT == 2) {
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(bq[0][0][0]), "+v"(bq[0][0][1]),
+                               "+v"(bq[0][1][0]), "+v"(bq[0][1][1]), "+v"(bq[1][0][0]), "+v"(bq[1][0][1]), "+v"(bq[1][1][0]),
+                               "+v"(bq[1][1][1])::"memory");
             } else {
-                // chunk g has landed once at most the PPW loads of chunk g + 1 are outstanding (this wave's pieces); the
-                // barrier extends that to every wave's pieces and says that everybody is done reading stage (g - 1) % 3
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                int s2 = stage + 2;
-                s2 = s2 >= BF_NST ? s2 - BF_NST : s2;
-                issue(s2);
-                read_frags(af, bq, stage);
-                wait_frags(af, bq);
+                static_assert(CT == 2 && PXT == 1, "tile configurations: 2x2 or 2x1 MFMA tiles per wave");
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(bq[0][0][0]), "+v"(bq[0][0][1]),
+                               "+v"(bq[1][0][0]), "+v"(bq[1][0][1])::"memory");
             }
-            // PIPE: the LDS-DMA of chunk g + 3 (into the stage whose fragments are in registers) is issued BETWEEN the MFMA
-            // groups -- an LDS-DMA instruction holds the wave's issue for 60-180 cycles (MI355X_MICROARCH.md), which the
-            // matrix pipe spends on the MFMAs already queued; issued as one block in front of them it was dead time
-            int dma_u = 0;
 #pragma unroll
-            for (int j = 0; j < NSUB; ++j)
+            for (int j = 0; j < BF_KC / 16; ++j)
 #pragma unroll
                 for (int pt = 0; pt < PXT; ++pt) {
-                    bf16x8 bf[NT];
+                    bf16x8 bf;
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            bf[t][e] = bq[t][j][pt][0][e];
-                            bf[t][4 + e] = bq[t][j][pt][1][e];
-                        }
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) {
-                        if constexpr (NT == 3) {  // smallest terms first: the order of k_pw_split_p (bit-identical results)
-                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][j][ct], bf[2], acc[ct][pt], 0, 0, 0);
-                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][j][ct], bf[0], acc[ct][pt], 0, 0, 0);
-                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][j][ct], bf[1], acc[ct][pt], 0, 0, 0);
-                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][j][ct], bf[1], acc[ct][pt], 0, 0, 0);
-                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][j][ct], bf[0], acc[ct][pt], 0, 0, 0);
-                        }
-                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][j][ct], bf[0], acc[ct][pt], 0, 0, 0);
-                        if constexpr (PIPE) {
-                            if (has_next) {
-                                constexpr int NGRP = NSUB * PXT * CT;                 // MFMA groups of this step
-                                constexpr int PER = (PPW + NGRP - 1) / NGRP;           // pieces behind each group
-                                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                                for (int e = 0; e < PER; ++e)
-                                    if (dma_u < PPW) issue_piece(dma_u++, stage);
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                        }
+                    for (int e = 0; e < 4; ++e) {
+                        bf[e] = bq[j][pt][0][e];
+                        bf[4 + e] = bq[j][pt][1][e];
                     }
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j][ct], bf, acc[ct][pt], 0, 0, 0);
                 }
-            if constexpr (PIPE) {
-                if (has_next) {
-#pragma unroll
-                    for (; dma_u < PPW;) issue_piece(dma_u++, stage);
-                    issue_advance();
-                }
-            }
-            if constexpr (PIPE) if (has_next) {
-                __builtin_amdgcn_sched_barrier(0);
-                wait_frags(afn, bqn);
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int j = 0; j < NSUB; ++j) {
-#pragma unroll
-                        for (int ct = 0; ct < CT; ++ct) af[t][j][ct] = afn[t][j][ct];
-#pragma unroll
-                        for (int pt = 0; pt < PXT; ++pt) {
-                            bq[t][j][pt][0] = bqn[t][j][pt][0];
-                            bq[t][j][pt][1] = bqn[t][j][pt][1];
-                        }
-                    }
-            }
-            stage = s1;
+            stage = stage + 1 >= BF_NST ? 0 : stage + 1;
         }
 
         // ---- epilogue: bias, floor, stores (the DMA of the next item's first chunks is in flight) ----
@@ -524,27 +365,22 @@ static int ensure_lds_b(size_t lds) {
 
 int pw_split_num_slots(int N, int P);  // splitmma.hip: N * ceil(P / 128)
 
-template <int WCO, int CT, int WPX, int PXT, int GW, typename TO, int NT>
+template <int WCO, int CT, int WPX, int PXT, int GW, typename TO>
 static int launch_pw_bf16_cfg(PwBfArgs& a, hipStream_t st) {
     constexpr int COT = WCO * CT * 32, PT = WPX * PXT * 32;
-    constexpr int KC = NT == 1 ? 32 : 16;
     a.nco = (a.M + COT - 1) / COT;
     a.tiles_per_img = (a.P + PT - 1) / PT;
     a.T = a.N * a.tiles_per_img;
     a.slots = pw_split_num_slots(a.N, a.P);
     const int items = ((a.T + 7) / 8) * 8 * a.nco;
-    constexpr size_t LDS = (size_t)BF_NST * NT * (KC * PT * 2 + (KC / 16) * COT * 32) + sizeof(float) * (BN_STAT_FLOATS(WPX, COT) + 2 * COT);
-    constexpr int WGS = NT == 1 ? 3 : 2;  // workgroups per CU
-    static_assert(LDS <= 160 * 1024 / WGS, "k_pw_bf16: LDS budget for the intended workgroups per CU");
-    constexpr auto kern = k_pw_bf16<WCO, CT, WPX, PXT, GW, TO, NT>;
-    int rc = ensure_lds_b<kern>(LDS);
+    const size_t lds = (size_t)BF_NST * (BF_KC * PT * 2 + (BF_KC / 16) * COT * 32) + sizeof(float) * (BN_STAT_FLOATS(WPX, COT) + 2 * COT);
+    constexpr auto kern = k_pw_bf16<WCO, CT, WPX, PXT, GW, TO>;
+    int rc = ensure_lds_b<kern>(lds);
     if (rc) return rc;
-    const int grid = items < WGS * 256 ? items : WGS * 256;  // persistent: the resident workgroups walk the items of their XCD
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WCO * WPX * 64), LDS, st, a);
-    if (a.part && a.T < a.slots) {  // (cannot happen with 128-pixel tiles; kept for symmetry with launch_pw_split_cfg)
-        for (int w = 0; w < 3; ++w)
-            HIP_RET(hipMemsetAsync(a.part + ((long)w * a.slots + a.T) * a.M, 0, sizeof(float) * (size_t)(a.slots - a.T) * a.M, st));
-    }
+    static_assert((size_t)BF_NST * (BF_KC * PT * 2 + (BF_KC / 16) * COT * 32) + sizeof(float) * (BN_STAT_FLOATS(WPX, COT) + 2 * COT) <=
+                      160 * 1024 / 3, "k_pw_bf16: three workgroups per CU");
+    const int grid = items < 768 ? items : 768;  // persistent: 3 workgroups per CU walk the items of their XCD
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WCO * WPX * 64), lds, st, a);
     return (int)hipGetLastError();
 }
 
@@ -554,32 +390,19 @@ int launch_pw_bf16(PwBfArgs& a, int out_dt, hipStream_t st) {
         ((((uintptr_t)a.x) & 3) != 0) || ((((uintptr_t)a.out) & 3) != 0) || ((((uintptr_t)a.planes) & 15) != 0))
         return -2;
     a.Cp = (a.Cin + 31) & ~31;
-    a.x_ps = 0;
     const bool g16 = (a.P & 7) == 0 && (a.x_bs & 7) == 0 && ((((uintptr_t)a.x) & 15) == 0);
 #define PWBF_GO(TO)                                                                                        \
     do {                                                                                                   \
         if (a.M > 64) {                                                                                    \
-            if (g16) return launch_pw_bf16_cfg<2, 2, 2, 2, 16, TO, 1>(a, st);                              \
-            return launch_pw_bf16_cfg<2, 2, 2, 2, 4, TO, 1>(a, st);                                        \
+            if (g16) return launch_pw_bf16_cfg<2, 2, 2, 2, 16, TO>(a, st);                                 \
+            return launch_pw_bf16_cfg<2, 2, 2, 2, 4, TO>(a, st);                                           \
         }                                                                                                  \
-        if (g16) return launch_pw_bf16_cfg<1, 2, 4, 1, 16, TO, 1>(a, st);                                  \
-        return launch_pw_bf16_cfg<1, 2, 4, 1, 4, TO, 1>(a, st);                                            \
+        if (g16) return launch_pw_bf16_cfg<1, 2, 4, 1, 16, TO>(a, st);                                     \
+        return launch_pw_bf16_cfg<1, 2, 4, 1, 4, TO>(a, st);                                               \
     } while (0)
     if (out_dt == SMAAT_BF16) PWBF_GO(bf16_t);
     PWBF_GO(float);
 #undef PWBF_GO
-}
-
-// exact three-plane form (x planes at stride a.x_ps, weight planes of smaat_split_planes), f32 output.
-// -2: not handled (M <= 64: the 64-row tile has no three-plane configuration; odd plane size; ...)
-int launch_pw_planes3(PwBfArgs& a, hipStream_t st) {
-    if (a.M <= 64 || (a.P & 1) != 0 || (long)a.Cin * a.P * 2 >= (1L << 31) || (a.x_bs & 1) != 0 || (a.x_ps & 1) != 0 ||
-        ((((uintptr_t)a.x) & 3) != 0) || ((((uintptr_t)a.out) & 3) != 0) || ((((uintptr_t)a.planes) & 15) != 0))
-        return -2;
-    a.Cp = (a.Cin + 15) & ~15;
-    const bool g16 = (a.P & 7) == 0 && (a.x_bs & 7) == 0 && (a.x_ps & 7) == 0 && ((((uintptr_t)a.x) & 15) == 0);
-    if (g16) return launch_pw_bf16_cfg<2, 2, 2, 2, 16, float, 3>(a, st);
-    return launch_pw_bf16_cfg<2, 2, 2, 2, 4, float, 3>(a, st);
 }
 
 // =====================================================================================

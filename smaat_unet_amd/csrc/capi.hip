@@ -111,8 +111,6 @@ int launch_dw3x3_fwd(const void*, int, long, const float*, const float*, void*, 
 // bf16gemm.hip (mixed precision)
 int launch_bf16_planes(const float* w, int R, int C, bf16_t* out, int src_t, hipStream_t st);
 int launch_pw_bf16(PwBfArgs& a, int out_dt, hipStream_t st);
-int launch_pw_planes3(PwBfArgs& a, hipStream_t st);
-int launch_split3(const float* x, long x_bs, bf16_t* out, long o_bs, long o_ps, int N, long len, hipStream_t st);
 int launch_wgrad_bf16(WgBfArgs& a, hipStream_t st);
 
 #define ST ((hipStream_t)(((void)hipGetLastError()), stream))
@@ -477,20 +475,6 @@ int smaat_pointwise_fwd_bf16(const void* x, long x_bs, const void* planes, const
     a.x = (const bf16_t*)x; a.x_bs = x_bs; a.planes = (const bf16_t*)planes; a.bias = bias; a.out = out; a.out_bs = out_bs;
     a.part = part; a.N = N; a.Cin = Cin; a.M = M; a.P = H * W;
     return launch_pw_bf16(a, out_dt, ST);
-}
-/* ---- exact-f32 GEMM from pre-split planes (deep layers): include/smaat_hip.h "pre-split planes" */
-int smaat_split_act3(const float* x, long x_bs, void* planes, long p_bs, long p_ps, int N, int C, int P, void* stream) {
-    if (!x || !planes || N < 1 || C < 1 || P < 1) return -1;
-    return launch_split3(x, x_bs, (bf16_t*)planes, p_bs, p_ps, N, (long)C * P, ST);
-}
-int smaat_pointwise_fwd_planes3(const void* xplanes, long x_bs, long x_ps, const void* wplanes, const float* bias, float* out,
-                                long out_bs, float* part, int N, int Cin, int M, int H, int W, int relu_out, void* stream) {
-    if (N < 1 || Cin < 1 || M < 1 || H < 1 || W < 1 || !xplanes || !wplanes || !out) return -1;
-    PwBfArgs a{};
-    a.out_floor = relu_out ? 0.f : NEG_INF;
-    a.x = (const bf16_t*)xplanes; a.x_bs = x_bs; a.x_ps = x_ps; a.planes = (const bf16_t*)wplanes; a.bias = bias; a.out = out;
-    a.out_bs = out_bs; a.part = part; a.N = N; a.Cin = Cin; a.M = M; a.P = H * W;
-    return launch_pw_planes3(a, ST);
 }
 int smaat_pointwise_wgrad_bf16(const void* y, long y_bs, const void* dz, long dz_bs, float* ws, float* dw_out, int N,
                                int Cin, int M, int H, int W, void* stream) {

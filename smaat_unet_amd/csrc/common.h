@@ -378,11 +378,9 @@ struct PwSplitArgs {
 
 // mixed-precision GEMMs (bf16gemm.hip)
 struct PwBfArgs {
-    const bf16_t* x;       // [N][Cin][P]; three-plane form: plane t at x + t * x_ps
+    const bf16_t* x;       // [N][Cin][P]
     long x_bs;
-    long x_ps;             // plane stride (elements) of the three-plane form, else 0
-    const bf16_t* planes;  // [Cp/16][M][16], Cp = Cin rounded up to 32 (smaat_bf16_planes); three-plane form:
-                           // [Cp/16][3][M][16], Cp = Cin rounded up to 16 (smaat_split_planes)
+    const bf16_t* planes;  // [Cp/16][M][16], Cp = Cin rounded up to 32 (smaat_bf16_planes)
     const float* bias;     // [M] or null
     void* out;             // [N][M][P], f32 or bf16
     long out_bs;
