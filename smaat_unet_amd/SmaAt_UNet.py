@@ -186,7 +186,8 @@ class UNetDSFamily(nn.Module):
         # deferred activation (training path): an encoder block hands out its pre-BatchNorm tensor + coefficients and
         # the attention block that consumes it applies BatchNorm + ReLU inside its channel-pooling kernel, which also
         # writes the activated tensor -- the separate pass over every encoder output disappears
-        defer = self.FUSE_ENCODER_ACT and torch.is_grad_enabled()
+        from . import train_ops
+        defer = self.FUSE_ENCODER_ACT and torch.is_grad_enabled() and not train_ops.active()
         h = self.inc(x, defer=True) if defer else self.inc(x)
         for lvl in range(4):
             up = ups[3 - lvl]  # the decoder level that consumes this skip
@@ -214,7 +215,9 @@ class UNetDSFamily(nn.Module):
         it (training path: the 64-channel block output and its gradient are never materialised), else None"""
         import torch
         conv = self.outc.conv
-        if (not self.FUSE_HEAD or not torch.is_grad_enabled() or conv.out_channels != 1 or conv.kernel_size != (1, 1)
+        from . import train_ops
+        if (not self.FUSE_HEAD or train_ops.active() or not torch.is_grad_enabled() or conv.out_channels != 1
+                or conv.kernel_size != (1, 1)
                 or any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks for m in self.outc.modules())):
             return None
         return conv

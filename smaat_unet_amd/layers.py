@@ -143,7 +143,6 @@ class CBAM(nn.Module):
     EVAL_FAST_PATH = True
 
     def _eval_fast(self):
-        import torch
         bn = self.spatial_att.bn
         return (self.EVAL_FAST_PATH and not self.training and not bn.training and not torch.is_grad_enabled()
                 and bn.track_running_stats and bn.running_mean is not None)
@@ -160,12 +159,16 @@ class CBAM(nn.Module):
         x, lazy = self._split_lazy(x)
         w1, b1, w2, b2 = self.channel_att._mlp_params()
         sp = self.spatial_att
+        from . import train_ops
+        if lazy is None and train_ops.active() and torch.is_grad_enabled():
+            g, b, rm, rv, training, momentum, eps = _bn_args(sp.bn)
+            return train_ops.cbam(x, w1, b1, w2, b2, sp.conv.weight, g, b, rm, rv, training, momentum, eps)
         if lazy is not None:
             g, b, rm, rv, training, momentum, eps = _bn_args(sp.bn)
             return ops.cbam(x, w1, b1, w2, b2, sp.conv.weight, g, b, rm, rv, training, momentum, eps, True, True,
                             lazy=lazy)
         if self._eval_fast():  # inference: three launches, BatchNorm(1) on the running statistics
-            import torch
+
             return torch.ops.smaat.cbam_infer(x, w1, b1, w2, b2, sp.conv.weight, sp.bn.weight, sp.bn.bias,
                                               sp.bn.running_mean, sp.bn.running_var, sp.bn.eps)
         g, b, rm, rv, training, momentum, eps = _bn_args(sp.bn)
@@ -178,12 +181,16 @@ class CBAM(nn.Module):
         x, lazy = self._split_lazy(x)
         w1, b1, w2, b2 = self.channel_att._mlp_params()
         sp = self.spatial_att
+        from . import train_ops
+        if lazy is None and train_ops.active() and torch.is_grad_enabled():
+            g, b, rm, rv, training, momentum, eps = _bn_args(sp.bn)
+            return train_ops.cbam_pool_cat(x, w1, b1, w2, b2, sp.conv.weight, g, b, rm, rv, training, momentum, eps, c_extra)
         if lazy is not None:
             g, b, rm, rv, training, momentum, eps = _bn_args(sp.bn)
             return ops.cbam_pool_cat(x, w1, b1, w2, b2, sp.conv.weight, g, b, rm, rv, training, momentum, eps, c_extra,
                                      lazy=lazy)
         if self._eval_fast():
-            import torch
+
             return torch.ops.smaat.cbam_pool_cat_infer(x, w1, b1, w2, b2, sp.conv.weight, sp.bn.weight, sp.bn.bias,
                                                        sp.bn.running_mean, sp.bn.running_var, sp.bn.eps, c_extra)
         g, b, rm, rv, training, momentum, eps = _bn_args(sp.bn)

@@ -67,6 +67,17 @@ class DoubleConvDS(nn.Module):
         rows st2[2], st2[3]) left to the consumer -- when the block runs as the fused training node; a plain tensor otherwise."""
         seq = self.double_conv
         hooked = any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks for m in seq.modules())
+        import torch
+        from . import train_ops
+        if (train_ops.active() and torch.is_grad_enabled() and not hooked
+                and seq[0].kernels_per_layer_ == seq[3].kernels_per_layer_):
+            # traceable wiring: the block as the custom operator smaat::double_conv_ds (no head / deferred-activation fusion)
+            for conv in (seq[0], seq[3]):
+                conv._check_geometry()
+            halves = [(seq[i].depthwise.weight, seq[i].depthwise.bias, seq[i].pointwise.weight, seq[i].pointwise.bias)
+                      + _bn_args(seq[i + 1]) for i in (0, 3)]
+            y = train_ops.double_conv_ds(x, halves[0], halves[1], seq[0].kernels_per_layer_)
+            return y if head is None else train_ops.pointwise(y, head.weight, head.bias)
         if defer:
             import torch
             if (not hooked and torch.is_grad_enabled() and seq[0].kernels_per_layer_ == seq[3].kernels_per_layer_
@@ -156,6 +167,9 @@ class UpDS(nn.Module):
         kw = {} if head is None else {"head": head}
         if self.bilinear:
             import torch
+            from . import train_ops
+            if train_ops.active() and torch.is_grad_enabled():
+                return self.conv(train_ops.upsample_into(cat, x1, cat.shape[1] - x1.shape[1]), **kw)
             if not torch.is_grad_enabled() and x1.dtype == torch.float32:
                 torch.ops.smaat.upsample_into_(cat, x1, cat.shape[1] - x1.shape[1])
                 return self.conv(cat, **kw)
@@ -173,6 +187,9 @@ class OutConv(nn.Module):
 
     def forward(self, x):
         import torch
+        from . import train_ops
+        if train_ops.active() and torch.is_grad_enabled():
+            return train_ops.pointwise(x, self.conv.weight, self.conv.bias)
         if not torch.is_grad_enabled() and x.dtype == torch.float32:
             return torch.ops.smaat.pointwise_infer(x, self.conv.weight, self.conv.bias)
         return ops.pointwise(x, self.conv.weight, self.conv.bias)

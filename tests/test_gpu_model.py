@@ -478,3 +478,29 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     assert rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2"
     assert rec["kernels"]  # the rank-0 per-kernel leg ran while rank 1 waited at the final barrier
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_traceable_training_operators_on_gpu(mode):
+    """the torch.library training operators (smaat_unet_amd/train_ops.py) run the same kernels as the autograd.Function
+    wiring: same logits (f32: the head / deferred-activation fusions only change which kernel applies an activation),
+    same running statistics, gradients at the round-off level of the default path"""
+    meta = dict(n_channels=12, n_classes=1, param_seed=3)
+    xn, yn = O.synthetic_precip(2, 12, 64, 64, seed=11)
+    x, y = torch.from_numpy(xn).to(DEV), torch.from_numpy(yn).to(DEV)
+    res = []
+    for traceable in (False, True):
+        model, _ = _load_model(meta)
+        model.set_precision(mode)
+        with S.traceable_training(traceable):
+            out = model(x)
+            loss = torch.nn.functional.mse_loss(out.squeeze(1), y, reduction="sum") / 2
+            loss.backward()
+        res.append((out.detach().clone(), torch.cat([p.grad.flatten() for p in model.parameters()]),
+                    {k: v.clone() for k, v in model.state_dict().items() if "running" in k}))
+    (o0, g0, s0), (o1, g1, s1) = res
+    assert o1.dtype == torch.float32
+    assert float((o1 - o0).norm() / o0.norm()) < (1e-5 if mode == "f32" else 5e-2)
+    for k in s0:
+        assert torch.allclose(s0[k], s1[k], rtol=1e-4 if mode == "f32" else 2e-2, atol=1e-6), k
+    assert float((g1 - g0).norm() / g0.norm()) < (5e-3 if mode == "f32" else 0.6)
