@@ -266,6 +266,17 @@ int smaat_pointwise_splitk_ws_floats(int N, int Cin, int M, int H, int W);
 int smaat_pointwise_fwd_split_act_k(const float* x, long x_bs, const void* planes, const float* bias, float* out,
                                     long out_bs, float* ws, int N, int Cin, int M, int H, int W, int relu_out,
                                     void* stream);
+/* training form: the slice count is the caller's (smaat_pointwise_splitk_slices with a budget of workgroup items: more
+ * than one only when the un-sliced launch leaves the chip under-filled -- the 18 x 18 layers at batch 32 are 384 serial
+ * chains of 64 chunks), ws = N * S * M * H * W floats, and the slice reduction also emits the BatchNorm partials
+ * part [3][smaat_pw_split_num_slots(N,H,W)][M] of the summed result (nullable), as smaat_pointwise_fwd_split does.
+ * reference: the pointwise conv of models/layers.py:49 in front of the train-mode BatchNorm of
+ * unet_parts_depthwise_separable.py:25,34.  -2: shape / alignment not handled (x must be dense, Cin / 16 divisible by S). */
+int smaat_pointwise_splitk_slices(int N, int Cin, int M, int H, int W, int budget_items);
+int smaat_pointwise_fwd_split_k(const float* x, long x_bs, const void* planes, const float* bias, float* out, long out_bs,
+                                float* part, float* ws, int S, int N, int Cin, int M, int H, int W, int relu_out,
+                                void* stream);
+
 int smaat_dsconv_split_num_slots(int N, int H, int W);
 int smaat_dsconv_fwd_split(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
                            const float* b_dw, const void* planes, const float* b_pw, float* z, long z_bs, float* part,
@@ -357,6 +368,12 @@ int smaat_upsample2x_bwd_t(const void* dout, long dout_bs, void* dx, long dx_bs,
  * scale != null is smaat_cbam_chpool_act (pools taken over the values as stored). */
 int smaat_cbam_chpool_t(const void* x, long x_bs, const float* scale, const float* shift, void* y, long y_bs, int N,
                         int C, int P, float* avg, float* mx, int* amax, int dt, void* stream);
+/* smaat_cbam_chpool_t + the MaxPool2d(2) of the same tensor (SmaAt_UNet.py:43-50: an encoder level feeds CBAM and the next
+ * DownDS) in one pass: pooled [N][C][H/2][W/2] (floor mode) written from the registers the channel pools are taken from.
+ * Bit-identical to smaat_cbam_chpool[_act] followed by smaat_maxpool2_fwd.  Either dtype.  -2: W % 4 != 0 / alignment. */
+int smaat_cbam_chpool_pool_t(const void* x, long x_bs, const float* scale, const float* shift, void* y, long y_bs,
+                             void* pooled, long pooled_bs, int N, int C, int H, int W, float* avg, float* mx, int* amax, int dt,
+                             void* stream);
 int smaat_cbam_sppool_t(const void* x, long x_bs, const float* s, int N, int C, int P, float* maps, int dt,
                         void* stream);
 int smaat_cbam_apply_t(const void* x, long x_bs, const float* s, const float* gate, void* out, long out_bs, int N, int C,

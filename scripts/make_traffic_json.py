@@ -8,9 +8,12 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r1", "r1r", "rocprof_summary.txt")
+# usage: make_traffic_json.py summary.txt [more_summaries.txt ...]   (e.g. the f32 run and the mixed-precision run of one
+# build: their kernels have different names -- element-type template arguments -- and share one JSON)
+srcs = [a for a in sys.argv[1:] if not a.startswith("sha=")] or [os.path.join(ROOT, "profiles", "r1", "r1r", "rocprof_summary.txt")]
+src = srcs[0]
 fetch, write = {}, {}
-for line in open(src):
+for line in [ln for f in srcs for ln in open(f)]:
     m = re.match(r"(.+?)\s+FETCH_SIZE ([\d.]+) MB over (\d+) disp \(x2 corrected ([\d.]+) MB\)", line)
     if m:
         fetch[m.group(1).strip()] = (float(m.group(4)) * 1e6, int(m.group(3)))
@@ -19,8 +22,8 @@ for line in open(src):
         write[m.group(1).strip()] = (float(m.group(2)) * 1e6, int(m.group(3)))
 sys.path.insert(0, ROOT)
 from bench import csrc_sha16  # noqa: E402
-sha = sys.argv[2] if len(sys.argv) > 2 else csrc_sha16()  # the build the counters were collected on
-out = {"source": os.path.relpath(src, ROOT), "csrc_sha16": sha, "unit": "bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) / dispatches",
+sha = next((a[4:] for a in sys.argv[1:] if a.startswith("sha=")), None) or csrc_sha16()  # the build the counters were collected on
+out = {"source": ", ".join(os.path.relpath(os.path.abspath(f), ROOT) for f in srcs), "csrc_sha16": sha, "unit": "bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) / dispatches",
        "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, (0.0, 0)), write.get(k, (0.0, 0))

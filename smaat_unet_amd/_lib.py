@@ -84,6 +84,8 @@ SIGNATURES = {
     "smaat_pointwise_fwd_split_act": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "smaat_pointwise_splitk_ws_floats": [_I, _I, _I, _I, _I],
     "smaat_pointwise_fwd_split_act_k": [_P, _L, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P],
+    "smaat_pointwise_splitk_slices": [_I, _I, _I, _I, _I, _I],
+    "smaat_pointwise_fwd_split_k": [_P, _L, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     # ---- mixed precision (bf16 activation storage) ----
     "smaat_bf16_planes": [_P, _I, _I, _P, _I, _P],
     "smaat_pointwise_fwd_bf16": [_P, _L, _P, _P, _P, _L, _I, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -100,6 +102,7 @@ SIGNATURES = {
     "smaat_upsample2x_fwd_t": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "smaat_upsample2x_bwd_t": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "smaat_cbam_chpool_t": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _I, _P],
+    "smaat_cbam_chpool_pool_t": [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "smaat_cbam_sppool_t": [_P, _L, _P, _I, _I, _I, _P, _I, _P],
     "smaat_cbam_apply_t": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "smaat_cbam_bwd_gate_t": [_P, _L, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P],

@@ -51,6 +51,8 @@ int smaat_cbam_spconv_blocks_impl(int N, int H, int W);
 int smaat_cbam_pix_blocks_impl(int N, int P);
 int launch_cbam_chpool(const void*, long, int, int, int, float*, float*, int*, hipStream_t, const float* = nullptr,
                        const float* = nullptr, void* = nullptr, long = 0, int dt = SMAAT_F32);
+int launch_cbam_chpool_pool(const void*, long, int, int, int, int, float*, float*, int*, hipStream_t, const float*,
+                            const float*, void*, long, void*, long, int);
 int launch_cbam_mlp(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int,
                     float*, float*, float*, hipStream_t);
 int launch_cbam_sppool(const void*, long, const float*, int, int, int, float*, hipStream_t, int dt = SMAAT_F32);
@@ -97,7 +99,7 @@ int dsconv_split_num_slots(int N, int H, int W);
 int split_mode();
 int set_split_mode(int m);
 int launch_split_planes(const float* w, int R, int C, unsigned short* out, hipStream_t st, int src_t = 0);
-int pw_splitk_slices(int N, int Cin, int M, int P);
+int pw_splitk_slices(int N, int Cin, int M, int P, int budget = 512);
 int launch_pw_split_k(PwSplitArgs& a, float* ws, int S, hipStream_t st);
 int pws_persistent_ok(int M, int P);
 int pw_split_num_slots(int N, int P);
@@ -434,6 +436,24 @@ int smaat_pointwise_fwd_split_act_k(const float* x, long x_bs, const void* plane
     a.part = nullptr; a.N = N; a.Cin = Cin; a.Cp = (Cin + 15) & ~15; a.M = M; a.P = H * W;
     return launch_pw_split_k(a, ws, S, ST);
 }
+/* training form of the sliced GEMM: explicit slice count, BatchNorm partials of the summed result */
+int smaat_pointwise_splitk_slices(int N, int Cin, int M, int H, int W, int budget_items) {
+    if (N < 1 || Cin < 1 || M < 1 || H < 1 || W < 1 || budget_items < 1) return 1;
+    return pw_splitk_slices(N, Cin, M, H * W, budget_items);
+}
+int smaat_pointwise_fwd_split_k(const float* x, long x_bs, const void* planes, const float* bias, float* out, long out_bs,
+                                float* part, float* ws, int S, int N, int Cin, int M, int H, int W, int relu_out,
+                                void* stream) {
+    if (N < 1 || Cin < 1 || M < 1 || H < 1 || W < 1 || S < 2 || !ws || !x || !planes || !out) return -1;
+    if (x_bs != (long)Cin * H * W || (out_bs & 3) != 0 || ((((uintptr_t)out) & 15) != 0) || ((((uintptr_t)ws) & 15) != 0) ||
+        ((H * W) & 3) != 0 || (Cin & 15) != 0 || (Cin / 16) % S != 0 || !pws_persistent_ok(M, H * W))
+        return -2;
+    PwSplitArgs a{};
+    a.out_floor = relu_out ? 0.f : NEG_INF;
+    a.x = x; a.x_bs = x_bs; a.planes = (const unsigned short*)planes; a.bias = bias; a.out = out; a.out_bs = out_bs;
+    a.part = part; a.N = N; a.Cin = Cin; a.Cp = (Cin + 15) & ~15; a.M = M; a.P = H * W;
+    return launch_pw_split_k(a, ws, S, ST);
+}
 int smaat_dsconv_split_num_slots(int N, int H, int W) { return dsconv_split_num_slots(N, H, W); }
 static int dsconv_fwd_split_impl(const float* x, long x_bs, const float* in_scale, const float* in_shift,
                                  const float* w_dw, const float* b_dw, const void* planes, const float* b_pw, float* z,
@@ -557,6 +577,12 @@ int smaat_cbam_chpool_t(const void* x, long x_bs, const float* scale, const floa
                         int C, int P, float* avg, float* mx, int* amax, int dt, void* stream) {
     if (!dt_ok(dt) || !x || (scale && (!shift || !y))) return -1;
     return launch_cbam_chpool(x, x_bs, N, C, P, avg, mx, amax, ST, scale, shift, y, y_bs, dt);
+}
+int smaat_cbam_chpool_pool_t(const void* x, long x_bs, const float* scale, const float* shift, void* y, long y_bs,
+                             void* pooled, long pooled_bs, int N, int C, int H, int W, float* avg, float* mx, int* amax, int dt,
+                             void* stream) {
+    if (!dt_ok(dt) || !x || !pooled || (scale && (!shift || !y)) || N < 1 || C < 1 || H < 1 || W < 1) return -1;
+    return launch_cbam_chpool_pool(x, x_bs, N, C, H, W, avg, mx, amax, ST, scale, shift, y, y_bs, pooled, pooled_bs, dt);
 }
 int smaat_cbam_sppool_t(const void* x, long x_bs, const float* s, int N, int C, int P, float* maps, int dt,
                         void* stream) {

@@ -118,6 +118,110 @@ __global__ __launch_bounds__(256) void k_cbam_chpool(const T* __restrict__ x, lo
     }
 }
 
+// Channel pooling + the MaxPool2d(2) that reads the same tensor (an encoder level of SmaAt_UNet.forward feeds both CBAM
+// and the next DownDS: reference SmaAt_UNet.py:43-50, unet_parts_depthwise_separable.py:48), in ONE pass: a thread owns
+// 2 x 4 patches (two window rows), so the pooled map comes from the registers the channel pools are taken from and the
+// separate max-pool pass over the level output (one read of every encoder activation) disappears.  Same sums, maxima and
+// first-argmax as k_cbam_chpool (a thread still visits its positions in increasing order), same activation expression,
+// same max order as k_maxpool2_fwd: bit-identical to the two kernels it replaces.  W % 4 == 0.
+template <bool ACT, typename T>
+__global__ __launch_bounds__(256) void k_cbam_chpool_pool(const T* __restrict__ x, long x_bs, int C, int H, int W,
+                                                          float* __restrict__ avg, float* __restrict__ mx,
+                                                          int* __restrict__ amax, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, T* __restrict__ y_out,
+                                                          long y_bs, T* __restrict__ pooled, long p_bs) {
+    __shared__ float rf[8];
+    __shared__ int ri[4];
+    const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
+    const int P = H * W, ncol4 = W >> 2, npair = (H + 1) >> 1, Ho = H >> 1, Wo = W >> 1;
+    const T* xp = x + (long)n * x_bs + (long)c * P;
+    T* yp = ACT ? y_out + (long)n * y_bs + (long)c * P : nullptr;
+    T* pp = pooled + (long)n * p_bs + (long)c * Ho * Wo;
+    const float asc = ACT ? scale[c] : 1.f, ash = ACT ? shift[c] : 0.f;
+    auto act4 = [&](float4 v) {
+        if (ACT) {
+            v.x = as_stored(yp, fmaxf(fmaf(v.x, asc, ash), 0.f));
+            v.y = as_stored(yp, fmaxf(fmaf(v.y, asc, ash), 0.f));
+            v.z = as_stored(yp, fmaxf(fmaf(v.z, asc, ash), 0.f));
+            v.w = as_stored(yp, fmaxf(fmaf(v.w, asc, ash), 0.f));
+        }
+        return v;
+    };
+    float s = 0.f, m = -INFINITY;
+    int mi = 0x7fffffff;
+    auto upd = [&](float v, int p) {
+        s += v;
+        const bool gt = v > m;
+        m = gt ? v : m;
+        mi = gt ? p : mi;
+    };
+    auto upd4 = [&](const float4 v, int p) {
+        upd(v.x, p);
+        upd(v.y, p + 1);
+        upd(v.z, p + 2);
+        upd(v.w, p + 3);
+    };
+    const int npatch = npair * ncol4;
+    typedef typename Elem<T>::raw4 R4;
+    for (int idx = threadIdx.x; idx < npatch; idx += 512) {  // two patches per trip: four loads in flight
+        const int idx2 = idx + 256;
+        const bool has2 = idx2 < npatch;
+        const int i0 = idx / ncol4, q0 = idx - i0 * ncol4;
+        const int i1 = has2 ? idx2 / ncol4 : i0, q1 = has2 ? idx2 - i1 * ncol4 : q0;
+        const int pa = 2 * i0 * W + 4 * q0, pb = 2 * i1 * W + 4 * q1;
+        const bool two0 = 2 * i0 + 1 < H, two1 = 2 * i1 + 1 < H;
+        const R4 ra0 = ldraw4(xp + pa), ra1 = ldraw4(xp + (two0 ? pa + W : pa));
+        const R4 rb0 = ldraw4(xp + pb), rb1 = ldraw4(xp + (two1 ? pb + W : pb));
+        {
+            const float4 v0 = act4(cvt4(ra0)), v1 = act4(cvt4(ra1));
+            if (ACT) st4(yp + pa, v0);
+            upd4(v0, pa);
+            if (two0) {
+                if (ACT) st4(yp + pa + W, v1);
+                upd4(v1, pa + W);
+                st2(pp + (long)i0 * Wo + 2 * q0, fmaxf(fmaxf(v0.x, v0.y), fmaxf(v1.x, v1.y)), fmaxf(fmaxf(v0.z, v0.w), fmaxf(v1.z, v1.w)));
+            }
+        }
+        if (has2) {
+            const float4 v0 = act4(cvt4(rb0)), v1 = act4(cvt4(rb1));
+            if (ACT) st4(yp + pb, v0);
+            upd4(v0, pb);
+            if (two1) {
+                if (ACT) st4(yp + pb + W, v1);
+                upd4(v1, pb + W);
+                st2(pp + (long)i1 * Wo + 2 * q1, fmaxf(fmaxf(v0.x, v0.y), fmaxf(v1.x, v1.y)), fmaxf(fmaxf(v0.z, v0.w), fmaxf(v1.z, v1.w)));
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float ws = wave_sum_all(s);
+    const float wm = wave_max_all(m);
+    if (lane == 0) {
+        rf[wave] = ws;
+        rf[4 + wave] = wm;
+    }
+    __syncthreads();
+    const float bm = fmaxf(fmaxf(rf[4], rf[5]), fmaxf(rf[6], rf[7]));
+    int cand = (m == bm) ? mi : 0x7fffffff;
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) {
+        const int o = __shfl_xor(cand, k, 64);
+        cand = o < cand ? o : cand;
+    }
+    if (lane == 0) ri[wave] = cand;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = (double)rf[0] + (double)rf[1] + (double)rf[2] + (double)rf[3];
+        avg[plane] = (float)(tot / (double)P);
+        mx[plane] = bm;
+        int a = ri[0];
+        a = ri[1] < a ? ri[1] : a;
+        a = ri[2] < a ? ri[2] : a;
+        a = ri[3] < a ? ri[3] : a;
+        amax[plane] = a;
+    }
+}
+
 // one block per sample.  LDS: avg[C], mx[C], ha[Cr], hm[Cr]
 __global__ __launch_bounds__(256) void k_cbam_mlp(const float* __restrict__ avg, const float* __restrict__ mx,
                                                   const float* __restrict__ w1, const float* __restrict__ b1,
@@ -961,6 +1065,23 @@ int launch_cbam_chpool(const void* x, long x_bs, int N, int C, int P, float* avg
         else
             hipLaunchKernelGGL((k_cbam_chpool<false, T>), dim3(N * C), dim3(256), 0, st, (const T*)x, x_bs, C, P, avg, mx, amax,
                                nullptr, nullptr, (T*)nullptr, 0L););
+    return (int)hipGetLastError();
+}
+// -2: shape / alignment not handled (the caller runs smaat_cbam_chpool[_act] + smaat_maxpool2_fwd)
+int launch_cbam_chpool_pool(const void* x, long x_bs, int N, int C, int H, int W, float* avg, float* mx, int* amax,
+                            hipStream_t st, const float* scale, const float* shift, void* y_out, long y_bs, void* pooled,
+                            long p_bs, int dt) {
+    const unsigned am = dt == SMAAT_BF16 ? 7u : 15u;
+    if ((W & 3) != 0 || H < 2 || (x_bs & 3) != 0 || (p_bs & 1) != 0 || ((((uintptr_t)x) & am) != 0) ||
+        ((((uintptr_t)pooled) & (am >> 1)) != 0) || (scale && ((y_bs & 3) != 0 || ((((uintptr_t)y_out) & am) != 0))))
+        return -2;
+    SMAAT_DISPATCH_ET(dt, T,
+        if (scale)
+            hipLaunchKernelGGL((k_cbam_chpool_pool<true, T>), dim3(N * C), dim3(256), 0, st, (const T*)x, x_bs, C, H, W, avg, mx,
+                               amax, scale, shift, (T*)y_out, y_bs, (T*)pooled, p_bs);
+        else
+            hipLaunchKernelGGL((k_cbam_chpool_pool<false, T>), dim3(N * C), dim3(256), 0, st, (const T*)x, x_bs, C, H, W, avg, mx,
+                               amax, nullptr, nullptr, (T*)nullptr, 0L, (T*)pooled, p_bs););
     return (int)hipGetLastError();
 }
 int launch_cbam_mlp(const float* avg, const float* mx, const float* w1, const float* b1, const float* w2,

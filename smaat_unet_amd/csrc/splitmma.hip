@@ -1023,20 +1023,79 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
     *(float4*)(out + (long)n * out_bs + e) = acc;
 }
 
-// number of K slices for a [N][Cin][P] -> [N][M][P] GEMM (1 = no split): fill ~512 workgroup slots, keep >= 8 chunks of
-// 16 channels per slice, at most 8 slices
-int pw_splitk_slices(int N, int Cin, int M, int P) {
+// number of K slices for a [N][Cin][P] -> [N][M][P] GEMM (1 = no split): fill ~`budget` workgroup slots (512 = the
+// persistent kernel's grid: inference at small batch), keep >= 8 chunks of 16 channels per slice, at most 8 slices.
+// Training passes a larger budget for the layers that leave the chip under-filled (18 x 18 planes at batch 32: 384
+// items, each a serial chain of 64 chunks): a few waves of short chains beat one wave of long ones.
+int pw_splitk_slices(int N, int Cin, int M, int P, int budget) {
     if ((Cin & 15) != 0 || (P & 3) != 0) return 1;
     const int cot = M > 64 ? 128 : 64;
     const long items = (long)N * ((P + 127) / 128) * ((M + cot - 1) / cot);
+    if (items >= 512 && budget > 512) return 1;  // the chip is full without slicing
     int s = 1;
-    while (s < 8 && items * (s * 2) <= 512 && (Cin / 16) % (s * 2) == 0 && Cin / 16 / (s * 2) >= 8) s *= 2;
+    while (s < 8 && items * (s * 2) <= budget && (Cin / 16) % (s * 2) == 0 && Cin / 16 / (s * 2) >= 8) s *= 2;
     return s;
 }
 
+// the slice reduction of a TRAINING forward GEMM: one workgroup per (image, output channel) plane adds the S partial
+// planes in a fixed order, writes z = max(sum + bias, floor) and the plane's BatchNorm partial (mean, M2, count) of the
+// raw sums (without the bias, the contract of the GEMM epilogues) about a shift that is a sample of the plane.
+// part [3][slots][M], slot = n * tiles_per_img (the image's other slots get count 0).
+__global__ __launch_bounds__(256) void k_splitk_reduce_stats(const float* __restrict__ ws, int S, const float* __restrict__ bias,
+                                                             float* __restrict__ out, long out_bs, int M, int P,
+                                                             float out_floor, float* __restrict__ part, int slots,
+                                                             int tiles_per_img) {
+    __shared__ float red[9];
+    const int plane = blockIdx.x, n = plane / M, m = plane - n * M;
+    const float* w0 = ws + ((long)n * S * M + m) * P;
+    const long sstride = (long)M * P;
+    float* op = out + (long)n * out_bs + (long)m * P;
+    const float b = bias ? bias[m] : 0.f;
+    if (threadIdx.x == 0) {
+        float v = 0.f;
+        for (int s = 0; s < S; ++s) v += w0[s * sstride];
+        red[8] = v;
+    }
+    __syncthreads();
+    const float sh = red[8];
+    float s1 = 0.f, s2 = 0.f;
+    for (int p = threadIdx.x * 4; p < P; p += 1024) {  // P % 4 == 0
+        float4 acc = *(const float4*)(w0 + p);
+        for (int s = 1; s < S; ++s) {
+            const float4 v = *(const float4*)(w0 + s * sstride + p);
+            acc.x += v.x;
+            acc.y += v.y;
+            acc.z += v.z;
+            acc.w += v.w;
+        }
+        const float d0 = acc.x - sh, d1 = acc.y - sh, d2 = acc.z - sh, d3 = acc.w - sh;
+        s1 += (d0 + d1) + (d2 + d3);
+        s2 = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, fmaf(d3, d3, s2))));
+        *(float4*)(op + p) = make_float4(fmaxf(acc.x + b, out_floor), fmaxf(acc.y + b, out_floor), fmaxf(acc.z + b, out_floor),
+                                         fmaxf(acc.w + b, out_floor));
+    }
+    const float t1 = block_sum_t0(s1, red);
+    const float t2 = block_sum_t0(s2, red + 4);
+    if (threadIdx.x == 0) {
+        const float cnt = (float)P, mean = sh + t1 / cnt;
+        const float m2 = fmaxf(t2 - t1 * t1 / cnt, 0.f);
+        const long slot = (long)n * tiles_per_img;
+        part[(0L * slots + slot) * M + m] = mean;
+        part[(1L * slots + slot) * M + m] = m2;
+        part[(2L * slots + slot) * M + m] = cnt;
+        for (int t = 1; t < tiles_per_img; ++t) {
+            part[(0L * slots + slot + t) * M + m] = 0.f;
+            part[(1L * slots + slot + t) * M + m] = 0.f;
+            part[(2L * slots + slot + t) * M + m] = 0.f;
+        }
+    }
+}
+
 int launch_pw_split_k(PwSplitArgs& a, float* ws, int S, hipStream_t st) {
-    // a: the un-split problem (N, Cin, dense x: x_bs == Cin * P); out / out_bs / bias / out_floor of the final result
+    // a: the un-split problem (N, Cin, dense x: x_bs == Cin * P); out / out_bs / bias / out_floor of the final result;
+    // a.part (nullable): BatchNorm partials of the final result, [3][pw_split_num_slots(N, P)][M]
     float* out = a.out;
+    float* part = a.part;
     const long out_bs = a.out_bs;
     const float* bias = a.bias;
     const float floor_ = a.out_floor;
@@ -1054,6 +1113,11 @@ int launch_pw_split_k(PwSplitArgs& a, float* ws, int S, hipStream_t st) {
     a.out_floor = -__builtin_inff();
     int rc = launch_pw_split(a, st);
     if (rc) return rc;
+    if (part) {
+        hipLaunchKernelGGL(k_splitk_reduce_stats, dim3((unsigned)(N * a.M)), dim3(256), 0, st, ws, S, bias, out, out_bs, a.M, a.P,
+                           floor_, part, pw_split_num_slots(N, a.P), (a.P + 127) / 128);
+        return (int)hipGetLastError();
+    }
     const long total4 = (long)N * a.M * a.P / 4;
     hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, ws, S, bias, out, out_bs,
                        a.M, a.P, floor_, total4);

@@ -184,6 +184,7 @@ def _split_on():
 # f32-MFMA forward for the plane-dominated layers, which is MFMA-bound at the f32 rate).  Inference
 # (running statistics, typically batch 1) keeps the fused f32 kernel for the narrow layers: one launch
 # instead of three matters more there than the matrix rate.
+SPLITK_TRAIN_BUDGET = int(os.environ.get("SMAAT_SPLITK_TRAIN", "2048"))  # workgroup items a sliced training GEMM may use (0 = off)
 FUSE_FIRST_ACTIVATION = True  # DoubleConvDS: apply the first BatchNorm + ReLU on load instead of writing y1
 SPLIT_POLICY = os.environ.get("SMAAT_SPLIT_POLICY", "auto")  # "auto" = the measured policy; "all" = every supported shape
 
@@ -272,6 +273,24 @@ def _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None,
         return None
     cout = w_pw.shape[0]
     planes = _split_planes_raw(w_pw.reshape(cout, -1))
+    L = _lib.get()
+    n, k, h, w = y.shape
+    # layers that leave the chip under-filled (18 x 18 at batch 32: 384 serial chains of 64 chunks): the contraction is cut
+    # into slices that run as virtual images; the slice reduction writes z and its BatchNorm partials
+    s_k = L.smaat_pointwise_splitk_slices(n, k, cout, h, w, SPLITK_TRAIN_BUDGET) if SPLITK_TRAIN_BUDGET > 0 else 1
+    if s_k > 1:
+        z = _new(y, n, cout, h, w)
+        ws = _new(y, n * s_k * cout * h * w)
+        part, slots = None, 0
+        if want_stats:
+            slots = L.smaat_pw_split_num_slots(n, h, w)
+            part = _new(y, 3, slots, cout)
+        rc = L.smaat_pointwise_fwd_split_k(_ptr(y), k * h * w, _ptr(planes), _ptr(b_pw), _ptr(z), cout * h * w, _ptr(part),
+                                           _ptr(ws), s_k, n, k, cout, h, w, 0, _stream(y))
+        if rc == 0:
+            return z, part, slots, y
+        if rc != -2:
+            _lib.check(rc, "smaat_pointwise_fwd_split_k")
     z, part, slots = _pointwise_split_raw(y, planes, b_pw, cout, want_stats)
     return z, part, slots, y
 

@@ -184,6 +184,19 @@ class EmuLib:
             zz[:] = np.maximum(zz, 0)
         return rc
 
+    def smaat_pointwise_splitk_slices(self, N, Cin, M, H, W, budget):
+        # (the emulation slices small deep layers in training so that the host wiring of the sliced path is exercised)
+        return 2 if (budget > 512 and Cin % 32 == 0 and (H * W) % 4 == 0 and N * H * W <= 1024) else 1
+
+    def smaat_pointwise_fwd_split_k(self, x, x_bs, pl, bias, out, out_bs, part, ws, S, N, Cin, M, H, W, relu_out, stream):
+        if x_bs != Cin * H * W or (H * W) % 4 or Cin % 16 or (Cin // 16) % S:
+            return -2
+        rc = self.smaat_pointwise_fwd_split(x, x_bs, pl, bias, out, out_bs, part, N, Cin, M, H, W, stream)
+        if rc == 0 and relu_out:
+            oo = planes(out, N, M, H * W, out_bs)
+            oo[:] = np.maximum(oo, 0)
+        return rc
+
     def smaat_pointwise_splitk_ws_floats(self, N, Cin, M, H, W):
         return 0
 

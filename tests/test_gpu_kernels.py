@@ -807,3 +807,33 @@ def test_cbam_chain(shape):
 
 def test_cbam_ks3():
     both(case_cbam, 2, 32, 10, 10, ks=3, tol=3e-5)
+
+
+@pytest.mark.parametrize("shape", [(32, 1024, 512, 18, 18), (4, 256, 128, 12, 12), (2, 512, 64, 16, 8)])
+def test_pointwise_fwd_split_k_training_form(shape):
+    """sliced GEMM with the statistics-emitting slice reduction (18 x 18 layers in training) against the un-sliced kernel"""
+    L, dev = _lib.get(), torch.device("cuda:0")
+    N, C, M, H, W = shape
+    p = H * W
+    x = T(rnd(1, N, C, H, W), dev)
+    w, b = T(rnd(2, M, C, scale=0.2), dev), T(rnd(3, M), dev)
+    cp = (C + 15) // 16 * 16
+    pl = torch.empty(3 * M * cp, dtype=torch.int16, device=dev)
+    assert L.smaat_split_planes(P(w), M, C, P(pl), stream(dev)) == 0
+    slots = L.smaat_pw_split_num_slots(N, H, W)
+    o0, o1 = torch.empty(N, M, H, W, device=dev), torch.full((N, M, H, W), float("nan"), device=dev)
+    p0, p1 = torch.empty(3, slots, M, device=dev), torch.full((3, slots, M), float("nan"), device=dev)
+    assert L.smaat_pointwise_fwd_split(P(x), C * p, P(pl), P(b), P(o0), M * p, P(p0), N, C, M, H, W, stream(dev)) == 0
+    S = max(2, L.smaat_pointwise_splitk_slices(N, C, M, H, W, 2048))
+    ws = torch.empty(N * S * M * p, device=dev)
+    assert L.smaat_pointwise_fwd_split_k(P(x), C * p, P(pl), P(b), P(o1), M * p, P(p1), P(ws), S, N, C, M, H, W, 0, stream(dev)) == 0
+    torch.cuda.synchronize()
+    assert rel(o1.cpu().numpy(), o0.cpu().numpy()) < 2e-6
+    n0, m0, v0 = part_stats(p0)
+    n1, m1, v1 = part_stats(p1)
+    assert torch.equal(n0, n1)
+    assert rel(m1.cpu().numpy(), m0.cpu().numpy()) < 1e-5 and rel(v1.cpu().numpy(), v0.cpu().numpy()) < 1e-5
+    if shape[0] == 32:
+        assert L.smaat_pointwise_splitk_slices(N, C, M, H, W, 2048) == 4   # 384 items -> 1536
+        assert L.smaat_pointwise_splitk_slices(N, C, M, H, W, 512) == 1    # the inference budget leaves it alone
+        assert L.smaat_pointwise_splitk_slices(32, 1024, 512, 36, 36, 2048) == 1  # 1408 items: the chip is full
