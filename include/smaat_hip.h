@@ -370,7 +370,8 @@ int smaat_cbam_chpool_t(const void* x, long x_bs, const float* scale, const floa
                         int C, int P, float* avg, float* mx, int* amax, int dt, void* stream);
 /* smaat_cbam_chpool_t + the MaxPool2d(2) of the same tensor (SmaAt_UNet.py:43-50: an encoder level feeds CBAM and the next
  * DownDS) in one pass: pooled [N][C][H/2][W/2] (floor mode) written from the registers the channel pools are taken from.
- * Bit-identical to smaat_cbam_chpool[_act] followed by smaat_maxpool2_fwd.  Either dtype.  -2: W % 4 != 0 / alignment. */
+ * y, pooled, mx, amax bit-identical to smaat_cbam_chpool[_act] followed by smaat_maxpool2_fwd; avg up to the f32 summation
+ * order.  Either dtype.  -2: W % 4 != 0 / alignment (run the two entry points instead). */
 int smaat_cbam_chpool_pool_t(const void* x, long x_bs, const float* scale, const float* shift, void* y, long y_bs,
                              void* pooled, long pooled_bs, int N, int C, int H, int W, float* avg, float* mx, int* amax, int dt,
                              void* stream);

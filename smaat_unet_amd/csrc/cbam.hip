@@ -121,9 +121,10 @@ __global__ __launch_bounds__(256) void k_cbam_chpool(const T* __restrict__ x, lo
 // Channel pooling + the MaxPool2d(2) that reads the same tensor (an encoder level of SmaAt_UNet.forward feeds both CBAM
 // and the next DownDS: reference SmaAt_UNet.py:43-50, unet_parts_depthwise_separable.py:48), in ONE pass: a thread owns
 // 2 x 4 patches (two window rows), so the pooled map comes from the registers the channel pools are taken from and the
-// separate max-pool pass over the level output (one read of every encoder activation) disappears.  Same sums, maxima and
+// separate max-pool pass over the level output (one read of every encoder activation) disappears.  Same maxima and
 // first-argmax as k_cbam_chpool (a thread still visits its positions in increasing order), same activation expression,
-// same max order as k_maxpool2_fwd: bit-identical to the two kernels it replaces.  W % 4 == 0.
+// same max order as k_maxpool2_fwd: those outputs are bit-identical to the two kernels it replaces; the mean adds the same
+// terms patch-major instead of row-major (f32 partial sums per thread, f64 across waves).  W % 4 == 0.
 template <bool ACT, typename T>
 __global__ __launch_bounds__(256) void k_cbam_chpool_pool(const T* __restrict__ x, long x_bs, int C, int H, int W,
                                                           float* __restrict__ avg, float* __restrict__ mx,

@@ -1163,9 +1163,11 @@ def upsample_cat(x1, x2):
 # CBAM (channel attention and/or spatial attention)
 # --------------------------------------------------------------------------------------
 def _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, use_ch, use_sp,
-                       out=None, lazy=None):
+                       out=None, lazy=None, pool=None):
     """out = spatial_att(channel_att(x)); `out` may be a channel slice of a larger buffer (dense
     planes, any batch stride).  Returns (out, saved tensors, flags).
+    pool = []: the caller also needs maxpool2(x) (an encoder level): when the shape allows, the channel pooling kernel
+    produces it in the same pass and it is appended to the list; otherwise the list stays empty.
     lazy = (scale, shift): x is the PRE-BatchNorm tensor of the block in front (deferred activation, see
     _DoubleConvDS): relu(x * scale + shift) is formed and written by the channel pooling kernel; saved[0] is that
     activated tensor."""
@@ -1199,7 +1201,23 @@ def _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, 
         avg = _new(dev, n, c)
         mx = _new(dev, n, c)
         amax = _new(dev, n, c, dtype=torch.int32)
-        if lazy is not None:
+        fused_pool = False
+        if pool is not None and w % 4 == 0 and h >= 2:
+            y = _new(dev, n, c, h, w, dtype=x.dtype) if lazy is not None else None
+            pooled = _new(dev, n, c, h // 2, w // 2, dtype=x.dtype)
+            rc = L.smaat_cbam_chpool_pool_t(_ptr(x), x_bs, _ptr(lazy[0]) if lazy is not None else None,
+                                            _ptr(lazy[1]) if lazy is not None else None, _ptr(y) if y is not None else None,
+                                            c * p, _ptr(pooled), c * (h // 2) * (w // 2), n, c, h, w, _ptr(avg), _ptr(mx),
+                                            _ptr(amax), _dt(x), s_)
+            if rc != -2:
+                _lib.check(rc, "smaat_cbam_chpool_pool_t")
+                fused_pool = True
+                pool.append(pooled)
+                if y is not None:
+                    x, x_bs = y, c * p
+        if fused_pool:
+            pass
+        elif lazy is not None:
             y = _new(dev, n, c, h, w, dtype=x.dtype)
             if bf:
                 _lib.check(L.smaat_cbam_chpool_t(_ptr(x), x_bs, _ptr(lazy[0]), _ptr(lazy[1]), _ptr(y), c * p, n, c, p,
@@ -1444,9 +1462,12 @@ class _CBAMPoolCat(torch.autograd.Function):
         cat = _new(x, n, c + c_extra, h, w, dtype=x.dtype)
         lazy = (lazy_scale, lazy_shift) if lazy_scale is not None else None
         _, saved, flags = _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps,
-                                             True, True, out=cat[:, :c], lazy=lazy)
-        x, x_bs = _planes(saved[0])  # (the activated tensor when the activation was deferred)
-        pooled = _maxpool2_fwd_raw(x, x_bs)
+                                             True, True, out=cat[:, :c], lazy=lazy, pool=(got := []))
+        if got:
+            pooled = got[0]
+        else:
+            x, x_bs = _planes(saved[0])  # (the activated tensor when the activation was deferred)
+            pooled = _maxpool2_fwd_raw(x, x_bs)
         ctx.save_for_backward(*saved)
         ctx.flags = flags
         return cat, pooled

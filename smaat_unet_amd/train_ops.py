@@ -207,8 +207,8 @@ def cbam_pool_cat_op(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, 
     rm, rv = (t.clone() if t is not None else None for t in (rm, rv))
     cat = torch.empty((n, c + c_extra, h, w), dtype=xx.dtype, device=xx.device)
     _, saved, _ = ops._cbam_forward_impl(xx, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, _mo_back(momentum), eps, True,
-                                         True, out=cat[:, :c])
-    pooled = ops._maxpool2_fwd_raw(xx, x_bs) if pool else _e(xx)
+                                         True, out=cat[:, :c], pool=(got := []) if pool else None)
+    pooled = (got[0] if got else ops._maxpool2_fwd_raw(xx, x_bs)) if pool else _e(xx)
     return [cat, pooled] + list(saved[5:]) + [t if (t is not None and training) else _e(xx) for t in (rm, rv)]
 
 

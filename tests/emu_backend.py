@@ -900,6 +900,14 @@ def _t_cbam_chpool(self, x, x_bs, scale, shift, y, y_bs, N, C, P, avg, mx, amax,
     return self.smaat_cbam_chpool(xi.ptr, xi.bs, N, C, P, avg, mx, amax, stream)
 
 
+def _t_cbam_chpool_pool(self, x, x_bs, scale, shift, y, y_bs, pooled, p_bs, N, C, H, W, avg, mx, amax, dt, stream):
+    if W % 4 or H < 2:
+        return -2
+    rc = _t_cbam_chpool(self, x, x_bs, scale, shift, y, y_bs, N, C, H * W, avg, mx, amax, dt, stream)
+    src, s_bs = (y, y_bs) if scale else (x, x_bs)
+    return rc or _t_maxpool2_fwd(self, src, s_bs, pooled, p_bs, N, C, H, W, dt, stream)
+
+
 def _t_cbam_sppool(self, x, x_bs, s, N, C, P, maps, dt, stream):
     xi = _TIn(x, dt, N, C, P, x_bs)
     return self.smaat_cbam_sppool(xi.ptr, xi.bs, s, N, C, P, maps, stream)
@@ -950,7 +958,7 @@ for _name, _fn in (("smaat_bf16_planes", _t_bf16_planes), ("smaat_pointwise_fwd_
                    ("smaat_outconv1_fwd_t", _t_outconv1_fwd), ("smaat_channel_sum_t", _t_channel_sum),
                    ("smaat_maxpool2_fwd_t", _t_maxpool2_fwd), ("smaat_maxpool2_bwd_t", _t_maxpool2_bwd),
                    ("smaat_upsample2x_fwd_t", _t_upsample2x_fwd), ("smaat_upsample2x_bwd_t", _t_upsample2x_bwd),
-                   ("smaat_cbam_chpool_t", _t_cbam_chpool), ("smaat_cbam_sppool_t", _t_cbam_sppool),
+                   ("smaat_cbam_chpool_t", _t_cbam_chpool), ("smaat_cbam_chpool_pool_t", _t_cbam_chpool_pool), ("smaat_cbam_sppool_t", _t_cbam_sppool),
                    ("smaat_cbam_apply_t", _t_cbam_apply), ("smaat_cbam_bwd_gate_t", _t_cbam_bwd_gate),
                    ("smaat_cbam_bwd_main_t", _t_cbam_bwd_main), ("smaat_cbam_bwd_final_t", _t_cbam_bwd_final),
                    ("smaat_cbam_bwd_final_pool_t", _t_cbam_bwd_final_pool)):

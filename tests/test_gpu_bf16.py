@@ -386,6 +386,48 @@ def test_upsample_t(shape):
     same_as_rounded(d1, d0, "upsample bwd")
 
 
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 24, 0), (3, 5, 9, 12, 2), (2, 64, 144, 144, 0), (1, 4, 36, 36, 3), (2, 3, 2, 4, 0)])
+def test_cbam_chpool_pool_is_the_two_kernels(shape, dt):
+    """channel pooling + MaxPool2d(2) in one pass == smaat_cbam_chpool_t followed by smaat_maxpool2_fwd_t: maxima, argmax, activation and
+    pooled map bit for bit, the mean up to the f32 summation order (odd H: the last row is pooled over but belongs to no window; pad: a channel slice of a wider buffer)"""
+    L = _lib.get()
+    N, C, H, W, pad = shape
+    p, Ho, Wo = H * W, H // 2, W // 2
+    td = torch.bfloat16 if dt == BF16 else torch.float32
+    xw = rnd(1, N, C + pad, H, W).to(td)
+    x_bs = (C + pad) * p
+    sc, sh = torch.rand(C, device=DEV) + 0.5, rnd(3, C, scale=0.3)
+    for act in (False, True):
+        a0, m0, i0 = torch.empty(N, C, device=DEV), torch.empty(N, C, device=DEV), torch.empty(N, C, dtype=torch.int32, device=DEV)
+        a1, m1, i1 = torch.empty_like(a0), torch.empty_like(m0), torch.empty_like(i0)
+        y0 = torch.full((N, C, H, W), 7.0, dtype=td, device=DEV)
+        y1 = torch.full((N, C, H, W), 9.0, dtype=td, device=DEV)
+        q0 = torch.full((N, C, Ho, Wo), 7.0, dtype=td, device=DEV)
+        q1 = torch.full((N, C, Ho, Wo), 9.0, dtype=td, device=DEV)
+        if act:
+            assert L.smaat_cbam_chpool_t(P(xw), x_bs, P(sc), P(sh), P(y0), C * p, N, C, p, P(a0), P(m0), P(i0), dt, S()) == 0
+            assert L.smaat_maxpool2_fwd_t(P(y0), C * p, P(q0), C * Ho * Wo, N, C, H, W, dt, S()) == 0
+            assert L.smaat_cbam_chpool_pool_t(P(xw), x_bs, P(sc), P(sh), P(y1), C * p, P(q1), C * Ho * Wo, N, C, H, W, P(a1),
+                                              P(m1), P(i1), dt, S()) == 0
+        else:
+            assert L.smaat_cbam_chpool_t(P(xw), x_bs, None, None, None, 0, N, C, p, P(a0), P(m0), P(i0), dt, S()) == 0
+            assert L.smaat_maxpool2_fwd_t(P(xw), x_bs, P(q0), C * Ho * Wo, N, C, H, W, dt, S()) == 0
+            assert L.smaat_cbam_chpool_pool_t(P(xw), x_bs, None, None, None, 0, P(q1), C * Ho * Wo, N, C, H, W, P(a1), P(m1),
+                                              P(i1), dt, S()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(m0, m1) and torch.equal(i0, i1), act
+        # the mean is summed patch-major instead of row-major: same terms, another f32 summation order
+        assert float((a0 - a1).abs().max()) <= 4e-6 * float(xw.float().abs().max()), act
+        assert torch.equal(q0, q1), act
+        if act:
+            assert torch.equal(y0, y1)
+    # a width the kernel does not take: the caller is told to run the two kernels
+    xb = rnd(2, 1, 2, 6, 6).to(td)
+    q = torch.empty(1, 2, 3, 3, dtype=td, device=DEV)
+    assert L.smaat_cbam_chpool_pool_t(P(xb), 72, None, None, None, 0, P(q), 18, 1, 2, 6, 6, P(a1), P(m1), P(i1), dt, S()) == -2
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 16, 24), (2, 32, 18, 18), (1, 8, 9, 11)])
 def test_cbam_kernels_t(shape):
     L = _lib.get()
