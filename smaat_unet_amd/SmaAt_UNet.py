@@ -85,6 +85,12 @@ class UNetDSFamily(nn.Module):
 
     # ---- inference: the whole forward as ONE captured hipGraph, owned by the module -----------------------------
     MAX_EVAL_GRAPHS = 8  # captured input shapes kept per module (least recently used one dropped beyond that)
+    # Opt-in (SMAAT_FORK_ATTENTION=1): capture the skip connections' attention as parallel branches of the graph.  Measured on
+    # MI355X / ROCm 7.0 at batch 1, 288 x 288: 0.711 ms against 0.687 ms without -- the graph executor does not overlap the
+    # branches (each replay still runs its kernels back to back) and the two extra dependency edges per level cost ~5 us
+    # each; kept as a switch for runtimes that do.
+    FORK_ATTENTION = os.environ.get("SMAAT_FORK_ATTENTION", "0") == "1"
+    FORK_MAX_PIXELS = 4 * 288 * 288  # N * H * W up to which the captured graph forks the attention branches
 
     def enable_eval_graph(self, enabled=True, clone_output=True):
         """Inference (eval mode under no_grad, reference call stack D): capture the forward for every input shape
@@ -152,12 +158,19 @@ class UNetDSFamily(nn.Module):
             static_in = x.detach().clone()
             side = torch.cuda.Stream(device=x.device)
             side.wait_stream(torch.cuda.current_stream(x.device))
-            with torch.cuda.stream(side):  # warm-up outside the capture: BatchNorm folding, lazy kernel attributes
-                self._forward_impl(static_in)
-            torch.cuda.current_stream(x.device).wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                static_out = self._forward_impl(static_in)
+            # small batches: every kernel under-fills the chip and the forward is a chain of ~60 dependent launches; the
+            # skip connections' attention then runs as a parallel branch of the graph (ops.cbam_eval_forked)
+            fork = self.FORK_ATTENTION and x.shape[0] * x.shape[2] * x.shape[3] <= self.FORK_MAX_PIXELS
+            self.__dict__["_fork_stream"] = torch.cuda.Stream(device=x.device) if fork else None
+            try:
+                with torch.cuda.stream(side):  # warm-up outside the capture: BatchNorm folding, lazy kernel attributes
+                    self._forward_impl(static_in)
+                torch.cuda.current_stream(x.device).wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    static_out = self._forward_impl(static_in)
+            finally:
+                self.__dict__["_fork_stream"] = None
             ent = self._graphs[key] = dict(sig=self._weights_signature(), graph=g, x=static_in, y=static_out)
         else:
             self._graphs[key] = self._graphs.pop(key)  # most recently used last
@@ -189,16 +202,26 @@ class UNetDSFamily(nn.Module):
         from . import train_ops
         defer = self.FUSE_ENCODER_ACT and torch.is_grad_enabled() and not train_ops.active()
         h = self.inc(x, defer=True) if defer else self.inc(x)
+        side = self.__dict__.get("_fork_stream")  # set by _graph_forward around the warm-up and the capture (small batches)
+        keep = []
         for lvl in range(4):
             up = ups[3 - lvl]  # the decoder level that consumes this skip
             ch = (h[0] if isinstance(h, tuple) else h).shape[1]
             c_extra = up.conv.double_conv[0].depthwise.in_channels - ch
-            cat, pooled = cbams[lvl].forward_pool_cat(h, c_extra)  # skip written straight into the decoder's cat buffer
+            forked = cbams[lvl].forward_pool_cat_forked(h, c_extra, side) if side is not None else None
+            if forked is not None:  # the skip's attention runs beside the deeper encoder levels (joined below)
+                cat, pooled, ka = forked
+                keep.append(ka)
+            else:
+                cat, pooled = cbams[lvl].forward_pool_cat(h, c_extra)  # skip written straight into the decoder's cat buffer
             cats.append(cat)
             last = downs[lvl].maxpool_conv[1]
             h = last(pooled, defer=True) if (defer and cbams[4] is not None or defer and lvl < 3) else last(pooled)
         if cbams[4] is not None:
             h = cbams[4](h)
+        if keep:
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            keep.clear()  # (allocated on this stream: reusable from here on)
         head = self._fused_head()
         for i, (up, cat) in enumerate(zip(ups, reversed(cats))):
             if head is not None and i == len(ups) - 1:

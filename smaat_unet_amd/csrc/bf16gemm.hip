@@ -8,8 +8,8 @@
 //
 // In bf16 every layer of the network is HBM-bound (SURVEY 8(d) ridge analysis), so these kernels are built around the
 // memory pipeline, not the matrix pipe:
-//   * operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no VALU, no ds_write; three
-//     LDS stages, two chunks of loads in flight per workgroup behind the one being consumed, counted s_waitcnt vmcnt and
+//   * operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no VALU, no ds_write; three or
+//     four LDS stages, two or three chunks of loads in flight per workgroup behind the one being consumed, counted s_waitcnt vmcnt and
 //     raw s_barrier (a __syncthreads() or a compiler-tracked LDS read would drain the DMA queue to vmcnt(0));
 //   * the activation tile is stored in LDS exactly as it lies in memory ([channel][pixel], pixels contiguous); the MFMA B
 //     operand needs 8 consecutive CHANNELS of one pixel per lane: ds_read_b64_tr_b16 (the gfx950 transpose read,
@@ -93,7 +93,12 @@ int launch_bf16_planes(const float* w, int R, int C, bf16_t* out, int src_t, hip
 // k_pw_bf16
 // =====================================================================================
 #define BF_KC 32  // channels per stage
-#define BF_NST 3  // LDS stages
+// LDS stages: NST - 1 chunks of loads are in flight behind the one being consumed.  Four where three workgroups of four
+// stages fit a CU's 160 KB (the 64-channel tiles: the 288^2 layers, which are pure streaming), three otherwise.
+template <int COT>
+struct BfStages {
+    static constexpr int value = COT <= 64 ? 4 : 3;
+};
 
 // GW: bytes per lane of an activation LDS-DMA (16: P % 8 == 0; 4: P % 2 == 0 -- the 18 x 18 planes)
 //
@@ -111,11 +116,12 @@ __global__ __launch_bounds__(WCO * WPX * 64, 3) void k_pw_bf16(const PwBfArgs a)
     constexpr int XB = BF_KC * PT * 2;          // X stage: [KC][PT] bf16
     constexpr int AB = (BF_KC / 16) * COT * 32;  // A stage: [KC/16][COT][16] bf16
     constexpr int STG = XB + AB;
+    constexpr int BF_NST = BfStages<COT>::value;
     constexpr int NXP = GW == 16 ? XB / 1024 : BF_KC;  // X pieces (one wave-instruction each) per stage
     constexpr int NAP = AB / 1024;
     static_assert(NXP % NW == 0 && NAP % NW == 0, "pieces divide evenly among the waves");
     constexpr int XPW = NXP / NW, APW = NAP / NW, PPW = XPW + APW;
-    static_assert(2 * PPW <= 63, "vmcnt is a 6-bit counter");
+    static_assert((BF_NST - 1) * PPW <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)lds;  // asm reads take LDS byte addresses
     float* stat = (float*)(lds + BF_NST * STG);            // [WPX][3][COT] + [8]
@@ -204,8 +210,8 @@ __global__ __launch_bounds__(WCO * WPX * 64, 3) void k_pw_bf16(const PwBfArgs a)
     const unsigned bias_rd = lds0 + (unsigned)(BIAS_OFF + (wco * CT * 32 + 4 * half) * 4);
 
     pf_setup();
-    issue(0);
-    issue(1);
+#pragma unroll
+    for (int s = 0; s < BF_NST - 1; ++s) issue(s);
     int stage = 0;
     for (int k = 0; k < nitems; ++k) {
         const int idx = idx0 + k * gstep;
@@ -226,13 +232,13 @@ __global__ __launch_bounds__(WCO * WPX * 64, 3) void k_pw_bf16(const PwBfArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
         for (int i = 0; i < nchunks; ++i) {
-            // the chunk at the head of the stream has landed once at most the PPW loads of the chunk after it are outstanding
-            // (this wave's pieces); the barrier extends that to every wave's pieces and says that everybody is done
+            // the chunk at the head of the stream has landed once at most the loads of the NST - 2 chunks after it are
+            // outstanding (this wave's pieces); the barrier extends that to every wave's pieces and says that everybody is done
             // reading the stage that the next issue overwrites
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((BF_NST - 2) * PPW) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            int s2 = stage + 2;
+            int s2 = stage + BF_NST - 1;
             s2 = s2 >= BF_NST ? s2 - BF_NST : s2;
             issue(s2);
             const unsigned sbase = (unsigned)(stage * STG);
@@ -373,6 +379,7 @@ static int launch_pw_bf16_cfg(PwBfArgs& a, hipStream_t st) {
     a.T = a.N * a.tiles_per_img;
     a.slots = pw_split_num_slots(a.N, a.P);
     const int items = ((a.T + 7) / 8) * 8 * a.nco;
+    constexpr int BF_NST = BfStages<COT>::value;
     const size_t lds = (size_t)BF_NST * (BF_KC * PT * 2 + (BF_KC / 16) * COT * 32) + sizeof(float) * (BN_STAT_FLOATS(WPX, COT) + 2 * COT);
     constexpr auto kern = k_pw_bf16<WCO, CT, WPX, PXT, GW, TO>;
     int rc = ensure_lds_b<kern>(lds);

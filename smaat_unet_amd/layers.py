@@ -174,6 +174,21 @@ class CBAM(nn.Module):
         g, b, rm, rv, training, momentum, eps = _bn_args(sp.bn)
         return ops.cbam(x, w1, b1, w2, b2, sp.conv.weight, g, b, rm, rv, training, momentum, eps, True, True)
 
+    def forward_pool_cat_forked(self, x, c_extra, side):
+        """forward_pool_cat for the captured inference graph at small batch: (cat, pooled, keepalive) with the attention
+        running on the stream `side` (ops.cbam_eval_forked), or None when that path does not apply"""
+        if isinstance(x, tuple) or not self._eval_fast() or not x.is_cuda:
+            return None
+        w1, b1, w2, b2 = self.channel_att._mlp_params()
+        sp = self.spatial_att
+        n, c, h, w = x.shape
+        cat = torch.empty((n, c + c_extra, h, w), dtype=x.dtype, device=x.device)
+        r = ops.cbam_eval_forked(x, w1, b1, w2, b2, sp.conv.weight, sp.bn.weight, sp.bn.bias, sp.bn.running_mean,
+                                 sp.bn.running_var, sp.bn.eps, cat[:, :c], side)
+        if r is None:
+            return None
+        return cat, r[0], r[1] + (cat,)
+
     def forward_pool_cat(self, x, c_extra):
         """(cat, pooled): CBAM(x) written into channels [0, C) of a fresh [N, C + c_extra, H, W]
         concatenation buffer, and maxpool2(x) -- the two consumers of an encoder level in

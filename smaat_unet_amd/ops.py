@@ -1424,6 +1424,45 @@ def cbam_eval(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, eps, out=None, pool
     return (out, pooled) if pool else out
 
 
+def cbam_eval_forked(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, eps, out, side):
+    """Inference CBAM of an encoder level with the attention taken OFF the encoder's critical path (small-batch latency:
+    every kernel of a batch-1 forward under-fills the chip, so the kernel chain, not the work, is the time).  The first
+    launch -- channel pooling + MaxPool2d(2) in one pass -- runs on the current stream and yields `pooled`, which is all
+    the next encoder level waits for; the shared MLP + channel maps and the spatial gate + product run on the HIP stream
+    `side`, concurrently with the deeper encoder levels.  The caller joins (`current.wait_stream(side)`) before the decoder
+    reads `out`, and keeps the returned tensors alive until then (they were allocated on the current stream).
+    Returns (pooled, keepalive) or None when the one-pass pooling kernel does not take the shape (W % 4 != 0)."""
+    _check(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv)
+    L = _lib.get()
+    x, x_bs = _planes(x)
+    n, c, h, w = x.shape
+    if w % 4 or h < 2 or x.dtype != torch.float32:
+        return None
+    p = h * w
+    cr = w1.shape[0]
+    w1, w2, wconv = w1.contiguous(), w2.contiguous(), wconv.contiguous()
+    avg, mx = _new(x, n, c), _new(x, n, c)
+    amax = _new(x, n, c, dtype=torch.int32)
+    sc = _new(x, n, c)
+    maps = _new(x, n, 2, h, w)
+    pooled = _new(x, n, c, h // 2, w // 2)
+    out_t, o_bs = _planes(out)
+    assert out_t is out, "cbam: the output slice must have dense [C][H][W] planes"
+    rc = L.smaat_cbam_chpool_pool_t(_ptr(x), x_bs, None, None, None, 0, _ptr(pooled), c * (h // 2) * (w // 2), n, c, h, w,
+                                    _ptr(avg), _ptr(mx), _ptr(amax), _dt(x), _stream(x))
+    if rc == -2:
+        return None
+    _lib.check(rc, "smaat_cbam_chpool_pool_t")
+    side.wait_stream(torch.cuda.current_stream(x.device))
+    ss = side.cuda_stream
+    _lib.check(L.smaat_cbam_eval_pool(_ptr(x), x_bs, _ptr(avg), _ptr(mx), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), n, c,
+                                      cr, p, _ptr(sc), _ptr(maps), ss), "smaat_cbam_eval_pool")
+    _lib.check(L.smaat_cbam_eval_apply(_ptr(x), x_bs, _ptr(sc), _ptr(maps), _ptr(wconv), wconv.shape[-1], _ptr(gamma),
+                                       _ptr(beta), _ptr(rm), _ptr(rv), float(eps), n, c, h, w, _ptr(out), o_bs,
+                                       None, 0, ss), "smaat_cbam_eval_apply")
+    return pooled, (x, avg, mx, amax, sc, maps, w1, w2, wconv, out)
+
+
 class _CBAM(torch.autograd.Function):
     """out = spatial_att(channel_att(x)); either half can be switched off (standalone
     ChannelAttention / SpatialAttention modules reuse the same kernels)."""

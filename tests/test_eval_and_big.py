@@ -258,7 +258,9 @@ def test_big_cases_gpu(golden_dir, name, policy, monkeypatch):
 @pytest.mark.gpu
 def test_module_owned_eval_graph(golden_dir):
     """SmaAt_UNet.enable_eval_graph(): the inference forward as one hipGraph owned by the module -- replay equals the
-    eager fast path bit for bit and the reference fixture to 1e-4; a weight update rebuilds the graph."""
+    eager fast path bit for bit (with the opt-in forked attention branches: to the f32 summation order of the channel
+    means, the one-pass pooling kernel adds the same terms in another order) and the reference fixture to 1e-4; a weight
+    update rebuilds the graph."""
     dev = torch.device("cuda:0")
     g = np.load(os.path.join(golden_dir, "unet_12x1_n3_64x48_eval.npz"))
     meta = json.loads(str(g["meta"]))
@@ -278,6 +280,18 @@ def test_module_owned_eval_graph(golden_dir):
         y2 = model(xb[:1])          # another shape: a second graph
         y3 = model(xb)              # replay of the first
     assert torch.equal(y1, eager) and torch.equal(y3, eager) and torch.equal(y2, eager[:1])
+    model.FORK_ATTENTION = True      # (instance attribute; opt-in) the skip connections' attention as parallel graph branches
+    model.enable_eval_graph()
+    with torch.no_grad():
+        f1 = model(xb)
+        f2 = model(xb)
+    assert torch.equal(f1, f2)
+    assert float((f1 - eager).abs().max()) <= 2e-6 * float(eager.abs().max())
+    del model.FORK_ATTENTION
+    model.enable_eval_graph()
+    with torch.no_grad():
+        model(xb)
+        model(xb[:1])
     assert check_summary(g, "eval/logits", y1.cpu().numpy()) < 1e-4
     assert len(model._graphs) == 2
     with torch.no_grad():
