@@ -11,9 +11,12 @@
  *  - all tensors are float32 (bf16 storage: the "mixed precision" section), NCHW, device pointers; "plane" = H*W contiguous floats;
  *    channel stride = H*W; batch stride is passed explicitly (`*_bs`, in elements) so
  *    that a tensor may be a channel slice of a larger concatenation buffer.
- *  - no allocation, no synchronisation, no global state inside: workspaces are passed in,
- *    kernels are enqueued on `stream` (a hipStream_t).
- *  - return value: 0 = ok, >0 = hipError_t, -1 = unsupported argument.
+ *  - no allocation, no synchronisation inside: workspaces are passed in, kernels are enqueued on `stream` (a
+ *    hipStream_t).  Element types are per-call arguments (dtype codes of the "mixed precision" section).  ONE process-wide
+ *    setting exists: smaat_set_split_mode, the A/B switch of the f32-storage matrix path (exact three-term split | single
+ *    bf16 term); hosts that need both in one process call it around the launches concerned (it is read at launch time).
+ *  - return value: 0 = ok, >0 = hipError_t, -1 = invalid argument, -2 = shape / alignment not taken by this entry point
+ *    (the caller uses the general one; documented per entry point).
  */
 #ifndef SMAAT_HIP_H
 #define SMAAT_HIP_H
