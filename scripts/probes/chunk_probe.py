@@ -19,6 +19,7 @@ N = int(os.environ.get("CP_BATCH", "32"))
 L = _lib.get()
 dev = torch.device("cuda:0")
 st = torch.cuda.current_stream().cuda_stream
+sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
 
 
 def timeit(fn, iters=4):
@@ -71,5 +72,21 @@ for name, cin, cout, h in LAYERS:
                 assert L.smaat_dw3x3_bwd(x[n0:].data_ptr(), cin * p, dy[n0:].data_ptr(), k * p, w_dw.data_ptr(), dx[n0:].data_ptr(),
                                          cin * p, ws2.data_ptr(), dwd.data_ptr(), dbd.data_ptr(), c, cin, 2, h, w, st) == 0
 
-        line += f"  c={c:2d}: fwd {timeit(fwd):6.3f} bwd {timeit(bwd):6.3f} |"
+        def fwd2():  # producer on stream A, consumer on stream B, chunk-granular events: launches overlap across chunks
+            cur = torch.cuda.current_stream()
+            sa.wait_stream(cur)
+            sb.wait_stream(cur)
+            for n0 in range(0, N, c):
+                assert L.smaat_dw3x3_fwd(x[n0:].data_ptr(), cin * p, None, None, w_dw.data_ptr(), b_dw.data_ptr(),
+                                         y[n0:].data_ptr(), k * p, c, cin, 2, h, w, sa.cuda_stream) == 0
+                ev = torch.cuda.Event()
+                ev.record(sa)
+                sb.wait_event(ev)
+                assert L.smaat_pointwise_fwd_split(y[n0:].data_ptr(), k * p, pl_f.data_ptr(), b_pw.data_ptr(), z[n0:].data_ptr(),
+                                                   cout * p, part.data_ptr(), c, k, cout, h, w, sb.cuda_stream) == 0
+            cur.wait_stream(sa)
+            cur.wait_stream(sb)
+
+        two = f" 2-stream fwd {timeit(fwd2):6.3f}" if (os.environ.get("CP_TWO", "1") == "1" and c < N) else ""
+        line += f"  c={c:2d}: fwd {timeit(fwd):6.3f} bwd {timeit(bwd):6.3f}{two} |"
     print(line, flush=True)
