@@ -257,6 +257,9 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const TX* __restrict__ x
 // The loads of a step are issued at its start and consumed in the same step: the latency is covered by occupancy (a
 // variant that kept the next row in flight needed 128 VGPRs + spills and ran 1.4x slower; profiles/r2/dw_bench_r2m).
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef DWR_BWD_PREFETCH
+#define DWR_BWD_PREFETCH 1
+#endif
 #ifndef DWR_BWD_WAVES
 #define DWR_BWD_WAVES 4  // 5 needs spills (18 VGPRs) and runs 1.3x slower; profiles/r2/dw_bench_r2n
 #endif
@@ -310,6 +313,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAV
         float d[KPL][6];
         DwrRaw<TG> raw[KPL];
         typename Elem<TX>::raw4 xn;
+        // PF (bf16 gradients): the loads of step k + 1 are issued at the start of step k.  The raw rows of a bf16 step are
+        // 8 registers, so the second set fits the 128-VGPR budget of four waves per SIMD; with f32 rows it spilled
+        // (profiles/r2/dw_bench_rows_prefetch_r2m.txt).
+        constexpr bool PF = DWR_BWD_PREFETCH && sizeof(TG) == 2 && sizeof(TX) == 2;
+        DwrRaw<TG> nraw[PF ? KPL : 1];
+        typename Elem<TX>::raw4 nxn;
+        if constexpr (PF) {
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) nraw[j] = dwr_issue(dyp + (long)j * g.P, r0 - 1, g.H, g.W, ln);
+            nxn = dwr_issue4(xp, r0, g.H, g.W, ln);
+        }
 #pragma unroll
         for (int s_ = 0; s_ < 3; ++s_)
 #pragma unroll
@@ -326,10 +340,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAV
                 if (k < g.BH + 2) {
                     const int rho = r0 - 1 + k;
                     const int sa = u % 3, sb = (u + 1) % 3, sc_ = (u + 2) % 3;
-                    // issue: dY row rho, x row rho + 1
+                    if constexpr (PF) {  // consume the rows issued one step ago, issue the next step's (rows are clamped)
 #pragma unroll
-                    for (int j = 0; j < KPL; ++j) raw[j] = dwr_issue(dyp + (long)j * g.P, rho, g.H, g.W, ln);
-                    xn = dwr_issue4(xp, rho + 1, g.H, g.W, ln);
+                        for (int j = 0; j < KPL; ++j) raw[j] = nraw[j];
+                        xn = nxn;
+#pragma unroll
+                        for (int j = 0; j < KPL; ++j) nraw[j] = dwr_issue(dyp + (long)j * g.P, rho + 1, g.H, g.W, ln);
+                        nxn = dwr_issue4(xp, rho + 2, g.H, g.W, ln);
+                    } else {  // issue: dY row rho, x row rho + 1
+#pragma unroll
+                        for (int j = 0; j < KPL; ++j) raw[j] = dwr_issue(dyp + (long)j * g.P, rho, g.H, g.W, ln);
+                        xn = dwr_issue4(xp, rho + 1, g.H, g.W, ln);
+                    }
 #pragma unroll
                     for (int j = 0; j < KPL; ++j) dwr_pin(raw[j]);
                     dwr_pin(xn);
