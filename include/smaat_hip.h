@@ -332,6 +332,18 @@ int smaat_pointwise_fwd_bf16(const void* x, long x_bs, const void* planes, const
  * nn.Conv2d); ws: [smaat_wgrad_num_splits(N,H,W,M,Cin)][M][Cin] floats, dw_out [M][Cin]. */
 int smaat_pointwise_wgrad_bf16(const void* y, long y_bs, const void* dz, long dz_bs, float* ws, float* dw_out, int N,
                                int Cin, int M, int H, int W, void* stream);
+/* ---- depthwise convolution of ANY geometry DepthwiseSeparableConv can be constructed with (models/layers.py:35-45:
+ *      nn.Conv2d(Cin, Cin * kpl, kernel_size, padding=padding, groups=Cin); stride 1, dilation 1, any kpl >= 1), f32.
+ *      The network's own 3 x 3 / padding 1 / kpl in {1, 2, 4} layers use smaat_dw3x3_*; this is the general form behind the
+ *      same module (direct gather kernels, deterministic reductions; coverage, not a roofline kernel).
+ *   x [N][Cin][H][W]; w_dw [Cin*kpl][KH][KW]; b_dw [Cin*kpl] (nullable); y, dy [N][Cin*kpl][Ho][Wo],
+ *   Ho = H + 2 pad_h - KH + 1, Wo = W + 2 pad_w - KW + 1  (-1 when that is < 1)
+ *   bwd: dx (nullable) [N][Cin][H][W]; dw_out (nullable) [Cin*kpl][KH][KW]; db_out (nullable, needs dw_out) [Cin*kpl] */
+int smaat_dwconv_fwd_any(const float* x, long x_bs, const float* w_dw, const float* b_dw, float* y, long y_bs, int N, int Cin,
+                         int kpl, int H, int W, int KH, int KW, int pad_h, int pad_w, void* stream);
+int smaat_dwconv_bwd_any(const float* x, long x_bs, const float* dy, long dy_bs, const float* w_dw, float* dx, long dx_bs,
+                         float* dw_out, float* db_out, int N, int Cin, int kpl, int H, int W, int KH, int KW, int pad_h,
+                         int pad_w, void* stream);
 /* typed smaat_dw3x3_fwd (models/layers.py:38-44,48): (x_dt, y_dt) in {(f32,f32), (f32,bf16), (bf16,bf16)} */
 int smaat_dw3x3_fwd_t(const void* x, int x_dt, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
                       const float* b_dw, void* y, int y_dt, long y_bs, int N, int Cin, int kpl, int H, int W,

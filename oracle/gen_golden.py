@@ -121,6 +121,29 @@ def gen_ops():
     print("ops.npz:", len(s), "arrays")
 
 
+GENERIC_DSCONV = {  # tag: (ctor arguments of the reference's DepthwiseSeparableConv, input shape)
+    "dsconv_g5": (dict(in_channels=4, output_channels=6, kernel_size=5, padding=2, kernels_per_layer=3), (2, 4, 9, 10)),
+    "dsconv_g3p0": (dict(in_channels=5, output_channels=7, kernel_size=3), (2, 5, 8, 9)),  # the module's defaults
+    "dsconv_g1": (dict(in_channels=6, output_channels=4, kernel_size=1, padding=0, kernels_per_layer=2), (2, 6, 5, 7)),
+    "dsconv_g7p1": (dict(in_channels=3, output_channels=5, kernel_size=7, padding=1, kernels_per_layer=5), (1, 3, 12, 11)),
+    "dsconv_g3k3": (dict(in_channels=4, output_channels=8, kernel_size=3, padding=1, kernels_per_layer=3), (2, 4, 8, 8)),
+    "dsconv_g3p2": (dict(in_channels=2, output_channels=3, kernel_size=3, padding=2, kernels_per_layer=2), (1, 2, 6, 4)),
+}
+
+
+def gen_ops_generic():
+    """DepthwiseSeparableConv outside the 3x3 / padding 1 / kpl in {1, 2, 4} configuration the network uses
+    (models/layers.py:35-45 accepts any kernel_size / padding / kernels_per_layer)"""
+    rng = np.random.default_rng(4242)
+    s = {}
+    for tag, (kw, shape) in GENERIC_DSCONV.items():
+        module_case(s, tag, DepthwiseSeparableConv(**kw), [rng.standard_normal(shape).astype(np.float32)], rng)
+    # a whole block at a kernels_per_layer the fused kernels are not built for (the reference accepts any integer)
+    module_case(s, "doubleconv_k3", DoubleConvDS(5, 8, kernels_per_layer=3), [rng.standard_normal((2, 5, 8, 10)).astype(np.float32)], rng)
+    np.savez_compressed(os.path.join(OUT, "ops_generic.npz"), **s)
+    print("ops_generic.npz:", len(s), "arrays")
+
+
 def module_case_eval(store, tag, mod, inputs, rng):
     """eval-mode counterpart of module_case (reference call stack D: model.eval() inference, and fine-tuning with
     frozen statistics): random parameters AND random running statistics, forward + backward with a random
@@ -708,6 +731,7 @@ if __name__ == "__main__":
     gen_ops()
     gen_ops_eval()
     gen_ops_strict()
+    gen_ops_generic()
     # benchmark-size cases, train + eval mode (inputs regenerated from the seed, summaries only)
     gen_unet_big("unet_12x1_n2_288", "precip", 12, 1, 2, 288, 288, 7)        # BASELINE configs[1] shape
     gen_unet_big("unet_3x21_n2_256", "voc", 3, 21, 2, 256, 256, 8)           # BASELINE configs[4] shape, CE loss

@@ -66,6 +66,51 @@ def dw3x3_bwd(x, w, dy, kpl):
 
 
 # --------------------------------------------------------------------------- #
+# depthwise convolution of any geometry  (reference: models/layers.py:35-45: the module is generic in
+#   kernel_size / padding / kernels_per_layer; nn.Conv2d(Cin, Cin*kpl, k, padding=p, groups=Cin), stride 1)
+#   pinned by tests/golden/ops_generic.npz (the reference module at 5x5/pad 2/kpl 3, 3x3/pad 0/kpl 1, 1x1, 7x7/pad 1/kpl 5)
+# --------------------------------------------------------------------------- #
+
+
+def dwconv_fwd(x, w, b, kpl, pad):
+    n, cin, h, wd = x.shape
+    cdw, _, kh, kw = w.shape
+    assert cdw == cin * kpl
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    ho, wo = h + 2 * ph - kh + 1, wd + 2 * pw - kw + 1
+    xp = np.zeros((n, cin, h + 2 * ph, wd + 2 * pw), x.dtype)
+    xp[:, :, ph:ph + h, pw:pw + wd] = x
+    xe = np.repeat(xp, kpl, axis=1)
+    y = np.zeros((n, cdw, ho, wo), x.dtype)
+    for i in range(kh):
+        for j in range(kw):
+            y += w[None, :, 0, i, j, None, None] * xe[:, :, i:i + ho, j:j + wo]
+    if b is not None:
+        y += b[None, :, None, None]
+    return y
+
+
+def dwconv_bwd(x, w, dy, kpl, pad):
+    """returns dx, dw, db"""
+    n, cin, h, wd = x.shape
+    cdw, _, kh, kw = w.shape
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    ho, wo = dy.shape[2], dy.shape[3]
+    xp = np.zeros((n, cin, h + 2 * ph, wd + 2 * pw), x.dtype)
+    xp[:, :, ph:ph + h, pw:pw + wd] = x
+    xe = np.repeat(xp, kpl, axis=1)
+    dwgt = np.zeros_like(w)
+    dxe = np.zeros_like(xe)
+    for i in range(kh):
+        for j in range(kw):
+            dwgt[:, 0, i, j] = np.einsum("nchw,nchw->c", dy, xe[:, :, i:i + ho, j:j + wo])
+            dxe[:, :, i:i + ho, j:j + wo] += w[None, :, 0, i, j, None, None] * dy
+    dxp = dxe.reshape(n, cin, kpl, h + 2 * ph, wd + 2 * pw).sum(axis=2)
+    dx = dxp[:, :, ph:ph + h, pw:pw + wd].copy()
+    return dx, dwgt, dy.sum(axis=(0, 2, 3))
+
+
+# --------------------------------------------------------------------------- #
 # pointwise 1x1  (reference: models/layers.py:45, called :49;
 #                 OutConv models/unet_parts.py:67-73)
 # --------------------------------------------------------------------------- #

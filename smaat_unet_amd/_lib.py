@@ -102,6 +102,8 @@ SIGNATURES = {
     "smaat_upsample2x_fwd_t": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "smaat_upsample2x_bwd_t": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "smaat_cbam_chpool_t": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _I, _P],
+    "smaat_dwconv_fwd_any": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "smaat_dwconv_bwd_any": [_P, _L, _P, _L, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "smaat_cbam_chpool_pool_t": [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "smaat_cbam_sppool_t": [_P, _L, _P, _I, _I, _I, _P, _I, _P],
     "smaat_cbam_apply_t": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P],

@@ -51,6 +51,10 @@ int smaat_cbam_spconv_blocks_impl(int N, int H, int W);
 int smaat_cbam_pix_blocks_impl(int N, int P);
 int launch_cbam_chpool(const void*, long, int, int, int, float*, float*, int*, hipStream_t, const float* = nullptr,
                        const float* = nullptr, void* = nullptr, long = 0, int dt = SMAAT_F32);
+int launch_dwconv_fwd_any(const float*, long, const float*, const float*, float*, long, int, int, int, int, int, int, int, int,
+                          int, hipStream_t);
+int launch_dwconv_bwd_any(const float*, long, const float*, long, const float*, float*, long, float*, float*, int, int, int,
+                          int, int, int, int, int, int, hipStream_t);
 int launch_cbam_chpool_pool(const void*, long, int, int, int, int, float*, float*, int*, hipStream_t, const float*,
                             const float*, void*, long, void*, long, int);
 int launch_cbam_mlp(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int,
@@ -506,6 +510,17 @@ int smaat_pointwise_wgrad_bf16(const void* y, long y_bs, const void* dz, long dz
     hipStream_t st = ST;
     CHK(launch_wgrad_bf16(a, st));
     return launch_reduce_rows(ws, a.nsplit, (long)M * Cin, dw_out, 1.f, st);
+}
+int smaat_dwconv_fwd_any(const float* x, long x_bs, const float* w_dw, const float* b_dw, float* y, long y_bs, int N, int Cin,
+                         int kpl, int H, int W, int KH, int KW, int pad_h, int pad_w, void* stream) {
+    if (!x || !w_dw || !y) return -1;
+    return launch_dwconv_fwd_any(x, x_bs, w_dw, b_dw, y, y_bs, N, Cin, kpl, H, W, KH, KW, pad_h, pad_w, ST);
+}
+int smaat_dwconv_bwd_any(const float* x, long x_bs, const float* dy, long dy_bs, const float* w_dw, float* dx, long dx_bs,
+                         float* dw_out, float* db_out, int N, int Cin, int kpl, int H, int W, int KH, int KW, int pad_h,
+                         int pad_w, void* stream) {
+    if (!x || !dy || !w_dw || (db_out && !dw_out)) return -1;
+    return launch_dwconv_bwd_any(x, x_bs, dy, dy_bs, w_dw, dx, dx_bs, dw_out, db_out, N, Cin, kpl, H, W, KH, KW, pad_h, pad_w, ST);
 }
 int smaat_dw3x3_fwd_t(const void* x, int x_dt, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
                       const float* b_dw, void* y, int y_dt, long y_bs, int N, int Cin, int kpl, int H, int W,

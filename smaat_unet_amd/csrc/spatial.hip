@@ -1221,3 +1221,132 @@ int launch_dw_reduce_split(const float* part, int rows, int Cdw, float* dw, floa
     return (int)hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Depthwise convolution of ANY geometry the reference's DepthwiseSeparableConv can be constructed with
+// (models/layers.py:35-45: nn.Conv2d(Cin, Cin * kpl, kernel_size, padding=padding, groups=Cin), stride 1, dilation 1;
+// any kernels_per_layer).  The 3x3 / padding-1 / kpl in {1, 2, 4} configuration of the network has its own kernels
+// above and in dwrows.hip; this is the general form behind the same module, written for coverage, not for the roofline:
+// direct gather kernels, one thread per output element, weights through the scalar cache.
+//   Ho = H + 2 ph - KH + 1, Wo = W + 2 pw - KW + 1
+//   y[n][k][oh][ow]  = b[k] + sum_{th,tw} w[k][th][tw] * x[n][k / kpl][oh + th - ph][ow + tw - pw]
+//   dx[n][c][h][w]   = sum_{j<kpl} sum_{th,tw} w[c kpl + j][th][tw] * dy[n][c kpl + j][h - th + ph][w - tw + pw]
+//   dw[k][th][tw]    = sum_{n,oh,ow} dy[n][k][oh][ow] * x[n][k / kpl][oh + th - ph][ow + tw - pw],   db[k] = sum dy[n][k]
+// The weight gradient runs one workgroup per (output channel, tap) -- tap KH*KW is the bias -- and reduces over the batch
+// and the plane in a fixed order (thread-strided partial sums, wave sums, fp64 across the four waves): deterministic.
+// ---------------------------------------------------------------------------------------------------------------
+struct DwgGeom {
+    int N, Cin, kpl, H, W, KH, KW, ph, pw, Ho, Wo;
+};
+
+__global__ __launch_bounds__(256) void k_dwconv_fwd_any(const float* __restrict__ x, long x_bs, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ y, long y_bs,
+                                                        const DwgGeom g) {
+    const int k = blockIdx.y, n = blockIdx.z, c = k / g.kpl;
+    const int po = blockIdx.x * 256 + threadIdx.x;
+    if (po >= g.Ho * g.Wo) return;
+    const int oh = po / g.Wo, ow = po - oh * g.Wo;
+    const float* xp = x + (long)n * x_bs + (long)c * g.H * g.W;
+    const float* wk = w + (long)k * g.KH * g.KW;
+    float acc = b ? b[k] : 0.f;
+    for (int th = 0; th < g.KH; ++th) {
+        const int ih = oh + th - g.ph;
+        if (ih < 0 || ih >= g.H) continue;
+        for (int tw = 0; tw < g.KW; ++tw) {
+            const int iw = ow + tw - g.pw;
+            if (iw >= 0 && iw < g.W) acc = fmaf(wk[th * g.KW + tw], xp[(long)ih * g.W + iw], acc);
+        }
+    }
+    y[(long)n * y_bs + (long)k * g.Ho * g.Wo + po] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_dwconv_bwd_dx_any(const float* __restrict__ dy, long dy_bs,
+                                                           const float* __restrict__ w, float* __restrict__ dx, long dx_bs,
+                                                           const DwgGeom g) {
+    const int c = blockIdx.y, n = blockIdx.z;
+    const int pi = blockIdx.x * 256 + threadIdx.x;
+    if (pi >= g.H * g.W) return;
+    const int h = pi / g.W, wc = pi - h * g.W;
+    float acc = 0.f;
+    for (int j = 0; j < g.kpl; ++j) {
+        const int k = c * g.kpl + j;
+        const float* gp = dy + (long)n * dy_bs + (long)k * g.Ho * g.Wo;
+        const float* wk = w + (long)k * g.KH * g.KW;
+        for (int th = 0; th < g.KH; ++th) {
+            const int oh = h - th + g.ph;
+            if (oh < 0 || oh >= g.Ho) continue;
+            for (int tw = 0; tw < g.KW; ++tw) {
+                const int ow = wc - tw + g.pw;
+                if (ow >= 0 && ow < g.Wo) acc = fmaf(wk[th * g.KW + tw], gp[(long)oh * g.Wo + ow], acc);
+            }
+        }
+    }
+    dx[(long)n * dx_bs + (long)c * g.H * g.W + pi] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_dwconv_bwd_w_any(const float* __restrict__ x, long x_bs, const float* __restrict__ dy,
+                                                          long dy_bs, float* __restrict__ dw, float* __restrict__ db,
+                                                          const DwgGeom g) {
+    __shared__ float red[4];
+    const int k = blockIdx.y, tap = blockIdx.x, c = k / g.kpl, KK = g.KH * g.KW;
+    const bool bias = tap == KK;
+    const int th = bias ? 0 : tap / g.KW, tw = bias ? 0 : tap - th * g.KW;
+    const int Po = g.Ho * g.Wo;
+    float s = 0.f;
+    for (int n = 0; n < g.N; ++n) {
+        const float* gp = dy + (long)n * dy_bs + (long)k * Po;
+        const float* xp = x + (long)n * x_bs + (long)c * g.H * g.W;
+        for (int po = threadIdx.x; po < Po; po += 256) {
+            const float gv = gp[po];
+            if (bias) {
+                s += gv;
+            } else {
+                const int oh = po / g.Wo, ow = po - oh * g.Wo;
+                const int ih = oh + th - g.ph, iw = ow + tw - g.pw;
+                if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) s = fmaf(gv, xp[(long)ih * g.W + iw], s);
+            }
+        }
+    }
+    s = wave_sum_l63(s);
+    if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (float)(((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]));
+        if (bias) {
+            if (db) db[k] = t;
+        } else {
+            dw[(long)k * KK + tap] = t;
+        }
+    }
+}
+
+static int dwg_geom(DwgGeom& g, int N, int Cin, int kpl, int H, int W, int KH, int KW, int ph, int pw) {
+    if (N < 1 || Cin < 1 || kpl < 1 || H < 1 || W < 1 || KH < 1 || KW < 1 || ph < 0 || pw < 0) return -1;
+    g = DwgGeom{N, Cin, kpl, H, W, KH, KW, ph, pw, H + 2 * ph - KH + 1, W + 2 * pw - KW + 1};
+    if (g.Ho < 1 || g.Wo < 1) return -1;
+    if ((long)Cin * kpl > 65535 || N > 65535 || (long)H * W >= (1L << 31) || (long)g.Ho * g.Wo >= (1L << 31)) return -2;
+    return 0;
+}
+
+int launch_dwconv_fwd_any(const float* x, long x_bs, const float* w, const float* b, float* y, long y_bs, int N, int Cin,
+                          int kpl, int H, int W, int KH, int KW, int ph, int pw, hipStream_t st) {
+    DwgGeom g;
+    const int rc = dwg_geom(g, N, Cin, kpl, H, W, KH, KW, ph, pw);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_dwconv_fwd_any, dim3(cdivs((long)g.Ho * g.Wo, 256), Cin * kpl, N), dim3(256), 0, st, x, x_bs, w, b, y,
+                       y_bs, g);
+    return (int)hipGetLastError();
+}
+
+int launch_dwconv_bwd_any(const float* x, long x_bs, const float* dy, long dy_bs, const float* w, float* dx, long dx_bs,
+                          float* dw, float* db, int N, int Cin, int kpl, int H, int W, int KH, int KW, int ph, int pw,
+                          hipStream_t st) {
+    DwgGeom g;
+    const int rc = dwg_geom(g, N, Cin, kpl, H, W, KH, KW, ph, pw);
+    if (rc) return rc;
+    if (dx)
+        hipLaunchKernelGGL(k_dwconv_bwd_dx_any, dim3(cdivs((long)H * W, 256), Cin, N), dim3(256), 0, st, dy, dy_bs, w, dx, dx_bs, g);
+    if (dw)
+        hipLaunchKernelGGL(k_dwconv_bwd_w_any, dim3(KH * KW + 1, Cin * kpl), dim3(256), 0, st, x, x_bs, dy, dy_bs, dw, db, g);
+    return (int)hipGetLastError();
+}

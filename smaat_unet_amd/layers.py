@@ -58,8 +58,10 @@ def _bn_args(bn: nn.BatchNorm2d):
 
 
 class DepthwiseSeparableConv(nn.Module):
-    """reference: models/layers.py:34-50.  Only the 3x3 / padding=1 configuration used by
-    DoubleConvDS is accelerated; other kernel sizes are rejected."""
+    """reference: models/layers.py:34-50.  The 3x3 / padding 1 / kernels_per_layer in {1, 2, 4} configuration every network
+    of the reference uses runs on the fused / row-streaming kernels; any other kernel_size, padding or
+    kernels_per_layer the reference's constructor accepts runs on the general depthwise kernels
+    (`smaat_dwconv_*_any`, f32) followed by the pointwise GEMM."""
 
     def __init__(self, in_channels, output_channels, kernel_size, padding=0, kernels_per_layer=1):
         super().__init__()
@@ -72,18 +74,27 @@ class DepthwiseSeparableConv(nn.Module):
         )
         self.pointwise = nn.Conv2d(in_channels * kernels_per_layer, output_channels, kernel_size=1)
         self.kernels_per_layer_ = kernels_per_layer
-        if kernels_per_layer not in (1, 2, 4):  # the reference accepts any integer; its scripts use 1, 2 and 4
-            raise NotImplementedError(f"kernels_per_layer={kernels_per_layer}: the gfx950 kernels are built for 1, 2, 4")
+
+    def _fast_geometry(self):
+        """the configuration the fused kernels are built for (and the only one DoubleConvDS constructs)"""
+        dw = self.depthwise
+        return (dw.kernel_size == (3, 3) and dw.padding == (1, 1) and dw.stride == (1, 1) and dw.dilation == (1, 1)
+                and self.kernels_per_layer_ in (1, 2, 4))
 
     def _check_geometry(self):
-        dw = self.depthwise
-        if dw.kernel_size != (3, 3) or dw.padding != (1, 1) or dw.stride != (1, 1) or dw.dilation != (1, 1):
-            raise NotImplementedError("smaat_unet_amd accelerates depthwise 3x3, stride 1, padding 1 only")
+        if not self._fast_geometry():
+            raise NotImplementedError("the fused DoubleConvDS kernels take depthwise 3x3, stride 1, padding 1, "
+                                      "kernels_per_layer in {1, 2, 4}")
 
     def forward(self, x):
-        self._check_geometry()
-        return ops.dsconv(x, self.depthwise.weight, self.depthwise.bias, self.pointwise.weight, self.pointwise.bias,
-                          self.kernels_per_layer_)
+        dw = self.depthwise
+        if self._fast_geometry():
+            return ops.dsconv(x, dw.weight, dw.bias, self.pointwise.weight, self.pointwise.bias, self.kernels_per_layer_)
+        if dw.stride != (1, 1) or dw.dilation != (1, 1) or not isinstance(dw.padding, tuple) or dw.padding_mode != "zeros":
+            raise NotImplementedError("depthwise stride / dilation / string padding modes: not constructible through "
+                                      "DepthwiseSeparableConv.__init__ and not built")
+        y = ops.depthwise_any(x, dw.weight, dw.bias, self.kernels_per_layer_, dw.padding[0], dw.padding[1])
+        return ops.pointwise(y, self.pointwise.weight, self.pointwise.bias)
 
 
 class Flatten(nn.Module):

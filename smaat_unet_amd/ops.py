@@ -973,6 +973,117 @@ def dsconv(x, w_dw, b_dw, w_pw, b_pw, kpl):
 
 
 # --------------------------------------------------------------------------------------
+# depthwise convolution of any geometry (DepthwiseSeparableConv outside the network's 3x3 / padding 1 / kpl in {1, 2, 4})
+# --------------------------------------------------------------------------------------
+class _DepthwiseAny(torch.autograd.Function):
+    """reference models/layers.py:38-44,48 for any kernel_size / padding / kernels_per_layer (stride 1, dilation 1); f32"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, kpl, ph, pw):
+        _check(x, w, b)
+        if x.dim() != 4:
+            raise ValueError(f"input: expected [N, C, H, W], got {tuple(x.shape)}")
+        if x.dtype != F32:
+            raise NotImplementedError("the general depthwise kernels are f32 only (mixed precision covers the 3x3 / padding 1 "
+                                      "layers of the network)")
+        n, cin, h, wd = x.shape
+        _expect(w, (cin * kpl, 1, None, None), "depthwise.weight")
+        _expect(b, (cin * kpl,), "depthwise.bias")
+        kh, kw = w.shape[2], w.shape[3]
+        ho, wo = h + 2 * ph - kh + 1, wd + 2 * pw - kw + 1
+        if ho < 1 or wo < 1:
+            raise RuntimeError(f"Calculated padded input size per channel: ({h + 2 * ph} x {wd + 2 * pw}). Kernel size: "
+                               f"({kh} x {kw}). Kernel size can't be greater than actual input size")
+        L = _lib.get()
+        x, x_bs = _planes(x)
+        w = w.contiguous()
+        y = _new(x, n, cin * kpl, ho, wo)
+        _lib.check(L.smaat_dwconv_fwd_any(_ptr(x), x_bs, _ptr(w), _ptr(b), _ptr(y), cin * kpl * ho * wo, n, cin, kpl, h, wd, kh,
+                                          kw, ph, pw, _stream(x)), "smaat_dwconv_fwd_any")
+        ctx.save_for_backward(x, w)
+        ctx.geom = (kpl, ph, pw, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        kpl, ph, pw, has_b = ctx.geom
+        L = _lib.get()
+        x, x_bs = _planes(x)
+        dy, dy_bs = _planes(dy.float())
+        n, cin, h, wd = x.shape
+        kh, kw = w.shape[2], w.shape[3]
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2])
+        dx = _new(x, n, cin, h, wd) if need_x else None
+        dw = _new(x, *w.shape) if need_w else None
+        db = _new(x, cin * kpl) if (need_w and has_b) else None
+        _lib.check(L.smaat_dwconv_bwd_any(_ptr(x), x_bs, _ptr(dy), dy_bs, _ptr(w), _ptr(dx), cin * h * wd, _ptr(dw), _ptr(db), n,
+                                          cin, kpl, h, wd, kh, kw, ph, pw, _stream(x)), "smaat_dwconv_bwd_any")
+        return dx, dw, db, None, None, None
+
+
+def depthwise_any(x, w, b, kpl, ph, pw):
+    return _DepthwiseAny.apply(x, w, b, kpl, ph, pw)
+
+
+class _PointwiseBNReLU(torch.autograd.Function):
+    """nn.Conv2d(K, M, 1) -> BatchNorm2d -> ReLU behind a general depthwise stage (a DoubleConvDS half whose
+    DepthwiseSeparableConv is outside the fused configuration; reference unet_parts_depthwise_separable.py:17-36):
+    f32-MFMA GEMM with the statistics partials in its epilogue, finalize, one apply pass; f32."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, rm, rv, training, momentum, eps):
+        _check(x, w, b, gamma, beta, rm, rv)
+        _expect(w, (None, x.shape[1], 1, 1), "pointwise.weight")
+        m, c = w.shape[0], w.shape[1]
+        _expect(b, (m,), "pointwise.bias")
+        for nm, t in (("bn.weight", gamma), ("bn.bias", beta), ("bn.running_mean", rm), ("bn.running_var", rv)):
+            _expect(t, (m,), nm)
+        if x.dtype != F32:
+            raise NotImplementedError("general DepthwiseSeparableConv geometries are f32 only")
+        L = _lib.get()
+        w = w.contiguous()
+        x, x_bs = _planes(x)
+        n, _, h, wd = x.shape
+        use_batch_stats = training or rm is None
+        wt = w.reshape(m, c).t().contiguous()
+        if use_batch_stats:
+            z = _new(x, n, m, h, wd)
+            slots = L.smaat_pw_num_slots(n, h, wd, m)
+            part = _new(x, 3, slots, m)
+            _lib.check(L.smaat_pointwise_fwd(_ptr(x), x_bs, _ptr(wt), _ptr(b), _ptr(z), m * h * wd, _ptr(part), n, c, m, h, wd,
+                                             _stream(x)), "smaat_pointwise_fwd")
+            st = _bn_finalize_raw(part, slots, m, n * h * wd, b, gamma, beta, eps, momentum if momentum is not None else 0.0,
+                                  rm if training else None, rv if training else None)
+        else:
+            z = _pointwise_raw(x, wt, b, m)
+            st = _bn_eval_coefs_raw(rm, rv, gamma, beta, eps)
+        y = _affine_act_raw(z, st[2], st[3], True)
+        ctx.save_for_backward(x, w, gamma, z, st)
+        ctx.flags = (use_batch_stats, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, gamma, z, st = ctx.saved_tensors
+        train_stats, has_bias = ctx.flags
+        m, c = w.shape[0], w.shape[1]
+        dz, dgamma, dbeta = _bn_bwd_raw(dy, z, st, gamma, True, train_stats)
+        dx = _pointwise_raw(dz, w.reshape(m, c), None, c) if ctx.needs_input_grad[0] else None
+        dw = _pointwise_wgrad_raw(x, dz, m).reshape(w.shape)
+        db = None
+        if has_bias:  # a bias in front of a train-mode BatchNorm has an exactly-zero gradient
+            db = torch.zeros_like(dgamma) if train_stats else _channel_sum_raw(dz)
+        if gamma is None:
+            dgamma = dbeta = None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None
+
+
+def pointwise_bn_relu(x, w, b, gamma, beta, rm, rv, training, momentum, eps):
+    return _PointwiseBNReLU.apply(x, w, b, gamma, beta, rm, rv, training, momentum, eps)
+
+
+# --------------------------------------------------------------------------------------
 # OutConv (plain 1x1)
 # --------------------------------------------------------------------------------------
 class _Pointwise(torch.autograd.Function):

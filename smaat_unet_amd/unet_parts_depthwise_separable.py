@@ -22,8 +22,13 @@ class DoubleConvDS(nn.Module):
 
     @staticmethod
     def _half(x, conv: DepthwiseSeparableConv, bn: nn.BatchNorm2d):
-        conv._check_geometry()
         g, b, rm, rv, training, momentum, eps = _bn_args(bn)
+        if not conv._fast_geometry():
+            # a kernels_per_layer (or, for a hand-built block, a kernel size / padding) outside the fused configuration:
+            # general depthwise kernels, then pointwise GEMM + BatchNorm + ReLU as one node
+            dw = conv.depthwise
+            y = ops.depthwise_any(x, dw.weight, dw.bias, conv.kernels_per_layer_, dw.padding[0], dw.padding[1])
+            return ops.pointwise_bn_relu(y, conv.pointwise.weight, conv.pointwise.bias, g, b, rm, rv, training, momentum, eps)
         return ops.dsconv_bn_relu(x, conv.depthwise.weight, conv.depthwise.bias, conv.pointwise.weight,
                                   conv.pointwise.bias, g, b, rm, rv, training, momentum, eps,
                                   conv.kernels_per_layer_)
@@ -69,6 +74,11 @@ class DoubleConvDS(nn.Module):
         hooked = any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks for m in seq.modules())
         import torch
         from . import train_ops
+        if not (seq[0]._fast_geometry() and seq[3]._fast_geometry()):
+            y = self._half(self._half(x, seq[0], seq[1]), seq[3], seq[4])  # half by half on the general kernels
+            if head is None:
+                return y
+            return ops.pointwise(y, head.weight, head.bias)
         if (train_ops.active() and torch.is_grad_enabled() and not hooked
                 and seq[0].kernels_per_layer_ == seq[3].kernels_per_layer_):
             # traceable wiring: the block as the custom operator smaat::double_conv_ds (no head / deferred-activation fusion)

@@ -429,6 +429,30 @@ class EmuLib:
         return 0
 
     # ------------------------------------------------------------------ pool / upsample
+    def smaat_dwconv_fwd_any(self, x, x_bs, w, b, y, y_bs, N, Cin, kpl, H, W, KH, KW, ph, pw, stream):
+        Ho, Wo = H + 2 * ph - KH + 1, W + 2 * pw - KW + 1
+        if Ho < 1 or Wo < 1:
+            return -1
+        K = Cin * kpl
+        xv = np.array(planes(x, N, Cin, H * W, x_bs)).reshape(N, Cin, H, W)
+        yv = O.dwconv_fwd(xv, f32(w, K * KH * KW).reshape(K, 1, KH, KW), f32(b, K) if b else None, kpl, (ph, pw))
+        planes(y, N, K, Ho * Wo, y_bs)[:] = yv.reshape(N, K, -1)
+        return 0
+
+    def smaat_dwconv_bwd_any(self, x, x_bs, dy, dy_bs, w, dx, dx_bs, dw, db, N, Cin, kpl, H, W, KH, KW, ph, pw, stream):
+        Ho, Wo = H + 2 * ph - KH + 1, W + 2 * pw - KW + 1
+        K = Cin * kpl
+        xv = np.array(planes(x, N, Cin, H * W, x_bs)).reshape(N, Cin, H, W)
+        gv = np.array(planes(dy, N, K, Ho * Wo, dy_bs)).reshape(N, K, Ho, Wo)
+        dxv, dwv, dbv = O.dwconv_bwd(xv, f32(w, K * KH * KW).reshape(K, 1, KH, KW), gv, kpl, (ph, pw))
+        if dx:
+            planes(dx, N, Cin, H * W, dx_bs)[:] = dxv.reshape(N, Cin, -1)
+        if dw:
+            f32(dw, K * KH * KW)[:] = dwv.reshape(-1)
+        if db:
+            f32(db, K)[:] = dbv
+        return 0
+
     def smaat_maxpool2_fwd(self, x, x_bs, y, y_bs, N, C, H, W, stream):
         xv = np.array(planes(x, N, C, H * W, x_bs)).reshape(N, C, H, W)
         yv, _ = O.maxpool2_fwd(xv)

@@ -71,6 +71,48 @@ def test_module_vs_reference_golden(ops, tag, ctor, zb):
     run_case(ops, tag, ctor(), zero_bias=zb)
 
 
+GENERIC_DSCONV = {  # tag: ctor arguments (the reference cases of oracle/gen_golden.py GENERIC_DSCONV)
+    "dsconv_g5": dict(in_channels=4, output_channels=6, kernel_size=5, padding=2, kernels_per_layer=3),
+    "dsconv_g3p0": dict(in_channels=5, output_channels=7, kernel_size=3),
+    "dsconv_g1": dict(in_channels=6, output_channels=4, kernel_size=1, padding=0, kernels_per_layer=2),
+    "dsconv_g7p1": dict(in_channels=3, output_channels=5, kernel_size=7, padding=1, kernels_per_layer=5),
+    "dsconv_g3k3": dict(in_channels=4, output_channels=8, kernel_size=3, padding=1, kernels_per_layer=3),
+    "dsconv_g3p2": dict(in_channels=2, output_channels=3, kernel_size=3, padding=2, kernels_per_layer=2),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(GENERIC_DSCONV) + ["doubleconv_k3"])
+def test_any_geometry_modules_vs_reference_golden(golden_dir, tag):
+    """the reference's DepthwiseSeparableConv accepts any kernel_size / padding / kernels_per_layer (models/layers.py:35-45):
+    outside the fused configuration the module runs the general depthwise kernels (smaat_dwconv_*_any) + the pointwise GEMM;
+    a DoubleConvDS at kernels_per_layer = 3 runs half by half"""
+    g = np.load(os.path.join(golden_dir, "ops_generic.npz"))
+    if tag == "doubleconv_k3":
+        run_case(g, tag, S.DoubleConvDS(5, 8, kernels_per_layer=3), zero_bias=True)
+    else:
+        run_case(g, tag, S.DepthwiseSeparableConv(**GENERIC_DSCONV[tag]), zero_bias=False)
+
+
+def test_network_at_kernels_per_layer_3_trains():
+    """SmaAt_UNet(kernels_per_layer=3): constructible in the reference, outside the fused kernels -- the network runs (general
+    path), matches the same weights evaluated by torch's own convolutions, and produces finite gradients for every parameter"""
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    model = S.SmaAt_UNet(4, 2, kernels_per_layer=3).to(DEV).train()
+    x = torch.randn(2, 4, 32, 32, device=DEV)
+    out = model(x)
+    assert out.shape == (2, 2, 32, 32)
+    out.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    # first half of the stem against torch: depthwise (groups) conv -> 1x1 conv
+    c0 = model.inc.double_conv[0]
+    cpu = lambda t: t.detach().cpu()  # noqa: E731  (torch's CPU convolutions: no MIOpen dependency on the box)
+    ref = F.conv2d(F.conv2d(cpu(x), cpu(c0.depthwise.weight), cpu(c0.depthwise.bias), padding=1, groups=4),
+                   cpu(c0.pointwise.weight), cpu(c0.pointwise.bias))
+    got = cpu(c0(x))
+    assert float((got - ref).norm() / ref.norm()) < 1e-5
+
+
 @pytest.mark.parametrize("name", VARIANTS)
 def test_sibling_networks_vs_reference_golden(golden_dir, name):
     """UNetDS / UNetDSAttention4CBAMs, kernels_per_layer 1, 2, 4, a size that needs the UpDS padding: tie-free

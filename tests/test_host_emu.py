@@ -74,6 +74,26 @@ def test_dsconv(ops):
              zero_bias=False)
 
 
+GENERIC_DSCONV = {  # tag: ctor arguments (the reference cases of oracle/gen_golden.py GENERIC_DSCONV)
+    "dsconv_g5": dict(in_channels=4, output_channels=6, kernel_size=5, padding=2, kernels_per_layer=3),
+    "dsconv_g3p0": dict(in_channels=5, output_channels=7, kernel_size=3),
+    "dsconv_g1": dict(in_channels=6, output_channels=4, kernel_size=1, padding=0, kernels_per_layer=2),
+    "dsconv_g7p1": dict(in_channels=3, output_channels=5, kernel_size=7, padding=1, kernels_per_layer=5),
+    "dsconv_g3k3": dict(in_channels=4, output_channels=8, kernel_size=3, padding=1, kernels_per_layer=3),
+    "dsconv_g3p2": dict(in_channels=2, output_channels=3, kernel_size=3, padding=2, kernels_per_layer=2),
+}
+
+
+def test_dsconv_any_geometry_host(golden_dir):
+    """DepthwiseSeparableConv at every geometry the reference's constructor accepts, and a DoubleConvDS at
+    kernels_per_layer = 3: host logic of the general path (general depthwise entry points + pointwise GEMM (+ BatchNorm +
+    ReLU node)) against the reference fixtures"""
+    g = np.load(os.path.join(golden_dir, "ops_generic.npz"))
+    for tag, kw in GENERIC_DSCONV.items():
+        run_case(g, tag, S.DepthwiseSeparableConv(**kw), zero_bias=False)
+    run_case(g, "doubleconv_k3", S.DoubleConvDS(5, 8, kernels_per_layer=3))
+
+
 def test_doubleconv(ops):
     run_case(ops, "doubleconv", S.DoubleConvDS(6, 16, kernels_per_layer=2))
     run_case(ops, "doubleconv_mid", S.DoubleConvDS(8, 4, mid_channels=12, kernels_per_layer=2))
@@ -406,8 +426,12 @@ def test_argument_validation_at_the_operator_boundary():
         K.dsconv(torch.randn(6, 8, 8), m.double_conv[0].depthwise.weight, None, m.double_conv[0].pointwise.weight, None, 2)
     with pytest.raises(ValueError, match="conv.weight"):
         K.pointwise(x, torch.randn(3, 5, 1, 1), None)
+    # kernels_per_layer = 3 is constructible (general kernels); the FUSED operator still names what it is built for
+    m3 = S.DepthwiseSeparableConv(4, 8, kernel_size=3, padding=1, kernels_per_layer=3)
     with pytest.raises(NotImplementedError, match="kernels_per_layer"):
-        S.DepthwiseSeparableConv(4, 8, kernel_size=3, padding=1, kernels_per_layer=3)
+        K.dsconv(torch.randn(1, 4, 8, 8), m3.depthwise.weight, None, m3.pointwise.weight, None, 3)
+    with pytest.raises(RuntimeError, match="Kernel size can't be greater"):  # torch's own message for an empty output
+        S.DepthwiseSeparableConv(4, 8, kernel_size=9)(torch.randn(1, 4, 6, 6))
     c = S.CBAM(32)
     with pytest.raises(ValueError, match="MLP.1.weight"):
         c(torch.randn(1, 16, 8, 8))

@@ -47,6 +47,40 @@ def test_dsconv(ops, tag, kpl):
     assert rel(dbd, g["depthwise.bias"]) < 2e-6
 
 
+GENERIC_DSCONV = {  # tag: ctor arguments (the reference cases of oracle/gen_golden.py GENERIC_DSCONV)
+    "dsconv_g5": dict(in_channels=4, output_channels=6, kernel_size=5, padding=2, kernels_per_layer=3),
+    "dsconv_g3p0": dict(in_channels=5, output_channels=7, kernel_size=3),
+    "dsconv_g1": dict(in_channels=6, output_channels=4, kernel_size=1, padding=0, kernels_per_layer=2),
+    "dsconv_g7p1": dict(in_channels=3, output_channels=5, kernel_size=7, padding=1, kernels_per_layer=5),
+    "dsconv_g3k3": dict(in_channels=4, output_channels=8, kernel_size=3, padding=1, kernels_per_layer=3),
+    "dsconv_g3p2": dict(in_channels=2, output_channels=3, kernel_size=3, padding=2, kernels_per_layer=2),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(GENERIC_DSCONV))
+def test_dsconv_any_geometry(golden_dir, tag):
+    """the general depthwise restatement against the REFERENCE module at kernel sizes / paddings / kernels_per_layer outside
+    the network's 3x3 / 1 / {1, 2, 4} (models/layers.py:35-45 accepts them all)"""
+    ops = np.load(os.path.join(golden_dir, "ops_generic.npz"))
+    kw = GENERIC_DSCONV[tag]
+    kpl, pad = kw.get("kernels_per_layer", 1), kw.get("padding", 0)
+    p, g = P(ops, tag), G(ops, tag)
+    x, cot = ops[f"{tag}/in0"], ops[f"{tag}/cot"]
+    y = O.dwconv_fwd(x, p["depthwise.weight"], p["depthwise.bias"], kpl, pad)
+    z = O.pw1x1_fwd(y, p["pointwise.weight"], p["pointwise.bias"])
+    assert z.shape == ops[f"{tag}/out"].shape
+    assert rel(z, ops[f"{tag}/out"]) < 2e-6
+    dy, dwp, dbp = O.pw1x1_bwd(y, p["pointwise.weight"], cot)
+    dx, dwd, dbd = O.dwconv_bwd(x, p["depthwise.weight"], dy, kpl, pad)
+    assert rel(dx, ops[f"{tag}/din0"]) < 2e-6
+    assert rel(dwp, g["pointwise.weight"]) < 2e-6
+    assert rel(dbp, g["pointwise.bias"]) < 2e-6
+    assert rel(dwd, g["depthwise.weight"]) < 2e-6
+    assert rel(dbd, g["depthwise.bias"]) < 2e-6
+    if kw["kernel_size"] == 3 and pad == 1:  # the 3x3 restatement is the same function at this geometry
+        assert np.array_equal(y, O.dw3x3_fwd(x, p["depthwise.weight"], p["depthwise.bias"], kpl))
+
+
 @pytest.mark.parametrize("tag,kpl", [("doubleconv", 2), ("doubleconv_mid", 2)])
 def test_doubleconv(ops, tag, kpl):
     p, g = P(ops, tag), G(ops, tag)
