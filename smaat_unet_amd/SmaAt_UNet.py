@@ -16,6 +16,7 @@ from torch import nn
 from . import ops
 from .layers import CBAM, batched_counters
 from .unet_parts import OutConv
+from .layers import DepthwiseSeparableConv
 from .unet_parts_depthwise_separable import DoubleConvDS, DownDS, UpDS
 
 _ENCODER_WIDTHS = (64, 128, 256, 512)
@@ -61,6 +62,21 @@ class UNetDSFamily(nn.Module):
         self._precision = mode
         self.__dict__["_graphs"] = {}
         return self
+
+    def _mixed_precision_ok(self, x):
+        """bf16 activation storage is built for the configurations the reference trains (bilinear up path, 3x3 depthwise
+        with kernels_per_layer 1, 2 or 4, input height and width multiples of 32: every level then has an even plane and
+        every upsampled width is a multiple of 4).  Anything else runs with f32 storage -- mixed precision is an
+        optimisation, not a contract on results -- and says so once."""
+        ok = (x.dim() == 4 and x.shape[2] % 32 == 0 and x.shape[3] % 32 == 0 and getattr(self, "bilinear", True)
+              and all(m._fast_geometry() for m in self.modules() if isinstance(m, DepthwiseSeparableConv)))
+        if not ok and not self.__dict__.get("_warned_mixed"):
+            self.__dict__["_warned_mixed"] = True
+            import warnings
+            warnings.warn("smaat_unet_amd: mixed precision (bf16 activation storage) is built for the bilinear up path, "
+                          "kernels_per_layer in {1, 2, 4} and input sizes that are multiples of 32; this call runs with f32 "
+                          f"storage (input {tuple(x.shape)})", stacklevel=3)
+        return ok
 
     # -- pieces ------------------------------------------------------------------------------------------
     def _levels(self):
@@ -183,7 +199,10 @@ class UNetDSFamily(nn.Module):
         if (getattr(self, "_graph_enabled", False) and not self.training and not torch.is_grad_enabled() and x.is_cuda
                 and not torch.cuda.is_current_stream_capturing()):
             return self._graph_forward(x)
-        with batched_counters(), ops.precision(getattr(self, "_precision", None)):
+        prec = getattr(self, "_precision", None)
+        if (prec == "bf16" or (prec is None and ops.mixed_precision_active())) and not self._mixed_precision_ok(x):
+            prec = "f32"  # (an enclosing torch.autocast / precision("bf16") is overridden for this call tree)
+        with batched_counters(), ops.precision(prec):
             # (batched_counters: one add for all num_batches_tracked counters of the step)
             out = self._forward_impl(x)
         return out.float() if out.dtype != x.dtype and x.dtype.is_floating_point else out

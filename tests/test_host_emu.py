@@ -520,3 +520,36 @@ def test_bf16_mixed_precision_voc_head_and_context_manager():
 def O_precip(n, c, h, w):
     from oracle import smaat_oracle as O
     return O.synthetic_precip(n, c, h, w, seed=3)[0]
+
+
+def test_mixed_precision_falls_back_to_f32_storage_where_it_is_not_built():
+    """bf16 activation storage covers the configurations the reference trains; a size that is not a multiple of 32, the
+    ConvTranspose up path or a general depthwise geometry run the SAME call with f32 storage (one warning), bit-identical to
+    the f32 mode -- never an exception from the middle of the network"""
+    import warnings
+    torch.manual_seed(3)
+    for ctor, shape in ((lambda: S.SmaAt_UNet(4, 2), (1, 4, 48, 40)), (lambda: S.SmaAt_UNet(4, 2, bilinear=False), (1, 4, 32, 32)),
+                        (lambda: S.SmaAt_UNet(4, 2, kernels_per_layer=3), (1, 4, 32, 32))):
+        m = ctor().train()
+        x = torch.randn(*shape)
+        ref = m(x)
+        m2 = ctor().train()
+        m2.load_state_dict(m.state_dict())
+        m2.load_state_dict({k: v for k, v in m.state_dict().items()})
+        for mod_a, mod_b in zip(m.modules(), m2.modules()):  # same running statistics before the second forward
+            if isinstance(mod_a, torch.nn.BatchNorm2d):
+                mod_b.running_mean.zero_()
+                mod_b.running_var.fill_(1.0)
+                mod_b.num_batches_tracked.zero_()
+        m2.set_precision("bf16")
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            out = m2(x)
+            out2 = m2(x)
+        assert out.dtype == torch.float32 and torch.equal(out, ref) and torch.equal(out2, ref)
+        assert sum("mixed precision" in str(i.message) for i in w) == 1  # said once per module
+    ok = S.SmaAt_UNet(4, 2).train().set_precision("bf16")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ok(torch.randn(1, 4, 32, 32))
+    assert not w
