@@ -272,6 +272,7 @@ def test_module_owned_eval_graph(golden_dir):
     with torch.no_grad():
         model(torch.from_numpy(x).to(dev))  # the training step of the fixture (running statistics)
     model.eval()
+    model.FORK_ATTENTION = False     # (the class default follows SMAAT_FORK_ATTENTION; this part pins the unforked graph)
     xb = torch.from_numpy(xe).to(dev)
     with torch.no_grad():
         eager = model(xb)

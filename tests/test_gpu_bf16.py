@@ -13,7 +13,12 @@ import torch
 
 from smaat_unet_amd import _lib
 
-pytestmark = pytest.mark.gpu
+import os  # noqa: E402
+
+# (bf16 storage has no fallback kernels: the A/B switches that turn the row-streaming kernels off turn it off as well)
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("SMAAT_DW_ROWS", "1") == "0" or os.environ.get("SMAAT_UP_ROWS", "1") == "0",
+                                 reason="row-streaming kernels switched off: mixed precision is not available")]
 DEV = torch.device("cuda:0")
 F32, BF16 = 0, 1
 

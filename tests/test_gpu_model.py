@@ -351,6 +351,8 @@ def test_bf16_mixed_precision_mode(ops):
     assert np.array_equal(again, ref_out)
 
 
+@pytest.mark.skipif(os.environ.get("SMAAT_DW_ROWS", "1") == "0" or os.environ.get("SMAAT_UP_ROWS", "1") == "0",
+                    reason="row-streaming kernels switched off: mixed precision is not available")
 def test_bf16_storage_mixed_precision(ops):
     """BASELINE configs[3], real mixed precision (model.set_precision("bf16")): every activation tensor and its gradient is
     STORED as bfloat16, f32 arithmetic / accumulation / BatchNorm statistics, f32 master weights and weight gradients.
