@@ -207,8 +207,10 @@ static int upr_enabled() {
     return v;
 }
 
+// target_bh / min_threads: measured per direction (profiles/r3/up_bench_geometry_r3.txt): the forward (a pure store stream per
+// thread) prefers long bands and fewer threads, the backward the opposite
 static UprGeom upr_geom(int N, int C, int H, int W, int Ho, int Wo, int pad_t, int pad_l, int ntr, int rows,
-                        int target_bh) {
+                        int target_bh, long min_threads) {
     UprGeom g;
     g.C = C;
     g.H = H;
@@ -220,7 +222,7 @@ static UprGeom upr_geom(int N, int C, int H, int W, int Ho, int Wo, int pad_t, i
     g.ntr = ntr;
     int nb = (rows + target_bh - 1) / target_bh;
     // enough threads to fill the chip (256 CUs x 2048 lanes) a few times over
-    while ((long)N * C * nb * ntr < 2000000L && nb < rows / 4) ++nb;
+    while ((long)N * C * nb * ntr < min_threads && nb < rows / 4) ++nb;
     if (nb < 1) nb = 1;
     g.BH = (rows + nb - 1) / nb;
     g.nbands = (rows + g.BH - 1) / g.BH;
@@ -235,7 +237,7 @@ int launch_upsample2x_fwd_rows(const void* x, long x_bs, void* out, long out_bs,
     const unsigned am = dt == SMAAT_BF16 ? 7u : 15u;
     if (!upr_enabled() || (Wo & 3) != 0 || (out_bs & 3) != 0 || ((((uintptr_t)out) & am) != 0) || H < 1 || W < 1)
         return -2;
-    const UprGeom g = upr_geom(N, C, H, W, Ho, Wo, pad_t, pad_l, Wo / 4, Ho, 32);
+    const UprGeom g = upr_geom(N, C, H, W, Ho, Wo, pad_t, pad_l, Wo / 4, Ho, 64, 500000L);
     if (g.total > (1L << 31) * 256L) return -2;
     SMAAT_DISPATCH_ET(dt, T,
         hipLaunchKernelGGL(k_upsample2x_fwd_rows<T>, dim3((unsigned)((g.total + 255) / 256)), dim3(256), 0, st, (const T*)x,
@@ -249,7 +251,7 @@ int launch_upsample2x_bwd_rows(const void* dout, long dout_bs, void* dx, long dx
     if (!upr_enabled() || (W & 1) != 0 || (Wo & 3) != 0 || (pad_l & 3) != 0 || (dout_bs & 3) != 0 ||
         ((((uintptr_t)dout) & am) != 0) || pad_t < 0 || pad_l < 0 || 2 * H + pad_t > Ho || 2 * W + pad_l > Wo)
         return -2;
-    const UprGeom g = upr_geom(N, C, H, W, Ho, Wo, pad_t, pad_l, W / 2 + 1, H, 16);
+    const UprGeom g = upr_geom(N, C, H, W, Ho, Wo, pad_t, pad_l, W / 2 + 1, H, 16, 2000000L);
     SMAAT_DISPATCH_ET(dt, T,
         hipLaunchKernelGGL(k_upsample2x_bwd_rows<T>, dim3((unsigned)((g.total + 255) / 256)), dim3(256), 0, st, (const T*)dout,
                            dout_bs, (T*)dx, dx_bs, g););
