@@ -657,10 +657,14 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
         for (int u = 0; u < NAT; ++u) {
             const int t = ASIMPLE ? ptid + NPT * u : (ptid + NPT * u) % (COT * 2 * NT);  // surplus tasks re-copy a valid piece
             const int pl = ASIMPLE ? u : t / (COT * 2), rem = ASIMPLE ? ptid : t - pl * (COT * 2);
+            // (row, half) of a task: consecutive lanes take consecutive ROWS of one half.  With 48-byte rows the 16 lanes of
+            // a ds_write_b128 group then hit 16 disjoint 4-bank windows; the earlier map (lanes 2i, 2i + 1 = the two halves
+            // of row i) put rows i and i + 5 on the same banks: SQ_LDS_BANK_CONFLICT was 19 % of the LDS-active cycles of
+            // this kernel (profiles/r3/pmc_lds_f32_before.txt), all of it from these writes.
             apl[u] = pl;
-            arow[u] = rem >> 1;
-            ah8[u] = (rem & 1) * 8;
-            aofs[u] = pl * APL + arow[u] * BROW + (rem & 1) * 16;
+            arow[u] = rem % COT;
+            ah8[u] = (rem / COT) * 8;
+            aofs[u] = pl * APL + arow[u] * BROW + (rem / COT) * 16;
         }
         constexpr int PD = 4;
         float breg[PD][NBT][8];
