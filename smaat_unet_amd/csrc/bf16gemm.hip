@@ -154,6 +154,11 @@ __global__ __launch_bounds__(WCO * WPX * 64, 3) void k_pw_bf16(const PwBfArgs a)
     const int xc4 = (lane >> 2) ^ (4 * (wv & 3));                // GW 4: piece q = wv + NW * u is row q; q & 3 == wv & 3
     const unsigned xrow0 = GW == 16 ? (unsigned)(4 * wv + xr) : (unsigned)wv;
     const int arow = lane >> 1, ah = (lane & 1) ^ ((lane >> 4) & 1);
+    // Per-lane byte offsets of the pieces, fixed within an item: the per-chunk address is a wave-uniform 64-bit base (scalar
+    // arithmetic) + this 32-bit offset -- the saddr form of global_load_lds, no vector address arithmetic per chunk.  (The
+    // first version recomputed clamp, 32-bit multiply and 64-bit add per piece and chunk: 26 VALU + a v_mad_i64 pair per
+    // 8 MFMAs; the counters showed 16 VALU instructions per MFMA for this kernel.)
+    unsigned pf_xo[XPW], pf_ao[APW];
     auto pf_setup = [&]() __attribute__((always_inline)) {
         const int it = pf_item < nitems ? pf_item : nitems - 1;  // surplus issues re-load the last item into a dead stage
         const int idx = idx0 + it * gstep;
@@ -164,25 +169,42 @@ __global__ __launch_bounds__(WCO * WPX * 64, 3) void k_pw_bf16(const PwBfArgs a)
         const int px = tl * PT + (GW == 16 ? 8 * xc16 : 8 * xc4 + 2 * (lane & 3));
         pf_xcol = (unsigned)(px < a.P ? px : 0) * 2u;
         pf_co0 = cot * COT;
-    };
-    auto issue = [&](int stage) __attribute__((always_inline)) {
-        const int k0 = pf_ch * BF_KC;
-        unsigned char* sb = lds + stage * STG;
 #pragma unroll
         for (int u = 0; u < XPW; ++u) {
-            const int q = wv + NW * u;
-            int row = k0 + (GW == 16 ? (int)xrow0 + 16 * u : q);
-            row = row < a.Cin ? row : a.Cin - 1;  // (the weight image is zero there)
-            glds<GW>(pf_x + (unsigned)row * rowbytes + pf_xcol, sb + q * (GW == 16 ? 1024 : 256));
+            const unsigned row0 = GW == 16 ? xrow0 + 16u * u : (unsigned)(wv + NW * u);
+            pf_xo[u] = row0 * rowbytes + pf_xcol;
         }
 #pragma unroll
         for (int u = 0; u < APW; ++u) {
             const int q = wv + NW * u;
-            const int j = q / (COT / 32), rb = q - j * (COT / 32);
+            const int jj = q / (COT / 32), rb = q - jj * (COT / 32);
             int m = pf_co0 + rb * 32 + arow;
             m = m < a.M ? m : a.M - 1;
-            const bf16_t* src = a.planes + ((long)((k0 >> 4) + j) * a.M + m) * 16 + ah * 8;
-            glds<16>(src, sb + XB + (j * COT + rb * 32) * 32);
+            pf_ao[u] = (unsigned)((jj * a.M + m) * 16 + ah * 8) * 2u;
+        }
+    };
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+        const int k0 = pf_ch * BF_KC;
+        unsigned char* sb = lds + stage * STG;
+        if (k0 + BF_KC <= a.Cin) {  // wave-uniform: every channel row of the chunk exists
+            const unsigned char* xs = pf_x + (long)k0 * rowbytes;
+#pragma unroll
+            for (int u = 0; u < XPW; ++u) glds<GW>(xs + pf_xo[u], sb + (wv + NW * u) * (GW == 16 ? 1024 : 256));
+        } else {  // last chunk of a contraction that is not a multiple of 32 (the 24-channel stem): clamp the row per lane
+#pragma unroll
+            for (int u = 0; u < XPW; ++u) {
+                const int q = wv + NW * u;
+                int row = k0 + (GW == 16 ? (int)xrow0 + 16 * u : q);
+                row = row < a.Cin ? row : a.Cin - 1;  // (the weight image is zero there)
+                glds<GW>(pf_x + (unsigned)row * rowbytes + pf_xcol, sb + q * (GW == 16 ? 1024 : 256));
+            }
+        }
+        const unsigned char* as = (const unsigned char*)a.planes + (long)(k0 >> 4) * a.M * 32;
+#pragma unroll
+        for (int u = 0; u < APW; ++u) {
+            const int q = wv + NW * u;
+            const int j = q / (COT / 32), rb = q - j * (COT / 32);
+            glds<16>(as + pf_ao[u], sb + XB + (j * COT + rb * 32) * 32);
         }
         if (++pf_ch == nchunks) {
             pf_ch = 0;
