@@ -927,261 +927,6 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// k_pw_split_d: the same exact-f32 six-MFMA GEMM WITHOUT the LDS round trip and without a barrier in the contraction
-// loop (experiment of round 3; SMAAT_PW_DIRECT=1).  Every wave loads its own operands straight into MFMA fragment layout:
-//   B (activations, f32 [channel][pixel]): lane (pixel l31, half) needs the 8 channels k0 + 8 half .. + 7 of its pixel: eight
-//     global_load_dword per 32-pixel tile, each a coalesced 128-byte row piece; the three-term split runs in the
-//     registers of the wave that consumes them;
-//   A (weight planes, chunk-major [Cp/16][3][M][16] bf16): lane (row l31, half) needs 16 contiguous bytes per plane: one
-//     global_load_dwordx4 per plane and 32-row tile, a wave reads 1 KB contiguous.
-// 128 x 128 tile = 2 x 2 waves of 64 x 64 (the operand re-reads of the partner waves hit L1/L2), items and statistics
-// slots as k_pw_split_p.  PD = 3 register sets of loads in flight, inline-asm loads with counted s_waitcnt (stores in the
-// queue can only lengthen a counted wait: loads return in order among themselves).  Same MFMA order per 16-deep chunk as
-// k_pw_split_p: results are bit-identical.
-// ---------------------------------------------------------------------------------------------------------------
-template <int CT, int PXT>
-__global__ __launch_bounds__(256, 2) void k_pw_split_d(const PwSplitArgs a) {
-    constexpr int WCO = 2, WPX = 2, COT = WCO * CT * 32, PT = WPX * PXT * 32, PD = 3;
-    constexpr int NTH = 256;
-    constexpr int STSZ = WPX * 3 * COT;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    float* stat = (float*)lds;                              // [2][STSZ] (only when partials are requested)
-    float* biasl = stat + (a.part ? 2 * STSZ : 0);          // [4 waves][2][CT * 32]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wco = wv % WCO, wpx = wv / WCO;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int b = blockIdx.x, xcd = b & 7, idx0 = b >> 3;
-    const int gstep = gridDim.x >> 3;
-    const int tpx = (a.T + 7) >> 3;
-    int lim_t = a.T - xcd * tpx;
-    lim_t = lim_t < tpx ? lim_t : tpx;
-    const int lim = lim_t > 0 ? lim_t * a.nco : 0;
-    if (idx0 >= lim) return;
-    const int nitems = (lim - 1 - idx0) / gstep + 1;
-    const int nchunks = (a.Cin + 15) >> 4;
-    const int G = nitems * nchunks;
-
-    float breg[PD][PXT][8];
-    u32x4 areg[PD][CT][3];
-    float bias_reg[PD];
-    const float* biasp = a.bias ? a.bias : (const float*)a.planes;
-    int pf_item = 0, pf_ch = 0;
-    const float* pf_x = a.x;
-    const unsigned short* pf_pl = a.planes;
-    int pf_bp[PXT];
-    unsigned pf_bvo[PXT], pf_avo[CT], pf_bidx = 0;
-    auto pf_setup = [&]() __attribute__((always_inline)) {
-        const int it = pf_item < nitems ? pf_item : nitems - 1;
-        const int idx = idx0 + it * gstep;
-        const int j = idx / a.nco, cot = idx - j * a.nco;
-        const int ptg = xcd * tpx + j;
-        const int n = ptg / a.tiles_per_img, tl = ptg - n * a.tiles_per_img;
-        pf_x = a.x + (long)n * a.x_bs;
-        pf_pl = a.planes + (a.ksplit > 1 ? (long)(n % a.ksplit) * a.planes_bs : 0L);
-        int bi = cot * COT + wco * CT * 32 + lane;
-        bi = bi < a.M ? bi : a.M - 1;
-        pf_bidx = (unsigned)bi * 4u;
-#pragma unroll
-        for (int pt = 0; pt < PXT; ++pt) {
-            const int p = tl * PT + (wpx * PXT + pt) * 32 + l31;
-            pf_bp[pt] = p < a.P ? p : a.P - 1;
-            pf_bvo[pt] = (unsigned)(half * 8 * a.P + pf_bp[pt]) * 4u;
-        }
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            int r = cot * COT + (wco * CT + ct) * 32 + l31;
-            r = r < a.M ? r : a.M - 1;
-            pf_avo[ct] = (unsigned)(r * 16 + half * 8) * 2u;
-        }
-    };
-    constexpr int LPC = PXT * 8 + CT * 3 + 1;
-    static_assert((PD - 1) * LPC <= 63, "vmcnt is a 6-bit counter");
-    const long aplane = (long)a.M * 16;
-    auto prefetch = [&](int set) __attribute__((always_inline)) {
-        const int k0 = pf_ch * 16;
-        if (k0 + 16 <= a.Cin) {
-            const float* sb = pf_x + (long)k0 * a.P;
-#pragma unroll
-            for (int pt = 0; pt < PXT; ++pt)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float* sbe = sb + (long)e * a.P;
-                    asm volatile("global_load_dword %0, %1, %2" : "=v"(breg[set][pt][e]) : "v"(pf_bvo[pt]), "s"(sbe));
-                }
-        } else {
-#pragma unroll
-            for (int pt = 0; pt < PXT; ++pt)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int c = k0 + half * 8 + e;
-                    const float* src = pf_x + (long)(c < a.Cin ? c : a.Cin - 1) * a.P + pf_bp[pt];
-                    asm volatile("global_load_dword %0, %1, off" : "=v"(breg[set][pt][e]) : "v"(src));
-                }
-        }
-        const unsigned short* sa = pf_pl + (long)k0 * 3 * a.M;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const unsigned short* sat = sa + t * aplane;
-                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(areg[set][ct][t]) : "v"(pf_avo[ct]), "s"(sat));
-            }
-        asm volatile("global_load_dword %0, %1, %2" : "=v"(bias_reg[set]) : "v"(pf_bidx), "s"(biasp));
-        if (++pf_ch == nchunks) {
-            pf_ch = 0;
-            ++pf_item;
-            pf_setup();
-        }
-    };
-
-    f32x16 acc[CT][PXT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int pt = 0; pt < PXT; ++pt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
-    int ci = 0, k = 0;  // chunk within the item, item
-    auto consume = [&](int set) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * LPC) : "memory");
-#pragma unroll
-        for (int pt = 0; pt < PXT; ++pt)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(breg[set][pt][e]));
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) asm volatile("" : "+v"(areg[set][ct][t]));
-        asm volatile("" : "+v"(bias_reg[set]));
-        const int k0 = ci * 16;
-        const bool partial = k0 + 16 > a.Cin;  // wave-uniform
-        bf16x8 bfr[PXT][3];
-#pragma unroll
-        for (int pt = 0; pt < PXT; ++pt) {
-            float p1[8], p2[8], p3[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float x = breg[set][pt][e];
-                if (partial) x = (k0 + half * 8 + e < a.Cin) ? x : 0.f;
-                p1[e] = bitsf(fbits(x) & 0xFFFF0000u);
-                const float r1 = x - p1[e];
-                p2[e] = bitsf(fbits(r1) & 0xFFFF0000u);
-                p3[e] = r1 - p2[e];
-            }
-            const u32x4 q1 = {pack_hi16(p1[0], p1[1]), pack_hi16(p1[2], p1[3]), pack_hi16(p1[4], p1[5]), pack_hi16(p1[6], p1[7])};
-            const u32x4 q2 = {pack_hi16(p2[0], p2[1]), pack_hi16(p2[2], p2[3]), pack_hi16(p2[4], p2[5]), pack_hi16(p2[6], p2[7])};
-            const u32x4 q3 = {pack_hi16(p3[0], p3[1]), pack_hi16(p3[2], p3[3]), pack_hi16(p3[4], p3[5]), pack_hi16(p3[6], p3[7])};
-            bfr[pt][0] = __builtin_bit_cast(bf16x8, q1);
-            bfr[pt][1] = __builtin_bit_cast(bf16x8, q2);
-            bfr[pt][2] = __builtin_bit_cast(bf16x8, q3);
-        }
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            const bf16x8 a0 = __builtin_bit_cast(bf16x8, areg[set][ct][0]), a1 = __builtin_bit_cast(bf16x8, areg[set][ct][1]),
-                         a2 = __builtin_bit_cast(bf16x8, areg[set][ct][2]);
-#pragma unroll
-            for (int pt = 0; pt < PXT; ++pt) {
-                acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfr[pt][2], acc[ct][pt], 0, 0, 0);
-                acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bfr[pt][0], acc[ct][pt], 0, 0, 0);
-                acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfr[pt][1], acc[ct][pt], 0, 0, 0);
-                acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfr[pt][1], acc[ct][pt], 0, 0, 0);
-                acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfr[pt][0], acc[ct][pt], 0, 0, 0);
-                acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfr[pt][0], acc[ct][pt], 0, 0, 0);
-            }
-        }
-    };
-    auto epilogue = [&](float bias_v) __attribute__((always_inline)) {
-        const int idx = idx0 + k * gstep;
-        const int j = idx / a.nco, cot = idx - j * a.nco;
-        const int ptg = xcd * tpx + j;
-        const int n = ptg / a.tiles_per_img, tl = ptg - n * a.tiles_per_img;
-        const int co0 = cot * COT, p0 = tl * PT;
-        float* bw = biasl + (wv * 2 + (k & 1)) * (CT * 32);  // this wave's slot (same-wave write -> read)
-        bw[lane] = a.bias ? bias_v : 0.f;
-        unsigned pvo[PXT];
-        bool pval[PXT];
-#pragma unroll
-        for (int pt = 0; pt < PXT; ++pt) {
-            const int p = p0 + (wpx * PXT + pt) * 32 + l31;
-            pval[pt] = p < a.P;
-            pvo[pt] = pval[pt] ? (unsigned)p * 4u : 0x80000000u;
-        }
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.out + (long)n * a.out_bs, 0, a.M * a.P * 4, 0x00020000);
-        const unsigned rowb = (unsigned)(co0 + wco * CT * 32 + 4 * half) * (unsigned)a.P * 4u;
-        const float* bl = bw + 4 * half;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rc = ct * 32 + (r & 3) + 8 * (r >> 2);
-                const float bvv = bl[rc];
-                const unsigned ro = rowb + (unsigned)rc * (unsigned)a.P * 4u;
-#pragma unroll
-                for (int pt = 0; pt < PXT; ++pt)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(acc[ct][pt][r] + bvv, a.out_floor)), rs,
-                                                          ro + pvo[pt], 0, 0);
-            }
-        }
-        if (a.part) {
-            float* sb = stat + (k & 1) * STSZ;
-            bn_wave_partials<CT, PXT>(acc, pval, l31, half, sb + wpx * 3 * COT + wco * CT * 32, COT, 0);
-            __syncthreads();  // (the only barrier: once per item, forward GEMMs only)
-            int nwv[WPX];
-#pragma unroll
-            for (int w = 0; w < WPX; ++w) {
-                const int v = a.P - (tl * PT + w * PXT * 32);
-                nwv[w] = v < 0 ? 0 : (v > PXT * 32 ? PXT * 32 : v);
-            }
-            for (int col = tid; col < COT; col += NTH) {
-                float mean, m2, cnt;
-                bn_tile_combine<WPX>(sb, nwv, COT, col, mean, m2, cnt);
-                const int m = co0 + col;
-                if (m < a.M) {
-                    a.part[((long)0 * a.slots + ptg) * a.M + m] = mean;
-                    a.part[((long)1 * a.slots + ptg) * a.M + m] = m2;
-                    a.part[((long)2 * a.slots + ptg) * a.M + m] = cnt;
-                }
-            }
-        }
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int pt = 0; pt < PXT; ++pt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[ct][pt][r] = 0.f;
-    };
-    pf_setup();
-#pragma unroll
-    for (int j = 0; j < PD; ++j) prefetch(j);
-    for (int g0 = 0; g0 < G; g0 += PD) {
-#pragma unroll
-        for (int u = 0; u < PD; ++u) {
-            if (g0 + u < G) {
-                consume(u);
-                const float bv = bias_reg[u];
-                prefetch(u);
-                if (++ci == nchunks) {
-                    epilogue(bv);
-                    ci = 0;
-                    ++k;
-                }
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus prefetches of the tail still target live registers
-}
-
-static int pw_direct() {  // SMAAT_PW_DIRECT=1: the barrier-free register-operand GEMM for the 128-row layers (experiment)
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("SMAAT_PW_DIRECT");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
-
 int pw_split_num_slots(int N, int P) {
     // upper bound over the tile choices of launch_pw_split (unused slots are never written: see below)
     const int PT = 128;
@@ -1245,23 +990,6 @@ int launch_pw_split(PwSplitArgs& a, hipStream_t st) {
     if (split_mode() == 1) {  // plain bf16 operands, one MFMA per product
         if (a.M > 64) return launch_pw_split_cfg<2, 2, 2, 2, 256, 1>(a, st);
         return launch_pw_split_cfg<1, 2, 4, 1, 256, 1>(a, st);
-    }
-    if (a.M > 64 && pw_direct() && (long)(a.M + 128) * a.P * 4 < (1L << 31) && (long)a.Cin * a.P * 4 < (1L << 31)) {
-        constexpr int COT = 128, PT = 128, WPX = 2;
-        a.nco = (a.M + COT - 1) / COT;
-        a.tiles_per_img = (a.P + PT - 1) / PT;
-        a.T = a.N * a.tiles_per_img;
-        a.slots = pw_split_num_slots(a.N, a.P);
-        a.dbg = 0;
-        const int items = ((a.T + 7) / 8) * 8 * a.nco;
-        const size_t lds = sizeof(float) * ((a.part ? 2 * WPX * 3 * COT : 0) + 4 * 2 * 64);
-        const int grid = items < 512 ? items : 512;
-        hipLaunchKernelGGL((k_pw_split_d<2, 2>), dim3(grid), dim3(256), lds, st, a);
-        if (a.part && a.T < a.slots) {
-            for (int w = 0; w < 3; ++w)
-                HIP_RET(hipMemsetAsync(a.part + ((long)w * a.slots + a.T) * a.M, 0, sizeof(float) * (size_t)(a.slots - a.T) * a.M, st));
-        }
-        return (int)hipGetLastError();
     }
     if (a.M > 64) return launch_pw_split_cfg<2, 2, 2, 2, 256>(a, st);  // 128 x 128
     return launch_pw_split_cfg<1, 2, 4, 1, 256>(a, st);                // 64 x 128
