@@ -133,6 +133,54 @@ def rocm_eager_baseline(batch, size, dev, steps=5, warmup=2):
         return {"error": str(e)[:200]}
 
 
+class PowerSampler:
+    """Shader clock and socket power while the timed steps run (rocm-smi from a host thread; nothing is launched on the GPU).
+    MI355X is power-managed: under combined MFMA + HBM load the clock sits well below the nominal 2.4 GHz, which the
+    cycle-based PMC utilisation figures do not see (profiles/r3/clock_under_load_r3.txt, mfma_power_probe_r3.txt)."""
+
+    def __init__(self, period=0.5):
+        import threading
+        self.period, self.samples = period, []
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _sample(self):
+        import re
+        import subprocess
+        try:
+            out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+        except Exception:  # noqa: BLE001  (no rocm-smi on this host)
+            return None
+        dev = os.environ.get("LOCAL_RANK", "0")
+        s = re.search(r"GPU\[%s\]\s*:\s*sclk clock level: \d+: \((\d+)Mhz\)" % dev, out) or re.search(r"sclk[^\n]*?\((\d+)Mhz\)", out)
+        w = re.search(r"GPU\[%s\]\s*:[^\n]*Power \(W\): ([\d.]+)" % dev, out) or re.search(r"Power \(W\): ([\d.]+)", out)
+        return (int(s.group(1)) if s else None, float(w.group(1)) if w else None)
+
+    def _run(self):
+        while not self._stop.is_set():
+            r = self._sample()
+            if r is not None:
+                self.samples.append(r)
+            self._stop.wait(self.period)
+
+    def start(self):
+        self._th.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        self._th.join(timeout=15)
+        clk = [c for c, _ in self.samples if c]
+        pw = [w for _, w in self.samples if w]
+        if not clk:
+            return None
+        return {"sclk_mhz_mean": round(sum(clk) / len(clk)), "sclk_mhz_min": min(clk), "sclk_mhz_nominal": 2400,
+                "power_w_mean": round(sum(pw) / len(pw)) if pw else None, "power_w_max": round(max(pw)) if pw else None,
+                "samples": len(clk),
+                "note": "sampled with rocm-smi during the timed steps; the GEMM phases run at the 1400 W board limit and "
+                        "~1.8 GHz, the streaming phases at ~1.0 kW and 2.4 GHz (profiles/r3/clock_under_load_r3.txt)"}
+
+
 def fwd_latency(model, size, dev, iters=50):
     """eval-mode, no_grad, batch-1 forward (reference call stack D: notebook / calc_metrics_test_set.py
     inference); median of `iters` HIP-event timings, eager launches and one captured HIP graph."""
@@ -250,6 +298,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the f32-MFMA-only reference run")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 eval forward latency")
+    ap.add_argument("--no-power", action="store_true", help="do not sample clock / power with rocm-smi during the timed steps")
     ap.add_argument("--no-eager-baseline", action="store_true", help="skip the stock PyTorch-ROCm eager baseline")
     ap.add_argument("--no-side-configs", action="store_true",
                     help="skip the short sub-records of BASELINE configs[3] (bf16, batch 64) and configs[4] (VOC head)")
@@ -341,11 +390,13 @@ def main():
         torch.cuda.synchronize()
 
     fence()
+    sampler = PowerSampler().start() if (rank == 0 and not args.no_power) else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
+    power = sampler.stop() if sampler is not None else None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -608,6 +659,7 @@ def main():
             "input_pipeline_fed": fed,
             "f32_mfma_only": alt,
             "configs": side,
+            "power": power,
             "fwd_latency": latency,
             "kernels": kernels,
         }
