@@ -233,7 +233,7 @@ def fwd_latency(model, size, dev, iters=50):
     return res
 
 
-def side_config(kind, dev, steps=10, warmup=3):
+def side_config(kind, dev, steps=24, warmup=6):
     """Short measurement of another single-GPU configuration of BASELINE.json inside the default run, so that the driver's
     BENCH record carries it: "bf16_b64" = configs[3] (12->1, 288x288, batch 64, mixed precision = bf16 activation storage),
     "voc_b16" = configs[4] (3->21, 256x256, batch 16, CrossEntropyLoss, f32).  Same step as the headline: forward + loss +
