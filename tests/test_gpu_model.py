@@ -502,6 +502,72 @@ def test_training_trajectory_against_the_aten_reference():
     assert all(torch.isfinite(v).all() for v in model.state_dict().values())
 
 
+@pytest.mark.parametrize("shape", [(1, 64, 64), (3, 48, 80), (2, 80, 48), (1, 96, 32), (2, 36, 36), (1, 40, 72), (5, 32, 32),
+                                   (2, 128, 64), (1, 100, 52), (2, 18, 22)])
+def test_shape_sweep_vs_the_aten_reference(shape):
+    """Every kernel family has shape-specialised forms (row-streaming / strip / element kernels, two-column last groups,
+    sliced GEMMs below a fill threshold, padded up path for odd levels): a sweep over batch sizes and H x W -- multiples of
+    16 and not, H != W, levels that become odd after pooling -- of the whole network, forward and every gradient, against
+    the reference's arithmetic on the CPU (oracle/torch_ref.py) in float32 AND float64.  Bounds: logits 1e-4 rel-L2 of the
+    float32 reference; the flat gradient no further from the float64 one than 2x what the float32 reference itself is, or
+    2x what the float64 gradient moves under a 1e-6 input perturbation (decision flips: 6e-4 ... 1e-2 at these sizes, the
+    larger of the two yardsticks), every tensor's cosine with the float64 gradient >= 0.999."""
+    from oracle import torch_ref
+    n, h, w = shape
+    Pn = oparams.make_smaat_params(12, 1, 2, 16, 21)
+    xn, yn = O.synthetic_precip(n, 12, h, w, seed=300 + h + w)
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(8)
+    try:
+        P = torch_ref.params_from_numpy(Pn)
+        rl, rlog = torch_ref.train_step(P, torch.from_numpy(xn), torch.from_numpy(yn))
+        def p64():
+            return {k: (v.detach().double().requires_grad_(v.requires_grad) if v.is_floating_point() else v)
+                    for k, v in torch_ref.params_from_numpy(Pn).items()}
+
+        P64 = p64()
+        x64, y64 = torch.from_numpy(xn).double(), torch.from_numpy(yn).double()
+        torch_ref.train_step(P64, x64, y64)
+        # how far the EXACT gradient moves when the input moves by 1e-6 (ReLU / max-pool / arg-max decisions at round-off
+        # distance from a tie flip): the reference's float32 run can land on either side of those, and so can this one
+        sens = []
+        for sd in range(4):
+            Pp = p64()
+            gen = torch.Generator().manual_seed(sd)
+            torch_ref.train_step(Pp, x64 * (1 + 1e-6 * torch.randn(x64.shape, generator=gen, dtype=torch.float64)), y64)
+            d2 = sum(float((Pp[k].grad - P64[k].grad).norm() ** 2) for k, v in P64.items() if v.requires_grad)
+            n2 = sum(float(P64[k].grad.norm() ** 2) for k, v in P64.items() if v.requires_grad)
+            sens.append((d2 / n2) ** 0.5)
+        sens = sorted(sens)[len(sens) // 2]
+    finally:
+        torch.set_num_threads(nthr)
+    model = S.SmaAt_UNet(12, 1)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in Pn.items()})
+    model.to(DEV).train()
+    y = torch.from_numpy(yn).to(DEV)
+    out = model(torch.from_numpy(xn).to(DEV))
+    loss = torch.nn.functional.mse_loss(out.squeeze(1), y, reduction="sum") / y.shape[0]
+    loss.backward()
+    e = float((out.detach().cpu() - rlog).norm() / rlog.norm())
+    assert e < 1e-4, ("logits", shape, e)
+    assert abs(float(loss.detach()) - float(rl)) < 1e-4 * abs(float(rl))
+    num = ref_num = den = 0.0
+    for k, p in model.named_parameters():
+        g, r32, r = p.grad.detach().cpu().double(), P[k].grad.double(), P64[k].grad
+        num += float((g - r).norm() ** 2)
+        ref_num += float((r32 - r).norm() ** 2)
+        den += float(r.norm() ** 2)
+        zero_by_construction = ".double_conv." in k and (k.endswith("pointwise.bias") or k.endswith("depthwise.bias"))
+        if not zero_by_construction and float(r.norm()) > 1e-9:
+            cos = float((g * r).sum() / (g.norm() * r.norm() + 1e-300))
+            assert cos > 0.999, (k, shape, cos)
+    ours, ref = (num / den) ** 0.5, (ref_num / den) ** 0.5
+    if os.path.isdir("gpurun_out"):
+        with open(f"gpurun_out/shape_sweep_{n}x{h}x{w}.json", "w") as f:
+            json.dump({"ours_vs_fp64": ours, "reference_fp32_vs_fp64": ref, "fp64_sensitivity_to_1e-6_input": sens, "logits": e}, f)
+    assert ours <= max(2.0 * ref, 2.0 * sens, 1e-4), (shape, ours, ref, sens)
+
+
 def test_voc_config_256_batch16():
     """BASELINE configs[4]: SmaAt_UNet(3, 21) on 256x256, batch 16, CrossEntropyLoss (reference
     train_SmaAtUNet.py:178-183): three Adam steps reduce the loss, everything stays finite."""
