@@ -566,6 +566,18 @@ def test_shape_sweep_vs_the_aten_reference(shape):
         with open(f"gpurun_out/shape_sweep_{n}x{h}x{w}.json", "w") as f:
             json.dump({"ours_vs_fp64": ours, "reference_fp32_vs_fp64": ref, "fp64_sensitivity_to_1e-6_input": sens, "logits": e}, f)
     assert ours <= max(2.0 * ref, 2.0 * sens, 1e-4), (shape, ours, ref, sens)
+    # the same shapes through the inference fast path (BatchNorm folded on the running statistics both sides just updated,
+    # fused / sliced kernels, module-owned hipGraph): eval logits against the reference's eval forward
+    with torch.no_grad():
+        ref_eval = torch_ref.forward(P, torch.from_numpy(xn), training=False)
+        model.eval()
+        ev = model(torch.from_numpy(xn).to(DEV))
+        model.enable_eval_graph()
+        evg = model(torch.from_numpy(xn).to(DEV))
+        model.enable_eval_graph(False)
+    ee = float((ev.cpu() - ref_eval).norm() / ref_eval.norm())
+    assert ee < 1e-4, ("eval logits", shape, ee)
+    assert torch.equal(ev, evg)
 
 
 def test_voc_config_256_batch16():
