@@ -580,6 +580,41 @@ def test_shape_sweep_vs_the_aten_reference(shape):
     assert torch.equal(ev, evg)
 
 
+@pytest.mark.skipif(os.environ.get("SMAAT_DW_ROWS", "1") == "0" or os.environ.get("SMAAT_UP_ROWS", "1") == "0",
+                    reason="row-streaming kernels switched off: mixed precision is not available")
+@pytest.mark.parametrize("shape", [(2, 64, 64), (1, 96, 32), (3, 32, 64), (2, 128, 64), (1, 32, 32)])
+def test_mixed_precision_shape_sweep(shape):
+    """bf16 activation storage over the shapes it is built for (multiples of 32, H != W, batch 1-3; the 18-wide / 2-wide
+    deepest planes take the two-column row kernels and the narrow LDS-DMA form): the step runs on bf16 tensors, is finite,
+    stays in the accuracy class of autocast (logits within 0.3 rel-L2 of the f32 path at random initialisation, gradient
+    cosine > 0.7, loss within 3 %), and a second run is bit-identical (no atomics, fixed reduction orders)."""
+    n, h, w = shape
+    Pn = oparams.make_smaat_params(12, 1, 2, 16, 31)
+    xn, yn = O.synthetic_precip(n, 12, h, w, seed=400 + h + w)
+
+    def run(prec):
+        model = S.SmaAt_UNet(12, 1)
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in Pn.items()})
+        model.to(DEV).train().set_precision(prec)
+        y = torch.from_numpy(yn).to(DEV)
+        out = model(torch.from_numpy(xn).to(DEV))
+        loss = torch.nn.functional.mse_loss(out.squeeze(1), y, reduction="sum") / y.shape[0]
+        loss.backward()
+        g = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+        return out.detach(), float(loss.detach()), g
+
+    o32, l32, g32 = run("f32")
+    ob, lb, gb = run("bf16")
+    ob2, lb2, gb2 = run("bf16")
+    assert ob.dtype == torch.float32 and torch.isfinite(ob).all() and torch.isfinite(gb).all()
+    assert torch.equal(ob, ob2) and torch.equal(gb, gb2) and lb == lb2
+    rel = float((ob - o32).norm() / o32.norm())
+    cos = float((gb.double() * g32.double()).sum() / (gb.double().norm() * g32.double().norm()))
+    assert 1e-4 < rel < 0.3, (shape, rel)          # (really rounded, and in the class of autocast)
+    assert cos > 0.7, (shape, cos)
+    assert abs(lb - l32) < 0.03 * abs(l32), (shape, lb, l32)
+
+
 def test_voc_config_256_batch16():
     """BASELINE configs[4]: SmaAt_UNet(3, 21) on 256x256, batch 16, CrossEntropyLoss (reference
     train_SmaAtUNet.py:178-183): three Adam steps reduce the loss, everything stays finite."""
