@@ -580,6 +580,54 @@ def test_shape_sweep_vs_the_aten_reference(shape):
     assert torch.equal(ev, evg)
 
 
+@pytest.mark.parametrize("kpl,shape", [(1, (2, 48, 64)), (4, (2, 48, 64)), (1, (1, 36, 20)), (4, (3, 32, 32)), (3, (2, 32, 48))])
+def test_kernels_per_layer_sweep_vs_the_aten_reference(kpl, shape):
+    """SmaAt_UNet at kernels_per_layer 1, 4 (strip / row kernels with other register shapes) and 3 (general depthwise path),
+    forward and flat gradient against the ATen restatement in float32 / float64 with the yardsticks of the shape sweep"""
+    import torch.nn.functional as F
+    from oracle import torch_ref
+    n, h, w = shape
+    Pn = oparams.make_smaat_params(12, 1, kpl, 16, 41)
+    xn, yn = O.synthetic_precip(n, 12, h, w, seed=500 + h + w + kpl)
+
+    def ref_step(dtype, x):
+        P = {k: (v.detach().to(dtype).requires_grad_(v.requires_grad) if v.is_floating_point() else v)
+             for k, v in torch_ref.params_from_numpy(Pn).items()}
+        logits = torch_ref.forward(P, x.to(dtype), kpl=kpl)
+        loss = F.mse_loss(logits.squeeze(1), torch.from_numpy(yn).to(dtype), reduction="sum") / n
+        loss.backward()
+        return P, logits.detach(), float(loss)
+
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(8)
+    try:
+        x0 = torch.from_numpy(xn)
+        P32, rlog, rl = ref_step(torch.float32, x0)
+        P64, _, _ = ref_step(torch.float64, x0)
+        gen = torch.Generator().manual_seed(0)
+        Pp, _, _ = ref_step(torch.float64, x0.double() * (1 + 1e-6 * torch.randn(x0.shape, generator=gen, dtype=torch.float64)))
+    finally:
+        torch.set_num_threads(nthr)
+    model = S.SmaAt_UNet(12, 1, kernels_per_layer=kpl)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in Pn.items()})
+    model.to(DEV).train()
+    y = torch.from_numpy(yn).to(DEV)
+    out = model(torch.from_numpy(xn).to(DEV))
+    loss = F.mse_loss(out.squeeze(1), y, reduction="sum") / n
+    loss.backward()
+    e = float((out.detach().cpu() - rlog).norm() / rlog.norm())
+    assert e < 1e-4, ("logits", kpl, shape, e)
+    num = ref_num = sens_num = den = 0.0
+    for k, p in model.named_parameters():
+        g, r = p.grad.detach().cpu().double(), P64[k].grad
+        num += float((g - r).norm() ** 2)
+        ref_num += float((P32[k].grad.double() - r).norm() ** 2)
+        sens_num += float((Pp[k].grad - r).norm() ** 2)
+        den += float(r.norm() ** 2)
+    ours, ref, sens = (num / den) ** 0.5, (ref_num / den) ** 0.5, (sens_num / den) ** 0.5
+    assert ours <= max(2.0 * ref, 2.0 * sens, 1e-4), (kpl, shape, ours, ref, sens)
+
+
 @pytest.mark.skipif(os.environ.get("SMAAT_DW_ROWS", "1") == "0" or os.environ.get("SMAAT_UP_ROWS", "1") == "0",
                     reason="row-streaming kernels switched off: mixed precision is not available")
 @pytest.mark.parametrize("shape", [(2, 64, 64), (1, 96, 32), (3, 32, 64), (2, 128, 64), (1, 32, 32)])
