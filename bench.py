@@ -398,6 +398,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     power = sampler.stop() if sampler is not None else None
+    peak_gb = round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)  # activations + workspaces + optimizer state of this rank
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -668,6 +669,7 @@ def main():
             "f32_mfma_only": alt,
             "configs": side,
             "power": power,
+            "hbm_peak_allocated_gib": peak_gb,
             "fwd_latency": latency,
             "kernels": kernels,
         }
