@@ -285,6 +285,22 @@ def side_config(kind, dev, steps=24, warmup=6):
     return rec
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this script under torch.distributed.run with N ranks on
+    this node (rendezvous on 127.0.0.1, a free port), exactly the driver's multi-GPU command line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    print("bench.py: launching", " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -321,15 +337,22 @@ def main():
     if args.precision != "f32" or args.batch != 32 or args.size != 288:
         args.no_side_configs = True  # they belong to the default (headline) run
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: launch ourselves as N ranks, one per GPU (the same command line the driver
+        # uses: torch.distributed.run on 127.0.0.1), pass the ranks' output through and return their exit code
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but torch.distributed.run started {world} ranks (WORLD_SIZE={world})")
     # SMAAT_BENCH_BACKEND=gloo (testing only): lets several ranks share one GPU to exercise the multi-rank control
     # flow on a single-GPU box; the driver's runs use nccl (= RCCL), one rank per GPU
     backend = os.environ.get("SMAAT_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"bench.py --gpus {world} needs {world} devices (one rank per GPU over RCCL); this host has {ndev}")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
@@ -638,6 +661,9 @@ def main():
             "value": round(frames / dt, 2),
             "unit": "frames/s",
             "n_gpus": world,
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "collective_backend": (backend + (" (RCCL %s)" % ".".join(map(str, torch.cuda.nccl.version()))
+                                              if backend == "nccl" else "")) if world > 1 else None,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),

@@ -152,11 +152,23 @@ class UNetDSFamily(nn.Module):
         return r
 
     def _weights_signature(self):
-        ts = self.__dict__.get("_sig_tensors")
-        if ts is None:  # (the flat tensor list is rebuilt after _apply / load_state_dict / invalidate_eval_cache)
-            ts = self.__dict__["_sig_tensors"] = list(self.parameters()) + list(self.buffers())
+        """sum of the autograd version counters of every parameter and buffer, or -1 (never equal to a stored
+        signature) when a Parameter / buffer OBJECT was replaced since the list was cached -- `module.weight =
+        nn.Parameter(...)`, `parent.load_state_dict(sd, assign=True)`, parametrize, swap_tensors: the cached graph holds
+        the old storage and would silently replay the old weights.  One pass of ~360 dict lookups (~15 us).
+        Remaining blind spot: writes through `.data` (see enable_eval_graph)."""
+        ents = self.__dict__.get("_sig_tensors")
+        if ents is None:  # (rebuilt after _apply / load_state_dict / invalidate_eval_cache)
+            ents = []
+            for m in self.modules():
+                ents += [(m._parameters, k, t) for k, t in m._parameters.items() if t is not None]
+                ents += [(m._buffers, k, t) for k, t in m._buffers.items() if t is not None]
+            self.__dict__["_sig_tensors"] = ents
         v = 0
-        for t in ts:
+        for d, k, t in ents:
+            if d.get(k) is not t:
+                self.__dict__["_sig_tensors"] = None
+                return -1
             v += t._version
         return v
 
@@ -165,9 +177,11 @@ class UNetDSFamily(nn.Module):
         key = (tuple(x.shape), x.dtype, x.device)
         sig = self._weights_signature()
         ent = self._graphs.get(key)
-        if ent is not None and ent["sig"] != sig:
+        if ent is not None and (sig < 0 or ent["sig"] != sig):
             self.invalidate_eval_cache()  # (the folded weights are stale as well)
             ent = None
+        if sig < 0:
+            self.invalidate_eval_cache()
         if ent is None:
             while len(self._graphs) >= self.MAX_EVAL_GRAPHS:
                 self._graphs.pop(next(iter(self._graphs)))

@@ -178,7 +178,8 @@ class CBAM(nn.Module):
             g, b, rm, rv, training, momentum, eps = _bn_args(sp.bn)
             return ops.cbam(x, w1, b1, w2, b2, sp.conv.weight, g, b, rm, rv, training, momentum, eps, True, True,
                             lazy=lazy)
-        if self._eval_fast():  # inference: three launches, BatchNorm(1) on the running statistics
+        if self._eval_fast() and x.dtype == torch.float32:  # inference: three launches, BatchNorm(1) on the running
+            # statistics (the inference operator set is f32: a bf16 activation takes the general operator below)
 
             return torch.ops.smaat.cbam_infer(x, w1, b1, w2, b2, sp.conv.weight, sp.bn.weight, sp.bn.bias,
                                               sp.bn.running_mean, sp.bn.running_var, sp.bn.eps)
@@ -188,7 +189,7 @@ class CBAM(nn.Module):
     def forward_pool_cat_forked(self, x, c_extra, side):
         """forward_pool_cat for the captured inference graph at small batch: (cat, pooled, keepalive) with the attention
         running on the stream `side` (ops.cbam_eval_forked), or None when that path does not apply"""
-        if isinstance(x, tuple) or not self._eval_fast() or not x.is_cuda:
+        if isinstance(x, tuple) or not self._eval_fast() or not x.is_cuda or x.dtype != torch.float32:
             return None
         w1, b1, w2, b2 = self.channel_att._mlp_params()
         sp = self.spatial_att
@@ -215,7 +216,7 @@ class CBAM(nn.Module):
             g, b, rm, rv, training, momentum, eps = _bn_args(sp.bn)
             return ops.cbam_pool_cat(x, w1, b1, w2, b2, sp.conv.weight, g, b, rm, rv, training, momentum, eps, c_extra,
                                      lazy=lazy)
-        if self._eval_fast():
+        if self._eval_fast() and x.dtype == torch.float32:
 
             return torch.ops.smaat.cbam_pool_cat_infer(x, w1, b1, w2, b2, sp.conv.weight, sp.bn.weight, sp.bn.bias,
                                                        sp.bn.running_mean, sp.bn.running_var, sp.bn.eps, c_extra)

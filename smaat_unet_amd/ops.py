@@ -40,14 +40,26 @@ def _stream(t):
     return None
 
 
-def _check(*tensors):
-    for t in tensors:
+def _check(*tensors, acts=1, bf16=True):
+    """Operator-boundary type check.  The first `acts` tensors are activations (or activation gradients): float32, or
+    bfloat16 when the operator has a bf16-storage kernel family (bf16=True; they dispatch on _dt()).  Every other tensor
+    is a parameter or buffer and must be float32: the kernels read and WRITE them (running statistics) as 4-byte
+    floats, so a model converted with .bfloat16() / Lightning "bf16-true" must fail here, not read out of bounds."""
+    for i, t in enumerate(tensors):
         if t is None:
             continue
         if not t.is_cuda and not _lib._ALLOW_HOST_POINTERS:
             raise _lib.SmaatHipError("smaat_unet_amd operators need ROCm (cuda) tensors: there is no CPU fallback")
-        if t.dtype not in (torch.float32, torch.int32, torch.bfloat16):
-            raise TypeError(f"smaat_unet_amd operators take float32 (and bfloat16 activations in mixed precision), got {t.dtype}")
+        if i < acts:
+            if t.dtype == torch.float32 or (bf16 and t.dtype == torch.bfloat16):
+                continue
+            raise TypeError("smaat_unet_amd: this operator takes float32 activations"
+                            + (" (or bfloat16 ones in mixed precision)" if bf16 else " only (no bf16-storage kernel)")
+                            + f", got {t.dtype}")
+        elif t.dtype != torch.float32:
+            raise TypeError(f"smaat_unet_amd: parameters and buffers must be float32 (master weights; mixed precision "
+                            f"stores only activations as bfloat16), got {t.dtype} -- use model.set_precision('bf16') or "
+                            f"torch.autocast instead of model.bfloat16()")
 
 
 def _dt(t):
@@ -896,7 +908,7 @@ def _unit_affine(c, ref):
 def dsconv_folded(x, w_dw, b_dw, fold, kpl, relu_out=True):
     """relu?(pointwise'(depthwise(x))) with BatchNorm folded into the pointwise conv and the ReLU fused into the GEMM
     epilogue: a whole DepthwiseSeparableConv -> BatchNorm2d(eval) -> ReLU half block.  No autograd (inference)."""
-    _check(x, w_dw, b_dw)
+    _check(x, w_dw, b_dw, bf16=False)
     L = _lib.get()
     x, x_bs = _planes(x)
     n, cin, h, w = x.shape
@@ -939,7 +951,7 @@ def double_conv_ds_eval(x, half1, half2, kpl):
 class _DSConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_dw, b_dw, w_pw, b_pw, kpl):
-        _check(x, w_dw, b_dw, w_pw, b_pw)
+        _check(x, w_dw, b_dw, w_pw, b_pw, bf16=False)
         _expect_dsconv(x, w_dw, b_dw, w_pw, b_pw, kpl)
         w_dw = w_dw.contiguous()
         w_pw = w_pw.contiguous()
@@ -1226,7 +1238,7 @@ def _copy_planes_raw(src_ptr, s_bs, dst_ptr, d_bs, n, plane_len, esize, s):
 class _UpsampleCat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, x2):
-        _check(x1, x2)
+        _check(x1, x2, acts=2)
         L = _lib.get()
         x1, x1_bs = _planes(x1)
         x2, x2_bs = _planes(x2)
@@ -1509,7 +1521,7 @@ def cbam_eval(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, eps, out=None, pool
     """Inference CBAM (eval mode, no autograd): three launches -- channel pooling, shared MLP + channel-wise
     mean/max maps, spatial conv + BatchNorm(1) on the running statistics + sigmoid + the final product -- and,
     with pool=True, MaxPool2d(2) of the un-attended input from the same loads.  Returns out or (out, pooled)."""
-    _check(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv)
+    _check(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, bf16=False)
     L = _lib.get()
     x, x_bs = _planes(x)
     n, c, h, w = x.shape
@@ -1656,7 +1668,7 @@ class _UpsampleInto(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cat, x1, c_off):
-        _check(cat, x1)
+        _check(cat, x1, acts=2)
         L = _lib.get()
         x1, x1_bs = _planes(x1)
         n, c1, h, w = x1.shape
@@ -1749,7 +1761,7 @@ class _UpConvInto(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cat, x1, w, b, c_off):
-        _check(cat, x1, w, b)
+        _check(cat, x1, w, b, acts=2)
         assert cat.is_contiguous() and cat.shape[1] == c_off + w.shape[1]
         ctx.geom = _upconv_forward(x1, w, b, cat, c_off)
         ctx.save_for_backward(x1, w)
@@ -1769,7 +1781,7 @@ class _UpConvCat(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x1, x2, w, b):
-        _check(x1, x2, w, b)
+        _check(x1, x2, w, b, acts=2)
         L = _lib.get()
         x2, x2_bs = _planes(x2)
         n2, c2, ho, wo = x2.shape

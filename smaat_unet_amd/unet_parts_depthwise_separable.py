@@ -57,10 +57,13 @@ class DoubleConvDS(nn.Module):
         self.__dict__["_fold_cache"] = {}
         return self
 
-    def _eval_fast_ok(self, hooked):
+    def _eval_fast_ok(self, hooked, x):
         import torch
         seq = self.double_conv
+        # (the inference operator set is f32; a bf16 activation -- mixed precision with a hooked block upstream -- takes
+        # the general operators below, which dispatch on the stored type)
         return (self.EVAL_FAST_PATH and not hooked and not self.training and not torch.is_grad_enabled()
+                and x.dtype == torch.float32
                 and all(seq[j].track_running_stats and seq[j].running_mean is not None and not seq[j].training
                         for j in (1, 4))
                 and seq[0].kernels_per_layer_ == seq[3].kernels_per_layer_)
@@ -109,7 +112,7 @@ class DoubleConvDS(nn.Module):
             halves = [(seq[i].depthwise.weight, seq[i].depthwise.bias, seq[i].pointwise.weight, seq[i].pointwise.bias)
                       + _bn_args(seq[i + 1]) for i in (0, 3)]
             return ops.double_conv_ds(x, halves[0], halves[1], seq[0].kernels_per_layer_, head=(head.weight, head.bias))
-        if self._eval_fast_ok(hooked):
+        if self._eval_fast_ok(hooked, x):
             for conv in (seq[0], seq[3]):
                 conv._check_geometry()
             return ops.double_conv_ds_eval(x, self._folded_half(0), self._folded_half(1), seq[0].kernels_per_layer_)

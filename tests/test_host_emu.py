@@ -553,3 +553,65 @@ def test_mixed_precision_falls_back_to_f32_storage_where_it_is_not_built():
         warnings.simplefilter("always")
         ok(torch.randn(1, 4, 32, 32))
     assert not w
+
+
+def test_bf16_parameters_and_bf16_inputs_to_f32_only_operators_raise():
+    """only ACTIVATIONS may be bfloat16, and only for operators that have a bf16-storage kernel
+    family.  A model converted with .bfloat16() (Lightning "bf16-true"), or a bf16 tensor reaching an f32-only kernel,
+    must raise a TypeError at the operator boundary -- the kernels would read the 2-byte buffers as 4-byte floats and
+    write running statistics out of bounds."""
+    from smaat_unet_amd import ops as K
+    x = torch.randn(2, 4, 32, 32)
+    for train in (True, False):
+        m = S.SmaAt_UNet(4, 2).train(train).bfloat16()
+        with pytest.raises(TypeError, match="must be float32"):
+            m(x)
+        with pytest.raises(TypeError, match="must be float32"), torch.no_grad():
+            m(x.bfloat16())
+    blk = S.DoubleConvDS(4, 8, kernels_per_layer=2).eval()
+    cb = S.CBAM(32).eval()
+    conv = blk.double_conv[0]
+    xb = x.bfloat16()
+    with torch.no_grad():
+        # f32-only entry points (inference operator set, plain DepthwiseSeparableConv): TypeError, not a wrong read
+        with pytest.raises(TypeError, match="float32 activations only"):
+            K.dsconv(xb, conv.depthwise.weight, conv.depthwise.bias, conv.pointwise.weight, conv.pointwise.bias, 2)
+        with pytest.raises(TypeError, match="float32 activations only"):
+            K.dsconv_folded(xb, *blk._folded_half(0), 2)
+        sp = cb.spatial_att
+        with pytest.raises(TypeError, match="float32 activations only"):
+            K.cbam_eval(torch.randn(1, 32, 8, 8).bfloat16(), *cb.channel_att._mlp_params(), sp.conv.weight, sp.bn.weight,
+                        sp.bn.bias, sp.bn.running_mean, sp.bn.running_var, sp.bn.eps)
+        # the modules themselves route a bf16 activation to the general (typed) operators instead of the f32 fast path
+        out = cb(torch.randn(1, 32, 8, 8).bfloat16())
+        assert out.dtype == torch.bfloat16
+        assert blk(xb).dtype == torch.bfloat16
+    # a bf16 parameter handed to a typed operator is refused as well
+    with pytest.raises(TypeError, match="must be float32"):
+        K.pointwise(x, torch.randn(3, 4, 1, 1).bfloat16(), None)
+
+
+def test_eval_with_a_hooked_block_under_bf16_precision():
+    """ADVICE r3's concrete trigger: eval + no_grad under precision("bf16") with a forward hook on a DoubleConvDS child.
+    The hooked block runs half by half in bf16; everything downstream must follow the stored type (general operators)
+    rather than feed a bf16 tensor to the f32 inference kernels."""
+    torch.manual_seed(5)
+    m = S.SmaAt_UNet(4, 2).eval()
+    x = torch.randn(1, 4, 32, 32)
+    with torch.no_grad():
+        ref = m(x)
+    from smaat_unet_amd import ops as K
+    dtypes = []
+    orig = K.dsconv_bn_relu
+    h = m.inc.double_conv[0].register_forward_hook(lambda mod, i, o: None)  # (selects the half-by-half wiring of the block)
+    m.set_precision("bf16")
+    K.dsconv_bn_relu = lambda x_, *a, **k: (dtypes.append(x_.dtype), orig(x_, *a, **k))[1]
+    try:
+        with torch.no_grad():
+            out = m(x)
+    finally:
+        K.dsconv_bn_relu = orig
+        h.remove()
+    assert dtypes == [torch.float32, torch.bfloat16]  # the hooked block ran half by half, its second half on bf16
+    assert out.dtype == torch.float32 and out.shape == ref.shape
+    assert rel(out.numpy(), ref.numpy()) < 0.2
