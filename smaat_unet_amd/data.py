@@ -63,6 +63,68 @@ class NpySampleSource:
             dst[b, ni] = s[-1]
 
 
+class H5SampleSource:
+    """The reference's dataset itself: `precipitation_maps_oversampled_h5` (/root/reference/utils/dataset_precip.py:48-80)
+    over the HDF5 file /root/reference/create_datasets.py writes -- group "train" | "test", dataset "images"
+    [samples][T][H][W] float32, chunked, gzip level 9.  `h5py` is not in this image: smaat_unet_amd.h5lite reads the format
+    directly (B-tree chunk index walk + zlib).  Same contract as NpySampleSource (`__getitem__`, `__len__`, `gather_into`,
+    `.data.shape`), so PrefetchLoader takes either.
+
+    gather_into inflates ONLY the chunks that hold the frames a sample contributes (`imgs[:num_input]` and `imgs[-1]`): with
+    h5py's chunk guess for the real geometry ((1, 3, 36, 72) for 18 x 288 x 288) that is 5 of the 6 chunk rows.  zlib
+    releases the GIL, so the loader's gather threads inflate in parallel; one descriptor, positional reads."""
+
+    def __init__(self, in_file, num_input_images=12, train=True, transform=None, dataset="images"):
+        from .h5lite import H5File
+        self.file = H5File(in_file)
+        self.data = self.file["train" if train else "test"][dataset]
+        if self.data.ndim != 4 or self.data.dtype != np.float32:
+            raise ValueError(f"expected a float32 dataset [samples][T][H][W], got {self.data.dtype} {self.data.shape}")
+        if not 0 < num_input_images < self.data.shape[1]:
+            raise ValueError("num_input_images must leave at least one frame for the target")
+        self.num_input = int(num_input_images)
+        self.transform = transform
+        self._frames = list(range(self.num_input)) + [self.data.shape[1] - 1]
+        self._tls = threading.local()
+
+    def __len__(self):
+        return self.data.shape[0]
+
+    def __getitem__(self, index):
+        imgs = self.data[index]  # np.array(self.dataset[index], dtype="float32")  (dataset_precip.py:69)
+        if self.transform is not None:
+            imgs = self.transform(imgs)
+        return imgs[: self.num_input], imgs[-1]
+
+    def gather_into(self, indices, dst):
+        ni = self.num_input
+        buf = getattr(self._tls, "buf", None)
+        if buf is None:
+            buf = self._tls.buf = np.empty(self.data.shape[1:], np.float32)  # one sample of scratch per gather thread
+        for b, i in enumerate(indices):
+            if self.transform is not None:
+                s = self.transform(self.data.read_into(int(i), buf))
+            else:
+                s = self.data.read_into(int(i), buf, frames=self._frames)
+            dst[b, :ni] = s[:ni]
+            dst[b, ni] = s[-1]
+
+    def close(self):
+        self.file.close()
+
+
+def write_precip_h5(path, splits, chunks=None, level=9):
+    """{"train": array, "test": array} (float32 [samples][T][H][W]) -> an HDF5 file in the reference's dataset layout
+    (create_datasets.py:31-61: chunked, gzip; chunks default to what h5py guesses for a (1, T, H, W) creation shape at
+    288 x 288: (1, 3, 36, 72)).  Used to lay down synthetic datasets (bench.py, tests) without libhdf5."""
+    from .h5lite import write_images_h5
+    any_arr = next(iter(splits.values()))
+    if chunks is None:
+        t, h, w = any_arr.shape[1:]
+        chunks = (1, min(3, t), min(36, h), min(72, w))
+    write_images_h5(path, splits, chunks, level=level)
+
+
 class PrefetchLoader:
     """Iterate `(x [B][num_input][H][W], y [B][H][W])` device tensors over `source`.
 

@@ -15,6 +15,7 @@ Tolerances: forward <= 1e-4 rel-L2 (north_star); eval-mode gradients <= 2e-3 per
 single-number BN(1) gradients of the spatial attentions); training gradients: error
 against the reference's fp64 anchors <= max(3 x the reference's own fp32-vs-fp64 error, 5e-3) per tensor
 (the reference disagrees with itself at 2e-3 .. 3e-2 end to end)."""
+import contextlib
 import json
 import os
 
@@ -37,6 +38,10 @@ EVAL_BLOCKS = {
     "dsconv_k2": lambda: S.DepthwiseSeparableConv(6, 10, kernel_size=3, padding=1, kernels_per_layer=2),
 }
 BIG = ["unet_12x1_n3_64x48_eval", "unet_12x1_n2_288", "unet_3x21_n2_256"]
+# round 4 (VERDICT r3 next #1a): the EXACT batches BASELINE.json quotes -- configs[1] = 32 x 12 x 288 x 288 and configs[4] =
+# 16 x 3 x 256 x 256 -- from the real reference (fp64 anchors block-checkpointed, oracle/gen_golden.py).  Batch changes what
+# runs: BatchNorm tile-partial merge depth, weight-gradient split counts, persistent-tile ranges, the split-K policy at 18^2.
+BIG_FULL = ["unet_12x1_n32_288", "unet_3x21_n16_256"]
 
 
 def _zero_grad_key(k):
@@ -207,7 +212,7 @@ def test_big_case_host_logic(golden_dir, _emu):
     run_big(golden_dir, "unet_12x1_n3_64x48_eval", torch.device("cpu"))
 
 
-@pytest.mark.parametrize("name", BIG)
+@pytest.mark.parametrize("name", BIG + BIG_FULL)
 def test_aten_port_pinned_to_big_goldens(golden_dir, name):
     """oracle/torch_ref.py (the cpu_baseline leg of bench.py) against the reference at the benchmark sizes, train
     and eval mode -- the same ATen operators, so agreement is at round-off level"""
@@ -218,7 +223,8 @@ def test_aten_port_pinned_to_big_goldens(golden_dir, name):
     torch.set_num_threads(8)
     P = torch_ref.params_from_numpy(oparams.make_smaat_params(meta["n_channels"], meta["n_classes"], 2, 16,
                                                               meta["param_seed"]))
-    logits = torch_ref.forward(P, torch.from_numpy(x), training=True)
+    with torch.no_grad() if name in BIG_FULL else contextlib.nullcontext():  # (no autograd graph at batch 32: ~35 GB)
+        logits = torch_ref.forward(P, torch.from_numpy(x), training=True)
     assert check_summary(g, "train/logits", logits.detach().numpy()) < 2e-5
     loss = _loss(meta["kind"], logits, torch.from_numpy(target), meta["n"])
     assert abs(loss.item() - float(g["train/loss"])) < 1e-5 * abs(float(g["train/loss"]))
@@ -241,8 +247,8 @@ def test_eval_blocks_gpu(ops_eval, tag, policy, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,policy", [(n, "auto") for n in BIG] + [("unet_12x1_n3_64x48_eval", "all"),
-                                                                      ("unet_12x1_n2_288", "all")])
+@pytest.mark.parametrize("name,policy", [(n, "auto") for n in BIG + BIG_FULL] + [("unet_12x1_n3_64x48_eval", "all"),
+                                                                                 ("unet_12x1_n2_288", "all")])
 def test_big_cases_gpu(golden_dir, name, policy, monkeypatch):
     from smaat_unet_amd import ops as _ops
     monkeypatch.setattr(_ops, "SPLIT_POLICY", policy)

@@ -361,9 +361,9 @@ def test_bf16_storage_mixed_precision(ops):
           (tests/emu_backend.py: f32 twins + one rounding per stored tensor): the loss within 1 %, the logits at less than
           half the distance of the f32 path, the flat gradient at cosine > 0.9 -- the kernels compute the mode they claim;
           the residual is 1-ulp bf16 flips caused by f32 accumulation order, amplified by the network;
-      (3) against the fp32 path: logits within 0.25.  Stock torch.autocast(bfloat16) around the REFERENCE modules moves the
-          logits of this random-init network by 0.16 and the flat gradient to cosine 0.82
-          (scripts/probes/ref_autocast_bf16_accuracy.py); this mode is in the same class, numbers in gpurun_out/bf16_storage.json;
+      (3) against the fp32 path: no further than 1.25 x what stock torch.autocast(bfloat16) does to the REFERENCE modules on
+          this case (fixture autocast_bf16_n2_64 generated from /root/reference: logits 0.180, flat gradient 1 - cos 0.220);
+          numbers in gpurun_out/bf16_storage.json;
       (4) every activation the autograd graph keeps is bf16 (2 bytes per element), logits and parameter gradients are f32;
       (5) training reduces the loss; the default path afterwards is bit-identical to before."""
     from tests import emu_backend
@@ -434,8 +434,13 @@ def test_bf16_storage_mixed_precision(ops):
     # random-init network amplifies any per-op perturbation 60-150x)
     assert report["logits_vs_emulated_mixed_precision"] < 0.5 * report["logits_vs_fp32_path"], report
     assert report["grad_cos_vs_emulated"] > 0.9, report
-    assert report["logits_vs_fp32_path"] < 0.25, report
-    assert report["grad_cos_vs_fp32"] > 0.7, report
+    # (3) the yardstick is what stock autocast does to the REFERENCE on this very case (tests/golden/autocast_bf16_n2_64.npz,
+    # same parameters / batch: logits 0.180, 1 - cosine 0.220); tests/test_autocast_yardstick.py holds the full rule
+    from tests.test_autocast_yardstick import FACTOR, yardstick
+    yard = yardstick(np.load(os.path.join(os.path.dirname(__file__), "golden", "autocast_bf16_n2_64.npz")))
+    report["reference_autocast_yardstick"] = yard
+    assert report["logits_vs_fp32_path"] < FACTOR * yard["logits"], report
+    assert 1.0 - report["grad_cos_vs_fp32"] < FACTOR * yard["one_minus_cos"], report
     assert abs(losses[0] - emu_losses[0]) < 1e-2 * abs(emu_losses[0]), report
     assert losses[-1] < losses[0], losses
     again, _, _ = run("f32")
