@@ -588,23 +588,15 @@ def main():
 
     # ---- the same step fed by the input pipeline: memory-mapped samples -> pinned ring -> async H2D
     #      on a copy stream -> batch-strided device views.  PCIe-inclusive; reported next to `value`, never as `value`.
-    fed = None
+    fed = fed_h5 = None
     if rank == 0 and args.gpus == 1 and not args.no_input_pipeline and args.precision == "f32":
-        try:
-            import tempfile
-            from smaat_unet_amd.data import NpySampleSource, PrefetchLoader
-            nsamp = 4 * args.batch
-            path = os.path.join(tempfile.gettempdir(), f"smaat_bench_samples_{os.getpid()}.npy")
-            rng = np.random.default_rng(7)
-            arr = np.lib.format.open_memmap(path, mode="w+", dtype=np.float32, shape=(nsamp, 18, args.size, args.size))
-            for i in range(nsamp):  # 18 frames per sample as in the reference's HDF5 layout (6 MB at 288 x 288)
-                u = rng.random((18, args.size, args.size), dtype=np.float32)
-                arr[i] = np.where(u > 0.7, (u - 0.7) / 0.3 * 0.5, 0)
-            arr.flush()
-            del arr
-            loader = PrefetchLoader(NpySampleSource(path, 12), args.batch, device=dev, depth=3, workers=8, shuffle=True)
+        import tempfile
+        from smaat_unet_amd.data import H5SampleSource, NpySampleSource, PrefetchLoader, write_precip_h5
+
+        def fed_run(source, workers, epochs):
+            loader = PrefetchLoader(source, args.batch, device=dev, depth=3, workers=workers, shuffle=True)
             nstep, t0 = 0, None
-            for ep in range(4):
+            for ep in range(epochs):
                 for xb, yb in loader:
                     if nstep == 4:  # warm-up: page cache, pinned ring
                         torch.cuda.synchronize()
@@ -617,15 +609,50 @@ def main():
                     nstep += 1
             torch.cuda.synchronize()
             dtf = time.perf_counter() - t0
-            fed = {"value": round(args.batch * (nstep - 4) / dtf, 2), "unit": "frames/s",
-                   "ms_per_step": round(dtf / (nstep - 4) * 1e3, 3), "steps": nstep - 4,
-                   "h2d_bytes_per_step": args.batch * 13 * args.size * args.size * 4,
-                   "what": "same training step fed by smaat_unet_amd.data.PrefetchLoader from a memory-mapped .npy of "
+            loader.close()
+            return {"value": round(args.batch * (nstep - 4) / dtf, 2), "unit": "frames/s",
+                    "ms_per_step": round(dtf / (nstep - 4) * 1e3, 3), "steps": nstep - 4, "gather_threads": workers,
+                    "h2d_bytes_per_step": args.batch * 13 * args.size * args.size * 4}
+
+        nsamp = 4 * args.batch
+        rng = np.random.default_rng(7)
+        path = os.path.join(tempfile.gettempdir(), f"smaat_bench_samples_{os.getpid()}.npy")
+        try:
+            arr = np.lib.format.open_memmap(path, mode="w+", dtype=np.float32, shape=(nsamp, 18, args.size, args.size))
+            for i in range(nsamp):  # 18 frames per sample as in the reference's HDF5 layout (6 MB at 288 x 288)
+                u = rng.random((18, args.size, args.size), dtype=np.float32)
+                arr[i] = np.where(u > 0.7, (u - 0.7) / 0.3 * 0.5, 0)
+            arr.flush()
+            del arr
+            fed = fed_run(NpySampleSource(path, 12), 8, 4)
+            fed["what"] = ("same training step fed by smaat_unet_amd.data.PrefetchLoader from a memory-mapped .npy of "
                            "18-frame samples (13 of 18 frames gathered into pinned buffers by 8 threads, async H2D on a copy "
-                           "stream, batch-strided device views): host gather + PCIe + step overlapped"}
-            os.remove(path)
+                           "stream, batch-strided device views): host gather + PCIe + step overlapped")
         except Exception as e:  # noqa: BLE001
             fed = {"error": str(e)[:200]}
+        # ---- the reference's own container: HDF5, chunked (1, 3, 36, 72), gzip level 9 (create_datasets.py:33-40), read by
+        #      the pure-Python reader (smaat_unet_amd/h5lite.py: B-tree chunk index + zlib inflate in the gather threads)
+        h5path = os.path.join(tempfile.gettempdir(), f"smaat_bench_samples_{os.getpid()}.h5")
+        try:
+            nh5 = 2 * args.batch
+            src = np.load(path, mmap_mode="r")[:nh5]
+            t0 = time.perf_counter()
+            write_precip_h5(h5path, {"train": np.asarray(src)}, level=9)
+            t_write = time.perf_counter() - t0
+            del src
+            workers = max(8, min(96, (os.cpu_count() or 8) // 2))
+            fed_h5 = fed_run(H5SampleSource(h5path, 12), workers, 8)
+            fed_h5.update(file_mb=round(os.path.getsize(h5path) / 1e6, 1), raw_mb=round(nh5 * 18 * args.size * args.size * 4 / 1e6, 1),
+                          write_s=round(t_write, 1),
+                          what=f"same step fed from an HDF5 file in the reference's layout (train/images [{nh5}][18][{args.size}]"
+                               f"[{args.size}] float32, chunks (1, 3, 36, 72), gzip level 9): the chunks of frames 0..11 and 17 of "
+                               f"each sample located through the version-1 B-tree index and inflated with zlib by {workers} gather "
+                               "threads, then the same pinned ring / async H2D path")
+        except Exception as e:  # noqa: BLE001
+            fed_h5 = {"error": str(e)[:200]}
+        for pth in (path, h5path):
+            if os.path.exists(pth):
+                os.remove(pth)
 
     eager = None
     if rank == 0 and args.gpus == 1 and not args.no_eager_baseline and args.precision == "f32":
@@ -692,6 +719,7 @@ def main():
             "cpu_baseline": cpu,
             "rocm_eager_baseline": eager,
             "input_pipeline_fed": fed,
+            "input_pipeline_fed_hdf5": fed_h5,
             "f32_mfma_only": alt,
             "configs": side,
             "power": power,

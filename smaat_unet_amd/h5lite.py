@@ -518,22 +518,27 @@ def _write_chunk_btree(o, entries, nd, end_key):
         items, level = nxt, level + 1
 
 
-def _write_dataset(o, arr, chunks, level):
+def _write_dataset(o, arr, chunks, level, threads):
     arr = np.ascontiguousarray(arr, dtype="<f4")
     nd = arr.ndim
     if len(chunks) != nd:
         raise ValueError("chunk rank")
     grid = [-(-s // c) for s, c in zip(arr.shape, chunks)]
-    entries = []
-    for cc in np.ndindex(*grid):
+
+    def deflate(cc):
         lo = [c * k for c, k in zip(cc, chunks)]
         blk = np.zeros(chunks, "<f4")  # edge chunks are stored whole (fill value beyond the extent)
         src = arr[tuple(slice(a, a + k) for a, k in zip(lo, chunks))]
         blk[tuple(slice(0, s) for s in src.shape)] = src
-        z = zlib.compress(blk.tobytes(), level)
-        a = o.alloc(len(z), align=1)
-        o.put(a, z)
-        entries.append((tuple(lo) + (0,), len(z), a))
+        return tuple(lo) + (0,), zlib.compress(blk.tobytes(), level)
+
+    entries = []
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max(1, threads)) as pool:  # zlib releases the GIL; map keeps the chunk order
+        for off, z in pool.map(deflate, np.ndindex(*grid), chunksize=16) if threads > 1 else map(deflate, np.ndindex(*grid)):
+            a = o.alloc(len(z), align=1)
+            o.put(a, z)
+            entries.append((off, len(z), a))
     end = (grid[0] * chunks[0],) + (0,) * nd
     bt = _write_chunk_btree(o, entries, nd, end)
     space = struct.pack("<BBB5x", 1, nd, 1) + struct.pack(f"<{nd}Q", *arr.shape) + \
@@ -550,7 +555,7 @@ def _write_dataset(o, arr, chunks, level):
     return a
 
 
-def write_images_h5(path, splits, chunks, level=9, dataset="images"):
+def write_images_h5(path, splits, chunks, level=9, dataset="images", threads=None):
     """{group name: float32 array [samples][T][H][W]} -> an HDF5 file with one chunked, deflate-compressed dataset
     `dataset` per group: the layout of /root/reference/create_datasets.py:31-61 (without the timestamps)."""
     with open(path, "wb") as fh:
@@ -558,7 +563,8 @@ def write_images_h5(path, splits, chunks, level=9, dataset="images"):
         sb = o.alloc(96)
         groups = {}
         for name, arr in splits.items():
-            d = _write_dataset(o, arr, tuple(int(c) for c in chunks), level)
+            d = _write_dataset(o, arr, tuple(int(c) for c in chunks), level,
+                               threads if threads is not None else min(32, os.cpu_count() or 1))
             groups[name], _, _ = _write_group(o, {dataset: d})
         root, bt, hh = _write_group(o, groups)
         eof = o.alloc(0)
