@@ -68,6 +68,23 @@ int smaat_dsconv_wgrad(const float* x, long x_bs, const float* in_scale, const f
 int smaat_pointwise_wgrad(const float* x, long x_bs, const float* dz, long dz_bs, float* ws, float* dw_out, int N,
                           int Cin, int M, int H, int W, void* stream);
 
+/* ---- the same weight gradient on the bf16-split matrix path with Y = depthwise3x3(act(x)) RECOMPUTED by the producer
+ *      waves from x (round 4; csrc/dswgrad.hip): reads Cin channels instead of the Cin*kpl channels of the kept
+ *      depthwise output, and lets the forward of the layer (smaat_dsconv_fwd_split) run without its y_out side output,
+ *      so the 2x-expanded tensor never exists in HBM.  in_scale / in_shift (nullable pair): x is the pre-BatchNorm
+ *      tensor of the previous half block, relu(x * scale + shift) is applied on load.  Exact three-term operand split
+ *      (f32-class error) or plain bf16 operands, following smaat_split_mode as the other split GEMMs.
+ *      smaat_dsconv_wgrad_split_ok: 1 when the kernel takes the shape (kernels_per_layer 2, W % 32 == 0, Cout <= 64);
+ *      otherwise smaat_dsconv_wgrad_split returns -2 and the caller streams a kept Y through smaat_pointwise_wgrad.
+ *      ws: [smaat_dsconv_wgrad_split_num_splits(...)][Cout][Cin*kpl] floats; fixed-order fp64 reduction, deterministic.
+ *      reference: autograd of nn.Conv2d(K, Cout, 1) behind the depthwise conv, models/layers.py:45,47-50.
+ */
+int smaat_dsconv_wgrad_split_ok(int kpl, int Cout, int H, int W);
+int smaat_dsconv_wgrad_split_num_splits(int N, int Cin, int Cout, int H, int W);
+int smaat_dsconv_wgrad_split(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                             const float* b_dw, const float* dz, long dz_bs, float* ws, float* dw_out, int N, int Cin,
+                             int kpl, int Cout, int H, int W, void* stream);
+
 /* ---- depthwise 3x3 backward (autograd of nn.Conv2d(groups=Cin), models/layers.py:38-44)
  *   dy [N][Cin*kpl][H][W] -> dx [N][Cin][H][W] (nullable), dw_out [Cin*kpl][9], db_out [Cin*kpl] (nullable)
  *   ws: [smaat_dw3x3_bwd_ws_rows(N,Cin,H,W)][Cin*kpl][10] floats

@@ -576,6 +576,65 @@ def gen_autocast(name, n, h, w, param_seed, input_seed, steps=4):
     print(name, {k: float(v) for k, v in s.items() if "/" in k}, "losses32", l32, "autocast", lac, "f64", l64)
 
 
+def gen_eval_noise(name, k=2):
+    """The reference's OWN float32-vs-float64 distance on the eval-mode input gradient of a benchmark-size case (the
+    fixture `name` stores fp64 anchors for the training gradients only).  Eval mode has no cross-sample coupling
+    (BatchNorm on the running statistics), so the first k samples of the eval batch are evaluated on their own, with
+    the running statistics the fixture recorded after its training step: dx of sample i here = dx of sample i in the
+    batch (up to the 1/n of the loss, which the relative error does not see)."""
+    g = np.load(os.path.join(OUT, name + ".npz"))
+    meta = json.loads(str(g["meta"]))
+    P = oparams.make_smaat_params(meta["n_channels"], meta["n_classes"], 2, 16, meta["param_seed"])
+    for key in g.files:
+        if key.startswith("train/after/"):
+            P[key[12:]] = g[key]
+    xe, te = oparams.synthetic_case(meta["kind"], meta["n"], meta["n_channels"], meta["h"], meta["w"], meta["n_classes"],
+                                    meta["param_seed"] + 200)
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        m = SmaAt_UNet(meta["n_channels"], meta["n_classes"])
+        load_np_state(m, P)
+        m = m.to(dt).eval()
+        x = torch.from_numpy(xe[:k]).to(dt).requires_grad_(True)
+        t = torch.from_numpy(te[:k])
+        t = t.to(dt) if meta["kind"] == "precip" else t
+        out = m(x)
+        (_loss(meta["kind"], out, t, k) * (k / meta["n"])).backward()  # the batch's loss restricted to these samples
+        res[dt] = (out.detach().double().numpy(), x.grad.double().numpy())
+    rl = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))  # noqa: E731
+    s = {"meta": np.array(json.dumps(dict(case=name, samples=k))),
+         "eval/noise/logits": np.float64(rl(res[torch.float32][0], res[torch.float64][0])),
+         "eval/noise/dx": np.float64(rl(res[torch.float32][1], res[torch.float64][1]))}
+    # cross-check with the batch run of the fixture: the same values at the sampled positions of these k samples
+    full = np.zeros((meta["n"],) + res[torch.float32][1].shape[1:], np.float32)
+    full[:k] = res[torch.float32][1]
+    idx = np.linspace(0, full.size - 1, 4096).astype(np.int64)
+    sel = idx < res[torch.float32][1].size
+    s["eval/dx_batch_vs_alone"] = np.float64(rl(full.ravel()[idx][sel].astype(np.float64),
+                                                g["eval/dx#vals"][sel].astype(np.float64)))
+    # ... and the reference against ITSELF on the whole batch: the same float32 evaluation sample by sample on ONE thread
+    # (another summation order inside ATen) against the fixture's 8-thread batch run, measured exactly as the tests measure
+    # (at the fixture's 4096 sampled positions, where a single ReLU / max-pool decision that flips under round-off can
+    # dominate: 2.9e-3 at batch 32 although the full-tensor distance is 3.8e-4).  The eval-mode dx bound of the tests is
+    # 1.5 x this figure (floor 2e-3).
+    nt = torch.get_num_threads()
+    torch.set_num_threads(1)
+    m = SmaAt_UNet(meta["n_channels"], meta["n_classes"])
+    load_np_state(m, P)
+    m.eval()
+    rows = []
+    for i in range(meta["n"]):
+        x = torch.from_numpy(xe[i:i + 1]).requires_grad_(True)
+        (_loss(meta["kind"], m(x), torch.from_numpy(te[i:i + 1]), 1) / meta["n"]).backward()
+        rows.append(x.grad.numpy().copy())
+    torch.set_num_threads(nt)
+    alone = np.concatenate(rows)
+    ref = g["eval/dx#vals"].astype(np.float64)
+    s["eval/self/dx_sampled"] = np.float64(rl(alone.ravel()[idx].astype(np.float64), ref))
+    np.savez_compressed(os.path.join(OUT, name + "_evalnoise.npz"), **s)
+    print(name + "_evalnoise", {k_: float(v) for k_, v in s.items() if k_ != "meta"})
+
+
 class _RefVariant(torch.nn.Module):
     """The sibling networks of /root/reference/models/unet_precip_regression_lightning.py wired from the
     REFERENCE blocks.  The reference classes themselves are Lightning modules (`lightning` is not in this
@@ -835,6 +894,9 @@ def _jobs():
     # minutes of CPU; the fp64 anchor runs block-checkpointed) and batch 16 VOC at 256 x 256 (configs[4])
     J["unet_12x1_n32_288"] = lambda: gen_unet_big("unet_12x1_n32_288", "precip", 12, 1, 32, 288, 288, 17, lean64=True)
     J["unet_3x21_n16_256"] = lambda: gen_unet_big("unet_3x21_n16_256", "voc", 3, 21, 16, 256, 256, 18, lean64=True)
+    J["unet_12x1_n32_288_evalnoise"] = lambda: gen_eval_noise("unet_12x1_n32_288")
+    J["unet_3x21_n16_256_evalnoise"] = lambda: gen_eval_noise("unet_3x21_n16_256")
+    J["unet_12x1_n2_288_evalnoise"] = lambda: gen_eval_noise("unet_12x1_n2_288")
     # round 4 (VERDICT r3 next #1b): the reference under torch.autocast(bfloat16)
     J["autocast_bf16_n2_64"] = lambda: gen_autocast("autocast_bf16_n2_64", 2, 64, 64, 3, 11)
     J["autocast_bf16_n2_288"] = lambda: gen_autocast("autocast_bf16_n2_288", 2, 288, 288, 7, 107)

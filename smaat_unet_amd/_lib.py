@@ -29,6 +29,9 @@ SIGNATURES = {
     "smaat_dsconv_wgrad_num_splits": [_I, _I, _I, _I, _I],
     "smaat_dsconv_wgrad": [_P, _L, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "smaat_pointwise_wgrad": [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _P],
+    "smaat_dsconv_wgrad_split_ok": [_I, _I, _I, _I],
+    "smaat_dsconv_wgrad_split_num_splits": [_I, _I, _I, _I, _I],
+    "smaat_dsconv_wgrad_split": [_P, _L, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "smaat_dw3x3_bwd_ws_rows": [_I, _I, _I, _I],
     "smaat_dw3x3_bwd": [_P, _L, _P, _L, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "smaat_dw3x3_strip_ok": [_I, _I, _I],
@@ -226,6 +229,7 @@ WORK_MODELS = {
     "smaat_dsconv_fwd_split": _w_dsconv_fwd,
     "smaat_pointwise_fwd": _w_pointwise_fwd,
     "smaat_dsconv_wgrad": _w_dsconv_wgrad,
+    "smaat_dsconv_wgrad_split": _w_dsconv_wgrad,
     "smaat_pointwise_wgrad": _w_pointwise_wgrad,
     "smaat_dw3x3_bwd": _w_dw_bwd,
     "smaat_affine_act": lambda a: (2.0 * a[6] * a[7] * a[8], 8.0 * a[6] * a[7] * a[8]),

@@ -7,6 +7,23 @@
 
 
 int launch_wgrad2(Wg2Args& a, hipStream_t st);
+struct DsWgArgs {  // dswgrad.hip
+    const float* x;
+    long x_bs;
+    const float* in_scale;
+    const float* in_shift;
+    const float* w_dw;
+    const float* b_dw;
+    const float* dz;
+    long dz_bs;
+    float* part;
+    int N, Cin, K, M, H, W, P;
+    int nkt, nsplit, strips, bands, RB, items, ips;
+};
+int dsconv_wgrad_split_ok(int kpl, int M, int H, int W);
+int dsconv_wgrad_split_num_splits(int N, int Cin, int M, int H, int W);
+int launch_dsconv_wgrad_split(DsWgArgs& a, int kpl, hipStream_t st);
+
 int smaat_dsconv_wgrad_num_splits_impl(int N, int H, int W, int M, int Kdim);
 int launch_pwgemm(PwArgs& a, bool dw, hipStream_t st);
 int launch_wgrad(WgArgs& a, bool dw, hipStream_t st);
@@ -182,6 +199,25 @@ int smaat_dsconv_wgrad(const float* x, long x_bs, const float* in_scale, const f
     a.N = N; a.Cin = Cin; a.kpl = kpl; a.Kdim = Cin * kpl; a.M = Cout; a.g.H = H; a.g.W = W;
     CHK(launch_wgrad(a, true, ST));
     return launch_reduce_rows(ws, a.nsplit, (long)Cout * a.Kdim, dw_out, 1.f, ST);
+}
+
+int smaat_dsconv_wgrad_split_ok(int kpl, int Cout, int H, int W) { return dsconv_wgrad_split_ok(kpl, Cout, H, W); }
+int smaat_dsconv_wgrad_split_num_splits(int N, int Cin, int Cout, int H, int W) {
+    return dsconv_wgrad_split_num_splits(N, Cin, Cout, H, W);
+}
+int smaat_dsconv_wgrad_split(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                             const float* b_dw, const float* dz, long dz_bs, float* ws, float* dw_out, int N, int Cin,
+                             int kpl, int Cout, int H, int W, void* stream) {
+    if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || !x || !w_dw || !dz || !ws || !dw_out) return -1;
+    if ((in_scale == nullptr) != (in_shift == nullptr)) return -1;
+    DsWgArgs a{};
+    a.x = x; a.x_bs = x_bs; a.in_scale = in_scale; a.in_shift = in_shift; a.w_dw = w_dw; a.b_dw = b_dw;
+    a.dz = dz; a.dz_bs = dz_bs; a.part = ws;
+    a.N = N; a.Cin = Cin; a.K = Cin * kpl; a.M = Cout; a.H = H; a.W = W;
+    hipStream_t st = ST;
+    const int rc = launch_dsconv_wgrad_split(a, kpl, st);
+    if (rc) return rc;
+    return launch_reduce_rows(ws, a.nsplit, (long)Cout * a.K, dw_out, 1.f, st);
 }
 
 int smaat_pointwise_wgrad(const float* x, long x_bs, const float* dz, long dz_bs, float* ws, float* dw_out, int N,

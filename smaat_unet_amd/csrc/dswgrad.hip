@@ -1,0 +1,418 @@
+// Pointwise weight gradient of a DepthwiseSeparableConv with the depthwise output RECOMPUTED on the fly
+// (bf16-split matrix path; round 4):
+//
+//   dW[m][k] = sum_{n,p} dz[n][m][p] * y[n][k][p],     y = depthwise3x3(act(x)) (+ b_dw),   k = 2 ci + j
+//   (reference models/layers.py:45,47-50 backward; act = the previous BatchNorm + ReLU applied on load, optional)
+//
+// k_wgrad_split (splitmma.hip) streams y from HBM: 4 (M + K) HW bytes per image.  Here the producer waves stream x
+// (Cin = K / 2 channels) instead and form y in registers, so the 2x-expanded depthwise tensor is neither read here nor
+// written by the forward (k_dsconv_split runs without its side output): 4 (M + K / 2) HW bytes, and the forward of the
+// layer loses a 4 K HW write.  The consumer side is k_wgrad_split's: 4 waves, ds_read_b128 + six v_mfma_f32_32x32x16_bf16
+// per 16-pixel step on [plane][row][32 px] bf16 images, output-stationary 64 (dz rows) x 128 (y rows) tile.
+//
+// Producers (4 waves = 256 threads): thread (ci = t >> 2, g = t & 3) owns channel ci of the 64-channel K tile and the 8
+// pixels 8g .. 8g + 7 of a 32-pixel row segment, and WALKS DOWN a band of rows of one column strip (32 columns) of one
+// image: the 3 x 10 window of act(x) it needs lives in registers and slides by one row per chunk (as in dwrows.hip), one
+// row = two global_load_dwordx4 + the two edge dwords (L1 / L2 hits: the neighbour thread's float4).  No LDS staging of
+// x, no halo re-reads inside a band; a band costs two extra (MFMA-free) priming iterations.  Per chunk a thread computes
+// y for its 2 k-rows x 8 pixels (tap order of k_dw3x3_fwd_rows: bit-identical y), splits the 16 values exactly into
+// three bf16 terms and writes three 16-byte pieces per k-row into the B image; the same threads split their share of the
+// dz chunk (64 rows x 32 px) into the A image.  All global loads are inline asm with counted s_waitcnt (PD row/chunk
+// groups in flight), one barrier per chunk.
+//
+// Work list: items (image, row band, column strip), strips innermost (neighbouring strips share their halo columns and
+// run on the same XCD); a workgroup (split, K tile) walks a contiguous range of items.  Partials part[split][M][K] are
+// summed in fixed order in fp64 by the existing reduction (capi: launch_reduce_rows): deterministic, no atomics.
+#include "common.h"
+#include <stdlib.h>
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned dwg_u32x4 __attribute__((ext_vector_type(4)));
+int split_mode();  // splitmma.hip
+
+#define DWG_SROW 80  // bytes per LDS row: 32 bf16 + 16 B pad (conflict-free ds_read_b128, as k_wgrad_split)
+#define DWG_CW 32    // pixels per chunk = width of a column strip
+
+struct DsWgArgs {
+    const float* x;
+    long x_bs;
+    const float* in_scale;
+    const float* in_shift;
+    const float* w_dw;  // [K][9]
+    const float* b_dw;  // [K] or null
+    const float* dz;
+    long dz_bs;
+    float* part;  // [nsplit][M][K]
+    int N, Cin, K, M, H, W, P;
+    int nkt, nsplit, strips, bands, RB, items, ips;
+};
+
+__device__ __forceinline__ unsigned dwg_fbits(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float dwg_bitsf(unsigned x) { return __builtin_bit_cast(float, x); }
+__device__ __forceinline__ unsigned dwg_pack_hi16(float lo, float hi) {
+    return __builtin_amdgcn_perm(dwg_fbits(hi), dwg_fbits(lo), 0x07060302u);  // {hi.hi16, lo.hi16}
+}
+// 8 consecutive f32 -> NT planes of 8 bf16 (one 16-byte LDS piece per plane); NT = 3: exact three-term split
+// (a = p1 + p2 + p3, truncations, residuals exact), NT = 1: round to nearest even (plain bf16 operands)
+template <int NT>
+__device__ __forceinline__ void dwg_split8(const float (&v)[8], dwg_u32x4 (&out)[NT]) {
+    float p1[8], p2[8], p3[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (NT == 1) {
+            const unsigned b = dwg_fbits(v[i]);
+            p1[i] = dwg_bitsf((b + 0x7FFFu + ((b >> 16) & 1u)) & 0xFFFF0000u);
+            p2[i] = p3[i] = 0.f;
+        } else {
+            p1[i] = dwg_bitsf(dwg_fbits(v[i]) & 0xFFFF0000u);
+            const float r1 = v[i] - p1[i];  // exact
+            p2[i] = dwg_bitsf(dwg_fbits(r1) & 0xFFFF0000u);
+            p3[i] = r1 - p2[i];             // exact, <= 8 significant bits
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        out[0][q] = dwg_pack_hi16(p1[2 * q], p1[2 * q + 1]);
+        if constexpr (NT == 3) {
+            out[1][q] = dwg_pack_hi16(p2[2 * q], p2[2 * q + 1]);
+            out[2][q] = dwg_pack_hi16(p3[2 * q], p3[2 * q + 1]);
+        }
+    }
+}
+
+template <int NT, bool AFF>
+__global__ __launch_bounds__(512) void k_dsconv_wgrad_split(const DsWgArgs a) {
+    constexpr int MT = 64, KT = 128, ROWS = MT + KT;
+    constexpr int PLSZ = ROWS * DWG_SROW, BUFSZ = NT * PLSZ;
+    constexpr int PD = 3;        // load groups in flight per producer thread
+    constexpr int LPG = 6;       // loads per group: x row = 2 x dwordx4 + 2 x dword, dz = 2 x dwordx4
+    static_assert((PD - 1) * LPG <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wv >= 4;
+    const int wave = wv & 3;
+    const int wm = wave & 1, wk = wave >> 1;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+    const int kt = idx % a.nkt;
+    const int split = xcd * (a.nsplit >> 3) + idx / a.nkt;  // contiguous split ranges per XCD (halo columns meet in one L2)
+    const int it_lo = split * a.ips;
+    int it_hi = it_lo + a.ips;
+    if (it_hi > a.items) it_hi = a.items;
+    const int nitems = it_hi > it_lo ? it_hi - it_lo : 0;
+    // flattened iteration space: every item contributes (rows of its band) + 2 priming iterations
+    const int bps = a.bands * a.strips;  // items per image
+    auto item_rows = [&](int item) {
+        const int band = (item % bps) / a.strips;
+        const int r0 = band * a.RB;
+        return (a.H - r0 < a.RB ? a.H - r0 : a.RB);
+    };
+    int total = 0;
+    for (int i = 0; i < nitems; ++i) total += item_rows(it_lo + i) + 2;  // (wave-uniform scalar loop, <= a few dozen items)
+
+    if (producer) {
+        const int ptid = tid - 256;
+        const int ci = ptid >> 2, g = ptid & 3;
+        const int cg = kt * 64 + ci;
+        const bool cv = cg < a.Cin;
+        const int cgc = cv ? cg : a.Cin - 1;
+        float wt[2][9], bs[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wt[j][k] = a.w_dw[(cgc * 2 + j) * 9 + k];
+            bs[j] = a.b_dw ? a.b_dw[cgc * 2 + j] : 0.f;
+        }
+        const float asc = AFF ? a.in_scale[cgc] : 1.f, ash = AFF ? a.in_shift[cgc] : 0.f;
+        // dz share: 64 rows x 8 float4 columns = 512 pieces, two per thread; within a group of 8 rows the row order is
+        // 0,4,1,5,2,6,3,7 (k_wgrad_split: the two rows a 16-lane group writes with one ds_write_b64 tile the banks)
+        const int q = ptid & 7, g8 = ptid >> 3;
+        const int rbase = (g8 & ~7) | ((g8 & 1) << 2) | ((g8 >> 1) & 3);
+        int zrow[2];
+        bool zv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            zrow[j] = rbase + 32 * j;
+            zv[j] = zrow[j] < a.M;
+        }
+        // ---- walk state (wave-uniform values live in SGPRs) ----
+        int w_item = it_lo - 1, w_j = 0, w_len = 0;  // issue cursor: item, iteration inside the item, its length
+        int w_n = 0, w_r0 = 0, w_c0 = 0;
+        auto advance = [&]() __attribute__((always_inline)) {  // next flattened iteration of the issue cursor
+            ++w_j;
+            if (w_j >= w_len) {
+                if (w_item + 1 < it_hi) {
+                    ++w_item;
+                    w_j = 0;
+                    const int n = w_item / bps, rem = w_item - n * bps;
+                    const int band = rem / a.strips, s = rem - band * a.strips;
+                    w_n = n;
+                    w_r0 = band * a.RB;
+                    w_c0 = s * DWG_CW;
+                    w_len = (a.H - w_r0 < a.RB ? a.H - w_r0 : a.RB) + 2;
+                } else {
+                    w_j = w_len - 1;  // past the end: keep re-loading the last row (never consumed)
+                }
+            }
+        };
+        // register sets of loads in flight
+        f32x4 sx0[PD], sx1[PD], sz0[PD], sz1[PD];
+        float sl[PD], sr[PD];
+        int srow[PD];     // x row index of the set (for the zero padding above / below the plane)
+        auto issue = [&](int set) __attribute__((always_inline)) {
+            advance();
+            const int xr = w_r0 - 1 + w_j;  // x row delivered by this iteration
+            const int xrc = xr < 0 ? 0 : (xr >= a.H ? a.H - 1 : xr);
+            const int col = w_c0 + 8 * g;
+            const float* xp = a.x + (long)w_n * a.x_bs + (long)cgc * a.P + (long)xrc * a.W + col;
+            const float* lp = xp + (col > 0 ? -1 : 0);
+            const float* rp = xp + (col + 8 < a.W ? 8 : 7);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sx0[set]) : "v"(xp));
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sx1[set]) : "v"(xp + 4));
+            asm volatile("global_load_dword %0, %1, off" : "=v"(sl[set]) : "v"(lp));
+            asm volatile("global_load_dword %0, %1, off" : "=v"(sr[set]) : "v"(rp));
+            srow[set] = xr;
+            // dz chunk of the same iteration: row zr = r0 + j - 2 (the chunk whose window this x row completes)
+            const int zr = w_r0 + w_j - 2;
+            const int zrc = zr < 0 ? 0 : zr;
+            const float* zp = a.dz + (long)w_n * a.dz_bs + (long)zrc * a.W + w_c0 + 4 * q;
+            const float* z0 = zp + (long)(zv[0] ? zrow[0] : 0) * a.P;
+            const float* z1 = zp + (long)(zv[1] ? zrow[1] : 0) * a.P;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sz0[set]) : "v"(z0));
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sz1[set]) : "v"(z1));
+        };
+        auto wait_set = [&](int set) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * LPG) : "memory");
+            asm volatile("" : "+v"(sx0[set]), "+v"(sx1[set]), "+v"(sl[set]), "+v"(sr[set]), "+v"(sz0[set]), "+v"(sz1[set]));
+        };
+        float win[3][10];  // act(x) rows r - 1, r, r + 1 of the chunk being formed; cols 8g - 1 .. 8g + 8
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 10; ++c) win[r][c] = 0.f;
+        // consume cursor (what the iteration being committed is)
+        int c_item = it_lo - 1, c_j = 0, c_len = 0, c_c0 = 0;
+        auto c_advance = [&]() __attribute__((always_inline)) {
+            ++c_j;
+            if (c_j >= c_len) {
+                ++c_item;
+                c_j = 0;
+                const int rem = c_item % bps;
+                const int band = rem / a.strips, s = rem - band * a.strips;
+                const int r0 = band * a.RB;
+                c_c0 = s * DWG_CW;
+                c_len = (a.H - r0 < a.RB ? a.H - r0 : a.RB) + 2;
+            }
+        };
+        // commit iteration `t` (flattened) into buffer `buf`: slide the window, form y, split, write A / B images
+        auto commit = [&](int set, int buf) __attribute__((always_inline)) {
+            c_advance();
+            const int xr = srow[set];
+            const bool rv = cv && xr >= 0 && xr < a.H;
+            const int col = c_c0 + 8 * g;
+            float nr[10];
+            nr[0] = sl[set];
+            nr[1] = sx0[set][0]; nr[2] = sx0[set][1]; nr[3] = sx0[set][2]; nr[4] = sx0[set][3];
+            nr[5] = sx1[set][0]; nr[6] = sx1[set][1]; nr[7] = sx1[set][2]; nr[8] = sx1[set][3];
+            nr[9] = sr[set];
+#pragma unroll
+            for (int c = 0; c < 10; ++c) {
+                float v = nr[c];
+                if (AFF) v = fmaxf(fmaf(v, asc, ash), 0.f);  // previous BatchNorm + ReLU on load; the padding stays zero
+                const bool ok = rv && (c > 0 || col > 0) && (c < 9 || col + 8 < a.W);
+                nr[c] = ok ? v : 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < 10; ++c) {
+                win[0][c] = win[1][c];
+                win[1][c] = win[2][c];
+                win[2][c] = nr[c];
+            }
+            if (c_j < 2) return;  // priming iteration: no chunk
+            unsigned char* base = lds + buf * BUFSZ;
+            // y rows k = 2 ci + j of the chunk: tap order of k_dw3x3_fwd_rows (bias, then row-major taps)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float y[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    float acc = bs[j];
+#pragma unroll
+                    for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+                        for (int tc = 0; tc < 3; ++tc) acc = fmaf(wt[j][tr * 3 + tc], win[tr][c + tc], acc);
+                    y[c] = cv ? acc : 0.f;  // (channels beyond Cin in the last K tile contribute zero rows)
+                }
+                dwg_u32x4 pl[NT];
+                dwg_split8<NT>(y, pl);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    *(dwg_u32x4*)(base + t * PLSZ + (MT + 2 * ci + j) * DWG_SROW + g * 16) = pl[t];
+            }
+            // dz share
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4 zz = j ? sz1[set] : sz0[set];
+                float v4[4] = {zv[j] ? zz[0] : 0.f, zv[j] ? zz[1] : 0.f, zv[j] ? zz[2] : 0.f, zv[j] ? zz[3] : 0.f};
+                float p1[4], p2[4], p3[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (NT == 1) {
+                        const unsigned bb = dwg_fbits(v4[i]);
+                        p1[i] = dwg_bitsf((bb + 0x7FFFu + ((bb >> 16) & 1u)) & 0xFFFF0000u);
+                        p2[i] = p3[i] = 0.f;
+                    } else {
+                        p1[i] = dwg_bitsf(dwg_fbits(v4[i]) & 0xFFFF0000u);
+                        const float r1 = v4[i] - p1[i];
+                        p2[i] = dwg_bitsf(dwg_fbits(r1) & 0xFFFF0000u);
+                        p3[i] = r1 - p2[i];
+                    }
+                }
+                unsigned char* dst = base + zrow[j] * DWG_SROW + q * 8;
+                *(uint2*)(dst) = make_uint2(dwg_pack_hi16(p1[0], p1[1]), dwg_pack_hi16(p1[2], p1[3]));
+                if (NT == 3) {
+                    *(uint2*)(dst + PLSZ) = make_uint2(dwg_pack_hi16(p2[0], p2[1]), dwg_pack_hi16(p2[2], p2[3]));
+                    *(uint2*)(dst + 2 * PLSZ) = make_uint2(dwg_pack_hi16(p3[0], p3[1]), dwg_pack_hi16(p3[2], p3[3]));
+                }
+            }
+        };
+        if (total > 0) {
+#pragma unroll
+            for (int s = 0; s < PD; ++s) issue(s);
+            wait_set(0);
+            commit(0, 0);  // iteration 0 -> buffer 0
+            issue(0);
+        }
+        __syncthreads();
+        for (int t0 = 0; t0 < total; t0 += PD) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                const int t = t0 + u;
+                if (t < total) {
+                    if (t + 1 < total) {
+                        wait_set((u + 1) % PD);              // iteration t + 1: issued PD iterations ago
+                        commit((u + 1) % PD, (t + 1) & 1);
+                        issue((u + 1) % PD);
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus loads of the tail still target live registers
+    } else {
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        // which flattened iterations carry a chunk: the same walk, scalar
+        int c_item = it_lo - 1, c_j = 0, c_len = 0;
+        __syncthreads();
+        for (int t = 0; t < total; ++t) {
+            ++c_j;
+            if (c_j >= c_len) {
+                ++c_item;
+                c_j = 0;
+                c_len = item_rows(c_item) + 2;
+            }
+            if (c_j >= 2) {
+                const unsigned char* base = lds + (t & 1) * BUFSZ;
+                const unsigned char* ap = base + (wm * 32 + l31) * DWG_SROW + half * 16;
+                const unsigned char* bp = base + (MT + (wk * 2) * 32 + l31) * DWG_SROW + half * 16;
+#pragma unroll
+                for (int s = 0; s < DWG_CW / 16; ++s) {
+                    bf16x8 af[NT], bf[2][NT];
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) af[tt] = *(const bf16x8*)(ap + tt * PLSZ + s * 32);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt) bf[j][tt] = *(const bf16x8*)(bp + tt * PLSZ + j * 32 * DWG_SROW + s * 32);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (NT == 3) {  // smallest terms first (the order of k_wgrad_split)
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][2], acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[j][0], acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[j][1], acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][1], acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[j][0], acc[j], 0, 0, 0);
+                        }
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][0], acc[j], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        float* ob = a.part + (long)split * a.M * a.K;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m < a.M) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int kg = kt * KT + (wk * 2 + j) * 32 + l31;
+                    if (kg < a.K) ob[(long)m * a.K + kg] = acc[j][r];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+static void dswg_geom(DsWgArgs& a) {
+    a.P = a.H * a.W;
+    a.strips = a.W / DWG_CW;
+    a.nkt = (a.K + 127) / 128;
+    // bands: long enough that the two priming iterations are a few per cent, short enough that every workgroup gets
+    // several items (balance); 36 rows at 288 x 288 (8 bands, 2304 items at batch 32 = 9 per workgroup)
+    int rb = a.H;
+    for (int cand = 48; cand >= 16; cand -= 4)
+        if (a.H % cand == 0) {
+            rb = cand;
+            break;
+        }
+    if (rb > 64) rb = 32;
+    a.RB = rb;
+    a.bands = (a.H + rb - 1) / rb;
+    a.items = a.N * a.bands * a.strips;
+    int ns = (256 / a.nkt) & ~7;  // one workgroup per CU (92 KB of LDS), split ranges contiguous per XCD
+    if (ns < 8) ns = 8;
+    while (ns > 8 && ns > a.items) ns -= 8;
+    a.nsplit = ns;
+    a.ips = (a.items + ns - 1) / ns;
+}
+
+// shapes this kernel takes: kernels_per_layer = 2, W a multiple of 32, at most 64 output channels, 16-byte aligned rows
+int dsconv_wgrad_split_ok(int kpl, int M, int H, int W) { return kpl == 2 && (W % DWG_CW) == 0 && M <= 64 && H >= 1; }
+
+int dsconv_wgrad_split_num_splits(int N, int Cin, int M, int H, int W) {
+    DsWgArgs a{};
+    a.N = N; a.Cin = Cin; a.K = 2 * Cin; a.M = M; a.H = H; a.W = W;
+    dswg_geom(a);
+    return a.nsplit;
+}
+
+template <int NT, bool AFF>
+static int launch_dswg_cfg(const DsWgArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)2 * NT * (64 + 128) * DWG_SROW;
+    constexpr auto kern = k_dsconv_wgrad_split<NT, AFF>;
+    static size_t granted = 0;
+    if (lds > granted) {
+        HIP_RET(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        granted = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.nsplit * a.nkt), dim3(512), lds, st, a);
+    return (int)hipGetLastError();
+}
+
+// returns -2 when the shape / alignment is not handled (caller keeps the depthwise output and streams it)
+int launch_dsconv_wgrad_split(DsWgArgs& a, int kpl, hipStream_t st) {
+    if (!dsconv_wgrad_split_ok(kpl, a.M, a.H, a.W) || a.K != 2 * a.Cin) return -2;
+    if ((a.x_bs & 3) || (a.dz_bs & 3) || (((uintptr_t)a.x) & 15) || (((uintptr_t)a.dz) & 15)) return -2;
+    dswg_geom(a);
+    const bool aff = a.in_scale != nullptr;
+    if (split_mode() == 1) return aff ? launch_dswg_cfg<1, true>(a, st) : launch_dswg_cfg<1, false>(a, st);
+    return aff ? launch_dswg_cfg<3, true>(a, st) : launch_dswg_cfg<3, false>(a, st);
+}

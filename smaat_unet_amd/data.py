@@ -86,6 +86,12 @@ class H5SampleSource:
         self.transform = transform
         self._frames = list(range(self.num_input)) + [self.data.shape[1] - 1]
         self._tls = threading.local()
+        # native gather (libsmaat_io.so: zlib inflate + scatter of one sample per foreign call, GIL released): frame f of a
+        # sample goes to destination frame fmap[f] -- inputs in place, the last frame behind them, the rest skipped
+        self._fmap = np.full(self.data.shape[1], -1, np.int32)
+        self._fmap[: self.num_input] = np.arange(self.num_input)
+        self._fmap[-1] = self.num_input
+        self.native = transform is None and self.data.native_ok()
 
     def __len__(self):
         return self.data.shape[0]
@@ -98,6 +104,10 @@ class H5SampleSource:
 
     def gather_into(self, indices, dst):
         ni = self.num_input
+        if self.native:
+            for b, i in enumerate(indices):
+                self.data.gather_native(int(i), self._fmap, dst[b])
+            return
         buf = getattr(self._tls, "buf", None)
         if buf is None:
             buf = self._tls.buf = np.empty(self.data.shape[1:], np.float32)  # one sample of scratch per gather thread

@@ -414,6 +414,53 @@ class H5Dataset:
                 out[tuple(sl_out)] = np.frombuffer(raw, self.dtype, int(np.prod(ch))).reshape(ch)[tuple(sl_in)]
         return out
 
+    # ---- native gather (csrc/h5gather.c -> libsmaat_io.so): one foreign call per sample, GIL released ----------------
+    def native_ok(self):
+        """the C helper handles: float32, 4-D chunked datasets with chunk extent 1 along the sample axis, filter pipeline
+        = deflate only (what create_datasets.py writes); the library must have been built (csrc/Makefile)"""
+        return (_io_lib() is not None and self.layout == "chunked" and self.ndim == 4 and self.dtype == np.float32
+                and self.chunks[0] == 1 and [f[0] for f in self.filters] == [1])
+
+    def gather_native(self, index, fmap, dst):
+        """dst[fmap[f]] <- dataset[index][f] for every frame f with fmap[f] >= 0 (fmap: int32 [T]); dst: float32 array whose
+        last axis is contiguous, shape [>= max(fmap) + 1][H][W].  Only the chunks holding wanted frames are read."""
+        import ctypes
+        lib = _io_lib()
+        if not 0 <= index < self.shape[0]:
+            raise IndexError(index)
+        if self._index is None:
+            self._build_index()
+        addr, size, mask, strides = self._index
+        plan = self.__dict__.get("_native_plan")
+        if plan is None or plan[0] is not fmap:
+            t, h, w = self.shape[1:]
+            ch, grid = self.chunks, self._grid()
+            rows = sorted({f // ch[1] for f in range(t) if fmap[f] >= 0})
+            cc = np.array([(a_, b_, c_) for a_ in rows for b_ in range(grid[2]) for c_ in range(grid[3])], np.int64)
+            rel = (cc * np.asarray(strides[1:], np.int64)).sum(axis=1)
+            origin = np.ascontiguousarray(cc * np.asarray(ch[1:], np.int64), dtype=np.int32)
+            plan = (fmap, rel, origin, np.asarray(ch[1:], np.int32), np.asarray(self.shape[1:], np.int32),
+                    np.ascontiguousarray(fmap, dtype=np.int32))
+            self.__dict__["_native_plan"] = plan
+        _, rel, origin, cdim, ext, fm = plan
+        lin = rel + int(index) * int(strides[0])
+        a = addr[lin]
+        if (mask[lin] != 0).any():
+            raise H5FormatError("a chunk of this sample skipped a filter (filter mask set): use read_into")
+        off = np.where(a == np.uint64(UNDEF), np.int64(-1), (a + np.uint64(self.f.base)).astype(np.int64)).astype(np.int64)
+        nb = np.ascontiguousarray(size[lin], dtype=np.int32)
+        if dst.dtype != np.float32 or dst.strides[-1] != 4 or dst.shape[-2:] != self.shape[2:]:
+            raise ValueError("dst must be float32 [frames][H][W] with a contiguous last axis")
+        fill = float(self._fill_value())
+        rc = lib.smaat_h5_gather(self.f.fd, len(lin), off.ctypes.data_as(ctypes.c_void_p), nb.ctypes.data_as(ctypes.c_void_p),
+                                 origin.ctypes.data_as(ctypes.c_void_p), cdim.ctypes.data_as(ctypes.c_void_p),
+                                 ext.ctypes.data_as(ctypes.c_void_p), fm.ctypes.data_as(ctypes.c_void_p),
+                                 ctypes.c_void_p(dst.ctypes.data), dst.strides[0] // 4, dst.strides[1] // 4, fill)
+        if rc != 0:
+            raise H5FormatError(f"{self.f.path}: native chunk gather failed with code {rc} (sample {index}) "
+                                "(-3 short read, -4 inflate error / chunk size mismatch)")
+        return dst
+
     def __getitem__(self, index):
         if isinstance(index, (int, np.integer)):
             index = int(index)
@@ -430,6 +477,29 @@ class H5Dataset:
 
     def __len__(self):
         return self.shape[0]
+
+
+_IO = [False]
+
+
+def _io_lib():
+    """libsmaat_io.so (csrc/h5gather.c), or None when it has not been built: the pure-Python path is used then"""
+    if _IO[0] is False:
+        import ctypes
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsmaat_io.so")
+        lib = None
+        if os.path.exists(path) and os.environ.get("SMAAT_H5_NATIVE", "1") != "0":
+            try:
+                lib = ctypes.CDLL(path)
+                P, I, L, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+                lib.smaat_h5_gather.argtypes = [I, I, P, P, P, P, P, P, P, L, L, F]
+                lib.smaat_h5_gather.restype = I
+                if lib.smaat_io_abi_version() != 1:
+                    lib = None
+            except OSError:
+                lib = None
+        _IO[0] = lib
+    return _IO[0]
 
 
 # ======================================================================================================================

@@ -355,6 +355,26 @@ def _dsconv_fwd_bf16(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, 
 FUSE_DW_SPLIT = os.environ.get("SMAAT_FUSE_DW", "auto")
 
 
+# Round 4: weight gradient with the depthwise output recomputed by the GEMM's producer waves (csrc/dswgrad.hip).  Where
+# it applies, training runs the fused forward WITHOUT the side output and keeps no depthwise tensor at all: the
+# 2x-expanded tensor is neither written (forward) nor read (weight gradient).  "auto" = the measured policy
+# (profiles/r4), "all" = every shape the kernels take, "off" = the round-3 behaviour.
+WGRAD_RECOMPUTE = os.environ.get("SMAAT_WGRAD_RECOMPUTE", "auto")
+
+
+def _recompute_wgrad_ok(n, cin, h, w, kpl, cout):
+    if WGRAD_RECOMPUTE == "off" or FUSE_DW_SPLIT == "off" or not _split_on():
+        return False
+    L = _lib.get()
+    if not L.smaat_dsconv_wgrad_split_ok(kpl, cout, h, w) or L.smaat_dsconv_split_num_slots(n, h, w) <= 0:
+        return False
+    if WGRAD_RECOMPUTE == "all":
+        return True
+    # a 64-channel K tile per workgroup: layers with fewer input channels (the 12-channel stem) would idle most producer
+    # threads; plane-dominated layers only (the deep layers are not HBM-bound in f32)
+    return cin >= 32 and h * w >= 16384
+
+
 def _fused_dw_ok(n, h, w, kpl, cout, keep_y, cin=0):
     if FUSE_DW_SPLIT == "off" or kpl != 2 or not _split_on():
         return False
@@ -584,11 +604,23 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None, i
     if y is not None:
         dw_pw = _pointwise_wgrad_raw(y, dz, cout)
     else:
-        ns = L.smaat_dsconv_wgrad_num_splits(n, h, w, cout, k)
-        ws = _new(x, ns, cout, k)
+        # no depthwise tensor was kept: it is recomputed from x (with the previous activation applied on load) inside
+        # the weight-gradient kernel -- on the split matrix path where that kernel takes the shape (the training policy,
+        # _recompute_wgrad_ok), else by the memory-lean f32-MFMA kernel (ops.KEEP_DEPTHWISE_OUTPUT = False)
+        isc, ish = in_aff if in_aff is not None else (None, None)
         dw_pw = _new(x, cout, k, 1, 1)
-        _lib.check(L.smaat_dsconv_wgrad(_ptr(x), x_bs, None, None, _ptr(w_dw), _ptr(b_dw), _ptr(dz), dz_bs, _ptr(ws),
-                                        _ptr(dw_pw), n, cin, kpl, cout, h, w, s), "smaat_dsconv_wgrad")
+        rc = -2
+        if _split_on() and WGRAD_RECOMPUTE != "off" and L.smaat_dsconv_wgrad_split_ok(kpl, cout, h, w):
+            ws = _new(x, L.smaat_dsconv_wgrad_split_num_splits(n, cin, cout, h, w), cout, k)
+            rc = L.smaat_dsconv_wgrad_split(_ptr(x), x_bs, _ptr(isc), _ptr(ish), _ptr(w_dw), _ptr(b_dw), _ptr(dz), dz_bs,
+                                            _ptr(ws), _ptr(dw_pw), n, cin, kpl, cout, h, w, s)
+            if rc != -2:
+                _lib.check(rc, "smaat_dsconv_wgrad_split")
+        if rc == -2:
+            ns = L.smaat_dsconv_wgrad_num_splits(n, h, w, cout, k)
+            ws = _new(x, ns, cout, k)
+            _lib.check(L.smaat_dsconv_wgrad(_ptr(x), x_bs, _ptr(isc), _ptr(ish), _ptr(w_dw), _ptr(b_dw), _ptr(dz), dz_bs,
+                                            _ptr(ws), _ptr(dw_pw), n, cin, kpl, cout, h, w, s), "smaat_dsconv_wgrad")
         del ws
     # data gradient of the pointwise conv: dY = W^T dZ  (wt := w_pw in its natural [Cout][K] layout)
     if _split_dgrad_ok(cout, k):
@@ -691,6 +723,8 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
     isc, ish = in_aff if in_aff is not None else (None, None)
     rs = None
     bf = _is_bf(x) or mixed_precision_active()
+    if keep_y and not bf and _recompute_wgrad_ok(n, cin, h, w, kpl, cout):
+        keep_y = False  # the weight gradient recomputes the depthwise output from x: nothing to keep (y_dw = None)
     if bf:  # mixed precision: bf16 depthwise output, bf16 GEMM, bf16 z (the f32 kernel families are not involved)
         rs = _dsconv_fwd_bf16(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish)
     elif _split_on() and _fused_dw_ok(n, h, w, kpl, cout, keep_y, cin):

@@ -254,6 +254,19 @@ class EmuLib:
         f32(dw_out, Cout * K).reshape(Cout, K)[:] = np.einsum("nmp,nkp->mk", dzv, y.reshape(N, K, P))
         return 0
 
+    def smaat_dsconv_wgrad_split_ok(self, kpl, Cout, H, W):
+        return int(kpl == 2 and W % 32 == 0 and Cout <= 64)
+
+    def smaat_dsconv_wgrad_split_num_splits(self, N, Cin, Cout, H, W):
+        return WG_SPLITS + 2
+
+    def smaat_dsconv_wgrad_split(self, x, x_bs, in_scale, in_shift, w_dw, b_dw, dz, dz_bs, ws, dw_out, N, Cin, kpl, Cout, H,
+                                 W, stream):
+        if not self.smaat_dsconv_wgrad_split_ok(kpl, Cout, H, W):
+            return -2
+        return self.smaat_dsconv_wgrad(x, x_bs, in_scale, in_shift, w_dw, b_dw, dz, dz_bs, ws, dw_out, N, Cin, kpl, Cout, H,
+                                       W, stream)
+
     def smaat_pointwise_wgrad(self, x, x_bs, dz, dz_bs, ws, dw_out, N, Cin, M, H, W, stream):
         P = H * W
         f32(dw_out, M * Cin).reshape(M, Cin)[:] = np.einsum("nmp,nkp->mk", planes(dz, N, M, P, dz_bs),

@@ -8,7 +8,8 @@ the distance of the AUTOCAST run from it.  The rule for this implementation's bf
 
     distance(ours bf16, reference f32)  <=  1.25 x distance(reference autocast, reference f32)
 
-on (a) logits rel-L2, (b) 1 - cosine of the flat gradient, (c) the largest relative loss deviation over the four steps.
+on (a) logits rel-L2, (b) 1 - cosine of the flat gradient, (c) the largest relative loss deviation over the four steps
+(yardstick (c): the larger of autocast-vs-f32 and f64-vs-f32 of the reference, see `yardstick`).
 The f32 mode of the same code must sit at round-off distance from the reference's f32 run (1e-4 logits).
 
 CPU (`-m "not gpu"`): through the numpy emulation of the C ABI (tests/emu_backend.py: f32 twins + one bf16 rounding per stored
@@ -71,9 +72,12 @@ def distances(g, meta, g32, first, grads, losses):
 
 
 def yardstick(g):
-    lac, l32 = g["losses_autocast"], g["losses32"]
+    """distances of the reference's autocast run from its float32 run.  The four-step loss trajectory of the float32 run is
+    itself only defined up to its distance from the float64 run (chaotic Adam steps from a random init: 4.2 % at step 4 of
+    the 288 x 288 case, where autocast happens to land within 1.4 %), so the loss yardstick is the larger of the two."""
+    lac, l32, l64 = g["losses_autocast"], g["losses32"], g["losses64"]
     return dict(logits=float(g["autocast/logits_vs32"]), one_minus_cos=float(g["autocast/one_minus_cos_vs32"]),
-                loss=float(np.max(np.abs(lac - l32) / l32)))
+                loss=float(max(np.max(np.abs(lac - l32) / l32), np.max(np.abs(l64 - l32) / l32))))
 
 
 def check(golden_dir, name, dev, report_dir=None, f32_too=True):

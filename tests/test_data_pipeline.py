@@ -165,12 +165,17 @@ def test_h5_reader_against_a_file_written_by_the_real_library(golden_dir):
             d.read_into(5, np.empty((18, 64, 64), np.float32))
 
 
-def test_h5_sample_source_contract_and_partial_reads(golden_dir):
+@pytest.mark.parametrize("native", [True, False])
+def test_h5_sample_source_contract_and_partial_reads(golden_dir, native):
+    """native=True: the chunks of a sample are inflated and scattered by libsmaat_io.so (csrc/h5gather.c, one foreign call
+    per sample, GIL released); native=False: the pure-Python path (also what runs when the helper library is absent)"""
     import os
     from smaat_unet_amd.data import H5SampleSource
     path = os.path.join(golden_dir, "precip_h5_fixture.h5")
     tr = _fixture_values("train", 5)
     src = H5SampleSource(path, num_input_images=12, train=True)
+    assert src.native, "libsmaat_io.so not built / not loadable"
+    src.native = native
     assert len(src) == 5
     x, y = src[3]   # reference: imgs = np.array(self.dataset[index], dtype="float32"); imgs[:num_input], imgs[-1]
     assert x.dtype == np.float32 and np.array_equal(x, tr[3, :12]) and np.array_equal(y, tr[3, -1])
@@ -181,12 +186,16 @@ def test_h5_sample_source_contract_and_partial_reads(golden_dir):
     # only the chunk rows holding frames 0..11 and 17 are inflated (rows 0, 1, 2 and 3 of 4: here nothing can be skipped;
     # with 3 input frames rows 1 and 2 are)
     few = H5SampleSource(path, num_input_images=3)
+    few.native = native
     calls = []
     orig = few.data._chunk_bytes
     few.data._chunk_bytes = lambda lin: (calls.append(lin), orig(lin))[1]
+    dst[:] = -1
     few.gather_into([1], dst[:1, :4])
-    assert len(calls) == 2 * 4 * 2  # 2 of 4 chunk rows x (64 / 16) x (64 / 32)
+    nchunks = len(few.data.__dict__["_native_plan"][1]) if native else len(calls)
+    assert nchunks == 2 * 4 * 2  # 2 of 4 chunk rows x (64 / 16) x (64 / 32)
     assert np.array_equal(dst[0, :3], tr[1, :3]) and np.array_equal(dst[0, 3], tr[1, 17])
+    assert (dst[0, 4:] == -1).all()  # nothing else is touched
     sq = H5SampleSource(path, 12, train=False, transform=lambda im: im * 2)
     te = _fixture_values("test", 2)
     x2, y2 = sq[1]
@@ -225,6 +234,11 @@ def test_h5_writer_round_trip_with_edge_chunks_and_a_multi_level_index(tmp_path)
     src = H5SampleSource(p, 5)
     x, y = src[2]
     assert np.array_equal(x, a[2, :5]) and np.array_equal(y, a[2, -1])
+    for native in (True, False):   # partial chunks on every axis through both gather paths
+        src.native = native and src.native
+        d = np.full((2, 6, 50, 70), np.nan, np.float32)
+        src.gather_into([1, 0], d)
+        assert np.array_equal(d[0, :5], a[1, :5]) and np.array_equal(d[0, 5], a[1, -1]) and np.array_equal(d[1, 5], a[0, -1])
     bad = tmp_path / "bad.h5"
     bad.write_bytes(b"not an hdf5 file at all" * 10)
     with pytest.raises(H5FormatError, match="no HDF5 signature"):

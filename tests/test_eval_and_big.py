@@ -183,7 +183,18 @@ def run_big(golden_dir, name, dev, graph=False, report=None):
         report["eval"] = dict(logits_b1=e1, logits=e2, worst_grad=worst, worst_single_number_grad=worst1)
     assert worst[1] < 2e-3, worst
     assert worst1[1] < 2e-2, worst1
-    assert check_summary(g, "eval/dx", xet.grad.cpu().numpy()) < 2e-3
+    # eval-mode input gradient.  A single ReLU / max-pool decision that flips under round-off moves dx of that sample by
+    # ~1e-3, and the fixtures compare at 4096 sampled positions: the reference against ITSELF (one thread, sample by
+    # sample, vs its 8-thread batch run) is 2.9e-3 by this measure at batch 32 (3.8e-4 on the full tensor).  That figure,
+    # generated from /root/reference (oracle/gen_golden.py::gen_eval_noise), is the yardstick where it exists.
+    edx = check_summary(g, "eval/dx", xet.grad.cpu().numpy())
+    bound = 2e-3
+    noise_file = os.path.join(golden_dir, name + "_evalnoise.npz")
+    if os.path.exists(noise_file):
+        bound = max(bound, 1.5 * float(np.load(noise_file)["eval/self/dx_sampled"]))
+    if report is not None:
+        report["eval"]["dx"] = dict(ours=edx, bound=bound)
+    assert edx < bound, (edx, bound)
     for k in g.files:  # eval mode did not move the running statistics
         if k.startswith("train/after/"):
             assert rel(model.state_dict()[k[12:]].cpu().numpy(), g[k]) < 1e-4, k

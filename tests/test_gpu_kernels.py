@@ -156,6 +156,66 @@ def test_dsconv_wgrad(shape):
     both(case_dsconv_wgrad, *shape, tol=2e-5)
 
 
+def case_dsconv_wgrad_split(L, dev, N, Cin, Cout, H, W, aff=False, bias=True, pad_c=0):
+    """round 4: weight gradient on the split matrix path with the depthwise output recomputed by the producer waves
+    (csrc/dswgrad.hip); x may be a channel slice of a larger buffer (batch stride), the previous BatchNorm + ReLU is
+    optionally applied on load"""
+    K = Cin * 2
+    xfull = T(rnd(1, N, Cin + pad_c, H, W), dev)
+    x = xfull[:, pad_c:]
+    w_dw, b_dw = T(rnd(2, K, 9, scale=0.3), dev), T(rnd(3, K, scale=0.3), dev)
+    dz = T(rnd(4, N, Cout, H, W), dev)
+    sc = T(np.random.default_rng(6).uniform(0.5, 1.5, Cin).astype(np.float32), dev) if aff else None
+    sh = T(rnd(7, Cin, scale=0.3), dev) if aff else None
+    assert L.smaat_dsconv_wgrad_split_ok(2, Cout, H, W) == 1
+    ns = L.smaat_dsconv_wgrad_split_num_splits(N, Cin, Cout, H, W)
+    ws = torch.full((ns, Cout, K), float("nan"), device=dev)
+    dw = torch.full((Cout, K), float("nan"), device=dev)
+    assert L.smaat_dsconv_wgrad_split(x.data_ptr(), (Cin + pad_c) * H * W, P(sc), P(sh), P(w_dw), P(b_dw) if bias else None,
+                                      P(dz), Cout * H * W, P(ws), P(dw), N, Cin, 2, Cout, H, W, stream(dev)) == 0
+    return dict(dw=dw)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 32, 32), (1, 40, 50, 8, 64), (2, 100, 64, 36, 96), (1, 8, 16, 70, 32),
+                                   (3, 130, 33, 5, 32), (2, 12, 64, 288, 288), (1, 64, 64, 50, 160), (2, 32, 1, 1, 32),
+                                   (9, 4, 8, 2, 64)])
+def test_dsconv_wgrad_split(shape):
+    both(case_dsconv_wgrad_split, *shape, tol=1e-5)
+    both(case_dsconv_wgrad_split, *shape, aff=True, bias=False, pad_c=3, tol=1e-5)
+
+
+def test_dsconv_wgrad_split_against_fp64_and_the_streamed_kernel():
+    """f32-class error: against an fp64 evaluation the recompute kernel is as close as the streamed split kernel
+    (k_wgrad_split on the kept depthwise output) and as the f32-MFMA kernel; it refuses what it does not take"""
+    L, dev = _lib.get(), torch.device("cuda:0")
+    N, Cin, Cout, H, W = 2, 96, 64, 72, 64
+    K = 2 * Cin
+    x, dz = rnd(1, N, Cin, H, W), rnd(4, N, Cout, H, W)
+    w_dw, b_dw = rnd(2, K, 9, scale=0.3), rnd(3, K, scale=0.3)
+    from oracle import smaat_oracle as O
+    y64 = O.dw3x3_fwd(x.astype(np.float64), w_dw.astype(np.float64).reshape(K, 1, 3, 3), b_dw.astype(np.float64), 2)
+    ref = np.einsum("nmp,nkp->mk", dz.astype(np.float64).reshape(N, Cout, -1), y64.reshape(N, K, -1))
+    new = case_dsconv_wgrad_split(L, dev, N, Cin, Cout, H, W)["dw"].cpu().numpy()
+    yt = torch.empty((N, K, H, W), device=dev)
+    assert L.smaat_dw3x3_fwd(P(T(x, dev)), Cin * H * W, None, None, P(T(w_dw, dev)), P(T(b_dw, dev)), P(yt), K * H * W, N, Cin, 2,
+                             H, W, stream(dev)) == 0
+    ws = torch.empty((L.smaat_wgrad_num_splits(N, H, W, Cout, K), Cout, K), device=dev)
+    old = torch.empty((Cout, K), device=dev)
+    assert L.smaat_pointwise_wgrad(P(yt), K * H * W, P(T(dz, dev)), Cout * H * W, P(ws), P(old), N, K, Cout, H, W,
+                                   stream(dev)) == 0
+    e_new, e_old = rel(new, ref), rel(old.cpu().numpy(), ref)
+    assert e_new < 2e-6 and e_new < 3 * e_old + 2e-7, (e_new, e_old)
+    # run to run bit-identical (fixed-order reduction, no atomics)
+    again = case_dsconv_wgrad_split(L, dev, N, Cin, Cout, H, W)["dw"].cpu().numpy()
+    assert np.array_equal(new, again)
+    # refusals
+    assert L.smaat_dsconv_wgrad_split_ok(2, 64, 18, 18) == 0 and L.smaat_dsconv_wgrad_split_ok(4, 64, 32, 32) == 0
+    assert L.smaat_dsconv_wgrad_split_ok(2, 128, 32, 32) == 0
+    t = torch.zeros(1, 4, 18, 18, device=dev)
+    assert L.smaat_dsconv_wgrad_split(P(t), 4 * 324, None, None, P(t), None, P(t), 4 * 324, P(t), P(t), 1, 4, 2, 4, 18, 18,
+                                      stream(dev)) == -2
+
+
 def case_pointwise_wgrad(L, dev, N, C, M, H, W):
     x, dz = T(rnd(1, N, C, H, W), dev), T(rnd(2, N, M, H, W), dev)
     ns = L.smaat_wgrad_num_splits(N, H, W, M, C)
