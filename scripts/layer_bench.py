@@ -93,6 +93,12 @@ def main():
             assert L.smaat_dsconv_wgrad(x.data_ptr(), cin * p, None, None, w_dw.data_ptr(), b_dw.data_ptr(), dz.data_ptr(),
                                         cout * p, wsr.data_ptr(), dw.data_ptr(), N, cin, 2, cout, h, w, st) == 0
 
+        def f_wgrad_recompute_split():
+            nsr = L.smaat_dsconv_wgrad_split_num_splits(N, cin, cout, h, w)
+            wsr = torch.empty(nsr, cout, k, device=dev)
+            assert L.smaat_dsconv_wgrad_split(x.data_ptr(), cin * p, None, None, w_dw.data_ptr(), b_dw.data_ptr(), dz.data_ptr(),
+                                              cout * p, wsr.data_ptr(), dw.data_ptr(), N, cin, 2, cout, h, w, st) == 0
+
         def f_gemm_split():
             assert L.smaat_pointwise_fwd_split(y.data_ptr(), k * p, pl_f.data_ptr(), b_pw.data_ptr(), z.data_ptr(),
                                                cout * p, part_s.data_ptr(), N, k, cout, h, w, st) == 0
@@ -134,10 +140,15 @@ def main():
                                         timeit(f_dwb))
         extra = ""
         if split and slots_f > 0 and os.environ.get("LB_FUSED", "1") != "0":
-            t_fu, t_fuy, t_wr = timeit(lambda: f_fused(False)), timeit(lambda: f_fused(True)), timeit(f_wgrad_recompute)
+            t_fu, t_fuy = timeit(lambda: f_fused(False)), timeit(lambda: f_fused(True))
+            t_wr = timeit(f_wgrad_recompute) if os.environ.get("LB_F32_RECOMPUTE", "0") == "1" else float("nan")
             gb = 4.0 * N * (cin + cout) * p / 1e6
             extra = (f" | FUSED fwd {t_fu:7.3f} ms {fl / t_fu / 1e9:6.1f} TF {gb / t_fu:7.1f} GB/s (with y_out {t_fuy:7.3f})"
                      f" | f32 recompute-wgrad {t_wr:7.3f}")
+            if L.smaat_dsconv_wgrad_split_ok(2, cout, h, w):  # round 4: split-path weight gradient that recomputes y from x
+                t_ws = timeit(f_wgrad_recompute_split)
+                gbw = 4.0 * N * (cin + cout) * p / 1e6
+                extra += f" | SPLIT recompute-wgrad {t_ws:7.3f} ms {fl / t_ws / 1e9:6.1f} TF {gbw / t_ws:7.1f} GB/s"
         bw = 4.0 * N * (k + 2 * cin) * p
         rows.append(dict(layer=name, cin=cin, k=k, cout=cout, hw=h, gflop=fl / 1e9, fwd_ms=t_f, fwd_noy_ms=t_fn,
                          dgrad_ms=t_d, wgrad_ms=t_w, dwb_ms=t_b, fwd_tf=fl / t_f / 1e9, fwd_noy_tf=fl / t_fn / 1e9,

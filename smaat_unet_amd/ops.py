@@ -365,6 +365,9 @@ WGRAD_RECOMPUTE = os.environ.get("SMAAT_WGRAD_RECOMPUTE", "auto")
 def _recompute_wgrad_ok(n, cin, h, w, kpl, cout):
     if WGRAD_RECOMPUTE == "off" or FUSE_DW_SPLIT == "off" or not _split_on():
         return False
+    from . import train_ops
+    if train_ops.active():  # (the traceable operators declare their saved tensors up front: kept depthwise outputs)
+        return False
     L = _lib.get()
     if not L.smaat_dsconv_wgrad_split_ok(kpl, cout, h, w) or L.smaat_dsconv_split_num_slots(n, h, w) <= 0:
         return False
