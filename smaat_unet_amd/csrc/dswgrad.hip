@@ -52,13 +52,13 @@ __device__ __forceinline__ float dwg_bitsf(unsigned x) { return __builtin_bit_ca
 __device__ __forceinline__ unsigned dwg_pack_hi16(float lo, float hi) {
     return __builtin_amdgcn_perm(dwg_fbits(hi), dwg_fbits(lo), 0x07060302u);  // {hi.hi16, lo.hi16}
 }
-// 8 consecutive f32 -> NT planes of 8 bf16 (one 16-byte LDS piece per plane); NT = 3: exact three-term split
+// 4 consecutive f32 -> NT planes of 4 bf16 (one 8-byte LDS piece per plane); NT = 3: exact three-term split
 // (a = p1 + p2 + p3, truncations, residuals exact), NT = 1: round to nearest even (plain bf16 operands)
 template <int NT>
-__device__ __forceinline__ void dwg_split8(const float (&v)[8], dwg_u32x4 (&out)[NT]) {
-    float p1[8], p2[8], p3[8];
+__device__ __forceinline__ void dwg_split4(const float (&v)[4], uint2 (&out)[NT]) {
+    float p1[4], p2[4], p3[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 4; ++i) {
         if (NT == 1) {
             const unsigned b = dwg_fbits(v[i]);
             p1[i] = dwg_bitsf((b + 0x7FFFu + ((b >> 16) & 1u)) & 0xFFFF0000u);
@@ -70,22 +70,19 @@ __device__ __forceinline__ void dwg_split8(const float (&v)[8], dwg_u32x4 (&out)
             p3[i] = r1 - p2[i];             // exact, <= 8 significant bits
         }
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        out[0][q] = dwg_pack_hi16(p1[2 * q], p1[2 * q + 1]);
-        if constexpr (NT == 3) {
-            out[1][q] = dwg_pack_hi16(p2[2 * q], p2[2 * q + 1]);
-            out[2][q] = dwg_pack_hi16(p3[2 * q], p3[2 * q + 1]);
-        }
+    out[0] = make_uint2(dwg_pack_hi16(p1[0], p1[1]), dwg_pack_hi16(p1[2], p1[3]));
+    if constexpr (NT == 3) {
+        out[1] = make_uint2(dwg_pack_hi16(p2[0], p2[1]), dwg_pack_hi16(p2[2], p2[3]));
+        out[2] = make_uint2(dwg_pack_hi16(p3[0], p3[1]), dwg_pack_hi16(p3[2], p3[3]));
     }
 }
 
 template <int NT, bool AFF>
-__global__ __launch_bounds__(512) void k_dsconv_wgrad_split(const DsWgArgs a) {
+__global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
     constexpr int MT = 64, KT = 128, ROWS = MT + KT;
     constexpr int PLSZ = ROWS * DWG_SROW, BUFSZ = NT * PLSZ;
-    constexpr int PD = 3;        // load groups in flight per producer thread
-    constexpr int LPG = 6;       // loads per group: x row = 2 x dwordx4 + 2 x dword, dz = 2 x dwordx4
+    constexpr int PD = 4;        // load groups in flight per producer thread
+    constexpr int LPG = 3;       // loads per group: x row = dwordx4 + one edge dword, dz = dwordx4
     static_assert((PD - 1) * LPG <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -113,8 +110,13 @@ __global__ __launch_bounds__(512) void k_dsconv_wgrad_split(const DsWgArgs a) {
     for (int i = 0; i < nitems; ++i) total += item_rows(it_lo + i) + 2;  // (wave-uniform scalar loop, <= a few dozen items)
 
     if (producer) {
+        // 8 producer waves (two per SIMD: one's VALU chain covers the other's waits).  Thread (ci, g): channel ci of the
+        // 64-channel K tile, the 4 pixels 4g .. 4g + 3 of the 32-pixel row segment; the 8 threads of a channel are 8
+        // consecutive lanes, so the two edge columns of a thread's 3 x 6 window are its neighbour lanes' float4 ends (DPP
+        // row shifts); only g = 0 / g = 7 read theirs from memory (ONE dword load per row whose per-lane offset is fixed
+        // per item: -1, +4, or 0 where there is no such column).
         const int ptid = tid - 256;
-        const int ci = ptid >> 2, g = ptid & 3;
+        const int ci = ptid >> 3, g = ptid & 7;
         const int cg = kt * 64 + ci;
         const bool cv = cg < a.Cin;
         const int cgc = cv ? cg : a.Cin - 1;
@@ -126,118 +128,108 @@ __global__ __launch_bounds__(512) void k_dsconv_wgrad_split(const DsWgArgs a) {
             bs[j] = a.b_dw ? a.b_dw[cgc * 2 + j] : 0.f;
         }
         const float asc = AFF ? a.in_scale[cgc] : 1.f, ash = AFF ? a.in_shift[cgc] : 0.f;
-        // dz share: 64 rows x 8 float4 columns = 512 pieces, two per thread; within a group of 8 rows the row order is
-        // 0,4,1,5,2,6,3,7 (k_wgrad_split: the two rows a 16-lane group writes with one ds_write_b64 tile the banks)
+        // dz share: 64 rows x 8 float4 columns = 512 pieces, one per thread; within a group of 8 rows the row order is
+        // 0,4,1,5,2,6,3,7 (k_wgrad_split: the rows a 16-lane group writes with one ds_write_b64 tile the banks)
         const int q = ptid & 7, g8 = ptid >> 3;
-        const int rbase = (g8 & ~7) | ((g8 & 1) << 2) | ((g8 >> 1) & 3);
-        int zrow[2];
-        bool zv[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            zrow[j] = rbase + 32 * j;
-            zv[j] = zrow[j] < a.M;
-        }
-        // ---- walk state (wave-uniform values live in SGPRs) ----
-        int w_item = it_lo - 1, w_j = 0, w_len = 0;  // issue cursor: item, iteration inside the item, its length
-        int w_n = 0, w_r0 = 0, w_c0 = 0;
-        auto advance = [&]() __attribute__((always_inline)) {  // next flattened iteration of the issue cursor
+        const int zrow = (g8 & ~7) | ((g8 & 1) << 2) | ((g8 >> 1) & 3);
+        const bool zv = zrow < a.M;
+        // per-lane byte offsets from the wave-uniform (scalar) row bases: no vector address arithmetic per iteration
+        const unsigned vo_x = (unsigned)(cgc * a.P + 4 * g) * 4u;
+        const unsigned vo_z = (unsigned)((zv ? zrow : 0) * a.P + 4 * q) * 4u;
+        unsigned vo_e = vo_x;  // edge load: set per item (strip position decides whether the neighbour column exists)
+        // ---- issue cursor (wave-uniform: SGPRs) ----
+        int w_item = it_lo - 1, w_j = 0, w_len = 0;
+        int w_r0 = 0;
+        const float* w_xb = a.x;   // x + n * x_bs + c0           (row 0 of the strip, channel 0)
+        const float* w_zb = a.dz;  // dz + n * dz_bs + c0
+        bool w_lok = false, w_rok = false;
+        auto advance = [&]() __attribute__((always_inline)) {
             ++w_j;
             if (w_j >= w_len) {
                 if (w_item + 1 < it_hi) {
                     ++w_item;
                     w_j = 0;
                     const int n = w_item / bps, rem = w_item - n * bps;
-                    const int band = rem / a.strips, s = rem - band * a.strips;
-                    w_n = n;
+                    const int band = rem / a.strips, st_ = rem - band * a.strips;
                     w_r0 = band * a.RB;
-                    w_c0 = s * DWG_CW;
+                    const int c0 = st_ * DWG_CW;
+                    w_xb = a.x + (long)n * a.x_bs + c0;
+                    w_zb = a.dz + (long)n * a.dz_bs + c0;
                     w_len = (a.H - w_r0 < a.RB ? a.H - w_r0 : a.RB) + 2;
+                    w_lok = c0 > 0;
+                    w_rok = c0 + DWG_CW < a.W;
+                    vo_e = vo_x + ((g == 0 && w_lok) ? -4 : ((g == 7 && w_rok) ? 16 : 0));
                 } else {
                     w_j = w_len - 1;  // past the end: keep re-loading the last row (never consumed)
                 }
             }
         };
-        // register sets of loads in flight
-        f32x4 sx0[PD], sx1[PD], sz0[PD], sz1[PD];
-        float sl[PD], sr[PD];
-        int srow[PD];     // x row index of the set (for the zero padding above / below the plane)
+        f32x4 sx[PD], sz[PD];
+        float se[PD];
+        int srow[PD];        // x row index of the set (zero padding above / below the plane)
+        bool slok[PD], srok[PD];
         auto issue = [&](int set) __attribute__((always_inline)) {
             advance();
             const int xr = w_r0 - 1 + w_j;  // x row delivered by this iteration
             const int xrc = xr < 0 ? 0 : (xr >= a.H ? a.H - 1 : xr);
-            const int col = w_c0 + 8 * g;
-            const float* xp = a.x + (long)w_n * a.x_bs + (long)cgc * a.P + (long)xrc * a.W + col;
-            const float* lp = xp + (col > 0 ? -1 : 0);
-            const float* rp = xp + (col + 8 < a.W ? 8 : 7);
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sx0[set]) : "v"(xp));
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sx1[set]) : "v"(xp + 4));
-            asm volatile("global_load_dword %0, %1, off" : "=v"(sl[set]) : "v"(lp));
-            asm volatile("global_load_dword %0, %1, off" : "=v"(sr[set]) : "v"(rp));
+            const float* xrow = w_xb + (long)xrc * a.W;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sx[set]) : "v"(vo_x), "s"(xrow));
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(se[set]) : "v"(vo_e), "s"(xrow));
             srow[set] = xr;
-            // dz chunk of the same iteration: row zr = r0 + j - 2 (the chunk whose window this x row completes)
-            const int zr = w_r0 + w_j - 2;
-            const int zrc = zr < 0 ? 0 : zr;
-            const float* zp = a.dz + (long)w_n * a.dz_bs + (long)zrc * a.W + w_c0 + 4 * q;
-            const float* z0 = zp + (long)(zv[0] ? zrow[0] : 0) * a.P;
-            const float* z1 = zp + (long)(zv[1] ? zrow[1] : 0) * a.P;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sz0[set]) : "v"(z0));
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sz1[set]) : "v"(z1));
+            slok[set] = w_lok;
+            srok[set] = w_rok;
+            const int zr = w_r0 + w_j - 2;  // the chunk whose window this x row completes
+            const float* zrowp = w_zb + (long)(zr < 0 ? 0 : zr) * a.W;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sz[set]) : "v"(vo_z), "s"(zrowp));
         };
         auto wait_set = [&](int set) __attribute__((always_inline)) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * LPG) : "memory");
-            asm volatile("" : "+v"(sx0[set]), "+v"(sx1[set]), "+v"(sl[set]), "+v"(sr[set]), "+v"(sz0[set]), "+v"(sz1[set]));
+            asm volatile("" : "+v"(sx[set]), "+v"(se[set]), "+v"(sz[set]));
         };
-        float win[3][10];  // act(x) rows r - 1, r, r + 1 of the chunk being formed; cols 8g - 1 .. 8g + 8
+        float win[3][6];  // act(x) rows r - 1, r, r + 1 of the chunk being formed; cols 4g - 1 .. 4g + 4
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int c = 0; c < 10; ++c) win[r][c] = 0.f;
-        // consume cursor (what the iteration being committed is)
-        int c_item = it_lo - 1, c_j = 0, c_len = 0, c_c0 = 0;
-        auto c_advance = [&]() __attribute__((always_inline)) {
+            for (int c = 0; c < 6; ++c) win[r][c] = 0.f;
+        int c_j = 0, c_len = 0, c_item = it_lo - 1;  // consume cursor
+        auto commit = [&](int set, int buf) __attribute__((always_inline)) {
             ++c_j;
             if (c_j >= c_len) {
                 ++c_item;
                 c_j = 0;
-                const int rem = c_item % bps;
-                const int band = rem / a.strips, s = rem - band * a.strips;
-                const int r0 = band * a.RB;
-                c_c0 = s * DWG_CW;
-                c_len = (a.H - r0 < a.RB ? a.H - r0 : a.RB) + 2;
+                c_len = item_rows(c_item) + 2;
             }
-        };
-        // commit iteration `t` (flattened) into buffer `buf`: slide the window, form y, split, write A / B images
-        auto commit = [&](int set, int buf) __attribute__((always_inline)) {
-            c_advance();
             const int xr = srow[set];
             const bool rv = cv && xr >= 0 && xr < a.H;
-            const int col = c_c0 + 8 * g;
-            float nr[10];
-            nr[0] = sl[set];
-            nr[1] = sx0[set][0]; nr[2] = sx0[set][1]; nr[3] = sx0[set][2]; nr[4] = sx0[set][3];
-            nr[5] = sx1[set][0]; nr[6] = sx1[set][1]; nr[7] = sx1[set][2]; nr[8] = sx1[set][3];
-            nr[9] = sr[set];
+            float m[4] = {sx[set][0], sx[set][1], sx[set][2], sx[set][3]};
+            float e = se[set];
+            if (AFF) {  // previous BatchNorm + ReLU on load (before the exchange: neighbours hand over activated values)
 #pragma unroll
-            for (int c = 0; c < 10; ++c) {
-                float v = nr[c];
-                if (AFF) v = fmaxf(fmaf(v, asc, ash), 0.f);  // previous BatchNorm + ReLU on load; the padding stays zero
-                const bool ok = rv && (c > 0 || col > 0) && (c < 9 || col + 8 < a.W);
-                nr[c] = ok ? v : 0.f;
+                for (int c = 0; c < 4; ++c) m[c] = fmaxf(fmaf(m[c], asc, ash), 0.f);
+                e = fmaxf(fmaf(e, asc, ash), 0.f);
             }
+            float l = dpp_src<0x111, 0xF>(m[3]);  // row_shr:1  (lane i <- lane i - 1, inside its 16-lane row)
+            float r = dpp_src<0x101, 0xF>(m[0]);  // row_shl:1  (lane i <- lane i + 1)
+            l = g == 0 ? e : l;
+            r = g == 7 ? e : r;
+            const bool lv = rv && (g > 0 || slok[set]), rvv = rv && (g < 7 || srok[set]);
 #pragma unroll
-            for (int c = 0; c < 10; ++c) {
+            for (int c = 0; c < 6; ++c) {
                 win[0][c] = win[1][c];
                 win[1][c] = win[2][c];
-                win[2][c] = nr[c];
             }
+            win[2][0] = lv ? l : 0.f;  // zero padding (after the activation)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) win[2][1 + c] = rv ? m[c] : 0.f;
+            win[2][5] = rvv ? r : 0.f;
             if (c_j < 2) return;  // priming iteration: no chunk
             unsigned char* base = lds + buf * BUFSZ;
-            // y rows k = 2 ci + j of the chunk: tap order of k_dw3x3_fwd_rows (bias, then row-major taps)
+            // y rows k = 2 ci + j of the chunk: tap order of k_dw3x3_fwd_rows (bias, then row-major taps): bit-identical y
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                float y[8];
+                float y[4];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
+                for (int c = 0; c < 4; ++c) {
                     float acc = bs[j];
 #pragma unroll
                     for (int tr = 0; tr < 3; ++tr)
@@ -245,42 +237,22 @@ __global__ __launch_bounds__(512) void k_dsconv_wgrad_split(const DsWgArgs a) {
                         for (int tc = 0; tc < 3; ++tc) acc = fmaf(wt[j][tr * 3 + tc], win[tr][c + tc], acc);
                     y[c] = cv ? acc : 0.f;  // (channels beyond Cin in the last K tile contribute zero rows)
                 }
-                dwg_u32x4 pl[NT];
-                dwg_split8<NT>(y, pl);
+                uint2 pl[NT];
+                dwg_split4<NT>(y, pl);
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    *(dwg_u32x4*)(base + t * PLSZ + (MT + 2 * ci + j) * DWG_SROW + g * 16) = pl[t];
+                for (int t = 0; t < NT; ++t) *(uint2*)(base + t * PLSZ + (MT + 2 * ci + j) * DWG_SROW + g * 8) = pl[t];
             }
-            // dz share
+            {  // dz share
+                const float v4[4] = {zv ? sz[set][0] : 0.f, zv ? sz[set][1] : 0.f, zv ? sz[set][2] : 0.f, zv ? sz[set][3] : 0.f};
+                uint2 pl[NT];
+                dwg_split4<NT>(v4, pl);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const f32x4 zz = j ? sz1[set] : sz0[set];
-                float v4[4] = {zv[j] ? zz[0] : 0.f, zv[j] ? zz[1] : 0.f, zv[j] ? zz[2] : 0.f, zv[j] ? zz[3] : 0.f};
-                float p1[4], p2[4], p3[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (NT == 1) {
-                        const unsigned bb = dwg_fbits(v4[i]);
-                        p1[i] = dwg_bitsf((bb + 0x7FFFu + ((bb >> 16) & 1u)) & 0xFFFF0000u);
-                        p2[i] = p3[i] = 0.f;
-                    } else {
-                        p1[i] = dwg_bitsf(dwg_fbits(v4[i]) & 0xFFFF0000u);
-                        const float r1 = v4[i] - p1[i];
-                        p2[i] = dwg_bitsf(dwg_fbits(r1) & 0xFFFF0000u);
-                        p3[i] = r1 - p2[i];
-                    }
-                }
-                unsigned char* dst = base + zrow[j] * DWG_SROW + q * 8;
-                *(uint2*)(dst) = make_uint2(dwg_pack_hi16(p1[0], p1[1]), dwg_pack_hi16(p1[2], p1[3]));
-                if (NT == 3) {
-                    *(uint2*)(dst + PLSZ) = make_uint2(dwg_pack_hi16(p2[0], p2[1]), dwg_pack_hi16(p2[2], p2[3]));
-                    *(uint2*)(dst + 2 * PLSZ) = make_uint2(dwg_pack_hi16(p3[0], p3[1]), dwg_pack_hi16(p3[2], p3[3]));
-                }
+                for (int t = 0; t < NT; ++t) *(uint2*)(base + t * PLSZ + zrow * DWG_SROW + q * 8) = pl[t];
             }
         };
         if (total > 0) {
 #pragma unroll
-            for (int s = 0; s < PD; ++s) issue(s);
+            for (int s_ = 0; s_ < PD; ++s_) issue(s_);
             wait_set(0);
             commit(0, 0);  // iteration 0 -> buffer 0
             issue(0);
@@ -403,7 +375,7 @@ static int launch_dswg_cfg(const DsWgArgs& a, hipStream_t st) {
         HIP_RET(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         granted = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(a.nsplit * a.nkt), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.nsplit * a.nkt), dim3(768), lds, st, a);
     return (int)hipGetLastError();
 }
 

@@ -192,10 +192,13 @@ class PrefetchLoader:
     def _gather(self, slot, idx):
         dst = self.host_np[slot]
         nb = len(idx)
-        if self.workers == 1 or nb < 2 * self.workers:
+        # (a cheap source -- memory-mapped rows -- is not worth a thread per couple of samples; a source that inflates
+        # compressed chunks is: one sample per thread at most)
+        heavy = getattr(self.source, "native", None) is not None
+        if self.workers == 1 or nb < 2 or (not heavy and nb < 2 * self.workers):
             self.source.gather_into(idx, dst)
             return
-        parts = [p for p in np.array_split(np.arange(nb), self.workers) if len(p)]
+        parts = [p for p in np.array_split(np.arange(nb), min(self.workers, nb)) if len(p)]
         errors = []
 
         def work(p):

@@ -604,6 +604,8 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None, i
     s = _stream(x)
     if _is_bf(dz):
         return _dsconv_bwd_bf16(x, x_bs, w_dw, w_pw, dz, kpl, need_dx, y, bnred, in_aff)
+    if _is_bf(x):  # the forward of this block fell back to f32 storage (_bf16_storage_ok) on a bf16 input
+        x, x_bs = _planes(x.float())
     if y is not None:
         dw_pw = _pointwise_wgrad_raw(y, dz, cout)
     else:
@@ -714,6 +716,12 @@ KEEP_DEPTHWISE_OUTPUT = True
 # --------------------------------------------------------------------------------------
 # DepthwiseSeparableConv (+ BatchNorm2d + ReLU)
 # --------------------------------------------------------------------------------------
+def _bf16_storage_ok(h, w, kpl):
+    """planes the bf16-storage depthwise / GEMM kernels take: an even width (rows of 4-element groups, the last one possibly
+    2 wide; an even plane for the GEMM's 2-pixel stores), kernels_per_layer 1, 2 or 4"""
+    return w % 2 == 0 and h >= 1 and kpl in (1, 2, 4)
+
+
 def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, momentum, eps, kpl, keep_y, in_aff=None,
                   want_act=True):
     """DepthwiseSeparableConv -> BatchNorm2d -> ReLU.  Returns y, z, st, y_dw, use_batch_stats.
@@ -726,6 +734,12 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
     isc, ish = in_aff if in_aff is not None else (None, None)
     rs = None
     bf = _is_bf(x) or mixed_precision_active()
+    if bf and not _bf16_storage_ok(h, w, kpl):
+        # a plane the bf16-storage kernel families do not take (odd width ...): this block runs with f32 storage -- mixed
+        # precision is an optimisation, not a contract on results (also for a standalone block under autocast)
+        bf = False
+        if _is_bf(x):
+            x = x.float()
     if keep_y and not bf and _recompute_wgrad_ok(n, cin, h, w, kpl, cout):
         keep_y = False  # the weight gradient recomputes the depthwise output from x: nothing to keep (y_dw = None)
     if bf:  # mixed precision: bf16 depthwise output, bf16 GEMM, bf16 z (the f32 kernel families are not involved)
@@ -792,8 +806,11 @@ class _DSConvBNReLU(torch.autograd.Function):
                                                          ("bn.running_var", rv)))
         w_dw = w_dw.contiguous()
         w_pw = w_pw.contiguous()
-        keep_y = ((KEEP_DEPTHWISE_OUTPUT or _is_bf(x) or mixed_precision_active())
-                  and any(ctx.needs_input_grad[:4]))  # forward runs under no_grad
+        # (mixed precision: the bf16 backward streams the kept depthwise output whatever input needs a gradient -- also
+        # when only the BatchNorm affine parameters do)
+        bfm = _is_bf(x) or mixed_precision_active()
+        keep_y = ((KEEP_DEPTHWISE_OUTPUT or bfm)
+                  and any(ctx.needs_input_grad[:7 if bfm else 4]))  # forward runs under no_grad
         y, z, st, y_dw, ubs = _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, momentum, eps,
                                             kpl, keep_y)
         ctx.save_for_backward(x, w_dw, b_dw, w_pw, gamma, z, st, y_dw)
@@ -1716,7 +1733,9 @@ class _UpsampleInto(torch.autograd.Function):
             raise NotImplementedError("UpDS with a skip connection smaller than the upsampled map (negative pad)")
         pt, pl = dy_ // 2, dx_ // 2
         if x1.dtype != cat.dtype:
-            raise TypeError(f"upsample_into: the concatenation buffer is {cat.dtype}, the upsampled tensor {x1.dtype}")
+            # a block in front fell back to f32 storage (_bf16_storage_ok) while the skip was stored as bf16, or the other
+            # way round: the upsampled map follows the buffer it is written into
+            x1, x1_bs = _planes(x1.to(cat.dtype))
         _upsample_fwd_raw(x1, x1_bs, cat.data_ptr() + cat.element_size() * c_off * ho * wo, ct * ho * wo, n, c1, h, w, ho, wo,
                           pt, pl, _stream(x1))
         ctx.geom = (n, c1, h, w, c_off, ho, wo, pt, pl)

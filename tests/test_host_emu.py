@@ -615,3 +615,35 @@ def test_eval_with_a_hooked_block_under_bf16_precision():
     assert dtypes == [torch.float32, torch.bfloat16]  # the hooked block ran half by half, its second half on bf16
     assert out.dtype == torch.float32 and out.shape == ref.shape
     assert rel(out.numpy(), ref.numpy()) < 0.2
+
+
+def test_standalone_block_under_bf16_precision_with_an_odd_plane_runs_with_f32_storage():
+    """the f32 fallback for geometries the bf16-storage kernels do not take lives in the operators, not only
+    in the network's forward: a standalone DoubleConvDS under precision("bf16") with an odd width runs (f32 storage,
+    bit-identical to the f32 mode) instead of raising; with only the BatchNorm affine parameters differentiable the bf16
+    backward still has its kept depthwise output"""
+    torch.manual_seed(2)
+    blk = S.DoubleConvDS(4, 8, kernels_per_layer=2).train()
+    x = torch.randn(2, 4, 9, 7)
+    ref = blk(x)
+    blk2 = S.DoubleConvDS(4, 8, kernels_per_layer=2).train()
+    blk2.load_state_dict(blk.state_dict())
+    for m in blk2.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.reset_running_stats()
+    with S.precision("bf16"):
+        out = blk2(x)
+        out.sum().backward()
+    assert out.dtype == torch.float32 and torch.equal(out, ref)
+    # only gamma / beta differentiable, bf16 storage active (an even plane)
+    blk3 = S.DoubleConvDS(4, 8, kernels_per_layer=2).train()
+    for k, p in blk3.named_parameters():
+        p.requires_grad_(k.endswith(("1.weight", "1.bias", "4.weight", "4.bias")))
+    half = blk3.double_conv
+    from smaat_unet_amd import ops as K
+    from smaat_unet_amd.layers import _bn_args
+    with S.precision("bf16"):
+        y = K.dsconv_bn_relu(torch.randn(2, 4, 8, 8), half[0].depthwise.weight, half[0].depthwise.bias, half[0].pointwise.weight,
+                             half[0].pointwise.bias, *_bn_args(half[1]), 2)
+        y.float().sum().backward()
+    assert half[1].weight.grad is not None and torch.isfinite(half[1].weight.grad).all()
