@@ -8,8 +8,13 @@ export SMAAT_REQUIRE_GPU=1
 timeout 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu --tb=short -p no:cacheprovider -k "wgrad" > "$OUT/pytest_wgrad.log" 2>&1
 echo "pytest wgrad exit=$? $(tail -1 "$OUT/pytest_wgrad.log")"
 grep -E "^(FAILED|ERROR)|rel err" "$OUT/pytest_wgrad.log" | head -20
-for l in inc up4; do LB_ONLY=$l timeout 600 python scripts/layer_bench.py >> "$OUT/layer_bench.txt" 2>&1; done
-grep -E "SPLIT recompute" "$OUT/layer_bench.txt"
+if ! grep -q " passed" "$OUT/pytest_wgrad.log" || grep -q "failed" "$OUT/pytest_wgrad.log"; then echo "parity not green: stop"; exit 1; fi
+for pk in 0 1; do
+  for l in inc.1 up4; do SMAAT_DWG_PK=$pk LB_ONLY=$l timeout 600 python scripts/layer_bench.py >> "$OUT/layer_bench_pk$pk.txt" 2>&1; done
+  echo "PK=$pk"; grep -E "SPLIT recompute" "$OUT/layer_bench_pk$pk.txt" | sed 's/.*wgrad/wgrad/'
+done
+SMAAT_DWG_PK=1 timeout 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu --tb=short -p no:cacheprovider -k "dsconv_wgrad_split" > "$OUT/pytest_wgrad_pk.log" 2>&1
+echo "pytest wgrad (PK) exit=$? $(tail -1 "$OUT/pytest_wgrad_pk.log")"
 for mode in off auto off auto; do
   SMAAT_WGRAD_RECOMPUTE=$mode timeout 600 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-alt --no-latency \
       --no-eager-baseline --no-side-configs --no-input-pipeline --no-power > "$OUT/bench_$mode.json" 2> "$OUT/bench_$mode.err"

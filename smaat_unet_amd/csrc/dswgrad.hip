@@ -77,7 +77,11 @@ __device__ __forceinline__ void dwg_split4(const float (&v)[4], uint2 (&out)[NT]
     }
 }
 
-template <int NT, bool AFF>
+typedef float dwg_f32x2 __attribute__((ext_vector_type(2)));
+
+// PK: the depthwise stage on packed f32 math (v_pk_fma_f32 over the two k-rows of a channel); experiment switch
+// SMAAT_DWG_PK=1 (the guide prices packed VALU beside MFMAs as an anti-lever: measured, profiles/r4)
+template <int NT, bool AFF, bool PK>
 __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
     constexpr int MT = 64, KT = 128, ROWS = MT + KT;
     constexpr int PLSZ = ROWS * DWG_SROW, BUFSZ = NT * PLSZ;
@@ -158,7 +162,10 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
                     w_len = (a.H - w_r0 < a.RB ? a.H - w_r0 : a.RB) + 2;
                     w_lok = c0 > 0;
                     w_rok = c0 + DWG_CW < a.W;
-                    vo_e = vo_x + ((g == 0 && w_lok) ? -4 : ((g == 7 && w_rok) ? 16 : 0));
+                    // edge load: scalar base = row start - 1 element when a column exists left of the strip (the per-lane
+                    // offset of a scalar-base load is UNSIGNED: it cannot reach backwards); lane g = 0 then reads column
+                    // c0 - 1, lane g = 7 column c0 + 32 (or its own last column when there is none), the others their own
+                    vo_e = vo_x + (g == 0 ? 0u : ((w_lok ? 4u : 0u) + (g == 7 ? (w_rok ? 16u : 12u) : 0u)));
                 } else {
                     w_j = w_len - 1;  // past the end: keep re-loading the last row (never consumed)
                 }
@@ -174,7 +181,8 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
             const int xrc = xr < 0 ? 0 : (xr >= a.H ? a.H - 1 : xr);
             const float* xrow = w_xb + (long)xrc * a.W;
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sx[set]) : "v"(vo_x), "s"(xrow));
-            asm volatile("global_load_dword %0, %1, %2" : "=v"(se[set]) : "v"(vo_e), "s"(xrow));
+            const float* erow = xrow - (w_lok ? 1 : 0);
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(se[set]) : "v"(vo_e), "s"(erow));
             srow[set] = xr;
             slok[set] = w_lok;
             srok[set] = w_rok;
@@ -225,20 +233,41 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
             if (c_j < 2) return;  // priming iteration: no chunk
             unsigned char* base = lds + buf * BUFSZ;
             // y rows k = 2 ci + j of the chunk: tap order of k_dw3x3_fwd_rows (bias, then row-major taps): bit-identical y
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float y[4];
+            float yy[2][4];
+            if (PK) {
+                // both k-rows of the channel share the window value: one v_pk_fma_f32 forms {y[0][c], y[1][c]} (the same
+                // fma per component, same tap order: bit-identical to the scalar form)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    float acc = bs[j];
+                    dwg_f32x2 acc = {bs[0], bs[1]};
 #pragma unroll
                     for (int tr = 0; tr < 3; ++tr)
 #pragma unroll
-                        for (int tc = 0; tc < 3; ++tc) acc = fmaf(wt[j][tr * 3 + tc], win[tr][c + tc], acc);
-                    y[c] = cv ? acc : 0.f;  // (channels beyond Cin in the last K tile contribute zero rows)
+                        for (int tc = 0; tc < 3; ++tc) {
+                            const dwg_f32x2 w2 = {wt[0][tr * 3 + tc], wt[1][tr * 3 + tc]};
+                            const dwg_f32x2 x2 = {win[tr][c + tc], win[tr][c + tc]};
+                            acc = __builtin_elementwise_fma(w2, x2, acc);
+                        }
+                    yy[0][c] = cv ? acc[0] : 0.f;
+                    yy[1][c] = cv ? acc[1] : 0.f;
                 }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float acc = bs[j];
+#pragma unroll
+                        for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+                            for (int tc = 0; tc < 3; ++tc) acc = fmaf(wt[j][tr * 3 + tc], win[tr][c + tc], acc);
+                        yy[j][c] = cv ? acc : 0.f;  // (channels beyond Cin in the last K tile contribute zero rows)
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
                 uint2 pl[NT];
-                dwg_split4<NT>(y, pl);
+                dwg_split4<NT>(yy[j], pl);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) *(uint2*)(base + t * PLSZ + (MT + 2 * ci + j) * DWG_SROW + g * 8) = pl[t];
             }
@@ -366,10 +395,10 @@ int dsconv_wgrad_split_num_splits(int N, int Cin, int M, int H, int W) {
     return a.nsplit;
 }
 
-template <int NT, bool AFF>
+template <int NT, bool AFF, bool PK>
 static int launch_dswg_cfg(const DsWgArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * NT * (64 + 128) * DWG_SROW;
-    constexpr auto kern = k_dsconv_wgrad_split<NT, AFF>;
+    constexpr auto kern = k_dsconv_wgrad_split<NT, AFF, PK>;
     static size_t granted = 0;
     if (lds > granted) {
         HIP_RET(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -385,6 +414,12 @@ int launch_dsconv_wgrad_split(DsWgArgs& a, int kpl, hipStream_t st) {
     if ((a.x_bs & 3) || (a.dz_bs & 3) || (((uintptr_t)a.x) & 15) || (((uintptr_t)a.dz) & 15)) return -2;
     dswg_geom(a);
     const bool aff = a.in_scale != nullptr;
-    if (split_mode() == 1) return aff ? launch_dswg_cfg<1, true>(a, st) : launch_dswg_cfg<1, false>(a, st);
-    return aff ? launch_dswg_cfg<3, true>(a, st) : launch_dswg_cfg<3, false>(a, st);
+    static int pk = -1;
+    if (pk < 0) {
+        const char* e = getenv("SMAAT_DWG_PK");
+        pk = (e && e[0] == '1') ? 1 : 0;
+    }
+    if (split_mode() == 1) return aff ? launch_dswg_cfg<1, true, false>(a, st) : launch_dswg_cfg<1, false, false>(a, st);
+    if (pk) return aff ? launch_dswg_cfg<3, true, true>(a, st) : launch_dswg_cfg<3, false, true>(a, st);
+    return aff ? launch_dswg_cfg<3, true, false>(a, st) : launch_dswg_cfg<3, false, false>(a, st);
 }
