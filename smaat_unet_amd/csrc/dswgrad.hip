@@ -79,6 +79,12 @@ __device__ __forceinline__ void dwg_split4(const float (&v)[4], uint2 (&out)[NT]
 
 typedef float dwg_f32x2 __attribute__((ext_vector_type(2)));
 
+__device__ __forceinline__ const float* dwg_uniform_ptr(const float* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const float*)(((unsigned long long)hi << 32) | lo);
+}
+
 // PK: the depthwise stage on packed f32 math (v_pk_fma_f32 over the two k-rows of a channel); experiment switch
 // SMAAT_DWG_PK=1 (the guide prices packed VALU beside MFMAs as an anti-lever: measured, profiles/r4)
 template <int NT, bool AFF, bool PK>
@@ -147,6 +153,7 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
         const float* w_xb = a.x;   // x + n * x_bs + c0           (row 0 of the strip, channel 0)
         const float* w_zb = a.dz;  // dz + n * dz_bs + c0
         bool w_lok = false, w_rok = false;
+        int w_eback = 0;  // 1 when a column exists left of the strip: the edge load's scalar base is one element back
         auto advance = [&]() __attribute__((always_inline)) {
             ++w_j;
             if (w_j >= w_len) {
@@ -160,7 +167,8 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
                     w_xb = a.x + (long)n * a.x_bs + c0;
                     w_zb = a.dz + (long)n * a.dz_bs + c0;
                     w_len = (a.H - w_r0 < a.RB ? a.H - w_r0 : a.RB) + 2;
-                    w_lok = c0 > 0;
+                    w_eback = __builtin_amdgcn_readfirstlane(c0 > 0 ? 1 : 0);
+                    w_lok = w_eback != 0;
                     w_rok = c0 + DWG_CW < a.W;
                     // edge load: scalar base = row start - 1 element when a column exists left of the strip (the per-lane
                     // offset of a scalar-base load is UNSIGNED: it cannot reach backwards); lane g = 0 then reads column
@@ -181,7 +189,10 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
             const int xrc = xr < 0 ? 0 : (xr >= a.H ? a.H - 1 : xr);
             const float* xrow = w_xb + (long)xrc * a.W;
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sx[set]) : "v"(vo_x), "s"(xrow));
-            const float* erow = xrow - (w_lok ? 1 : 0);
+            // (the "s" constraint does not make a value uniform: hipcc kept this pointer in VGPRs when the -1 came from a
+            // select on the bool and emitted a VGPR pair in the scalar-base slot -> memory fault; built from an integer
+            // that is provably wave-uniform instead)
+            const float* erow = dwg_uniform_ptr(xrow - w_eback);
             asm volatile("global_load_dword %0, %1, %2" : "=v"(se[set]) : "v"(vo_e), "s"(erow));
             srow[set] = xr;
             slok[set] = w_lok;

@@ -27,3 +27,25 @@ def test_split_gemm_isa_has_no_drained_loops_or_serialised_stores():
             assert drains == 0, (fn, "a producer/consumer loop waits with vmcnt(0) with < 3 loads in flight")
             assert serial <= 2, (fn, f"{serial}/{nstore} stores follow an s_waitcnt vmcnt(0)")
     assert seen >= 8  # every instantiation of the two kernels was inspected
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc not available")
+def test_scalar_base_loads_really_have_a_scalar_base():
+    """Round 4: inline-asm loads of the form `global_load_* vdst, voffset, sbase` take their base through an "s" constraint,
+    which does NOT make a value uniform -- when hipcc keeps the pointer in VGPRs (it did for a base formed with a select
+    on a bool) it prints a VGPR pair into the scalar slot, the assembler accepts it, and the kernel faults on the GPU.
+    Every such load / store in the recompute weight gradient and the split GEMMs must name an SGPR pair."""
+    import re
+    import subprocess
+    import tempfile
+    for src in ("dswgrad.hip", "splitmma.hip", "dsconv_split.hip"):
+        with tempfile.NamedTemporaryFile(suffix=".s") as f:
+            subprocess.run([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S",
+                            "--cuda-device-only", os.path.join(ROOT, "smaat_unet_amd", "csrc", src), "-o", f.name],
+                           check=True, capture_output=True)
+            asm = open(f.name).read()
+        bad = [ln.strip() for ln in asm.splitlines()
+               if re.match(r"\s*(global|buffer)_(load|store)", ln) and re.search(r",\s*v\d+,\s*v\[\d+:\d+\]", ln)]
+        assert not bad, (src, bad[:3])
+        if src == "dswgrad.hip":
+            assert len(re.findall(r"global_load_dwordx?4? v\[?\d+[:\d\]]*, v\d+, s\[\d+:\d+\]", asm)) >= 24
