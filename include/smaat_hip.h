@@ -302,6 +302,24 @@ int smaat_dsconv_fwd_split(const float* x, long x_bs, const float* in_scale, con
                            const float* b_dw, const void* planes, const float* b_pw, float* z, long z_bs, float* part,
                            float* y_out, int N, int Cin, int kpl, int Cout, int H, int W, void* stream);
 
+/* ---- the same fused forward as a ROW-WALKING kernel (round 4; csrc/dsrows.hip): a workgroup walks down a band of rows of
+ *      one 32-column strip, the depthwise window lives in the producer threads' registers (no halo re-reads, no staging),
+ *      the pointwise weight's MFMA fragments live in the consumer waves' registers for the whole walk.  Same reference
+ *      call site (models/layers.py:47-50 + the BatchNorm partials for unet_parts_depthwise_separable.py:25,34).
+ *      x_dt / z_dt: SMAAT_DT_F32 | SMAAT_DT_BF16.  f32 storage (x f32, z f32): planes = smaat_split_planes of
+ *      pointwise.weight [Cout][K] (exact three-term split, or one term in bf16-operand mode).  bf16 storage (z bf16; x bf16,
+ *      or f32 for the stem): planes = smaat_bf16_planes of the weight, one MFMA per product, f32 accumulation.
+ *      part: nullable [3][smaat_dsconv_rows_num_slots(N,H,W)][Cout] (mean, M2, count of z - b_pw per band x strip x image).
+ *      There is no depthwise side output: the weight gradient recomputes it (smaat_dsconv_wgrad_split).
+ *      smaat_dsconv_rows_ok: 1 when the kernel takes the shape (kernels_per_layer 2, W % 32 == 0, Cout <= 64, Cin % 8 == 0,
+ *      Cin <= 128); otherwise smaat_dsconv_fwd_rows returns -2 (use smaat_dsconv_fwd_split / the unfused pair).
+ */
+int smaat_dsconv_rows_ok(int kpl, int Cin, int Cout, int H, int W);
+int smaat_dsconv_rows_num_slots(int N, int H, int W);
+int smaat_dsconv_fwd_rows(const void* x, int x_dt, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                          const float* b_dw, const void* planes, const float* b_pw, void* z, int z_dt, long z_bs, float* part,
+                          int N, int Cin, int kpl, int Cout, int H, int W, void* stream);
+
 /* ---- inference forms (reference call stack D, calc_metrics_test_set.py:119): the same three
  *      forward GEMM entry points without statistics / side outputs and with an optional fused ReLU epilogue
  *      (relu_out != 0: out = max(acc + bias, 0)).  With BatchNorm folded into the pointwise weights by the host

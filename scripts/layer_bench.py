@@ -145,6 +145,17 @@ def main():
             gb = 4.0 * N * (cin + cout) * p / 1e6
             extra = (f" | FUSED fwd {t_fu:7.3f} ms {fl / t_fu / 1e9:6.1f} TF {gb / t_fu:7.1f} GB/s (with y_out {t_fuy:7.3f})"
                      f" | f32 recompute-wgrad {t_wr:7.3f}")
+            if L.smaat_dsconv_rows_ok(2, cin, cout, h, w):  # round 4: row-walking fused forward
+                slots_r = L.smaat_dsconv_rows_num_slots(N, h, w)
+                part_r = torch.empty(3, slots_r, cout, device=dev)
+
+                def f_rows():
+                    assert L.smaat_split_planes(w_pw.data_ptr(), cout, k, pl_f.data_ptr(), st) == 0
+                    assert L.smaat_dsconv_fwd_rows(x.data_ptr(), 0, cin * p, None, None, w_dw.data_ptr(), b_dw.data_ptr(),
+                                                   pl_f.data_ptr(), b_pw.data_ptr(), z.data_ptr(), 0, cout * p, part_r.data_ptr(),
+                                                   N, cin, 2, cout, h, w, st) == 0
+                t_r = timeit(f_rows)
+                extra += f" | ROWS fwd {t_r:7.3f} ms {fl / t_r / 1e9:6.1f} TF {gb / t_r:7.1f} GB/s"
             if L.smaat_dsconv_wgrad_split_ok(2, cout, h, w):  # round 4: split-path weight gradient that recomputes y from x
                 t_ws = timeit(f_wgrad_recompute_split)
                 gbw = 4.0 * N * (cin + cout) * p / 1e6

@@ -82,6 +82,9 @@ SIGNATURES = {
     "smaat_pointwise_fwd_split": [_P, _L, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P],
     "smaat_dsconv_split_num_slots": [_I, _I, _I],
     "smaat_dsconv_fwd_split": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "smaat_dsconv_rows_ok": [_I, _I, _I, _I, _I],
+    "smaat_dsconv_rows_num_slots": [_I, _I, _I],
+    "smaat_dsconv_fwd_rows": [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _L, _P, _I, _I, _I, _I, _I, _I, _P],
     "smaat_dsconv_fwd_act": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P],
     "smaat_dsconv_fwd_split_act": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P],
     "smaat_pointwise_fwd_split_act": [_P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
@@ -227,6 +230,8 @@ WORK_MODELS = {
                                   4.0 * a[8] * a[9] * (1 + a[10]) * a[11] * a[12]),
     "smaat_dsconv_fwd": _w_dsconv_fwd,
     "smaat_dsconv_fwd_split": _w_dsconv_fwd,
+    "smaat_dsconv_fwd_rows": lambda a: (2.0 * a[13] * a[14] * a[15] * a[16] * a[17] * a[18],
+                                        a[13] * (_es(a[1]) * a[14] + _es(a[10]) * a[16]) * a[17] * a[18]),
     "smaat_pointwise_fwd": _w_pointwise_fwd,
     "smaat_dsconv_wgrad": _w_dsconv_wgrad,
     "smaat_dsconv_wgrad_split": _w_dsconv_wgrad,

@@ -7,6 +7,24 @@
 
 
 int launch_wgrad2(Wg2Args& a, hipStream_t st);
+struct DsRowsArgs {  // dsrows.hip
+    const void* x;
+    long x_bs;
+    const float* in_scale;
+    const float* in_shift;
+    const float* w_dw;
+    const float* b_dw;
+    const unsigned short* planes;
+    const float* bias;
+    void* out;
+    long out_bs;
+    float* part;
+    int N, Cin, K, M, H, W, P;
+    int nsplit, strips, bands, RB, items, ips, npl;
+};
+int dsconv_rows_ok(int kpl, int Cin, int M, int H, int W);
+int dsconv_rows_num_slots(int N, int H, int W);
+int launch_dsconv_rows(DsRowsArgs& a, int kpl, int x_dt, int z_dt, hipStream_t st);
 struct DsWgArgs {  // dswgrad.hip
     const float* x;
     long x_bs;
@@ -513,6 +531,20 @@ int smaat_dsconv_fwd_split(const float* x, long x_bs, const float* in_scale, con
                            float* y_out, int N, int Cin, int kpl, int Cout, int H, int W, void* stream) {
     return dsconv_fwd_split_impl(x, x_bs, in_scale, in_shift, w_dw, b_dw, planes, b_pw, z, z_bs, part, y_out, N, Cin, kpl,
                                  Cout, H, W, 0, stream);
+}
+int smaat_dsconv_rows_ok(int kpl, int Cin, int Cout, int H, int W) { return dsconv_rows_ok(kpl, Cin, Cout, H, W); }
+int smaat_dsconv_rows_num_slots(int N, int H, int W) { return dsconv_rows_num_slots(N, H, W); }
+int smaat_dsconv_fwd_rows(const void* x, int x_dt, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                          const float* b_dw, const void* planes, const float* b_pw, void* z, int z_dt, long z_bs, float* part,
+                          int N, int Cin, int kpl, int Cout, int H, int W, void* stream) {
+    if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || !x || !w_dw || !planes || !z) return -1;
+    if ((in_scale == nullptr) != (in_shift == nullptr)) return -1;
+    if ((x_dt != SMAAT_F32 && x_dt != SMAAT_BF16) || (z_dt != SMAAT_F32 && z_dt != SMAAT_BF16)) return -1;
+    DsRowsArgs a{};
+    a.x = x; a.x_bs = x_bs; a.in_scale = in_scale; a.in_shift = in_shift; a.w_dw = w_dw; a.b_dw = b_dw;
+    a.planes = (const unsigned short*)planes; a.bias = b_pw; a.out = z; a.out_bs = z_bs; a.part = part;
+    a.N = N; a.Cin = Cin; a.K = Cin * kpl; a.M = Cout; a.H = H; a.W = W;
+    return launch_dsconv_rows(a, kpl, x_dt, z_dt, ST);
 }
 int smaat_dsconv_fwd_split_act(const float* x, long x_bs, const float* in_scale, const float* in_shift,
                                const float* w_dw, const float* b_dw, const void* planes, const float* b_pw, float* z,

@@ -417,6 +417,36 @@ def _dsconv_fwd_fused(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None,
     return z, part, (slots if want_stats else 0), y
 
 
+# Row-walking fused forward (csrc/dsrows.hip, round 4): the depthwise window in the producer threads' registers, the
+# pointwise weight's MFMA fragments in the consumer waves' registers; no depthwise side output (the weight gradient
+# recomputes it).  "auto": wherever the kernel takes the shape and nothing has to be kept; "off": the tile kernel.
+FWD_ROWS = os.environ.get("SMAAT_FWD_ROWS", "auto")
+
+
+def _dsconv_fwd_rows(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, in_shift=None, out_dtype=None):
+    """-> (z, part, slots, None) or None when the row-walking kernel does not take the shape.  x f32 -> z f32 (split planes);
+    out_dtype = torch.bfloat16: mixed precision (x f32 | bf16, bf16 weight image, z bf16)"""
+    if FWD_ROWS == "off":
+        return None
+    L = _lib.get()
+    x, x_bs = _planes(x)
+    n, cin, h, w = x.shape
+    cout = w_pw.shape[0]
+    if not L.smaat_dsconv_rows_ok(kpl, cin, cout, h, w):
+        return None
+    out_dtype = out_dtype or x.dtype
+    planes = (_bf16_planes_raw(w_pw.reshape(cout, -1)) if out_dtype == BF16 else _split_planes_raw(w_pw.reshape(cout, -1)))
+    slots = L.smaat_dsconv_rows_num_slots(n, h, w)
+    z = _new(x, n, cout, h, w, dtype=out_dtype)
+    part = _new(x, 3, slots, cout) if want_stats else None
+    rc = L.smaat_dsconv_fwd_rows(_ptr(x), _dt(x), x_bs, _ptr(in_scale), _ptr(in_shift), _ptr(w_dw), _ptr(b_dw), _ptr(planes),
+                                 _ptr(b_pw), _ptr(z), _dt(z), cout * h * w, _ptr(part), n, cin, kpl, cout, h, w, _stream(x))
+    if rc == -2:
+        return None
+    _lib.check(rc, "smaat_dsconv_fwd_rows")
+    return z, part, (slots if want_stats else 0), None
+
+
 def _bn_finalize_raw(part, slots, c, count, bias_shift, gamma, beta, eps, momentum, rm, rv):
     L = _lib.get()
     st = _new(part, 4, c)
@@ -745,7 +775,10 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
     if bf:  # mixed precision: bf16 depthwise output, bf16 GEMM, bf16 z (the f32 kernel families are not involved)
         rs = _dsconv_fwd_bf16(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish)
     elif _split_on() and _fused_dw_ok(n, h, w, kpl, cout, keep_y, cin):
-        rs = _dsconv_fwd_fused(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish, want_y=keep_y)
+        if not keep_y:
+            rs = _dsconv_fwd_rows(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish)
+        if rs is None:
+            rs = _dsconv_fwd_fused(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish, want_y=keep_y)
     if rs is None and not bf and _split_fwd_ok(cin * kpl, cout, use_batch_stats):
         rs = _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish)
     if rs is not None and use_batch_stats:

@@ -988,6 +988,52 @@ def _t_cbam_bwd_final_pool(self, dx, dx_bs, davg, dmx, amax, x, x_bs, dpool, dp_
     return rc
 
 
+def _t_dsconv_rows_ok(self, kpl, Cin, Cout, H, W):
+    return int(kpl == 2 and W % 32 == 0 and 1 <= Cout <= 64 and Cin % 8 == 0 and 8 <= Cin <= 128)
+
+
+def _t_dsconv_rows_num_slots(self, N, H, W):
+    return PW_SLOTS + 3 if W % 32 == 0 else 0
+
+
+def _t_dsconv_fwd_rows(self, x, x_dt, x_bs, in_scale, in_shift, w_dw, b_dw, pl, b_pw, z, z_dt, z_bs, part, N, Cin, kpl, Cout, H, W,
+                       stream):
+    """row-walking fused forward (csrc/dsrows.hip): f32 storage through the emulation of the tile kernel (same arithmetic:
+    exact split planes), bf16 storage = f32 depthwise on the converted input, one bf16 rounding of y, bf16 weight image"""
+    if not self.smaat_dsconv_rows_ok(kpl, Cin, Cout, H, W) or (x_dt, z_dt) not in ((0, 0), (0, 1), (1, 1)):
+        return -2
+    P, K = H * W, Cin * kpl
+    T = self.smaat_dsconv_rows_num_slots(N, H, W)
+    xi = _TIn(x, x_dt, N, Cin, P, x_bs)
+    xv = xi.a.reshape(N, Cin, H, W)
+    if in_scale:
+        sc, sh = f32(in_scale, Cin), f32(in_shift, Cin)
+        xv = np.maximum(xv * sc[None, :, None, None] + sh[None, :, None, None], 0).astype(np.float32)
+    y = O.dw3x3_fwd(xv, f32(w_dw, K * 9).reshape(K, 1, 3, 3), f32(b_dw, K) if b_dw else None, kpl).reshape(N, K, P)
+    o = _TOut(z, z_dt, N, Cout, P, z_bs)
+    if z_dt == 0:
+        Kp = (K + 15) // 16 * 16
+        u = np.ctypeslib.as_array((ctypes.c_uint16 * (3 * Cout * Kp)).from_address(int(pl))).reshape(Kp // 16, 3, Cout, 16)
+        u = u.transpose(1, 2, 0, 3).reshape(3, Cout, Kp)
+        a = ((u.astype(np.uint32) << np.uint32(16)).view(np.float32)).astype(np.float64).sum(axis=0)[:, :K]
+        acc = np.einsum("mk,nkp->nmp", a.astype(np.float32), y)
+    else:
+        Kp = (K + 31) // 32 * 32
+        u = np.ctypeslib.as_array((ctypes.c_uint16 * (Cout * Kp)).from_address(int(pl))).reshape(Kp // 16, Cout, 16)
+        a = bf16_to_f32(np.ascontiguousarray(u.transpose(1, 0, 2)).reshape(Cout, Kp))[:, :K]
+        yb = bf16_to_f32(f32_to_bf16(y)).reshape(N, K, P)
+        acc = np.einsum("mk,nkp->nmp", a.astype(np.float64), yb.astype(np.float64)).astype(np.float32)
+    o.a[:] = acc + (f32(b_pw, Cout)[None, :, None] if b_pw else 0)
+    o.commit()
+    self._write_part(part, T, Cout, acc)
+    return 0
+
+
+for _name, _fn in (("smaat_dsconv_rows_ok", _t_dsconv_rows_ok), ("smaat_dsconv_rows_num_slots", _t_dsconv_rows_num_slots),
+                   ("smaat_dsconv_fwd_rows", _t_dsconv_fwd_rows)):
+    setattr(EmuLib, _name, _fn)
+
+
 for _name, _fn in (("smaat_bf16_planes", _t_bf16_planes), ("smaat_pointwise_fwd_bf16", _t_pointwise_fwd_bf16),
                    ("smaat_pointwise_wgrad_bf16", _t_pointwise_wgrad_bf16), ("smaat_dw3x3_fwd_t", _t_dw3x3_fwd),
                    ("smaat_dw3x3_bwd_t", _t_dw3x3_bwd), ("smaat_affine_act_t", _t_affine_act),

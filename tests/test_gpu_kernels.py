@@ -379,6 +379,74 @@ def test_dsconv_fwd_split(shape):
     both(case_dsconv_fwd_split, *shape, aff=True, pad_c=4, bias=False, want_y=False, tol=2e-6)
 
 
+def case_dsconv_fwd_rows(L, dev, N, Cin, Cout, H, W, aff=False, pad_c=0, bias=True, x_bf=False, z_bf=False):
+    """row-walking fused forward (smaat_dsconv_fwd_rows, csrc/dsrows.hip): f32 storage (split planes) or bf16 storage"""
+    K = Cin * 2
+    xf = rnd(1, N, Cin + pad_c, H, W) * np.exp(rnd(7, 1, Cin + pad_c, 1, 1))  # wide range across channels
+    xfull = T(xf, dev)
+    if x_bf:
+        xfull = xfull.to(torch.bfloat16)
+    x = xfull[:, pad_c:]
+    x_bs = (Cin + pad_c) * H * W
+    w_dw, b_dw = T(rnd(2, K, 9, scale=0.3), dev), T(rnd(3, K, scale=0.3), dev)
+    w, b_pw = T(rnd(4, Cout, K, scale=0.2), dev), T(rnd(5, Cout), dev)
+    sc = T(np.random.default_rng(6).uniform(0.5, 1.5, Cin).astype(np.float32), dev) if aff else None
+    sh = T(rnd(7, Cin, scale=0.3), dev) if aff else None
+    if z_bf:
+        pl = torch.full(((K + 31) // 32 * 2, Cout, 16), -1, dtype=torch.int16, device=dev)
+        assert L.smaat_bf16_planes(P(w), Cout, K, P(pl), 0, stream(dev)) == 0
+    else:
+        pl = torch.full((3, Cout, (K + 15) // 16 * 16), -1, dtype=torch.int16, device=dev)
+        assert L.smaat_split_planes(P(w), Cout, K, P(pl), stream(dev)) == 0
+    z = torch.full((N, Cout, H, W), float("nan"), device=dev).to(torch.bfloat16 if z_bf else torch.float32)
+    assert L.smaat_dsconv_rows_ok(2, Cin, Cout, H, W) == 1
+    slots = L.smaat_dsconv_rows_num_slots(N, H, W)
+    part = torch.full((3, slots, Cout), float("nan"), device=dev)
+    rc = L.smaat_dsconv_fwd_rows(x.data_ptr(), 1 if x_bf else 0, x_bs, P(sc), P(sh), P(w_dw), P(b_dw) if bias else None, P(pl),
+                                 P(b_pw) if bias else None, P(z), 1 if z_bf else 0, Cout * H * W, P(part), N, Cin, 2, Cout, H, W,
+                                 stream(dev))
+    assert rc == 0
+    pn, pmean, pvar = part_stats(part)
+    return dict(z=z.float(), pn=pn, pmean=pmean, pvar=pvar)
+
+
+ROWS_SHAPES = [
+    # N, Cin, Cout, H, W
+    (2, 64, 64, 32, 32),      # one strip, one band, K = 128
+    (1, 8, 10, 5, 64),        # two strips, partial channel tile, K = 16
+    (2, 40, 50, 36, 96),      # three strips, K = 80 (contraction steps beyond K are zero)
+    (1, 128, 64, 70, 32),     # two channels per producer thread (K = 256), bands of 32 with a short last one
+    (3, 72, 33, 9, 32),       # K = 144: the second channel of most producer threads is beyond Cin
+    (2, 64, 64, 288, 288),    # the inc.1 / up4.1 geometry
+    (9, 16, 1, 2, 64),        # more items than fit one workgroup each, a single output channel
+]
+
+
+@pytest.mark.parametrize("shape", ROWS_SHAPES)
+def test_dsconv_fwd_rows(shape):
+    both(case_dsconv_fwd_rows, *shape, tol=2e-6)
+    both(case_dsconv_fwd_rows, *shape, aff=True, pad_c=4, bias=False, tol=2e-6)
+
+
+@pytest.mark.parametrize("shape", ROWS_SHAPES[:5])
+def test_dsconv_fwd_rows_bf16_storage(shape):
+    """mixed precision: bf16 x (or the f32 stem input) -> bf16 z, one bf16 MFMA per product, f32 accumulation and statistics.
+    Against the emulation (f32 depthwise, ONE rounding of y, bf16 weights, fp64 sum): an f32 accumulation-order difference can
+    flip the final bf16 rounding of z by one ulp (2^-8 relative) on a few elements"""
+    both(case_dsconv_fwd_rows, *shape, x_bf=True, z_bf=True, tol=2e-3)
+    both(case_dsconv_fwd_rows, *shape, x_bf=False, z_bf=True, aff=True, pad_c=4, tol=2e-3)
+
+
+def test_dsconv_fwd_rows_refuses_what_it_does_not_handle():
+    L, dev = _lib.get(), torch.device("cuda:0")
+    assert L.smaat_dsconv_rows_ok(2, 64, 64, 18, 18) == 0 and L.smaat_dsconv_rows_ok(4, 64, 64, 32, 32) == 0
+    assert L.smaat_dsconv_rows_ok(2, 64, 128, 32, 32) == 0 and L.smaat_dsconv_rows_ok(2, 12, 64, 32, 32) == 0
+    assert L.smaat_dsconv_rows_ok(2, 256, 64, 32, 32) == 0 and L.smaat_dsconv_rows_num_slots(2, 18, 18) == 0
+    t = torch.zeros(1, 8, 18, 18, device=dev)
+    assert L.smaat_dsconv_fwd_rows(P(t), 0, 8 * 324, None, None, P(t), None, P(t), None, P(t), 0, 8 * 324, None, 1, 8, 2, 8, 18, 18,
+                                   stream(dev)) == -2
+
+
 def test_dsconv_fwd_split_refuses_what_it_does_not_handle():
     L, dev = _lib.get(), torch.device("cuda:0")
     assert L.smaat_dsconv_split_num_slots(2, 18, 18) == 0 and L.smaat_dsconv_split_num_slots(2, 4, 16) == 0
