@@ -84,6 +84,12 @@ int smaat_dsconv_wgrad_split_num_splits(int N, int Cin, int Cout, int H, int W);
 int smaat_dsconv_wgrad_split(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
                              const float* b_dw, const float* dz, long dz_bs, float* ws, float* dw_out, int N, int Cin,
                              int kpl, int Cout, int H, int W, void* stream);
+/* typed form (mixed precision): x_dt / dz_dt = SMAAT_DT_F32 | SMAAT_DT_BF16.  Built: everything f32 (= the entry point
+ * above); bf16 dz with bf16 x, or f32 x for the stem -- plain bf16 operands (the stored gradient IS the MFMA operand), f32
+ * depthwise arithmetic, f32 accumulation and result.  -2 for any other combination. */
+int smaat_dsconv_wgrad_split_t(const void* x, int x_dt, long x_bs, const float* in_scale, const float* in_shift,
+                               const float* w_dw, const float* b_dw, const void* dz, int dz_dt, long dz_bs, float* ws,
+                               float* dw_out, int N, int Cin, int kpl, int Cout, int H, int W, void* stream);
 
 /* ---- depthwise 3x3 backward (autograd of nn.Conv2d(groups=Cin), models/layers.py:38-44)
  *   dy [N][Cin*kpl][H][W] -> dx [N][Cin][H][W] (nullable), dw_out [Cin*kpl][9], db_out [Cin*kpl] (nullable)

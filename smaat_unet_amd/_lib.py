@@ -32,6 +32,7 @@ SIGNATURES = {
     "smaat_dsconv_wgrad_split_ok": [_I, _I, _I, _I],
     "smaat_dsconv_wgrad_split_num_splits": [_I, _I, _I, _I, _I],
     "smaat_dsconv_wgrad_split": [_P, _L, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "smaat_dsconv_wgrad_split_t": [_P, _I, _L, _P, _P, _P, _P, _P, _I, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "smaat_dw3x3_bwd_ws_rows": [_I, _I, _I, _I],
     "smaat_dw3x3_bwd": [_P, _L, _P, _L, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "smaat_dw3x3_strip_ok": [_I, _I, _I],
@@ -235,6 +236,8 @@ WORK_MODELS = {
     "smaat_pointwise_fwd": _w_pointwise_fwd,
     "smaat_dsconv_wgrad": _w_dsconv_wgrad,
     "smaat_dsconv_wgrad_split": _w_dsconv_wgrad,
+    "smaat_dsconv_wgrad_split_t": lambda a: (2.0 * a[12] * a[13] * a[14] * a[15] * a[16] * a[17],
+                                             a[12] * (_es(a[1]) * a[13] + _es(a[8]) * a[15]) * a[16] * a[17]),
     "smaat_pointwise_wgrad": _w_pointwise_wgrad,
     "smaat_dw3x3_bwd": _w_dw_bwd,
     "smaat_affine_act": lambda a: (2.0 * a[6] * a[7] * a[8], 8.0 * a[6] * a[7] * a[8]),

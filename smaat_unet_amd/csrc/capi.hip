@@ -26,13 +26,13 @@ int dsconv_rows_ok(int kpl, int Cin, int M, int H, int W);
 int dsconv_rows_num_slots(int N, int H, int W);
 int launch_dsconv_rows(DsRowsArgs& a, int kpl, int x_dt, int z_dt, hipStream_t st);
 struct DsWgArgs {  // dswgrad.hip
-    const float* x;
+    const void* x;
     long x_bs;
     const float* in_scale;
     const float* in_shift;
     const float* w_dw;
     const float* b_dw;
-    const float* dz;
+    const void* dz;
     long dz_bs;
     float* part;
     int N, Cin, K, M, H, W, P;
@@ -40,7 +40,7 @@ struct DsWgArgs {  // dswgrad.hip
 };
 int dsconv_wgrad_split_ok(int kpl, int M, int H, int W);
 int dsconv_wgrad_split_num_splits(int N, int Cin, int M, int H, int W);
-int launch_dsconv_wgrad_split(DsWgArgs& a, int kpl, hipStream_t st);
+int launch_dsconv_wgrad_split(DsWgArgs& a, int kpl, int x_dt, int dz_dt, hipStream_t st);
 
 int smaat_dsconv_wgrad_num_splits_impl(int N, int H, int W, int M, int Kdim);
 int launch_pwgemm(PwArgs& a, bool dw, hipStream_t st);
@@ -223,19 +223,26 @@ int smaat_dsconv_wgrad_split_ok(int kpl, int Cout, int H, int W) { return dsconv
 int smaat_dsconv_wgrad_split_num_splits(int N, int Cin, int Cout, int H, int W) {
     return dsconv_wgrad_split_num_splits(N, Cin, Cout, H, W);
 }
-int smaat_dsconv_wgrad_split(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
-                             const float* b_dw, const float* dz, long dz_bs, float* ws, float* dw_out, int N, int Cin,
-                             int kpl, int Cout, int H, int W, void* stream) {
+int smaat_dsconv_wgrad_split_t(const void* x, int x_dt, long x_bs, const float* in_scale, const float* in_shift,
+                               const float* w_dw, const float* b_dw, const void* dz, int dz_dt, long dz_bs, float* ws,
+                               float* dw_out, int N, int Cin, int kpl, int Cout, int H, int W, void* stream) {
     if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || !x || !w_dw || !dz || !ws || !dw_out) return -1;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return -1;
+    if ((x_dt != SMAAT_F32 && x_dt != SMAAT_BF16) || (dz_dt != SMAAT_F32 && dz_dt != SMAAT_BF16)) return -1;
     DsWgArgs a{};
     a.x = x; a.x_bs = x_bs; a.in_scale = in_scale; a.in_shift = in_shift; a.w_dw = w_dw; a.b_dw = b_dw;
     a.dz = dz; a.dz_bs = dz_bs; a.part = ws;
     a.N = N; a.Cin = Cin; a.K = Cin * kpl; a.M = Cout; a.H = H; a.W = W;
     hipStream_t st = ST;
-    const int rc = launch_dsconv_wgrad_split(a, kpl, st);
+    const int rc = launch_dsconv_wgrad_split(a, kpl, x_dt, dz_dt, st);
     if (rc) return rc;
     return launch_reduce_rows(ws, a.nsplit, (long)Cout * a.K, dw_out, 1.f, st);
+}
+int smaat_dsconv_wgrad_split(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                             const float* b_dw, const float* dz, long dz_bs, float* ws, float* dw_out, int N, int Cin,
+                             int kpl, int Cout, int H, int W, void* stream) {
+    return smaat_dsconv_wgrad_split_t(x, SMAAT_F32, x_bs, in_scale, in_shift, w_dw, b_dw, dz, SMAAT_F32, dz_bs, ws, dw_out, N, Cin,
+                                      kpl, Cout, H, W, stream);
 }
 
 int smaat_pointwise_wgrad(const float* x, long x_bs, const float* dz, long dz_bs, float* ws, float* dw_out, int N,

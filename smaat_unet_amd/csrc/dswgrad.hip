@@ -34,13 +34,13 @@ int split_mode();  // splitmma.hip
 #define DWG_CW 32    // pixels per chunk = width of a column strip
 
 struct DsWgArgs {
-    const float* x;
+    const void* x;   // TX
     long x_bs;
     const float* in_scale;
     const float* in_shift;
     const float* w_dw;  // [K][9]
     const float* b_dw;  // [K] or null
-    const float* dz;
+    const void* dz;  // TG
     long dz_bs;
     float* part;  // [nsplit][M][K]
     int N, Cin, K, M, H, W, P;
@@ -79,16 +79,31 @@ __device__ __forceinline__ void dwg_split4(const float (&v)[4], uint2 (&out)[NT]
 
 typedef float dwg_f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ const float* dwg_uniform_ptr(const float* p) {
+__device__ __forceinline__ const void* dwg_uniform_ptr(const void* p) {
     const unsigned long long v = (unsigned long long)p;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (const float*)(((unsigned long long)hi << 32) | lo);
+    return (const void*)(((unsigned long long)hi << 32) | lo);
 }
 
 // PK: the depthwise stage on packed f32 math (v_pk_fma_f32 over the two k-rows of a channel); experiment switch
 // SMAAT_DWG_PK=1 (the guide prices packed VALU beside MFMAs as an anti-lever: measured, profiles/r4)
-template <int NT, bool AFF, bool PK>
+// raw registers of a 4-element row piece (ext vector types: inline-asm outputs)
+typedef unsigned dwg_u32x2 __attribute__((ext_vector_type(2)));
+template <typename T> struct DwgRaw;
+template <> struct DwgRaw<float> { typedef f32x4 type; };
+template <> struct DwgRaw<bf16_t> { typedef dwg_u32x2 type; };
+__device__ __forceinline__ void dwg_vals(const f32x4 v, float (&m)[4]) {
+    m[0] = v[0]; m[1] = v[1]; m[2] = v[2]; m[3] = v[3];
+}
+__device__ __forceinline__ void dwg_vals(const dwg_u32x2 v, float (&m)[4]) {
+    m[0] = bf16_lo(v[0]); m[1] = bf16_hi(v[0]); m[2] = bf16_lo(v[1]); m[3] = bf16_hi(v[1]);
+}
+
+// TX / TG: storage types of x and dz (float | bf16).  bf16 dz (mixed precision, NT = 1) is the MFMA operand as it lies in
+// memory: its pieces go to the A image unconverted.
+template <int NT, bool AFF, bool PK, typename TX, typename TG>
 __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
+    static_assert(sizeof(TG) == 4 || NT == 1, "bf16 gradients are plain bf16 operands");
     constexpr int MT = 64, KT = 128, ROWS = MT + KT;
     constexpr int PLSZ = ROWS * DWG_SROW, BUFSZ = NT * PLSZ;
     constexpr int PD = 4;        // load groups in flight per producer thread
@@ -144,14 +159,14 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
         const int zrow = (g8 & ~7) | ((g8 & 1) << 2) | ((g8 >> 1) & 3);
         const bool zv = zrow < a.M;
         // per-lane byte offsets from the wave-uniform (scalar) row bases: no vector address arithmetic per iteration
-        const unsigned vo_x = (unsigned)(cgc * a.P + 4 * g) * 4u;
-        const unsigned vo_z = (unsigned)((zv ? zrow : 0) * a.P + 4 * q) * 4u;
+        const unsigned vo_x = (unsigned)(cgc * a.P + 4 * g) * (unsigned)sizeof(TX);
+        const unsigned vo_z = (unsigned)((zv ? zrow : 0) * a.P + 4 * q) * (unsigned)sizeof(TG);
         unsigned vo_e = vo_x;  // edge load: set per item (strip position decides whether the neighbour column exists)
         // ---- issue cursor (wave-uniform: SGPRs) ----
         int w_item = it_lo - 1, w_j = 0, w_len = 0;
         int w_r0 = 0;
-        const float* w_xb = a.x;   // x + n * x_bs + c0           (row 0 of the strip, channel 0)
-        const float* w_zb = a.dz;  // dz + n * dz_bs + c0
+        const TX* w_xb = (const TX*)a.x;   // x + n * x_bs + c0           (row 0 of the strip, channel 0)
+        const TG* w_zb = (const TG*)a.dz;  // dz + n * dz_bs + c0
         bool w_lok = false, w_rok = false;
         int w_eback = 0;  // 1 when a column exists left of the strip: the edge load's scalar base is one element back
         auto advance = [&]() __attribute__((always_inline)) {
@@ -164,8 +179,8 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
                     const int band = rem / a.strips, st_ = rem - band * a.strips;
                     w_r0 = band * a.RB;
                     const int c0 = st_ * DWG_CW;
-                    w_xb = a.x + (long)n * a.x_bs + c0;
-                    w_zb = a.dz + (long)n * a.dz_bs + c0;
+                    w_xb = (const TX*)a.x + (long)n * a.x_bs + c0;
+                    w_zb = (const TG*)a.dz + (long)n * a.dz_bs + c0;
                     w_len = (a.H - w_r0 < a.RB ? a.H - w_r0 : a.RB) + 2;
                     w_eback = __builtin_amdgcn_readfirstlane(c0 > 0 ? 1 : 0);
                     w_lok = w_eback != 0;
@@ -173,33 +188,43 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
                     // edge load: scalar base = row start - 1 element when a column exists left of the strip (the per-lane
                     // offset of a scalar-base load is UNSIGNED: it cannot reach backwards); lane g = 0 then reads column
                     // c0 - 1, lane g = 7 column c0 + 32 (or its own last column when there is none), the others their own
-                    vo_e = vo_x + (g == 0 ? 0u : ((w_lok ? 4u : 0u) + (g == 7 ? (w_rok ? 16u : 12u) : 0u)));
+                    vo_e = vo_x + (g == 0 ? 0u : ((w_lok ? 1u : 0u) + (g == 7 ? (w_rok ? 4u : 3u) : 0u))) * (unsigned)sizeof(TX);
                 } else {
                     w_j = w_len - 1;  // past the end: keep re-loading the last row (never consumed)
                 }
             }
         };
-        f32x4 sx[PD], sz[PD];
-        float se[PD];
+        typename DwgRaw<TX>::type sx[PD];
+        typename DwgRaw<TG>::type sz[PD];
+        unsigned se[PD];
         int srow[PD];        // x row index of the set (zero padding above / below the plane)
         bool slok[PD], srok[PD];
         auto issue = [&](int set) __attribute__((always_inline)) {
             advance();
             const int xr = w_r0 - 1 + w_j;  // x row delivered by this iteration
             const int xrc = xr < 0 ? 0 : (xr >= a.H ? a.H - 1 : xr);
-            const float* xrow = w_xb + (long)xrc * a.W;
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sx[set]) : "v"(vo_x), "s"(xrow));
+            const TX* xrow = (const TX*)dwg_uniform_ptr(w_xb + (long)xrc * a.W);
+            if (sizeof(TX) == 4)
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sx[set]) : "v"(vo_x), "s"(xrow));
+            else
+                asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(sx[set]) : "v"(vo_x), "s"(xrow));
             // (the "s" constraint does not make a value uniform: hipcc kept this pointer in VGPRs when the -1 came from a
             // select on the bool and emitted a VGPR pair in the scalar-base slot -> memory fault; built from an integer
             // that is provably wave-uniform instead)
-            const float* erow = dwg_uniform_ptr(xrow - w_eback);
-            asm volatile("global_load_dword %0, %1, %2" : "=v"(se[set]) : "v"(vo_e), "s"(erow));
+            const TX* erow = (const TX*)dwg_uniform_ptr(xrow - w_eback);
+            if (sizeof(TX) == 4)
+                asm volatile("global_load_dword %0, %1, %2" : "=v"(se[set]) : "v"(vo_e), "s"(erow));
+            else
+                asm volatile("global_load_ushort %0, %1, %2" : "=v"(se[set]) : "v"(vo_e), "s"(erow));
             srow[set] = xr;
             slok[set] = w_lok;
             srok[set] = w_rok;
             const int zr = w_r0 + w_j - 2;  // the chunk whose window this x row completes
-            const float* zrowp = w_zb + (long)(zr < 0 ? 0 : zr) * a.W;
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sz[set]) : "v"(vo_z), "s"(zrowp));
+            const TG* zrowp = (const TG*)dwg_uniform_ptr(w_zb + (long)(zr < 0 ? 0 : zr) * a.W);
+            if (sizeof(TG) == 4)
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sz[set]) : "v"(vo_z), "s"(zrowp));
+            else
+                asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(sz[set]) : "v"(vo_z), "s"(zrowp));
         };
         auto wait_set = [&](int set) __attribute__((always_inline)) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * LPG) : "memory");
@@ -220,8 +245,9 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
             }
             const int xr = srow[set];
             const bool rv = cv && xr >= 0 && xr < a.H;
-            float m[4] = {sx[set][0], sx[set][1], sx[set][2], sx[set][3]};
-            float e = se[set];
+            float m[4];
+            dwg_vals(sx[set], m);
+            float e = sizeof(TX) == 4 ? dwg_bitsf(se[set]) : bf16_lo(se[set]);
             if (AFF) {  // previous BatchNorm + ReLU on load (before the exchange: neighbours hand over activated values)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) m[c] = fmaxf(fmaf(m[c], asc, ash), 0.f);
@@ -282,12 +308,14 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) *(uint2*)(base + t * PLSZ + (MT + 2 * ci + j) * DWG_SROW + g * 8) = pl[t];
             }
-            {  // dz share
+            if constexpr (sizeof(TG) == 4) {  // dz share: split into the A image
                 const float v4[4] = {zv ? sz[set][0] : 0.f, zv ? sz[set][1] : 0.f, zv ? sz[set][2] : 0.f, zv ? sz[set][3] : 0.f};
                 uint2 pl[NT];
                 dwg_split4<NT>(v4, pl);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) *(uint2*)(base + t * PLSZ + zrow * DWG_SROW + q * 8) = pl[t];
+            } else {  // bf16 gradients are the operand as stored
+                *(uint2*)(base + zrow * DWG_SROW + q * 8) = zv ? make_uint2(sz[set][0], sz[set][1]) : make_uint2(0u, 0u);
             }
         };
         if (total > 0) {
@@ -344,7 +372,7 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
                         for (int tt = 0; tt < NT; ++tt) bf[j][tt] = *(const bf16x8*)(bp + tt * PLSZ + j * 32 * DWG_SROW + s * 32);
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        if (NT == 3) {  // smallest terms first (the order of k_wgrad_split)
+                        if constexpr (NT == 3) {  // smallest terms first (the order of k_wgrad_split)
                             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][2], acc[j], 0, 0, 0);
                             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[j][0], acc[j], 0, 0, 0);
                             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[j][1], acc[j], 0, 0, 0);
@@ -406,10 +434,10 @@ int dsconv_wgrad_split_num_splits(int N, int Cin, int M, int H, int W) {
     return a.nsplit;
 }
 
-template <int NT, bool AFF, bool PK>
+template <int NT, bool AFF, bool PK, typename TX, typename TG>
 static int launch_dswg_cfg(const DsWgArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * NT * (64 + 128) * DWG_SROW;
-    constexpr auto kern = k_dsconv_wgrad_split<NT, AFF, PK>;
+    constexpr auto kern = k_dsconv_wgrad_split<NT, AFF, PK, TX, TG>;
     static size_t granted = 0;
     if (lds > granted) {
         HIP_RET(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -419,18 +447,29 @@ static int launch_dswg_cfg(const DsWgArgs& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-// returns -2 when the shape / alignment is not handled (caller keeps the depthwise output and streams it)
-int launch_dsconv_wgrad_split(DsWgArgs& a, int kpl, hipStream_t st) {
+// x_dt / dz_dt: SMAAT_F32 | SMAAT_BF16 (built: everything f32; bf16 dz with x bf16 or f32 -- mixed precision, plain bf16
+// operands).  returns -2 when the shape / alignment / type combination is not handled (the caller keeps the depthwise
+// output and streams it)
+int launch_dsconv_wgrad_split(DsWgArgs& a, int kpl, int x_dt, int dz_dt, hipStream_t st) {
     if (!dsconv_wgrad_split_ok(kpl, a.M, a.H, a.W) || a.K != 2 * a.Cin) return -2;
-    if ((a.x_bs & 3) || (a.dz_bs & 3) || (((uintptr_t)a.x) & 15) || (((uintptr_t)a.dz) & 15)) return -2;
+    const int xe = x_dt == SMAAT_BF16 ? 2 : 4, ze = dz_dt == SMAAT_BF16 ? 2 : 4;
+    if ((a.x_bs & 3) || (a.dz_bs & 3) || (((uintptr_t)a.x) & (4 * xe - 1)) || (((uintptr_t)a.dz) & (4 * ze - 1))) return -2;
+    if ((long)a.Cin * a.H * a.W * xe >= (1L << 32) || (long)a.M * a.H * a.W * ze >= (1L << 32)) return -2;
     dswg_geom(a);
     const bool aff = a.in_scale != nullptr;
+    if (dz_dt == SMAAT_BF16) {
+        if (x_dt == SMAAT_BF16)
+            return aff ? launch_dswg_cfg<1, true, false, bf16_t, bf16_t>(a, st) : launch_dswg_cfg<1, false, false, bf16_t, bf16_t>(a, st);
+        return aff ? launch_dswg_cfg<1, true, false, float, bf16_t>(a, st) : launch_dswg_cfg<1, false, false, float, bf16_t>(a, st);
+    }
+    if (x_dt != SMAAT_F32) return -2;
     static int pk = -1;
     if (pk < 0) {
         const char* e = getenv("SMAAT_DWG_PK");
         pk = (e && e[0] == '1') ? 1 : 0;
     }
-    if (split_mode() == 1) return aff ? launch_dswg_cfg<1, true, false>(a, st) : launch_dswg_cfg<1, false, false>(a, st);
-    if (pk) return aff ? launch_dswg_cfg<3, true, true>(a, st) : launch_dswg_cfg<3, false, true>(a, st);
-    return aff ? launch_dswg_cfg<3, true, false>(a, st) : launch_dswg_cfg<3, false, false>(a, st);
+    if (split_mode() == 1)
+        return aff ? launch_dswg_cfg<1, true, false, float, float>(a, st) : launch_dswg_cfg<1, false, false, float, float>(a, st);
+    if (pk) return aff ? launch_dswg_cfg<3, true, true, float, float>(a, st) : launch_dswg_cfg<3, false, true, float, float>(a, st);
+    return aff ? launch_dswg_cfg<3, true, false, float, float>(a, st) : launch_dswg_cfg<3, false, false, float, float>(a, st);
 }

@@ -988,6 +988,27 @@ def _t_cbam_bwd_final_pool(self, dx, dx_bs, davg, dmx, amax, x, x_bs, dpool, dp_
     return rc
 
 
+def _t_dsconv_wgrad_split(self, x, x_dt, x_bs, in_scale, in_shift, w_dw, b_dw, dz, dz_dt, dz_bs, ws, dw_out, N, Cin, kpl, Cout, H, W,
+                          stream):
+    """typed recompute weight gradient: f32 = the f32 entry point; bf16 dz: f32 depthwise on the converted input, ONE
+    rounding of y to bf16 (the MFMA operand), fp64 sum"""
+    if not self.smaat_dsconv_wgrad_split_ok(kpl, Cout, H, W) or (x_dt, dz_dt) not in ((0, 0), (0, 1), (1, 1)):
+        return -2
+    if dz_dt == 0:
+        return self.smaat_dsconv_wgrad_split(x, x_bs, in_scale, in_shift, w_dw, b_dw, dz, dz_bs, ws, dw_out, N, Cin, kpl, Cout, H,
+                                             W, stream)
+    P, K = H * W, Cin * kpl
+    xi, di = _TIn(x, x_dt, N, Cin, P, x_bs), _TIn(dz, 1, N, Cout, P, dz_bs)
+    xv = xi.a.reshape(N, Cin, H, W)
+    if in_scale:
+        sc, sh = f32(in_scale, Cin), f32(in_shift, Cin)
+        xv = np.maximum(xv * sc[None, :, None, None] + sh[None, :, None, None], 0).astype(np.float32)
+    y = O.dw3x3_fwd(xv, f32(w_dw, K * 9).reshape(K, 1, 3, 3), f32(b_dw, K) if b_dw else None, kpl).reshape(N, K, P)
+    yb = bf16_to_f32(f32_to_bf16(y)).reshape(N, K, P)
+    f32(dw_out, Cout * K).reshape(Cout, K)[:] = np.einsum("nmp,nkp->mk", di.a.astype(np.float64), yb.astype(np.float64))
+    return 0
+
+
 def _t_dsconv_rows_ok(self, kpl, Cin, Cout, H, W):
     return int(kpl == 2 and W % 32 == 0 and 1 <= Cout <= 64 and Cin % 8 == 0 and 8 <= Cin <= 128)
 
@@ -1029,7 +1050,7 @@ def _t_dsconv_fwd_rows(self, x, x_dt, x_bs, in_scale, in_shift, w_dw, b_dw, pl, 
     return 0
 
 
-for _name, _fn in (("smaat_dsconv_rows_ok", _t_dsconv_rows_ok), ("smaat_dsconv_rows_num_slots", _t_dsconv_rows_num_slots),
+for _name, _fn in (("smaat_dsconv_wgrad_split_t", _t_dsconv_wgrad_split), ("smaat_dsconv_rows_ok", _t_dsconv_rows_ok), ("smaat_dsconv_rows_num_slots", _t_dsconv_rows_num_slots),
                    ("smaat_dsconv_fwd_rows", _t_dsconv_fwd_rows)):
     setattr(EmuLib, _name, _fn)
 

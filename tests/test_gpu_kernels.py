@@ -184,6 +184,32 @@ def test_dsconv_wgrad_split(shape):
     both(case_dsconv_wgrad_split, *shape, aff=True, bias=False, pad_c=3, tol=1e-5)
 
 
+def case_dsconv_wgrad_split_t(L, dev, N, Cin, Cout, H, W, x_bf=True, aff=False, pad_c=0):
+    """typed form, mixed precision: bf16 dz (the MFMA operand as stored), x bf16 or f32 (the stem), plain bf16 operands"""
+    K = Cin * 2
+    xfull = T(rnd(1, N, Cin + pad_c, H, W), dev)
+    if x_bf:
+        xfull = xfull.to(torch.bfloat16)
+    x = xfull[:, pad_c:]
+    w_dw, b_dw = T(rnd(2, K, 9, scale=0.3), dev), T(rnd(3, K, scale=0.3), dev)
+    dz = T(rnd(4, N, Cout, H, W), dev).to(torch.bfloat16)
+    sc = T(np.random.default_rng(6).uniform(0.5, 1.5, Cin).astype(np.float32), dev) if aff else None
+    sh = T(rnd(7, Cin, scale=0.3), dev) if aff else None
+    ws = torch.full((L.smaat_dsconv_wgrad_split_num_splits(N, Cin, Cout, H, W), Cout, K), float("nan"), device=dev)
+    dw = torch.full((Cout, K), float("nan"), device=dev)
+    assert L.smaat_dsconv_wgrad_split_t(x.data_ptr(), 1 if x_bf else 0, (Cin + pad_c) * H * W, P(sc), P(sh), P(w_dw), P(b_dw), P(dz),
+                                        1, Cout * H * W, P(ws), P(dw), N, Cin, 2, Cout, H, W, stream(dev)) == 0
+    return dict(dw=dw)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 32, 32), (1, 40, 50, 8, 64), (2, 100, 64, 36, 96), (1, 8, 16, 70, 32)])
+def test_dsconv_wgrad_split_bf16_storage(shape):
+    # (y is rounded to bf16 once before the MFMA: an f32 rounding difference in y moves single products by 2^-8; the sums
+    # over thousands of pixels agree to ~1e-3 of the gradient norm at worst, measured ~1e-4)
+    both(case_dsconv_wgrad_split_t, *shape, tol=2e-3)
+    both(case_dsconv_wgrad_split_t, *shape, x_bf=False, aff=True, pad_c=3, tol=2e-3)
+
+
 def test_dsconv_wgrad_split_against_fp64_and_the_streamed_kernel():
     """f32-class error: against an fp64 evaluation the recompute kernel is as close as the streamed split kernel
     (k_wgrad_split on the kept depthwise output) and as the f32-MFMA kernel; it refuses what it does not take"""
