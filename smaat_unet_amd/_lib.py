@@ -258,7 +258,8 @@ class Profiler:
         self._orig = {}
         for name in SIGNATURES:
             fn = getattr(self.lib, name)
-            if name.endswith(("_slots", "_splits", "_blocks", "_version", "_rows", "_enabled", "_mode", "_bytes", "_ok")):
+            if name.endswith(("_slots", "_splits", "_blocks", "_version", "_ws_rows", "_enabled", "_mode", "_bytes", "_ok",
+                              "_slices", "_floats")):
                 continue
             self._orig[name] = fn
             setattr(self.lib, name, self._wrap(name, fn))

@@ -360,6 +360,7 @@ FUSE_DW_SPLIT = os.environ.get("SMAAT_FUSE_DW", "auto")
 # 2x-expanded tensor is neither written (forward) nor read (weight gradient).  "auto" = the measured policy
 # (profiles/r4), "all" = every shape the kernels take, "off" = the round-3 behaviour.
 WGRAD_RECOMPUTE = os.environ.get("SMAAT_WGRAD_RECOMPUTE", "auto")
+BF16_RECOMPUTE = os.environ.get("SMAAT_BF16_RECOMPUTE", "1") != "0"  # the same policy under bf16 storage (A/B switch)
 
 
 def _recompute_wgrad_ok(n, cin, h, w, kpl, cout):
@@ -435,6 +436,10 @@ def _dsconv_fwd_rows(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, 
     if not L.smaat_dsconv_rows_ok(kpl, cin, cout, h, w):
         return None
     out_dtype = out_dtype or x.dtype
+    if out_dtype != BF16 and cin > 64 and FWD_ROWS != "all":
+        # K = 256 with the exact three-term split: 96 registers of resident weight fragments per consumer wave do not fit
+        # beside 8 producer waves (33 spilled registers, 1.43 vs 1.10 ms on up4.0: profiles/r4): the tile kernel keeps it
+        return None
     planes = (_bf16_planes_raw(w_pw.reshape(cout, -1)) if out_dtype == BF16 else _split_planes_raw(w_pw.reshape(cout, -1)))
     slots = L.smaat_dsconv_rows_num_slots(n, h, w)
     z = _new(x, n, cout, h, w, dtype=out_dtype)
@@ -633,7 +638,7 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None, i
     k = cin * kpl
     s = _stream(x)
     if _is_bf(dz):
-        return _dsconv_bwd_bf16(x, x_bs, w_dw, w_pw, dz, kpl, need_dx, y, bnred, in_aff)
+        return _dsconv_bwd_bf16(x, x_bs, w_dw, b_dw, w_pw, dz, kpl, need_dx, y, bnred, in_aff)
     if _is_bf(x):  # the forward of this block fell back to f32 storage (_bf16_storage_ok) on a bf16 input
         x, x_bs = _planes(x.float())
     if y is not None:
@@ -698,7 +703,7 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None, i
     return dx, dw_dw, db_dw, dw_pw
 
 
-def _dsconv_bwd_bf16(x, x_bs, w_dw, w_pw, dz, kpl, need_dx, y, bnred, in_aff):
+def _dsconv_bwd_bf16(x, x_bs, w_dw, b_dw, w_pw, dz, kpl, need_dx, y, bnred, in_aff):
     """mixed-precision form of _dsconv_bwd_raw: dz, y (the kept depthwise output) and the depthwise-output gradient are
     bf16; x is bf16, or f32 for the stem (then dx, if wanted, is f32 too).  Same return convention."""
     L = _lib.get()
@@ -707,9 +712,22 @@ def _dsconv_bwd_bf16(x, x_bs, w_dw, w_pw, dz, kpl, need_dx, y, bnred, in_aff):
     k = cin * kpl
     s = _stream(x)
     if y is None:
-        raise _lib.SmaatHipError("mixed precision keeps the depthwise output for the weight gradient "
-                                 "(ops.KEEP_DEPTHWISE_OUTPUT = False is an f32-only option)")
-    dw_pw = _pointwise_wgrad_raw(y, dz, cout)
+        # nothing was kept (the training policy of the plane-dominated layers, _recompute_wgrad_ok): the typed
+        # weight-gradient kernel recomputes the depthwise output from x with the previous activation applied on load
+        if not L.smaat_dsconv_wgrad_split_ok(kpl, cout, h, w):
+            raise _lib.SmaatHipError("mixed precision keeps the depthwise output for the weight gradient except where "
+                                     "smaat_dsconv_wgrad_split_t takes the shape (ops.KEEP_DEPTHWISE_OUTPUT = False is an "
+                                     "f32-only option)")
+        isc_, ish_ = in_aff if in_aff is not None else (None, None)
+        dw_pw = _new(x, cout, k, 1, 1)
+        ws = _new(x, L.smaat_dsconv_wgrad_split_num_splits(n, cin, cout, h, w), cout, k)
+        dzp, dz_bs = _planes(dz)
+        _lib.check(L.smaat_dsconv_wgrad_split_t(_ptr(x), _dt(x), x_bs, _ptr(isc_), _ptr(ish_), _ptr(w_dw), _ptr(b_dw), _ptr(dzp), _dt(dzp),
+                                                dz_bs, _ptr(ws), _ptr(dw_pw), n, cin, kpl, cout, h, w, s),
+                   "smaat_dsconv_wgrad_split_t")
+        del ws
+    else:
+        dw_pw = _pointwise_wgrad_raw(y, dz, cout)
     planes_t = _bf16_planes_raw(w_pw.reshape(cout, k), transpose=True)  # A[k][co] = w_pw[co][k]
     dy, _, _ = _pointwise_bf16_raw(dz, planes_t, None, k)
     dx = _new(x, n, cin, h, w, dtype=x.dtype) if need_dx else None
@@ -770,10 +788,16 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
         bf = False
         if _is_bf(x):
             x = x.float()
-    if keep_y and not bf and _recompute_wgrad_ok(n, cin, h, w, kpl, cout):
+    rec = keep_y and _recompute_wgrad_ok(n, cin, h, w, kpl, cout) and (not bf or BF16_RECOMPUTE)
+    if rec:
         keep_y = False  # the weight gradient recomputes the depthwise output from x: nothing to keep (y_dw = None)
     if bf:  # mixed precision: bf16 depthwise output, bf16 GEMM, bf16 z (the f32 kernel families are not involved)
-        rs = _dsconv_fwd_bf16(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish)
+        if rec or not keep_y:  # no depthwise tensor wanted: the row-walking fused kernel where it takes the shape
+            rs = _dsconv_fwd_rows(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish, out_dtype=BF16)
+        if rs is None:
+            rs = _dsconv_fwd_bf16(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish)
+            if rec:
+                rs = rs[:3] + (None,)
     elif _split_on() and _fused_dw_ok(n, h, w, kpl, cout, keep_y, cin):
         if not keep_y:
             rs = _dsconv_fwd_rows(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish)

@@ -647,3 +647,39 @@ def test_standalone_block_under_bf16_precision_with_an_odd_plane_runs_with_f32_s
                              half[0].pointwise.bias, *_bn_args(half[1]), 2)
         y.float().sum().backward()
     assert half[1].weight.grad is not None and torch.isfinite(half[1].weight.grad).all()
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_recompute_policy_wiring_equals_the_kept_depthwise_output(mode, monkeypatch):
+    """Round 4 training policy (ops._recompute_wgrad_ok): row-walking fused forward without a depthwise side output +
+    weight gradient that recomputes the depthwise output from x (previous activation on load, depthwise bias included).
+    Through the emulation both wirings evaluate the same arithmetic, so logits and every gradient must agree -- this pins
+    the host plumbing (in_aff / bias / dtype arguments, nothing kept for backward), in f32 and in bf16 storage."""
+    from smaat_unet_amd import ops as K
+    torch.manual_seed(7)
+    x = torch.from_numpy(O_precip(2, 12, 32, 64))
+    y = torch.rand(2, 32, 64) * 0.3
+    m = S.SmaAt_UNet(12, 1).train()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    res = {}
+    for policy in ("off", "all"):
+        monkeypatch.setattr(K, "WGRAD_RECOMPUTE", policy)
+        m.load_state_dict(sd)
+        m.zero_grad(set_to_none=True)
+        m.set_precision(mode)
+        saved = []
+        with torch.autograd.graph.saved_tensors_hooks(lambda t: (saved.append(tuple(t.shape)), t)[1], lambda t: t):
+            out = m(x)
+        loss = torch.nn.functional.mse_loss(out.squeeze(1), y, reduction="sum") / 2
+        loss.backward()
+        res[policy] = (out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}, saved)
+    (o0, g0, s0), (o1, g1, s1) = res["off"], res["all"]
+    tol = 1e-5 if mode == "f32" else 3e-2   # (bf16: the two wirings round y / z at different places)
+    assert rel(o1.numpy(), o0.numpy()) < tol
+    f0 = torch.cat([g.flatten() for g in g0.values()])
+    f1 = torch.cat([g1[k].flatten() for k in g0])
+    assert rel(f1.numpy(), f0.numpy()) < (1e-4 if mode == "f32" else 0.2)
+    # the 2x-expanded depthwise tensors of the full-resolution layers are no longer kept: inc.1 (128 ch) and the up4 block
+    # (a 128-channel tensor remains at that resolution: the decoder's concatenation buffer, the input of up4)
+    big = lambda s_, c: len([sh for sh in s_ if len(sh) == 4 and sh[2:] == (32, 64) and sh[1] == c])  # noqa: E731
+    assert (big(s0, 128), big(s0, 256)) == (3, 1) and (big(s1, 128), big(s1, 256)) == (1, 0), (s0, s1)
