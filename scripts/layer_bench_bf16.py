@@ -86,6 +86,19 @@ def main():
         t_dwb = timeit(lambda: chk(L.smaat_dw3x3_bwd_t(x.data_ptr(), 1, cin * p, None, None, dy.data_ptr(), 1, k * p,
                                                        w_dw.data_ptr(), dx.data_ptr(), 1, cin * p, ws2.data_ptr(), dwd.data_ptr(),
                                                        dbd.data_ptr(), None, None, None, N, cin, 2, h, w, st)))
+        extra = ""
+        if L.smaat_dsconv_rows_ok(2, cin, cout, h, w):  # round 4: row-walking fused forward + typed recompute weight gradient
+            part_r = torch.empty(3, L.smaat_dsconv_rows_num_slots(N, h, w), cout, device=dev)
+            t_rows = timeit(lambda: chk(L.smaat_dsconv_fwd_rows(x.data_ptr(), 1, cin * p, None, None, w_dw.data_ptr(), b_dw.data_ptr(),
+                                                                pl.data_ptr(), b_pw.data_ptr(), z.data_ptr(), 1, cout * p,
+                                                                part_r.data_ptr(), N, cin, 2, cout, h, w, st)))
+            extra += f" | ROWS fwd {t_rows:6.3f} ({2.0 * N * (cin + cout) * p / (t_rows * 1e-3) / 1e9:5.0f}) vs dw+gemm {t_dwf + t_fwd:6.3f}"
+        if L.smaat_dsconv_wgrad_split_ok(2, cout, h, w):
+            wsr = torch.empty(L.smaat_dsconv_wgrad_split_num_splits(N, cin, cout, h, w), cout, k, device=dev)
+            t_wr = timeit(lambda: chk(L.smaat_dsconv_wgrad_split_t(x.data_ptr(), 1, cin * p, None, None, w_dw.data_ptr(), b_dw.data_ptr(),
+                                                                   dz.data_ptr(), 1, cout * p, wsr.data_ptr(), dw.data_ptr(), N, cin, 2,
+                                                                   cout, h, w, st)))
+            extra += f" | recompute wgrad {t_wr:6.3f} ({2.0 * N * (cin + cout) * p / (t_wr * 1e-3) / 1e9:5.0f}) vs {t_wg:6.3f}"
         gb = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9  # noqa: E731
         b_dwf = 2.0 * N * (cin + k) * p
         b_g = 2.0 * N * (k + cout) * p
@@ -99,7 +112,7 @@ def main():
         tot["wgrad"] += t_wg
         tot["dwb"] += t_dwb
         print(f"{name:9s} {t_dwf:6.3f} ({r['dwf_gbs']:5.0f}) {t_fwd:6.3f} ({r['fwd_gbs']:5.0f}) {t_dg:6.3f} ({r['dgrad_gbs']:5.0f}) "
-              f"{t_wg:6.3f} ({r['wgrad_gbs']:5.0f}) {t_dwb:6.3f} ({r['dwb_gbs']:5.0f})")
+              f"{t_wg:6.3f} ({r['wgrad_gbs']:5.0f}) {t_dwb:6.3f} ({r['dwb_gbs']:5.0f})" + extra, flush=True)
         del x, y, z, dz, dy, dx, ws, ws2
     print("total ms: " + "  ".join(f"{k_} {v:.3f}" for k_, v in tot.items()))
     os.makedirs("gpurun_out", exist_ok=True)

@@ -88,7 +88,10 @@ __device__ __forceinline__ void dsr_store(float* p, float v) { *p = v; }
 __device__ __forceinline__ void dsr_store(bf16_t* p, float v) { *p = (bf16_t)(pack_bf16x2(v, 0.f) & 0xFFFFu); }
 
 // CPT: channels per producer thread (1: Cin <= 64, 2: Cin <= 128); KS = K / 16 contraction steps (<= 8 * CPT)
-template <int NT, bool AFF, int CPT, typename TX, typename TZ>
+typedef float dsr_f32x2 __attribute__((ext_vector_type(2)));
+
+// PK: depthwise stage on packed f32 math (experiment switch SMAAT_DWG_PK=1, bf16-storage instantiations only)
+template <int NT, bool AFF, int CPT, typename TX, typename TZ, bool PK = false>
 __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
     constexpr int KMAX = 128 * CPT;          // k rows the B image holds
     constexpr int ROWB = KMAX * 2 + 16;      // bytes per pixel row of the B image (dword stride = 4 mod 64: conflict-free b128)
@@ -135,8 +138,8 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
 #pragma unroll
-                for (int k = 0; k < 9; ++k) wt[u][j][k] = a.w_dw[(cgc[u] * 2 + j) * 9 + k];
-                bs[u][j] = a.b_dw ? a.b_dw[cgc[u] * 2 + j] : 0.f;
+                for (int k = 0; k < 9; ++k) wt[u][j][k] = cv[u] ? a.w_dw[(cgc[u] * 2 + j) * 9 + k] : 0.f;
+                bs[u][j] = (cv[u] && a.b_dw) ? a.b_dw[cgc[u] * 2 + j] : 0.f;  // channels beyond Cin: y = 0 exactly
             }
             asc[u] = AFF ? a.in_scale[cgc[u]] : 1.f;
             ash[u] = AFF ? a.in_shift[cgc[u]] : 0.f;
@@ -251,17 +254,34 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
 #pragma unroll
             for (int u = 0; u < CPT; ++u) {
                 float yy[2][4];
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
+                if (PK) {  // both k-rows of the channel in one v_pk_fma_f32 (same fma per component, same tap order)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        float acc = bs[u][j];  // tap order of k_dw3x3_fwd_rows: bit-identical y
+                        dsr_f32x2 acc = {bs[u][0], bs[u][1]};
 #pragma unroll
                         for (int tr = 0; tr < 3; ++tr)
 #pragma unroll
-                            for (int tc = 0; tc < 3; ++tc) acc = fmaf(wt[u][j][tr * 3 + tc], win[u][tr][c + tc], acc);
-                        yy[j][c] = cv[u] ? acc : 0.f;
+                            for (int tc = 0; tc < 3; ++tc) {
+                                const dsr_f32x2 w2 = {wt[u][0][tr * 3 + tc], wt[u][1][tr * 3 + tc]};
+                                const dsr_f32x2 x2 = {win[u][tr][c + tc], win[u][tr][c + tc]};
+                                acc = __builtin_elementwise_fma(w2, x2, acc);
+                            }
+                        yy[0][c] = acc[0];
+                        yy[1][c] = acc[1];
                     }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            float acc = bs[u][j];  // tap order of k_dw3x3_fwd_rows: bit-identical y
+#pragma unroll
+                            for (int tr = 0; tr < 3; ++tr)
+#pragma unroll
+                                for (int tc = 0; tc < 3; ++tc) acc = fmaf(wt[u][j][tr * 3 + tc], win[u][tr][c + tc], acc);
+                            yy[j][c] = acc;
+                        }
+                }
                 const int dw_ = ((ci + 64 * u) ^ bsw) * 4;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -474,11 +494,11 @@ int dsconv_rows_num_slots(int N, int H, int W) {
     return a.items;
 }
 
-template <int NT, bool AFF, int CPT, typename TX, typename TZ>
+template <int NT, bool AFF, int CPT, typename TX, typename TZ, bool PK = false>
 static int launch_dsr_cfg(const DsRowsArgs& a, hipStream_t st) {
     constexpr int ROWB = 128 * CPT * 2 + 16;
     const size_t lds = (size_t)2 * NT * DSR_CW * ROWB + (size_t)2 * 4 * 8 * 64 * sizeof(float);
-    constexpr auto kern = k_dsconv_rows_fwd<NT, AFF, CPT, TX, TZ>;
+    constexpr auto kern = k_dsconv_rows_fwd<NT, AFF, CPT, TX, TZ, PK>;
     static size_t granted = 0;
     if (lds > granted) {
         HIP_RET(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -488,11 +508,11 @@ static int launch_dsr_cfg(const DsRowsArgs& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-template <int NT, typename TX, typename TZ>
+template <int NT, typename TX, typename TZ, bool PK = false>
 static int launch_dsr_sel(const DsRowsArgs& a, hipStream_t st) {
     const bool aff = a.in_scale != nullptr;
-    if (a.Cin <= 64) return aff ? launch_dsr_cfg<NT, true, 1, TX, TZ>(a, st) : launch_dsr_cfg<NT, false, 1, TX, TZ>(a, st);
-    return aff ? launch_dsr_cfg<NT, true, 2, TX, TZ>(a, st) : launch_dsr_cfg<NT, false, 2, TX, TZ>(a, st);
+    if (a.Cin <= 64) return aff ? launch_dsr_cfg<NT, true, 1, TX, TZ, PK>(a, st) : launch_dsr_cfg<NT, false, 1, TX, TZ, PK>(a, st);
+    return aff ? launch_dsr_cfg<NT, true, 2, TX, TZ, PK>(a, st) : launch_dsr_cfg<NT, false, 2, TX, TZ, PK>(a, st);
 }
 
 // x_dt / z_dt: SMAAT_F32 | SMAAT_BF16.  f32 storage: planes = the three split planes (or plane 0 only in bf16-operand
@@ -506,7 +526,12 @@ int launch_dsconv_rows(DsRowsArgs& a, int kpl, int x_dt, int z_dt, hipStream_t s
     dsr_geom(a);
     if (z_dt == SMAAT_BF16) {  // mixed precision: bf16 z, bf16 operands; x f32 (the stem) or bf16
         a.npl = 1;
-        if (x_dt == SMAAT_BF16) return launch_dsr_sel<1, bf16_t, bf16_t>(a, st);
+        static int pk = -1;
+        if (pk < 0) {
+            const char* e = getenv("SMAAT_DWG_PK");
+            pk = (e && e[0] == '1') ? 1 : 0;
+        }
+        if (x_dt == SMAAT_BF16) return pk ? launch_dsr_sel<1, bf16_t, bf16_t, true>(a, st) : launch_dsr_sel<1, bf16_t, bf16_t>(a, st);
         return launch_dsr_sel<1, float, bf16_t>(a, st);
     }
     if (x_dt != SMAAT_F32) return -2;

@@ -60,9 +60,7 @@ __device__ __forceinline__ void dwg_split4(const float (&v)[4], uint2 (&out)[NT]
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (NT == 1) {
-            const unsigned b = dwg_fbits(v[i]);
-            p1[i] = dwg_bitsf((b + 0x7FFFu + ((b >> 16) & 1u)) & 0xFFFF0000u);
-            p2[i] = p3[i] = 0.f;
+            p1[i] = p2[i] = p3[i] = 0.f;  // (rounded below, two values per v_cvt_pk_bf16_f32)
         } else {
             p1[i] = dwg_bitsf(dwg_fbits(v[i]) & 0xFFFF0000u);
             const float r1 = v[i] - p1[i];  // exact
@@ -70,7 +68,10 @@ __device__ __forceinline__ void dwg_split4(const float (&v)[4], uint2 (&out)[NT]
             p3[i] = r1 - p2[i];             // exact, <= 8 significant bits
         }
     }
-    out[0] = make_uint2(dwg_pack_hi16(p1[0], p1[1]), dwg_pack_hi16(p1[2], p1[3]));
+    if constexpr (NT == 1)
+        out[0] = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));  // round to nearest even
+    else
+        out[0] = make_uint2(dwg_pack_hi16(p1[0], p1[1]), dwg_pack_hi16(p1[2], p1[3]));
     if constexpr (NT == 3) {
         out[1] = make_uint2(dwg_pack_hi16(p2[0], p2[1]), dwg_pack_hi16(p2[2], p2[3]));
         out[2] = make_uint2(dwg_pack_hi16(p3[0], p3[1]), dwg_pack_hi16(p3[2], p3[3]));
@@ -149,8 +150,8 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) wt[j][k] = a.w_dw[(cgc * 2 + j) * 9 + k];
-            bs[j] = a.b_dw ? a.b_dw[cgc * 2 + j] : 0.f;
+            for (int k = 0; k < 9; ++k) wt[j][k] = cv ? a.w_dw[(cgc * 2 + j) * 9 + k] : 0.f;
+            bs[j] = (cv && a.b_dw) ? a.b_dw[cgc * 2 + j] : 0.f;  // channels beyond Cin: zero window, zero taps -> y = 0
         }
         const float asc = AFF ? a.in_scale[cgc] : 1.f, ash = AFF ? a.in_shift[cgc] : 0.f;
         // dz share: 64 rows x 8 float4 columns = 512 pieces, one per thread; within a group of 8 rows the row order is
@@ -285,8 +286,8 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
                             const dwg_f32x2 x2 = {win[tr][c + tc], win[tr][c + tc]};
                             acc = __builtin_elementwise_fma(w2, x2, acc);
                         }
-                    yy[0][c] = cv ? acc[0] : 0.f;
-                    yy[1][c] = cv ? acc[1] : 0.f;
+                    yy[0][c] = acc[0];
+                    yy[1][c] = acc[1];
                 }
             } else {
 #pragma unroll
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
                         for (int tr = 0; tr < 3; ++tr)
 #pragma unroll
                             for (int tc = 0; tc < 3; ++tc) acc = fmaf(wt[j][tr * 3 + tc], win[tr][c + tc], acc);
-                        yy[j][c] = cv ? acc : 0.f;  // (channels beyond Cin in the last K tile contribute zero rows)
+                        yy[j][c] = acc;  // (channels beyond Cin in the last K tile: zero taps and bias -> zero rows)
                     }
             }
 #pragma unroll
@@ -457,17 +458,19 @@ int launch_dsconv_wgrad_split(DsWgArgs& a, int kpl, int x_dt, int dz_dt, hipStre
     if ((long)a.Cin * a.H * a.W * xe >= (1L << 32) || (long)a.M * a.H * a.W * ze >= (1L << 32)) return -2;
     dswg_geom(a);
     const bool aff = a.in_scale != nullptr;
-    if (dz_dt == SMAAT_BF16) {
-        if (x_dt == SMAAT_BF16)
-            return aff ? launch_dswg_cfg<1, true, false, bf16_t, bf16_t>(a, st) : launch_dswg_cfg<1, false, false, bf16_t, bf16_t>(a, st);
-        return aff ? launch_dswg_cfg<1, true, false, float, bf16_t>(a, st) : launch_dswg_cfg<1, false, false, float, bf16_t>(a, st);
-    }
-    if (x_dt != SMAAT_F32) return -2;
     static int pk = -1;
     if (pk < 0) {
         const char* e = getenv("SMAAT_DWG_PK");
         pk = (e && e[0] == '1') ? 1 : 0;
     }
+    if (dz_dt == SMAAT_BF16) {
+        if (x_dt == SMAAT_BF16) {
+            if (pk) return aff ? launch_dswg_cfg<1, true, true, bf16_t, bf16_t>(a, st) : launch_dswg_cfg<1, false, true, bf16_t, bf16_t>(a, st);
+            return aff ? launch_dswg_cfg<1, true, false, bf16_t, bf16_t>(a, st) : launch_dswg_cfg<1, false, false, bf16_t, bf16_t>(a, st);
+        }
+        return aff ? launch_dswg_cfg<1, true, false, float, bf16_t>(a, st) : launch_dswg_cfg<1, false, false, float, bf16_t>(a, st);
+    }
+    if (x_dt != SMAAT_F32) return -2;
     if (split_mode() == 1)
         return aff ? launch_dswg_cfg<1, true, false, float, float>(a, st) : launch_dswg_cfg<1, false, false, float, float>(a, st);
     if (pk) return aff ? launch_dswg_cfg<3, true, true, float, float>(a, st) : launch_dswg_cfg<3, false, true, float, float>(a, st);
