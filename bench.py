@@ -525,10 +525,15 @@ def main():
                   "k_pw_split_p: persistent wave-specialised GEMM (v_mfma_f32_32x32x16_bf16, exact 3-term operand "
                   "split): pointwise forward of the GEMM-sized layers + every data gradient", pmc=("k_pw_split",),
                   peak_name=BF16),
-            klass(["smaat_dsconv_fwd_split"], "mfma", PEAK_BF16_MFMA_TFLOPS, "TFLOP/s", nt,
-                  "k_dsconv_split: fused depthwise 3x3 -> split GEMM forward of the 288^2 layers (depthwise tensor written "
-                  "once as a side output for the weight gradient, never re-read by the forward)", pmc=("k_dsconv_split",),
-                  peak_name=BF16),
+            klass(["smaat_dsconv_fwd_split"] + (["smaat_dsconv_fwd_rows"] if args.precision != "bf16" else []), "mfma",
+                  PEAK_BF16_MFMA_TFLOPS, "TFLOP/s", nt,
+                  "k_dsconv_rows_fwd / k_dsconv_split: fused depthwise 3x3 -> split GEMM forward of the 288^2 layers (row-walking "
+                  "register window + register-resident weight fragments where Cin <= 64, pixel-tile kernel for K = 256); no "
+                  "depthwise tensor in HBM", pmc=("k_dsconv_rows_fwd", "k_dsconv_split"), peak_name=BF16),
+            klass(["smaat_dsconv_wgrad_split"], "mfma", PEAK_BF16_MFMA_TFLOPS, "TFLOP/s", nt,
+                  "k_dsconv_wgrad_split: pointwise weight gradient of the 288^2 layers with the depthwise output recomputed from "
+                  "x by the producer waves (reads Cin instead of 2 Cin channels; VALU-bound beside the MFMAs)",
+                  pmc=("k_dsconv_wgrad_split",), peak_name=BF16),
             klass(["smaat_pointwise_wgrad"], "mfma", PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS, "TFLOP/s",
                   nt if split else 1.0, "k_wgrad_split" if split else "k_wgrad2 (v_mfma_f32_32x32x2_f32)",
                   pmc=("k_wgrad_split",) if split else ("k_wgrad2",), peak_name=BF16 if split else F32),
@@ -545,6 +550,12 @@ def main():
                   peak_name=HBM),
         ]
         classes += [  # mixed precision (bf16 storage): every layer is HBM-bound, all classes priced on HBM
+            klass(["smaat_dsconv_fwd_rows"], "hbm", PEAK_HBM_GBS, "GB/s", 1.0,
+                  "k_dsconv_rows_fwd<bf16>: row-walking fused depthwise -> bf16 GEMM forward of the 288^2 layers (no depthwise "
+                  "tensor in HBM)", pmc=("k_dsconv_rows_fwd",), peak_name=HBM) if args.precision == "bf16" else None,
+            klass(["smaat_dsconv_wgrad_split_t"], "hbm", PEAK_HBM_GBS, "GB/s", 1.0,
+                  "k_dsconv_wgrad_split<bf16>: weight gradient with the depthwise output recomputed from x",
+                  pmc=("k_dsconv_wgrad_split",), peak_name=HBM),
             klass(["smaat_pointwise_fwd_bf16"], "hbm", PEAK_HBM_GBS, "GB/s", 1.0,
                   "k_pw_bf16: bf16 GEMM fed by LDS-DMA + ds_read_b64_tr_b16 (pointwise forward + every data gradient), "
                   "bf16 in / bf16 out, f32 accumulate", pmc=("k_pw_bf16",), peak_name=HBM),
