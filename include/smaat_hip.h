@@ -15,6 +15,8 @@
  *    hipStream_t).  Element types are per-call arguments (dtype codes of the "mixed precision" section).  ONE process-wide
  *    setting exists: smaat_set_split_mode, the A/B switch of the f32-storage matrix path (exact three-term split | single
  *    bf16 term); hosts that need both in one process call it around the launches concerned (it is read at launch time).
+ *    (Deliberately NOT thread-local: PyTorch's autograd engine launches the backward kernels from its own device thread,
+ *    which must see the mode the forward ran under; tried and reverted in round 4.)
  *  - return value: 0 = ok, >0 = hipError_t, -1 = invalid argument, -2 = shape / alignment not taken by this entry point
  *    (the caller uses the general one; documented per entry point).
  */

@@ -330,9 +330,9 @@ def summarize(store, tag, arr, full_max=8192, nsample=4096, store_idx=True):
         store[tag + "#vals"] = a[idx]
 
 
-def gen_unet(name, n_channels, n_classes, n, h, w, loss_kind, seed):
-    P = oparams.make_smaat_params(n_channels, n_classes, 2, 16, seed)
-    model = SmaAt_UNet(n_channels, n_classes)
+def gen_unet(name, n_channels, n_classes, n, h, w, loss_kind, seed, kpl=2):
+    P = oparams.make_smaat_params(n_channels, n_classes, kpl, 16, seed)
+    model = SmaAt_UNet(n_channels, n_classes, kernels_per_layer=kpl)
     load_np_state(model, P)
     model.train()
     rng = np.random.default_rng(seed + 100)
@@ -360,7 +360,7 @@ def gen_unet(name, n_channels, n_classes, n, h, w, loss_kind, seed):
         hk.remove()
     s = {"x": x, "target": target, "logits": t2n(logits), "loss": np.float64(loss.item()),
          "meta": np.array(json.dumps(dict(n_channels=n_channels, n_classes=n_classes, n=n, h=h, w=w, loss=loss_kind,
-                                          param_seed=seed)))}
+                                          param_seed=seed, kpl=kpl)))}
     rename = dict(inc="x1", cbam1="x1Att", down1="x2", cbam2="x2Att", down2="x3", cbam3="x3Att", down3="x4",
                   cbam4="x4Att", down4="x5", cbam5="x5Att", up1="u1", up2="u2", up3="u3", up4="u4")
     for k, v in acts.items():
@@ -373,7 +373,7 @@ def gen_unet(name, n_channels, n_classes, n, h, w, loss_kind, seed):
             s["after/" + k] = t2n(v)
     # round 3: fp64 anchors + the reference's own fp32-vs-fp64 error per gradient tensor, so that the tests can use the
     # per-tensor 3 x noise rule of the benchmark-size fixtures instead of one flat bound
-    m64 = SmaAt_UNet(n_channels, n_classes).double()
+    m64 = SmaAt_UNet(n_channels, n_classes, kernels_per_layer=kpl).double()
     m64.load_state_dict({k: torch.from_numpy(np.asarray(v)).double() if np.asarray(v).dtype == np.float32
                          else torch.from_numpy(np.asarray(v)) for k, v in P.items()})
     m64.train()
@@ -903,6 +903,9 @@ def _jobs():
     J["unet_12x1_n2_32"] = lambda: gen_unet("unet_12x1_n2_32", 12, 1, 2, 32, 32, "mse", 0)
     J["unet_12x1_n2_64x48"] = lambda: gen_unet("unet_12x1_n2_64x48", 12, 1, 2, 64, 48, "mse", 1)
     J["unet_3x21_n1_32"] = lambda: gen_unet("unet_3x21_n1_32", 3, 21, 1, 32, 32, "cot", 2)
+    # round 4 (VERDICT r3 missing #6): the network at kernels_per_layer = 3 (models/SmaAt_UNet.py:12 accepts any integer):
+    # outside the fused kernels, every block on the general depthwise geometry path
+    J["unet_4x2_k3_n2_32"] = lambda: gen_unet("unet_4x2_k3_n2_32", 4, 2, 2, 32, 32, "cot", 12, kpl=3)
     # sibling networks: no attention / four CBAMs, kernels_per_layer 1, 2 and 4;
     # 48 x 40: the width is not a multiple of 16, so UpDS has to F.pad (unet_parts_depthwise_separable.py:78-81).
     # Tie-free fixtures (gen_variant_strict), incl. the four-CBAM network at kernels_per_layer = 4
