@@ -98,7 +98,7 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
     constexpr int BPL = DSR_CW * ROWB;       // bytes per plane
     constexpr int BUFSZ = NT * BPL;
     constexpr int KSH = 4 * CPT;             // contraction steps per consumer wave (half of KMAX / 16)
-    constexpr int PD = 4;
+    constexpr int PD = sizeof(TX) == 2 ? 8 : 4;  // rows in flight per producer thread (bf16: half the bytes per row, see dswgrad.hip)
     constexpr int LPG = 2 * CPT;             // loads per group and producer thread: row piece + edge element per channel
     static_assert((PD - 1) * LPG <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];

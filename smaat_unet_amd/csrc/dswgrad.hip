@@ -107,7 +107,10 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
     static_assert(sizeof(TG) == 4 || NT == 1, "bf16 gradients are plain bf16 operands");
     constexpr int MT = 64, KT = 128, ROWS = MT + KT;
     constexpr int PLSZ = ROWS * DWG_SROW, BUFSZ = NT * PLSZ;
-    constexpr int PD = 4;        // load groups in flight per producer thread
+    // load groups (rows) in flight per producer thread.  bf16 storage halves the bytes per row AND the iteration time
+    // (one MFMA per product, no operand split), so four rows ahead are only ~9 MB in flight on the chip: measured latency-
+    // bound (2.2 TB/s); eight rows restore the f32 build's bytes in flight
+    constexpr int PD = sizeof(TX) == 2 ? 8 : 4;
     constexpr int LPG = 3;       // loads per group: x row = dwordx4 + one edge dword, dz = dwordx4
     static_assert((PD - 1) * LPG <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
