@@ -465,13 +465,21 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
 static void dsr_geom(DsRowsArgs& a) {
     a.P = a.H * a.W;
     a.strips = a.W / DSR_CW;
-    int rb = a.H;
-    for (int cand = 48; cand >= 16; cand -= 4)
-        if (a.H % cand == 0) {
+    // band length: every band costs two priming iterations, and a workgroup walks ceil(items / workgroups) items -- pick the
+    // divisor of H (12 .. 64 rows) that minimises the iterations of the busiest workgroup (288 rows at batch 32: 36-row
+    // bands = 9 items per workgroup exactly, 342 iterations; 48-row bands would leave 7 / 6 items, 350)
+    const int wgs = 256;
+    int rb = a.H > 64 ? 32 : a.H;
+    long best = -1;
+    for (int cand = 64; cand >= 12; --cand) {
+        if (a.H % cand) continue;
+        const long items = (long)a.N * (a.H / cand) * a.strips;
+        const long cost = ((items + wgs - 1) / wgs) * (cand + 2);
+        if (best < 0 || cost < best) {
+            best = cost;
             rb = cand;
-            break;
         }
-    if (rb > 64) rb = 32;
+    }
     a.RB = rb;
     a.bands = (a.H + rb - 1) / rb;
     a.items = a.N * a.bands * a.strips;
