@@ -178,7 +178,7 @@ def case_dsconv_wgrad_split(L, dev, N, Cin, Cout, H, W, aff=False, bias=True, pa
 
 @pytest.mark.parametrize("shape", [(2, 64, 64, 32, 32), (1, 40, 50, 8, 64), (2, 100, 64, 36, 96), (1, 8, 16, 70, 32),
                                    (3, 130, 33, 5, 32), (2, 12, 64, 288, 288), (1, 64, 64, 50, 160), (2, 32, 1, 1, 32),
-                                   (9, 4, 8, 2, 64)])
+                                   (9, 4, 8, 2, 64), (1, 8, 16, 67, 32)])  # (67: a prime height -> a short last band)
 def test_dsconv_wgrad_split(shape):
     both(case_dsconv_wgrad_split, *shape, tol=1e-5)
     both(case_dsconv_wgrad_split, *shape, aff=True, bias=False, pad_c=3, tol=1e-5)
@@ -445,6 +445,7 @@ ROWS_SHAPES = [
     (3, 72, 33, 9, 32),       # K = 144: the second channel of most producer threads is beyond Cin
     (2, 64, 64, 288, 288),    # the inc.1 / up4.1 geometry
     (9, 16, 1, 2, 64),        # more items than fit one workgroup each, a single output channel
+    (1, 8, 16, 67, 32),       # a prime height above 64: 32-row bands with a short last one (3 rows)
 ]
 
 
