@@ -26,10 +26,51 @@
 
 struct DwrGeom {
     int H, W, P, ncol4, nbands, BH, wpp;
+    int seg, ppw;  // plane packing (small planes): a wave holds ppw = 64 / seg planes, one per segment of seg lanes
 };
 
+static int dwr_pack_enabled() {  // SMAAT_DW_PACK=0: A/B timing of the plane packing
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("SMAAT_DW_PACK");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
+// the (image, channel, lane-in-plane index) of a lane.  PACK: the wave's ppw planes are the SAME channel of ppw consecutive
+// images (the channel, hence the weights and the BatchNorm coefficients, stay wave-uniform: SGPRs); lanes of images beyond
+// the batch walk the last image with every output masked.  Returns false when the whole wave has nothing to do.
+template <bool PACK>
+__device__ __forceinline__ bool dwr_place(const DwrGeom& g, int gw, int lane, int N, int Cin, int& n, int& ci, int& wip, int& t,
+                                          bool& lane_on) {
+    lane_on = true;
+    if constexpr (PACK) {
+        const int grp = gw / Cin;
+        if (grp * g.ppw >= N) return false;
+        ci = gw - grp * Cin;
+        const int pi = lane / g.seg;
+        t = lane - pi * g.seg;
+        wip = 0;
+        n = grp * g.ppw + pi;
+        if (n >= N) {
+            n = N - 1;
+            lane_on = false;
+        }
+    } else {
+        const int plane = gw / g.wpp;
+        wip = gw - plane * g.wpp;
+        if (plane >= N * Cin) return false;
+        n = plane / Cin;
+        ci = plane - n * Cin;
+        t = wip * 64 + lane;
+    }
+    return true;
+}
+
 // band / wave decomposition of a plane: maximise lane utilisation x (BH / (BH + 2)) x chip fill
-DwrGeom dw_rows_geom(long planes, int H, int W) {
+DwrGeom dw_rows_geom(int N, int Cin, int H, int W) {
+    const long planes = (long)N * Cin;
     DwrGeom g;
     g.H = H;
     g.W = W;
@@ -39,6 +80,8 @@ DwrGeom dw_rows_geom(long planes, int H, int W) {
     g.nbands = 1;
     g.BH = H;
     g.wpp = 0;
+    g.seg = 64;
+    g.ppw = 1;
     for (int nb = 1; nb <= H && (long)nb * g.ncol4 <= 64 * 64; ++nb) {
         const int bh = (H + nb - 1) / nb;
         if ((nb - 1) * bh >= H) continue;  // an empty trailing band: a smaller nb gives the same BH
@@ -57,10 +100,35 @@ DwrGeom dw_rows_geom(long planes, int H, int W) {
             g.wpp = wpp;
         }
     }
+    // Plane packing (round 4): a plane whose (band, column group) list fills at most half a wave -- the 18 x 18 planes of
+    // the bottleneck: 20 of 64 lanes, one short wave per plane, 0.8 TB/s -- shares the wave with the same channel's plane
+    // of the next image(s) (dwr_place).  A plane takes one DPP row (16 lanes) or two (32), so that the per-plane sums of
+    // the backward are the row / half-wave DPP sums.
+    for (int nb = 1; nb <= H && nb * g.ncol4 <= 32; ++nb) {
+        const int bh = (H + nb - 1) / nb;
+        if ((nb - 1) * bh >= H) continue;
+        if (bh < 4 && nb > 1) break;
+        const int T = g.ncol4 * nb;
+        const int seg = T <= 16 ? 16 : 32, ppw = 64 / seg;
+        const long waves = (long)((N + ppw - 1) / ppw) * Cin;
+        const double util = (double)T * (double)planes / (64.0 * (double)waves);
+        const double halo = (double)bh / (bh + 2.0);
+        double fill = (double)waves / 8192.0;
+        if (fill > 1.0) fill = 1.0;
+        const double score = util * halo * (0.25 + 0.75 * fill);
+        if (score > best && dwr_pack_enabled()) {
+            best = score;
+            g.nbands = nb;
+            g.BH = bh;
+            g.wpp = 1;
+            g.seg = seg;
+            g.ppw = ppw;
+        }
+    }
     return g;
 }
 
-int dw_rows_wpp(int N, int Cin, int H, int W) { return dw_rows_geom((long)N * Cin, H, W).wpp; }
+int dw_rows_wpp(int N, int Cin, int H, int W) { return dw_rows_geom(N, Cin, H, W).wpp; }
 
 __device__ __forceinline__ float dwr_act(float v, bool aff, float sc, float sh) {
     return aff ? fmaxf(fmaf(v, sc, sh), 0.f) : v;
@@ -165,7 +233,7 @@ __device__ __forceinline__ void dwr_finish(float (&w)[6], const DwrRaw<T>& vr, i
 // forward:  y[ci*KPL + j][r][c] = b[j] + sum_{tr,tc} w[j][tr][tc] * act(x)[ci][r + tr - 1][c + tc - 1]
 // ---------------------------------------------------------------------------------------------------------------
 // TX / TY: element types of x and y (f32 | bf16 storage; the arithmetic is f32 either way)
-template <int KPL, typename TX, typename TY, bool PART>
+template <int KPL, typename TX, typename TY, bool PART, bool PACK = false>
 __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const TX* __restrict__ x, long x_bs,
                                                          const float* __restrict__ w_dw,
                                                          const float* __restrict__ b_dw, TY* __restrict__ y,
@@ -174,12 +242,11 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const TX* __restrict__ x
                                                          const float* __restrict__ in_shift) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (tid >> 6));  // (plane, wave of the plane) list
-    const int plane = gw / g.wpp, wip = gw - plane * g.wpp;
-    if (plane >= nplanes) return;  // (whole wave)
-    const int n = plane / Cin, ci = plane - n * Cin;
-    const int t = wip * 64 + lane;
+    int n, ci, wip, t;
+    bool lane_on;
+    if (!dwr_place<PACK>(g, gw, lane, nplanes / Cin, Cin, n, ci, wip, t, lane_on)) return;  // (whole wave)
     const int band_ = t / g.ncol4, q = t - band_ * g.ncol4;
-    const bool active = band_ < g.nbands;  // surplus lanes of the last wave walk the last band again (stores masked)
+    const bool active = lane_on && band_ < g.nbands;  // surplus lanes walk the last band again (stores masked)
     const int band = active ? band_ : g.nbands - 1;
     const int r0 = band * g.BH;
     const TX* xp = x + (long)n * x_bs + (long)ci * g.P + 4 * q;
@@ -266,7 +333,8 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const TX* __restrict__ x
 // RP: the variant that also emits rpart keeps the raw (pre-BatchNorm) rows of the three open lines in registers: the
 // counter passes showed the re-load of the completed row as +25 % HBM fetch (it had left the L2 two steps later).
 // TX / TG / TD: element types of x (or z), dY and dX
-template <int KPL, bool RP, typename TX, typename TG, typename TD, bool PART>
+// PACK: plane packing (dw_rows_geom, dwr_place)
+template <int KPL, bool RP, typename TX, typename TG, typename TD, bool PART, bool PACK = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAVES, DWR_BWD_WAVES))) void k_dw3x3_bwd_rows(const TX* __restrict__ x, long x_bs,
                                                          const TG* __restrict__ dy, long dy_bs,
                                                          const float* __restrict__ w_dw, TD* __restrict__ dx,
@@ -278,13 +346,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAV
                                                          const float* __restrict__ in_shift) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (tid >> 6));  // (plane, wave of the plane) list
-    const int plane = gw / g.wpp, wip = gw - plane * g.wpp;
-    if (plane >= nplanes) return;  // (whole wave; no barrier below)
-    const bool pvalid = true;
-    const int n = plane / Cin, ci = plane - n * Cin;
-    const int t = wip * 64 + lane;
+    int n, ci, wip, t;
+    bool lane_on;
+    if (!dwr_place<PACK>(g, gw, lane, N, Cin, n, ci, wip, t, lane_on)) return;  // (whole wave; no barrier below)
     const int band_ = t / g.ncol4, q = t - band_ * g.ncol4;
-    const bool active = pvalid && band_ < g.nbands;  // the other lanes walk a valid band with every output masked
+    const bool active = lane_on && band_ < g.nbands;  // the other lanes walk a valid band with every output masked
     const int band = band_ < g.nbands ? band_ : g.nbands - 1;
     const int r0 = band * g.BH;
     const TX* xp = x + (long)n * x_bs + (long)ci * g.P + 4 * q;
@@ -412,19 +478,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DWR_BWD_WAV
             }
         }
     }
-    // wave sums -> one partial row per (image, wave of the plane)
+    // wave sums -> one partial row per (image, wave of the plane).  PACK: one sum per plane = per segment of the wave (a DPP
+    // row or a half-wave; masked lanes hold zeros), written by the segment's last lane.
     const long row = (long)n * g.wpp + wip;
+    const bool seg16 = PACK && g.seg == 16;
+    auto psum = [&](float v) { return !PACK ? wave_sum_l63(v) : (seg16 ? row16_sum(v) : half32_sum_hi(v)); };
+    const bool writer = !PACK ? lane == 63 : (lane_on && (lane & (g.seg - 1)) == g.seg - 1);
 #pragma unroll
     for (int j = 0; j < KPL; ++j)
 #pragma unroll
         for (int k = 0; k < 10; ++k) {
-            const float v = wave_sum_l63(accw[j][k]);
-            if (lane == 63) part[(row * Cin * KPL + ci * KPL + j) * 10 + k] = v;
+            const float v = psum(accw[j][k]);
+            if (writer) part[(row * Cin * KPL + ci * KPL + j) * 10 + k] = v;
         }
     if (RP) {
-        const float v1 = wave_sum_l63(r1s), v2 = wave_sum_l63(r2s);
+        const float v1 = psum(r1s), v2 = psum(r2s);
         const long rows = (long)N * g.wpp;
-        if (lane == 63) {
+        if (writer) {
             rpart[row * Cin + ci] = v1;
             rpart[(rows + row) * Cin + ci] = v2;
         }
@@ -452,17 +522,22 @@ int launch_dw3x3_fwd_rows(const void* x, int x_dt, long x_bs, const float* w_dw,
                           long y_bs, int N, int Cin, int kpl, int H, int W, hipStream_t st, const float* in_scale,
                           const float* in_shift) {
     const int nplanes = N * Cin;
-    const DwrGeom g = dw_rows_geom(nplanes, H, W);
+    const DwrGeom g = dw_rows_geom(N, Cin, H, W);
     if (g.wpp == 0) return -2;
-    const dim3 grid((unsigned)(((long)nplanes * g.wpp + 3) / 4)), blk(256);
+    const bool pack = g.ppw > 1;
+    const long nwaves = pack ? (long)((N + g.ppw - 1) / g.ppw) * Cin : (long)nplanes * g.wpp;
+    const dim3 grid((unsigned)((nwaves + 3) / 4)), blk(256);
     const bool part = (W & 3) != 0;
-#define DWF_GO1(K, TX, TY, PT)                                                                                            \
-    hipLaunchKernelGGL((k_dw3x3_fwd_rows<K, TX, TY, PT>), grid, blk, 0, st, (const TX*)x, x_bs, w_dw, b_dw, (TY*)y, y_bs,   \
+#define DWF_GO1(K, TX, TY, PT, PK)                                                                                          \
+    hipLaunchKernelGGL((k_dw3x3_fwd_rows<K, TX, TY, PT, PK>), grid, blk, 0, st, (const TX*)x, x_bs, w_dw, b_dw, (TY*)y, y_bs, \
                        Cin, nplanes, g, in_scale, in_shift)
-#define DWF_GO(K, TX, TY)                  \
-    do {                                   \
-        if (part) DWF_GO1(K, TX, TY, true); \
-        else DWF_GO1(K, TX, TY, false);    \
+#define DWF_GO(K, TX, TY)                                   \
+    do {                                                    \
+        if (pack) {                                         \
+            if (part) DWF_GO1(K, TX, TY, true, true);       \
+            else DWF_GO1(K, TX, TY, false, true);           \
+        } else if (part) DWF_GO1(K, TX, TY, true, false);   \
+        else DWF_GO1(K, TX, TY, false, false);              \
     } while (0)
 #define DWF_K(TX, TY)                        \
     do {                                     \
@@ -485,18 +560,23 @@ int launch_dw3x3_bwd_rows(const void* x, int x_dt, long x_bs, const void* dy, in
                           hipStream_t st, const float* bn_mean, const float* bn_invstd, float* rpart,
                           const float* in_scale, const float* in_shift) {
     const int nplanes = N * Cin;
-    const DwrGeom g = dw_rows_geom(nplanes, H, W);
+    const DwrGeom g = dw_rows_geom(N, Cin, H, W);
     if (g.wpp == 0) return -2;
     if (kpl != 1 && kpl != 2) return -2;
-    const dim3 grid((unsigned)(((long)nplanes * g.wpp + 3) / 4)), blk(256);
+    const bool pack = g.ppw > 1;
+    const long nwaves = pack ? (long)((N + g.ppw - 1) / g.ppw) * Cin : (long)nplanes * g.wpp;
+    const dim3 grid((unsigned)((nwaves + 3) / 4)), blk(256);
     const bool pgrp = (W & 3) != 0;
-#define DWR_GO1(K, R, TX, TG, TD, PT)                                                                                      \
-    hipLaunchKernelGGL((k_dw3x3_bwd_rows<K, R, TX, TG, TD, PT>), grid, blk, 0, st, (const TX*)x, x_bs, (const TG*)dy, dy_bs, \
+#define DWR_GO1(K, R, TX, TG, TD, PT, PK)                                                                                      \
+    hipLaunchKernelGGL((k_dw3x3_bwd_rows<K, R, TX, TG, TD, PT, PK>), grid, blk, 0, st, (const TX*)x, x_bs, (const TG*)dy, dy_bs, \
                        w_dw, (TD*)dx, dx_bs, part, Cin, nplanes, N, g, bn_mean, bn_invstd, rpart, in_scale, in_shift)
-#define DWR_GO(K, R, TX, TG, TD)                     \
-    do {                                             \
-        if (pgrp) DWR_GO1(K, R, TX, TG, TD, true);   \
-        else DWR_GO1(K, R, TX, TG, TD, false);       \
+#define DWR_GO(K, R, TX, TG, TD)                                  \
+    do {                                                          \
+        if (pack) {                                               \
+            if (pgrp) DWR_GO1(K, R, TX, TG, TD, true, true);      \
+            else DWR_GO1(K, R, TX, TG, TD, false, true);          \
+        } else if (pgrp) DWR_GO1(K, R, TX, TG, TD, true, false);  \
+        else DWR_GO1(K, R, TX, TG, TD, false, false);             \
     } while (0)
 #define DWR_K(TX, TG, TD)                                                  \
     do {                                                                   \

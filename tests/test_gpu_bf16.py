@@ -178,7 +178,8 @@ def test_pointwise_wgrad_bf16(shape):
 # ------------------------------------------------------------------------------------------------------------------
 # typed streaming kernels against their f32 twins
 # ------------------------------------------------------------------------------------------------------------------
-DW_SHAPES = [(2, 6, 2, 16, 24), (2, 5, 1, 12, 16), (1, 3, 4, 8, 8), (3, 8, 2, 18, 18), (2, 4, 2, 36, 36), (1, 4, 2, 288, 288)]
+DW_SHAPES = [(2, 6, 2, 16, 24), (2, 5, 1, 12, 16), (1, 3, 4, 8, 8), (3, 8, 2, 18, 18), (2, 4, 2, 36, 36), (1, 4, 2, 288, 288),
+             (5, 6, 2, 18, 18)]  # (plane packing with a partial image group)
 
 
 @pytest.mark.parametrize("shape", DW_SHAPES)
@@ -241,7 +242,7 @@ def test_dw3x3_bwd_t(shape, combo):
     assert torch.equal(dw1, dw0) and torch.equal(db1, db0)
 
 
-@pytest.mark.parametrize("shape", [(2, 6, 2, 16, 24), (2, 4, 2, 36, 36), (1, 4, 1, 72, 72)])
+@pytest.mark.parametrize("shape", [(2, 6, 2, 16, 24), (2, 4, 2, 36, 36), (1, 4, 1, 72, 72), (3, 8, 2, 18, 18)])
 def test_dw3x3_bwd_t_bnred(shape):
     """the fused BatchNorm reduction of the second half (x = pre-BatchNorm tensor, activation on load)"""
     L = _lib.get()

@@ -279,7 +279,10 @@ def case_dw_bwd(L, dev, N, Cin, kpl, H, W, need_dx=True):
                                    (1, 5, 2, 10, 12), (1, 2, 2, 50, 64), (1, 2, 1, 21, 48),
                                    # row-streaming kernels: 4 / 6 / 40 float4 columns, planes over several waves and blocks
                                    (3, 64, 2, 16, 16), (2, 96, 2, 32, 24), (1, 3, 2, 64, 160), (3, 130, 1, 16, 12),
-                                   (1, 2, 2, 1, 8), (1, 3, 2, 3, 4), (2, 3, 1, 2, 12)])
+                                   (1, 2, 2, 1, 8), (1, 3, 2, 3, 4), (2, 3, 1, 2, 12),
+                                   # plane packing (several images' planes of one channel per wave): full and partial image
+                                   # groups, the two-column last group of the 18 x 18 bottleneck planes, one DPP row per plane
+                                   (3, 20, 2, 18, 18), (5, 7, 1, 18, 18), (8, 16, 2, 18, 18), (7, 9, 2, 12, 8), (6, 4, 2, 8, 20)])
 def test_dw3x3_bwd(shape):
     both(case_dw_bwd, *shape, tol=2e-5)
     both(case_dw_bwd, *shape, need_dx=False, tol=2e-5)
@@ -504,7 +507,8 @@ def case_dw_fwd(L, dev, N, Cin, kpl, H, W, bias=True, pad_c=0, aff=False):
                                    (2, 4, 2, 72, 72), (1, 5, 2, 10, 12), (1, 2, 2, 50, 64), (1, 2, 1, 21, 48),
                                    (1, 2, 2, 3, 4), (1, 2, 2, 1, 8), (3, 64, 2, 16, 16), (2, 96, 2, 32, 24), (1, 3, 2, 64, 160),
                                    # rows that are not 16-byte aligned: the flat-copy small-plane kernel
-                                   (2, 20, 2, 18, 18), (3, 5, 1, 9, 11), (1, 3, 4, 7, 5), (2, 37, 2, 6, 6), (1, 2, 2, 39, 41)])
+                                   (2, 20, 2, 18, 18), (3, 5, 1, 9, 11), (1, 3, 4, 7, 5), (2, 37, 2, 6, 6), (1, 2, 2, 39, 41),
+                                   (5, 7, 4, 18, 18), (8, 16, 2, 18, 18), (7, 9, 2, 12, 8)])  # (plane packing)
 def test_dw3x3_fwd(shape):
     both(case_dw_fwd, *shape)
     both(case_dw_fwd, *shape, bias=False, pad_c=4)
@@ -546,7 +550,8 @@ def case_dw_bwd_bnred(L, dev, N, Cin, kpl, H, W, gamma_mode="normal"):
 
 @pytest.mark.parametrize("shape", [(2, 12, 2, 32, 32), (2, 5, 1, 8, 8), (2, 8, 2, 36, 36), (2, 4, 2, 144, 144),
                                    (2, 3, 2, 288, 288), (1, 4, 2, 100, 100), (1, 3, 4, 8, 12), (1, 5, 2, 10, 12),
-                                   (3, 64, 2, 16, 16), (2, 96, 2, 32, 24), (1, 3, 2, 64, 160)])
+                                   (3, 64, 2, 16, 16), (2, 96, 2, 32, 24), (1, 3, 2, 64, 160),
+                                   (3, 20, 2, 18, 18), (8, 16, 2, 18, 18), (7, 9, 2, 12, 8)])  # (plane packing)
 def test_dw3x3_bwd_bnred(shape):
     both(case_dw_bwd_bnred, *shape, tol=2e-5)
 
