@@ -41,7 +41,7 @@ def main():
     rows = []
     tot = dict(fwd=0.0, dgrad=0.0, wgrad=0.0, dwb=0.0)
     for name, cin, cout, h in LAYERS:
-        if only and only not in name:
+        if only and not any(o in name for o in only.split(",")):
             continue
         w = h
         k = cin * 2

@@ -45,7 +45,7 @@ def main():
     print(f"batch {N}: ms (algorithmic GB/s)")
     print(f"{'layer':9s} {'dw fwd':>14s} {'gemm fwd':>14s} {'dgrad':>14s} {'wgrad':>14s} {'dw bwd':>14s}")
     for name, cin, cout, h in LAYERS:
-        if only and only not in name:
+        if only and not any(o in name for o in only.split(",")):
             continue
         w = h
         k = cin * 2

@@ -7,37 +7,10 @@
 
 
 int launch_wgrad2(Wg2Args& a, hipStream_t st);
-struct DsRowsArgs {  // dsrows.hip
-    const void* x;
-    long x_bs;
-    const float* in_scale;
-    const float* in_shift;
-    const float* w_dw;
-    const float* b_dw;
-    const unsigned short* planes;
-    const float* bias;
-    void* out;
-    long out_bs;
-    float* part;
-    int N, Cin, K, M, H, W, P;
-    int nsplit, strips, bands, RB, items, ips, npl;
-};
+#include "rows_args.h"  // DsRowsArgs (dsrows.hip), DsWgArgs (dswgrad.hip)
 int dsconv_rows_ok(int kpl, int Cin, int M, int H, int W);
 int dsconv_rows_num_slots(int N, int H, int W);
 int launch_dsconv_rows(DsRowsArgs& a, int kpl, int x_dt, int z_dt, hipStream_t st);
-struct DsWgArgs {  // dswgrad.hip
-    const void* x;
-    long x_bs;
-    const float* in_scale;
-    const float* in_shift;
-    const float* w_dw;
-    const float* b_dw;
-    const void* dz;
-    long dz_bs;
-    float* part;
-    int N, Cin, K, M, H, W, P;
-    int nkt, nsplit, strips, bands, RB, items, ips;
-};
 int dsconv_wgrad_split_ok(int kpl, int M, int H, int W);
 int dsconv_wgrad_split_num_splits(int N, int Cin, int M, int H, int W);
 int launch_dsconv_wgrad_split(DsWgArgs& a, int kpl, int x_dt, int dz_dt, hipStream_t st);

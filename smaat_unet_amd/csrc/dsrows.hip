@@ -31,21 +31,7 @@ int split_mode();  // splitmma.hip
 
 #define DSR_CW 32  // pixels per row segment = width of a column strip
 
-struct DsRowsArgs {
-    const void* x;
-    long x_bs;
-    const float* in_scale;
-    const float* in_shift;
-    const float* w_dw;             // [K][9]
-    const float* b_dw;             // [K] or null
-    const unsigned short* planes;  // pointwise weight images, chunk-major [K/16][NPL][M][16] (NPL = 3 split planes | 1)
-    const float* bias;             // [M] or null
-    void* out;
-    long out_bs;
-    float* part;  // [3][items][M] or null
-    int N, Cin, K, M, H, W, P;
-    int nsplit, strips, bands, RB, items, ips, npl;
-};
+#include "rows_args.h"
 
 __device__ __forceinline__ unsigned dsr_fbits(float x) { return __builtin_bit_cast(unsigned, x); }
 __device__ __forceinline__ float dsr_bitsf(unsigned x) { return __builtin_bit_cast(float, x); }
@@ -110,10 +96,26 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
 
     const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
     const int split = xcd * (a.nsplit >> 3) + idx;  // contiguous item ranges per XCD (neighbouring strips share an L2)
-    const int it_lo = split * a.ips;
-    int it_hi = it_lo + a.ips;
-    if (it_hi > a.items) it_hi = a.items;
-    const int nitems = it_hi > it_lo ? it_hi - it_lo : 0;
+    // item j of this workgroup = it_lo + j * it_st (j < nitems): contiguous ranges, or (ilv, the default) the items of the XCD's
+    // range dealt round-robin to its workgroups -- neighbouring strips then run at the same time on one XCD, so the halves of a
+    // bf16 line / the neighbouring lines of a DRAM page are touched together (dswgrad.hip, measured there)
+    const int s8 = a.nsplit >> 3;
+    int it_lo, it_st, nitems;
+    if (a.ilv) {
+        const int xlo = xcd * s8 * a.ips;
+        int xhi = xlo + s8 * a.ips;
+        if (xhi > a.items) xhi = a.items;
+        it_lo = xlo + idx;
+        it_st = s8;
+        nitems = it_lo < xhi ? (xhi - it_lo + s8 - 1) / s8 : 0;
+    } else {
+        it_lo = split * a.ips;
+        it_st = 1;
+        int hi = it_lo + a.ips;
+        if (hi > a.items) hi = a.items;
+        nitems = hi > it_lo ? hi - it_lo : 0;
+    }
+    const int it_hi = it_lo + nitems * it_st;  // (exclusive bound of the walk)
     const int bps = a.bands * a.strips;
     auto item_rows = [&](int item) {
         const int band = (item % bps) / a.strips;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
         return (a.H - r0 < a.RB ? a.H - r0 : a.RB);
     };
     int total = 0;
-    for (int i = 0; i < nitems; ++i) total += item_rows(it_lo + i) + 2;  // rows + 2 priming iterations per item
+    for (int i = 0; i < nitems; ++i) total += item_rows(it_lo + i * it_st) + 2;  // rows + 2 priming iterations per item
 
     if (producer) {
         const int ptid = tid - 256;
@@ -146,15 +148,27 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
             vo_x[u] = (unsigned)(cgc[u] * a.P + 4 * g) * (unsigned)sizeof(TX);
             vo_e[u] = vo_x[u];
         }
+        // (complete the compiler-visible loads before the first inline-asm load: a load still pending at the loop entry makes
+        // hipcc drain vmcnt to 0 at the value's first use inside the loop, every iteration -- see dswgrad.hip)
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) asm volatile("" : "+v"(wt[u][j][k]));
+                asm volatile("" : "+v"(bs[u][j]));
+            }
+            asm volatile("" : "+v"(asc[u]), "+v"(ash[u]));
+        }
         // issue cursor (wave-uniform)
-        int w_item = it_lo - 1, w_j = 0, w_len = 0, w_r0 = 0, w_eback = 0;
+        int w_item = it_lo - it_st, w_j = 0, w_len = 0, w_r0 = 0, w_eback = 0;
         const TX* w_xb = (const TX*)a.x;
         bool w_lok = false, w_rok = false;
         auto advance = [&]() __attribute__((always_inline)) {
             ++w_j;
             if (w_j >= w_len) {
-                if (w_item + 1 < it_hi) {
-                    ++w_item;
+                if (w_item + it_st < it_hi) {
+                    w_item += it_st;
                     w_j = 0;
                     const int n = w_item / bps, rem = w_item - n * bps;
                     const int band = rem / a.strips, st_ = rem - band * a.strips;
@@ -211,13 +225,13 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int c = 0; c < 6; ++c) win[u][r][c] = 0.f;
-        int c_j = 0, c_len = 0, c_item = it_lo - 1;
+        int c_j = 0, c_len = 0, c_item = it_lo - it_st;
         // B image address of this thread: pixel 4g + i, dword (ci + 64 u) ^ 8 (g >> 2)  (swizzle: conflict-free writes)
         const int bsw = (g >> 2) << 3;
         auto commit = [&](int set, int buf) __attribute__((always_inline)) {
             ++c_j;
             if (c_j >= c_len) {
-                ++c_item;
+                c_item += it_st;
                 c_j = 0;
                 c_len = item_rows(c_item) + 2;
             }
@@ -353,7 +367,7 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
         float s1[8], s2[8], sh[8];
         int nrows = 0;            // rows accumulated into the statistics of the open item
         // consume cursor + the chunk whose result is pending (finished one iteration later)
-        int c_item = it_lo - 1, c_j = 0, c_len = 0;
+        int c_item = it_lo - it_st, c_j = 0, c_len = 0;
         bool pend = false;
         int p_item = 0, p_row = 0, p_buf = 0;
         const int swz = ((l31 >> 4) & 1) << 5;  // byte XOR of the B image's k index for pixels 16 .. 31 (8 dwords)
@@ -411,7 +425,7 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
             ++c_j;
             bool newitem = false;
             if (c_j >= c_len) {
-                ++c_item;
+                c_item += it_st;
                 c_j = 0;
                 c_len = item_rows(c_item) + 2;
                 newitem = true;
@@ -420,7 +434,7 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
                 finish();
                 pend = false;
             }
-            if (newitem && c_item > it_lo) flush_stats(c_item - 1);  // (its last chunk was finished just above)
+            if (newitem && c_item > it_lo) flush_stats(c_item - it_st);  // (its last chunk was finished just above)
             if (c_j >= 2) {
                 const unsigned char* base = lds + (t & 1) * BUFSZ + l31 * ROWB;
 #pragma unroll
@@ -457,7 +471,7 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
             __syncthreads();
         }
         if (pend) finish();
-        if (nitems > 0) flush_stats(it_hi - 1);
+        if (nitems > 0) flush_stats(it_hi - it_st);
     }
 }
 
@@ -532,6 +546,14 @@ int launch_dsconv_rows(DsRowsArgs& a, int kpl, int x_dt, int z_dt, hipStream_t s
     if ((a.x_bs & 3) || ((((uintptr_t)a.x) * 1) & (4 * xe - 1)) || (((uintptr_t)a.planes) & 15)) return -2;
     if ((long)a.Cin * a.H * a.W * xe >= (1L << 32)) return -2;
     dsr_geom(a);
+    {
+        static int ilv = -1;  // SMAAT_ROWS_ILV=0: contiguous item ranges (A/B timing)
+        if (ilv < 0) {
+            const char* e = getenv("SMAAT_ROWS_ILV");
+            ilv = e ? atoi(e) : 1;
+        }
+        a.ilv = ilv;
+    }
     if (z_dt == SMAAT_BF16) {  // mixed precision: bf16 z, bf16 operands; x f32 (the stem) or bf16
         a.npl = 1;
         static int pk = -1;

@@ -30,22 +30,17 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned dwg_u32x4 __attribute__((ext_vector_type(4)));
 int split_mode();  // splitmma.hip
 
+// timing ablations for experiment builds (make EXTRA=-DDWG_DBG=<bits> OUT=...; the results are wrong, only the time means
+// something): 1 no LDS reads + MFMA, 2 no LDS writes, 4 no depthwise math, 8 no global loads, 16 no per-chunk barrier.
+// Compile-time on purpose: the same switches as run-time flags changed the code of the normal path (hipcc drained the
+// loads in flight with vmcnt(0) at the head of the branch targets).
+#ifndef DWG_DBG
+#define DWG_DBG 0
+#endif
 #define DWG_SROW 80  // bytes per LDS row: 32 bf16 + 16 B pad (conflict-free ds_read_b128, as k_wgrad_split)
 #define DWG_CW 32    // pixels per chunk = width of a column strip
 
-struct DsWgArgs {
-    const void* x;   // TX
-    long x_bs;
-    const float* in_scale;
-    const float* in_shift;
-    const float* w_dw;  // [K][9]
-    const float* b_dw;  // [K] or null
-    const void* dz;  // TG
-    long dz_bs;
-    float* part;  // [nsplit][M][K]
-    int N, Cin, K, M, H, W, P;
-    int nkt, nsplit, strips, bands, RB, items, ips;
-};
+#include "rows_args.h"
 
 __device__ __forceinline__ unsigned dwg_fbits(float x) { return __builtin_bit_cast(unsigned, x); }
 __device__ __forceinline__ float dwg_bitsf(unsigned x) { return __builtin_bit_cast(float, x); }
@@ -102,15 +97,18 @@ __device__ __forceinline__ void dwg_vals(const dwg_u32x2 v, float (&m)[4]) {
 
 // TX / TG: storage types of x and dz (float | bf16).  bf16 dz (mixed precision, NT = 1) is the MFMA operand as it lies in
 // memory: its pieces go to the A image unconverted.
-template <int NT, bool AFF, bool PK, typename TX, typename TG>
-__global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
+// W2: TWO workgroups per CU (bf16 storage: 30 KB of LDS each).  The two barrier domains are independent: while the 12 waves of
+// one workgroup meet at their per-chunk barrier the other workgroup's producers keep the VALU busy.  Needs <= 80 VGPRs (six
+// waves per SIMD): four rows of loads in flight per thread instead of eight (the same bytes in flight per CU).
+template <int NT, bool AFF, bool PK, typename TX, typename TG, bool W2 = false>
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(W2 ? 6 : 3, W2 ? 6 : 8))) void k_dsconv_wgrad_split(const DsWgArgs a) {
     static_assert(sizeof(TG) == 4 || NT == 1, "bf16 gradients are plain bf16 operands");
     constexpr int MT = 64, KT = 128, ROWS = MT + KT;
     constexpr int PLSZ = ROWS * DWG_SROW, BUFSZ = NT * PLSZ;
     // load groups (rows) in flight per producer thread.  bf16 storage halves the bytes per row AND the iteration time
     // (one MFMA per product, no operand split), so four rows ahead are only ~9 MB in flight on the chip: measured latency-
     // bound (2.2 TB/s); eight rows restore the f32 build's bytes in flight
-    constexpr int PD = sizeof(TX) == 2 ? 8 : 4;
+    constexpr int PD = (sizeof(TX) == 2 && !W2) ? 8 : 4;
     constexpr int LPG = 3;       // loads per group: x row = dwordx4 + one edge dword, dz = dwordx4
     static_assert((PD - 1) * LPG <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -124,10 +122,27 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
     const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
     const int kt = idx % a.nkt;
     const int split = xcd * (a.nsplit >> 3) + idx / a.nkt;  // contiguous split ranges per XCD (halo columns meet in one L2)
-    const int it_lo = split * a.ips;
-    int it_hi = it_lo + a.ips;
-    if (it_hi > a.items) it_hi = a.items;
-    const int nitems = it_hi > it_lo ? it_hi - it_lo : 0;
+    // item j of this workgroup = it_lo + j * it_st (j < nitems).  Contiguous ranges (it_st = 1), or -- ilv -- the items of the
+    // XCD's range dealt round-robin to its workgroups: the strips of a band then run AT THE SAME TIME on neighbouring
+    // workgroups of one XCD, so the two 64-byte halves of a bf16 line (and neighbouring lines of a DRAM page) are requested
+    // together instead of one band walk (~40 us) apart.
+    const int s8 = a.nsplit >> 3;
+    int it_lo, it_st, nitems;
+    if (a.ilv) {
+        const int xlo = xcd * s8 * a.ips;
+        int xhi = xlo + s8 * a.ips;
+        if (xhi > a.items) xhi = a.items;
+        it_lo = xlo + idx / a.nkt;
+        it_st = s8;
+        nitems = it_lo < xhi ? (xhi - it_lo + s8 - 1) / s8 : 0;
+    } else {
+        it_lo = split * a.ips;
+        it_st = 1;
+        int it_hi = it_lo + a.ips;
+        if (it_hi > a.items) it_hi = a.items;
+        nitems = it_hi > it_lo ? it_hi - it_lo : 0;
+    }
+    const int it_hi = it_lo + nitems * it_st;  // (exclusive bound of the walk)
     // flattened iteration space: every item contributes (rows of its band) + 2 priming iterations
     const int bps = a.bands * a.strips;  // items per image
     auto item_rows = [&](int item) {
@@ -136,7 +151,7 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
         return (a.H - r0 < a.RB ? a.H - r0 : a.RB);
     };
     int total = 0;
-    for (int i = 0; i < nitems; ++i) total += item_rows(it_lo + i) + 2;  // (wave-uniform scalar loop, <= a few dozen items)
+    for (int i = 0; i < nitems; ++i) total += item_rows(it_lo + i * it_st) + 2;  // (wave-uniform scalar loop, <= a few dozen items)
 
     if (producer) {
         // 8 producer waves (two per SIMD: one's VALU chain covers the other's waits).  Thread (ci, g): channel ci of the
@@ -156,7 +171,18 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
             for (int k = 0; k < 9; ++k) wt[j][k] = cv ? a.w_dw[(cgc * 2 + j) * 9 + k] : 0.f;
             bs[j] = (cv && a.b_dw) ? a.b_dw[cgc * 2 + j] : 0.f;  // channels beyond Cin: zero window, zero taps -> y = 0
         }
-        const float asc = AFF ? a.in_scale[cgc] : 1.f, ash = AFF ? a.in_shift[cgc] : 0.f;
+        float asc = AFF ? a.in_scale[cgc] : 1.f, ash = AFF ? a.in_shift[cgc] : 0.f;
+        // hipcc does not see the inline-asm loads below.  A compiler-visible load that is still pending at the loop entry makes it
+        // drain the vector-memory counter (s_waitcnt vmcnt(0)) at the value's first use INSIDE the loop -- once per iteration,
+        // which empties the prefetch queue every chunk (found in round 4 with the ablation builds: all but two instantiations
+        // did this).  Using the values here completes those loads once, before the first asm load is issued.
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) asm volatile("" : "+v"(wt[j][k]));
+            asm volatile("" : "+v"(bs[j]));
+        }
+        asm volatile("" : "+v"(asc), "+v"(ash));
         // dz share: 64 rows x 8 float4 columns = 512 pieces, one per thread; within a group of 8 rows the row order is
         // 0,4,1,5,2,6,3,7 (k_wgrad_split: the rows a 16-lane group writes with one ds_write_b64 tile the banks)
         const int q = ptid & 7, g8 = ptid >> 3;
@@ -167,7 +193,7 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
         const unsigned vo_z = (unsigned)((zv ? zrow : 0) * a.P + 4 * q) * (unsigned)sizeof(TG);
         unsigned vo_e = vo_x;  // edge load: set per item (strip position decides whether the neighbour column exists)
         // ---- issue cursor (wave-uniform: SGPRs) ----
-        int w_item = it_lo - 1, w_j = 0, w_len = 0;
+        int w_item = it_lo - it_st, w_j = 0, w_len = 0;
         int w_r0 = 0;
         const TX* w_xb = (const TX*)a.x;   // x + n * x_bs + c0           (row 0 of the strip, channel 0)
         const TG* w_zb = (const TG*)a.dz;  // dz + n * dz_bs + c0
@@ -176,8 +202,8 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
         auto advance = [&]() __attribute__((always_inline)) {
             ++w_j;
             if (w_j >= w_len) {
-                if (w_item + 1 < it_hi) {
-                    ++w_item;
+                if (w_item + it_st < it_hi) {
+                    w_item += it_st;
                     w_j = 0;
                     const int n = w_item / bps, rem = w_item - n * bps;
                     const int band = rem / a.strips, st_ = rem - band * a.strips;
@@ -205,6 +231,12 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
         bool slok[PD], srok[PD];
         auto issue = [&](int set) __attribute__((always_inline)) {
             advance();
+            if constexpr ((DWG_DBG & 8) != 0) {
+                srow[set] = w_r0 - 1 + w_j;
+                slok[set] = w_lok;
+                srok[set] = w_rok;
+                return;
+            }
             const int xr = w_r0 - 1 + w_j;  // x row delivered by this iteration
             const int xrc = xr < 0 ? 0 : (xr >= a.H ? a.H - 1 : xr);
             const TX* xrow = (const TX*)dwg_uniform_ptr(w_xb + (long)xrc * a.W);
@@ -231,7 +263,7 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
                 asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(sz[set]) : "v"(vo_z), "s"(zrowp));
         };
         auto wait_set = [&](int set) __attribute__((always_inline)) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * LPG) : "memory");
+            if constexpr ((DWG_DBG & 8) == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * LPG) : "memory");
             asm volatile("" : "+v"(sx[set]), "+v"(se[set]), "+v"(sz[set]));
         };
         float win[3][6];  // act(x) rows r - 1, r, r + 1 of the chunk being formed; cols 4g - 1 .. 4g + 4
@@ -239,11 +271,11 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < 6; ++c) win[r][c] = 0.f;
-        int c_j = 0, c_len = 0, c_item = it_lo - 1;  // consume cursor
+        int c_j = 0, c_len = 0, c_item = it_lo - it_st;  // consume cursor
         auto commit = [&](int set, int buf) __attribute__((always_inline)) {
             ++c_j;
             if (c_j >= c_len) {
-                ++c_item;
+                c_item += it_st;
                 c_j = 0;
                 c_len = item_rows(c_item) + 2;
             }
@@ -275,7 +307,12 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
             unsigned char* base = lds + buf * BUFSZ;
             // y rows k = 2 ci + j of the chunk: tap order of k_dw3x3_fwd_rows (bias, then row-major taps): bit-identical y
             float yy[2][4];
-            if (PK) {
+            if constexpr ((DWG_DBG & 4) != 0) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) yy[j][c] = win[1][1 + c] + bs[j];
+            } else if (PK) {
                 // both k-rows of the channel share the window value: one v_pk_fma_f32 forms {y[0][c], y[1][c]} (the same
                 // fma per component, same tap order: bit-identical to the scalar form)
 #pragma unroll
@@ -304,6 +341,10 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
                             for (int tc = 0; tc < 3; ++tc) acc = fmaf(wt[j][tr * 3 + tc], win[tr][c + tc], acc);
                         yy[j][c] = acc;  // (channels beyond Cin in the last K tile: zero taps and bias -> zero rows)
                     }
+            }
+            if constexpr ((DWG_DBG & 2) != 0) {  // (keep the values alive)
+                asm volatile("" ::"v"(yy[0][0]), "v"(yy[0][1]), "v"(yy[0][2]), "v"(yy[0][3]), "v"(yy[1][0]), "v"(yy[1][1]), "v"(yy[1][2]), "v"(yy[1][3]));
+                return;
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -340,7 +381,7 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
                         commit((u + 1) % PD, (t + 1) & 1);
                         issue((u + 1) % PD);
                     }
-                    __syncthreads();
+                    if constexpr ((DWG_DBG & 16) == 0) __syncthreads();
                 }
             }
         }
@@ -352,16 +393,16 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         // which flattened iterations carry a chunk: the same walk, scalar
-        int c_item = it_lo - 1, c_j = 0, c_len = 0;
+        int c_item = it_lo - it_st, c_j = 0, c_len = 0;
         __syncthreads();
         for (int t = 0; t < total; ++t) {
             ++c_j;
             if (c_j >= c_len) {
-                ++c_item;
+                c_item += it_st;
                 c_j = 0;
                 c_len = item_rows(c_item) + 2;
             }
-            if (c_j >= 2) {
+            if (c_j >= 2 && (DWG_DBG & 1) == 0) {
                 const unsigned char* base = lds + (t & 1) * BUFSZ;
                 const unsigned char* ap = base + (wm * 32 + l31) * DWG_SROW + half * 16;
                 const unsigned char* bp = base + (MT + (wk * 2) * 32 + l31) * DWG_SROW + half * 16;
@@ -387,7 +428,7 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
                     }
                 }
             }
-            __syncthreads();
+            if constexpr ((DWG_DBG & 16) == 0) __syncthreads();
         }
         float* ob = a.part + (long)split * a.M * a.K;
 #pragma unroll
@@ -405,14 +446,24 @@ __global__ __launch_bounds__(768) void k_dsconv_wgrad_split(const DsWgArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+static int dswg_w2() {  // SMAAT_DWG_W2=1: two workgroups per CU for the bf16-storage instantiations (experiment)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("SMAAT_DWG_W2");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v;
+}
+
 static void dswg_geom(DsWgArgs& a) {
+    const int slots = dswg_w2() ? 512 : 256;
     a.P = a.H * a.W;
     a.strips = a.W / DWG_CW;
     a.nkt = (a.K + 127) / 128;
     // band length: every band costs two priming iterations, and a workgroup walks ceil(items / workgroups) items -- pick the
     // divisor of H (12 .. 64 rows) that minimises the iterations of the busiest workgroup (288 rows at batch 32: 36-row
     // bands = 9 items per workgroup exactly, 342 iterations; 48-row bands would leave 7 / 6 items, 350)
-    const int wgs = (256 / a.nkt) & ~7 ? (256 / a.nkt) & ~7 : 8;
+    const int wgs = (slots / a.nkt) & ~7 ? (slots / a.nkt) & ~7 : 8;
     int rb = a.H > 64 ? 32 : a.H;
     long best = -1;
     for (int cand = 64; cand >= 12; --cand) {
@@ -427,7 +478,7 @@ static void dswg_geom(DsWgArgs& a) {
     a.RB = rb;
     a.bands = (a.H + rb - 1) / rb;
     a.items = a.N * a.bands * a.strips;
-    int ns = (256 / a.nkt) & ~7;  // one workgroup per CU (92 KB of LDS), split ranges contiguous per XCD
+    int ns = (slots / a.nkt) & ~7;  // one workgroup per CU (92 KB of LDS), split ranges contiguous per XCD
     if (ns < 8) ns = 8;
     while (ns > 8 && ns > a.items) ns -= 8;
     a.nsplit = ns;
@@ -444,10 +495,10 @@ int dsconv_wgrad_split_num_splits(int N, int Cin, int M, int H, int W) {
     return a.nsplit;
 }
 
-template <int NT, bool AFF, bool PK, typename TX, typename TG>
+template <int NT, bool AFF, bool PK, typename TX, typename TG, bool W2 = false>
 static int launch_dswg_cfg(const DsWgArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * NT * (64 + 128) * DWG_SROW;
-    constexpr auto kern = k_dsconv_wgrad_split<NT, AFF, PK, TX, TG>;
+    constexpr auto kern = k_dsconv_wgrad_split<NT, AFF, PK, TX, TG, W2>;
     static size_t granted = 0;
     if (lds > granted) {
         HIP_RET(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -466,6 +517,14 @@ int launch_dsconv_wgrad_split(DsWgArgs& a, int kpl, int x_dt, int dz_dt, hipStre
     if ((a.x_bs & 3) || (a.dz_bs & 3) || (((uintptr_t)a.x) & (4 * xe - 1)) || (((uintptr_t)a.dz) & (4 * ze - 1))) return -2;
     if ((long)a.Cin * a.H * a.W * xe >= (1L << 32) || (long)a.M * a.H * a.W * ze >= (1L << 32)) return -2;
     dswg_geom(a);
+    {
+        static int ilv = -1;  // SMAAT_ROWS_ILV=0: contiguous item ranges (A/B timing)
+        if (ilv < 0) {
+            const char* e = getenv("SMAAT_ROWS_ILV");
+            ilv = e ? atoi(e) : 1;
+        }
+        a.ilv = ilv;
+    }
     const bool aff = a.in_scale != nullptr;
     static int pk = -1;
     if (pk < 0) {
@@ -473,6 +532,12 @@ int launch_dsconv_wgrad_split(DsWgArgs& a, int kpl, int x_dt, int dz_dt, hipStre
         pk = (e && e[0] == '1') ? 1 : 0;
     }
     if (dz_dt == SMAAT_BF16) {
+        if (x_dt == SMAAT_BF16 && dswg_w2()) {
+            // (the scalar-math AFF build needs 116 VGPRs at any prefetch depth -- a scheduling artefact; the packed one 80)
+            if (aff) return launch_dswg_cfg<1, true, true, bf16_t, bf16_t, true>(a, st);
+            return pk ? launch_dswg_cfg<1, false, true, bf16_t, bf16_t, true>(a, st)
+                      : launch_dswg_cfg<1, false, false, bf16_t, bf16_t, true>(a, st);
+        }
         if (x_dt == SMAAT_BF16) {
             if (pk) return aff ? launch_dswg_cfg<1, true, true, bf16_t, bf16_t>(a, st) : launch_dswg_cfg<1, false, true, bf16_t, bf16_t>(a, st);
             return aff ? launch_dswg_cfg<1, true, false, bf16_t, bf16_t>(a, st) : launch_dswg_cfg<1, false, false, bf16_t, bf16_t>(a, st);

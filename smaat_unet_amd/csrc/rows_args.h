@@ -1,0 +1,35 @@
+// Argument blocks of the row-walking kernels (dsrows.hip, dswgrad.hip), shared with the C ABI (capi.hip): ONE declaration, so
+// that a field added for a kernel cannot silently disagree with the caller's copy.
+#pragma once
+
+struct DsRowsArgs {
+    const void* x;
+    long x_bs;
+    const float* in_scale;
+    const float* in_shift;
+    const float* w_dw;             // [K][9]
+    const float* b_dw;             // [K] or null
+    const unsigned short* planes;  // pointwise weight images, chunk-major [K/16][NPL][M][16] (NPL = 3 split planes | 1)
+    const float* bias;             // [M] or null
+    void* out;
+    long out_bs;
+    float* part;  // [3][items][M] or null
+    int N, Cin, K, M, H, W, P;
+    int nsplit, strips, bands, RB, items, ips, npl;
+    int ilv;  // 1: the workgroups of an XCD take its items round-robin (set by the launcher)
+};
+
+struct DsWgArgs {
+    const void* x;   // TX
+    long x_bs;
+    const float* in_scale;
+    const float* in_shift;
+    const float* w_dw;  // [K][9]
+    const float* b_dw;  // [K] or null
+    const void* dz;  // TG
+    long dz_bs;
+    float* part;  // [nsplit][M][K]
+    int N, Cin, K, M, H, W, P;
+    int nkt, nsplit, strips, bands, RB, items, ips;
+    int ilv;  // 1: the workgroups of an XCD take its items round-robin (neighbouring strips run at the same time)
+};

@@ -49,3 +49,44 @@ def test_scalar_base_loads_really_have_a_scalar_base():
         assert not bad, (src, bad[:3])
         if src == "dswgrad.hip":
             assert len(re.findall(r"global_load_dwordx?4? v\[?\d+[:\d\]]*, v\d+, s\[\d+:\d+\]", asm)) >= 24
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc not available")
+def test_row_walking_kernels_do_not_drain_their_prefetch_queue():
+    """Round 4: the row-walking kernels (dswgrad.hip, dsrows.hip) keep PD rows of inline-asm loads in flight behind counted
+    `s_waitcnt vmcnt(N)`.  hipcc does not see those loads -- but a compiler-visible load (the depthwise weights, the BatchNorm
+    coefficients) that was still pending at the loop entry made it emit `s_waitcnt vmcnt(0)` at the value's first use INSIDE
+    the loop, once per iteration, in all but two instantiations: the queue was emptied every chunk.  The kernels now use those
+    values once before the first asm load; no loop of theirs may contain a full drain.  (Exception: the f32 two-channel
+    instantiation of the fused forward spills registers -- scratch traffic needs the wait -- and is not selected by ops.py.)"""
+    import re
+    import subprocess
+    import tempfile
+    for src in ("dswgrad.hip", "dsrows.hip"):
+        with tempfile.NamedTemporaryFile(suffix=".s") as f:
+            subprocess.run([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S",
+                            "--cuda-device-only", os.path.join(ROOT, "smaat_unet_amd", "csrc", src), "-o", f.name],
+                           check=True, capture_output=True)
+            asm = open(f.name).read()
+        fn, inloop, drains, seen = None, False, {}, 0
+        for ln in asm.splitlines():
+            m = re.match(r"^(_Z\w+):", ln)
+            if m:
+                fn, inloop = m.group(1), False
+                drains[fn] = 0
+                continue
+            if ln.startswith(".Lfunc_end"):
+                fn = None
+            if fn is None:
+                continue
+            if re.match(r"^\.LBB\d+_\d+:", ln) or re.match(r"^; %bb\.\d+:", ln):
+                inloop = "in Loop" in ln or "Loop Header" in ln
+            if inloop and "s_waitcnt vmcnt(0)" in ln:
+                drains[fn] += 1
+        for fn, n in drains.items():
+            if "k_dsconv_wgrad_split" in fn or "k_dsconv_rows_fwd" in fn:
+                seen += 1
+                if "k_dsconv_rows_fwdILi3ELb" in fn and "ELi2EffLb0EE" in fn:
+                    continue  # (NT = 3, two channels per thread: 108 bytes of scratch per lane)
+                assert n == 0, (fn, f"{n} full drains of the vector-memory counter inside a loop")
+        assert seen >= 12, (src, seen)
