@@ -1,8 +1,10 @@
 #!/usr/bin/env python
 """Where does an iteration of the recompute weight gradient go?  Times csrc/dswgrad.hip on one layer with parts of the
-iteration switched off (SMAAT_DWG_DBG bits: 1 no LDS reads + MFMA, 2 no LDS writes, 4 no depthwise math, 8 no global loads,
-16 no barrier; the results are wrong, only the time means something).  One child process per setting (the switch is read
-once per process)."""
+iteration compiled out (DWG_DBG bits: 1 no LDS reads + MFMA, 2 no LDS writes, 4 no depthwise math, 8 no global loads,
+16 no barrier; the results are wrong, only the time means something).  One experiment library per setting
+(smaat_unet_amd/exp/libsmaat_hip_dwgdbg<bits>.so: `hipcc -DDWG_DBG=<bits> -c dswgrad.hip`, linked with the other objects),
+one child process per library (SMAAT_LIB).  The switches are compile-time on purpose: as run-time flags they changed the
+code of the normal path."""
 import os
 import subprocess
 import sys
@@ -47,15 +49,17 @@ def child():
         torch.cuda.synchronize()
         out.append(e0.elapsed_time(e1) / 10)
         del x, dz, ws
-    print(f"dbg={int(os.environ.get('SMAAT_DWG_DBG', '0')):2d}  bf16 B=64 {out[0]:7.3f} ms   f32 B=32 {out[1]:7.3f} ms", flush=True)
+    print(f"dbg={int(os.environ.get('DWG_DBG_TAG', '0')):2d}  bf16 B=64 {out[0]:7.3f} ms   f32 B=32 {out[1]:7.3f} ms", flush=True)
 
 
 if __name__ == "__main__":
     if os.environ.get("DWG_CHILD") == "1":
         child()
     else:
-        for dbg in [int(v) for v in os.environ.get("DWG_DBGS", "0,1,2,4,8,16,3,6,7,12,15,31,0").split(",")]:
-            env = dict(os.environ, DWG_CHILD="1", SMAAT_DWG_DBG=str(dbg))
+        for dbg in [int(v) for v in os.environ.get("DWG_DBGS", "0,1,2,4,8,16,7,12,15,31,0").split(",")]:
+            env = dict(os.environ, DWG_CHILD="1", DWG_DBG_TAG=str(dbg))
+            if dbg:
+                env["SMAAT_LIB"] = os.path.join(ROOT, "smaat_unet_amd", "exp", f"libsmaat_hip_dwgdbg{dbg}.so")
             r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=300)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("dbg=")]
             print(lines[-1] if lines else f"dbg={dbg} FAILED rc={r.returncode} {r.stderr[-300:]}", flush=True)

@@ -29,6 +29,12 @@
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 int split_mode();  // splitmma.hip
 
+// timing ablations for experiment builds (hipcc -DDSR_DBG=<bits>; results are wrong, only the time means something; compile-time
+// for the reason given in dswgrad.hip): 1 no LDS reads + MFMA, 2 no B-image writes, 4 no depthwise math, 8 no global loads,
+// 16 no per-chunk barrier, 32 no output stores, 64 no BatchNorm partials
+#ifndef DSR_DBG
+#define DSR_DBG 0
+#endif
 #define DSR_CW 32  // pixels per row segment = width of a column strip
 
 #include "rows_args.h"
@@ -201,7 +207,9 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
             const TX* erow = (const TX*)dsr_uniform_ptr(xrow - w_eback);
 #pragma unroll
             for (int u = 0; u < CPT; ++u) {
-                if (sizeof(TX) == 4) {
+                if constexpr ((DSR_DBG & 8) != 0) {
+                    asm volatile("" : "+s"(xrow), "+s"(erow));
+                } else if (sizeof(TX) == 4) {
                     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sx[set][u]) : "v"(vo_x[u]), "s"(xrow));
                     asm volatile("global_load_dword %0, %1, %2" : "=v"(se[set][u]) : "v"(vo_e[u]), "s"(erow));
                 } else {
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
             srok[set] = w_rok;
         };
         auto wait_set = [&](int set) __attribute__((always_inline)) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * LPG) : "memory");
+            if constexpr ((DSR_DBG & 8) == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * LPG) : "memory");
 #pragma unroll
             for (int u = 0; u < CPT; ++u) asm volatile("" : "+v"(sx[set][u]), "+v"(se[set][u]));
         };
@@ -268,7 +276,12 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
 #pragma unroll
             for (int u = 0; u < CPT; ++u) {
                 float yy[2][4];
-                if (PK) {  // both k-rows of the channel in one v_pk_fma_f32 (same fma per component, same tap order)
+                if constexpr ((DSR_DBG & 4) != 0) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) yy[j][c] = win[u][1][1 + c] + bs[u][j];
+                } else if (PK) {  // both k-rows of the channel in one v_pk_fma_f32 (same fma per component, same tap order)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         dsr_f32x2 acc = {bs[u][0], bs[u][1]};
@@ -297,6 +310,10 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
                         }
                 }
                 const int dw_ = ((ci + 64 * u) ^ bsw) * 4;
+                if constexpr ((DSR_DBG & 2) != 0) {
+                    asm volatile("" ::"v"(yy[0][0]), "v"(yy[0][1]), "v"(yy[0][2]), "v"(yy[0][3]), "v"(yy[1][0]), "v"(yy[1][1]), "v"(yy[1][2]), "v"(yy[1][3]));
+                    continue;
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     unsigned pl[NT];
@@ -324,7 +341,7 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
                         commit((u + 1) % PD, (t + 1) & 1);
                         issue((u + 1) % PD);
                     }
-                    __syncthreads();
+                    if constexpr ((DSR_DBG & 16) == 0) __syncthreads();
                 }
             }
         }
@@ -356,23 +373,29 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
         // rows this wave finishes: registers r = 8 wkh .. 8 wkh + 7 of its tile  ->  m = wm * 32 + (r & 3) + 8 (r >> 2) + 4 half
         float bias[8];
         int mrow[8];
+        unsigned loff[8];  // element offset of (row mrow[i], column l31) from the chunk's first output element
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int r = 8 * wkh + i;
             mrow[i] = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             bias[i] = (a.bias && mrow[i] < a.M) ? a.bias[mrow[i] < a.M ? mrow[i] : 0] : 0.f;
+            loff[i] = (unsigned)(mrow[i] < a.M ? mrow[i] : 0) * (unsigned)a.P + (unsigned)l31;
         }
         f32x16 acc;
         float keep[8];
         float s1[8], s2[8], sh[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s1[i] = s2[i] = sh[i] = 0.f;
+        TZ* c_ob = (TZ*)a.out;  // output element (channel 0, first row of the band, first column of the strip) of the open item
+        TZ* p_op = (TZ*)a.out;  // ... of the pending chunk's row
         int nrows = 0;            // rows accumulated into the statistics of the open item
         // consume cursor + the chunk whose result is pending (finished one iteration later)
         int c_item = it_lo - it_st, c_j = 0, c_len = 0;
         bool pend = false;
-        int p_item = 0, p_row = 0, p_buf = 0;
+        int p_buf = 0;
         const int swz = ((l31 >> 4) & 1) << 5;  // byte XOR of the B image's k index for pixels 16 .. 31 (8 dwords)
         auto flush_stats = [&](int item) __attribute__((always_inline)) {
-            if (!a.part || nrows == 0) return;
+            if ((DSR_DBG & 64) != 0 || !a.part || nrows == 0) return;
             const float fn = (float)nrows, inv = 1.f / fn;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -397,23 +420,40 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
                 }
             }
             nrows = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
         };
+        // Round 4 (ablation builds): the epilogue was the critical path of the whole workgroup -- eight LDS reads each followed by
+        // lgkmcnt(0) and an exec-masked store (the row guard made every row its own basic block), and three scalar divisions per
+        // chunk for the output address.  Now: the eight partner values are read first (one wait), the row guard is a wave-uniform
+        // branch around the whole store group (M == 64: no guard), the band's output pointer is cached per item.
         auto finish = [&]() __attribute__((always_inline)) {  // the pending chunk: add the partner half, store, statistics
             const float* xp = X + ((p_buf * 4 + partner) * 8) * 64 + lane;
-            const int n = p_item / bps, rem = p_item - n * bps;
-            const int st_ = rem % a.strips;
-            TZ* op = (TZ*)a.out + (long)n * a.out_bs + (long)p_row * a.W + st_ * DSR_CW + l31;
-            const bool first = nrows == 0;
+            float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float v = keep[i] + xp[i * 64];
-                if (mrow[i] < a.M) dsr_store(op + (long)mrow[i] * a.P, v + bias[i]);
-                if (first) {
-                    sh[i] = v;
-                    s1[i] = 0.f;
-                    s2[i] = 0.f;
+            for (int i = 0; i < 8; ++i) v[i] = xp[i * 64];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += keep[i];
+            if constexpr ((DSR_DBG & 32) == 0) {
+                if (a.M == 64) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dsr_store(p_op + loff[i], v[i] + bias[i]);
                 } else {
-                    const float d = v - sh[i];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (mrow[i] < a.M) dsr_store(p_op + loff[i], v[i] + bias[i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(v[i]));
+            }
+            if constexpr ((DSR_DBG & 64) == 0) {
+                const bool first = nrows == 0;  // (s1 = s2 = 0 then: flush_stats)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float sv = first ? v[i] : sh[i];
+                    sh[i] = sv;
+                    const float d = v[i] - sv;
                     s1[i] += d;
                     s2[i] = fmaf(d, d, s2[i]);
                 }
@@ -427,7 +467,11 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
             if (c_j >= c_len) {
                 c_item += it_st;
                 c_j = 0;
-                c_len = item_rows(c_item) + 2;
+                const int n = c_item / bps, rem = c_item - n * bps;
+                const int band = rem / a.strips, st_ = rem - band * a.strips;
+                const int r0 = band * a.RB;
+                c_len = (a.H - r0 < a.RB ? a.H - r0 : a.RB) + 2;
+                c_ob = (TZ*)a.out + (long)n * a.out_bs + (long)r0 * a.W + st_ * DSR_CW;
                 newitem = true;
             }
             if (pend) {
@@ -435,7 +479,11 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
                 pend = false;
             }
             if (newitem && c_item > it_lo) flush_stats(c_item - it_st);  // (its last chunk was finished just above)
-            if (c_j >= 2) {
+            if (c_j >= 2 && (DSR_DBG & 1) != 0) {
+                pend = true;
+                p_buf = t & 1;
+                p_op = c_ob + (long)(c_j - 2) * a.W;
+            } else if (c_j >= 2) {
                 const unsigned char* base = lds + (t & 1) * BUFSZ + l31 * ROWB;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -463,12 +511,10 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
                     keep[i] = acc[8 * wkh + i];
                 }
                 pend = true;
-                p_item = c_item;
                 p_buf = t & 1;
-                const int band = (c_item % bps) / a.strips;
-                p_row = band * a.RB + c_j - 2;
+                p_op = c_ob + (long)(c_j - 2) * a.W;
             }
-            __syncthreads();
+            if constexpr ((DSR_DBG & 16) == 0) __syncthreads();
         }
         if (pend) finish();
         if (nitems > 0) flush_stats(it_hi - it_st);
@@ -544,7 +590,7 @@ int launch_dsconv_rows(DsRowsArgs& a, int kpl, int x_dt, int z_dt, hipStream_t s
     if (!dsconv_rows_ok(kpl, a.Cin, a.M, a.H, a.W) || a.K != 2 * a.Cin) return -2;
     const int xe = x_dt == SMAAT_BF16 ? 2 : 4;
     if ((a.x_bs & 3) || ((((uintptr_t)a.x) * 1) & (4 * xe - 1)) || (((uintptr_t)a.planes) & 15)) return -2;
-    if ((long)a.Cin * a.H * a.W * xe >= (1L << 32)) return -2;
+    if ((long)a.Cin * a.H * a.W * xe >= (1L << 32) || (long)a.M * a.H * a.W >= (1L << 31)) return -2;  // (32-bit element offsets)
     dsr_geom(a);
     {
         static int ilv = -1;  // SMAAT_ROWS_ILV=0: contiguous item ranges (A/B timing)
