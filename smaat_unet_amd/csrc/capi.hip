@@ -529,6 +529,23 @@ int smaat_dsconv_fwd_rows(const void* x, int x_dt, long x_bs, const float* in_sc
 int smaat_dsconv_fwd_split_act(const float* x, long x_bs, const float* in_scale, const float* in_shift,
                                const float* w_dw, const float* b_dw, const void* planes, const float* b_pw, float* z,
                                long z_bs, int N, int Cin, int kpl, int Cout, int H, int W, int relu_out, void* stream) {
+    // Inference (round 4): where the row-walking kernel of the training forward takes the shape it also runs the folded half
+    // block -- no BatchNorm partials, the ReLU in its epilogue (same weight-plane format).  f32: up to 64 input channels
+    // (the two-channel-per-thread build spills).  SMAAT_EVAL_ROWS=0: the tile kernel everywhere (A/B timing).
+    static int rows_eval = -1;
+    if (rows_eval < 0) {
+        const char* e = getenv("SMAAT_EVAL_ROWS");
+        rows_eval = e ? atoi(e) : 1;
+    }
+    if (rows_eval && x && w_dw && planes && z && N >= 1 && kpl == 2 && Cin <= 64 && dsconv_rows_ok(kpl, Cin, Cout, H, W) &&
+        (in_scale == nullptr) == (in_shift == nullptr)) {
+        DsRowsArgs r{};
+        r.x = x; r.x_bs = x_bs; r.in_scale = in_scale; r.in_shift = in_shift; r.w_dw = w_dw; r.b_dw = b_dw;
+        r.planes = (const unsigned short*)planes; r.bias = b_pw; r.out = z; r.out_bs = z_bs; r.part = nullptr;
+        r.N = N; r.Cin = Cin; r.K = Cin * kpl; r.M = Cout; r.H = H; r.W = W; r.relu = relu_out ? 1 : 0;
+        const int rc = launch_dsconv_rows(r, kpl, SMAAT_F32, SMAAT_F32, ST);
+        if (rc != -2) return rc;
+    }
     return dsconv_fwd_split_impl(x, x_bs, in_scale, in_shift, w_dw, b_dw, planes, b_pw, z, z_bs, nullptr, nullptr, N, Cin,
                                  kpl, Cout, H, W, relu_out, stream);
 }

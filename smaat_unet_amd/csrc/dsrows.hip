@@ -435,19 +435,23 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] += keep[i];
             if constexpr ((DSR_DBG & 32) == 0) {
-                if (a.M == 64) {
+                if (a.M == 64 && !a.relu) {  // (the training form: no guard, no clamp)
 #pragma unroll
                     for (int i = 0; i < 8; ++i) dsr_store(p_op + loff[i], v[i] + bias[i]);
+                } else if (a.M == 64) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dsr_store(p_op + loff[i], fmaxf(v[i] + bias[i], 0.f));
                 } else {
+                    const float fl = a.relu ? 0.f : -__builtin_inff();
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        if (mrow[i] < a.M) dsr_store(p_op + loff[i], v[i] + bias[i]);
+                        if (mrow[i] < a.M) dsr_store(p_op + loff[i], fmaxf(v[i] + bias[i], fl));
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(v[i]));
             }
-            if constexpr ((DSR_DBG & 64) == 0) {
+            if ((DSR_DBG & 64) == 0 && a.part) {
                 const bool first = nrows == 0;  // (s1 = s2 = 0 then: flush_stats)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {

@@ -16,7 +16,8 @@ struct DsRowsArgs {
     float* part;  // [3][items][M] or null
     int N, Cin, K, M, H, W, P;
     int nsplit, strips, bands, RB, items, ips, npl;
-    int ilv;  // 1: the workgroups of an XCD take its items round-robin (set by the launcher)
+    int ilv;   // 1: the workgroups of an XCD take its items round-robin (set by the launcher)
+    int relu;  // 1: the output is max(z + bias, 0) (inference: BatchNorm folded into the weights, ReLU in the epilogue)
 };
 
 struct DsWgArgs {
