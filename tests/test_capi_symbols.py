@@ -48,3 +48,22 @@ def test_query_entry_points_need_no_gpu(built):
     assert L.smaat_plane_num_slots(2, 324) == 2
     assert L.smaat_wgrad_num_splits(32, 288, 288, 64, 128) >= 1
     assert L.smaat_cbam_pix_blocks(2, 300) == 4
+
+
+def test_workspace_queries_of_the_round_4_geometries(built):
+    """Host-side geometry only (no launch): the depthwise backward's partial rows under plane packing, and the work lists of
+    the row-walking kernels."""
+    L = _lib._Lib(built)
+    # 18 x 18 planes share a wave with the same channel's plane of the next images: still ONE partial row per image (+ 1)
+    assert L.smaat_dw3x3_bwd_ws_rows(32, 512, 18, 18) == 32 + 1
+    assert L.smaat_dw3x3_bwd_ws_rows(1, 512, 18, 18) == 1 + 1
+    # 288 x 288: 72 column groups x bands over several waves per plane
+    assert L.smaat_dw3x3_bwd_ws_rows(2, 64, 288, 288) > 2 + 1
+    # row-walking kernels: shapes they take / refuse, one statistics slot per (image, band, strip)
+    assert L.smaat_dsconv_rows_ok(2, 64, 64, 288, 288) == 1
+    assert L.smaat_dsconv_rows_ok(2, 64, 64, 144, 144) == 0   # W % 32 != 0
+    assert L.smaat_dsconv_rows_ok(2, 64, 128, 288, 288) == 0  # more than 64 output channels
+    assert L.smaat_dsconv_rows_num_slots(32, 288, 288) % (32 * 9) == 0
+    assert L.smaat_dsconv_wgrad_split_ok(2, 64, 288, 288) == 1
+    ns = L.smaat_dsconv_wgrad_split_num_splits(32, 64, 64, 288, 288)
+    assert ns >= 8 and ns % 8 == 0  # contiguous split ranges per XCD
