@@ -270,6 +270,13 @@ int smaat_split_planes(const float* w, int R, int C, void* planes, void* stream)
 /* planes of the TRANSPOSE of a matrix stored [C][R] (same output layout as smaat_split_planes(w^T, R, C)): the data
  * gradient of a pointwise conv takes A = pointwise.weight^T without a transposed copy of the weight */
 int smaat_split_planes_t(const float* w, int R, int C, void* planes, void* stream);
+/* The operand images of several weight matrices in one launch (they all become stale together, at the optimizer step; the
+ * reference has no counterpart: cuDNN / MKLDNN re-pack weights inside every convolution call).  desc: DEVICE array
+ * [n_desc][8] of int64 { src (f32 matrix), dst (image), R, C, kind, src_t, first block, blocks }, blocks = ceil(R * Cp / 256),
+ * kind 0 = smaat_split_planes / _t (Cp = C rounded up to 16; src_t = 1: the transpose of a matrix stored [C][R]),
+ * kind 2 = smaat_bf16_planes (Cp = C rounded up to 32); total_blocks = the sum of blocks.  Images are bit-identical to the
+ * single-matrix entry points'. */
+int smaat_weight_planes_multi(const void* desc, int n_desc, int total_blocks, void* stream);
 int smaat_pw_split_num_slots(int N, int H, int W);
 int smaat_dw3x3_fwd(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
                     const float* b_dw, float* y, long y_bs, int N, int Cin, int kpl, int H, int W, void* stream);

@@ -78,6 +78,7 @@ SIGNATURES = {
     "smaat_set_split_mode": [_I],
     "smaat_split_planes": [_P, _I, _I, _P, _P],
     "smaat_split_planes_t": [_P, _I, _I, _P, _P],
+    "smaat_weight_planes_multi": [_P, _I, _I, _P],
     "smaat_pw_split_num_slots": [_I, _I, _I],
     "smaat_dw3x3_fwd": [_P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P],
     "smaat_pointwise_fwd_split": [_P, _L, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P],

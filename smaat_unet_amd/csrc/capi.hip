@@ -8,6 +8,7 @@
 
 int launch_wgrad2(Wg2Args& a, hipStream_t st);
 #include "rows_args.h"  // DsRowsArgs (dsrows.hip), DsWgArgs (dswgrad.hip)
+int launch_weight_planes_multi(const long long* desc, int nd, int total_blocks, hipStream_t st);  // splitmma.hip
 int dsconv_rows_ok(int kpl, int Cin, int M, int H, int W);
 int dsconv_rows_num_slots(int N, int H, int W);
 int launch_dsconv_rows(DsRowsArgs& a, int kpl, int x_dt, int z_dt, hipStream_t st);
@@ -430,6 +431,10 @@ int smaat_split_planes(const float* w, int R, int C, void* planes, void* stream)
 int smaat_split_planes_t(const float* w, int R, int C, void* planes, void* stream) {
     if (R < 1 || C < 1) return -1;
     return launch_split_planes(w, R, C, (unsigned short*)planes, ST, 1);
+}
+int smaat_weight_planes_multi(const void* desc, int n_desc, int total_blocks, void* stream) {
+    if (!desc || n_desc < 1 || total_blocks < 1) return -1;
+    return launch_weight_planes_multi((const long long*)desc, n_desc, total_blocks, ST);
 }
 int smaat_pw_split_num_slots(int N, int H, int W) { return pw_split_num_slots(N, H * W); }
 int smaat_dw3x3_fwd(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,

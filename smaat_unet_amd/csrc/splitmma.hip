@@ -343,6 +343,54 @@ int launch_split_planes(const float* w, int R, int C, unsigned short* out, hipSt
 }
 
 // =====================================================================================
+// k_weight_planes_multi: the operand images of MANY weight matrices in ONE launch (round 4).  A training step needs the
+// images of 18 pointwise weights and of 17 transposes -- 35 launches of ~5 us each doing a few KB of work, one after the
+// other in the stream.  All of them become stale at the same moment (the optimizer step), so the host refreshes every
+// registered image at the first use after it (smaat_unet_amd/ops.py: _weight_planes).
+// desc [n][8] int64 in device memory: { src, dst, R, C, kind, src_t, first block, blocks }
+//   kind 0: split planes as k_split_planes (bf16_only = the current split mode, passed by the host)
+//   kind 2: the single bf16 image of the mixed-precision kernels (k_bf16_planes in bf16gemm.hip: Cp = C rounded up to 32)
+// The element arithmetic is that of the single-matrix kernels: bit-identical images.
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_weight_planes_multi(const long long* __restrict__ desc, int nd, int bf16_only) {
+    __shared__ int sel;
+    const int b = blockIdx.x;
+    for (int j = threadIdx.x; j < nd; j += 256) {
+        const long long b0 = desc[j * 8 + 6], nb = desc[j * 8 + 7];
+        if (b >= b0 && b < b0 + nb) sel = j;  // (block ranges are disjoint: one writer)
+    }
+    __syncthreads();
+    const long long* d = desc + (long)sel * 8;
+    const float* __restrict__ w = (const float*)d[0];
+    unsigned short* __restrict__ out = (unsigned short*)d[1];
+    const int R = (int)d[2], C = (int)d[3], kind = (int)d[4], src_t = (int)d[5];
+    const int Cp = kind == 2 ? ((C + 31) & ~31) : ((C + 15) & ~15);
+    const long i = (long)(b - (int)d[6]) * 256 + threadIdx.x;
+    if (i >= (long)R * Cp) return;
+    const int r = src_t ? (int)(i % R) : (int)(i / Cp), c = src_t ? (int)(i / R) : (int)(i - (long)r * Cp);
+    const float x = c < C ? (src_t ? w[(long)c * R + r] : w[(long)r * C + c]) : 0.f;
+    if (kind == 2) {
+        out[((long)(c >> 4) * R + r) * 16 + (c & 15)] = (unsigned short)(pack_bf16x2(x, 0.f) & 0xFFFFu);
+        return;
+    }
+    const float p1 = bf16_only ? rne_bf16(x) : bitsf(fbits(x) & 0xFFFF0000u);
+    const float r1 = bf16_only ? 0.f : x - p1;
+    const float p2 = bitsf(fbits(r1) & 0xFFFF0000u);
+    const float p3 = r1 - p2;
+    const long o = ((long)(c >> 4) * 3 * R + r) * 16 + (c & 15);
+    const long plane = (long)R * 16;
+    out[o] = (unsigned short)(fbits(p1) >> 16);
+    out[o + plane] = (unsigned short)(fbits(p2) >> 16);
+    out[o + 2 * plane] = (unsigned short)(fbits(p3) >> 16);
+}
+
+int launch_weight_planes_multi(const long long* desc, int nd, int total_blocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_weight_planes_multi, dim3((unsigned)total_blocks), dim3(256), 0, st, desc, nd,
+                       split_mode() == 1 ? 1 : 0);
+    return (int)hipGetLastError();
+}
+
+// =====================================================================================
 // k_pw_split:  out[n][m][p] = sum_c A[m][c] * x[n][c][p] + bias[m]   (+ BatchNorm partials)
 //   A = pre-split planes, chunk-major [Cp/16][3][M][16] (k_split_planes); x split on the fly by the producer waves.
 //   Used for the pointwise conv of the forward pass (x = depthwise output) and for its data gradient

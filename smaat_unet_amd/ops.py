@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import contextlib
 import os
+import weakref
 import threading
 
 import torch
@@ -227,16 +228,94 @@ def set_matrix_mode(mode):
     return {0: "f32", 1: "bf16", 2: "f32_split2", 3: "f32_split"}[prev]
 
 
-def _split_planes_raw(w2d, transpose=False):
-    """w2d [R][C] f32 contiguous -> int16 bf16 planes, 3 * R * ceil16(C) elements (chunk-major [ceil16(C)/16][3][R][16]).
-    transpose=True: the planes of w2d^T (w2d is [C][R]), read straight from w2d"""
+# ---- operand images of the pointwise weights: one refresh launch per optimizer step -------------------------------------------
+# A training step needs the image of every pointwise weight (forward) and of its transpose (data gradient): 35 launches of ~5 us
+# doing a few KB of work each, one after the other in the stream (0.19 ms of a 32.6 ms step).  Every one of them goes stale at the
+# same moment -- the optimizer step -- so images live in a cache keyed by the weight's storage, and the first stale image asked
+# for after a weight update refreshes ALL registered stale images in ONE launch (smaat_weight_planes_multi).  A use is served from
+# the cache only if the weight tensor is the same object at the same address with the same version counter; in-place updates
+# (optimizer, load_state_dict, DDP broadcast) bump the version, replaced parameters are new objects.  The returned image is
+# shared: callers only read it.  SMAAT_PLANE_CACHE=0 restores one launch per use.
+PLANE_CACHE = os.environ.get("SMAAT_PLANE_CACHE", "1") != "0"
+_PLANES = {}
+_PLANES_TABLE = {}  # tuple of entry ids -> device descriptor table
+
+
+class _PlaneEntry:
+    __slots__ = ("ref", "off", "src", "version", "planes", "r", "c", "kind", "src_t", "dev", "stream", "mode", "nblk")
+
+
+def _weight_planes(w2d, transpose, kind):
+    """kind 0: split planes (smaat_split_planes / _t), kind 2: bf16 image (smaat_bf16_planes); see the note above"""
     L = _lib.get()
     r, c = (w2d.shape[1], w2d.shape[0]) if transpose else w2d.shape
-    cp = (c + 15) // 16 * 16
-    planes = torch.empty((3, r, cp), dtype=torch.int16, device=w2d.device)
-    fn = L.smaat_split_planes_t if transpose else L.smaat_split_planes
-    _lib.check(fn(_ptr(w2d), r, c, _ptr(planes), _stream(w2d)), "smaat_split_planes")
-    return planes
+    if kind == 0:
+        cp = (c + 15) // 16 * 16
+        shape = (3, r, cp)
+    else:
+        cp = (c + 31) // 32 * 32
+        shape = (cp // 16, r, 16)
+
+    def direct():
+        planes = torch.empty(shape, dtype=torch.int16, device=w2d.device)
+        if kind == 0:
+            fn = L.smaat_split_planes_t if transpose else L.smaat_split_planes
+            _lib.check(fn(_ptr(w2d), r, c, _ptr(planes), _stream(w2d)), "smaat_split_planes")
+        else:
+            _lib.check(L.smaat_bf16_planes(_ptr(w2d), r, c, _ptr(planes), 1 if transpose else 0, _stream(w2d)), "smaat_bf16_planes")
+        return planes
+
+    base = w2d._base if w2d._base is not None else w2d
+    if (not PLANE_CACHE or not w2d.is_contiguous() or base.dtype != torch.float32 or base.is_inference()
+            or (w2d.is_cuda and torch.cuda.is_current_stream_capturing())):
+        return direct()  # (inference tensors have no version counter; a capture must not bake in a cache decision)
+    stream = _stream(w2d)
+    mode = L.smaat_split_mode() if kind == 0 else -1
+    key = (w2d.data_ptr(), r, c, bool(transpose), kind, mode, stream)
+    e = _PLANES.get(key)
+    if e is not None and e.ref() is base:
+        if e.version == base._version:
+            return e.planes
+    else:
+        e = _PlaneEntry()
+        e.ref, e.off, e.src = weakref.ref(base), w2d.data_ptr() - base.data_ptr(), w2d.data_ptr()
+        e.version, e.r, e.c, e.kind, e.src_t = -1, r, c, kind, 1 if transpose else 0
+        e.dev, e.stream, e.mode = w2d.device, stream, mode
+        e.nblk = (r * cp + 255) // 256
+        e.planes = torch.empty(shape, dtype=torch.int16, device=w2d.device)
+        _PLANES[key] = e
+    # refresh every stale image of this device / stream / split mode in one launch
+    stale, dead = [], []
+    for k, x in _PLANES.items():
+        b = x.ref()
+        if b is None or b.data_ptr() + x.off != x.src:
+            dead.append(k)
+        elif x.dev == e.dev and x.stream == stream and (x.kind != 0 or x.mode == mode) and x.version != b._version:
+            stale.append((x, b._version))
+    for k in dead:
+        del _PLANES[k]
+    ids = tuple(id(x) for x, _ in stale)
+    table = _PLANES_TABLE.get(ids)
+    if table is None:
+        if len(_PLANES_TABLE) > 16:
+            _PLANES_TABLE.clear()
+        rows, b0 = [], 0
+        for x, _ in stale:
+            rows.append([x.src, x.planes.data_ptr(), x.r, x.c, x.kind, x.src_t, b0, x.nblk])
+            b0 += x.nblk
+        table = (torch.tensor(rows, dtype=torch.int64).to(e.dev), b0, [x for x, _ in stale])  # (keeps the entries alive)
+        _PLANES_TABLE[ids] = table
+    _lib.check(L.smaat_weight_planes_multi(_ptr(table[0]), len(stale), table[1], stream), "smaat_weight_planes_multi")
+    for x, v in stale:
+        x.version = v
+    return e.planes
+
+
+def _split_planes_raw(w2d, transpose=False):
+    """w2d [R][C] f32 contiguous -> int16 bf16 planes, 3 * R * ceil16(C) elements (chunk-major [ceil16(C)/16][3][R][16]).
+    transpose=True: the planes of w2d^T (w2d is [C][R]), read straight from w2d.  The result is a shared cached image
+    (_weight_planes): read-only for the caller."""
+    return _weight_planes(w2d, transpose, 0)
 
 
 def _pointwise_split_raw(x, planes, bias, m, want_stats=False):
@@ -309,12 +388,9 @@ def _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None,
 
 # ---- mixed precision (bf16 storage): depthwise kernel (bf16 out) + bf16 GEMM fed by LDS-DMA (csrc/bf16gemm.hip) ----
 def _bf16_planes_raw(w2d, transpose=False):
-    """w2d [R][C] f32 -> bf16 image [ceil32(C)/16][R][16]; transpose=True: the image of w2d^T (w2d stored [C][R])"""
-    L = _lib.get()
-    r, c = (w2d.shape[1], w2d.shape[0]) if transpose else w2d.shape
-    planes = torch.empty(((c + 31) // 32 * 2, r, 16), dtype=torch.int16, device=w2d.device)
-    _lib.check(L.smaat_bf16_planes(_ptr(w2d), r, c, _ptr(planes), 1 if transpose else 0, _stream(w2d)), "smaat_bf16_planes")
-    return planes
+    """w2d [R][C] f32 -> bf16 image [ceil32(C)/16][R][16]; transpose=True: the image of w2d^T (w2d stored [C][R]).  A shared
+    cached image (_weight_planes): read-only for the caller."""
+    return _weight_planes(w2d, transpose, 2)
 
 
 def _pointwise_bf16_raw(x, planes, bias, m, want_stats=False, out_dtype=BF16, relu=False):

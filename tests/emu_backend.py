@@ -112,9 +112,23 @@ class EmuLib:
         assert not rem.any(), "three bf16 terms must represent an f32 exactly"
         return 0
 
+    def smaat_weight_planes_multi(self, desc, n_desc, total_blocks, stream):
+        d = np.ctypeslib.as_array((ctypes.c_int64 * (8 * n_desc)).from_address(int(desc))).reshape(n_desc, 8)
+        assert int(d[:, 7].sum()) == total_blocks
+        for src, dst, R, C, kind, src_t, _b0, nb in d.tolist():
+            Cp = (C + 31) // 32 * 32 if kind == 2 else (C + 15) // 16 * 16
+            assert nb == (R * Cp + 255) // 256
+            if kind == 2:  # (the class's own methods: a test may have wrapped the instance's to count launches)
+                rc = EmuLib.smaat_bf16_planes(self, src, R, C, dst, src_t, stream)
+            else:
+                rc = (EmuLib.smaat_split_planes_t if src_t else EmuLib.smaat_split_planes)(self, src, R, C, dst, stream)
+            if rc:
+                return rc
+        return 0
+
     def smaat_split_planes_t(self, w, R, C, out, stream):
         wt = np.ascontiguousarray(f32(w, R * C).reshape(C, R).T)
-        return self.smaat_split_planes(wt.ctypes.data, R, C, out, stream)
+        return EmuLib.smaat_split_planes(self, wt.ctypes.data, R, C, out, stream)
 
     def smaat_dw3x3_fwd(self, x, x_bs, in_scale, in_shift, w_dw, b_dw, y, y_bs, N, Cin, kpl, H, W, stream):
         if kpl not in (1, 2, 4) or (W % 4 and H * W > 1600):  # small planes take the flat-copy kernel, any width

@@ -726,6 +726,37 @@ def test_split_planes_transposed(shape):
     assert torch.equal(a, b)
 
 
+def test_weight_planes_multi_is_the_single_matrix_kernels():
+    """smaat_weight_planes_multi: the images of many weight matrices (split planes of a matrix / of a transpose, bf16 images
+    in both orientations, ragged sizes) in ONE launch, bit-identical to the single-matrix entry points"""
+    L, dev = _lib.get(), torch.device("cuda:0")
+    BF = 1
+    mats = [(64, 128, 0, 0), (128, 64, 0, 1), (37, 19, 0, 0), (19, 37, 0, 1), (1, 5, 0, 0), (512, 1024, 0, 1), (64, 24, 0, 0),
+            (64, 128, 2, 0), (128, 64, 2, 1), (37, 19, 2, 0), (21, 64, 2, 1), (1024, 512, 2, 0)]  # (R, C, kind, src_t)
+    rows, keep, b0 = [], [], 0
+    for i, (R, C, kind, src_t) in enumerate(mats):
+        w = T(rnd(10 + i, C, R) if src_t else rnd(10 + i, R, C), dev)  # src_t: stored [C][R]
+        Cp = (C + 31) // 32 * 32 if kind == 2 else (C + 15) // 16 * 16
+        n16 = R * Cp * (1 if kind == 2 else 3)
+        ref = torch.full((n16,), -1, dtype=torch.int16, device=dev)
+        got = torch.full((n16,), -2, dtype=torch.int16, device=dev)
+        if kind == 2:
+            assert L.smaat_bf16_planes(P(w), R, C, P(ref), src_t, stream(dev)) == 0
+        else:
+            assert (L.smaat_split_planes_t if src_t else L.smaat_split_planes)(P(w), R, C, P(ref), stream(dev)) == 0
+        nb = (R * Cp + 255) // 256
+        rows.append([w.data_ptr(), got.data_ptr(), R, C, kind, src_t, b0, nb])
+        b0 += nb
+        keep.append((w, ref, got))
+    desc = torch.tensor(rows, dtype=torch.int64).to(dev)
+    assert L.smaat_weight_planes_multi(P(desc), len(rows), b0, stream(dev)) == 0
+    torch.cuda.synchronize()
+    for (R, C, kind, src_t), (_, ref, got) in zip(mats, keep):
+        assert torch.equal(ref, got), (R, C, kind, src_t)
+    assert L.smaat_weight_planes_multi(None, 1, 1, stream(dev)) == -1
+    del BF
+
+
 @pytest.mark.parametrize("shape", [(1, 512, 256, 36, 36), (1, 1024, 512, 18, 18), (2, 256, 256, 36, 36),
                                    (1, 2048, 512, 36, 36), (1, 64, 64, 32, 32), (1, 256, 128, 72, 72)])
 def test_pointwise_split_k_slices(shape):

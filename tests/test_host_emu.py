@@ -708,3 +708,56 @@ def test_recompute_policy_wiring_equals_the_kept_depthwise_output(mode, monkeypa
     # (a 128-channel tensor remains at that resolution: the decoder's concatenation buffer, the input of up4)
     big = lambda s_, c: len([sh for sh in s_ if len(sh) == 4 and sh[2:] == (32, 64) and sh[1] == c])  # noqa: E731
     assert (big(s0, 128), big(s0, 256)) == (3, 1) and (big(s1, 128), big(s1, 256)) == (1, 0), (s0, s1)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_weight_images_are_refreshed_in_one_launch_per_optimizer_step(mode, monkeypatch):
+    """Round 4: the operand images of all pointwise weights (and of their transposes, for the data gradients) go stale
+    together, at the optimizer step; the first use after it refreshes every registered image in ONE launch
+    (ops._weight_planes / smaat_weight_planes_multi).  Three training steps with the cache must be what three steps without
+    it are (bit for bit on the emulated C ABI), and steps 2 and 3 must each issue exactly one refresh launch that covers all
+    images and no single-matrix launches."""
+    import contextlib
+    from smaat_unet_amd import _lib as L_, ops as _ops
+
+    def run(cache):
+        monkeypatch.setattr(_ops, "PLANE_CACHE", cache)
+        _ops._PLANES.clear()
+        _ops._PLANES_TABLE.clear()
+        torch.manual_seed(0)
+        model = S.SmaAt_UNet(4, 2, kernels_per_layer=2).train()
+        opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+        x, t = torch.randn(2, 4, 32, 32), torch.randn(2, 2, 32, 32)
+        lib = L_.get()
+        calls = []
+        single = {n: getattr(lib, n) for n in ("smaat_split_planes", "smaat_split_planes_t", "smaat_bf16_planes")}
+        multi = lib.smaat_weight_planes_multi
+        for n, f in single.items():
+            monkeypatch.setattr(lib, n, (lambda f_, n_: lambda *a: (calls.append((n_, 1)), f_(*a))[1])(f, n), raising=False)
+        monkeypatch.setattr(lib, "smaat_weight_planes_multi",
+                            lambda d, nd, tb, st: (calls.append(("multi", nd)), multi(d, nd, tb, st))[1], raising=False)
+        losses, per_step = [], []
+        ctx = _ops.precision("bf16") if mode == "bf16" else contextlib.nullcontext()
+        with ctx:
+            for _ in range(3):
+                calls.clear()
+                opt.zero_grad(set_to_none=True)
+                loss = ((model(x) - t) ** 2).sum()
+                loss.backward()
+                opt.step()
+                losses.append(loss.item())
+                per_step.append(list(calls))
+        for n, f in single.items():
+            monkeypatch.setattr(lib, n, f, raising=False)
+        monkeypatch.setattr(lib, "smaat_weight_planes_multi", multi, raising=False)
+        return losses, per_step, [p.detach().clone() for p in model.parameters()]
+
+    l0, c0, p0 = run(False)
+    l1, c1, p1 = run(True)
+    assert l0 == l1
+    assert all(torch.equal(a, b) for a, b in zip(p0, p1))
+    n_images = sum(n for _, n in c1[0])  # step 1 registers the images one by one
+    assert n_images >= 30 and all(k == "multi" for k, _ in c1[0])
+    for step in (1, 2):
+        assert c1[step] == [("multi", n_images)], c1[step][:5]
+    assert all(k != "multi" for k, _ in c0[1]) and len(c0[1]) == n_images  # without the cache: one launch per image
