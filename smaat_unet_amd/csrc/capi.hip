@@ -535,14 +535,14 @@ int smaat_dsconv_fwd_split_act(const float* x, long x_bs, const float* in_scale,
                                const float* w_dw, const float* b_dw, const void* planes, const float* b_pw, float* z,
                                long z_bs, int N, int Cin, int kpl, int Cout, int H, int W, int relu_out, void* stream) {
     // Inference (round 4): where the row-walking kernel of the training forward takes the shape it also runs the folded half
-    // block -- no BatchNorm partials, the ReLU in its epilogue (same weight-plane format).  f32: up to 64 input channels
-    // (the two-channel-per-thread build spills).  SMAAT_EVAL_ROWS=0: the tile kernel everywhere (A/B timing).
+    // block -- no BatchNorm partials, the ReLU in its epilogue (same weight-plane format).  SMAAT_EVAL_ROWS=0: the tile
+    // kernel everywhere (A/B timing).
     static int rows_eval = -1;
     if (rows_eval < 0) {
         const char* e = getenv("SMAAT_EVAL_ROWS");
         rows_eval = e ? atoi(e) : 1;
     }
-    if (rows_eval && x && w_dw && planes && z && N >= 1 && kpl == 2 && Cin <= 64 && dsconv_rows_ok(kpl, Cin, Cout, H, W) &&
+    if (rows_eval && x && w_dw && planes && z && N >= 1 && kpl == 2 && dsconv_rows_ok(kpl, Cin, Cout, H, W) &&
         (in_scale == nullptr) == (in_shift == nullptr)) {
         DsRowsArgs r{};
         r.x = x; r.x_bs = x_bs; r.in_scale = in_scale; r.in_shift = in_shift; r.w_dw = w_dw; r.b_dw = b_dw;

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
     constexpr int BPL = DSR_CW * ROWB;       // bytes per plane
     constexpr int BUFSZ = NT * BPL;
     constexpr int KSH = 4 * CPT;             // contraction steps per consumer wave (half of KMAX / 16)
+    constexpr bool A3L = NT == 3 && CPT == 2;  // third weight plane in LDS (see the consumer prologue)
     constexpr int PD = sizeof(TX) == 2 ? 8 : 4;  // rows in flight per producer thread (bf16: half the bytes per row, see dswgrad.hip)
     constexpr int LPG = 2 * CPT;             // loads per group and producer thread: row piece + edge element per channel
     static_assert((PD - 1) * LPG <= 63, "vmcnt is a 6-bit counter");
@@ -352,7 +353,12 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
         const int partner = wave ^ 2;
         const int KS = a.K >> 4;  // contraction steps present (K % 16 == 0)
         // ---- A fragments of this wave: rows wm * 32 + l31, steps wkh * KSH .. + KSH, resident for the whole walk ----
-        bf16x8 af[KSH][NT];
+        // A3L (exact split with two channels per producer thread, K = 256): 96 registers of fragments beside the accumulators,
+        // the statistics and the epilogue values do not fit the 168 VGPRs of three waves per SIMD (the build spilled 30).  The
+        // third plane -- the smallest term of the weight split, used by ONE of the six MFMAs of a step -- lives in LDS instead
+        // (32 KB, written once by the wave that reads it, conflict-free 16-byte lanes).
+        bf16x8 af[KSH][A3L ? 2 : NT];
+        unsigned char* a3p = A3L ? lds + 2 * BUFSZ + 2 * 4 * 8 * 64 * 4 + (wave * KSH * 64 + lane) * 16 : nullptr;  // (after X)
         {
             const int m = wm * 32 + l31;
             const int mc = m < a.M ? m : a.M - 1;
@@ -366,20 +372,30 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
                     bf16x8 z;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) z[e] = 0;
-                    af[s][t] = (ks < KS && m < a.M) ? v : z;
+                    if constexpr (A3L) {
+                        const bf16x8 fv = (ks < KS && m < a.M) ? v : z;
+                        if (t == 2)
+                            *(bf16x8*)(a3p + s * 64 * 16) = fv;
+                        else
+                            af[s][t < 2 ? t : 0] = fv;
+                    } else {
+                        af[s][t] = (ks < KS && m < a.M) ? v : z;
+                    }
                 }
             }
         }
         // rows this wave finishes: registers r = 8 wkh .. 8 wkh + 7 of its tile  ->  m = wm * 32 + (r & 3) + 8 (r >> 2) + 4 half
         float bias[8];
         int mrow[8];
-        unsigned loff[8];  // element offset of (row mrow[i], column l31) from the chunk's first output element
+        // output addressing: row mrow[i] = (wm * 32 + 4 half) + rsub(i), rsub(i) = (r & 3) + 8 (r >> 2) wave-uniform.  The lane part
+        // is ONE 32-bit element offset, the row part a scalar pointer per store (SALU) -- eight per-lane 64-bit addresses cost
+        // 16 VGPRs and a VALU add each
+        const unsigned loff0 = (unsigned)(wm * 32 + 4 * half) * (unsigned)a.P + (unsigned)l31;
+        auto rsub = [&](int i) { const int r = 8 * wkh + i; return (r & 3) + 8 * (r >> 2); };
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int r = 8 * wkh + i;
-            mrow[i] = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            mrow[i] = wm * 32 + rsub(i) + 4 * half;
             bias[i] = (a.bias && mrow[i] < a.M) ? a.bias[mrow[i] < a.M ? mrow[i] : 0] : 0.f;
-            loff[i] = (unsigned)(mrow[i] < a.M ? mrow[i] : 0) * (unsigned)a.P + (unsigned)l31;
         }
         f32x16 acc;
         float keep[8];
@@ -437,15 +453,15 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
             if constexpr ((DSR_DBG & 32) == 0) {
                 if (a.M == 64 && !a.relu) {  // (the training form: no guard, no clamp)
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) dsr_store(p_op + loff[i], v[i] + bias[i]);
+                    for (int i = 0; i < 8; ++i) dsr_store(p_op + (long)rsub(i) * a.P + loff0, v[i] + bias[i]);
                 } else if (a.M == 64) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) dsr_store(p_op + loff[i], fmaxf(v[i] + bias[i], 0.f));
+                    for (int i = 0; i < 8; ++i) dsr_store(p_op + (long)rsub(i) * a.P + loff0, fmaxf(v[i] + bias[i], 0.f));
                 } else {
                     const float fl = a.relu ? 0.f : -__builtin_inff();
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        if (mrow[i] < a.M) dsr_store(p_op + loff[i], fmaxf(v[i] + bias[i], fl));
+                        if (mrow[i] < a.M) dsr_store(p_op + (long)rsub(i) * a.P + loff0, fmaxf(v[i] + bias[i], fl));
                 }
             } else {
 #pragma unroll
@@ -498,7 +514,14 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
 #pragma unroll
                     for (int tt = 0; tt < NT; ++tt)
                         bf[tt] = *(const bf16x8*)(base + tt * BPL + ((ks * 32 + half * 16) ^ swz));
-                    if (NT == 3) {  // smallest terms first (the order of the other split GEMMs)
+                    if constexpr (A3L) {  // (the same six products in the same order; the third plane comes from LDS)
+                        const bf16x8 a_lo = *(const bf16x8*)(a3p + s * 64 * 16);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0], bf[2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bf[0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][1], bf[1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0], bf[1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][1], bf[0], acc, 0, 0, 0);
+                    } else if (NT == 3) {  // smallest terms first (the order of the other split GEMMs)
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0], bf[NT - 1], acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][NT - 1], bf[0], acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][NT / 2], bf[NT / 2], acc, 0, 0, 0);
@@ -569,7 +592,8 @@ int dsconv_rows_num_slots(int N, int H, int W) {
 template <int NT, bool AFF, int CPT, typename TX, typename TZ, bool PK = false>
 static int launch_dsr_cfg(const DsRowsArgs& a, hipStream_t st) {
     constexpr int ROWB = 128 * CPT * 2 + 16;
-    const size_t lds = (size_t)2 * NT * DSR_CW * ROWB + (size_t)2 * 4 * 8 * 64 * sizeof(float);
+    const size_t lds = (size_t)2 * NT * DSR_CW * ROWB + (size_t)2 * 4 * 8 * 64 * sizeof(float) +
+                       ((NT == 3 && CPT == 2) ? (size_t)4 * (4 * CPT) * 64 * 16 : 0);  // + the third weight plane (A3L)
     constexpr auto kern = k_dsconv_rows_fwd<NT, AFF, CPT, TX, TZ, PK>;
     static size_t granted = 0;
     if (lds > granted) {

@@ -512,10 +512,8 @@ def _dsconv_fwd_rows(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, 
     if not L.smaat_dsconv_rows_ok(kpl, cin, cout, h, w):
         return None
     out_dtype = out_dtype or x.dtype
-    if out_dtype != BF16 and cin > 64 and FWD_ROWS != "all":
-        # K = 256 with the exact three-term split: 96 registers of resident weight fragments per consumer wave do not fit
-        # beside 8 producer waves (33 spilled registers, 1.43 vs 1.10 ms on up4.0: profiles/r4): the tile kernel keeps it
-        return None
+    # (K = 256 with the exact three-term split -- up4.0 -- used to stay on the tile kernel: 96 registers of resident weight
+    # fragments per consumer wave spilled.  Its third weight plane now lives in LDS: 0.83 vs 1.09 ms, profiles/r4.)
     planes = (_bf16_planes_raw(w_pw.reshape(cout, -1)) if out_dtype == BF16 else _split_planes_raw(w_pw.reshape(cout, -1)))
     slots = L.smaat_dsconv_rows_num_slots(n, h, w)
     z = _new(x, n, cout, h, w, dtype=out_dtype)

@@ -57,8 +57,9 @@ def test_row_walking_kernels_do_not_drain_their_prefetch_queue():
     `s_waitcnt vmcnt(N)`.  hipcc does not see those loads -- but a compiler-visible load (the depthwise weights, the BatchNorm
     coefficients) that was still pending at the loop entry made it emit `s_waitcnt vmcnt(0)` at the value's first use INSIDE
     the loop, once per iteration, in all but two instantiations: the queue was emptied every chunk.  The kernels now use those
-    values once before the first asm load; no loop of theirs may contain a full drain.  (Exception: the f32 two-channel
-    instantiation of the fused forward spills registers -- scratch traffic needs the wait -- and is not selected by ops.py.)"""
+    values once before the first asm load; no loop of theirs may contain a full drain -- which also means no instantiation may
+    spill (scratch reloads wait with vmcnt(0)): the f32 two-channel build of the fused forward did until its third weight
+    plane moved to LDS and its store addresses to scalar row pointers."""
     import re
     import subprocess
     import tempfile
@@ -86,7 +87,5 @@ def test_row_walking_kernels_do_not_drain_their_prefetch_queue():
         for fn, n in drains.items():
             if "k_dsconv_wgrad_split" in fn or "k_dsconv_rows_fwd" in fn:
                 seen += 1
-                if "k_dsconv_rows_fwdILi3ELb" in fn and "ELi2EffLb0EE" in fn:
-                    continue  # (NT = 3, two channels per thread: 108 bytes of scratch per lane)
                 assert n == 0, (fn, f"{n} full drains of the vector-memory counter inside a loop")
         assert seen >= 12, (src, seen)
