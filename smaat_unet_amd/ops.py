@@ -234,15 +234,17 @@ def set_matrix_mode(mode):
 # same moment -- the optimizer step -- so images live in a cache keyed by the weight's storage, and the first stale image asked
 # for after a weight update refreshes ALL registered stale images in ONE launch (smaat_weight_planes_multi).  A use is served from
 # the cache only if the weight tensor is the same object at the same address with the same version counter; in-place updates
-# (optimizer, load_state_dict, DDP broadcast) bump the version, replaced parameters are new objects.  The returned image is
-# shared: callers only read it.  SMAAT_PLANE_CACHE=0 restores one launch per use.
+# (optimizer, load_state_dict, DDP broadcast) bump the version, replaced parameters are new objects; and because writes through
+# `.data` bump nothing, an image is served at most ONCE per refresh -- its second use (a new pass over the network) refreshes all
+# images again, so such writes are honoured from the next pass on, at one launch per pass.  The returned image is shared: callers
+# only read it.  SMAAT_PLANE_CACHE=0 restores one launch per use.
 PLANE_CACHE = os.environ.get("SMAAT_PLANE_CACHE", "1") != "0"
 _PLANES = {}
 _PLANES_TABLE = {}  # tuple of entry ids -> device descriptor table
 
 
 class _PlaneEntry:
-    __slots__ = ("ref", "off", "src", "version", "planes", "r", "c", "kind", "src_t", "dev", "stream", "mode", "nblk")
+    __slots__ = ("ref", "off", "src", "version", "planes", "r", "c", "kind", "src_t", "dev", "stream", "mode", "nblk", "used")
 
 
 def _weight_planes(w2d, transpose, kind):
@@ -273,14 +275,21 @@ def _weight_planes(w2d, transpose, kind):
     mode = L.smaat_split_mode() if kind == 0 else -1
     key = (w2d.data_ptr(), r, c, bool(transpose), kind, mode, stream)
     e = _PLANES.get(key)
+    force = False
     if e is not None and e.ref() is base:
         if e.version == base._version:
-            return e.planes
+            if not e.used:
+                e.used = True
+                return e.planes
+            # second use of an image since its last refresh: a new pass over the network with (as far as the version counters
+            # say) unchanged weights -- gradient accumulation, repeated evaluation, or weights written through `.data`, which no
+            # counter sees.  Refresh everything once per pass: one launch, and `.data` writes between passes are honoured.
+            force = True
     else:
         e = _PlaneEntry()
         e.ref, e.off, e.src = weakref.ref(base), w2d.data_ptr() - base.data_ptr(), w2d.data_ptr()
         e.version, e.r, e.c, e.kind, e.src_t = -1, r, c, kind, 1 if transpose else 0
-        e.dev, e.stream, e.mode = w2d.device, stream, mode
+        e.dev, e.stream, e.mode, e.used = w2d.device, stream, mode, False
         e.nblk = (r * cp + 255) // 256
         e.planes = torch.empty(shape, dtype=torch.int16, device=w2d.device)
         _PLANES[key] = e
@@ -290,7 +299,7 @@ def _weight_planes(w2d, transpose, kind):
         b = x.ref()
         if b is None or b.data_ptr() + x.off != x.src:
             dead.append(k)
-        elif x.dev == e.dev and x.stream == stream and (x.kind != 0 or x.mode == mode) and x.version != b._version:
+        elif x.dev == e.dev and x.stream == stream and (x.kind != 0 or x.mode == mode) and (force or x.version != b._version):
             stale.append((x, b._version))
     for k in dead:
         del _PLANES[k]
@@ -307,7 +316,8 @@ def _weight_planes(w2d, transpose, kind):
         _PLANES_TABLE[ids] = table
     _lib.check(L.smaat_weight_planes_multi(_ptr(table[0]), len(stale), table[1], stream), "smaat_weight_planes_multi")
     for x, v in stale:
-        x.version = v
+        x.version, x.used = v, False
+    e.used = True
     return e.planes
 
 

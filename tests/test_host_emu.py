@@ -763,3 +763,32 @@ def test_weight_images_are_refreshed_in_one_launch_per_optimizer_step(mode, monk
     for step in (1, 2):
         assert c1[step] == [("multi", n_images)], c1[step][:5]
     assert all(k != "multi" for k, _ in c0[1]) and len(c0[1]) == n_images  # without the cache: one launch per image
+
+
+def test_weight_image_cache_honours_writes_through_data(monkeypatch):
+    """`p.data.mul_()` bumps no version counter.  An image is served at most once per refresh, so the next pass over the
+    network refreshes everything (one launch) and sees the written weights; a second pass WITHOUT any write costs one launch
+    too (gradient accumulation) and changes nothing."""
+    from smaat_unet_amd import ops as _ops
+
+    def run(cache):
+        monkeypatch.setattr(_ops, "PLANE_CACHE", cache)
+        _ops._PLANES.clear()
+        _ops._PLANES_TABLE.clear()
+        torch.manual_seed(1)
+        mod = S.DoubleConvDS(32, 32, kernels_per_layer=2).train()
+        x = torch.randn(2, 32, 16, 16)
+        outs = []
+        with torch.no_grad():
+            outs.append(mod(x).clone())
+            outs.append(mod(x).clone())                 # nothing written: same result
+            v0 = mod.double_conv[0].pointwise.weight._version
+            mod.double_conv[0].pointwise.weight.data.mul_(1.5)   # invisible to the version counter
+            assert mod.double_conv[0].pointwise.weight._version == v0
+            outs.append(mod(x).clone())
+        return outs
+
+    a, b = run(False), run(True)
+    assert torch.equal(a[0], a[1]) and not torch.equal(a[1], a[2])
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
