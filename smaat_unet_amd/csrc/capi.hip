@@ -542,7 +542,10 @@ int smaat_dsconv_fwd_split_act(const float* x, long x_bs, const float* in_scale,
         const char* e = getenv("SMAAT_EVAL_ROWS");
         rows_eval = e ? atoi(e) : 1;
     }
+    // (more than 64 input channels -- two channels per producer thread -- only from a few frames on: at batch 1 a 288 x 288 layer
+    // is 216 short items and that build takes 32 us against the tile kernel's 27, profiles/r4/eval_b1_kernel_table_r4_final.txt)
     if (rows_eval && x && w_dw && planes && z && N >= 1 && kpl == 2 && dsconv_rows_ok(kpl, Cin, Cout, H, W) &&
+        (Cin <= 64 || (long)N * H * W >= 4L * 288 * 288) &&
         (in_scale == nullptr) == (in_shift == nullptr)) {
         DsRowsArgs r{};
         r.x = x; r.x_bs = x_bs; r.in_scale = in_scale; r.in_shift = in_shift; r.w_dw = w_dw; r.b_dw = b_dw;
