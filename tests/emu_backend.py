@@ -10,6 +10,7 @@ The product package never imports this file.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import numpy as np
 
@@ -38,6 +39,31 @@ def planes(ptr, n, c, p, bs):
 PW_SLOTS = 3
 PLANE_SLOTS = 2
 WG_SPLITS = 2
+
+
+# ---- study switch (scripts/probes/split_formats_network.py, DESIGN 4.7 "what comes next"): SMAAT_EMU_GEMM=f16x2 makes the
+# emulated f32-storage GEMMs (forward, data gradient, weight gradient, fused forwards) use a TWO-term fp16 operand split with a
+# per-tensor power-of-two scale and three products per term pair -- the candidate replacement of the exact three-term bf16 split --
+# so that the reference-generated network fixtures can be run against it on the CPU.  Default: plain float32 einsum, as before.
+def _f16x2_terms(x):
+    x = np.asarray(x, np.float32)
+    m = float(np.abs(x).max())
+    s = np.float32(2.0 ** (14 - np.ceil(np.log2(m)))) if m > 0 else np.float32(1.0)
+    xs = (x * s).astype(np.float32)
+    p1 = xs.astype(np.float16).astype(np.float32)
+    p2 = (xs - p1).astype(np.float16).astype(np.float32)
+    return p1, p2, np.float32(s)  # (float32 holds an fp16 value exactly; products of two such values too: 22 bits)
+
+
+def mm(spec, a, b):
+    """np.einsum(spec, a, b) in float32 -- or, under SMAAT_EMU_GEMM=f16x2, a0 b0 + a0 b1 + a1 b0 of the two-term fp16 splits"""
+    if os.environ.get("SMAAT_EMU_GEMM", "") != "f16x2":
+        return np.einsum(spec, a, b)
+    a0, a1, sa = _f16x2_terms(a)
+    b0, b1, sb = _f16x2_terms(b)
+    r = (np.einsum(spec, a1, b0) + np.einsum(spec, a0, b1)) + np.einsum(spec, a0, b0)  # float32 accumulation, as the MFMA's
+    return (r / (sa * sb)).astype(np.float32)
+
 
 
 class EmuLib:
@@ -149,7 +175,7 @@ class EmuLib:
         u = u.transpose(1, 2, 0, 3).reshape(3, M, Cp)
         a = ((u.astype(np.uint32) << np.uint32(16)).view(np.float32)).astype(np.float64).sum(axis=0)[:, :Cin]
         xv = planes(x, N, Cin, P, x_bs)
-        acc = np.einsum("mc,ncp->nmp", a.astype(np.float32), xv)
+        acc = mm("mc,ncp->nmp", a.astype(np.float32), xv)
         planes(out, N, M, P, out_bs)[:] = acc + (f32(bias, M)[None, :, None] if bias else 0)
         self._write_part(part, PW_SLOTS + 1, M, acc)
         return 0
@@ -172,7 +198,7 @@ class EmuLib:
         u = np.ctypeslib.as_array((ctypes.c_uint16 * (3 * Cout * Kp)).from_address(int(pl))).reshape(Kp // 16, 3, Cout, 16)
         u = u.transpose(1, 2, 0, 3).reshape(3, Cout, Kp)
         a = ((u.astype(np.uint32) << np.uint32(16)).view(np.float32)).astype(np.float64).sum(axis=0)[:, :K]
-        acc = np.einsum("mk,nkp->nmp", a.astype(np.float32), y.reshape(N, K, P))
+        acc = mm("mk,nkp->nmp", a.astype(np.float32), y.reshape(N, K, P))
         planes(z, N, Cout, P, z_bs)[:] = acc + (f32(b_pw, Cout)[None, :, None] if b_pw else 0)
         self._write_part(part, T, Cout, acc)
         if y_out:
@@ -265,7 +291,7 @@ class EmuLib:
             xv = np.maximum(xv * sc[None, :, None, None] + sh[None, :, None, None], 0)
         y = O.dw3x3_fwd(xv, f32(w_dw, K * 9).reshape(K, 1, 3, 3), f32(b_dw, K) if b_dw else None, kpl)
         dzv = planes(dz, N, Cout, P, dz_bs)
-        f32(dw_out, Cout * K).reshape(Cout, K)[:] = np.einsum("nmp,nkp->mk", dzv, y.reshape(N, K, P))
+        f32(dw_out, Cout * K).reshape(Cout, K)[:] = mm("nmp,nkp->mk", dzv, y.reshape(N, K, P))
         return 0
 
     def smaat_dsconv_wgrad_split_ok(self, kpl, Cout, H, W):
@@ -283,7 +309,7 @@ class EmuLib:
 
     def smaat_pointwise_wgrad(self, x, x_bs, dz, dz_bs, ws, dw_out, N, Cin, M, H, W, stream):
         P = H * W
-        f32(dw_out, M * Cin).reshape(M, Cin)[:] = np.einsum("nmp,nkp->mk", planes(dz, N, M, P, dz_bs),
+        f32(dw_out, M * Cin).reshape(M, Cin)[:] = mm("nmp,nkp->mk", planes(dz, N, M, P, dz_bs),
                                                              planes(x, N, Cin, P, x_bs))
         return 0
 
@@ -1051,7 +1077,7 @@ def _t_dsconv_fwd_rows(self, x, x_dt, x_bs, in_scale, in_shift, w_dw, b_dw, pl, 
         u = np.ctypeslib.as_array((ctypes.c_uint16 * (3 * Cout * Kp)).from_address(int(pl))).reshape(Kp // 16, 3, Cout, 16)
         u = u.transpose(1, 2, 0, 3).reshape(3, Cout, Kp)
         a = ((u.astype(np.uint32) << np.uint32(16)).view(np.float32)).astype(np.float64).sum(axis=0)[:, :K]
-        acc = np.einsum("mk,nkp->nmp", a.astype(np.float32), y)
+        acc = mm("mk,nkp->nmp", a.astype(np.float32), y)
     else:
         Kp = (K + 31) // 32 * 32
         u = np.ctypeslib.as_array((ctypes.c_uint16 * (Cout * Kp)).from_address(int(pl))).reshape(Kp // 16, Cout, 16)
