@@ -8,6 +8,12 @@
 #include <cstdlib>
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+// -DPROBE_F16=1 (round 4, for the two-term fp16 split studied in DESIGN 4.7): the same chains on v_mfma_f32_32x32x16_f16 with
+// operands whose 10 mantissa bits are random -- does the fp16 pipe sustain what the bf16 pipe does under the power limit?
+#ifndef PROBE_F16
+#define PROBE_F16 0
+#endif
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // mode 0: constant operands; 1: pseudo-random operands, fixed per lane; 2: pseudo-random operands that change every trip
@@ -19,13 +25,14 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
         s ^= s << 13;
         s ^= s >> 17;
         s ^= s << 5;
+        if (PROBE_F16) return (short)(((s >> 8) & 0x83FF) | 0x3C00);  // fp16: sign + 10 mantissa bits random, exponent of 1.0
         return (short)(((s >> 8) & 0x807F) | 0x3F00);  // sign + 7 mantissa bits random, exponent near 1: finite
     };
     bf16x8 a[3], b[3];
     for (int t = 0; t < 3; ++t)
         for (int e = 0; e < 8; ++e) {
-            a[t][e] = MODE == 0 ? (short)0x3F80 : rnd16();
-            b[t][e] = MODE == 0 ? (short)0x3F80 : rnd16();
+            a[t][e] = MODE == 0 ? (short)(PROBE_F16 ? 0x3C00 : 0x3F80) : rnd16();
+            b[t][e] = MODE == 0 ? (short)(PROBE_F16 ? 0x3C00 : 0x3F80) : rnd16();
         }
     f32x16 acc[4];
     for (int i = 0; i < 4; ++i)
@@ -38,13 +45,19 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {  // the six-term order of the split GEMMs
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[i], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) {  // the six-term order of the split GEMMs (fp16: the same six issue slots)
+#if PROBE_F16
+#define MF(A, B) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), acc[i], 0, 0, 0)
+#else
+#define MF(A, B) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, acc[i], 0, 0, 0)
+#endif
+            MF(a[0], b[2]);
+            MF(a[2], b[0]);
+            MF(a[1], b[1]);
+            MF(a[0], b[1]);
+            MF(a[1], b[0]);
+            MF(a[0], b[0]);
+#undef MF
         }
         if ((it & 63) == 63)  // keep the accumulators finite
             for (int i = 0; i < 4; ++i)
