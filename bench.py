@@ -527,8 +527,8 @@ def main():
                   peak_name=BF16),
             klass(["smaat_dsconv_fwd_split"] + (["smaat_dsconv_fwd_rows"] if args.precision != "bf16" else []), "mfma",
                   PEAK_BF16_MFMA_TFLOPS, "TFLOP/s", nt,
-                  "k_dsconv_rows_fwd / k_dsconv_split: fused depthwise 3x3 -> split GEMM forward of the 288^2 layers (row-walking "
-                  "register window + register-resident weight fragments where Cin <= 64, pixel-tile kernel for K = 256); no "
+                  "k_dsconv_rows_fwd: fused depthwise 3x3 -> split GEMM forward of the 288^2 layers (row-walking "
+                  "register window + register-resident weight fragments; K = 256: the third weight plane in LDS); no "
                   "depthwise tensor in HBM", pmc=("k_dsconv_rows_fwd", "k_dsconv_split"), peak_name=BF16),
             klass(["smaat_dsconv_wgrad_split"], "mfma", PEAK_BF16_MFMA_TFLOPS, "TFLOP/s", nt,
                   "k_dsconv_wgrad_split: pointwise weight gradient of the 288^2 layers with the depthwise output recomputed from "
