@@ -23,7 +23,7 @@ from tests.test_host_emu import check_param_grads, check_summary, rel  # noqa: E
 
 _ops.SPLIT_POLICY = "all"  # every supported layer through the split-GEMM wiring
 GOLD = os.path.join(ROOT, "tests", "golden")
-for name in ("unet_12x1_n2_32", "unet_3x21_n1_32", "unet_12x1_n3_64x48"):
+for name in ("unet_12x1_n2_32", "unet_3x21_n1_32", "unet_12x1_n2_64x48"):
     path = os.path.join(GOLD, name + ".npz")
     if not os.path.exists(path):
         continue
