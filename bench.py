@@ -505,8 +505,9 @@ def main():
             if c and "frac_executed" in c:
                 c["frac_algorithmic_vs_bf16_peak"] = c["frac"]
                 c["frac"] = c["frac_executed"]
-                c["frac_definition"] = ("executed bf16 MFMA TFLOP/s (6 per f32 product) / 2500 = matrix-pipe utilisation; "
-                                        "equivalently algorithmic TFLOP/s / the 417 TFLOP/s an exact-f32 six-MFMA split can reach")
+                m_ = round(c["executed"] / max(c["algorithmic_tflops"], 1e-9))
+                c["frac_definition"] = (f"executed 16-bit MFMA TFLOP/s ({m_} per f32 product) / 2500 = matrix-pipe utilisation; "
+                                        f"equivalently algorithmic TFLOP/s / the {2500 // max(m_, 1)} TFLOP/s a {m_}-MFMA split can reach")
                 # measured on this part (profiles/r3/mfma_power_probe_r3.txt, clock_under_load_r3.txt): bare MFMA chains on
                 # operands with random bits sustain 1960 TFLOP/s (1.99 GHz, 1.32 kW); this kernel class runs at the 1400 W
                 # board limit with the clock at ~1.8 GHz
@@ -520,7 +521,15 @@ def main():
         F32 = "f32-input MFMA 157.3 TFLOP/s"
         HBM = "HBM3E 8000 GB/s"
         nt = 6.0 if _lib.get().smaat_split_mode() == 3 else (3.0 if _lib.get().smaat_split_mode() == 2 else 1.0)
+        F16 = "dense fp16 MFMA 2500 TFLOP/s (the pipe the kernel runs on)"
         classes = [
+            klass(["smaat_pointwise_fwd_split_h", "smaat_pointwise_fwd_split_k_h"], "mfma", PEAK_BF16_MFMA_TFLOPS, "TFLOP/s", 3.0,
+                  "k_pw_split_p<NT=2>: persistent wave-specialised GEMM on the TWO-term fp16 operand split (three "
+                  "v_mfma_f32_32x32x16_f16 per product, per-tensor power-of-two scales from the producing kernels' maxima): "
+                  "pointwise forward of the GEMM-sized layers + every data gradient", pmc=("k_pw_split",), peak_name=F16),
+            klass(["smaat_pointwise_wgrad_h"], "mfma", PEAK_BF16_MFMA_TFLOPS, "TFLOP/s", 3.0,
+                  "k_wgrad_split<NT=2>: streamed pointwise weight gradient on the two-term fp16 split", pmc=("k_wgrad_split",),
+                  peak_name=F16),
             klass(["smaat_pointwise_fwd_split"], "mfma", PEAK_BF16_MFMA_TFLOPS, "TFLOP/s", nt,
                   "k_pw_split_p: persistent wave-specialised GEMM (v_mfma_f32_32x32x16_bf16, exact 3-term operand "
                   "split): pointwise forward of the GEMM-sized layers + every data gradient", pmc=("k_pw_split",),
@@ -543,9 +552,11 @@ def main():
             klass(["smaat_dw3x3_bwd", "smaat_dw3x3_bwd_bnred"], "hbm", PEAK_HBM_GBS, "GB/s", 1.0,
                   "k_dw3x3_bwd_rows (register row-streaming depthwise backward, + the fused BatchNorm reduction)",
                   pmc=("k_dw3x3_bwd",), peak_name=HBM),
-            klass(["smaat_dw3x3_fwd"], "hbm", PEAK_HBM_GBS, "GB/s", 1.0, "k_dw3x3_fwd_rows (register row-streaming "
-                  "depthwise forward)", pmc=("k_dw3x3_fwd",), peak_name=HBM),
-            klass(["smaat_bn_bwd_apply", "smaat_bn_bwd_reduce", "smaat_affine_act"], "hbm", PEAK_HBM_GBS, "GB/s", 1.0,
+            klass(["smaat_dw3x3_fwd", "smaat_dw3x3_fwd_amax"], "hbm", PEAK_HBM_GBS, "GB/s", 1.0, "k_dw3x3_fwd_rows (register "
+                  "row-streaming depthwise forward; _amax: + the maximum of its output for the fp16 split)", pmc=("k_dw3x3_fwd",),
+                  peak_name=HBM),
+            klass(["smaat_bn_bwd_apply", "smaat_bn_bwd_apply_amax", "smaat_bn_bwd_reduce", "smaat_affine_act"], "hbm", PEAK_HBM_GBS,
+                  "GB/s", 1.0,
                   "BatchNorm/ReLU streaming kernels", pmc=("k_bn_bwd_apply", "k_bn_bwd_reduce", "k_affine_act"),
                   peak_name=HBM),
         ]
@@ -576,8 +587,11 @@ def main():
         roof["other_classes"] = classes[1:]
         roof["matrix_path"] = ("mixed precision: bf16 activations / weights images into v_mfma_f32_32x32x16_bf16, one MFMA "
                                "per product, f32 accumulate" if args.precision == "bf16" else
-                               "f32 operands split exactly into 3 bf16 terms, 6 bf16 MFMAs per product, f32 accumulate "
-                               "(f32-class error, tests/ + profiles/); SMAAT_SPLIT=0 selects the f32-MFMA kernels only"
+                               "f32 operands on the 16-bit matrix pipe: two-term fp16 split with per-tensor power-of-two scales, "
+                               "3 fp16 MFMAs per product (GEMMs whose operands come with their maxima: *_h entry points) or the "
+                               "exact three-term bf16 split, 6 bf16 MFMAs per product (fused forwards, recompute weight gradients); "
+                               "f32 accumulate, f32-class error (tests/ + profiles/); SMAAT_F16_SPLIT=0 = three-term split only, "
+                               "SMAAT_SPLIT=0 = f32-MFMA kernels only"
                                if split else "f32 MFMA (v_mfma_f32_32x32x2_f32) only")
         roof["definition"] = ("achieved = ALGORITHMIC flops (2 K Cout HW N per launch) or bytes (SURVEY 8(d)) / HIP-event time; "
                               "frac = achieved / peak for HBM-bound classes and for the f32-MFMA family; for the bf16-split "

@@ -251,7 +251,7 @@ int smaat_cbam_bwd_final_pool(float* dx, long dx_bs, const float* davg, const fl
  *      sites as smaat_dsconv_fwd / smaat_pointwise_fwd; the depthwise stage runs as its own kernel
  *      and the pointwise GEMM reads its output.
  *   smaat_split_mode / smaat_set_split_mode (process-wide switch, initial value from env SMAAT_SPLIT, default 3):
- *        0 = f32-MFMA kernels only; 3 = exact three-term split (f32-class error); 2 = two-term split (~1e-5);
+ *        0 = f32-MFMA kernels only; 3 (and 2) = exact three-term split (f32-class error);
  *        1 = operands rounded to bf16, ONE MFMA per product = the bf16 mixed-precision mode of BASELINE
  *        configs[3] (f32 storage, f32 accumulation, ~1e-2 class).  set returns the previous mode, -1 on a bad argument.
  *   smaat_split_enabled: 1 when mode != 0
@@ -282,6 +282,48 @@ int smaat_dw3x3_fwd(const float* x, long x_bs, const float* in_scale, const floa
                     const float* b_dw, float* y, long y_bs, int N, int Cin, int kpl, int H, int W, void* stream);
 int smaat_pointwise_fwd_split(const float* x, long x_bs, const void* planes, const float* bias, float* out,
                               long out_bs, float* part, int N, int Cin, int M, int H, int W, void* stream);
+
+/* ---- two-term fp16 split (round 5): the same GEMMs with THREE fp16 MFMAs per product instead of six bf16 ones.
+ *      reference call sites: nn.Conv2d(K, Cout, 1) forward and its autograd (data and weight gradient),
+ *      models/layers.py:45,49 -- the arithmetic the reference leaves to MKLDNN / cuDNN in f32.
+ *   An f32 operand tensor T is used as  T * 2^k = h + g + O(2^-22 |T| 2^k),  h = fp16(T 2^k), g = fp16(T 2^k - h)  (round to
+ *   nearest), with ONE power-of-two scale per operand tensor: k puts max |T| into [2^14, 2^15).  A product is evaluated as
+ *   h_a h_b + h_a g_b + g_a h_b (each an exact 22-bit product, f32 accumulation) and the accumulator is scaled back by the exact
+ *   2^-(k_a + k_b): f32-class error (tests/test_gpu_kernels.py: next to the three-term split against fp64, incl. operands with
+ *   one channel 1e8 above the rest, gradients in the denormal range, all-zero planes).
+ *   The maxima are produced by the kernels that WRITE the operands, as a side output `amax`: ONE device word (uint32 bit pattern
+ *   of a non-negative float) that must hold 0 before the producing launch and afterwards holds max |v| over the tensor
+ *   (order-independent: bit-reproducible):
+ *     smaat_dw3x3_fwd_amax      = smaat_dw3x3_fwd + amax of y; -2 when the row-streaming kernel does not take the shape
+ *                                 (then: smaat_dw3x3_fwd and the three-term GEMMs)
+ *     smaat_bn_bwd_apply_amax   = smaat_bn_bwd_apply (head_w null) or smaat_bn_bwd_apply_head (head_w [C], dy = dlog) + amax of dz
+ *   Weights:  smaat_split_planes_h (transposed = 1: the image of w^T, w stored [C][R]) writes the fp16 image
+ *     [Cp/16][2][R][16] of w * 2^kexp followed by the trailer { int32 kexp; 12 bytes; scratch } into a buffer of
+ *     smaat_split_planes_h_bytes(R, C) bytes (16-byte aligned); its maximum is taken by a first launch over
+ *     smaat_split_planes_h_pieces(R, C) 4096-element pieces -- no atomics, no state.  In smaat_weight_planes_multi_h (the
+ *     one-launch-per-step refresh) such an image is a descriptor of kind 3 and h_pieces = the sum of the pieces of all kind-3
+ *     rows (0: exactly smaat_weight_planes_multi).
+ *   GEMMs (arguments as the entry points without the suffix; x_amax / dz_amax = the operands' amax words, planes = an fp16 image):
+ *     smaat_pointwise_fwd_split_h, smaat_pointwise_fwd_split_k_h, smaat_pointwise_wgrad_h (x = the kept depthwise output).
+ *   A NaN / Inf in an operand gives k = 0 for that tensor and propagates through the fp16 terms.
+ */
+int smaat_dw3x3_fwd_amax(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                         const float* b_dw, float* y, long y_bs, void* amax, int N, int Cin, int kpl, int H, int W,
+                         void* stream);
+int smaat_bn_bwd_apply_amax(const float* dy, long dy_bs, const float* head_w, const float* z, long z_bs, const float* scale,
+                            const float* shift, const float* mean, const float* invstd, const float* coef, float* dz,
+                            long dz_bs, void* amax, int N, int C, int P, int relu, void* stream);
+int smaat_split_planes_h_bytes(int R, int C);
+int smaat_split_planes_h_pieces(int R, int C);
+int smaat_split_planes_h(const float* w, int R, int C, void* planes, int transposed, void* stream);
+int smaat_weight_planes_multi_h(const void* desc, int n_desc, int total_blocks, int h_pieces, void* stream);
+int smaat_pointwise_fwd_split_h(const float* x, long x_bs, const void* x_amax, const void* planes, const float* bias,
+                                float* out, long out_bs, float* part, int N, int Cin, int M, int H, int W, void* stream);
+int smaat_pointwise_fwd_split_k_h(const float* x, long x_bs, const void* x_amax, const void* planes, const float* bias,
+                                  float* out, long out_bs, float* part, float* ws, int S, int N, int Cin, int M, int H, int W,
+                                  void* stream);
+int smaat_pointwise_wgrad_h(const float* x, long x_bs, const void* x_amax, const float* dz, long dz_bs, const void* dz_amax,
+                            float* ws, float* dw_out, int N, int Cin, int M, int H, int W, void* stream);
 
 /* ---- fused DepthwiseSeparableConv forward on the bf16-split matrix pipe (training path of the plane-dominated
  *      layers; same reference call site as smaat_dsconv_fwd, models/layers.py:47-50).  The depthwise output never

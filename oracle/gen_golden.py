@@ -314,6 +314,25 @@ def gen_ops_strict():
     print("ops_strict.npz:", len(s), "arrays")
 
 
+def gen_ops_strict_rows():
+    """Round 5 (VERDICT r4 next #1a): tie-free block fixtures whose shapes ROUTE THROUGH the row-walking fused forward
+    (csrc/dsrows.hip) and the recompute weight gradient (csrc/dswgrad.hip): kernels_per_layer 2, W % 32 == 0, <= 64 output
+    channels, 32 ... 128 input channels -- DoubleConvDS(32, 64) (K = 64 and K = 128 halves) and UpDS(128, 64) (K = 256 and
+    K = 128 halves), on planes small enough that a draw with every ReLU >= 2e-4 (of the tensor's rms) away from a tie exists
+    (the chance per draw is ~exp(-1.6e-4 * elements): 8 x 32 planes).  Own file and own seed: ops_strict.npz stays as it is."""
+    rng = np.random.default_rng(5151)
+    s = {}
+    f32 = lambda r, *shape: r.standard_normal(shape).astype(np.float32)  # noqa: E731
+    module_case_strict(s, "rows_doubleconv_32_64", lambda: DoubleConvDS(32, 64, kernels_per_layer=2),
+                       lambda r: [f32(r, 1, 32, 8, 32)], rng, max_tries=20000)
+    module_case_strict(s, "rows_doubleconv_64_64_w64", lambda: DoubleConvDS(64, 64, kernels_per_layer=2),
+                       lambda r: [f32(r, 1, 64, 4, 64)], rng, max_tries=20000)
+    module_case_strict(s, "rows_up_128_64", lambda: UpDS(128, 64, bilinear=True, kernels_per_layer=2),
+                       lambda r: [f32(r, 1, 64, 4, 16), f32(r, 1, 64, 8, 32)], rng, max_tries=20000)
+    np.savez_compressed(os.path.join(OUT, "ops_strict_rows.npz"), **s)
+    print("ops_strict_rows.npz:", len(s), "arrays")
+
+
 def summarize(store, tag, arr, full_max=8192, nsample=4096, store_idx=True):
     """small tensors in full; large ones as l2 norm + sum + `nsample` evenly spaced samples (the sample positions
     are np.linspace(0, size - 1, nsample) -- stored, or with store_idx=False recomputed by the reader)"""
@@ -885,6 +904,7 @@ def _jobs():
     J["ops"] = gen_ops
     J["ops_eval"] = gen_ops_eval
     J["ops_strict"] = gen_ops_strict
+    J["ops_strict_rows"] = gen_ops_strict_rows
     J["ops_generic"] = gen_ops_generic
     # benchmark-size cases, train + eval mode (inputs regenerated from the seed, summaries only)
     J["unet_12x1_n2_288"] = lambda: gen_unet_big("unet_12x1_n2_288", "precip", 12, 1, 2, 288, 288, 7)   # configs[1] shape

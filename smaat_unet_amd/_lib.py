@@ -94,6 +94,16 @@ SIGNATURES = {
     "smaat_pointwise_fwd_split_act_k": [_P, _L, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P],
     "smaat_pointwise_splitk_slices": [_I, _I, _I, _I, _I, _I],
     "smaat_pointwise_fwd_split_k": [_P, _L, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    # ---- two-term fp16 split (three fp16 MFMAs per product; operand maxima from the producing kernels) ----
+    "smaat_dw3x3_fwd_amax": [_P, _L, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P],
+    "smaat_bn_bwd_apply_amax": [_P, _L, _P, _P, _L, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _P],
+    "smaat_split_planes_h_bytes": [_I, _I],
+    "smaat_split_planes_h_pieces": [_I, _I],
+    "smaat_split_planes_h": [_P, _I, _I, _P, _I, _P],
+    "smaat_weight_planes_multi_h": [_P, _I, _I, _I, _P],
+    "smaat_pointwise_fwd_split_h": [_P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P],
+    "smaat_pointwise_fwd_split_k_h": [_P, _L, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "smaat_pointwise_wgrad_h": [_P, _L, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     # ---- mixed precision (bf16 activation storage) ----
     "smaat_bf16_planes": [_P, _I, _I, _P, _I, _P],
     "smaat_pointwise_fwd_bf16": [_P, _L, _P, _P, _P, _L, _I, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -228,6 +238,13 @@ WORK_MODELS = {
     "smaat_dw3x3_bwd_bnred": lambda a: (38.0 * a[15] * a[16] * a[17] * a[18] * a[19],
                                         4.0 * a[15] * (a[16] * a[17] + 2 * a[16]) * a[18] * a[19]),
     "smaat_pointwise_fwd_split": _w_pw_split,
+    "smaat_pointwise_fwd_split_h": lambda a: (2.0 * a[8] * a[9] * a[10] * a[11] * a[12], 4.0 * a[8] * (a[9] + a[10]) * a[11] * a[12]),
+    "smaat_pointwise_fwd_split_k_h": lambda a: (2.0 * a[10] * a[11] * a[12] * a[13] * a[14],
+                                                4.0 * a[10] * (a[11] + a[12]) * a[13] * a[14]),
+    "smaat_pointwise_wgrad_h": lambda a: (2.0 * a[8] * a[9] * a[10] * a[11] * a[12], 4.0 * a[8] * (a[9] + a[10]) * a[11] * a[12]),
+    "smaat_dw3x3_fwd_amax": lambda a: (18.0 * a[9] * a[10] * a[11] * a[12] * a[13],
+                                       4.0 * a[9] * a[10] * (1 + a[11]) * a[12] * a[13]),
+    "smaat_bn_bwd_apply_amax": lambda a: (8.0 * a[13] * a[14] * a[15], (12.0 if not a[2] else 8.0) * a[13] * a[14] * a[15]),
     "smaat_dw3x3_fwd": lambda a: (18.0 * a[8] * a[9] * a[10] * a[11] * a[12],
                                   4.0 * a[8] * a[9] * (1 + a[10]) * a[11] * a[12]),
     "smaat_dsconv_fwd": _w_dsconv_fwd,
@@ -260,7 +277,7 @@ class Profiler:
         for name in SIGNATURES:
             fn = getattr(self.lib, name)
             if name.endswith(("_slots", "_splits", "_blocks", "_version", "_ws_rows", "_enabled", "_mode", "_bytes", "_ok",
-                              "_slices", "_floats")):
+                              "_slices", "_floats", "_pieces")):
                 continue
             self._orig[name] = fn
             setattr(self.lib, name, self._wrap(name, fn))

@@ -308,10 +308,12 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const TG* __restrict__ dy,
                                                       const float* __restrict__ invstd,
                                                       const float* __restrict__ coef, TD* __restrict__ dz,
                                                       long dz_bs, int C, int P, int seg_len,
-                                                      const float* __restrict__ hw) {
+                                                      const float* __restrict__ hw, unsigned* __restrict__ amax) {
+    // amax (nullable): max |dz| over the whole tensor, for the two-term fp16 split GEMMs that read dz (common.h)
     const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
     const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
     const float c1 = coef[c], c2 = coef[C + c], c3 = coef[2 * C + c];
+    float am = 0.f;
     const float wc = HEAD ? hw[c] : 1.f;  // HEAD: dy[n][c][p] = hw[c] * dlog[n][p], see k_bn_bwd_reduce
     const TZ* zp = z + (long)n * z_bs + (long)c * P;
     const TG* gp = dy + (long)n * dy_bs + (HEAD ? 0L : (long)c * P);
@@ -332,6 +334,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const TG* __restrict__ dy,
                 float g = HEAD ? wc * gg[j] : gg[j];
                 if (RELU && !(fmaf(zz[j], sc, sh) > 0.f)) g = 0.f;
                 o[j] = c1 * (g - c2 - (zz[j] - mu) * is * c3);
+                am = fmaxf(am, fabsf(o[j]));
             }
             st4(op + p, make_float4(o[0], o[1], o[2], o[3]));
         };
@@ -352,9 +355,12 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const TG* __restrict__ dy,
             const float zz = ld1(zp + p);
             float g = HEAD ? wc * ld1(gp + p) : ld1(gp + p);
             if (RELU && !(fmaf(zz, sc, sh) > 0.f)) g = 0.f;
-            st1(op + p, c1 * (g - c2 - (zz - mu) * is * c3));
+            const float o = c1 * (g - c2 - (zz - mu) * is * c3);
+            am = fmaxf(am, fabsf(o));
+            st1(op + p, o);
         }
     }
+    if (amax) amax_publish(amax, am);
 }
 
 // ---------------------------------------------------------------------------------
@@ -519,12 +525,12 @@ int launch_bn_bwd_finalize(const float* part, int slots, int C, double count, co
 
 int launch_bn_bwd_apply(const void* dy, int dy_dt, long dy_bs, const void* z, int z_dt, long z_bs, const float* scale,
                         const float* shift, const float* mean, const float* invstd, const float* coef, void* dz, int dz_dt,
-                        long dz_bs, int N, int C, int P, int relu, hipStream_t st, const float* hw) {
+                        long dz_bs, int N, int C, int P, int relu, hipStream_t st, const float* hw, unsigned* amax) {
     const int seg = plane_seg_len(P);
     dim3 grid(N * C, cdiv(P, seg));
 #define BNA_GO(R, H, TG, TZ, TD)                                                                                        \
     hipLaunchKernelGGL((k_bn_bwd_apply<R, H, TG, TZ, TD>), grid, dim3(256), 0, st, (const TG*)dy, dy_bs, (const TZ*)z, z_bs,  \
-                       scale, shift, mean, invstd, coef, (TD*)dz, dz_bs, C, P, seg, hw)
+                       scale, shift, mean, invstd, coef, (TD*)dz, dz_bs, C, P, seg, hw, amax)
 #define BNA_T(TG, TZ, TD)                                                              \
     do {                                                                               \
         if (hw) {                                                                      \

@@ -8,7 +8,10 @@
 
 int launch_wgrad2(Wg2Args& a, hipStream_t st);
 #include "rows_args.h"  // DsRowsArgs (dsrows.hip), DsWgArgs (dswgrad.hip)
-int launch_weight_planes_multi(const long long* desc, int nd, int total_blocks, hipStream_t st);  // splitmma.hip
+int launch_weight_planes_multi(const long long* desc, int nd, int total_blocks, hipStream_t st, int h_pieces = 0);  // splitmma.hip
+int launch_split_planes_h(const float* w, int R, int C, unsigned short* out, int src_t, hipStream_t st);
+long split_planes_h_bytes(int R, int C);
+long split_planes_h_kexp_offset(int R, int C);
 int dsconv_rows_ok(int kpl, int Cin, int M, int H, int W);
 int dsconv_rows_num_slots(int N, int H, int W);
 int launch_dsconv_rows(DsRowsArgs& a, int kpl, int x_dt, int z_dt, hipStream_t st);
@@ -33,7 +36,7 @@ int launch_bn_bwd_finalize(const float*, int, int, double, const float*, const f
                            hipStream_t);
 int launch_bn_bwd_apply(const void*, int, long, const void*, int, long, const float*, const float*, const float*,
                         const float*, const float*, void*, int, long, int, int, int, int, hipStream_t,
-                        const float* hw = nullptr);
+                        const float* hw = nullptr, unsigned* amax = nullptr);
 int launch_outconv1_fwd(const void*, int, long, const float*, const float*, const float*, const float*, float*, long, int,
                         int, int, hipStream_t);
 int launch_reduce_rows(const float*, int, long, float*, float, hipStream_t);
@@ -121,7 +124,7 @@ int launch_precip_metrics_update(const float* preds, const float* target, long n
                                  int denorm, void* ws, double* state_f64, long long* state_i64, hipStream_t st);
 int launch_pw_split(PwSplitArgs& a, hipStream_t st);
 int launch_dw3x3_fwd(const void*, int, long, const float*, const float*, void*, int, long, int, int, int, int, int,
-                     hipStream_t, const float*, const float*);
+                     hipStream_t, const float*, const float*, unsigned* amax = nullptr);
 
 // bf16gemm.hip (mixed precision)
 int launch_bf16_planes(const float* w, int R, int C, bf16_t* out, int src_t, hipStream_t st);
@@ -497,6 +500,70 @@ int smaat_pointwise_fwd_split_k(const float* x, long x_bs, const void* planes, c
     a.part = part; a.N = N; a.Cin = Cin; a.Cp = (Cin + 15) & ~15; a.M = M; a.P = H * W;
     return launch_pw_split_k(a, ws, S, ST);
 }
+/* ---- two-term fp16 split (round 5; include/smaat_hip.h "two-term fp16 split"): three fp16 MFMAs per product --------- */
+int smaat_dw3x3_fwd_amax(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                         const float* b_dw, float* y, long y_bs, void* amax, int N, int Cin, int kpl, int H, int W,
+                         void* stream) {
+    if (N < 1 || Cin < 1 || H < 1 || W < 1 || !amax) return -1;
+    return launch_dw3x3_fwd(x, SMAAT_F32, x_bs, w_dw, b_dw, y, SMAAT_F32, y_bs, N, Cin, kpl, H, W, ST, in_scale, in_shift,
+                            (unsigned*)amax);
+}
+int smaat_bn_bwd_apply_amax(const float* dy, long dy_bs, const float* head_w, const float* z, long z_bs, const float* scale,
+                            const float* shift, const float* mean, const float* invstd, const float* coef, float* dz,
+                            long dz_bs, void* amax, int N, int C, int P, int relu, void* stream) {
+    if (!dy || !dz || !amax) return -1;
+    return launch_bn_bwd_apply(dy, SMAAT_F32, dy_bs, z, SMAAT_F32, z_bs, scale, shift, mean, invstd, coef, dz, SMAAT_F32, dz_bs,
+                               N, C, P, head_w ? 1 : relu, ST, head_w, (unsigned*)amax);
+}
+int smaat_split_planes_h_bytes(int R, int C) { return (R < 1 || C < 1) ? 0 : (int)split_planes_h_bytes(R, C); }
+int smaat_split_planes_h_pieces(int R, int C) { return (R < 1 || C < 1) ? 0 : (int)(((long)R * C + 4095) / 4096); }
+int smaat_split_planes_h(const float* w, int R, int C, void* planes, int transposed, void* stream) {
+    if (R < 1 || C < 1 || !w || !planes) return -1;
+    return launch_split_planes_h(w, R, C, (unsigned short*)planes, transposed ? 1 : 0, ST);
+}
+int smaat_weight_planes_multi_h(const void* desc, int n_desc, int total_blocks, int h_pieces, void* stream) {
+    if (!desc || n_desc < 1 || total_blocks < 1 || h_pieces < 0) return -1;
+    return launch_weight_planes_multi((const long long*)desc, n_desc, total_blocks, ST, h_pieces);
+}
+static int pw_split_h_args(PwSplitArgs& a, const float* x, long x_bs, const void* x_amax, const void* planes,
+                           const float* bias, float* out, long out_bs, float* part, int N, int Cin, int M, int H, int W) {
+    if (N < 1 || Cin < 1 || M < 1 || H < 1 || W < 1 || !x || !x_amax || !planes || !out) return -1;
+    a.out_floor = NEG_INF;
+    a.x = x; a.x_bs = x_bs; a.planes = (const unsigned short*)planes; a.bias = bias; a.out = out; a.out_bs = out_bs;
+    a.part = part; a.N = N; a.Cin = Cin; a.Cp = (Cin + 15) & ~15; a.M = M; a.P = H * W;
+    a.x_amax = (const unsigned*)x_amax;
+    a.a_kexp = (const int*)((const unsigned char*)planes + split_planes_h_kexp_offset(M, Cin));
+    return 0;
+}
+int smaat_pointwise_fwd_split_h(const float* x, long x_bs, const void* x_amax, const void* planes, const float* bias,
+                                float* out, long out_bs, float* part, int N, int Cin, int M, int H, int W, void* stream) {
+    PwSplitArgs a{};
+    CHK(pw_split_h_args(a, x, x_bs, x_amax, planes, bias, out, out_bs, part, N, Cin, M, H, W));
+    return launch_pw_split(a, ST);
+}
+int smaat_pointwise_fwd_split_k_h(const float* x, long x_bs, const void* x_amax, const void* planes, const float* bias,
+                                  float* out, long out_bs, float* part, float* ws, int S, int N, int Cin, int M, int H, int W,
+                                  void* stream) {
+    if (S < 2 || !ws) return -1;
+    if (x_bs != (long)Cin * H * W || (out_bs & 3) != 0 || ((((uintptr_t)out) & 15) != 0) || ((((uintptr_t)ws) & 15) != 0) ||
+        ((H * W) & 3) != 0 || (Cin & 15) != 0 || (Cin / 16) % S != 0 || !pws_persistent_ok(M, H * W))
+        return -2;
+    PwSplitArgs a{};
+    CHK(pw_split_h_args(a, x, x_bs, x_amax, planes, bias, out, out_bs, part, N, Cin, M, H, W));
+    return launch_pw_split_k(a, ws, S, ST);
+}
+int smaat_pointwise_wgrad_h(const float* x, long x_bs, const void* x_amax, const float* dz, long dz_bs, const void* dz_amax,
+                            float* ws, float* dw_out, int N, int Cin, int M, int H, int W, void* stream) {
+    if (N < 1 || Cin < 1 || M < 1 || H < 1 || W < 1 || !x_amax || !dz_amax) return -1;
+    Wg2Args a{};
+    a.dz = dz; a.dz_bs = dz_bs; a.y = x; a.y_bs = x_bs; a.part = ws;
+    a.N = N; a.M = M; a.K = Cin; a.P = H * W;
+    a.dz_amax = (const unsigned*)dz_amax; a.y_amax = (const unsigned*)x_amax;
+    hipStream_t st = ST;
+    CHK(launch_wgrad2(a, st));
+    return launch_reduce_rows(ws, a.nsplit, (long)M * Cin, dw_out, 1.f, st);
+}
+
 int smaat_dsconv_split_num_slots(int N, int H, int W) { return dsconv_split_num_slots(N, H, W); }
 static int dsconv_fwd_split_impl(const float* x, long x_bs, const float* in_scale, const float* in_shift,
                                  const float* w_dw, const float* b_dw, const void* planes, const float* b_pw, float* z,

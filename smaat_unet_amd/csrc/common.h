@@ -128,6 +128,32 @@ __device__ __forceinline__ float wave_max_all(float v) {
     return v;
 }
 
+// ---- operand maxima for the two-term fp16 split GEMMs (splitmma.hip, NT == 2) ---------------------------------
+// A kernel that WRITES a GEMM operand (depthwise output, BatchNorm-backward dz) also leaves max |v| over the whole tensor in
+// a device word: the GEMM derives the operand's power-of-two scale from it.  m >= 0 is this lane's running maximum
+// (fmaxf drops NaNs: a NaN element stays a NaN in the scaled operand).  One conditional atomic per WAVE: the slot only grows,
+// so a wave whose maximum is not above the value it reads has nothing to add (the read may be stale: then the atomic is
+// merely redundant) -- a few dozen atomics per tensor instead of one per wave.  Unsigned compare on the bit pattern of a
+// non-negative float is the float compare; the result is order-independent, i.e. bit-reproducible.  slot starts at 0.
+__device__ __forceinline__ void amax_publish(unsigned* slot, float m) {
+    m = wave_max_all(m);
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned b = __builtin_bit_cast(unsigned, m);
+        if (b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            __hip_atomic_fetch_max(slot, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// scale exponent of an operand whose max |x| has the bit pattern `am`: x * 2^k has its maximum in [2^14, 2^15), inside
+// fp16's range (65504) with 28 binades of normal range below it.  inf / nan / 0 -> 0; |k| <= 126 so that 2^k and 2^-k
+// are both normal floats.
+__host__ __device__ __forceinline__ int f16_kexp(unsigned am) {
+    const int e = (int)((am >> 23) & 0xFFu);
+    if (e == 255 || (am & 0x7FFFFFFFu) == 0u) return 0;
+    const int k = 141 - e;
+    return k > 126 ? 126 : (k < -126 ? -126 : k);
+}
+__device__ __forceinline__ float pow2i(int k) { return __builtin_bit_cast(float, (unsigned)(k + 127) << 23); }  // |k| <= 126
+
 // block-wide sum for 256-thread blocks; result valid in thread 0. `red` = 4 floats of LDS.
 __device__ __forceinline__ float block_sum_t0(float v, float* red) {
     v = wave_sum_l63(v);
@@ -342,6 +368,10 @@ struct Wg2Args {
     long y_bs;
     float* part;  // [nsplit][M][K]
     int N, M, K, P, nmt, nkt, nsplit, chunks_per_split, nchunk_img, total_chunks;
+    // two-term fp16 split (splitmma.hip, NT == 2): bit patterns of max |dz| and max |y| over the whole operand tensors
+    // (device memory, written by the kernels that produce the operands); null selects the exact three-term bf16 split
+    const unsigned* dz_amax;
+    const unsigned* y_amax;
 };
 
 struct WgArgs {
@@ -374,6 +404,10 @@ struct PwSplitArgs {
     // otherwise
     int ksplit;
     long planes_bs;
+    // two-term fp16 split (NT == 2): planes = fp16 image [Cp/16][2][M][16] of A * 2^kexp (smaat_split_planes_h), a_kexp -> that
+    // exponent (the image's trailer), x_amax -> bit pattern of max |x| over the whole operand tensor.  Both null otherwise.
+    const unsigned* x_amax;
+    const int* a_kexp;
 };
 
 // mixed-precision GEMMs (bf16gemm.hip)

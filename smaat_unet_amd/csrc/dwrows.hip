@@ -239,12 +239,15 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const TX* __restrict__ x
                                                          const float* __restrict__ b_dw, TY* __restrict__ y,
                                                          long y_bs, int Cin, int nplanes, const DwrGeom g,
                                                          const float* __restrict__ in_scale,
-                                                         const float* __restrict__ in_shift) {
+                                                         const float* __restrict__ in_shift,
+                                                         unsigned* __restrict__ amax) {
+    // amax (nullable): max |y| over the whole tensor, for the two-term fp16 split GEMMs that read y (common.h)
     const int tid = threadIdx.x, lane = tid & 63;
     const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (tid >> 6));  // (plane, wave of the plane) list
     int n, ci, wip, t;
     bool lane_on;
     if (!dwr_place<PACK>(g, gw, lane, nplanes / Cin, Cin, n, ci, wip, t, lane_on)) return;  // (whole wave)
+    float am = 0.f;
     const int band_ = t / g.ncol4, q = t - band_ * g.ncol4;
     const bool active = lane_on && band_ < g.nbands;  // surplus lanes walk the last band again (stores masked)
     const int band = active ? band_ : g.nbands - 1;
@@ -282,7 +285,12 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const TX* __restrict__ x
                 for (int tc = 0; tc < 3; ++tc) acc = fmaf(wt[j][6 + tc], R2[c + tc], acc);
                 o[c] = acc;
             }
-            if (active && r < g.H) dwr_store<PART>(yp + (long)j * g.P + (long)r * g.W, make_float4(o[0], o[1], o[2], o[3]), ln);
+            if (active && r < g.H) {
+                dwr_store<PART>(yp + (long)j * g.P + (long)r * g.W, make_float4(o[0], o[1], o[2], o[3]), ln);
+                float m = fmaxf(fabsf(o[0]), fabsf(o[1]));
+                if (!(PART && ln.part)) m = fmaxf(m, fmaxf(fabsf(o[2]), fabsf(o[3])));  // (a 2-wide last group stores o[0..1])
+                am = fmaxf(am, m);
+            }
         }
     };
     {
@@ -309,6 +317,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const TX* __restrict__ x
     dwr_pin(raw[0]);  // (loads still in flight target live registers)
     dwr_pin(raw[1]);
     dwr_pin(raw[2]);
+    if (amax) amax_publish(amax, am);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -520,7 +529,7 @@ int dw_rows_ok(int kpl, int H, int W) {
 // or bf16 input (forward), bf16 dY with x and dX both f32 or both bf16 (backward).  -2 otherwise.
 int launch_dw3x3_fwd_rows(const void* x, int x_dt, long x_bs, const float* w_dw, const float* b_dw, void* y, int y_dt,
                           long y_bs, int N, int Cin, int kpl, int H, int W, hipStream_t st, const float* in_scale,
-                          const float* in_shift) {
+                          const float* in_shift, unsigned* amax) {
     const int nplanes = N * Cin;
     const DwrGeom g = dw_rows_geom(N, Cin, H, W);
     if (g.wpp == 0) return -2;
@@ -530,7 +539,7 @@ int launch_dw3x3_fwd_rows(const void* x, int x_dt, long x_bs, const float* w_dw,
     const bool part = (W & 3) != 0;
 #define DWF_GO1(K, TX, TY, PT, PK)                                                                                          \
     hipLaunchKernelGGL((k_dw3x3_fwd_rows<K, TX, TY, PT, PK>), grid, blk, 0, st, (const TX*)x, x_bs, w_dw, b_dw, (TY*)y, y_bs, \
-                       Cin, nplanes, g, in_scale, in_shift)
+                       Cin, nplanes, g, in_scale, in_shift, amax)
 #define DWF_GO(K, TX, TY)                                   \
     do {                                                    \
         if (pack) {                                         \

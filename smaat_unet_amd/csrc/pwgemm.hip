@@ -1668,7 +1668,9 @@ int launch_wgrad2(Wg2Args& a, hipStream_t st) {
     a.chunks_per_split = ceil_div(a.total_chunks, a.nsplit);
     a.nkt = ceil_div(a.K, 128);
     if (split_mode() >= 1) {  // bf16 matrix path (splitmma.hip); -2 = shape not handled there
-        const int rc = launch_wgrad_split(a, split_mode() >= 3 ? 3 : split_mode(), st);
+        // both operand maxima given (smaat_pointwise_wgrad_h): the two-term fp16 split, unless plain-bf16 mode is on
+        const int nt = (a.dz_amax && a.y_amax && split_mode() != 1) ? 2 : (split_mode() >= 2 ? 3 : 1);
+        const int rc = launch_wgrad_split(a, nt, st);
         if (rc != -2) return rc;
         a.nchunk_img = ceil_div(a.P, 64);
         a.total_chunks = a.N * a.nchunk_img;

@@ -1059,14 +1059,16 @@ static int launch_dw3x3_fwd_small(const void* x, int x_dt, long x_bs, const floa
 int dw_rows_ok(int kpl, int H, int W);
 int dw_rows_wpp(int N, int Cin, int H, int W);
 int launch_dw3x3_fwd_rows(const void*, int, long, const float*, const float*, void*, int, long, int, int, int, int, int,
-                          hipStream_t, const float*, const float*);
+                          hipStream_t, const float*, const float*, unsigned* amax);
 int launch_dw3x3_bwd_rows(const void*, int, long, const void*, int, long, const float*, void*, int, long, float*, int, int,
                           int, int, int, hipStream_t, const float*, const float*, float*, const float*, const float*);
 
 // x_dt / y_dt: SMAAT_F32 | SMAAT_BF16 (bf16 storage: the row-streaming and the small-plane kernels only)
 int launch_dw3x3_fwd(const void* xv, int x_dt, long x_bs, const float* w_dw, const float* b_dw, void* yv, int y_dt,
                      long y_bs, int N, int Cin, int kpl, int H, int W, hipStream_t st, const float* in_scale,
-                     const float* in_shift) {
+                     const float* in_shift, unsigned* amax) {
+    // amax (nullable): device word that receives max |y| (bit pattern; must hold 0 on entry) -- only the row-streaming
+    // kernels produce it: -2 when another kernel would take the shape
     const unsigned xm = x_dt == SMAAT_BF16 ? 7u : 15u, ym = y_dt == SMAAT_BF16 ? 7u : 15u;
     const bool aligned = ((W & 3) == 0) && ((x_bs & 3) == 0) && ((((uintptr_t)xv) & xm) == 0) && H >= 1 &&
                          (kpl == 1 || kpl == 2 || kpl == 4);
@@ -1074,12 +1076,13 @@ int launch_dw3x3_fwd(const void* xv, int x_dt, long x_bs, const float* w_dw, con
     // W % 4 == 2 (18 x 18 ...): the row kernels with a two-column last group; rows are 8- (f32) / 4-byte (bf16) aligned
     if (!aligned && (W & 3) == 2 && dw_rows_ok(kpl, H, W) && (x_bs & 1) == 0 && (y_bs & 1) == 0 &&
         ((((uintptr_t)xv) & (xm >> 1)) == 0) && ((((uintptr_t)yv) & (ym >> 1)) == 0))
-        return launch_dw3x3_fwd_rows(xv, x_dt, x_bs, w_dw, b_dw, yv, y_dt, y_bs, N, Cin, kpl, H, W, st, in_scale, in_shift);
+        return launch_dw3x3_fwd_rows(xv, x_dt, x_bs, w_dw, b_dw, yv, y_dt, y_bs, N, Cin, kpl, H, W, st, in_scale, in_shift, amax);
+    if (amax && !(aligned && dw_rows_ok(kpl, H, W) && (y_bs & 3) == 0 && ((((uintptr_t)yv) & ym) == 0))) return -2;
     if (!aligned && H * W <= DWS_PMAX)  // small planes with unaligned rows (18 x 18 ...): the flat-copy kernel
         return launch_dw3x3_fwd_small(xv, x_dt, x_bs, w_dw, b_dw, yv, y_dt, y_bs, N, Cin, kpl, H, W, st, in_scale, in_shift);
     if (!aligned) return -2;  // caller falls back to the fused f32 kernel
     if (dw_rows_ok(kpl, H, W) && (y_bs & 3) == 0 && ((((uintptr_t)yv) & ym) == 0))
-        return launch_dw3x3_fwd_rows(xv, x_dt, x_bs, w_dw, b_dw, yv, y_dt, y_bs, N, Cin, kpl, H, W, st, in_scale, in_shift);
+        return launch_dw3x3_fwd_rows(xv, x_dt, x_bs, w_dw, b_dw, yv, y_dt, y_bs, N, Cin, kpl, H, W, st, in_scale, in_shift, amax);
     if (x_dt != SMAAT_F32 || y_dt != SMAAT_F32) return -2;
     const float* x = (const float*)xv;
     float* y = (float*)yv;

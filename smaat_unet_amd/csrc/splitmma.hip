@@ -7,8 +7,18 @@
 // i.e. SIX v_mfma_f32_32x32x16_bf16 per 16-deep step, each term exact in the f32 accumulator input
 // (8 bit x 8 bit products), f32 accumulation as in the f32 MFMA.  The dropped terms are below one f32
 // ulp of the product, so the result has f32-class error (tests compare against the fp64 oracle next
-// to the f32-MFMA kernels).  NT = 2 keeps only  a1 b1 + a1 b2 + a2 b1  (a2 rounded to nearest):
-// ~2^-17 relative per product, three MFMAs.
+// to the f32-MFMA kernels).
+//
+// NT = 2 (round 5) is the TWO-term fp16 split:  a * 2^ka = h1 + h2 + O(2^-22 |a| 2^ka)  with h1 = fp16(a 2^ka),
+// h2 = fp16(a 2^ka - h1) (round to nearest; 11 significant bits each) and a power-of-two scale 2^ka PER OPERAND TENSOR that
+// puts the tensor's largest magnitude into [2^14, 2^15) (fp16 overflows at 65504; its normal range reaches 28 binades
+// below that).  A product is  h1 g1 + h1 g2 + h2 g1  -- THREE v_mfma_f32_32x32x16_f16, each term an exact 22-bit product,
+// f32 accumulation; the dropped term h2 g2 is 2^-22 of the product -- and the accumulator is scaled back by the exact
+// 2^-(ka+kb).  Elements more than 2^17 below the tensor's maximum lose relative precision (their second term goes
+// subnormal), with an absolute error still <= 2^-39 of the maximum: f32-class in every norm a GEMM result is judged in
+// (profiles/r4/split_formats_*_study.txt; tests/test_gpu_kernels.py compares with fp64 next to the three-term split).
+// The maxima come from the kernels that WRITE the operands (amax_publish, common.h): depthwise forward (y), BatchNorm
+// backward apply (dz), the weight-image kernel (weights); a call without them runs the three-term bf16 split.
 //
 //   k_wgrad_split   dW[m][k] = sum_{n,p} dz[n][m][p] * y[n][k][p]      (pointwise weight gradient)
 //
@@ -19,6 +29,8 @@
 #include <stdlib.h>
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 static int pws_cfg();
 int split_mode();
@@ -34,28 +46,94 @@ __device__ __forceinline__ float rne_bf16(float x) {  // round-to-nearest-even t
     return bitsf((b + 0x7FFFu + ((b >> 16) & 1u)) & 0xFFFF0000u);
 }
 
-// split 4 consecutive f32 into NT bf16 planes; plane t of the 4 values -> uint2
+// ---- two-term fp16 split of a pair (already scaled): h = {fp16(t0), fp16(t1)}, g = fp16 of the exact residuals
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {  // one v_cvt_pk_f16_f32 (round to nearest even)
+    const f32x2_native v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+__device__ __forceinline__ void split2_f16(float t0, float t1, unsigned& h, unsigned& g) {
+    h = pack_f16(t0, t1);
+    const f16x2 hv = __builtin_bit_cast(f16x2, h);
+    g = pack_f16(t0 - (float)hv.x, t1 - (float)hv.y);  // the residual of a rounding to fewer bits is exact in f32
+}
+
+// NT MFMA terms of one 32x32x16 block product, smallest terms first (NT = 3 / 1: bf16 planes, NT = 2: fp16 planes)
 template <int NT>
-__device__ __forceinline__ void split4(const float4 v, uint2 (&out)[NT]) {
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    float p1[4], p2[4], p3[4];
+__device__ __forceinline__ void mma_terms(f32x16& acc, const bf16x8 (&a)[NT], const bf16x8 (&b)[NT]) {
+    if constexpr (NT == 2) {
+        const f16x8 a0 = __builtin_bit_cast(f16x8, a[0]), a1 = __builtin_bit_cast(f16x8, a[1]);
+        const f16x8 b0 = __builtin_bit_cast(f16x8, b[0]), b1 = __builtin_bit_cast(f16x8, b[1]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
+    } else {
+        if constexpr (NT == 3) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+    }
+}
+
+// split 4 consecutive f32 into NT planes; plane t of the 4 values -> uint2.  NT = 3 / 1: bf16 terms; NT = 2: fp16 terms
+// of v * sc (sc = the operand's power-of-two scale)
+template <int NT>
+__device__ __forceinline__ void split4(const float4 v, uint2 (&out)[NT], float sc) {
+    if constexpr (NT == 2) {
+        split2_f16(v.x * sc, v.y * sc, out[0].x, out[1].x);
+        split2_f16(v.z * sc, v.w * sc, out[0].y, out[1].y);
+    } else {
+        const float x[4] = {v.x, v.y, v.z, v.w};
+        float p1[4], p2[4], p3[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        p1[i] = NT == 1 ? rne_bf16(x[i]) : bitsf(fbits(x[i]) & 0xFFFF0000u);
-        const float r1 = x[i] - p1[i];  // exact
-        if (NT == 1) {
-            p2[i] = p3[i] = 0.f;
-        } else if (NT == 2) {
-            p2[i] = rne_bf16(r1);
-            p3[i] = 0.f;
-        } else {
-            p2[i] = bitsf(fbits(r1) & 0xFFFF0000u);
-            p3[i] = r1 - p2[i];  // exact, <= 8 significant bits: its truncation to bf16 is exact
+        for (int i = 0; i < 4; ++i) {
+            p1[i] = NT == 1 ? rne_bf16(x[i]) : bitsf(fbits(x[i]) & 0xFFFF0000u);
+            const float r1 = x[i] - p1[i];  // exact
+            if (NT == 1) {
+                p2[i] = p3[i] = 0.f;
+            } else {
+                p2[i] = bitsf(fbits(r1) & 0xFFFF0000u);
+                p3[i] = r1 - p2[i];  // exact, <= 8 significant bits: its truncation to bf16 is exact
+            }
+        }
+        out[0] = make_uint2(pack_hi16(p1[0], p1[1]), pack_hi16(p1[2], p1[3]));
+        if constexpr (NT == 3) {
+            out[1] = make_uint2(pack_hi16(p2[0], p2[1]), pack_hi16(p2[2], p2[3]));
+            out[2] = make_uint2(pack_hi16(p3[0], p3[1]), pack_hi16(p3[2], p3[3]));
         }
     }
-    out[0] = make_uint2(pack_hi16(p1[0], p1[1]), pack_hi16(p1[2], p1[3]));
-    if (NT >= 2) out[1] = make_uint2(pack_hi16(p2[0], p2[1]), pack_hi16(p2[2], p2[3]));
-    if (NT == 3) out[2] = make_uint2(pack_hi16(p3[0], p3[1]), pack_hi16(p3[2], p3[3]));
+}
+
+// 8 f32 values of one pixel (8 consecutive channels) -> NT planes of a [pixel][16 ch] image, one 16-byte store per plane
+template <int NT>
+__device__ __forceinline__ void split8_store(const float (&x)[8], float sc, unsigned char* dst, int plane_bytes) {
+    if constexpr (NT == 2) {
+        unsigned h[4], g[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2_f16(x[2 * e] * sc, x[2 * e + 1] * sc, h[e], g[e]);
+        *(uint4*)(dst) = make_uint4(h[0], h[1], h[2], h[3]);
+        *(uint4*)(dst + plane_bytes) = make_uint4(g[0], g[1], g[2], g[3]);
+    } else {
+        float p1[8], p2[8], p3[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            p1[e] = NT == 1 ? rne_bf16(x[e]) : bitsf(fbits(x[e]) & 0xFFFF0000u);
+            const float r1 = x[e] - p1[e];
+            p2[e] = bitsf(fbits(r1) & 0xFFFF0000u);
+            p3[e] = r1 - p2[e];
+        }
+        *(uint4*)(dst) = make_uint4(pack_hi16(p1[0], p1[1]), pack_hi16(p1[2], p1[3]), pack_hi16(p1[4], p1[5]),
+                                    pack_hi16(p1[6], p1[7]));
+        if constexpr (NT == 3) {
+            *(uint4*)(dst + plane_bytes) = make_uint4(pack_hi16(p2[0], p2[1]), pack_hi16(p2[2], p2[3]),
+                                                      pack_hi16(p2[4], p2[5]), pack_hi16(p2[6], p2[7]));
+            *(uint4*)(dst + 2 * plane_bytes) = make_uint4(pack_hi16(p3[0], p3[1]), pack_hi16(p3[2], p3[3]),
+                                                          pack_hi16(p3[4], p3[5]), pack_hi16(p3[6], p3[7]));
+        }
+    }
 }
 
 #define SPS 32       // pixels per chunk
@@ -88,8 +166,16 @@ __global__ __launch_bounds__(256 + NPT) void k_wgrad_split(const Wg2Args a) {
     const int c_begin = split, c_end = a.total_chunks, c_step = a.nsplit;
     int nit = 0;
     if (c_begin < c_end) nit = (c_end - c_begin + c_step - 1) / c_step;
+    // NT == 2: per-tensor power-of-two scales of the two operands (wave-uniform scalar loads)
+    int kdz = 0, ky = 0;
+    if constexpr (NT == 2) {
+        kdz = f16_kexp(*a.dz_amax);
+        ky = f16_kexp(*a.y_amax);
+        asm volatile("" : "+s"(kdz), "+s"(ky));  // (the scalar loads are waited for HERE, not at a first use inside the loop)
+    }
 
     if (producer) {
+        const float sdz = pow2i(kdz), sy = pow2i(ky);
         // thread -> (row group, float4 column): 8 lanes cover one 128-byte row segment
         // 8 lanes cover one 128-byte row segment (32 pixels).  Within a group of 8 rows the row order is
         // 0,4,1,5,2,6,3,7: the two rows a 16-lane group writes with one ds_write_b64 are 4 rows (320 B = 16
@@ -153,7 +239,7 @@ __global__ __launch_bounds__(256 + NPT) void k_wgrad_split(const Wg2Args a) {
                 v.z = ok ? pf[set][j][2] : 0.f;
                 v.w = ok ? pf[set][j][3] : 0.f;
                 uint2 pl[NT];
-                split4<NT>(v, pl);
+                split4<NT>(v, pl, (rbase + RSTEP * j) < MT ? sdz : sy);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) *(uint2*)(base + t * PLSZ + lofs[j]) = pl[t];
             }
@@ -208,23 +294,14 @@ __global__ __launch_bounds__(256 + NPT) void k_wgrad_split(const Wg2Args a) {
 #pragma unroll
                 for (int i = 0; i < MTT; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        // smallest terms first
-                        if (NT == 3) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-                        }
-                        if (NT >= 2) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                        }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-                    }
+                    for (int j = 0; j < 2; ++j) mma_terms<NT>(acc[i][j], af[i], bf[j]);  // smallest terms first
             }
             __syncthreads();
         }
         float* ob = a.part + (long)split * a.M * a.K;
+        // two exact factors, the exponent split evenly: 2^-(kdz + ky) itself may be out of range, and so may the product of
+        // the accumulator with 2^-kdz alone while the final result is not
+        const float e1 = pow2i(-((kdz + ky) / 2)), e2 = pow2i(-((kdz + ky) - (kdz + ky) / 2));
 #pragma unroll
         for (int i = 0; i < MTT; ++i)
 #pragma unroll
@@ -234,7 +311,7 @@ __global__ __launch_bounds__(256 + NPT) void k_wgrad_split(const Wg2Args a) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int kg = k0 + (wk * 2 + j) * 32 + l31;
-                        if (kg < a.K) ob[(long)m * a.K + kg] = acc[i][j][r];
+                        if (kg < a.K) ob[(long)m * a.K + kg] = NT == 2 ? acc[i][j][r] * e1 * e2 : acc[i][j][r];
                     }
                 }
             }
@@ -299,6 +376,7 @@ int launch_wgrad_split(Wg2Args& a, int nt, hipStream_t st) {
         if (a.M > 64) return launch_wgrad_split_cfg<3, 2, 256>(a, st);
         return launch_wgrad_split_cfg<3, 1, 256>(a, st);
     }
+    if (!a.dz_amax || !a.y_amax) return -1;  // nt == 2: the two-term fp16 split needs both operand maxima
     if (a.M > 64) return launch_wgrad_split_cfg<2, 2, 256>(a, st);
     return launch_wgrad_split_cfg<2, 1, 256>(a, st);
 }
@@ -342,6 +420,92 @@ int launch_split_planes(const float* w, int R, int C, unsigned short* out, hipSt
     return (int)hipGetLastError();
 }
 
+// ---- fp16 two-term weight images (NT == 2 GEMMs) ---------------------------------------------------------------------
+// image of A * 2^kexp: [Cp/16][2][R][16] halves (h, g: A 2^kexp = h + g + O(2^-22)), followed by a trailer
+//   { int kexp; 12 bytes pad; float pmax[npart] }   (smaat_split_planes_h_bytes)
+// kexp = f16_kexp(max |A|): the maximum is taken in two levels without atomics or zero-filled state -- a first launch leaves
+// the maxima of 4096-element pieces of the SOURCE in pmax, every block of the image launch reduces those (<= a few hundred
+// values) for itself.  Bit-reproducible; the trailer's kexp is what the GEMM reads (PwSplitArgs::a_kexp).
+#define HPIECE 4096
+__host__ __device__ static inline long h_image_elems(int R, int Cp) { return (long)(Cp >> 4) * 2 * R * 16; }
+__host__ __device__ static inline int h_npart(int R, int C) { return (int)(((long)R * C + HPIECE - 1) / HPIECE); }
+long split_planes_h_bytes(int R, int C) {
+    const int Cp = (C + 15) & ~15;
+    return h_image_elems(R, Cp) * 2 + 16 + (long)h_npart(R, C) * 4;
+}
+long split_planes_h_kexp_offset(int R, int C) { return h_image_elems(R, (C + 15) & ~15) * 2; }  // bytes from the image start
+
+__device__ __forceinline__ float block256_max(float m, float* red) {  // all 256 threads take part; result in every thread
+    m = wave_max_all(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+// piece `p` of a source of n floats -> pmax[p]
+__device__ __forceinline__ void amax_piece(const float* __restrict__ w, long n, int p, float* __restrict__ pmax, float* red) {
+    const long b = (long)p * HPIECE;
+    float m = 0.f;
+#pragma unroll 4
+    for (int t = threadIdx.x; t < HPIECE; t += 256)
+        if (b + t < n) m = fmaxf(m, fabsf(w[b + t]));
+    m = block256_max(m, red);
+    if (threadIdx.x == 0) pmax[p] = m;
+}
+// one element of the image; i = linear index of the [R][Cp] domain as in k_split_planes
+__device__ __forceinline__ void h_image_elem(const float* __restrict__ w, int R, int C, int Cp, int src_t, long i, float sc,
+                                             unsigned short* __restrict__ out) {
+    const int r = src_t ? (int)(i % R) : (int)(i / Cp), c = src_t ? (int)(i / R) : (int)(i - (long)r * Cp);
+    const float x = c < C ? (src_t ? w[(long)c * R + r] : w[(long)r * C + c]) : 0.f;
+    unsigned h, g;
+    split2_f16(x * sc, 0.f, h, g);
+    const long o = ((long)(c >> 4) * 2 * R + r) * 16 + (c & 15);
+    out[o] = (unsigned short)(h & 0xFFFFu);
+    out[o + (long)R * 16] = (unsigned short)(g & 0xFFFFu);
+}
+__global__ __launch_bounds__(256) void k_amax_pieces(const float* __restrict__ w, long n, float* __restrict__ pmax) {
+    __shared__ float red[4];
+    amax_piece(w, n, blockIdx.x, pmax, red);
+}
+__global__ __launch_bounds__(256) void k_split_planes_h(const float* __restrict__ w, int R, int C, int Cp,
+                                                        unsigned short* __restrict__ out, int src_t) {
+    __shared__ float red[4];
+    int* trailer = (int*)(out + h_image_elems(R, Cp));
+    const float* pmax = (const float*)(trailer + 4);
+    const int np = h_npart(R, C);
+    float m = 0.f;
+    for (int t = threadIdx.x; t < np; t += 256) m = fmaxf(m, pmax[t]);
+    m = block256_max(m, red);
+    const int kexp = f16_kexp(__builtin_bit_cast(unsigned, m));
+    if (blockIdx.x == 0 && threadIdx.x == 0) trailer[0] = kexp;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < (long)R * Cp) h_image_elem(w, R, C, Cp, src_t, i, pow2i(kexp), out);
+}
+int launch_split_planes_h(const float* w, int R, int C, unsigned short* out, int src_t, hipStream_t st) {
+    const int Cp = (C + 15) & ~15;
+    float* pmax = (float*)((int*)(out + h_image_elems(R, Cp)) + 4);
+    hipLaunchKernelGGL(k_amax_pieces, dim3((unsigned)h_npart(R, C)), dim3(256), 0, st, w, (long)R * C, pmax);
+    const long n = (long)R * Cp;
+    hipLaunchKernelGGL(k_split_planes_h, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, R, C, Cp, out, src_t);
+    return (int)hipGetLastError();
+}
+// first launch of a multi-image refresh that contains kind-3 rows: block b -> the b-th piece over all kind-3 matrices
+__global__ __launch_bounds__(256) void k_weight_amax_multi(const long long* __restrict__ desc, int nd) {
+    __shared__ float red[4];
+    int cum = 0;
+    for (int j = 0; j < nd; ++j) {  // (wave-uniform walk over <= a few dozen descriptors)
+        const long long* d = desc + (long)j * 8;
+        if ((int)d[4] != 3) continue;
+        const int R = (int)d[2], C = (int)d[3], np = h_npart(R, C);
+        if ((int)blockIdx.x < cum + np) {
+            unsigned short* out = (unsigned short*)d[1];
+            float* pmax = (float*)((int*)(out + h_image_elems(R, (C + 15) & ~15)) + 4);
+            amax_piece((const float*)d[0], (long)R * C, (int)blockIdx.x - cum, pmax, red);
+            return;
+        }
+        cum += np;
+    }
+}
+
 // =====================================================================================
 // k_weight_planes_multi: the operand images of MANY weight matrices in ONE launch (round 4).  A training step needs the
 // images of 18 pointwise weights and of 17 transposes -- 35 launches of ~5 us each doing a few KB of work, one after the
@@ -366,6 +530,19 @@ __global__ __launch_bounds__(256) void k_weight_planes_multi(const long long* __
     const int R = (int)d[2], C = (int)d[3], kind = (int)d[4], src_t = (int)d[5];
     const int Cp = kind == 2 ? ((C + 31) & ~31) : ((C + 15) & ~15);
     const long i = (long)(b - (int)d[6]) * 256 + threadIdx.x;
+    if (kind == 3) {  // fp16 two-term image (block-uniform branch: the whole block belongs to one matrix)
+        __shared__ float red[4];
+        int* trailer = (int*)(out + h_image_elems(R, Cp));
+        const float* pmax = (const float*)(trailer + 4);
+        const int np = h_npart(R, C);
+        float m = 0.f;
+        for (int t = threadIdx.x; t < np; t += 256) m = fmaxf(m, pmax[t]);
+        m = block256_max(m, red);
+        const int kexp = f16_kexp(__builtin_bit_cast(unsigned, m));
+        if (b == (int)d[6] && threadIdx.x == 0) trailer[0] = kexp;
+        if (i < (long)R * Cp) h_image_elem(w, R, C, Cp, src_t, i, pow2i(kexp), out);
+        return;
+    }
     if (i >= (long)R * Cp) return;
     const int r = src_t ? (int)(i % R) : (int)(i / Cp), c = src_t ? (int)(i / R) : (int)(i - (long)r * Cp);
     const float x = c < C ? (src_t ? w[(long)c * R + r] : w[(long)r * C + c]) : 0.f;
@@ -384,7 +561,9 @@ __global__ __launch_bounds__(256) void k_weight_planes_multi(const long long* __
     out[o + 2 * plane] = (unsigned short)(fbits(p3) >> 16);
 }
 
-int launch_weight_planes_multi(const long long* desc, int nd, int total_blocks, hipStream_t st) {
+int launch_weight_planes_multi(const long long* desc, int nd, int total_blocks, hipStream_t st, int h_pieces) {
+    // h_pieces > 0: the table holds kind-3 rows with that many 4096-element pieces in total (maxima first)
+    if (h_pieces > 0) hipLaunchKernelGGL(k_weight_amax_multi, dim3((unsigned)h_pieces), dim3(256), 0, st, desc, nd);
     hipLaunchKernelGGL(k_weight_planes_multi, dim3((unsigned)total_blocks), dim3(256), 0, st, desc, nd,
                        split_mode() == 1 ? 1 : 0);
     return (int)hipGetLastError();
@@ -411,6 +590,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
     constexpr int BUFSZ = NT * (APL + BPL);  // NT planes of A then NT planes of B
     constexpr int NBT = PT * 2 / NPT;    // B tasks (pixel, k half) per producer thread
     constexpr int NAT = (COT * 2 * NT + NPT - 1) / NPT;  // A copy tasks per producer thread
+    constexpr int NPL = NT == 2 ? 2 : 3;  // planes per chunk of the weight image (the bf16 image always has three)
     static_assert(NCW == 4 || NCW == 8, "4 or 8 consumer waves");
     static_assert((PT * 2) % NPT == 0, "producer mapping");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -433,6 +613,13 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
     const int co0 = cot * COT, p0 = tl * PT;
     const int nchunks = (a.Cin + 15) >> 4;
     const float* xn = a.x + (long)n * a.x_bs;
+    int kx = 0, ka = 0;  // NT == 2: power-of-two scale exponents of x (from its maximum) and of the weight image
+    if constexpr (NT == 2) {
+        kx = f16_kexp(*a.x_amax);
+        ka = *a.a_kexp;
+        asm volatile("" : "+s"(kx), "+s"(ka));
+    }
+    const float sx = pow2i(kx);
     if (tid < COT) {  // bias through LDS (visible after the first barrier): a global load in the epilogue would
         const int m = co0 + tid;  // serialise the stores behind vmcnt(0)
         const float* bp = a.bias ? a.bias : (const float*)a.planes;
@@ -466,7 +653,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
             const int row = rem >> 1, h = rem & 1;
             arow[u] = row;
             av[u] = (co0 + row) < a.M;
-            asrc[u] = ((long)pl * a.M + (av[u] ? co0 + row : 0)) * 16 + h * 8;  // + chunk * 3 * M * 16
+            asrc[u] = ((long)pl * a.M + (av[u] ? co0 + row : 0)) * 16 + h * 8;  // + chunk * NPL * M * 16
             aofs[u] = pl * APL + row * BROW + h * 16;
         }
         // PD register sets: the global loads of PD chunks are in flight at any time (an iteration lasts
@@ -485,7 +672,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
                     breg[set][u][e] = xn[(long)(c < a.Cin ? c : a.Cin - 1) * a.P + bp[u]];
                 }
 #pragma unroll
-            for (int u = 0; u < NAT; ++u) areg[set][u] = *(const uint4*)(a.planes + asrc[u] + (long)k0 * 3 * a.M);
+            for (int u = 0; u < NAT; ++u) areg[set][u] = *(const uint4*)(a.planes + asrc[u] + (long)k0 * NPL * a.M);
         };
         auto commit = [&](int ch_, int buf, int set) {
             const int ch = ch_ < nchunks ? ch_ : nchunks - 1;
@@ -493,25 +680,13 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
             unsigned char* base = lds + buf * BUFSZ;
 #pragma unroll
             for (int u = 0; u < NBT; ++u) {
-                float p1[8], p2[8], p3[8];
+                float xv[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int c = k0 + bhalf[u] * 8 + e;
-                    const float x = (bv[u] && c < a.Cin) ? breg[set][u][e] : 0.f;
-                    p1[e] = NT == 1 ? rne_bf16(x) : bitsf(fbits(x) & 0xFFFF0000u);
-                    const float r1 = x - p1[e];
-                    p2[e] = bitsf(fbits(r1) & 0xFFFF0000u);
-                    p3[e] = r1 - p2[e];
+                    xv[e] = (bv[u] && c < a.Cin) ? breg[set][u][e] : 0.f;
                 }
-                unsigned char* dst = base + NT * APL + bpix[u] * BROW + bhalf[u] * 16;
-                *(uint4*)(dst) = make_uint4(pack_hi16(p1[0], p1[1]), pack_hi16(p1[2], p1[3]), pack_hi16(p1[4], p1[5]),
-                                            pack_hi16(p1[6], p1[7]));
-                if (NT == 3) {
-                    *(uint4*)(dst + BPL) = make_uint4(pack_hi16(p2[0], p2[1]), pack_hi16(p2[2], p2[3]),
-                                                      pack_hi16(p2[4], p2[5]), pack_hi16(p2[6], p2[7]));
-                    *(uint4*)(dst + 2 * BPL) = make_uint4(pack_hi16(p3[0], p3[1]), pack_hi16(p3[2], p3[3]),
-                                                          pack_hi16(p3[4], p3[5]), pack_hi16(p3[6], p3[7]));
-                }
+                split8_store<NT>(xv, sx, base + NT * APL + bpix[u] * BROW + bhalf[u] * 16, BPL);
             }
 #pragma unroll
             for (int u = 0; u < NAT; ++u) {
@@ -566,16 +741,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int pt = 0; pt < PXT; ++pt) {
-                    if (NT == 3) {
-                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][0], bf[pt][NT - 1], acc[ct][pt], 0, 0, 0);
-                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][NT - 1], bf[pt][0], acc[ct][pt], 0, 0, 0);
-                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][NT / 2], bf[pt][NT / 2], acc[ct][pt], 0, 0, 0);
-                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][0], bf[pt][NT / 2], acc[ct][pt], 0, 0, 0);
-                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][NT / 2], bf[pt][0], acc[ct][pt], 0, 0, 0);
-                    }
-                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][0], bf[pt][0], acc[ct][pt], 0, 0, 0);
-                }
+                for (int pt = 0; pt < PXT; ++pt) mma_terms<NT>(acc[ct][pt], af[ct], bf[pt]);
         };
         __syncthreads();
         for (int i = 0; i < nchunks; ++i) {
@@ -583,6 +749,15 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
             load(af, bf, i & 1);
             mma(af, bf);
             __syncthreads();
+        }
+        if constexpr (NT == 2) {  // back to the operands' own scale (exact powers of two)
+            const float e1 = pow2i(-((kx + ka) / 2)), e2 = pow2i(-((kx + ka) - (kx + ka) / 2));  // (exponent split evenly)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < PXT; ++pt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[ct][pt][r] = acc[ct][pt][r] * e1 * e2;
         }
         // ---- epilogue: bias + coalesced row stores, BatchNorm partials of the raw accumulators ----
         int off[PXT];
@@ -657,6 +832,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
     constexpr int BUFSZ = NT * (APL + BPL);
     constexpr int NBT = PT * 2 / NPT;
     constexpr int NAT = (COT * 2 * NT + NPT - 1) / NPT;
+    constexpr int NPL = NT == 2 ? 2 : 3;  // planes per chunk of the weight image
     static_assert(NCW == 4 || NCW == 8, "4 or 8 consumer waves");
     static_assert((PT * 2) % NPT == 0, "producer mapping");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -688,6 +864,12 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
     const int nitems = (lim - 1 - idx0) / gstep + 1;
     const int nchunks = (a.Cin + 15) >> 4;
     const int G = nitems * nchunks;  // chunks of this workgroup
+    int kx = 0, ka = 0;  // NT == 2: power-of-two scale exponents of x (from its maximum) and of the weight image
+    if constexpr (NT == 2) {
+        kx = f16_kexp(*a.x_amax);
+        ka = *a.a_kexp;
+        asm volatile("" : "+s"(kx), "+s"(ka));  // (waited for here, not inside the chunk loop)
+    }
 
     if (producer) {
         int bpix[NBT], bhalf[NBT];
@@ -715,6 +897,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
             aofs[u] = pl * APL + arow[u] * BROW + (rem / COT) * 16;
         }
         constexpr int PD = 4;
+        const float sx = pow2i(kx);
         float breg[PD][NBT][8];
         u32x4 areg[PD][NAT];
         float bias_reg[PD];  // bias of channel (ptid % COT) of the chunk's item: reaches the consumers through LDS
@@ -782,7 +965,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
                     }
             }
             {
-                const unsigned short* sa = pf_pl + (long)k0 * 3 * a.M;
+                const unsigned short* sa = pf_pl + (long)k0 * NPL * a.M;
 #pragma unroll
                 for (int u = 0; u < NAT; ++u) {
                     const unsigned short* sau = sa + (ASIMPLE ? u * aplane : 0);
@@ -813,25 +996,14 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
             unsigned char* base = lds + buf * BUFSZ;
 #pragma unroll
             for (int u = 0; u < NBT; ++u) {
-                float p1[8], p2[8], p3[8];
+                float xv[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float x = breg[set][u][e];
                     if (partial) x = (k0 + bhalf[u] * 8 + e < a.Cin) ? x : 0.f;
-                    p1[e] = NT == 1 ? rne_bf16(x) : bitsf(fbits(x) & 0xFFFF0000u);
-                    const float r1 = x - p1[e];
-                    p2[e] = bitsf(fbits(r1) & 0xFFFF0000u);
-                    p3[e] = r1 - p2[e];
+                    xv[e] = x;
                 }
-                unsigned char* dst = base + NT * APL + bpix[u] * BROW + bhalf[u] * 16;
-                *(uint4*)(dst) = make_uint4(pack_hi16(p1[0], p1[1]), pack_hi16(p1[2], p1[3]), pack_hi16(p1[4], p1[5]),
-                                            pack_hi16(p1[6], p1[7]));
-                if (NT == 3) {
-                    *(uint4*)(dst + BPL) = make_uint4(pack_hi16(p2[0], p2[1]), pack_hi16(p2[2], p2[3]),
-                                                      pack_hi16(p2[4], p2[5]), pack_hi16(p2[6], p2[7]));
-                    *(uint4*)(dst + 2 * BPL) = make_uint4(pack_hi16(p3[0], p3[1]), pack_hi16(p3[2], p3[3]),
-                                                          pack_hi16(p3[4], p3[5]), pack_hi16(p3[6], p3[7]));
-                }
+                split8_store<NT>(xv, sx, base + NT * APL + bpix[u] * BROW + bhalf[u] * 16, BPL);
             }
 #pragma unroll
             for (int u = 0; u < NAT; ++u) *(u32x4*)(base + (ASIMPLE ? aofs[0] + u * APL : aofs[u])) = areg[set][u];
@@ -917,16 +1089,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                    for (int pt = 0; pt < PXT; ++pt) {
-                        if (NT == 3) {
-                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][0], bf[pt][NT - 1], acc[ct][pt], 0, 0, 0);
-                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][NT - 1], bf[pt][0], acc[ct][pt], 0, 0, 0);
-                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][NT / 2], bf[pt][NT / 2], acc[ct][pt], 0, 0, 0);
-                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][0], bf[pt][NT / 2], acc[ct][pt], 0, 0, 0);
-                            acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][NT / 2], bf[pt][0], acc[ct][pt], 0, 0, 0);
-                        }
-                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ct][0], bf[pt][0], acc[ct][pt], 0, 0, 0);
-                    }
+                    for (int pt = 0; pt < PXT; ++pt) mma_terms<NT>(acc[ct][pt], af[ct], bf[pt]);
                 __syncthreads();
             }
             // ---- epilogue (no barriers: the producers keep streaming the next item meanwhile) ----
@@ -936,6 +1099,15 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
             // descriptor of the output image: rows >= M fall beyond num_records and pixels >= P get an offset
             // with bit 31 set, so the hardware range check drops them.
             if (a.part && k > 0) flush((k - 1) & 1, prev_ptg, prev_co0);
+            if constexpr (NT == 2) {  // back to the operands' own scale (exact powers of two; two EVEN factors: 2^-(kx+ka) may
+                const float e1 = pow2i(-((kx + ka) / 2)), e2 = pow2i(-((kx + ka) - (kx + ka) / 2));  // be out of range
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < PXT; ++pt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[ct][pt][r] = acc[ct][pt][r] * e1 * e2;
+            }
             unsigned pvo[PXT];
             bool pval[PXT];
 #pragma unroll
@@ -1038,6 +1210,11 @@ int launch_pw_split(PwSplitArgs& a, hipStream_t st) {
     if (split_mode() == 1) {  // plain bf16 operands, one MFMA per product
         if (a.M > 64) return launch_pw_split_cfg<2, 2, 2, 2, 256, 1>(a, st);
         return launch_pw_split_cfg<1, 2, 4, 1, 256, 1>(a, st);
+    }
+    if (a.x_amax || a.a_kexp) {  // two-term fp16 split: an fp16 weight image + the maximum of x
+        if (!a.x_amax || !a.a_kexp) return -1;
+        if (a.M > 64) return launch_pw_split_cfg<2, 2, 2, 2, 256, 2>(a, st);
+        return launch_pw_split_cfg<1, 2, 4, 1, 256, 2>(a, st);
     }
     if (a.M > 64) return launch_pw_split_cfg<2, 2, 2, 2, 256>(a, st);  // 128 x 128
     return launch_pw_split_cfg<1, 2, 4, 1, 256>(a, st);                // 64 x 128
@@ -1153,7 +1330,7 @@ int launch_pw_split_k(PwSplitArgs& a, float* ws, int S, hipStream_t st) {
     const float floor_ = a.out_floor;
     const int N = a.N;
     a.ksplit = S;
-    a.planes_bs = (long)(a.Cin / S / 16) * 3 * a.M * 16;
+    a.planes_bs = (long)(a.Cin / S / 16) * (a.x_amax ? 2 : 3) * a.M * 16;
     a.x_bs = (long)(a.Cin / S) * a.P;
     a.Cin = a.Cin / S;
     a.Cp = a.Cin;

@@ -219,6 +219,38 @@ def _split_dgrad_ok(cout, k):
     return _split_on() and (_split_all() or (cout >= 64 and k >= 64))
 
 
+# ---- two-term fp16 split (round 5; csrc/splitmma.hip NT == 2): three fp16 MFMAs per product instead of six bf16 ones ------
+# On by default for the f32-storage training GEMMs whose operands come with their maxima: the forward pointwise GEMM (the
+# depthwise kernel that writes its operand also leaves max |y|), the data gradient and the streamed weight gradient (the
+# BatchNorm-backward apply kernel leaves max |dz|).  Everything else -- fused forwards, inference, ConvTranspose, OutConv,
+# callers that pass no maxima -- runs the exact three-term bf16 split as before.  SMAAT_F16_SPLIT=0 switches it off (A/B).
+F16_SPLIT = os.environ.get("SMAAT_F16_SPLIT", "1") != "0"
+_AMAX_LOCK = threading.Lock()
+_AMAX_ARENA = {}  # device -> [int32 tensor of zeros, next free word]
+
+
+def _f16_on():
+    if not F16_SPLIT or not _split_on() or _lib.get().smaat_split_mode() != 3:
+        return False
+    from . import train_ops
+    return not train_ops.active()  # (the traceable operators declare their saved tensors up front)
+
+
+def _amax_words(ref, n):
+    """n fresh ZERO int32 words on ref's device (the operand-maximum words of include/smaat_hip.h "two-term fp16 split").
+    Handed out from a zero-filled arena and never reused, so a training step costs no fill launch: one per 4096 words."""
+    if ref.is_cuda and torch.cuda.is_current_stream_capturing():
+        return torch.zeros(n, dtype=torch.int32, device=ref.device)
+    with _AMAX_LOCK:
+        a = _AMAX_ARENA.get(ref.device)
+        if a is None or a[1] + n > a[0].numel():
+            a = [torch.zeros(4096, dtype=torch.int32, device=ref.device), 0]
+            _AMAX_ARENA[ref.device] = a
+        w = a[0][a[1]:a[1] + n]
+        a[1] += n
+    return w
+
+
 def set_matrix_mode(mode):
     """"f32" = f32-MFMA kernels only; "f32_split" (default) = exact three-term bf16 operand split (f32-class
     error); "bf16" = bf16 operands / f32 accumulation (mixed precision, BASELINE configs[3]).  Returns the
@@ -241,6 +273,16 @@ def set_matrix_mode(mode):
 PLANE_CACHE = os.environ.get("SMAAT_PLANE_CACHE", "1") != "0"
 _PLANES = {}
 _PLANES_TABLE = {}  # tuple of entry ids -> device descriptor table
+_PLANES_LOCK = threading.RLock()  # (replicas / a background evaluation thread share the cache)
+
+
+def invalidate_weight_images():
+    """Forget every cached operand image: the call to make after writing weights through `.data` (no version counter sees
+    such a write) when the very next use must see it.  Without it a write through `.data` is seen from the SECOND use of the
+    image after its last refresh on (see _weight_planes)."""
+    with _PLANES_LOCK:
+        _PLANES.clear()
+        _PLANES_TABLE.clear()
 
 
 class _PlaneEntry:
@@ -248,21 +290,34 @@ class _PlaneEntry:
 
 
 def _weight_planes(w2d, transpose, kind):
-    """kind 0: split planes (smaat_split_planes / _t), kind 2: bf16 image (smaat_bf16_planes); see the note above"""
+    """kind 0: split planes (smaat_split_planes / _t), kind 2: bf16 image (smaat_bf16_planes), kind 3: fp16 two-term image +
+    scale exponent (smaat_split_planes_h); see the note above"""
+    with _PLANES_LOCK:
+        return _weight_planes_locked(w2d, transpose, kind)
+
+
+def _weight_planes_locked(w2d, transpose, kind):
     L = _lib.get()
     r, c = (w2d.shape[1], w2d.shape[0]) if transpose else w2d.shape
     if kind == 0:
         cp = (c + 15) // 16 * 16
         shape = (3, r, cp)
+    elif kind == 3:
+        cp = (c + 15) // 16 * 16
+        shape = (int(L.smaat_split_planes_h_bytes(r, c)) // 2,)
     else:
         cp = (c + 31) // 32 * 32
         shape = (cp // 16, r, 16)
 
-    def direct():
-        planes = torch.empty(shape, dtype=torch.int16, device=w2d.device)
+    def direct(planes=None):
+        if planes is None:
+            planes = torch.empty(shape, dtype=torch.int16, device=w2d.device)
         if kind == 0:
             fn = L.smaat_split_planes_t if transpose else L.smaat_split_planes
             _lib.check(fn(_ptr(w2d), r, c, _ptr(planes), _stream(w2d)), "smaat_split_planes")
+        elif kind == 3:
+            _lib.check(L.smaat_split_planes_h(_ptr(w2d), r, c, _ptr(planes), 1 if transpose else 0, _stream(w2d)),
+                       "smaat_split_planes_h")
         else:
             _lib.check(L.smaat_bf16_planes(_ptr(w2d), r, c, _ptr(planes), 1 if transpose else 0, _stream(w2d)), "smaat_bf16_planes")
         return planes
@@ -275,16 +330,19 @@ def _weight_planes(w2d, transpose, kind):
     mode = L.smaat_split_mode() if kind == 0 else -1
     key = (w2d.data_ptr(), r, c, bool(transpose), kind, mode, stream)
     e = _PLANES.get(key)
-    force = False
     if e is not None and e.ref() is base:
         if e.version == base._version:
             if not e.used:
                 e.used = True
                 return e.planes
-            # second use of an image since its last refresh: a new pass over the network with (as far as the version counters
-            # say) unchanged weights -- gradient accumulation, repeated evaluation, or weights written through `.data`, which no
-            # counter sees.  Refresh everything once per pass: one launch, and `.data` writes between passes are honoured.
-            force = True
+            # second use of an image since its last refresh with (as far as the version counters say) unchanged weights --
+            # gradient accumulation, repeated evaluation, or weights written through `.data`, which no counter sees.  THIS image
+            # is refreshed by itself (one small launch) and nothing else is touched: a refresh of all images here would hand the
+            # images of OTHER modules another unrefreshed use, and a `.data` write to one of those in between would be served
+            # stale (A(x); B(x); A(x); B.w.data.add_(); B(x)).  The one-launch refresh below stays what the training
+            # loop sees: an optimizer step bumps every version counter.
+            direct(e.planes)
+            return e.planes
     else:
         e = _PlaneEntry()
         e.ref, e.off, e.src = weakref.ref(base), w2d.data_ptr() - base.data_ptr(), w2d.data_ptr()
@@ -294,12 +352,13 @@ def _weight_planes(w2d, transpose, kind):
         e.planes = torch.empty(shape, dtype=torch.int16, device=w2d.device)
         _PLANES[key] = e
     # refresh every stale image of this device / stream / split mode in one launch
+    cur_mode = L.smaat_split_mode()
     stale, dead = [], []
     for k, x in _PLANES.items():
         b = x.ref()
         if b is None or b.data_ptr() + x.off != x.src:
             dead.append(k)
-        elif x.dev == e.dev and x.stream == stream and (x.kind != 0 or x.mode == mode) and (force or x.version != b._version):
+        elif x.dev == e.dev and x.stream == stream and (x.kind != 0 or x.mode == cur_mode) and x.version != b._version:
             stale.append((x, b._version))
     for k in dead:
         del _PLANES[k]
@@ -308,13 +367,19 @@ def _weight_planes(w2d, transpose, kind):
     if table is None:
         if len(_PLANES_TABLE) > 16:
             _PLANES_TABLE.clear()
-        rows, b0 = [], 0
+        rows, b0, hp = [], 0, 0
         for x, _ in stale:
             rows.append([x.src, x.planes.data_ptr(), x.r, x.c, x.kind, x.src_t, b0, x.nblk])
             b0 += x.nblk
-        table = (torch.tensor(rows, dtype=torch.int64).to(e.dev), b0, [x for x, _ in stale])  # (keeps the entries alive)
+            if x.kind == 3:
+                hp += L.smaat_split_planes_h_pieces(x.r, x.c)
+        table = (torch.tensor(rows, dtype=torch.int64).to(e.dev), b0, [x for x, _ in stale], hp)  # (keeps the entries alive)
         _PLANES_TABLE[ids] = table
-    _lib.check(L.smaat_weight_planes_multi(_ptr(table[0]), len(stale), table[1], stream), "smaat_weight_planes_multi")
+    if table[3] > 0:  # fp16 two-term images among them: their maxima first (a second launch), then all images
+        _lib.check(L.smaat_weight_planes_multi_h(_ptr(table[0]), len(stale), table[1], table[3], stream),
+                   "smaat_weight_planes_multi_h")
+    else:
+        _lib.check(L.smaat_weight_planes_multi(_ptr(table[0]), len(stale), table[1], stream), "smaat_weight_planes_multi")
     for x, v in stale:
         x.version, x.used = v, False
     e.used = True
@@ -328,8 +393,16 @@ def _split_planes_raw(w2d, transpose=False):
     return _weight_planes(w2d, transpose, 0)
 
 
-def _pointwise_split_raw(x, planes, bias, m, want_stats=False):
-    """out[n][m][p] = sum_c A[m][c] x[n][c][p] + bias[m] with A given as split planes"""
+def _split_planes_h_raw(w2d, transpose=False):
+    """w2d [R][C] f32 -> the fp16 two-term image of w2d * 2^kexp with its trailer (smaat_split_planes_h); transpose=True: of
+    w2d^T (w2d stored [C][R]).  A shared cached image (_weight_planes): read-only for the caller."""
+    return _weight_planes(w2d, transpose, 3)
+
+
+def _pointwise_split_raw(x, planes, bias, m, want_stats=False, amax=None):
+    """out[n][m][p] = sum_c A[m][c] x[n][c][p] + bias[m] with A given as split planes.  amax (int32 word holding the bit
+    pattern of max |x|, written by the kernel that produced x): planes is then an fp16 image (_split_planes_h_raw) and the
+    GEMM runs the two-term fp16 split"""
     L = _lib.get()
     x, x_bs = _planes(x)
     n, c, h, w = x.shape
@@ -338,14 +411,20 @@ def _pointwise_split_raw(x, planes, bias, m, want_stats=False):
     if want_stats:
         slots = L.smaat_pw_split_num_slots(n, h, w)
         part = _new(x, 3, slots, m)
+    if amax is not None:
+        _lib.check(L.smaat_pointwise_fwd_split_h(_ptr(x), x_bs, _ptr(amax), _ptr(planes), _ptr(bias), _ptr(out), m * h * w,
+                                                 _ptr(part), n, c, m, h, w, _stream(x)), "smaat_pointwise_fwd_split_h")
+        return out, part, slots
     _lib.check(L.smaat_pointwise_fwd_split(_ptr(x), x_bs, _ptr(planes), _ptr(bias), _ptr(out), m * h * w, _ptr(part),
                                            n, c, m, h, w, _stream(x)), "smaat_pointwise_fwd_split")
     return out, part, slots
 
 
-def _dw3x3_fwd_raw(x, w_dw, b_dw, kpl, in_scale=None, in_shift=None, out_dtype=None):
+def _dw3x3_fwd_raw(x, w_dw, b_dw, kpl, in_scale=None, in_shift=None, out_dtype=None, amx=None):
     """standalone depthwise 3x3 forward; None when the library does not handle the shape.  out_dtype: torch.float32
-    (default: the dtype of x) or torch.bfloat16 (mixed precision: x may be f32 -- the stem -- or bf16)"""
+    (default: the dtype of x) or torch.bfloat16 (mixed precision: x may be f32 -- the stem -- or bf16).
+    amx (f32 only): {"w": int32 words [y, dz], ...}; the kernel leaves max |y| in word 0 and amx["y"] = True, when the
+    row-streaming kernel takes the shape"""
     L = _lib.get()
     x, x_bs = _planes(x)
     n, cin, h, w = x.shape
@@ -359,6 +438,14 @@ def _dw3x3_fwd_raw(x, w_dw, b_dw, kpl, in_scale=None, in_shift=None, out_dtype=N
             raise NotImplementedError(f"depthwise 3x3 with bf16 storage: shape [{n},{cin},{h},{w}] kpl={kpl} not built")
         _lib.check(rc, "smaat_dw3x3_fwd_t")
         return y
+    if amx is not None:
+        rc = L.smaat_dw3x3_fwd_amax(_ptr(x), x_bs, _ptr(in_scale), _ptr(in_shift), _ptr(w_dw), _ptr(b_dw), _ptr(y), k * h * w,
+                                    _ptr(amx["w"]), n, cin, kpl, h, w, _stream(x))
+        if rc == 0:
+            amx["y"] = True
+            return y
+        if rc != -2:
+            _lib.check(rc, "smaat_dw3x3_fwd_amax")
     rc = L.smaat_dw3x3_fwd(_ptr(x), x_bs, _ptr(in_scale), _ptr(in_shift), _ptr(w_dw), _ptr(b_dw), _ptr(y), k * h * w,
                            n, cin, kpl, h, w, _stream(x))
     if rc == -2:
@@ -367,13 +454,15 @@ def _dw3x3_fwd_raw(x, w_dw, b_dw, kpl, in_scale=None, in_shift=None, out_dtype=N
     return y
 
 
-def _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, in_shift=None):
-    """depthwise kernel + split pointwise GEMM; returns (z, part, slots, y) or None (unsupported shape)"""
-    y = _dw3x3_fwd_raw(x, w_dw, b_dw, kpl, in_scale, in_shift)
+def _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, in_shift=None, amx=None):
+    """depthwise kernel + split pointwise GEMM; returns (z, part, slots, y) or None (unsupported shape).  amx: see
+    _dw3x3_fwd_raw -- with the maximum of the depthwise output at hand the GEMM runs the two-term fp16 split"""
+    y = _dw3x3_fwd_raw(x, w_dw, b_dw, kpl, in_scale, in_shift, amx=amx)
     if y is None:
         return None
     cout = w_pw.shape[0]
-    planes = _split_planes_raw(w_pw.reshape(cout, -1))
+    ay = amx["w"][0:1] if (amx is not None and amx.get("y")) else None
+    planes = _split_planes_h_raw(w_pw.reshape(cout, -1)) if ay is not None else _split_planes_raw(w_pw.reshape(cout, -1))
     L = _lib.get()
     n, k, h, w = y.shape
     # layers that leave the chip under-filled (18 x 18 at batch 32: 384 serial chains of 64 chunks): the contraction is cut
@@ -386,13 +475,17 @@ def _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None,
         if want_stats:
             slots = L.smaat_pw_split_num_slots(n, h, w)
             part = _new(y, 3, slots, cout)
-        rc = L.smaat_pointwise_fwd_split_k(_ptr(y), k * h * w, _ptr(planes), _ptr(b_pw), _ptr(z), cout * h * w, _ptr(part),
-                                           _ptr(ws), s_k, n, k, cout, h, w, 0, _stream(y))
+        if ay is not None:
+            rc = L.smaat_pointwise_fwd_split_k_h(_ptr(y), k * h * w, _ptr(ay), _ptr(planes), _ptr(b_pw), _ptr(z), cout * h * w,
+                                                 _ptr(part), _ptr(ws), s_k, n, k, cout, h, w, _stream(y))
+        else:
+            rc = L.smaat_pointwise_fwd_split_k(_ptr(y), k * h * w, _ptr(planes), _ptr(b_pw), _ptr(z), cout * h * w, _ptr(part),
+                                               _ptr(ws), s_k, n, k, cout, h, w, 0, _stream(y))
         if rc == 0:
             return z, part, slots, y
         if rc != -2:
             _lib.check(rc, "smaat_pointwise_fwd_split_k")
-    z, part, slots = _pointwise_split_raw(y, planes, b_pw, cout, want_stats)
+    z, part, slots = _pointwise_split_raw(y, planes, b_pw, cout, want_stats, amax=ay)
     return z, part, slots, y
 
 
@@ -572,9 +665,10 @@ def _affine_act_raw(z, scale, shift, relu, out=None):
     return out
 
 
-def _bn_bwd_raw(dy, z, st, gamma, relu, train, pre_part=None):
+def _bn_bwd_raw(dy, z, st, gamma, relu, train, pre_part=None, amax=None):
     """dz, dgamma, dbeta for y = relu?(bn(z)).  st rows: mean, invstd, scale, shift.
-    pre_part = (part [2][slots][C], slots): the reduction already produced by smaat_dw3x3_bwd_bnred."""
+    pre_part = (part [2][slots][C], slots): the reduction already produced by smaat_dw3x3_bwd_bnred.
+    amax (f32 storage only): int32 word that receives the bit pattern of max |dz| (two-term fp16 split of the consumers)"""
     L = _lib.get()
     dy, dy_bs = _planes(dy)
     z, z_bs = _planes(z)
@@ -610,13 +704,18 @@ def _bn_bwd_raw(dy, z, st, gamma, relu, train, pre_part=None):
                                           _ptr(st[0]), _ptr(st[1]), _ptr(coef), _ptr(dz), _dt(dz), c * p, n, c, p,
                                           1 if relu else 0, None, s), "smaat_bn_bwd_apply_t")
         return dz, dgamma, dbeta
+    if amax is not None:
+        _lib.check(L.smaat_bn_bwd_apply_amax(_ptr(dy), dy_bs, None, _ptr(z), z_bs, _ptr(st[2]), _ptr(st[3]), _ptr(st[0]),
+                                             _ptr(st[1]), _ptr(coef), _ptr(dz), c * p, _ptr(amax), n, c, p, 1 if relu else 0, s),
+                   "smaat_bn_bwd_apply_amax")
+        return dz, dgamma, dbeta
     _lib.check(L.smaat_bn_bwd_apply(_ptr(dy), dy_bs, _ptr(z), z_bs, _ptr(st[2]), _ptr(st[3]), _ptr(st[0]),
                                     _ptr(st[1]), _ptr(coef), _ptr(dz), c * p, n, c, p, 1 if relu else 0, s),
                "smaat_bn_bwd_apply")
     return dz, dgamma, dbeta
 
 
-def _bn_bwd_head_raw(dlog, w_out, z, st, gamma, train):
+def _bn_bwd_head_raw(dlog, w_out, z, st, gamma, train, amax=None):
     """BatchNorm + ReLU backward when the consumer of y = relu(bn(z)) is a 1x1 convolution to ONE channel whose output
     gradient is dlog [N][1][H][W]: dy = w_out[c] * dlog is formed on the fly (smaat_bn_bwd_*_head), never stored.
     -> dz, dgamma, dbeta, dw_out [1][C][1][1]"""
@@ -647,6 +746,10 @@ def _bn_bwd_head_raw(dlog, w_out, z, st, gamma, train):
         _lib.check(L.smaat_bn_bwd_apply_t(_ptr(dlog), 0, dl_bs, _ptr(z), _dt(z), z_bs, _ptr(st[2]), _ptr(st[3]), _ptr(st[0]),
                                           _ptr(st[1]), _ptr(coef), _ptr(dz), _dt(dz), c * p, n, c, p, 1, _ptr(wv), s),
                    "smaat_bn_bwd_apply_t(head)")
+    elif amax is not None:
+        _lib.check(L.smaat_bn_bwd_apply_amax(_ptr(dlog), dl_bs, _ptr(wv), _ptr(z), z_bs, _ptr(st[2]), _ptr(st[3]), _ptr(st[0]),
+                                             _ptr(st[1]), _ptr(coef), _ptr(dz), c * p, _ptr(amax), n, c, p, 1, s),
+                   "smaat_bn_bwd_apply_amax(head)")
     else:
         _lib.check(L.smaat_bn_bwd_apply_head(_ptr(dlog), dl_bs, _ptr(wv), _ptr(z), z_bs, _ptr(st[2]), _ptr(st[3]),
                                              _ptr(st[0]), _ptr(st[1]), _ptr(coef), _ptr(dz), c * p, n, c, p, s),
@@ -686,8 +789,9 @@ def _channel_sum_raw(x):
     return out
 
 
-def _pointwise_wgrad_raw(y, dz, m):
-    """dW[m][k] = sum_{n,p} dz[n][m][p] * y[n][k][p]  -> tensor [m][k][1][1]"""
+def _pointwise_wgrad_raw(y, dz, m, amax_y=None, amax_dz=None):
+    """dW[m][k] = sum_{n,p} dz[n][m][p] * y[n][k][p]  -> tensor [m][k][1][1].  amax_y / amax_dz (both or neither; f32
+    storage): the operands' maximum words -> two-term fp16 split"""
     L = _lib.get()
     y, y_bs = _planes(y)
     dz, dz_bs = _planes(dz)
@@ -705,12 +809,16 @@ def _pointwise_wgrad_raw(y, dz, m):
             raise NotImplementedError(f"bf16 pointwise weight gradient: [{n},{k},{h},{w}] x {m} not built (odd plane size?)")
         _lib.check(rc, "smaat_pointwise_wgrad_bf16")
         return dw
+    if amax_y is not None and amax_dz is not None:
+        _lib.check(L.smaat_pointwise_wgrad_h(_ptr(y), y_bs, _ptr(amax_y), _ptr(dz), dz_bs, _ptr(amax_dz), _ptr(ws), _ptr(dw), n,
+                                             k, m, h, w, _stream(y)), "smaat_pointwise_wgrad_h")
+        return dw
     _lib.check(L.smaat_pointwise_wgrad(_ptr(y), y_bs, _ptr(dz), dz_bs, _ptr(ws), _ptr(dw), n, k, m, h, w,
                                        _stream(y)), "smaat_pointwise_wgrad")
     return dw
 
 
-def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None, in_aff=None):
+def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None, in_aff=None, amx=None):
     """gradients of z = pointwise(depthwise(x)) given dz: dx, dw_dw, db_dw, dw_pw.
     y: the depthwise output kept by the forward (streamed weight gradient); when None the
     memory-lean kernel recomputes it from x."""
@@ -725,8 +833,11 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None, i
         return _dsconv_bwd_bf16(x, x_bs, w_dw, b_dw, w_pw, dz, kpl, need_dx, y, bnred, in_aff)
     if _is_bf(x):  # the forward of this block fell back to f32 storage (_bf16_storage_ok) on a bf16 input
         x, x_bs = _planes(x.float())
+    # amx = {"w": int32 words [max |y|, max |dz|], "y": bool, "dz": bool}: which maxima the producing kernels left
+    a_dz = amx["w"][1:2] if (amx is not None and amx.get("dz")) else None
+    a_y = amx["w"][0:1] if (amx is not None and amx.get("y")) else None
     if y is not None:
-        dw_pw = _pointwise_wgrad_raw(y, dz, cout)
+        dw_pw = _pointwise_wgrad_raw(y, dz, cout, a_y if a_dz is not None else None, a_dz if a_y is not None else None)
     else:
         # no depthwise tensor was kept: it is recomputed from x (with the previous activation applied on load) inside
         # the weight-gradient kernel -- on the split matrix path where that kernel takes the shape (the training policy,
@@ -749,8 +860,11 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None, i
     # data gradient of the pointwise conv: dY = W^T dZ  (wt := w_pw in its natural [Cout][K] layout)
     if _split_dgrad_ok(cout, k):
         # A[m' = k][c = co] = w_pw[co][k]: planes of the transposed weight
-        planes_t = _split_planes_raw(w_pw.reshape(cout, k), transpose=True)
-        dy, _, _ = _pointwise_split_raw(dz, planes_t, None, k)
+        if a_dz is not None:
+            planes_t = _split_planes_h_raw(w_pw.reshape(cout, k), transpose=True)
+        else:
+            planes_t = _split_planes_raw(w_pw.reshape(cout, k), transpose=True)
+        dy, _, _ = _pointwise_split_raw(dz, planes_t, None, k, amax=a_dz)
     else:
         dy = _new(x, n, k, h, w)
         _lib.check(L.smaat_pointwise_fwd(_ptr(dz), dz_bs, _ptr(w_pw), None, _ptr(dy), k * h * w, None, n, cout, k, h,
@@ -855,10 +969,12 @@ def _bf16_storage_ok(h, w, kpl):
 
 
 def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, momentum, eps, kpl, keep_y, in_aff=None,
-                  want_act=True):
+                  want_act=True, amx=None):
     """DepthwiseSeparableConv -> BatchNorm2d -> ReLU.  Returns y, z, st, y_dw, use_batch_stats.
     in_aff = (scale, shift): x is a PRE-BatchNorm tensor and relu(x*scale + shift) is applied on load.
-    want_act=False: do not materialise y (the consumer applies this BatchNorm + ReLU on load)."""
+    want_act=False: do not materialise y (the consumer applies this BatchNorm + ReLU on load).
+    amx (dict, filled in place; None = exact three-term split everywhere): the operand maxima of this half for the two-term
+    fp16 split -- {"w": int32 words [max |y_dw|, max |dz|], "y": produced by the forward, "dz": to be produced by the backward}"""
     n, cin, h, w = x.shape
     cout = w_pw.shape[0]
     use_batch_stats = training or rm is None
@@ -887,8 +1003,14 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
             rs = _dsconv_fwd_rows(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish)
         if rs is None:
             rs = _dsconv_fwd_fused(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish, want_y=keep_y)
+    if amx is not None:
+        amx.update(w=None, y=False, dz=False)
+        if not bf and use_batch_stats and _f16_on():
+            amx["w"] = _amax_words(x, 2)
+            amx["dz"] = True  # (the backward's BatchNorm apply kernel will leave max |dz| in word 1)
     if rs is None and not bf and _split_fwd_ok(cin * kpl, cout, use_batch_stats):
-        rs = _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish)
+        rs = _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish,
+                               amx=amx if (amx is not None and amx["w"] is not None) else None)
     if rs is not None and use_batch_stats:
         z, part, slots, y_dw = rs
         if not keep_y:
@@ -916,15 +1038,18 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
 
 
 def _half_backward(x, w_dw, b_dw, w_pw, gamma, z, st, y_dw, dy, kpl, train_stats, has_bias, need_dx, pre_part=None,
-                   bnred=None, in_aff=None, head=None):
+                   bnred=None, in_aff=None, head=None, amx=None):
     """-> (dx, dw_dw, db_dw, dw_pw, db_pw, dgamma, dbeta), red.  pre_part: this BatchNorm's backward sums
     (from the following block's depthwise backward); in_aff=(scale, shift) + bnred=(mean, invstd) of the PREVIOUS
     BatchNorm: x is its input, the activation is applied on load and its backward sums are emitted (`red`)."""
+    if amx is not None and (amx.get("w") is None or not amx.get("dz") or _is_bf(z) or _is_bf(dy) or not _f16_on()):
+        amx = None  # (no maxima words, or a storage / mode change since the forward)
+    a_dz = amx["w"][1:2] if amx is not None else None
     if head is not None:  # dy is w_out (x) dlog, formed on the fly; head["dw"] receives the 1x1 conv's weight gradient
-        dz, dgamma, dbeta, head["dw"] = _bn_bwd_head_raw(head["dlog"], head["w"], z, st, gamma, train_stats)
+        dz, dgamma, dbeta, head["dw"] = _bn_bwd_head_raw(head["dlog"], head["w"], z, st, gamma, train_stats, amax=a_dz)
     else:
-        dz, dgamma, dbeta = _bn_bwd_raw(dy, z, st, gamma, True, train_stats, pre_part=pre_part)
-    r = _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=y_dw, bnred=bnred, in_aff=in_aff)
+        dz, dgamma, dbeta = _bn_bwd_raw(dy, z, st, gamma, True, train_stats, pre_part=pre_part, amax=a_dz)
+    r = _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=y_dw, bnred=bnred, in_aff=in_aff, amx=amx)
     dx, dw_dw, db_dw, dw_pw = r[:4]
     red = r[4] if bnred is not None else None
     if train_stats:
@@ -952,8 +1077,10 @@ class _DSConvBNReLU(torch.autograd.Function):
         bfm = _is_bf(x) or mixed_precision_active()
         keep_y = ((KEEP_DEPTHWISE_OUTPUT or bfm)
                   and any(ctx.needs_input_grad[:7 if bfm else 4]))  # forward runs under no_grad
+        amx = {} if keep_y else None
         y, z, st, y_dw, ubs = _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, momentum, eps,
-                                            kpl, keep_y)
+                                            kpl, keep_y, amx=amx)
+        ctx.amx = amx
         ctx.save_for_backward(x, w_dw, b_dw, w_pw, gamma, z, st, y_dw)
         ctx.kpl = kpl
         ctx.train_stats = ubs
@@ -964,7 +1091,7 @@ class _DSConvBNReLU(torch.autograd.Function):
     def backward(ctx, dy):
         x, w_dw, b_dw, w_pw, gamma, z, st, y_dw = ctx.saved_tensors
         g, _ = _half_backward(x, w_dw, b_dw, w_pw, gamma, z, st, y_dw, dy, ctx.kpl, ctx.train_stats, ctx.has_bias,
-                              ctx.needs_input_grad[0])
+                              ctx.needs_input_grad[0], amx=ctx.amx)
         return g + (None,) * 6
 
 
@@ -998,8 +1125,9 @@ class _DoubleConvDS(torch.autograd.Function):
         fuse = (FUSE_FIRST_ACTIVATION and keep_y and g1 is not None
                 and bool(_lib.get().smaat_dw3x3_strip_ok(kpl, h, w))
                 and (not bf or kpl <= 2))  # (bf16 storage: the row-streaming backward, kernels_per_layer <= 2)
+        amx1, amx2 = ({}, {}) if keep_y else (None, None)  # operand maxima of the two halves (two-term fp16 split)
         y1, z1, st1, ydw1, ubs1 = _half_forward(x, w_dw1, b_dw1, w_pw1, b_pw1, g1, be1, rm1, rv1, tr1, mo1, eps1, kpl,
-                                                keep_y, want_act=not fuse)
+                                                keep_y, want_act=not fuse, amx=amx1)
         # head: an OutConv with ONE output channel consumes the block (w_out [1][C][1][1]): the block output is not
         # written, the logits come from the pre-BatchNorm tensor with the activation applied on load
         head = w_out is not None
@@ -1008,7 +1136,8 @@ class _DoubleConvDS(torch.autograd.Function):
             _expect(b_out, (1,), "outc.conv.bias")
         y2, z2, st2, ydw2, ubs2 = _half_forward(z1 if fuse else y1, w_dw2, b_dw2, w_pw2, b_pw2, g2, be2, rm2, rv2, tr2,
                                                 mo2, eps2, kpl, keep_y, in_aff=(st1[2], st1[3]) if fuse else None,
-                                                want_act=not (head or defer))
+                                                want_act=not (head or defer), amx=amx2)
+        ctx.amx = (amx1, amx2)
         ctx.save_for_backward(x, w_dw1, b_dw1, w_pw1, g1, be1, z1, st1, ydw1, y1, w_dw2, b_dw2, w_pw2, g2, z2, st2,
                               ydw2, w_out)
         ctx.fuse = fuse
@@ -1037,9 +1166,9 @@ class _DoubleConvDS(torch.autograd.Function):
         gr2, red = _half_backward(z1 if ctx.fuse else y1, w_dw2, b_dw2, w_pw2, g2, z2, st2, ydw2, dy2, ctx.kpl,
                                   ctx.train_stats[1], ctx.has_bias[1], True,
                                   bnred=(st1[0], st1[1]) if ctx.fuse else None,
-                                  in_aff=(st1[2], st1[3]) if ctx.fuse else None, head=head)
+                                  in_aff=(st1[2], st1[3]) if ctx.fuse else None, head=head, amx=ctx.amx[1])
         gr1, _ = _half_backward(x, w_dw1, b_dw1, w_pw1, g1, z1, st1, ydw1, gr2[0], ctx.kpl, ctx.train_stats[0],
-                                ctx.has_bias[0], ctx.needs_input_grad[0], pre_part=red)
+                                ctx.has_bias[0], ctx.needs_input_grad[0], pre_part=red, amx=ctx.amx[0])
         ghead = (None, None)
         if head is not None:
             ghead = (head["dw"], _channel_sum_raw(head["dlog"]) if ctx.head[1] else None)

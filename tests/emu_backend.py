@@ -66,6 +66,60 @@ def mm(spec, a, b):
 
 
 
+# ---- two-term fp16 split, as csrc/splitmma.hip NT == 2 evaluates it (the twin of the *_h entry points) ------------------
+def f16_kexp(amax_bits):
+    """scale exponent from the bit pattern of max |x| (csrc/common.h f16_kexp)"""
+    am = int(amax_bits) & 0xFFFFFFFF
+    e = (am >> 23) & 0xFF
+    if e == 255 or (am & 0x7FFFFFFF) == 0:
+        return 0
+    return max(-126, min(126, 141 - e))
+
+
+def _amax_bits(a):
+    a = np.asarray(a, np.float32)
+    m = np.float32(np.nanmax(np.abs(a))) if a.size and not np.all(np.isnan(a)) else np.float32(0)  # (fmaxf drops NaNs)
+    return int(np.array([m], np.float32).view(np.uint32)[0])
+
+
+def _amax_publish(ptr, a):
+    """what the producing kernels leave in the amax word: max(old, max |a|) on the bit patterns"""
+    w = np.ctypeslib.as_array((ctypes.c_uint32 * 1).from_address(int(ptr)))
+    w[0] = max(int(w[0]), _amax_bits(a))
+
+
+def _h_terms(x, k):
+    """x * 2^k -> (h, g) as float32 arrays holding fp16 values (round to nearest even twice, exact residual)"""
+    with np.errstate(over="ignore", invalid="ignore"):
+        xs = (np.asarray(x, np.float32) * np.float32(2.0 ** k)).astype(np.float32)
+        h = xs.astype(np.float16).astype(np.float32)
+        g = (xs - h).astype(np.float16).astype(np.float32)
+    return h, g
+
+
+def mm_h(spec, a_terms, ka, b, kb):
+    """the three-product evaluation: (h_a g_b + g_a h_b) + h_a h_b in float32, scaled back by the two exact factors"""
+    ha, ga = a_terms
+    hb, gb = _h_terms(b, kb)
+    with np.errstate(over="ignore", invalid="ignore"):
+        r = (np.einsum(spec, ha, gb) + np.einsum(spec, ga, hb)) + np.einsum(spec, ha, hb)
+        if os.environ.get("SMAAT_EMU_H4", "") == "1":  # study: the fourth product g_a g_b as well
+            r = ((np.einsum(spec, ga, gb) + np.einsum(spec, ha, gb)) + np.einsum(spec, ga, hb)) + np.einsum(spec, ha, hb)
+        ks = ka + kb
+        h1 = int(ks / 2)  # (C integer division: towards zero) -- the kernels split the exponent evenly over two exact factors
+        return ((r * np.float32(2.0 ** -h1)) * np.float32(2.0 ** -(ks - h1))).astype(np.float32)
+
+
+def _h_image(ptr, R, C):
+    """decode an fp16 image written by smaat_split_planes_h: ((h, g) [R][C] float32, kexp)"""
+    Cp = (C + 15) // 16 * 16
+    n = (Cp // 16) * 2 * R * 16
+    u = np.ctypeslib.as_array((ctypes.c_uint16 * n).from_address(int(ptr))).reshape(Cp // 16, 2, R, 16)
+    t = u.view(np.float16).astype(np.float32).transpose(1, 2, 0, 3).reshape(2, R, Cp)[:, :, :C]
+    kexp = int(np.ctypeslib.as_array((ctypes.c_int32 * 1).from_address(int(ptr) + 2 * n))[0])
+    return (t[0], t[1]), kexp
+
+
 class EmuLib:
     # ------------------------------------------------------------------ queries
     def smaat_abi_version(self):
@@ -146,6 +200,8 @@ class EmuLib:
             assert nb == (R * Cp + 255) // 256
             if kind == 2:  # (the class's own methods: a test may have wrapped the instance's to count launches)
                 rc = EmuLib.smaat_bf16_planes(self, src, R, C, dst, src_t, stream)
+            elif kind == 3:
+                rc = EmuLib.smaat_split_planes_h(self, src, R, C, dst, src_t, stream)
             else:
                 rc = (EmuLib.smaat_split_planes_t if src_t else EmuLib.smaat_split_planes)(self, src, R, C, dst, stream)
             if rc:
@@ -178,6 +234,76 @@ class EmuLib:
         acc = mm("mc,ncp->nmp", a.astype(np.float32), xv)
         planes(out, N, M, P, out_bs)[:] = acc + (f32(bias, M)[None, :, None] if bias else 0)
         self._write_part(part, PW_SLOTS + 1, M, acc)
+        return 0
+
+    # ------------------------------------------------------------------ two-term fp16 split (round 5)
+    def smaat_dw3x3_fwd_amax(self, x, x_bs, in_scale, in_shift, w_dw, b_dw, y, y_bs, amax, N, Cin, kpl, H, W, stream):
+        if kpl not in (1, 2, 4) or W % 2 or W < 4:  # (only the row-streaming kernels produce the maximum)
+            return -2
+        rc = EmuLib.smaat_dw3x3_fwd(self, x, x_bs, in_scale, in_shift, w_dw, b_dw, y, y_bs, N, Cin, kpl, H, W, stream)
+        if rc == 0:
+            _amax_publish(amax, planes(y, N, Cin * kpl, H * W, y_bs))
+        return rc
+
+    def smaat_bn_bwd_apply_amax(self, dy, dy_bs, head_w, z, z_bs, scale, shift, mean, invstd, coef, dz, dz_bs, amax, N, C, P,
+                                relu, stream):
+        if head_w:
+            rc = EmuLib.smaat_bn_bwd_apply_head(self, dy, dy_bs, head_w, z, z_bs, scale, shift, mean, invstd, coef, dz, dz_bs,
+                                                N, C, P, stream)
+        else:
+            rc = EmuLib.smaat_bn_bwd_apply(self, dy, dy_bs, z, z_bs, scale, shift, mean, invstd, coef, dz, dz_bs, N, C, P, relu,
+                                           stream)
+        if rc == 0:
+            _amax_publish(amax, planes(dz, N, C, P, dz_bs))
+        return rc
+
+    def smaat_split_planes_h_pieces(self, R, C):
+        return (R * C + 4095) // 4096
+
+    def smaat_split_planes_h_bytes(self, R, C):
+        Cp = (C + 15) // 16 * 16
+        return (Cp // 16) * 2 * R * 16 * 2 + 16 + 4 * ((R * C + 4095) // 4096)
+
+    def smaat_split_planes_h(self, w, R, C, out, transposed, stream):
+        """fp16 image [Cp/16][2][R][16] of w * 2^kexp + trailer { int32 kexp }"""
+        wv = f32(w, R * C).reshape(C, R).T if transposed else f32(w, R * C).reshape(R, C)
+        Cp = (C + 15) // 16 * 16
+        k = f16_kexp(_amax_bits(wv))
+        pad = np.zeros((R, Cp), np.float32)
+        pad[:, :C] = wv
+        h, g = _h_terms(pad, k)
+        n = (Cp // 16) * 2 * R * 16
+        o = np.ctypeslib.as_array((ctypes.c_uint16 * n).from_address(int(out))).reshape(Cp // 16, 2, R, 16)
+        o[:, 0] = h.astype(np.float16).view(np.uint16).reshape(R, Cp // 16, 16).transpose(1, 0, 2)
+        o[:, 1] = g.astype(np.float16).view(np.uint16).reshape(R, Cp // 16, 16).transpose(1, 0, 2)
+        np.ctypeslib.as_array((ctypes.c_int32 * 1).from_address(int(out) + 2 * n))[0] = k
+        return 0
+
+    def smaat_weight_planes_multi_h(self, desc, n_desc, total_blocks, h_pieces, stream):
+        d = np.ctypeslib.as_array((ctypes.c_int64 * (8 * n_desc)).from_address(int(desc))).reshape(n_desc, 8)
+        assert h_pieces == sum((int(r[2]) * int(r[3]) + 4095) // 4096 for r in d if int(r[4]) == 3)
+        return EmuLib.smaat_weight_planes_multi(self, desc, n_desc, total_blocks, stream)
+
+    def smaat_pointwise_fwd_split_h(self, x, x_bs, x_amax, pl, bias, out, out_bs, part, N, Cin, M, H, W, stream):
+        P = H * W
+        a_terms, ka = _h_image(pl, M, Cin)
+        kx = f16_kexp(np.ctypeslib.as_array((ctypes.c_uint32 * 1).from_address(int(x_amax)))[0])
+        acc = mm_h("mc,ncp->nmp", a_terms, ka, planes(x, N, Cin, P, x_bs), kx)
+        planes(out, N, M, P, out_bs)[:] = acc + (f32(bias, M)[None, :, None] if bias else 0)
+        self._write_part(part, PW_SLOTS + 1, M, acc)
+        return 0
+
+    def smaat_pointwise_fwd_split_k_h(self, x, x_bs, x_amax, pl, bias, out, out_bs, part, ws, S, N, Cin, M, H, W, stream):
+        if x_bs != Cin * H * W or (H * W) % 4 or Cin % 16 or (Cin // 16) % S:
+            return -2
+        return self.smaat_pointwise_fwd_split_h(x, x_bs, x_amax, pl, bias, out, out_bs, part, N, Cin, M, H, W, stream)
+
+    def smaat_pointwise_wgrad_h(self, x, x_bs, x_amax, dz, dz_bs, dz_amax, ws, dw_out, N, Cin, M, H, W, stream):
+        P = H * W
+        rd = lambda p: int(np.ctypeslib.as_array((ctypes.c_uint32 * 1).from_address(int(p)))[0])  # noqa: E731
+        kx, kd = f16_kexp(rd(x_amax)), f16_kexp(rd(dz_amax))
+        f32(dw_out, M * Cin).reshape(M, Cin)[:] = mm_h("nmp,nkp->mk", _h_terms(planes(dz, N, M, P, dz_bs), kd), kd,
+                                                       planes(x, N, Cin, P, x_bs), kx)
         return 0
 
     def smaat_dsconv_split_num_slots(self, N, H, W):

@@ -1,0 +1,327 @@
+"""GPU: the two-term fp16 split GEMMs (round 5; csrc/splitmma.hip NT == 2, include/smaat_hip.h "two-term fp16 split") and the
+kernels that produce their operand maxima, through the C ABI.
+
+reference arithmetic: nn.Conv2d(K, Cout, 1) forward and its autograd, /root/reference models/layers.py:45,49 (f32 in ATen).
+Bars: every GEMM against an fp64 evaluation NEXT TO the exact three-term bf16 split it replaces (f32-class: no worse than
+3 x that kernel's error + 2e-7) and against the numpy twin (tests/emu_backend.py evaluates the same three fp16 products);
+operand images bit-exact against the twin; maxima bit-exact; producers' main outputs bit-identical to the entry points
+without the side output; adversarial operands (one channel 1e8 above the rest, gradients in the denormal range, all-zero
+planes, NaN) stay f32-class / propagate."""
+import numpy as np
+import pytest
+import torch
+
+from smaat_unet_amd import _lib
+from tests.emu_backend import EmuLib, f16_kexp
+from tests.test_gpu_kernels import P, T, both, part_stats, rel, rnd, stream
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _amax_word(dev):
+    return torch.zeros(1, dtype=torch.int32, device=dev)
+
+
+def _bits(x):
+    return int(np.array([x], np.float32).view(np.uint32)[0])
+
+
+def _publish(t):
+    """an amax word holding max |t| as the producing kernels would leave it"""
+    w = torch.zeros(1, dtype=torch.int32, device=t.device)
+    m = float(t.abs().max()) if t.numel() else 0.0
+    w[0] = np.array([m], np.float32).view(np.int32)[0].item()
+    return w
+
+
+def _h_image(L, dev, w, transposed=False):
+    R, C = (w.shape[1], w.shape[0]) if transposed else w.shape
+    pl = torch.full((int(L.smaat_split_planes_h_bytes(R, C)) // 2,), -1, dtype=torch.int16, device=dev)
+    assert L.smaat_split_planes_h(P(w), R, C, P(pl), 1 if transposed else 0, stream(dev)) == 0
+    return pl
+
+
+# ------------------------------------------------------------------------------------------------ operand images
+def case_planes_h(L, dev, R, C, transposed, scale):
+    w = T(rnd(5, C, R, scale=scale) if transposed else rnd(5, R, C, scale=scale), dev)
+    pl = _h_image(L, dev, w, transposed)
+    Cp = (C + 15) // 16 * 16
+    n = (Cp // 16) * 2 * R * 16
+    return dict(image=pl[:n].to(torch.int32), kexp=pl[n:n + 2].view(torch.int32).clone())
+
+
+@pytest.mark.parametrize("shape", [(64, 128, False, 0.2), (128, 64, True, 0.2), (70, 37, False, 3e-9), (19, 200, True, 4e5),
+                                   (512, 2048, False, 0.05), (2048, 512, True, 0.05), (1, 1, False, 1.0)])
+def test_split_planes_h_is_the_twin_bit_for_bit(shape):
+    r = both(case_planes_h, *shape, tol=0.0)
+    assert r["hip"]["kexp"][0] == r["emu"]["kexp"][0]
+
+
+def test_weight_planes_multi_h_equals_the_single_matrix_entry_points():
+    """kind-3 rows next to kind-0 rows in one refresh: images and exponents bit-identical to smaat_split_planes_h / smaat_split_planes"""
+    L, dev = _lib.get(), DEV
+    ws = [T(rnd(10 + i, r, c, scale=s), dev) for i, (r, c, s) in enumerate([(64, 128, 0.1), (300, 70, 2.0), (128, 512, 1e-3), (64, 64, 1.0)])]
+    kinds = [3, 3, 0, 3]
+    src_t = [0, 1, 0, 0]
+    rows, outs, b0, hp = [], [], 0, 0
+    for w, kind, st in zip(ws, kinds, src_t):
+        R, C = (w.shape[1], w.shape[0]) if st else w.shape
+        Cp = (C + 15) // 16 * 16
+        if kind == 3:
+            o = torch.full((int(L.smaat_split_planes_h_bytes(R, C)) // 2,), -1, dtype=torch.int16, device=dev)
+            hp += L.smaat_split_planes_h_pieces(R, C)
+        else:
+            o = torch.full((3 * R * Cp,), -1, dtype=torch.int16, device=dev)
+        nb = (R * Cp + 255) // 256
+        rows.append([w.data_ptr(), o.data_ptr(), R, C, kind, st, b0, nb])
+        b0 += nb
+        outs.append(o)
+    desc = torch.tensor(rows, dtype=torch.int64).to(dev)
+    assert L.smaat_weight_planes_multi_h(P(desc), len(rows), b0, hp, stream(dev)) == 0
+    torch.cuda.synchronize()
+    for w, kind, st, o in zip(ws, kinds, src_t, outs):
+        R, C = (w.shape[1], w.shape[0]) if st else w.shape
+        if kind == 3:
+            ref = _h_image(L, dev, w, bool(st))
+            n = ((C + 15) // 16) * 2 * R * 16 + 2  # image + the exponent word (the scratch behind it is unspecified)
+            assert torch.equal(o[:n], ref[:n])
+        else:
+            ref = torch.empty_like(o)
+            assert L.smaat_split_planes(P(w), R, C, P(ref), stream(dev)) == 0
+            assert torch.equal(o, ref)
+
+
+# ------------------------------------------------------------------------------------------------ producers of the maxima
+@pytest.mark.parametrize("shape", [(2, 12, 2, 32, 32), (3, 20, 2, 18, 18), (2, 4, 2, 144, 144), (1, 3, 4, 8, 12), (2, 5, 1, 8, 8),
+                                   (2, 64, 2, 36, 36), (1, 8, 2, 288, 288), (7, 9, 2, 12, 8), (1, 2, 2, 1, 8)])
+@pytest.mark.parametrize("aff", [False, True])
+def test_dw3x3_fwd_amax(shape, aff):
+    """y bit-identical to smaat_dw3x3_fwd; the word holds exactly max |y| (bit pattern)"""
+    L, dev = _lib.get(), DEV
+    N, Cin, kpl, H, W = shape
+    K = Cin * kpl
+    x = T(rnd(1, N, Cin, H, W), dev)
+    w_dw, b_dw = T(rnd(2, K, 9, scale=0.3), dev), T(rnd(3, K, scale=0.3), dev)
+    sc = T(np.random.default_rng(6).uniform(0.5, 1.5, Cin).astype(np.float32), dev) if aff else None
+    sh = T(rnd(7, Cin, scale=0.3), dev) if aff else None
+    y0 = torch.full((N, K, H, W), float("nan"), device=dev)
+    y1 = torch.full((N, K, H, W), float("nan"), device=dev)
+    assert L.smaat_dw3x3_fwd(P(x), Cin * H * W, P(sc), P(sh), P(w_dw), P(b_dw), P(y0), K * H * W, N, Cin, kpl, H, W, stream(dev)) == 0
+    am = _amax_word(dev)
+    assert L.smaat_dw3x3_fwd_amax(P(x), Cin * H * W, P(sc), P(sh), P(w_dw), P(b_dw), P(y1), K * H * W, P(am), N, Cin, kpl, H, W,
+                                  stream(dev)) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    assert am.item() == _publish(y1).item(), (am.item(), _publish(y1).item())
+
+
+def test_dw3x3_fwd_amax_refuses_what_the_row_kernels_do_not_take():
+    L, dev = _lib.get(), DEV
+    t = torch.zeros(1, 4, 9, 11, device=dev)
+    y = torch.zeros(1, 8, 9, 11, device=dev)
+    am = _amax_word(dev)
+    assert L.smaat_dw3x3_fwd_amax(P(t), 4 * 99, None, None, P(t), None, P(y), 8 * 99, P(am), 1, 4, 2, 9, 11, stream(dev)) == -2
+    assert L.smaat_dw3x3_fwd_amax(P(t), 4 * 99, None, None, P(t), None, P(y), 8 * 99, None, 1, 4, 2, 9, 11, stream(dev)) == -1
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 32 * 32), (3, 20, 18 * 18), (2, 7, 99), (1, 64, 288 * 288), (4, 130, 36 * 36)])
+@pytest.mark.parametrize("head", [False, True])
+def test_bn_bwd_apply_amax(shape, head):
+    """dz bit-identical to smaat_bn_bwd_apply / _head; the word holds exactly max |dz|"""
+    L, dev = _lib.get(), DEV
+    N, C, Pn = shape
+    z = T(rnd(1, N, C, Pn), dev)
+    dy = T(rnd(2, N, 1 if head else C, Pn, scale=3e-4), dev)
+    hw = T(rnd(8, C), dev) if head else None
+    scale, shift = T(np.abs(rnd(3, C)) + 0.5, dev), T(rnd(4, C, scale=0.2), dev)
+    mean, invstd = T(rnd(5, C, scale=0.1), dev), T(np.abs(rnd(6, C)) + 0.5, dev)
+    coef = T(rnd(9, 3, C, scale=0.1), dev)
+    dz0 = torch.full((N, C, Pn), float("nan"), device=dev)
+    dz1 = torch.full((N, C, Pn), float("nan"), device=dev)
+    dy_bs = Pn if head else C * Pn
+    if head:
+        assert L.smaat_bn_bwd_apply_head(P(dy), dy_bs, P(hw), P(z), C * Pn, P(scale), P(shift), P(mean), P(invstd), P(coef), P(dz0),
+                                         C * Pn, N, C, Pn, stream(dev)) == 0
+    else:
+        assert L.smaat_bn_bwd_apply(P(dy), dy_bs, P(z), C * Pn, P(scale), P(shift), P(mean), P(invstd), P(coef), P(dz0), C * Pn, N,
+                                    C, Pn, 1, stream(dev)) == 0
+    am = _amax_word(dev)
+    assert L.smaat_bn_bwd_apply_amax(P(dy), dy_bs, P(hw), P(z), C * Pn, P(scale), P(shift), P(mean), P(invstd), P(coef), P(dz1),
+                                     C * Pn, P(am), N, C, Pn, 1, stream(dev)) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dz0, dz1)
+    assert am.item() == _publish(dz1).item()
+
+
+# ------------------------------------------------------------------------------------------------ GEMMs
+def case_pw_split_h(L, dev, N, C, M, H, W, with_part=False, x=None, w=None, slices=0):
+    x = T(rnd(1, N, C, H, W) * np.exp(rnd(7, N, C, 1, 1)) if x is None else x, dev)   # wide dynamic range across channels
+    w = T(rnd(2, M, C, scale=0.2) if w is None else w, dev)
+    b = T(rnd(3, M), dev)
+    pl = _h_image(L, dev, w)
+    am = _publish(x)
+    out = torch.full((N, M, H, W), float("nan"), device=dev)
+    slots = L.smaat_pw_split_num_slots(N, H, W)
+    part = torch.full((3, slots, M), float("nan"), device=dev) if with_part else None
+    if slices:
+        ws = torch.empty(N * slices * M * H * W, device=dev)
+        rc = L.smaat_pointwise_fwd_split_k_h(P(x), C * H * W, P(am), P(pl), P(b), P(out), M * H * W, P(part), P(ws), slices, N, C, M,
+                                             H, W, stream(dev))
+    else:
+        rc = L.smaat_pointwise_fwd_split_h(P(x), C * H * W, P(am), P(pl), P(b), P(out), M * H * W, P(part), N, C, M, H, W,
+                                           stream(dev))
+    assert rc == 0, rc
+    r = dict(out=out)
+    if with_part:
+        r["pn"], r["pmean"], r["pvar"] = part_stats(part)
+    return r
+
+
+PW_SHAPES = [(2, 64, 1, 32, 32), (2, 64, 21, 16, 16), (2, 16, 3, 6, 7), (2, 128, 256, 36, 36), (4, 64, 70, 288, 288),
+             (2, 1, 64, 20, 20), (2, 512, 1024, 18, 18), (4, 40, 130, 288, 288), (2, 24, 64, 32, 32), (1, 37, 19, 5, 9),
+             (4, 16, 64, 288, 288), (3, 8, 200, 144, 144)]
+
+
+@pytest.mark.parametrize("shape", PW_SHAPES)
+def test_pointwise_fwd_split_h(shape):
+    both(case_pw_split_h, *shape, tol=2e-6)
+    both(case_pw_split_h, *shape, with_part=True, tol=2e-5)  # (the variance partials: as test_pointwise_fwd_split)
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 64, 18, 18, 2), (3, 1024, 512, 18, 18, 4), (1, 512, 130, 6, 10, 2)])
+def test_pointwise_fwd_split_k_h(shape):
+    *s, S = shape
+    both(case_pw_split_h, *s, with_part=True, slices=S, tol=2e-5)
+
+
+def _fp64_pw(x, w, b):
+    return np.einsum("mc,nchw->nmhw", w.astype(np.float64), x.astype(np.float64)) + b.astype(np.float64)[None, :, None, None]
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 64, 72, 64), (2, 1024, 512, 18, 18), (4, 256, 128, 36, 36), (1, 64, 64, 288, 288)])
+def test_pointwise_fwd_split_h_against_fp64_next_to_the_three_term_split(shape):
+    L, dev = _lib.get(), DEV
+    N, C, M, H, W = shape
+    x = rnd(1, N, C, H, W) * np.exp(rnd(7, N, C, 1, 1))
+    w, b = rnd(2, M, C, scale=0.2), rnd(3, M)
+    ref = _fp64_pw(x, w, b)
+    new = case_pw_split_h(L, dev, N, C, M, H, W)["out"].cpu().numpy()
+    from tests.test_gpu_kernels import case_pw_split
+    old = case_pw_split(L, dev, N, C, M, H, W)["out"].cpu().numpy()
+    e_new, e_old = rel(new, ref), rel(old, ref)
+    assert e_new < 1e-6 and e_new < 3 * e_old + 2e-7, (e_new, e_old)
+    again = case_pw_split_h(L, dev, N, C, M, H, W)["out"].cpu().numpy()
+    assert np.array_equal(new, again)  # bit-reproducible
+
+
+def test_pointwise_fwd_split_h_adversarial_operands():
+    """(a) one input channel 1e8 above the rest, (b) one weight row 1e8 above the rest, (c) an operand whose values sit in the
+    denormal range of f32 / far below fp16's range, (d) all-zero operand, (e) a NaN: f32-class in rel-L2 (a-c), per output row
+    bounded (b), exact zeros + bias (d), propagated (e)"""
+    L, dev = _lib.get(), DEV
+    N, C, M, H, W = 2, 128, 64, 16, 32
+    b = rnd(3, M)
+    # (a)
+    x = rnd(1, N, C, H, W)
+    x[:, 5] *= 1e8
+    w = rnd(2, M, C, scale=0.2)
+    out = case_pw_split_h(L, dev, N, C, M, H, W, x=x, w=w)["out"].cpu().numpy()
+    assert rel(out, _fp64_pw(x, w, b)) < 1e-6
+    # with that channel's weights zeroed the result is made of the SMALL channels only: they sit 2^26 below the tensor's
+    # maximum, their second fp16 term is subnormal -- the documented loss: relative error ~2^-13 on those elements, i.e. an
+    # absolute error <= 2^-39 of the operand maximum
+    w0 = w.copy()
+    w0[:, 5] = 0
+    out0 = case_pw_split_h(L, dev, N, C, M, H, W, x=x, w=w0)["out"].cpu().numpy()
+    ref0 = _fp64_pw(x, w0, b)
+    assert np.abs(out0 - ref0).max() <= 2.0 ** -36 * np.abs(x).max() * np.abs(w0).sum(1).max()
+    # (b)
+    w2 = rnd(2, M, C, scale=0.2)
+    w2[7] *= 1e8
+    x2 = rnd(1, N, C, H, W)
+    out2 = case_pw_split_h(L, dev, N, C, M, H, W, x=x2, w=w2)["out"].cpu().numpy()
+    ref2 = _fp64_pw(x2, w2, b)
+    assert rel(out2, ref2) < 1e-6 and rel(out2[:, 7], ref2[:, 7]) < 1e-6
+    small = np.arange(M) != 7
+    assert np.abs(out2[:, small] - ref2[:, small]).max() <= 2.0 ** -36 * np.abs(w2).max() * np.abs(x2).sum(1).max()
+    # (c) tiny operand: the scale lifts it into range
+    x3 = rnd(1, N, C, H, W) * np.float32(1e-36)
+    out3 = case_pw_split_h(L, dev, N, C, M, H, W, x=x3, w=w)["out"].cpu().numpy()
+    ref3 = _fp64_pw(x3, w, np.zeros(M, np.float32)) + 0
+    assert rel(out3 - b[None, :, None, None], ref3) < 1e-5  # (products near the f32 denormal boundary themselves)
+    x4 = rnd(1, N, C, H, W) * np.float32(1e-20)
+    out4 = case_pw_split_h(L, dev, N, C, M, H, W, x=x4, w=w)["out"].cpu().numpy()
+    assert rel(out4 - b[None, :, None, None], _fp64_pw(x4, w, np.zeros(M, np.float32))) < 1e-6
+    # (d)
+    out5 = case_pw_split_h(L, dev, N, C, M, H, W, x=np.zeros((N, C, H, W), np.float32), w=w)["out"].cpu().numpy()
+    assert np.array_equal(out5, np.broadcast_to(b[None, :, None, None], out5.shape))
+    # (e)
+    x6 = rnd(1, N, C, H, W)
+    x6[1, 3, 2, 2] = np.nan
+    out6 = case_pw_split_h(L, dev, N, C, M, H, W, x=x6, w=w)["out"].cpu().numpy()
+    assert np.isnan(out6[1, :, 2, 2]).all() and np.isfinite(out6[0]).all()
+
+
+def case_wgrad_h(L, dev, N, C, M, H, W, x=None, dz=None):
+    x = T(rnd(1, N, C, H, W) if x is None else x, dev)
+    dz = T(rnd(2, N, M, H, W) * np.exp(2 * rnd(8, N, M, 1, 1)) * 1e-4 if dz is None else dz, dev)  # log-normal gradient scales
+    ns = L.smaat_wgrad_num_splits(N, H, W, M, C)
+    ws = torch.empty((ns, M, C), device=dev)
+    dw = torch.full((M, C), float("nan"), device=dev)
+    ax, adz = _publish(x), _publish(dz)
+    assert L.smaat_pointwise_wgrad_h(P(x), C * H * W, P(ax), P(dz), M * H * W, P(adz), P(ws), P(dw), N, C, M, H, W, stream(dev)) == 0
+    return dict(dw=dw)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 1, 32, 32), (2, 64, 21, 16, 16), (2, 16, 3, 6, 7), (2, 64, 1, 288, 288),
+                                   (2, 128, 64, 36, 36), (2, 24, 64, 64, 64), (3, 130, 70, 9, 11), (2, 256, 200, 18, 18),
+                                   (1, 1024, 512, 18, 18), (2, 256, 64, 144, 144), (1, 5, 3, 7, 9)])
+def test_pointwise_wgrad_h(shape):
+    both(case_wgrad_h, *shape, tol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 64, 72, 64), (2, 1024, 512, 18, 18), (2, 128, 128, 144, 144)])
+def test_pointwise_wgrad_h_against_fp64_next_to_the_three_term_split(shape):
+    L, dev = _lib.get(), DEV
+    N, C, M, H, W = shape
+    x = rnd(1, N, C, H, W)
+    dz = rnd(2, N, M, H, W) * np.exp(2 * rnd(8, N, M, 1, 1)) * 1e-4
+    dz[:, :, ::7, ::5] *= 1e4  # outliers
+    ref = np.einsum("nmp,nkp->mk", dz.astype(np.float64).reshape(N, M, -1), x.astype(np.float64).reshape(N, C, -1))
+    new = case_wgrad_h(L, dev, N, C, M, H, W, x=x, dz=dz)["dw"].cpu().numpy()
+    ns = L.smaat_wgrad_num_splits(N, H, W, M, C)
+    ws = torch.empty((ns, M, C), device=dev)
+    old = torch.empty((M, C), device=dev)
+    assert L.smaat_pointwise_wgrad(P(T(x, dev)), C * H * W, P(T(dz, dev)), M * H * W, P(ws), P(old), N, C, M, H, W, stream(dev)) == 0
+    e_new, e_old = rel(new, ref), rel(old.cpu().numpy(), ref)
+    assert e_new < 2e-6 and e_new < 3 * e_old + 2e-7, (e_new, e_old)
+    assert np.array_equal(new, case_wgrad_h(L, dev, N, C, M, H, W, x=x, dz=dz)["dw"].cpu().numpy())
+
+
+def test_pointwise_wgrad_h_denormal_range_gradient_and_zero_planes():
+    L, dev = _lib.get(), DEV
+    N, C, M, H, W = 2, 128, 64, 16, 32
+    x = rnd(1, N, C, H, W)
+    x[:, 10] = 0  # an all-zero plane of y
+    dz = rnd(2, N, M, H, W) * np.float32(3e-39)  # f32 denormals
+    dz[:, 3] = 0
+    ref = np.einsum("nmp,nkp->mk", dz.astype(np.float64).reshape(N, M, -1), x.astype(np.float64).reshape(N, C, -1))
+    dw = case_wgrad_h(L, dev, N, C, M, H, W, x=x, dz=dz)["dw"].cpu().numpy()
+    assert np.all(dw[3] == 0) and np.all(dw[:, 10] == 0)
+    # (dz itself carries ~8 significant bits down there; the GEMM must not lose more than the operand has)
+    assert rel(dw, ref) < 1e-5
+    dz2 = rnd(2, N, M, H, W) * np.float32(1e-30)
+    ref2 = np.einsum("nmp,nkp->mk", dz2.astype(np.float64).reshape(N, M, -1), x.astype(np.float64).reshape(N, C, -1))
+    assert rel(case_wgrad_h(L, dev, N, C, M, H, W, x=x, dz=dz2)["dw"].cpu().numpy(), ref2) < 1e-6
+
+
+def test_kexp_matches_the_twin_on_edge_maxima():
+    """the scale exponent the kernels derive from a maximum word: spot values through a 1 x 1 GEMM"""
+    L, dev = _lib.get(), DEV
+    for m in (1.0, 65504.0, 3e-39, 1e-45, 3e38, 2.0 ** -113, 0.75):
+        x = np.full((1, 16, 2, 2), m, np.float32)
+        w = np.ones((1, 16), np.float32)
+        out = case_pw_split_h(L, dev, 1, 16, 1, 2, 2, x=x, w=w)["out"].cpu().numpy()
+        want = np.float32(16) * np.float32(m) + rnd(3, 1)[0]
+        assert np.allclose(out, want, rtol=2e-6, atol=0), (m, out.ravel()[:2], want, f16_kexp(_bits(m)))
