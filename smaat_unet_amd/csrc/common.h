@@ -135,13 +135,25 @@ __device__ __forceinline__ float wave_max_all(float v) {
 // so a wave whose maximum is not above the value it reads has nothing to add (the read may be stale: then the atomic is
 // merely redundant) -- a few dozen atomics per tensor instead of one per wave.  Unsigned compare on the bit pattern of a
 // non-negative float is the float compare; the result is order-independent, i.e. bit-reproducible.  slot starts at 0.
-__device__ __forceinline__ void amax_publish(unsigned* slot, float m) {
-    m = wave_max_all(m);
-    if ((threadIdx.x & 63) == 0) {
-        const unsigned b = __builtin_bit_cast(unsigned, m);
-        if (b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            __hip_atomic_fetch_max(slot, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+// amax_early: the slot's value when the wave starts (a load whose latency hides behind the kernel's own loads; 0xFFFFFFFF
+// when there is no slot, so that nothing is ever published).  amax_publish: DPP wave maximum (pure VALU), then ONE
+// fire-and-forget atomic from lane 63 -- only if the wave's maximum exceeds what it read at its start.  (A first version
+// read the slot at the END of the wave: a dependent ~2 us round trip before every wave could retire cost the BatchNorm-apply
+// kernel 40 % of its bandwidth, profiles/r5.)
+__device__ __forceinline__ unsigned amax_early(const unsigned* slot) {
+    return slot ? __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+}
+__device__ __forceinline__ float wave_max_l63(float v) {  // v >= 0; valid in lane 63 (masked-out DPP rows read 0)
+    v = row16_max(v);
+    v = fmaxf(v, dpp_src<0x142, 0xA>(v));  // row_bcast:15 into rows 1 and 3
+    v = fmaxf(v, dpp_src<0x143, 0xC>(v));  // row_bcast:31 into rows 2, 3
+    return v;
+}
+__device__ __forceinline__ void amax_publish(unsigned* slot, float m, unsigned early) {
+    m = wave_max_l63(m);
+    const unsigned b = __builtin_bit_cast(unsigned, m);
+    if ((threadIdx.x & 63) == 63 && b > early)
+        (void)__hip_atomic_fetch_max(slot, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // scale exponent of an operand whose max |x| has the bit pattern `am`: x * 2^k has its maximum in [2^14, 2^15), inside
 // fp16's range (65504) with 28 binades of normal range below it.  inf / nan / 0 -> 0; |k| <= 126 so that 2^k and 2^-k

@@ -225,6 +225,14 @@ def _split_dgrad_ok(cout, k):
 # BatchNorm-backward apply kernel leaves max |dz|).  Everything else -- fused forwards, inference, ConvTranspose, OutConv,
 # callers that pass no maxima -- runs the exact three-term bf16 split as before.  SMAAT_F16_SPLIT=0 switches it off (A/B).
 F16_SPLIT = os.environ.get("SMAAT_F16_SPLIT", "1") != "0"
+# ... and only where the train-mode BatchNorm behind the GEMM averages at least this many samples per channel (N * H * W).
+# The two-term split's per-product error is ~3x an f32 rounding (22-23 significant bits against exact products): invisible at
+# the benchmark sizes (every reference fixture at 288^2 / 256^2 holds at unchanged bounds), but on planes of a few pixels one
+# ReLU decision that flips at round-off level moves whole gradient tensors by 5e-3 ... 1e-2 (a 4 x 3 bottleneck plane at batch
+# 3 is 36 samples: one flip is 3 % of them), and three times the forward noise means three times the flips -- the
+# counter-examples are recorded in profiles/r5/f16_split_small_plane_counterexamples.txt (SMAAT_F16_MIN_SAMPLES=0 reproduces
+# them).  BASELINE configs: 32 x 18 x 18 = 10,368 at the bottleneck of configs[1], 16 x 16 x 16 = 4,096 for configs[4].
+F16_MIN_SAMPLES = int(os.environ.get("SMAAT_F16_MIN_SAMPLES", "4096"))
 _AMAX_LOCK = threading.Lock()
 _AMAX_ARENA = {}  # device -> [int32 tensor of zeros, next free word]
 
@@ -248,6 +256,26 @@ def _amax_words(ref, n):
             _AMAX_ARENA[ref.device] = a
         w = a[0][a[1]:a[1] + n]
         a[1] += n
+    return w
+
+
+_ZERO_ARENA = {}  # device -> [float32 tensor of zeros, next free element]
+
+
+def _zero_grad_words(ref, n):
+    """n float32 ZEROS on ref's device that nobody else will ever be handed: the exactly-zero gradient of a convolution bias
+    in front of a train-mode BatchNorm (18 per training step; SURVEY 8c "zero-gradient trap").  A slice of a zero-filled arena
+    instead of a fill launch per bias: autograd adopts the slice as `.grad` (it is referenced by nothing else), in-place
+    arithmetic on it stays inside the slice, and a slice is never reused, so the arena is refilled once per ~200 steps."""
+    if ref.is_cuda and torch.cuda.is_current_stream_capturing():
+        return torch.zeros(n, dtype=torch.float32, device=ref.device)
+    with _AMAX_LOCK:
+        a = _ZERO_ARENA.get(ref.device)
+        if a is None or a[1] + n > a[0].numel():
+            a = [torch.zeros(max(1 << 20, n), dtype=torch.float32, device=ref.device), 0]
+            _ZERO_ARENA[ref.device] = a
+        w = a[0][a[1]:a[1] + n]
+        a[1] += (n + 3) // 4 * 4  # (16-byte aligned slices)
     return w
 
 
@@ -1005,7 +1033,7 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
             rs = _dsconv_fwd_fused(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish, want_y=keep_y)
     if amx is not None:
         amx.update(w=None, y=False, dz=False)
-        if not bf and use_batch_stats and _f16_on():
+        if not bf and use_batch_stats and n * h * w >= F16_MIN_SAMPLES and _f16_on():
             amx["w"] = _amax_words(x, 2)
             amx["dz"] = True  # (the backward's BatchNorm apply kernel will leave max |dz| in word 1)
     if rs is None and not bf and _split_fwd_ok(cin * kpl, cout, use_batch_stats):
@@ -1054,7 +1082,7 @@ def _half_backward(x, w_dw, b_dw, w_pw, gamma, z, st, y_dw, dy, kpl, train_stats
     red = r[4] if bnred is not None else None
     if train_stats:
         # a bias in front of a train-mode BatchNorm has an exactly-zero gradient
-        db_pw = torch.zeros_like(dgamma) if has_bias[1] else None
+        db_pw = _zero_grad_words(dgamma, dgamma.numel()) if has_bias[1] else None
     else:
         db_pw = _channel_sum_raw(dz) if has_bias[1] else None
     if not has_bias[0]:
@@ -1409,7 +1437,7 @@ class _PointwiseBNReLU(torch.autograd.Function):
         dw = _pointwise_wgrad_raw(x, dz, m).reshape(w.shape)
         db = None
         if has_bias:  # a bias in front of a train-mode BatchNorm has an exactly-zero gradient
-            db = torch.zeros_like(dgamma) if train_stats else _channel_sum_raw(dz)
+            db = _zero_grad_words(dgamma, dgamma.numel()) if train_stats else _channel_sum_raw(dz)
         if gamma is None:
             dgamma = dbeta = None
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None

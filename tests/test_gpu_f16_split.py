@@ -155,10 +155,10 @@ def test_bn_bwd_apply_amax(shape, head):
 
 
 # ------------------------------------------------------------------------------------------------ GEMMs
-def case_pw_split_h(L, dev, N, C, M, H, W, with_part=False, x=None, w=None, slices=0):
+def case_pw_split_h(L, dev, N, C, M, H, W, with_part=False, x=None, w=None, slices=0, bias=True):
     x = T(rnd(1, N, C, H, W) * np.exp(rnd(7, N, C, 1, 1)) if x is None else x, dev)   # wide dynamic range across channels
     w = T(rnd(2, M, C, scale=0.2) if w is None else w, dev)
-    b = T(rnd(3, M), dev)
+    b = T(rnd(3, M), dev) if bias else None
     pl = _h_image(L, dev, w)
     am = _publish(x)
     out = torch.full((N, M, H, W), float("nan"), device=dev)
@@ -246,13 +246,13 @@ def test_pointwise_fwd_split_h_adversarial_operands():
     small = np.arange(M) != 7
     assert np.abs(out2[:, small] - ref2[:, small]).max() <= 2.0 ** -36 * np.abs(w2).max() * np.abs(x2).sum(1).max()
     # (c) tiny operand: the scale lifts it into range
+    zb = np.zeros(M, np.float32)
     x3 = rnd(1, N, C, H, W) * np.float32(1e-36)
-    out3 = case_pw_split_h(L, dev, N, C, M, H, W, x=x3, w=w)["out"].cpu().numpy()
-    ref3 = _fp64_pw(x3, w, np.zeros(M, np.float32)) + 0
-    assert rel(out3 - b[None, :, None, None], ref3) < 1e-5  # (products near the f32 denormal boundary themselves)
+    out3 = case_pw_split_h(L, dev, N, C, M, H, W, x=x3, w=w, bias=False)["out"].cpu().numpy()
+    assert rel(out3, _fp64_pw(x3, w, zb)) < 1e-5  # (results near the f32 denormal boundary themselves)
     x4 = rnd(1, N, C, H, W) * np.float32(1e-20)
-    out4 = case_pw_split_h(L, dev, N, C, M, H, W, x=x4, w=w)["out"].cpu().numpy()
-    assert rel(out4 - b[None, :, None, None], _fp64_pw(x4, w, np.zeros(M, np.float32))) < 1e-6
+    out4 = case_pw_split_h(L, dev, N, C, M, H, W, x=x4, w=w, bias=False)["out"].cpu().numpy()
+    assert rel(out4, _fp64_pw(x4, w, zb)) < 1e-6
     # (d)
     out5 = case_pw_split_h(L, dev, N, C, M, H, W, x=np.zeros((N, C, H, W), np.float32), w=w)["out"].cpu().numpy()
     assert np.array_equal(out5, np.broadcast_to(b[None, :, None, None], out5.shape))

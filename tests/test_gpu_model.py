@@ -126,6 +126,21 @@ def test_sibling_networks_vs_reference_golden(golden_dir, name):
                 json.dump(report, f, indent=1, default=float)
 
 
+def _per_tensor_in_the_autocast_class(model, ga, gb, fixture="autocast_bf16_n2_64"):
+    """every parameter-gradient tensor of `ga` against `gb` (flat vectors in model.parameters() order), bounded tensor by
+    tensor by what stock autocast does to the REFERENCE (tests/test_autocast_yardstick.py::check_per_tensor): a wrong
+    gradient in one mixed-precision layer cannot hide in the norm of the flat vector (VERDICT r4 weak #2)"""
+    from tests.test_autocast_yardstick import check_per_tensor, load_case, per_tensor_yardstick
+    g, meta, _ = load_case(os.path.join(os.path.dirname(__file__), "golden"), fixture)
+    names = [k for k, _ in model.named_parameters()]
+    assert names == meta["names"]
+    sizes = [p.numel() for p in model.parameters()]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    da = {k: ga[off[i]:off[i + 1]].double().cpu().numpy() for i, k in enumerate(names)}
+    db = {k: gb[off[i]:off[i + 1]].double().cpu().numpy() for i, k in enumerate(names)}
+    return check_per_tensor(names, da, db, per_tensor_yardstick(g, meta))
+
+
 def _load_model(meta):
     kpl = meta.get("kpl", 2)
     P = oparams.make_smaat_params(meta["n_channels"], meta["n_classes"], kpl, 16, meta["param_seed"])
@@ -438,6 +453,10 @@ def test_bf16_storage_mixed_precision(ops):
     report["reference_autocast_yardstick"] = yard
     assert report["logits_vs_fp32_path"] < FACTOR * yard["logits"], report
     assert 1.0 - report["grad_cos_vs_fp32"] < FACTOR * yard["one_minus_cos"], report
+    # ... and tensor by tensor: against the f32 path and against the emulation of the same mixed-precision arithmetic
+    names_model, _ = _load_model(meta)
+    _per_tensor_in_the_autocast_class(names_model, g, f32_g)
+    _per_tensor_in_the_autocast_class(names_model, g, emu_g)
     assert abs(losses[0] - emu_losses[0]) < 1e-2 * abs(emu_losses[0]), report
     assert losses[-1] < losses[0], losses
     again, _, _ = run("f32")
@@ -642,6 +661,8 @@ def test_mixed_precision_shape_sweep(shape):
     Pn = oparams.make_smaat_params(12, 1, 2, 16, 31)
     xn, yn = O.synthetic_precip(n, 12, h, w, seed=400 + h + w)
 
+    models = []
+
     def run(prec):
         model = S.SmaAt_UNet(12, 1)
         model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in Pn.items()})
@@ -651,11 +672,13 @@ def test_mixed_precision_shape_sweep(shape):
         loss = torch.nn.functional.mse_loss(out.squeeze(1), y, reduction="sum") / y.shape[0]
         loss.backward()
         g = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+        models.append(model)
         return out.detach(), float(loss.detach()), g
 
     o32, l32, g32 = run("f32")
     ob, lb, gb = run("bf16")
     ob2, lb2, gb2 = run("bf16")
+    _per_tensor_in_the_autocast_class(models[0], gb, g32)  # tensor by tensor, not only the flat vector
     assert ob.dtype == torch.float32 and torch.isfinite(ob).all() and torch.isfinite(gb).all()
     assert torch.equal(ob, ob2) and torch.equal(gb, gb2) and lb == lb2
     rel = float((ob - o32).norm() / o32.norm())
@@ -748,10 +771,14 @@ def test_bench_two_ranks_share_the_gpu_over_gloo():
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
-def test_traceable_training_operators_on_gpu(mode):
+def test_traceable_training_operators_on_gpu(mode, monkeypatch):
     """the torch.library training operators (smaat_unet_amd/train_ops.py) run the same kernels as the autograd.Function
     wiring: same logits (f32: the head / deferred-activation fusions only change which kernel applies an activation),
-    same running statistics, gradients at the round-off level of the default path"""
+    same running statistics, gradients at the round-off level of the default path.  (The traceable operators keep the
+    exact three-term split -- their saved tensors are declared up front, the operand maxima of the two-term fp16 split are
+    not among them -- so the default path is switched to it as well: this test compares wirings at equal arithmetic.)"""
+    from smaat_unet_amd import ops as _ops
+    monkeypatch.setattr(_ops, "F16_SPLIT", False)
     meta = dict(n_channels=12, n_classes=1, param_seed=3)
     xn, yn = O.synthetic_precip(2, 12, 64, 64, seed=11)
     x, y = torch.from_numpy(xn).to(DEV), torch.from_numpy(yn).to(DEV)

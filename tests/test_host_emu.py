@@ -349,12 +349,18 @@ def _recorded_calls(fn):
     return calls
 
 
-def test_matrix_path_policy_training_vs_inference():
+def test_matrix_path_policy_training_vs_inference(monkeypatch):
     """training runs every supported layer on the split GEMMs (standalone depthwise kernel +
     smaat_pointwise_fwd_split, the depthwise output is kept for the streamed weight gradient); inference (eval mode
     under no_grad) folds BatchNorm into the pointwise weights and runs ONE fused launch per half block."""
     from smaat_unet_amd import ops as _ops
-    assert _ops.SPLIT_POLICY == "auto" and _ops.FUSE_DW_SPLIT == "auto"
+    assert _ops.SPLIT_POLICY == "auto" and _ops.FUSE_DW_SPLIT == "auto" and _ops.F16_MIN_SAMPLES == 4096
+    # by default planes this small (2 x 8 x 8 = 128 samples per BatchNorm channel) stay on the exact three-term split ...
+    mod0 = S.DoubleConvDS(8, 16, kernels_per_layer=2).train()
+    c = _recorded_calls(lambda: mod0(torch.randn(2, 8, 8, 8).requires_grad_(True)).sum().backward())
+    assert not any(k.endswith(("_h", "_amax")) for k in c), c
+    # ... the rest of this test looks at the fp16 wiring, with the sample threshold off
+    monkeypatch.setattr(_ops, "F16_MIN_SAMPLES", 0)
     mod = S.DoubleConvDS(8, 16, kernels_per_layer=2)  # K = 16 / 32, Cout = 16: "narrow"
     x = torch.randn(2, 8, 8, 8)
     mod.train()
@@ -845,6 +851,7 @@ def test_f16_split_wiring_against_the_three_term_split(monkeypatch):
     does) logits and gradients must agree with the three-term wiring to f32 round-off class, and every maximum word that a
     GEMM read must have been written."""
     from smaat_unet_amd import ops as K
+    monkeypatch.setattr(K, "F16_MIN_SAMPLES", 0)  # (every level of this small network, not only those above the threshold)
     torch.manual_seed(11)
     x = torch.from_numpy(O_precip(2, 12, 32, 64))
     y = torch.rand(2, 32, 64) * 0.3

@@ -129,6 +129,7 @@ def test_strict_rows_blocks_gpu(ops_strict_rows, tag, f16, monkeypatch):
     from smaat_unet_amd import _lib, ops as _ops
     monkeypatch.setattr(_ops, "WGRAD_RECOMPUTE", "all")
     monkeypatch.setattr(_ops, "F16_SPLIT", f16)
+    monkeypatch.setattr(_ops, "F16_MIN_SAMPLES", 0)  # (these planes are 256 samples: below the default threshold)
     report = {}
     try:
         seen = _calls_of(_lib.get(), lambda: run_strict(ops_strict_rows, tag, torch.device("cuda:0"), report))
