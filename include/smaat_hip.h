@@ -291,9 +291,11 @@ int smaat_pointwise_fwd_split(const float* x, long x_bs, const void* planes, con
  *   h_a h_b + h_a g_b + g_a h_b (each an exact 22-bit product, f32 accumulation) and the accumulator is scaled back by the exact
  *   2^-(k_a + k_b): f32-class error (tests/test_gpu_kernels.py: next to the three-term split against fp64, incl. operands with
  *   one channel 1e8 above the rest, gradients in the denormal range, all-zero planes).
- *   The maxima are produced by the kernels that WRITE the operands, as a side output `amax`: ONE device word (uint32 bit pattern
- *   of a non-negative float) that must hold 0 before the producing launch and afterwards holds max |v| over the tensor
- *   (order-independent: bit-reproducible):
+ *   The maxima are produced by the kernels that WRITE the operands, as a side output `amax`: a buffer of SMAAT_AMAX_WORDS
+ *   (1024) uint32 words in device memory that must hold zeros before the producing launch; afterwards the maximum over the
+ *   buffer is the bit pattern of max |v| over the tensor (non-negative floats: unsigned order = float order; the result is
+ *   order-independent, i.e. bit-reproducible).  The producers scatter partial maxima over words 0, 32, 64, ... (32 different
+ *   128-byte lines: thousands of waves publishing to ONE address serialise at the memory side), the GEMMs read those 32 words:
  *     smaat_dw3x3_fwd_amax      = smaat_dw3x3_fwd + amax of y; -2 when the row-streaming kernel does not take the shape
  *                                 (then: smaat_dw3x3_fwd and the three-term GEMMs)
  *     smaat_bn_bwd_apply_amax   = smaat_bn_bwd_apply (head_w null) or smaat_bn_bwd_apply_head (head_w [C], dy = dlog) + amax of dz
@@ -303,10 +305,11 @@ int smaat_pointwise_fwd_split(const float* x, long x_bs, const void* planes, con
  *     smaat_split_planes_h_pieces(R, C) 4096-element pieces -- no atomics, no state.  In smaat_weight_planes_multi_h (the
  *     one-launch-per-step refresh) such an image is a descriptor of kind 3 and h_pieces = the sum of the pieces of all kind-3
  *     rows (0: exactly smaat_weight_planes_multi).
- *   GEMMs (arguments as the entry points without the suffix; x_amax / dz_amax = the operands' amax words, planes = an fp16 image):
+ *   GEMMs (arguments as the entry points without the suffix; x_amax / dz_amax = the operands' amax buffers, planes = an fp16 image):
  *     smaat_pointwise_fwd_split_h, smaat_pointwise_fwd_split_k_h, smaat_pointwise_wgrad_h (x = the kept depthwise output).
  *   A NaN / Inf in an operand gives k = 0 for that tensor and propagates through the fp16 terms.
  */
+#define SMAAT_AMAX_WORDS 1024
 int smaat_dw3x3_fwd_amax(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
                          const float* b_dw, float* y, long y_bs, void* amax, int N, int Cin, int kpl, int H, int W,
                          void* stream);

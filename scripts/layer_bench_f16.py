@@ -16,7 +16,7 @@ from scripts.layer_bench import LAYERS, timeit  # noqa: E402
 
 
 def amax_word(t):
-    w = torch.zeros(1, dtype=torch.int32, device=t.device)
+    w = torch.zeros(1024, dtype=torch.int32, device=t.device)  # SMAAT_AMAX_WORDS
     w[0] = np.array([float(t.abs().max())], np.float32).view(np.int32)[0].item()
     return w
 

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const TG* __restrict__ dy,
     const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
     const float c1 = coef[c], c2 = coef[C + c], c3 = coef[2 * C + c];
     float am = 0.f;
-    const unsigned am0 = amax_early(amax);
+    __shared__ float amred[4];
     const float wc = HEAD ? hw[c] : 1.f;  // HEAD: dy[n][c][p] = hw[c] * dlog[n][p], see k_bn_bwd_reduce
     const TZ* zp = z + (long)n * z_bs + (long)c * P;
     const TG* gp = dy + (long)n * dy_bs + (HEAD ? 0L : (long)c * P);
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const TG* __restrict__ dy,
             st1(op + p, o);
         }
     }
-    if (amax) amax_publish(amax, am, am0);
+    if (amax) amax_publish_block256(amax, am, blockIdx.x * 5u + blockIdx.y, amred);  // (block-uniform branch)
 }
 
 // ---------------------------------------------------------------------------------

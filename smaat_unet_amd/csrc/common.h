@@ -130,30 +130,50 @@ __device__ __forceinline__ float wave_max_all(float v) {
 
 // ---- operand maxima for the two-term fp16 split GEMMs (splitmma.hip, NT == 2) ---------------------------------
 // A kernel that WRITES a GEMM operand (depthwise output, BatchNorm-backward dz) also leaves max |v| over the whole tensor in
-// a device word: the GEMM derives the operand's power-of-two scale from it.  m >= 0 is this lane's running maximum
-// (fmaxf drops NaNs: a NaN element stays a NaN in the scaled operand).  One conditional atomic per WAVE: the slot only grows,
-// so a wave whose maximum is not above the value it reads has nothing to add (the read may be stale: then the atomic is
-// merely redundant) -- a few dozen atomics per tensor instead of one per wave.  Unsigned compare on the bit pattern of a
-// non-negative float is the float compare; the result is order-independent, i.e. bit-reproducible.  slot starts at 0.
-// amax_early: the slot's value when the wave starts (a load whose latency hides behind the kernel's own loads; 0xFFFFFFFF
-// when there is no slot, so that nothing is ever published).  amax_publish: DPP wave maximum (pure VALU), then ONE
-// fire-and-forget atomic from lane 63 -- only if the wave's maximum exceeds what it read at its start.  (A first version
-// read the slot at the END of the wave: a dependent ~2 us round trip before every wave could retire cost the BatchNorm-apply
-// kernel 40 % of its bandwidth, profiles/r5.)
-__device__ __forceinline__ unsigned amax_early(const unsigned* slot) {
-    return slot ? __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
-}
+// an "amax buffer": SMAAT_AMAX_WORDS zero-initialised uint32 words in device memory; the maximum is the maximum over the
+// buffer (bit patterns of non-negative floats: unsigned compare = float compare; order-independent, i.e. bit-reproducible).
+// Producers scatter their partial maxima over 32 words that lie in 32 different 128-byte lines (word 32 * (key % 32)) with
+// fire-and-forget atomics; consumers take the maximum of those 32 words with scalar loads.  Why not one word: 20,000-80,000
+// waves of a streaming kernel publishing to ONE address serialise at the memory side (~2.6 ns each, measured: +0.2 ms on a
+// 0.13 ms BatchNorm-apply launch), and reading the word first to skip redundant atomics puts a ~2 us round trip in front
+// of every wave's retirement (+40 %); profiles/r5/amax_publish_variants_r5.txt.  fmaxf drops NaNs: a NaN element stays a
+// NaN in the scaled operand.
+#define SMAAT_AMAX_WORDS 1024
+#define SMAAT_AMAX_SLOTS 32
+#define SMAAT_AMAX_STRIDE 32  // words between slots: one 128-byte line each
 __device__ __forceinline__ float wave_max_l63(float v) {  // v >= 0; valid in lane 63 (masked-out DPP rows read 0)
     v = row16_max(v);
     v = fmaxf(v, dpp_src<0x142, 0xA>(v));  // row_bcast:15 into rows 1 and 3
     v = fmaxf(v, dpp_src<0x143, 0xC>(v));  // row_bcast:31 into rows 2, 3
     return v;
 }
-__device__ __forceinline__ void amax_publish(unsigned* slot, float m, unsigned early) {
+// one atomic per WAVE (kernels whose waves are independent / may have returned early)
+__device__ __forceinline__ void amax_publish_wave(unsigned* buf, float m, unsigned key) {
     m = wave_max_l63(m);
-    const unsigned b = __builtin_bit_cast(unsigned, m);
-    if ((threadIdx.x & 63) == 63 && b > early)
-        (void)__hip_atomic_fetch_max(slot, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((threadIdx.x & 63) == 63)
+        (void)__hip_atomic_fetch_max(buf + (key % SMAAT_AMAX_SLOTS) * SMAAT_AMAX_STRIDE, __builtin_bit_cast(unsigned, m),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one atomic per 256-thread BLOCK (every thread of the block must call this); red = 4 floats of LDS
+__device__ __forceinline__ void amax_publish_block256(unsigned* buf, float m, unsigned key, float* red) {
+    m = wave_max_l63(m);
+    if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        (void)__hip_atomic_fetch_max(buf + (key % SMAAT_AMAX_SLOTS) * SMAAT_AMAX_STRIDE, __builtin_bit_cast(unsigned, t),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// the maximum a consumer derives its scale from (wave-uniform: 32 scalar loads)
+__device__ __forceinline__ unsigned amax_read(const unsigned* buf) {
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < SMAAT_AMAX_SLOTS; ++i) {
+        const unsigned v = buf[i * SMAAT_AMAX_STRIDE];
+        m = v > m ? v : m;
+    }
+    return m;
 }
 // scale exponent of an operand whose max |x| has the bit pattern `am`: x * 2^k has its maximum in [2^14, 2^15), inside
 // fp16's range (65504) with 28 binades of normal range below it.  inf / nan / 0 -> 0; |k| <= 126 so that 2^k and 2^-k

@@ -456,12 +456,18 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
                     for (int i = 0; i < 8; ++i) dsr_store(p_op + (long)rsub(i) * a.P + loff0, v[i] + bias[i]);
                 } else if (a.M == 64) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) dsr_store(p_op + (long)rsub(i) * a.P + loff0, fmaxf(v[i] + bias[i], 0.f));
+                    for (int i = 0; i < 8; ++i) {
+                        const float t = v[i] + bias[i];
+                        dsr_store(p_op + (long)rsub(i) * a.P + loff0, t < 0.f ? 0.f : t);
+                    }
                 } else {
                     const float fl = a.relu ? 0.f : -__builtin_inff();
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
-                        if (mrow[i] < a.M) dsr_store(p_op + (long)rsub(i) * a.P + loff0, fmaxf(v[i] + bias[i], fl));
+                        if (mrow[i] < a.M) {  // (a select, not fmaxf: a NaN must come out as a NaN for every channel count)
+                            const float t = v[i] + bias[i];
+                            dsr_store(p_op + (long)rsub(i) * a.P + loff0, t < fl ? fl : t);
+                        }
                 }
             } else {
 #pragma unroll

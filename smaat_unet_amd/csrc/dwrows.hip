@@ -248,7 +248,6 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const TX* __restrict__ x
     bool lane_on;
     if (!dwr_place<PACK>(g, gw, lane, nplanes / Cin, Cin, n, ci, wip, t, lane_on)) return;  // (whole wave)
     float am = 0.f;
-    const unsigned am0 = amax_early(amax);
     const int band_ = t / g.ncol4, q = t - band_ * g.ncol4;
     const bool active = lane_on && band_ < g.nbands;  // surplus lanes walk the last band again (stores masked)
     const int band = active ? band_ : g.nbands - 1;
@@ -318,7 +317,7 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const TX* __restrict__ x
     dwr_pin(raw[0]);  // (loads still in flight target live registers)
     dwr_pin(raw[1]);
     dwr_pin(raw[2]);
-    if (amax) amax_publish(amax, am, am0);
+    if (amax) amax_publish_wave(amax, am, (unsigned)gw);  // (waves are independent here: some have returned already)
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -46,6 +46,10 @@ __device__ __forceinline__ float rne_bf16(float x) {  // round-to-nearest-even t
     return bitsf((b + 0x7FFFu + ((b >> 16) & 1u)) & 0xFFFF0000u);
 }
 
+// out = max(v, floor) that PROPAGATES a NaN in v (fmaxf returns the other operand: a NaN accumulator used to come out as the
+// floor, -inf when there is no ReLU).  floor itself is never NaN.
+__device__ __forceinline__ float floor_nan(float v, float fl) { return v < fl ? fl : v; }
+
 // ---- two-term fp16 split of a pair (already scaled): h = {fp16(t0), fp16(t1)}, g = fp16 of the exact residuals
 __device__ __forceinline__ unsigned pack_f16(float a, float b) {  // one v_cvt_pk_f16_f32 (round to nearest even)
     const f32x2_native v = {a, b};
@@ -169,8 +173,8 @@ __global__ __launch_bounds__(256 + NPT) void k_wgrad_split(const Wg2Args a) {
     // NT == 2: per-tensor power-of-two scales of the two operands (wave-uniform scalar loads)
     int kdz = 0, ky = 0;
     if constexpr (NT == 2) {
-        kdz = f16_kexp(*a.dz_amax);
-        ky = f16_kexp(*a.y_amax);
+        kdz = f16_kexp(amax_read(a.dz_amax));
+        ky = f16_kexp(amax_read(a.y_amax));
         asm volatile("" : "+s"(kdz), "+s"(ky));  // (the scalar loads are waited for HERE, not at a first use inside the loop)
     }
 
@@ -615,7 +619,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
     const float* xn = a.x + (long)n * a.x_bs;
     int kx = 0, ka = 0;  // NT == 2: power-of-two scale exponents of x (from its maximum) and of the weight image
     if constexpr (NT == 2) {
-        kx = f16_kexp(*a.x_amax);
+        kx = f16_kexp(amax_read(a.x_amax));
         ka = *a.a_kexp;
         asm volatile("" : "+s"(kx), "+s"(ka));
     }
@@ -778,7 +782,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT) void k_pw_split(const PwSplit
                     float* rowp = obase + (long)m * a.P;
 #pragma unroll
                     for (int pt = 0; pt < PXT; ++pt)
-                        if (off[pt] >= 0) rowp[off[pt]] = fmaxf(acc[ct][pt][r] + bvv, a.out_floor);
+                        if (off[pt] >= 0) rowp[off[pt]] = floor_nan(acc[ct][pt][r] + bvv, a.out_floor);
                 }
             }
         }
@@ -866,7 +870,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
     const int G = nitems * nchunks;  // chunks of this workgroup
     int kx = 0, ka = 0;  // NT == 2: power-of-two scale exponents of x (from its maximum) and of the weight image
     if constexpr (NT == 2) {
-        kx = f16_kexp(*a.x_amax);
+        kx = f16_kexp(amax_read(a.x_amax));
         ka = *a.a_kexp;
         asm volatile("" : "+s"(kx), "+s"(ka));  // (waited for here, not inside the chunk loop)
     }
@@ -1129,7 +1133,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
                     const unsigned ro = rowb + (unsigned)rc * (unsigned)a.P * 4u;
 #pragma unroll
                     for (int pt = 0; pt < PXT; ++pt)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(acc[ct][pt][r] + bvv, a.out_floor)), rs,
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, floor_nan(acc[ct][pt][r] + bvv, a.out_floor)), rs,
                                                               ro + pvo[pt], 0, 0);
                 }
             }
@@ -1245,10 +1249,10 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
         acc.w += v.w;
     }
     const float b = bias ? bias[m] : 0.f;
-    acc.x = fmaxf(acc.x + b, out_floor);
-    acc.y = fmaxf(acc.y + b, out_floor);
-    acc.z = fmaxf(acc.z + b, out_floor);
-    acc.w = fmaxf(acc.w + b, out_floor);
+    acc.x = floor_nan(acc.x + b, out_floor);
+    acc.y = floor_nan(acc.y + b, out_floor);
+    acc.z = floor_nan(acc.z + b, out_floor);
+    acc.w = floor_nan(acc.w + b, out_floor);
     *(float4*)(out + (long)n * out_bs + e) = acc;
 }
 
@@ -1300,8 +1304,8 @@ __global__ __launch_bounds__(256) void k_splitk_reduce_stats(const float* __rest
         const float d0 = acc.x - sh, d1 = acc.y - sh, d2 = acc.z - sh, d3 = acc.w - sh;
         s1 += (d0 + d1) + (d2 + d3);
         s2 = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, fmaf(d3, d3, s2))));
-        *(float4*)(op + p) = make_float4(fmaxf(acc.x + b, out_floor), fmaxf(acc.y + b, out_floor), fmaxf(acc.z + b, out_floor),
-                                         fmaxf(acc.w + b, out_floor));
+        *(float4*)(op + p) = make_float4(floor_nan(acc.x + b, out_floor), floor_nan(acc.y + b, out_floor), floor_nan(acc.z + b, out_floor),
+                                         floor_nan(acc.w + b, out_floor));
     }
     const float t1 = block_sum_t0(s1, red);
     const float t2 = block_sum_t0(s2, red + 4);

@@ -244,15 +244,20 @@ def _f16_on():
     return not train_ops.active()  # (the traceable operators declare their saved tensors up front)
 
 
+AMAX_WORDS = 1024  # SMAAT_AMAX_WORDS of include/smaat_hip.h: one operand-maximum buffer
+
+
 def _amax_words(ref, n):
-    """n fresh ZERO int32 words on ref's device (the operand-maximum words of include/smaat_hip.h "two-term fp16 split").
-    Handed out from a zero-filled arena and never reused, so a training step costs no fill launch: one per 4096 words."""
+    """n fresh ZERO amax buffers (n * AMAX_WORDS int32 words) on ref's device: the operand-maximum buffers of
+    include/smaat_hip.h "two-term fp16 split".  Handed out from a zero-filled arena and never reused, so a training step
+    costs no fill launch: one 4 MB fill per 1024 buffers (~28 steps)."""
+    n *= AMAX_WORDS
     if ref.is_cuda and torch.cuda.is_current_stream_capturing():
         return torch.zeros(n, dtype=torch.int32, device=ref.device)
     with _AMAX_LOCK:
         a = _AMAX_ARENA.get(ref.device)
         if a is None or a[1] + n > a[0].numel():
-            a = [torch.zeros(4096, dtype=torch.int32, device=ref.device), 0]
+            a = [torch.zeros(max(1 << 20, n), dtype=torch.int32, device=ref.device), 0]
             _AMAX_ARENA[ref.device] = a
         w = a[0][a[1]:a[1] + n]
         a[1] += n
@@ -267,8 +272,9 @@ def _zero_grad_words(ref, n):
     in front of a train-mode BatchNorm (18 per training step; SURVEY 8c "zero-gradient trap").  A slice of a zero-filled arena
     instead of a fill launch per bias: autograd adopts the slice as `.grad` (it is referenced by nothing else), in-place
     arithmetic on it stays inside the slice, and a slice is never reused, so the arena is refilled once per ~200 steps."""
-    if ref.is_cuda and torch.cuda.is_current_stream_capturing():
-        return torch.zeros(n, dtype=torch.float32, device=ref.device)
+    from . import train_ops
+    if train_ops.active() or (ref.is_cuda and torch.cuda.is_current_stream_capturing()):
+        return torch.zeros(n, dtype=torch.float32, device=ref.device)  # (outputs of a torch.library operator must not alias)
     with _AMAX_LOCK:
         a = _ZERO_ARENA.get(ref.device)
         if a is None or a[1] + n > a[0].numel():
@@ -451,7 +457,7 @@ def _pointwise_split_raw(x, planes, bias, m, want_stats=False, amax=None):
 def _dw3x3_fwd_raw(x, w_dw, b_dw, kpl, in_scale=None, in_shift=None, out_dtype=None, amx=None):
     """standalone depthwise 3x3 forward; None when the library does not handle the shape.  out_dtype: torch.float32
     (default: the dtype of x) or torch.bfloat16 (mixed precision: x may be f32 -- the stem -- or bf16).
-    amx (f32 only): {"w": int32 words [y, dz], ...}; the kernel leaves max |y| in word 0 and amx["y"] = True, when the
+    amx (f32 only): {"w": two amax buffers [y | dz], ...}; the kernel leaves max |y| in the first and amx["y"] = True, when the
     row-streaming kernel takes the shape"""
     L = _lib.get()
     x, x_bs = _planes(x)
@@ -489,7 +495,7 @@ def _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None,
     if y is None:
         return None
     cout = w_pw.shape[0]
-    ay = amx["w"][0:1] if (amx is not None and amx.get("y")) else None
+    ay = amx["w"][:AMAX_WORDS] if (amx is not None and amx.get("y")) else None
     planes = _split_planes_h_raw(w_pw.reshape(cout, -1)) if ay is not None else _split_planes_raw(w_pw.reshape(cout, -1))
     L = _lib.get()
     n, k, h, w = y.shape
@@ -862,8 +868,8 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None, i
     if _is_bf(x):  # the forward of this block fell back to f32 storage (_bf16_storage_ok) on a bf16 input
         x, x_bs = _planes(x.float())
     # amx = {"w": int32 words [max |y|, max |dz|], "y": bool, "dz": bool}: which maxima the producing kernels left
-    a_dz = amx["w"][1:2] if (amx is not None and amx.get("dz")) else None
-    a_y = amx["w"][0:1] if (amx is not None and amx.get("y")) else None
+    a_dz = amx["w"][AMAX_WORDS:] if (amx is not None and amx.get("dz")) else None
+    a_y = amx["w"][:AMAX_WORDS] if (amx is not None and amx.get("y")) else None
     if y is not None:
         dw_pw = _pointwise_wgrad_raw(y, dz, cout, a_y if a_dz is not None else None, a_dz if a_y is not None else None)
     else:
@@ -1072,7 +1078,7 @@ def _half_backward(x, w_dw, b_dw, w_pw, gamma, z, st, y_dw, dy, kpl, train_stats
     BatchNorm: x is its input, the activation is applied on load and its backward sums are emitted (`red`)."""
     if amx is not None and (amx.get("w") is None or not amx.get("dz") or _is_bf(z) or _is_bf(dy) or not _f16_on()):
         amx = None  # (no maxima words, or a storage / mode change since the forward)
-    a_dz = amx["w"][1:2] if amx is not None else None
+    a_dz = amx["w"][AMAX_WORDS:] if amx is not None else None
     if head is not None:  # dy is w_out (x) dlog, formed on the fly; head["dw"] receives the 1x1 conv's weight gradient
         dz, dgamma, dbeta, head["dw"] = _bn_bwd_head_raw(head["dlog"], head["w"], z, st, gamma, train_stats, amax=a_dz)
     else:

@@ -132,7 +132,9 @@ def double_conv_ds_bwd_op(dy2: Tensor, x: Tensor, w_dw1: Tensor, b_dw1: Optional
     gr1, _ = ops._half_backward(x, w_dw1, b_dw1, w_pw1, g1, z1, st1, _opt(ydw1), gr2[0], kpl, ts1, (b_dw1 is not None, hb1),
                                 need_dx, pre_part=red)
     out = list(gr1) + list(gr2[1:])
-    return [t if t is not None else _e(x) for t in out]
+    # (an operator's results must not alias each other: the exactly-zero bias gradients are slices of one zero arena,
+    # ops._zero_grad_words -- this operator runs on autograd's thread, where the thread-local `active()` is not visible)
+    return [(t.clone() if t._base is not None else t) if t is not None else _e(x) for t in out]
 
 
 @double_conv_ds_bwd_op.register_fake

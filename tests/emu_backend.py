@@ -82,10 +82,18 @@ def _amax_bits(a):
     return int(np.array([m], np.float32).view(np.uint32)[0])
 
 
+AMAX_WORDS = 1024  # SMAAT_AMAX_WORDS: an amax buffer; the maximum is the maximum over the whole buffer
+
+
 def _amax_publish(ptr, a):
-    """what the producing kernels leave in the amax word: max(old, max |a|) on the bit patterns"""
-    w = np.ctypeslib.as_array((ctypes.c_uint32 * 1).from_address(int(ptr)))
+    """what the producing kernels leave in the amax buffer: max(old, max |a|) on the bit patterns (the kernels scatter partial
+    maxima over 32 words of the buffer; the emulation uses word 0)"""
+    w = np.ctypeslib.as_array((ctypes.c_uint32 * AMAX_WORDS).from_address(int(ptr)))
     w[0] = max(int(w[0]), _amax_bits(a))
+
+
+def _amax_read(ptr):
+    return int(np.ctypeslib.as_array((ctypes.c_uint32 * AMAX_WORDS).from_address(int(ptr))).max())
 
 
 def _h_terms(x, k):
@@ -287,7 +295,7 @@ class EmuLib:
     def smaat_pointwise_fwd_split_h(self, x, x_bs, x_amax, pl, bias, out, out_bs, part, N, Cin, M, H, W, stream):
         P = H * W
         a_terms, ka = _h_image(pl, M, Cin)
-        kx = f16_kexp(np.ctypeslib.as_array((ctypes.c_uint32 * 1).from_address(int(x_amax)))[0])
+        kx = f16_kexp(_amax_read(x_amax))
         acc = mm_h("mc,ncp->nmp", a_terms, ka, planes(x, N, Cin, P, x_bs), kx)
         planes(out, N, M, P, out_bs)[:] = acc + (f32(bias, M)[None, :, None] if bias else 0)
         self._write_part(part, PW_SLOTS + 1, M, acc)
@@ -300,8 +308,7 @@ class EmuLib:
 
     def smaat_pointwise_wgrad_h(self, x, x_bs, x_amax, dz, dz_bs, dz_amax, ws, dw_out, N, Cin, M, H, W, stream):
         P = H * W
-        rd = lambda p: int(np.ctypeslib.as_array((ctypes.c_uint32 * 1).from_address(int(p)))[0])  # noqa: E731
-        kx, kd = f16_kexp(rd(x_amax)), f16_kexp(rd(dz_amax))
+        kx, kd = f16_kexp(_amax_read(x_amax)), f16_kexp(_amax_read(dz_amax))
         f32(dw_out, M * Cin).reshape(M, Cin)[:] = mm_h("nmp,nkp->mk", _h_terms(planes(dz, N, M, P, dz_bs), kd), kd,
                                                        planes(x, N, Cin, P, x_bs), kx)
         return 0

@@ -13,7 +13,7 @@ oracle/torch_ref.py pinned against the three big fixtures.  GPU (`-m gpu`): the 
 
 Tolerances: forward <= 1e-4 rel-L2 (north_star); eval-mode gradients <= 2e-3 per tensor (2e-2 for the ten
 single-number BN(1) gradients of the spatial attentions); training gradients: error
-against the reference's fp64 anchors <= max(3 x the reference's own fp32-vs-fp64 error, 5e-3) per tensor
+against the reference's fp64 anchors <= max(2 x the reference's own fp32-vs-fp64 error, 5e-3) per tensor
 (the reference disagrees with itself at 2e-3 .. 3e-2 end to end)."""
 import contextlib
 import json
@@ -123,13 +123,13 @@ def run_big(golden_dir, name, dev, graph=False, report=None):
         ours = check_summary(g, "train/grad64/" + k, gk)
         noise = float(g["train/noise/" + k])
         table[k] = (ours, noise)
-        if ours > max(3.0 * noise, 5e-3):
+        if ours > max(NOISE_FACTOR * noise, 5e-3):
             bad.append((k, ours, noise))
     if scal["ours"]:
         o, r32, r64 = (np.array(scal[q], np.float64) for q in ("ours", "ref32", "ref64"))
         ours, noise = np.linalg.norm(o - r64) / np.linalg.norm(r64), np.linalg.norm(r32 - r64) / np.linalg.norm(r64)
         table["<BN(1) affine gradients of the spatial attentions, as one vector>"] = (ours, noise)
-        if ours > max(3.0 * noise, 5e-3):
+        if ours > max(NOISE_FACTOR * noise, 5e-3):
             bad.append(("spatial_att.bn.* (vector)", ours, noise))
     if report is not None:
         report["train"] = dict(logits=e, worst=max(table.items(), key=lambda kv: kv[1][0]),
@@ -219,8 +219,31 @@ def test_eval_blocks_host_logic(ops_eval, tag, _emu):
     run_eval_block(ops_eval, tag, torch.device("cpu"), tol_out=1e-5)
 
 
+NOISE_FACTOR = 2.0  # "pass if ours <= 2 x the reference's own error" (rounds 2-4 used 3 x)
+SMALL_PLANES = ("unet_12x1_n3_64x48_eval",)  # bottleneck planes of 4 x 3 pixels: one ReLU decision = 1/36 of a BatchNorm's samples
+
+
+def run_big_tie_aware(golden_dir, name, dev, report=None, **kw):
+    """run_big; on the fixtures with planes of a few pixels a violation of the gradient bound is accepted IF tests/tie_flips.py
+    attributes it to ReLU decisions at a tie -- the run on the exact three-term split of the same build satisfies the bound and
+    the two runs differ only in decisions whose pre-activation is within 2e-4 (of the tensor's rms) of zero in both; the
+    flipped elements go into the report.  (Round 5: the two-term fp16 split changes the forward at f32 round-off level, which
+    is enough to land on the other side of a tie; element (1, 344, 5, 1) of up1.0 of this fixture sits 1.5e-6 from zero.)"""
+    if name not in SMALL_PLANES:
+        return run_big(golden_dir, name, dev, report=report, **kw)
+    from tests.tie_flips import attribute, record_pre_activations
+
+    def run(f16, store):
+        with record_pre_activations(store):
+            run_big(golden_dir, name, dev, report=report if f16 else None, **kw)
+    flips = attribute(run)
+    if report is not None:
+        report["relu_decisions_flipped_at_a_tie"] = [dict(half=i, element=list(e), exact=a, f16=b, rms=r) for i, e, b, a, r in flips]
+    return flips
+
+
 def test_big_case_host_logic(golden_dir, _emu):
-    run_big(golden_dir, "unet_12x1_n3_64x48_eval", torch.device("cpu"))
+    run_big_tie_aware(golden_dir, "unet_12x1_n3_64x48_eval", torch.device("cpu"))
 
 
 @pytest.mark.parametrize("name", BIG + BIG_FULL)
@@ -265,7 +288,7 @@ def test_big_cases_gpu(golden_dir, name, policy, monkeypatch):
     monkeypatch.setattr(_ops, "SPLIT_POLICY", policy)
     report = {}
     try:
-        run_big(golden_dir, name, torch.device("cuda:0"), graph=True, report=report)
+        run_big_tie_aware(golden_dir, name, torch.device("cuda:0"), graph=True, report=report)
     finally:
         if os.path.isdir("gpurun_out"):
             with open(f"gpurun_out/big_case_{name}_{policy}.json", "w") as f:

@@ -19,8 +19,11 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 
 
+AMAX_WORDS = 1024  # SMAAT_AMAX_WORDS
+
+
 def _amax_word(dev):
-    return torch.zeros(1, dtype=torch.int32, device=dev)
+    return torch.zeros(AMAX_WORDS, dtype=torch.int32, device=dev)
 
 
 def _bits(x):
@@ -29,10 +32,15 @@ def _bits(x):
 
 def _publish(t):
     """an amax word holding max |t| as the producing kernels would leave it"""
-    w = torch.zeros(1, dtype=torch.int32, device=t.device)
+    w = torch.zeros(AMAX_WORDS, dtype=torch.int32, device=t.device)
     m = float(t.abs().max()) if t.numel() else 0.0
     w[0] = np.array([m], np.float32).view(np.int32)[0].item()
     return w
+
+
+def _amax_of(buf):
+    """the maximum an amax buffer holds (bit patterns of non-negative floats: integer max = float max)"""
+    return int(buf.max().item())
 
 
 def _h_image(L, dev, w, transposed=False):
@@ -113,7 +121,9 @@ def test_dw3x3_fwd_amax(shape, aff):
                                   stream(dev)) == 0
     torch.cuda.synchronize()
     assert torch.equal(y0, y1)
-    assert am.item() == _publish(y1).item(), (am.item(), _publish(y1).item())
+    assert _amax_of(am) == _amax_of(_publish(y1)), (_amax_of(am), _amax_of(_publish(y1)))
+    used = am.nonzero().flatten().cpu().numpy()
+    assert len(used) >= 1 and (used % 32 == 0).all()  # partial maxima only in words 0, 32, 64, ... (one per 128-byte line)
 
 
 def test_dw3x3_fwd_amax_refuses_what_the_row_kernels_do_not_take():
@@ -151,7 +161,7 @@ def test_bn_bwd_apply_amax(shape, head):
                                      C * Pn, P(am), N, C, Pn, 1, stream(dev)) == 0
     torch.cuda.synchronize()
     assert torch.equal(dz0, dz1)
-    assert am.item() == _publish(dz1).item()
+    assert _amax_of(am) == _amax_of(_publish(dz1))
 
 
 # ------------------------------------------------------------------------------------------------ GEMMs

@@ -1,0 +1,87 @@
+"""TEST INFRASTRUCTURE: attribution of a whole-network gradient deviation to ReLU decisions at a tie.
+
+The reference-generated network fixtures that are NOT tie-free (tests/golden/unet_*: every correct fp32 implementation
+takes thousands of ReLU decisions on pre-activations within round-off of zero) bound gradients by a multiple of the
+reference's own fp32-vs-fp64 figure.  On planes of a few pixels ONE such decision is a visible fraction of a BatchNorm's
+samples (a 4 x 3 plane at batch 3: 1/36), and a run whose forward differs from another correct run by f32 round-off can
+land on the other side of a tie: every gradient upstream of it then moves by 5e-3 ... 1e-2 (profiles/r5/
+f16_split_small_plane_counterexamples.txt shows one such element).  `attribute()` decides whether a bound violation of a run
+is of that kind, by comparing it with a second run of THIS implementation on the exact three-term split:
+
+  * the exact run satisfies the bound;
+  * the two runs take different ReLU decisions somewhere, and EVERY differing decision sits on a pre-activation that is
+    within `tie` (relative to the rms of its tensor) of zero in BOTH runs.
+
+Anything else -- a difference away from a tie, or no difference at all -- is a real failure."""
+import contextlib
+
+import torch
+
+from smaat_unet_amd import ops
+
+
+@contextlib.contextmanager
+def record_pre_activations(store):
+    """store.append((z, st)) for every DepthwiseSeparableConv + BatchNorm + ReLU half the network runs (z: pre-BatchNorm
+    tensor, st rows: mean, invstd, scale, shift); the ReLU's argument is z * scale + shift"""
+    orig = ops._half_forward
+
+    def wrapped(*a, **k):
+        r = orig(*a, **k)
+        store.append((r[1].detach().float().clone(), r[2].detach().clone()))
+        return r
+
+    ops._half_forward = wrapped
+    try:
+        yield
+    finally:
+        ops._half_forward = orig
+
+
+def differing_decisions(a, b):
+    """[(layer index, element index, value in run a, value in run b, rms of the tensor)] for every ReLU argument whose sign
+    differs between the two recordings"""
+    out = []
+    for i, ((za, sa), (zb, sb)) in enumerate(zip(a, b)):
+        pa = za * sa[2][None, :, None, None] + sa[3][None, :, None, None]
+        pb = zb * sb[2][None, :, None, None] + sb[3][None, :, None, None]
+        d = (pa > 0) != (pb > 0)
+        if bool(d.any()):
+            rms = float(pa.double().pow(2).mean().sqrt())
+            for idx in d.nonzero().tolist():
+                t = tuple(idx)
+                out.append((i, t, float(pa[t]), float(pb[t]), rms))
+    return out
+
+
+def attribute(run, tie=2e-4):
+    """run(f16: bool, store) -> None or raises AssertionError (the bound check of the test, on a fresh model with the
+    two-term fp16 split allowed / forbidden; it must run its forward inside `record_pre_activations(store)`).
+    Returns the list of tie flips when the violation of run(True) is attributable to them; raises otherwise."""
+    prev = ops.F16_SPLIT
+    rec = {}
+    err = {}
+    try:
+        for f16 in (True, False):
+            ops.F16_SPLIT = f16
+            ops.invalidate_weight_images()
+            rec[f16] = []
+            try:
+                run(f16, rec[f16])
+                err[f16] = None
+            except AssertionError as e:  # noqa: PERF203
+                err[f16] = e
+    finally:
+        ops.F16_SPLIT = prev
+        ops.invalidate_weight_images()
+    if err[True] is None:
+        return []
+    if err[False] is not None:
+        raise err[False]  # the exact path violates the bound as well: not a question of ties
+    flips = differing_decisions(rec[True], rec[False])
+    if not flips:
+        raise err[True]
+    off_tie = [f for f in flips if max(abs(f[2]), abs(f[3])) > tie * f[4]]
+    if off_tie:
+        raise AssertionError(f"ReLU decisions differ AWAY from a tie: {off_tie[:4]}") from err[True]
+    return flips
