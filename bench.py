@@ -233,6 +233,58 @@ def fwd_latency(model, size, dev, iters=50):
     return res
 
 
+def side_roofline(summ, dtype):
+    """dominant entry-point class of a profiled pair of steps -> roofline record (bound, achieved, peak, frac, traffic).
+    bf16 storage: every class is HBM-bound; f32: the split GEMMs are priced on the 16-bit matrix pipe
+    (executed = 3 fp16 or 6 bf16 MFMAs per product), everything else on HBM."""
+    gemm3 = ("smaat_pointwise_fwd_split_h", "smaat_pointwise_fwd_split_k_h", "smaat_pointwise_wgrad_h")
+    gemm6 = ("smaat_pointwise_fwd_split", "smaat_pointwise_wgrad", "smaat_dsconv_fwd_rows", "smaat_dsconv_wgrad_split",
+             "smaat_dsconv_fwd_split")
+    groups = {}
+    for name, d in summ.items():
+        if not d["flop"] and not d["bytes"]:
+            continue
+        key = ("split GEMM, 2-term fp16 (3 MFMAs per product)" if name in gemm3 else
+               "split GEMM, 3-term bf16 (6 MFMAs per product)" if (name in gemm6 and dtype == "f32") else name)
+        g = groups.setdefault(key, dict(ms=0.0, flop=0.0, bytes=0.0, calls=0, names=[]))
+        g["ms"] += d["ms"] / 2.0
+        g["flop"] += d["flop"] / 2.0
+        g["bytes"] += d["bytes"] / 2.0
+        g["calls"] += d["calls"] // 2
+        g["names"].append(name)
+    if not groups:
+        return None
+    key, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
+    tf, gbs = g["flop"] / (g["ms"] * 1e-3) / 1e12, g["bytes"] / (g["ms"] * 1e-3) / 1e9
+    mfma = dtype == "f32" and key.startswith("split GEMM")
+    rec = {"kernel": key, "entry_points": sorted(g["names"]), "ms_per_step": round(g["ms"], 3), "launches_per_step": g["calls"],
+           "timing": "instrumented pass (HIP events around every entry point)",
+           "bound": "mfma" if mfma else "hbm", "algorithmic_tflops": round(tf, 2), "algorithmic_gbs": round(gbs, 1),
+           "traffic": None, "traffic_note": "counter passes are collected for the headline configuration only "
+                                             "(profiles/hbm_traffic.json); bf16 at batch 64: profiles/r*/prof_*_bf16"}
+    if mfma:
+        mult = 3.0 if "2-term" in key else 6.0
+        rec.update(achieved=round(tf, 2), peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s", executed=round(tf * mult, 2),
+                   frac=round(tf * mult / PEAK_BF16_MFMA_TFLOPS, 4), frac_of_f32_mfma_peak=round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+                   frac_definition=f"executed 16-bit MFMA TFLOP/s ({mult:g} per f32 product) / 2500")
+    else:
+        rec.update(achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4))
+    return rec
+
+
+def allreduce_model(nbytes, n=8):
+    """with one GPU at hand, the MODELLED cost of the gradient exchange of configs[2] -- one ring all-reduce of
+    the flat fp32 gradient buffer over xGMI (point-to-point links, ~153 GB/s per direction per link, MI355X_MICROARCH.md):
+    2 (n-1)/n of the buffer crosses each link, plus 2 (n-1) hops of link latency.  A model, not a measurement."""
+    link_gbs, hop_us = 153.0, 5.0
+    ring = 2.0 * (n - 1) / n * nbytes / (link_gbs * 1e9) * 1e3
+    lat = 2 * (n - 1) * hop_us * 1e-3
+    return {"modelled": True, "n_gpus": n, "bytes": int(nbytes), "link_gbs_assumed": link_gbs, "hop_latency_us_assumed": hop_us,
+            "bandwidth_term_ms": round(ring, 3), "latency_term_ms": round(lat, 3), "allreduce_modelled_ms": round(ring + lat, 3),
+            "note": "ring all-reduce over xGMI, ONE collective per step (two buckets in smaat_unet_amd/ddp.py); against the "
+                    "measured single-GPU step this predicts the weak-scaling loss if nothing is overlapped"}
+
+
 def side_config(kind, dev, steps=24, warmup=6):
     """Short measurement of another single-GPU configuration of BASELINE.json inside the default run, so that the driver's
     BENCH record carries it: "bf16_b64" = configs[3] (12->1, 288x288, batch 64, mixed precision = bf16 activation storage),
@@ -278,6 +330,16 @@ def side_config(kind, dev, steps=24, warmup=6):
         rec = {"value": round(batch * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3),
                "steps": steps, "warmup": warmup, "batch": batch, "dtype": dtype, "final_loss": round(loss.item(), 5),
                "workload": what}
+        # roofline of this configuration's dominant kernel class: HIP events around every entry point
+        # for two more steps, ALGORITHMIC bytes / flops of the class (smaat_unet_amd/_lib.py WORK_MODELS = SURVEY 8(d)) over
+        # its time, against the roofline that bounds it
+        from smaat_unet_amd import _lib
+        prof = _lib.Profiler()
+        for _ in range(2):
+            step()
+        summ = prof.summary()
+        prof.close()
+        rec["roofline"] = side_roofline(summ, dtype)
     except Exception as e:  # noqa: BLE001
         rec = {"error": str(e)[:300]}
     del model, opt, x, y
@@ -361,6 +423,19 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+
+    # multi-GPU pre-flight record: which device every rank drives, and the IPC mode RCCL needs on this
+    # host driver (dmabuf only: HSA_ENABLE_IPC_MODE_LEGACY must be 0, else hipIpcGetMemHandle fails at the first collective)
+    placement = [(rank, local_rank, dev_index)]
+    if world > 1:
+        if backend == "nccl" and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "") != "0":
+            print(f"[bench rank {rank}] WARNING: HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')!r}; "
+                  "RCCL over xGMI needs 0 on this driver", file=sys.stderr)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, placement[0])
+        placement = sorted(gathered)
+        if backend == "nccl" and len({d for _, _, d in placement}) != world:
+            raise SystemExit(f"rank -> device map is not one-to-one: {placement}")
 
     import smaat_unet_amd as S
     from smaat_unet_amd import _lib
@@ -485,6 +560,8 @@ def main():
             alg_gb = sum(summ[k]["bytes"] for k in names) / 2.0 / (ms * 1e-3) / 1e9
             alg = alg_tf if bound == "mfma" else alg_gb
             r = {"bound": bound, "achieved": round(alg, 2), "peak": peak, "unit": unit, "frac": round(alg / peak, 4),
+                 "timing": "instrumented pass after the timed region (HIP events around every entry point: class times sum to "
+                           "~3-4 % more than ms_per_step of the headline)",
                  "peak_name": peak_name, "traffic": pmc_traffic(pmc) if pmc else None, "kernel": what,
                  "entry_points": names, "launches_per_step": calls, "avg_launch_ms": round(ms / max(calls, 1), 4),
                  "ms_per_step": round(ms, 3), "algorithmic_tflops": round(alg_tf, 2),
@@ -736,11 +813,21 @@ def main():
                        "arithmetic": ("bf16 activation / activation-gradient storage, bf16 MFMA GEMMs (one per product), f32 "
                                       "accumulation, f32 BatchNorm statistics, f32 master weights and weight gradients"
                                       if args.precision == "bf16" else
-                                      "f32 storage and accumulation; pointwise GEMMs of the deep layers on the bf16 matrix "
-                                      "pipe via exact 3-term operand splitting (f32-class error)"),
+                                      "f32 storage and accumulation; pointwise GEMMs on the 16-bit matrix pipe: two-term fp16 "
+                                      "operand split with per-tensor power-of-two scales (3 MFMAs per product) where the operand "
+                                      "maxima are at hand and the BatchNorm behind the GEMM averages >= 4096 samples, exact "
+                                      "three-term bf16 split (6 MFMAs) elsewhere; f32-class error"),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "final_loss": round(final_loss, 5)},
             "roofline": roof,
+            "gradient_exchange": (allreduce_model(ddp.numel * 4) if world == 1 else
+                                  {"modelled": False, "bytes": ddp.numel * 4, "buckets": len(ddp._buckets),
+                                   "note": "measured inside ms_per_step (RCCL all-reduce of the flat buffer)"}),
+            "placement": {"rank_localrank_device": placement, "devices_visible": ndev,
+                          "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")},
+            "ddp_semantics": ("per-replica BatchNorm statistics, gradients averaged; stock DDP's per-step broadcast_buffers is "
+                              "SKIPPED (every rank keeps the running statistics of its own shard, as with "
+                              "DistributedDataParallel(broadcast_buffers=False)); smaat_unet_amd.ddp.sync_buffers() restores it"),
             "cpu_baseline": cpu,
             "rocm_eager_baseline": eager,
             "input_pipeline_fed": fed,

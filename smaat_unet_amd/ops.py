@@ -592,6 +592,15 @@ def _recompute_wgrad_ok(n, cin, h, w, kpl, cout):
     return cin >= 32 and h * w >= 16384
 
 
+def _recompute_operand_ok(x):
+    """what smaat_dsconv_wgrad_split(_t) asks of x beyond the shape (it returns -2 otherwise, and by then -- in the backward --
+    nothing has been kept to fall back on): 16-byte aligned rows of a dense-plane tensor, a batch stride that is a
+    multiple of 4 elements, one image below 4 GiB.  The network's own buffers always qualify; an offset or strided view
+    handed in by a caller may not, and then the forward keeps the depthwise output as it did before round 4."""
+    xx, x_bs = _planes(x)
+    return (xx.data_ptr() % 16 == 0 and x_bs % 4 == 0 and xx.shape[1] * xx.shape[2] * xx.shape[3] * xx.element_size() < (1 << 32))
+
+
 def _fused_dw_ok(n, h, w, kpl, cout, keep_y, cin=0):
     if FUSE_DW_SPLIT == "off" or kpl != 2 or not _split_on():
         return False
@@ -1022,7 +1031,8 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
         bf = False
         if _is_bf(x):
             x = x.float()
-    rec = keep_y and _recompute_wgrad_ok(n, cin, h, w, kpl, cout) and (not bf or BF16_RECOMPUTE)
+    rec = (keep_y and _recompute_wgrad_ok(n, cin, h, w, kpl, cout) and (not bf or BF16_RECOMPUTE)
+           and _recompute_operand_ok(x))
     if rec:
         keep_y = False  # the weight gradient recomputes the depthwise output from x: nothing to keep (y_dw = None)
     if bf:  # mixed precision: bf16 depthwise output, bf16 GEMM, bf16 z (the f32 kernel families are not involved)

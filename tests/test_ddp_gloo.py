@@ -64,6 +64,8 @@ def _worker(rank, world, port, out_dir):
     assert torch.equal(flats[0], flats[1])  # same input, same parameters (no optimizer step): same reduced gradient
     # reverse registration order: the output layer's gradient leads the buffer
     assert ddp._range[model.outc.conv.bias][0] == 0
+    if rank == 0:
+        np.save(os.path.join(out_dir, "buckets.npy"), np.array([(a, b) for a, b, _ in ddp._buckets], np.int64))
     np.save(os.path.join(out_dir, f"flat{rank}.npy"), flat.numpy())
     np.save(os.path.join(out_dir, f"w{rank}.npy"), model.outc.conv.weight.detach().numpy())
     # a rank-local step (bench.py's profiling pass) must not touch the process group
@@ -108,3 +110,77 @@ def test_flat_allreduce_world2(tmp_path, overlap, monkeypatch):
         off += n
     err = np.linalg.norm(f0[mask] - acc[mask]) / np.linalg.norm(acc[mask])
     assert err < 2e-2, err
+    # ... and per BUCKET: the two buckets' gradient norms differ by orders of magnitude, so a mis-scaled
+    # or un-reduced small bucket would vanish in the whole-vector norm.  A missing 1 / world or a bucket that was not reduced
+    # is an error of order one in ITS bucket.
+    buckets = np.load(tmp_path / "buckets.npy")
+    assert len(buckets) == 2 and buckets[0][0] == 0 and buckets[-1][1] == f0.size and buckets[0][1] == buckets[1][0]
+    norms = []
+    for a, b in buckets:
+        m = mask[a:b]
+        e = np.linalg.norm(f0[a:b][m] - acc[a:b][m]) / np.linalg.norm(acc[a:b][m])
+        norms.append(float(np.linalg.norm(acc[a:b][m])))
+        assert e < 2e-2, ((a, b), e)
+    # ... and per parameter tensor against the oracle (the single-number BatchNorm(1) gradients as one vector): the network's
+    # own end-to-end gradient noise at this size is 2-5e-3; 5e-2 still separates "reduced and averaged" from not
+    off, singles = 0, ([], [])
+    for k in names:
+        n = int(np.prod(P[k].shape))
+        a, o = f0[off:off + n], acc[off:off + n]
+        off += n
+        if ".double_conv." in k and (k.endswith("depthwise.bias") or k.endswith("pointwise.bias")):
+            continue
+        if n == 1:
+            singles[0].append(a[0])
+            singles[1].append(o[0])
+            continue
+        assert np.linalg.norm(a - o) / np.linalg.norm(o) < 5e-2, (k, np.linalg.norm(a - o) / np.linalg.norm(o))
+    sa, so = np.array(singles[0]), np.array(singles[1])
+    assert np.linalg.norm(sa - so) / np.linalg.norm(so) < 5e-2
+
+
+def _worker4(rank, world, port, out_dir):
+    """4 ranks, mixed precision (bf16 activation storage), overlap mode: what the driver's first 8-GPU run exercises besides
+    the kernels -- hooks firing from autograd's thread in bf16 mode, bucket all-reduces launched during the backward,
+    averaging, the rank-local (collective-free) profiling step, the final barrier."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import emu_backend
+    from smaat_unet_amd.ddp import FlatGradAllReduce
+    emu_backend.install()
+    torch.manual_seed(99 + rank)
+    model = S.SmaAt_UNet(12, 1).train()
+    model.set_precision("bf16")
+    ddp = FlatGradAllReduce(model, buckets=2, overlap=True)
+    assert ddp.world == 4 and ddp.overlap
+    ddp.broadcast_parameters(0)
+    xn, yn = O.synthetic_precip(1, 12, 32, 32, seed=300 + rank)
+    x, y = torch.from_numpy(xn), torch.from_numpy(yn)
+
+    def backward():
+        ddp.zero_grad()
+        out = model(x)
+        assert out.dtype == torch.float32
+        (torch.nn.functional.mse_loss(out.squeeze(1), y, reduction="sum") / 1).backward()
+        return ddp.finish().clone()
+    ddp.active = False          # rank-local gradient, no collective
+    local = backward()
+    ddp.active = True
+    gathered = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    mean = torch.stack(gathered).double().mean(0).float()
+    reduced = backward()        # hooks launch the bucket all-reduces during the backward
+    assert torch.isfinite(reduced).all()
+    assert torch.allclose(reduced, mean, rtol=1e-5, atol=1e-6 * float(mean.abs().max()))
+    assert not torch.equal(local, reduced)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), reduced.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_allreduce_world4_bf16_overlap(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker4, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    r = [np.load(tmp_path / f"r{i}.npy") for i in range(4)]
+    assert all(np.array_equal(r[0], x) for x in r[1:])
