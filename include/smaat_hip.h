@@ -327,6 +327,18 @@ int smaat_pointwise_fwd_split_k_h(const float* x, long x_bs, const void* x_amax,
                                   void* stream);
 int smaat_pointwise_wgrad_h(const float* x, long x_bs, const void* x_amax, const float* dz, long dz_bs, const void* dz_amax,
                             float* ws, float* dw_out, int N, int Cin, int M, int H, int W, void* stream);
+/* ... and for the layers whose depthwise output never exists in memory (the row-walking pair of the 288^2 layers): the fused
+ * forward smaat_dsconv_fwd_rows (f32 storage) as smaat_dsconv_fwd_rows_amax ALSO leaves max |y| of the depthwise output its
+ * producer waves form -- the forward GEMM itself keeps the three-term split: its operand's maximum is not known before it
+ * runs -- and the recompute weight gradient smaat_dsconv_wgrad_split_h, which re-forms the same y bit for bit in the
+ * backward, runs the two-term fp16 split with that maximum and the one of dz.  Arguments otherwise as smaat_dsconv_fwd_rows /
+ * smaat_dsconv_wgrad_split (reference: models/layers.py:47-50 forward, :45 weight gradient). */
+int smaat_dsconv_fwd_rows_amax(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                               const float* b_dw, const void* planes, const float* b_pw, float* z, long z_bs, float* part,
+                               void* y_amax, int N, int Cin, int kpl, int Cout, int H, int W, void* stream);
+int smaat_dsconv_wgrad_split_h(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                               const float* b_dw, const void* y_amax, const float* dz, long dz_bs, const void* dz_amax, float* ws,
+                               float* dw_out, int N, int Cin, int kpl, int Cout, int H, int W, void* stream);
 
 /* ---- fused DepthwiseSeparableConv forward on the bf16-split matrix pipe (training path of the plane-dominated
  *      layers; same reference call site as smaat_dsconv_fwd, models/layers.py:47-50).  The depthwise output never

@@ -104,6 +104,8 @@ SIGNATURES = {
     "smaat_pointwise_fwd_split_h": [_P, _L, _P, _P, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P],
     "smaat_pointwise_fwd_split_k_h": [_P, _L, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "smaat_pointwise_wgrad_h": [_P, _L, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "smaat_dsconv_fwd_rows_amax": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "smaat_dsconv_wgrad_split_h": [_P, _L, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     # ---- mixed precision (bf16 activation storage) ----
     "smaat_bf16_planes": [_P, _I, _I, _P, _I, _P],
     "smaat_pointwise_fwd_bf16": [_P, _L, _P, _P, _P, _L, _I, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -254,6 +256,10 @@ WORK_MODELS = {
     "smaat_pointwise_fwd": _w_pointwise_fwd,
     "smaat_dsconv_wgrad": _w_dsconv_wgrad,
     "smaat_dsconv_wgrad_split": _w_dsconv_wgrad,
+    "smaat_dsconv_wgrad_split_h": lambda a: (2.0 * a[12] * a[13] * a[14] * a[15] * a[16] * a[17],
+                                             4.0 * a[12] * (a[13] + a[15]) * a[16] * a[17]),
+    "smaat_dsconv_fwd_rows_amax": lambda a: (2.0 * a[12] * a[13] * a[14] * a[15] * a[16] * a[17],
+                                             4.0 * a[12] * (a[13] + a[15]) * a[16] * a[17]),
     "smaat_dsconv_wgrad_split_t": lambda a: (2.0 * a[12] * a[13] * a[14] * a[15] * a[16] * a[17],
                                              a[12] * (_es(a[1]) * a[13] + _es(a[8]) * a[15]) * a[16] * a[17]),
     "smaat_pointwise_wgrad": _w_pointwise_wgrad,

@@ -222,6 +222,24 @@ int smaat_dsconv_wgrad_split(const float* x, long x_bs, const float* in_scale, c
                                       kpl, Cout, H, W, stream);
 }
 
+/* two-term fp16 split form (round 5): y_amax = the buffer smaat_dsconv_fwd_rows_amax filled in the forward of this layer (the
+ * kernel re-forms the same y bit for bit), dz_amax = the buffer of the kernel that wrote dz */
+int smaat_dsconv_wgrad_split_h(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                               const float* b_dw, const void* y_amax, const float* dz, long dz_bs, const void* dz_amax, float* ws,
+                               float* dw_out, int N, int Cin, int kpl, int Cout, int H, int W, void* stream) {
+    if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || !x || !w_dw || !dz || !ws || !dw_out || !y_amax || !dz_amax) return -1;
+    if ((in_scale == nullptr) != (in_shift == nullptr)) return -1;
+    DsWgArgs a{};
+    a.x = x; a.x_bs = x_bs; a.in_scale = in_scale; a.in_shift = in_shift; a.w_dw = w_dw; a.b_dw = b_dw;
+    a.dz = dz; a.dz_bs = dz_bs; a.part = ws;
+    a.N = N; a.Cin = Cin; a.K = Cin * kpl; a.M = Cout; a.H = H; a.W = W;
+    a.y_amax = (const unsigned*)y_amax; a.dz_amax = (const unsigned*)dz_amax;
+    hipStream_t st = ST;
+    const int rc = launch_dsconv_wgrad_split(a, kpl, SMAAT_F32, SMAAT_F32, st);
+    if (rc) return rc;
+    return launch_reduce_rows(ws, a.nsplit, (long)Cout * a.K, dw_out, 1.f, st);
+}
+
 int smaat_pointwise_wgrad(const float* x, long x_bs, const float* dz, long dz_bs, float* ws, float* dw_out, int N,
                           int Cin, int M, int H, int W, void* stream) {
     if (N < 1 || Cin < 1 || M < 1 || H < 1 || W < 1) return -1;
@@ -586,9 +604,26 @@ int smaat_dsconv_fwd_split(const float* x, long x_bs, const float* in_scale, con
 }
 int smaat_dsconv_rows_ok(int kpl, int Cin, int Cout, int H, int W) { return dsconv_rows_ok(kpl, Cin, Cout, H, W); }
 int smaat_dsconv_rows_num_slots(int N, int H, int W) { return dsconv_rows_num_slots(N, H, W); }
+static int dsconv_fwd_rows_impl(const void* x, int x_dt, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                                const float* b_dw, const void* planes, const float* b_pw, void* z, int z_dt, long z_bs, float* part,
+                                void* y_amax, int N, int Cin, int kpl, int Cout, int H, int W, void* stream);
 int smaat_dsconv_fwd_rows(const void* x, int x_dt, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
                           const float* b_dw, const void* planes, const float* b_pw, void* z, int z_dt, long z_bs, float* part,
                           int N, int Cin, int kpl, int Cout, int H, int W, void* stream) {
+    return dsconv_fwd_rows_impl(x, x_dt, x_bs, in_scale, in_shift, w_dw, b_dw, planes, b_pw, z, z_dt, z_bs, part, nullptr, N, Cin,
+                                kpl, Cout, H, W, stream);
+}
+/* f32 storage + the maximum of the depthwise output the kernel forms (never stored): the scale of smaat_dsconv_wgrad_split_h */
+int smaat_dsconv_fwd_rows_amax(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                               const float* b_dw, const void* planes, const float* b_pw, float* z, long z_bs, float* part,
+                               void* y_amax, int N, int Cin, int kpl, int Cout, int H, int W, void* stream) {
+    if (!y_amax) return -1;
+    return dsconv_fwd_rows_impl(x, SMAAT_F32, x_bs, in_scale, in_shift, w_dw, b_dw, planes, b_pw, z, SMAAT_F32, z_bs, part, y_amax, N,
+                                Cin, kpl, Cout, H, W, stream);
+}
+static int dsconv_fwd_rows_impl(const void* x, int x_dt, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                                const float* b_dw, const void* planes, const float* b_pw, void* z, int z_dt, long z_bs, float* part,
+                                void* y_amax, int N, int Cin, int kpl, int Cout, int H, int W, void* stream) {
     if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || !x || !w_dw || !planes || !z) return -1;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return -1;
     if ((x_dt != SMAAT_F32 && x_dt != SMAAT_BF16) || (z_dt != SMAAT_F32 && z_dt != SMAAT_BF16)) return -1;
@@ -596,6 +631,7 @@ int smaat_dsconv_fwd_rows(const void* x, int x_dt, long x_bs, const float* in_sc
     a.x = x; a.x_bs = x_bs; a.in_scale = in_scale; a.in_shift = in_shift; a.w_dw = w_dw; a.b_dw = b_dw;
     a.planes = (const unsigned short*)planes; a.bias = b_pw; a.out = z; a.out_bs = z_bs; a.part = part;
     a.N = N; a.Cin = Cin; a.K = Cin * kpl; a.M = Cout; a.H = H; a.W = W;
+    a.y_amax = (unsigned*)y_amax;
     return launch_dsconv_rows(a, kpl, x_dt, z_dt, ST);
 }
 int smaat_dsconv_fwd_split_act(const float* x, long x_bs, const float* in_scale, const float* in_shift,

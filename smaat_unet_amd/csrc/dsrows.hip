@@ -235,6 +235,7 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
 #pragma unroll
                 for (int c = 0; c < 6; ++c) win[u][r][c] = 0.f;
         int c_j = 0, c_len = 0, c_item = it_lo - it_st;
+        float yam = 0.f;  // running max |y| of this thread (published once, at the end of the walk, when a.y_amax is given)
         // B image address of this thread: pixel 4g + i, dword (ci + 64 u) ^ 8 (g >> 2)  (swizzle: conflict-free writes)
         const int bsw = (g >> 2) << 3;
         auto commit = [&](int set, int buf) __attribute__((always_inline)) {
@@ -310,6 +311,8 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
                             yy[j][c] = acc;
                         }
                 }
+                yam = fmaxf(yam, fmaxf(fmaxf(fmaxf(fabsf(yy[0][0]), fabsf(yy[0][1])), fmaxf(fabsf(yy[0][2]), fabsf(yy[0][3]))),
+                                       fmaxf(fmaxf(fabsf(yy[1][0]), fabsf(yy[1][1])), fmaxf(fabsf(yy[1][2]), fabsf(yy[1][3])))));
                 const int dw_ = ((ci + 64 * u) ^ bsw) * 4;
                 if constexpr ((DSR_DBG & 2) != 0) {
                     asm volatile("" ::"v"(yy[0][0]), "v"(yy[0][1]), "v"(yy[0][2]), "v"(yy[0][3]), "v"(yy[1][0]), "v"(yy[1][1]), "v"(yy[1][2]), "v"(yy[1][3]));
@@ -347,6 +350,7 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (a.y_amax) amax_publish_wave(a.y_amax, yam, (unsigned)(blockIdx.x * 8 + (wv - 4)));  // (wave-uniform branch)
     } else {
         const int wave = wv & 3;
         const int wm = wave & 1, wkh = wave >> 1;

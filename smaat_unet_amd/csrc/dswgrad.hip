@@ -49,8 +49,25 @@ __device__ __forceinline__ unsigned dwg_pack_hi16(float lo, float hi) {
 }
 // 4 consecutive f32 -> NT planes of 4 bf16 (one 8-byte LDS piece per plane); NT = 3: exact three-term split
 // (a = p1 + p2 + p3, truncations, residuals exact), NT = 1: round to nearest even (plain bf16 operands)
+typedef _Float16 dwg_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 dwg_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned dwg_pack_f16(float a, float b) {  // one v_cvt_pk_f16_f32 (round to nearest even)
+    const f32x2_native v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, dwg_f16x2));
+}
+__device__ __forceinline__ void dwg_split2_f16(float t0, float t1, unsigned& h, unsigned& g) {  // as splitmma.hip split2_f16
+    h = dwg_pack_f16(t0, t1);
+    const dwg_f16x2 hv = __builtin_bit_cast(dwg_f16x2, h);
+    g = dwg_pack_f16(t0 - (float)hv.x, t1 - (float)hv.y);
+}
+// NT = 2 (round 5): two fp16 terms of v * sc (sc = the operand tensor's power-of-two scale, splitmma.hip)
 template <int NT>
-__device__ __forceinline__ void dwg_split4(const float (&v)[4], uint2 (&out)[NT]) {
+__device__ __forceinline__ void dwg_split4(const float (&v)[4], uint2 (&out)[NT], float sc = 1.f) {
+    if constexpr (NT == 2) {
+        dwg_split2_f16(v[0] * sc, v[1] * sc, out[0].x, out[1].x);
+        dwg_split2_f16(v[2] * sc, v[3] * sc, out[0].y, out[1].y);
+        return;
+    }
     float p1[4], p2[4], p3[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -152,6 +169,12 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(W2 ? 6 : 3,
     };
     int total = 0;
     for (int i = 0; i < nitems; ++i) total += item_rows(it_lo + i * it_st) + 2;  // (wave-uniform scalar loop, <= a few dozen items)
+    int ky = 0, kdz = 0;  // NT == 2: power-of-two scale exponents of y (its maximum was left by the forward) and dz
+    if constexpr (NT == 2) {
+        ky = f16_kexp(amax_read(a.y_amax));
+        kdz = f16_kexp(amax_read(a.dz_amax));
+        asm volatile("" : "+s"(ky), "+s"(kdz));
+    }
 
     if (producer) {
         // 8 producer waves (two per SIMD: one's VALU chain covers the other's waits).  Thread (ci, g): channel ci of the
@@ -172,6 +195,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(W2 ? 6 : 3,
             bs[j] = (cv && a.b_dw) ? a.b_dw[cgc * 2 + j] : 0.f;  // channels beyond Cin: zero window, zero taps -> y = 0
         }
         float asc = AFF ? a.in_scale[cgc] : 1.f, ash = AFF ? a.in_shift[cgc] : 0.f;
+        const float sy = pow2i(ky), sdz = pow2i(kdz);
         // hipcc does not see the inline-asm loads below.  A compiler-visible load that is still pending at the loop entry makes it
         // drain the vector-memory counter (s_waitcnt vmcnt(0)) at the value's first use INSIDE the loop -- once per iteration,
         // which empties the prefetch queue every chunk (found in round 4 with the ablation builds: all but two instantiations
@@ -349,14 +373,14 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(W2 ? 6 : 3,
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 uint2 pl[NT];
-                dwg_split4<NT>(yy[j], pl);
+                dwg_split4<NT>(yy[j], pl, sy);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) *(uint2*)(base + t * PLSZ + (MT + 2 * ci + j) * DWG_SROW + g * 8) = pl[t];
             }
             if constexpr (sizeof(TG) == 4) {  // dz share: split into the A image
                 const float v4[4] = {zv ? sz[set][0] : 0.f, zv ? sz[set][1] : 0.f, zv ? sz[set][2] : 0.f, zv ? sz[set][3] : 0.f};
                 uint2 pl[NT];
-                dwg_split4<NT>(v4, pl);
+                dwg_split4<NT>(v4, pl, sdz);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) *(uint2*)(base + t * PLSZ + zrow * DWG_SROW + q * 8) = pl[t];
             } else {  // bf16 gradients are the operand as stored
@@ -417,6 +441,14 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(W2 ? 6 : 3,
                         for (int tt = 0; tt < NT; ++tt) bf[j][tt] = *(const bf16x8*)(bp + tt * PLSZ + j * 32 * DWG_SROW + s * 32);
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
+                        if constexpr (NT == 2) {  // two-term fp16 split: h g' + g h' + h h'
+                            const dwg_f16x8 a0 = __builtin_bit_cast(dwg_f16x8, af[0]), a1 = __builtin_bit_cast(dwg_f16x8, af[1]);
+                            const dwg_f16x8 b0 = __builtin_bit_cast(dwg_f16x8, bf[j][0]), b1 = __builtin_bit_cast(dwg_f16x8, bf[j][1]);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[j], 0, 0, 0);
+                            continue;
+                        }
                         if constexpr (NT == 3) {  // smallest terms first (the order of k_wgrad_split)
                             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][2], acc[j], 0, 0, 0);
                             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[j][0], acc[j], 0, 0, 0);
@@ -431,6 +463,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(W2 ? 6 : 3,
             if constexpr ((DWG_DBG & 16) == 0) __syncthreads();
         }
         float* ob = a.part + (long)split * a.M * a.K;
+        const float e1 = pow2i(-((ky + kdz) / 2)), e2 = pow2i(-((ky + kdz) - (ky + kdz) / 2));  // (NT == 2: exponent split evenly)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -438,7 +471,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(W2 ? 6 : 3,
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int kg = kt * KT + (wk * 2 + j) * 32 + l31;
-                    if (kg < a.K) ob[(long)m * a.K + kg] = acc[j][r];
+                    if (kg < a.K) ob[(long)m * a.K + kg] = NT == 2 ? acc[j][r] * e1 * e2 : acc[j][r];
                 }
             }
         }
@@ -547,6 +580,8 @@ int launch_dsconv_wgrad_split(DsWgArgs& a, int kpl, int x_dt, int dz_dt, hipStre
     if (x_dt != SMAAT_F32) return -2;
     if (split_mode() == 1)
         return aff ? launch_dswg_cfg<1, true, false, float, float>(a, st) : launch_dswg_cfg<1, false, false, float, float>(a, st);
+    if (a.y_amax && a.dz_amax)  // both operand maxima at hand: two-term fp16 split (three MFMAs per product)
+        return aff ? launch_dswg_cfg<2, true, false, float, float>(a, st) : launch_dswg_cfg<2, false, false, float, float>(a, st);
     if (pk) return aff ? launch_dswg_cfg<3, true, true, float, float>(a, st) : launch_dswg_cfg<3, false, true, float, float>(a, st);
     return aff ? launch_dswg_cfg<3, true, false, float, float>(a, st) : launch_dswg_cfg<3, false, false, float, float>(a, st);
 }

@@ -18,6 +18,8 @@ struct DsRowsArgs {
     int nsplit, strips, bands, RB, items, ips, npl;
     int ilv;   // 1: the workgroups of an XCD take its items round-robin (set by the launcher)
     int relu;  // 1: the output is max(z + bias, 0) (inference: BatchNorm folded into the weights, ReLU in the epilogue)
+    unsigned* y_amax;  // nullable amax buffer (common.h): receives max |y| of the depthwise output the producers form -- the scale
+                       // of the two-term fp16 recompute weight gradient that re-forms the same y in the backward
 };
 
 struct DsWgArgs {
@@ -33,4 +35,6 @@ struct DsWgArgs {
     int N, Cin, K, M, H, W, P;
     int nkt, nsplit, strips, bands, RB, items, ips;
     int ilv;  // 1: the workgroups of an XCD take its items round-robin (neighbouring strips run at the same time)
+    const unsigned* y_amax;   // NT == 2 (two-term fp16 split): amax buffers of the depthwise output (from the forward) and of dz
+    const unsigned* dz_amax;
 };

@@ -646,9 +646,11 @@ def _dsconv_fwd_fused(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None,
 FWD_ROWS = os.environ.get("SMAAT_FWD_ROWS", "auto")
 
 
-def _dsconv_fwd_rows(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, in_shift=None, out_dtype=None):
+def _dsconv_fwd_rows(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, in_shift=None, out_dtype=None, amx=None):
     """-> (z, part, slots, None) or None when the row-walking kernel does not take the shape.  x f32 -> z f32 (split planes);
-    out_dtype = torch.bfloat16: mixed precision (x f32 | bf16, bf16 weight image, z bf16)"""
+    out_dtype = torch.bfloat16: mixed precision (x f32 | bf16, bf16 weight image, z bf16).
+    amx (f32 storage; see _half_forward): the kernel also leaves max |y| of the depthwise output it forms -- never stored -- in
+    the first amax buffer, for the two-term fp16 recompute weight gradient of the backward"""
     if FWD_ROWS == "off":
         return None
     L = _lib.get()
@@ -664,6 +666,16 @@ def _dsconv_fwd_rows(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, 
     slots = L.smaat_dsconv_rows_num_slots(n, h, w)
     z = _new(x, n, cout, h, w, dtype=out_dtype)
     part = _new(x, 3, slots, cout) if want_stats else None
+    if amx is not None and amx.get("w") is not None and x.dtype == F32 and out_dtype == F32:
+        rc = L.smaat_dsconv_fwd_rows_amax(_ptr(x), x_bs, _ptr(in_scale), _ptr(in_shift), _ptr(w_dw), _ptr(b_dw), _ptr(planes),
+                                          _ptr(b_pw), _ptr(z), cout * h * w, _ptr(part), _ptr(amx["w"][:AMAX_WORDS]), n, cin, kpl,
+                                          cout, h, w, _stream(x))
+        if rc == 0:
+            amx["y"] = True
+            return z, part, (slots if want_stats else 0), None
+        if rc != -2:
+            _lib.check(rc, "smaat_dsconv_fwd_rows_amax")
+        return None
     rc = L.smaat_dsconv_fwd_rows(_ptr(x), _dt(x), x_bs, _ptr(in_scale), _ptr(in_shift), _ptr(w_dw), _ptr(b_dw), _ptr(planes),
                                  _ptr(b_pw), _ptr(z), _dt(z), cout * h * w, _ptr(part), n, cin, kpl, cout, h, w, _stream(x))
     if rc == -2:
@@ -890,8 +902,12 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None, i
         rc = -2
         if _split_on() and WGRAD_RECOMPUTE != "off" and L.smaat_dsconv_wgrad_split_ok(kpl, cout, h, w):
             ws = _new(x, L.smaat_dsconv_wgrad_split_num_splits(n, cin, cout, h, w), cout, k)
-            rc = L.smaat_dsconv_wgrad_split(_ptr(x), x_bs, _ptr(isc), _ptr(ish), _ptr(w_dw), _ptr(b_dw), _ptr(dz), dz_bs,
-                                            _ptr(ws), _ptr(dw_pw), n, cin, kpl, cout, h, w, s)
+            if a_y is not None and a_dz is not None:  # the forward left max |y|, the BatchNorm apply max |dz|: fp16 split
+                rc = L.smaat_dsconv_wgrad_split_h(_ptr(x), x_bs, _ptr(isc), _ptr(ish), _ptr(w_dw), _ptr(b_dw), _ptr(a_y), _ptr(dz),
+                                                  dz_bs, _ptr(a_dz), _ptr(ws), _ptr(dw_pw), n, cin, kpl, cout, h, w, s)
+            else:
+                rc = L.smaat_dsconv_wgrad_split(_ptr(x), x_bs, _ptr(isc), _ptr(ish), _ptr(w_dw), _ptr(b_dw), _ptr(dz), dz_bs,
+                                                _ptr(ws), _ptr(dw_pw), n, cin, kpl, cout, h, w, s)
             if rc != -2:
                 _lib.check(rc, "smaat_dsconv_wgrad_split")
         if rc == -2:
@@ -1035,6 +1051,11 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
            and _recompute_operand_ok(x))
     if rec:
         keep_y = False  # the weight gradient recomputes the depthwise output from x: nothing to keep (y_dw = None)
+    if amx is not None:
+        amx.update(w=None, y=False, dz=False)
+        if not bf and use_batch_stats and n * h * w >= F16_MIN_SAMPLES and _f16_on():
+            amx["w"] = _amax_words(x, 2)
+            amx["dz"] = True  # (the backward's BatchNorm apply kernel will leave max |dz| in the second buffer)
     if bf:  # mixed precision: bf16 depthwise output, bf16 GEMM, bf16 z (the f32 kernel families are not involved)
         if rec or not keep_y:  # no depthwise tensor wanted: the row-walking fused kernel where it takes the shape
             rs = _dsconv_fwd_rows(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish, out_dtype=BF16)
@@ -1044,14 +1065,9 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
                 rs = rs[:3] + (None,)
     elif _split_on() and _fused_dw_ok(n, h, w, kpl, cout, keep_y, cin):
         if not keep_y:
-            rs = _dsconv_fwd_rows(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish)
+            rs = _dsconv_fwd_rows(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish, amx=amx if rec else None)
         if rs is None:
             rs = _dsconv_fwd_fused(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish, want_y=keep_y)
-    if amx is not None:
-        amx.update(w=None, y=False, dz=False)
-        if not bf and use_batch_stats and n * h * w >= F16_MIN_SAMPLES and _f16_on():
-            amx["w"] = _amax_words(x, 2)
-            amx["dz"] = True  # (the backward's BatchNorm apply kernel will leave max |dz| in word 1)
     if rs is None and not bf and _split_fwd_ok(cin * kpl, cout, use_batch_stats):
         rs = _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish,
                                amx=amx if (amx is not None and amx["w"] is not None) else None)

@@ -1223,8 +1223,40 @@ def _t_dsconv_fwd_rows(self, x, x_dt, x_bs, in_scale, in_shift, w_dw, b_dw, pl, 
     return 0
 
 
+def _dsconv_fwd_rows_amax(self, x, x_bs, in_scale, in_shift, w_dw, b_dw, pl, b_pw, z, z_bs, part, y_amax, N, Cin, kpl, Cout, H, W,
+                          stream):
+    """smaat_dsconv_fwd_rows (f32 storage) + max |y| of the depthwise output it forms"""
+    rc = _t_dsconv_fwd_rows(self, x, 0, x_bs, in_scale, in_shift, w_dw, b_dw, pl, b_pw, z, 0, z_bs, part, N, Cin, kpl, Cout, H, W, stream)
+    if rc == 0:
+        P, K = H * W, Cin * kpl
+        xv = np.array(planes(x, N, Cin, P, x_bs)).reshape(N, Cin, H, W)
+        if in_scale:
+            sc, sh = f32(in_scale, Cin), f32(in_shift, Cin)
+            xv = np.maximum(xv * sc[None, :, None, None] + sh[None, :, None, None], 0).astype(np.float32)
+        _amax_publish(y_amax, O.dw3x3_fwd(xv, f32(w_dw, K * 9).reshape(K, 1, 3, 3), f32(b_dw, K) if b_dw else None, kpl))
+    return rc
+
+
+def _dsconv_wgrad_split_h(self, x, x_bs, in_scale, in_shift, w_dw, b_dw, y_amax, dz, dz_bs, dz_amax, ws, dw_out, N, Cin, kpl, Cout,
+                          H, W, stream):
+    """recompute weight gradient on the two-term fp16 split: y re-formed from x, scales from the two amax buffers"""
+    if not self.smaat_dsconv_wgrad_split_ok(kpl, Cout, H, W):
+        return -2
+    P, K = H * W, Cin * kpl
+    xv = np.array(planes(x, N, Cin, P, x_bs)).reshape(N, Cin, H, W)
+    if in_scale:
+        sc, sh = f32(in_scale, Cin), f32(in_shift, Cin)
+        xv = np.maximum(xv * sc[None, :, None, None] + sh[None, :, None, None], 0).astype(np.float32)
+    y = O.dw3x3_fwd(xv, f32(w_dw, K * 9).reshape(K, 1, 3, 3), f32(b_dw, K) if b_dw else None, kpl).astype(np.float32)
+    ky, kd = f16_kexp(_amax_read(y_amax)), f16_kexp(_amax_read(dz_amax))
+    f32(dw_out, Cout * K).reshape(Cout, K)[:] = mm_h("nmp,nkp->mk", _h_terms(planes(dz, N, Cout, P, dz_bs), kd), kd,
+                                                     y.reshape(N, K, P), ky)
+    return 0
+
+
 for _name, _fn in (("smaat_dsconv_wgrad_split_t", _t_dsconv_wgrad_split), ("smaat_dsconv_rows_ok", _t_dsconv_rows_ok), ("smaat_dsconv_rows_num_slots", _t_dsconv_rows_num_slots),
-                   ("smaat_dsconv_fwd_rows", _t_dsconv_fwd_rows)):
+                   ("smaat_dsconv_fwd_rows", _t_dsconv_fwd_rows), ("smaat_dsconv_fwd_rows_amax", _dsconv_fwd_rows_amax),
+                   ("smaat_dsconv_wgrad_split_h", _dsconv_wgrad_split_h)):
     setattr(EmuLib, _name, _fn)
 
 

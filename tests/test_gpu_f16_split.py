@@ -335,3 +335,77 @@ def test_kexp_matches_the_twin_on_edge_maxima():
         out = case_pw_split_h(L, dev, 1, 16, 1, 2, 2, x=x, w=w)["out"].cpu().numpy()
         want = np.float32(16) * np.float32(m) + rnd(3, 1)[0]
         assert np.allclose(out, want, rtol=2e-6, atol=0), (m, out.ravel()[:2], want, f16_kexp(_bits(m)))
+
+
+# ------------------------------------------------------------------------------------------------ the row-walking pair
+def case_rows_amax_and_wgrad_h(L, dev, N, Cin, Cout, H, W, aff=False):
+    """smaat_dsconv_fwd_rows_amax: z and the BatchNorm partials as smaat_dsconv_fwd_rows, + max |y|; then
+    smaat_dsconv_wgrad_split_h with that buffer and the one of dz"""
+    K = 2 * Cin
+    x = T(rnd(1, N, Cin, H, W), dev)
+    w_dw, b_dw = T(rnd(2, K, 9, scale=0.3), dev), T(rnd(3, K, scale=0.3), dev)
+    w_pw, b_pw = T(rnd(4, Cout, K, scale=0.2), dev), T(rnd(5, Cout), dev)
+    sc = T(np.random.default_rng(6).uniform(0.5, 1.5, Cin).astype(np.float32), dev) if aff else None
+    sh = T(rnd(7, Cin, scale=0.3), dev) if aff else None
+    Kp = (K + 15) // 16 * 16
+    pl = torch.empty((3, Cout, Kp), dtype=torch.int16, device=dev)
+    assert L.smaat_split_planes(P(w_pw), Cout, K, P(pl), stream(dev)) == 0
+    slots = L.smaat_dsconv_rows_num_slots(N, H, W)
+    z = torch.full((N, Cout, H, W), float("nan"), device=dev)
+    part = torch.full((3, slots, Cout), float("nan"), device=dev)
+    ay = _amax_word(dev)
+    assert L.smaat_dsconv_fwd_rows_amax(P(x), Cin * H * W, P(sc), P(sh), P(w_dw), P(b_dw), P(pl), P(b_pw), P(z), Cout * H * W, P(part),
+                                        P(ay), N, Cin, 2, Cout, H, W, stream(dev)) == 0
+    dz = T(rnd(8, N, Cout, H, W) * np.exp(2 * rnd(9, N, Cout, 1, 1)) * 1e-4, dev)
+    adz = _publish(dz)
+    ws = torch.empty((L.smaat_dsconv_wgrad_split_num_splits(N, Cin, Cout, H, W), Cout, K), device=dev)
+    dw = torch.full((Cout, K), float("nan"), device=dev)
+    assert L.smaat_dsconv_wgrad_split_h(P(x), Cin * H * W, P(sc), P(sh), P(w_dw), P(b_dw), P(ay), P(dz), Cout * H * W, P(adz), P(ws),
+                                        P(dw), N, Cin, 2, Cout, H, W, stream(dev)) == 0
+    pn, pmean, pvar = part_stats(part)
+    return dict(z=z, dw=dw, amax=torch.tensor([_amax_of(ay)], dtype=torch.int64), pn=pn, pmean=pmean)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 32, 32), (1, 40, 50, 8, 64), (2, 128, 64, 36, 96), (1, 8, 16, 70, 32)])
+@pytest.mark.parametrize("aff", [False, True])
+def test_rows_forward_amax_and_recompute_wgrad_h(shape, aff):
+    L, dev = _lib.get(), DEV
+    N, Cin, Cout, H, W = shape
+    r = both(case_rows_amax_and_wgrad_h, *shape, aff=aff, tol=1e-5)
+    # the maximum is that of the depthwise output the standalone kernel writes (the producers form y in its tap order)
+    K = 2 * Cin
+    x = T(rnd(1, N, Cin, H, W), dev)
+    w_dw, b_dw = T(rnd(2, K, 9, scale=0.3), dev), T(rnd(3, K, scale=0.3), dev)
+    sc = T(np.random.default_rng(6).uniform(0.5, 1.5, Cin).astype(np.float32), dev) if aff else None
+    sh = T(rnd(7, Cin, scale=0.3), dev) if aff else None
+    y = torch.empty((N, K, H, W), device=dev)
+    assert L.smaat_dw3x3_fwd(P(x), Cin * H * W, P(sc), P(sh), P(w_dw), P(b_dw), P(y), K * H * W, N, Cin, 2, H, W, stream(dev)) == 0
+    assert int(r["hip"]["amax"][0]) == _amax_of(_publish(y))
+    # z is bit-identical to the entry point without the side output
+    z0 = torch.empty((N, Cout, H, W), device=dev)
+    w_pw, b_pw = T(rnd(4, Cout, K, scale=0.2), dev), T(rnd(5, Cout), dev)
+    pl = torch.empty((3, Cout, (K + 15) // 16 * 16), dtype=torch.int16, device=dev)
+    assert L.smaat_split_planes(P(w_pw), Cout, K, P(pl), stream(dev)) == 0
+    assert L.smaat_dsconv_fwd_rows(P(x), 0, Cin * H * W, P(sc), P(sh), P(w_dw), P(b_dw), P(pl), P(b_pw), P(z0), 0, Cout * H * W, None,
+                                   N, Cin, 2, Cout, H, W, stream(dev)) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(z0.cpu().numpy(), r["hip"]["z"])
+
+
+def test_recompute_wgrad_h_against_fp64_next_to_the_three_term_kernel():
+    L, dev = _lib.get(), DEV
+    N, Cin, Cout, H, W = 2, 96, 64, 72, 64
+    K = 2 * Cin
+    from oracle import smaat_oracle as O
+    x, dzs = rnd(1, N, Cin, H, W), rnd(8, N, Cout, H, W) * np.exp(2 * rnd(9, N, Cout, 1, 1)) * 1e-4
+    w_dw, b_dw = rnd(2, K, 9, scale=0.3), rnd(3, K, scale=0.3)
+    y64 = O.dw3x3_fwd(x.astype(np.float64), w_dw.astype(np.float64).reshape(K, 1, 3, 3), b_dw.astype(np.float64), 2)
+    ref = np.einsum("nmp,nkp->mk", dzs.astype(np.float64).reshape(N, Cout, -1), y64.reshape(N, K, -1))
+    new = case_rows_amax_and_wgrad_h(L, dev, N, Cin, Cout, H, W)["dw"].cpu().numpy()
+    ws = torch.empty((L.smaat_dsconv_wgrad_split_num_splits(N, Cin, Cout, H, W), Cout, K), device=dev)
+    old = torch.empty((Cout, K), device=dev)
+    assert L.smaat_dsconv_wgrad_split(P(T(x, dev)), Cin * H * W, None, None, P(T(w_dw, dev)), P(T(b_dw, dev)), P(T(dzs, dev)),
+                                      Cout * H * W, P(ws), P(old), N, Cin, 2, Cout, H, W, stream(dev)) == 0
+    e_new, e_old = rel(new, ref), rel(old.cpu().numpy(), ref)
+    assert e_new < 2e-6 and e_new < 3 * e_old + 2e-7, (e_new, e_old)
+    assert np.array_equal(new, case_rows_amax_and_wgrad_h(L, dev, N, Cin, Cout, H, W)["dw"].cpu().numpy())

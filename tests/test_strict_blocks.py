@@ -137,7 +137,9 @@ def test_strict_rows_blocks_gpu(ops_strict_rows, tag, f16, monkeypatch):
         if os.path.isdir("gpurun_out"):
             with open(f"gpurun_out/strict_{tag}_f16{int(f16)}.json", "w") as f:
                 json.dump(report, f, indent=1, default=float)
-    assert seen.count("smaat_dsconv_fwd_rows") == 2 and seen.count("smaat_dsconv_wgrad_split") == 2, sorted(set(seen))
+    fwd = "smaat_dsconv_fwd_rows_amax" if f16 else "smaat_dsconv_fwd_rows"      # (f16: + the maximum of the depthwise output)
+    wg = "smaat_dsconv_wgrad_split_h" if f16 else "smaat_dsconv_wgrad_split"    # (f16: the recompute kernel on the fp16 split)
+    assert seen.count(fwd) == 2 and seen.count(wg) == 2, sorted(set(seen))
     assert ("smaat_pointwise_fwd_split_h" in seen) == f16
 
 
