@@ -83,10 +83,45 @@ def main():
             for nm, fn in (("fwd3", fwd3), ("fwdh", fwdh), ("dg3", dg3), ("dgh", dgh), ("wg3", wg3), ("wgh", wgh)):
                 t[nm] = min(t.get(nm, 1e9), timeit(fn, iters=int(os.environ.get("LB_ITERS", "5"))))
         fl = 2.0 * N * k * cout * p
+        if L.smaat_dsconv_rows_ok(2, cin, cout, h, w) and L.smaat_dsconv_wgrad_split_ok(2, cout, h, w):
+            # the row-walking pair: fused forward with / without the maximum of its depthwise output, recompute weight gradient
+            # on the three-term / two-term split
+            x = torch.randn(N, cin, h, w, device=dev)
+            w_dw, b_dw = torch.randn(k, 9, device=dev) * 0.3, torch.randn(k, device=dev) * 0.1
+            partr = torch.empty(3, L.smaat_dsconv_rows_num_slots(N, h, w), cout, device=dev)
+            wsr = torch.empty(L.smaat_dsconv_wgrad_split_num_splits(N, cin, cout, h, w), cout, k, device=dev)
+            ayr = torch.zeros(1024, dtype=torch.int32, device=dev)
+
+            def rf():
+                assert L.smaat_dsconv_fwd_rows(x.data_ptr(), 0, cin * p, None, None, w_dw.data_ptr(), b_dw.data_ptr(), pl_f.data_ptr(),
+                                               b_pw.data_ptr(), z.data_ptr(), 0, cout * p, partr.data_ptr(), N, cin, 2, cout, h, w, st) == 0
+
+            def rfa():
+                assert L.smaat_dsconv_fwd_rows_amax(x.data_ptr(), cin * p, None, None, w_dw.data_ptr(), b_dw.data_ptr(), pl_f.data_ptr(),
+                                                    b_pw.data_ptr(), z.data_ptr(), cout * p, partr.data_ptr(), ayr.data_ptr(), N, cin, 2,
+                                                    cout, h, w, st) == 0
+
+            def rw3():
+                assert L.smaat_dsconv_wgrad_split(x.data_ptr(), cin * p, None, None, w_dw.data_ptr(), b_dw.data_ptr(), dz.data_ptr(),
+                                                  cout * p, wsr.data_ptr(), dw.data_ptr(), N, cin, 2, cout, h, w, st) == 0
+
+            def rwh():
+                assert L.smaat_dsconv_wgrad_split_h(x.data_ptr(), cin * p, None, None, w_dw.data_ptr(), b_dw.data_ptr(), ayr.data_ptr(),
+                                                    dz.data_ptr(), cout * p, adz.data_ptr(), wsr.data_ptr(), dw.data_ptr(), N, cin, 2,
+                                                    cout, h, w, st) == 0
+            rfa()
+            tr = {}
+            for rep in range(2):
+                for nm, fn in (("rows_fwd", rf), ("rows_fwd_amax", rfa), ("rwg3", rw3), ("rwgh", rwh)):
+                    tr[nm] = min(tr.get(nm, 1e9), timeit(fn, iters=5))
+            print(f"{name:8s}   row-walking pair: fused fwd {tr['rows_fwd']:.3f} ms, + max|y| {tr['rows_fwd_amax']:.3f} ms | recompute wgrad "
+                  f"3xbf16 {tr['rwg3']:.3f} ms {fl / tr['rwg3'] / 1e9:6.1f} TF  2xfp16 {tr['rwgh']:.3f} ms {fl / tr['rwgh'] / 1e9:6.1f} TF", flush=True)
+            t.update(tr)
+            del x
         r = dict(layer=name, k=k, cout=cout, hw=h, gflop=fl / 1e9, **{a + "_ms": v for a, v in t.items()})
         rows.append(r)
         for a in tot:
-            tot[a] += t[a]
+            tot[a] += t.get(a, 0.0)
         tf = lambda ms: fl / ms / 1e9  # noqa: E731
         print(f"{name:8s} K={k:5d} M={cout:4d} {h:3d}^2 | fwd 3xbf16 {t['fwd3']:7.3f} ms {tf(t['fwd3']):6.1f} TF  2xfp16 {t['fwdh']:7.3f} ms "
               f"{tf(t['fwdh']):6.1f} TF | dgrad {t['dg3']:7.3f} {tf(t['dg3']):6.1f}  {t['dgh']:7.3f} {tf(t['dgh']):6.1f} | wgrad "

@@ -580,8 +580,14 @@ int launch_dsconv_wgrad_split(DsWgArgs& a, int kpl, int x_dt, int dz_dt, hipStre
     if (x_dt != SMAAT_F32) return -2;
     if (split_mode() == 1)
         return aff ? launch_dswg_cfg<1, true, false, float, float>(a, st) : launch_dswg_cfg<1, false, false, float, float>(a, st);
-    if (a.y_amax && a.dz_amax)  // both operand maxima at hand: two-term fp16 split (three MFMAs per product)
-        return aff ? launch_dswg_cfg<2, true, false, float, float>(a, st) : launch_dswg_cfg<2, false, false, float, float>(a, st);
+    if (a.y_amax && a.dz_amax) {  // both operand maxima at hand: two-term fp16 split (three MFMAs per product)
+        // AFF: the PACKED-math build (v_pk_fma_f32 over the two k-rows of a channel; bit-identical y, 100 VGPRs).  The scalar-math
+        // AFF build of this instantiation comes out of hipcc 7.2 at 132 VGPRs and is WRONG on the GPU: results differ from call to
+        // call by 1e-3 (scripts/probes/dswgrad_h_debug.py, profiles/r5/dswgrad_h_aff_scalar_build_nondeterministic.txt) while the
+        // ISA shows the same loads, waits and barriers as the correct builds -- not understood, not shipped (never instantiated).
+        if (aff) return launch_dswg_cfg<2, true, true, float, float>(a, st);
+        return launch_dswg_cfg<2, false, false, float, float>(a, st);
+    }
     if (pk) return aff ? launch_dswg_cfg<3, true, true, float, float>(a, st) : launch_dswg_cfg<3, false, true, float, float>(a, st);
     return aff ? launch_dswg_cfg<3, true, false, float, float>(a, st) : launch_dswg_cfg<3, false, false, float, float>(a, st);
 }

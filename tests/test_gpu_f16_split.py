@@ -392,6 +392,16 @@ def test_rows_forward_amax_and_recompute_wgrad_h(shape, aff):
     assert np.array_equal(z0.cpu().numpy(), r["hip"]["z"])
 
 
+@pytest.mark.parametrize("aff", [False, True])
+def test_recompute_wgrad_h_is_bit_reproducible(aff):
+    """six calls on the same inputs: bit-identical (the scalar-math AFF build of this kernel was not -- profiles/r5/
+    dswgrad_h_aff_scalar_build_nondeterministic.txt -- and is no longer instantiated)"""
+    L, dev = _lib.get(), DEV
+    first = case_rows_amax_and_wgrad_h(L, dev, 2, 64, 64, 32, 32, aff=aff)["dw"].cpu().numpy()
+    for _ in range(5):
+        assert np.array_equal(first, case_rows_amax_and_wgrad_h(L, dev, 2, 64, 64, 32, 32, aff=aff)["dw"].cpu().numpy())
+
+
 def test_recompute_wgrad_h_against_fp64_next_to_the_three_term_kernel():
     L, dev = _lib.get(), DEV
     N, Cin, Cout, H, W = 2, 96, 64, 72, 64
