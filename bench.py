@@ -532,7 +532,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             traffic_rec["why"] = str(e)[:120]
 
-        def pmc_traffic(kernel_prefixes):
+        def pmc_traffic(kernel_prefixes, ends=None):
             """HBM bytes per launch of a kernel class from the rocprofv3 counter passes OF THIS BUILD
             (profiles/hbm_traffic.json <- scripts/prof_round.sh + scripts/make_traffic_json.py, stamped with the
             hash of the kernel sources): (2 x FETCH_SIZE + WRITE_SIZE) / dispatches over the kernels whose name
@@ -541,12 +541,12 @@ def main():
                 return None
             tot, nd = 0.0, 0
             for kname, v in traffic_rec["kernels"].items():
-                if any(kname.startswith(pfx) for pfx in kernel_prefixes):
+                if any(kname.startswith(pfx) for pfx in kernel_prefixes) and (ends is None or kname.rstrip().endswith(ends)):
                     tot += float(v["fetch_bytes"]) + float(v["write_bytes"])
                     nd += int(v["dispatches"])
             return round(tot / nd) if nd else None
 
-        def klass(names, bound, peak, unit, mult=1.0, what="", pmc=(), peak_name=""):
+        def klass(names, bound, peak, unit, mult=1.0, what="", pmc=(), peak_name="", pmc_ends=None):
             """`achieved` / `frac` follow SURVEY 8(d): ALGORITHMIC work (2 K Cout HW N flops, or the per-stage
             algorithmic bytes) / measured time / the peak named in `peak_name`.  For the bf16-split GEMMs the
             executed matrix-pipe work is `mult` x that (six bf16 MFMAs per f32 product): reported separately as
@@ -562,7 +562,7 @@ def main():
             r = {"bound": bound, "achieved": round(alg, 2), "peak": peak, "unit": unit, "frac": round(alg / peak, 4),
                  "timing": "instrumented pass after the timed region (HIP events around every entry point: class times sum to "
                            "~3-4 % more than ms_per_step of the headline)",
-                 "peak_name": peak_name, "traffic": pmc_traffic(pmc) if pmc else None, "kernel": what,
+                 "peak_name": peak_name, "traffic": pmc_traffic(pmc, pmc_ends) if pmc else None, "kernel": what,
                  "entry_points": names, "launches_per_step": calls, "avg_launch_ms": round(ms / max(calls, 1), 4),
                  "ms_per_step": round(ms, 3), "algorithmic_tflops": round(alg_tf, 2),
                  "algorithmic_gbs": round(alg_gb, 1), "hbm_frac_algorithmic": round(alg_gb / PEAK_HBM_GBS, 4)}
@@ -603,9 +603,10 @@ def main():
             klass(["smaat_pointwise_fwd_split_h", "smaat_pointwise_fwd_split_k_h"], "mfma", PEAK_BF16_MFMA_TFLOPS, "TFLOP/s", 3.0,
                   "k_pw_split_p<NT=2>: persistent wave-specialised GEMM on the TWO-term fp16 operand split (three "
                   "v_mfma_f32_32x32x16_f16 per product, per-tensor power-of-two scales from the producing kernels' maxima): "
-                  "pointwise forward of the GEMM-sized layers + every data gradient", pmc=("k_pw_split",), peak_name=F16),
+                  "pointwise forward of the GEMM-sized layers + every data gradient", pmc=("k_pw_split",), peak_name=F16,
+                  pmc_ends=", 2>"),
             klass(["smaat_pointwise_wgrad_h"], "mfma", PEAK_BF16_MFMA_TFLOPS, "TFLOP/s", 3.0,
-                  "k_wgrad_split<NT=2>: streamed pointwise weight gradient on the two-term fp16 split", pmc=("k_wgrad_split",),
+                  "k_wgrad_split<NT=2>: streamed pointwise weight gradient on the two-term fp16 split", pmc=("k_wgrad_split<2,",),
                   peak_name=F16),
             klass(["smaat_pointwise_fwd_split"], "mfma", PEAK_BF16_MFMA_TFLOPS, "TFLOP/s", nt,
                   "k_pw_split_p: persistent wave-specialised GEMM (v_mfma_f32_32x32x16_bf16, exact 3-term operand "
@@ -613,7 +614,7 @@ def main():
                   peak_name=BF16),
             klass(["smaat_dsconv_wgrad_split_h"], "mfma", PEAK_BF16_MFMA_TFLOPS, "TFLOP/s", 3.0,
                   "k_dsconv_wgrad_split<NT=2>: recompute weight gradient of the 288^2 layers on the two-term fp16 split (the "
-                  "forward left the maximum of the depthwise output it formed)", pmc=("k_dsconv_wgrad_split",), peak_name=F16),
+                  "forward left the maximum of the depthwise output it formed)", pmc=("k_dsconv_wgrad_split<2,",), peak_name=F16),
             klass(["smaat_dsconv_fwd_split", "smaat_dsconv_fwd_rows_amax"] + (["smaat_dsconv_fwd_rows"] if args.precision != "bf16" else []), "mfma",
                   PEAK_BF16_MFMA_TFLOPS, "TFLOP/s", nt,
                   "k_dsconv_rows_fwd: fused depthwise 3x3 -> split GEMM forward of the 288^2 layers (row-walking "
