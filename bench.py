@@ -826,7 +826,7 @@ def main():
             "roofline": roof,
             "gradient_exchange": (allreduce_model(ddp.numel * 4) if world == 1 else
                                   {"modelled": False, "bytes": ddp.numel * 4, "buckets": len(ddp._buckets),
-                                   "note": "measured inside ms_per_step (RCCL all-reduce of the flat buffer)"}),
+                                   "note": f"measured inside ms_per_step ({backend} all-reduce of the flat buffer, two buckets)"}),
             "placement": {"rank_localrank_device": placement, "devices_visible": ndev,
                           "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")},
             "ddp_semantics": ("per-replica BatchNorm statistics, gradients averaged; stock DDP's per-step broadcast_buffers is "

@@ -193,7 +193,8 @@ def run_big(golden_dir, name, dev, graph=False, report=None):
     if os.path.exists(noise_file):
         bound = max(bound, 1.5 * float(np.load(noise_file)["eval/self/dx_sampled"]))
     if report is not None:
-        report["eval"]["dx"] = dict(ours=edx, bound=bound)
+        report["eval"]["dx"] = dict(ours=edx, bound=bound, margin=bound / max(edx, 1e-30),
+                                    bound_source="reference-vs-itself figure x 1.5" if bound > 2e-3 else "2e-3 (no noise fixture)")
     assert edx < bound, (edx, bound)
     for k in g.files:  # eval mode did not move the running statistics
         if k.startswith("train/after/"):
