@@ -540,7 +540,13 @@ def main():
             if traffic_rec["stale"]:
                 return None
             tot, nd = 0.0, 0
+            bf_run = args.precision == "bf16"
             for kname, v in traffic_rec["kernels"].items():
+                # the record holds the f32 run and the mixed-precision run of one build: typed kernels carry their element
+                # types in the name ("float" / "unsigned short" template arguments) -- take the instantiations of THIS run
+                is_bf, is_f = "unsigned short" in kname, "float" in kname
+                if (is_bf and not bf_run) or (bf_run and is_f and not is_bf):
+                    continue
                 if any(kname.startswith(pfx) for pfx in kernel_prefixes) and (ends is None or kname.rstrip().endswith(ends)):
                     tot += float(v["fetch_bytes"]) + float(v["write_bytes"])
                     nd += int(v["dispatches"])
