@@ -234,7 +234,7 @@ F16_SPLIT = os.environ.get("SMAAT_F16_SPLIT", "1") != "0"
 # them).  BASELINE configs: 32 x 18 x 18 = 10,368 at the bottleneck of configs[1], 16 x 16 x 16 = 4,096 for configs[4].
 F16_MIN_SAMPLES = int(os.environ.get("SMAAT_F16_MIN_SAMPLES", "4096"))
 _AMAX_LOCK = threading.Lock()
-_AMAX_ARENA = {}  # device -> [int32 tensor of zeros, next free word]
+_AMAX_ARENA = {}  # (device, stream) -> [int32 tensor of zeros, next free word]
 
 
 def _f16_on():
@@ -254,17 +254,18 @@ def _amax_words(ref, n):
     n *= AMAX_WORDS
     if ref.is_cuda and torch.cuda.is_current_stream_capturing():
         return torch.zeros(n, dtype=torch.int32, device=ref.device)
+    key = (ref.device, _stream(ref))  # (per stream: the arena's one fill launch is ordered before every use on that stream)
     with _AMAX_LOCK:
-        a = _AMAX_ARENA.get(ref.device)
+        a = _AMAX_ARENA.get(key)
         if a is None or a[1] + n > a[0].numel():
             a = [torch.zeros(max(1 << 20, n), dtype=torch.int32, device=ref.device), 0]
-            _AMAX_ARENA[ref.device] = a
+            _AMAX_ARENA[key] = a
         w = a[0][a[1]:a[1] + n]
         a[1] += n
     return w
 
 
-_ZERO_ARENA = {}  # device -> [float32 tensor of zeros, next free element]
+_ZERO_ARENA = {}  # (device, stream) -> [float32 tensor of zeros, next free element]
 
 
 def _zero_grad_words(ref, n):
@@ -275,11 +276,12 @@ def _zero_grad_words(ref, n):
     from . import train_ops
     if train_ops.active() or (ref.is_cuda and torch.cuda.is_current_stream_capturing()):
         return torch.zeros(n, dtype=torch.float32, device=ref.device)  # (outputs of a torch.library operator must not alias)
+    key = (ref.device, _stream(ref))
     with _AMAX_LOCK:
-        a = _ZERO_ARENA.get(ref.device)
+        a = _ZERO_ARENA.get(key)
         if a is None or a[1] + n > a[0].numel():
             a = [torch.zeros(max(1 << 20, n), dtype=torch.float32, device=ref.device), 0]
-            _ZERO_ARENA[ref.device] = a
+            _ZERO_ARENA[key] = a
         w = a[0][a[1]:a[1] + n]
         a[1] += (n + 3) // 4 * 4  # (16-byte aligned slices)
     return w
