@@ -800,3 +800,32 @@ def test_traceable_training_operators_on_gpu(mode, monkeypatch):
     for k in s0:
         assert torch.allclose(s0[k], s1[k], rtol=1e-4 if mode == "f32" else 2e-2, atol=1e-6), k
     assert float((g1 - g0).norm() / g0.norm()) < (5e-3 if mode == "f32" else 0.6)
+
+
+def test_training_runs_are_bit_reproducible_with_the_f16_split(monkeypatch):
+    """two identical runs of eight Adam steps (fresh batch every step) end in bit-identical parameters: fixed reduction
+    orders everywhere, and the operand maxima of the two-term fp16 split -- forced onto every layer here -- are
+    order-independent (atomicMax on bit patterns).  scripts/probes/soak_determinism.py is the long form (150 steps at
+    288 x 288, profiles/r5/soak_determinism_r5.txt)."""
+    from smaat_unet_amd import ops as _ops
+    monkeypatch.setattr(_ops, "F16_MIN_SAMPLES", 0)
+
+    def run():
+        torch.manual_seed(0)
+        m = S.SmaAt_UNet(12, 1).to(DEV).train()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        g = torch.Generator().manual_seed(3)
+        losses = []
+        for _ in range(8):
+            x = torch.rand(3, 12, 96, 64, generator=g).to(DEV)
+            y = torch.rand(3, 96, 64, generator=g).to(DEV)
+            loss = torch.nn.functional.mse_loss(m(x).squeeze(1), y, reduction="sum") / 3
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        return losses, [p.detach().clone() for p in m.parameters()]
+
+    (la, pa), (lb, pb) = run(), run()
+    assert la == lb and all(np.isfinite(la)) and la[-1] < la[0]
+    assert all(torch.equal(a, b) for a, b in zip(pa, pb))
