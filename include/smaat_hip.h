@@ -513,6 +513,35 @@ int smaat_cbam_bwd_final_pool_t(void* dx, long dx_bs, const float* davg, const f
                                 long x_bs, const void* dpool, long dp_bs, int N, int C, int H, int W, int dt,
                                 void* stream);
 
+/* ---- the attention backward of a level in three passes (round 5) ---------------------------------------------------
+ * Same gradients as smaat_cbam_bwd_gate_t + smaat_cbam_bwd_main_t + smaat_cbam_bwd_final[_pool]_t (the autograd of
+ * models/layers.py:105-111, 122-129, 138-141 and of the MaxPool2d of unet_parts_depthwise_separable.py:48 that reads the same
+ * tensor), with dx written once, and with the channels of a level split over the waves of a workgroup where one wave per 256
+ * pixels would walk hundreds of channels in a dependent chain (the 72 x 72 ... 18 x 18 levels):
+ *   smaat_cbam_sppool_idx_t   (forward) smaat_cbam_sppool_t + amaxc[n][p] = the FIRST channel that attains max_c x * s
+ *                             (models/layers.py:123-125; what torch.max's backward routes the gradient to)
+ *   smaat_cbam_bwd_gate_ds_t  the gate pass + dspart[blk][n][c] = sum_p (dout * gate) * x              (reads dout, x)
+ *   smaat_cbam_bwd_ds2_t      dspart[blk][n][c] = sum_p (dmaps0 / C + [c == amaxc] dmaps1) * x         (reads x)
+ *     -> ds = the sum of both partial sets (smaat_reduce_rows over 2 * blocks rows), then smaat_cbam_bwd_mlp
+ *   smaat_cbam_bwd_apply_t    dx = (dout * gate + dmaps0 / C + [c == amaxc] dmaps1) * s + davg / P + [p == amax] dmx
+ *                                  (+ [p first maximum of its 2 x 2 window] dpool when dpool != NULL)
+ * blk as in smaat_cbam_pix_blocks (blocks of 256 pixels per image).  smaat_cbam_bwd3_ok: 1 when the shapes, strides and
+ * alignments allow this route (H * W % 4 == 0, 4-element aligned planes; with dpool: H even and W % 4 == 0); otherwise the
+ * entries return -2 and the caller keeps smaat_cbam_sppool_t and the gate / main / final sequence. */
+int smaat_cbam_bwd3_ok(const void* x, long x_bs, const void* dout, long dout_bs, const void* dpool, long dp_bs, int N, int C,
+                       int H, int W, int dt);
+int smaat_cbam_sppool_idx_t(const void* x, long x_bs, const float* s, int N, int C, int P, float* maps, int* amaxc, int dt,
+                            void* stream);
+int smaat_cbam_bwd_gate_ds_t(const void* dout, long dout_bs, const void* x, long x_bs, const float* s, const float* gate,
+                             const float* conv, const float* mean, const float* invstd, int N, int C, int P, float* dbn,
+                             float* part, float* dspart, int dt, void* stream);
+int smaat_cbam_bwd_ds2_t(const void* x, long x_bs, const float* dmaps, const int* amaxc, int N, int C, int P, float* dspart,
+                         int dt, void* stream);
+int smaat_cbam_bwd_apply_t(const void* dout, long dout_bs, const void* x, long x_bs, const float* s, const float* gate,
+                           const float* dmaps, const int* amaxc, const float* davg, const float* dmx, const int* amax,
+                           const void* dpool, long dp_bs, int N, int C, int H, int W, void* dx, long dx_bs, int dt,
+                           void* stream);
+
 /* ---- on-device PrecipitationMetrics.update ---------------------------------------------
  * replaces metric/precipitation_metrics.py:37-95 (called every train/val/test step, models/regression_lightning.py:
  * 75,86,94): NaN check, sum (p-t)^2 / batch, sum (p*f - t*f)^2 / batch, and the 4-bin confusion counts of

@@ -131,6 +131,11 @@ SIGNATURES = {
     "smaat_cbam_bwd_main_t": [_P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _P, _L, _P, _I, _P],
     "smaat_cbam_bwd_final_t": [_P, _L, _P, _P, _P, _I, _I, _I, _I, _P],
     "smaat_cbam_bwd_final_pool_t": [_P, _L, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _P],
+    "smaat_cbam_bwd3_ok": [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I],
+    "smaat_cbam_bwd_gate_ds_t": [_P, _L, _P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P],
+    "smaat_cbam_sppool_idx_t": [_P, _L, _P, _I, _I, _I, _P, _P, _I, _P],
+    "smaat_cbam_bwd_ds2_t": [_P, _L, _P, _P, _I, _I, _I, _P, _I, _P],
+    "smaat_cbam_bwd_apply_t": [_P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _L, _I, _P],
     "smaat_precip_metrics_ws_bytes": [_L],
     "smaat_precip_metrics_update": [_P, _P, _L, _I, _F, _F, _I, _P, _P, _P, _P],
 }

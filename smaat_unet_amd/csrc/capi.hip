@@ -92,6 +92,14 @@ int launch_cbam_bwd_final(void*, long, const float*, const float*, const int*, i
                           int dt = SMAAT_F32);
 int launch_cbam_final_pool_bwd(void*, long, const float*, const float*, const int*, const void*, long, const void*, long,
                                int, int, int, int, hipStream_t, int dt = SMAAT_F32);
+int cbam_bwd3_ok(const void*, long, const void*, long, const void*, long, int, int, int, int, int);
+int launch_cbam_sppool_idx(const void*, long, const float*, int, int, int, float*, int*, hipStream_t, int);
+int launch_cbam_bwd_gate_ds(const void*, long, const void*, long, const float*, const float*, const float*, const float*,
+                            const float*, int, int, int, float*, float*, float*, hipStream_t, int);
+int launch_cbam_bwd_ds2(const void*, long, const float*, const int*, int, int, int, float*, hipStream_t, int);
+int launch_cbam_bwd_apply(const void*, long, const void*, long, const float*, const float*, const float*, const int*,
+                          const float*, const float*, const int*, const void*, long, int, int, int, int, void*, long,
+                          hipStream_t, int);
 
 
 struct DsSplitArgs {  // dsconv_split.hip
@@ -807,6 +815,42 @@ int smaat_cbam_bwd_final_pool_t(void* dx, long dx_bs, const float* davg, const f
                                 void* stream) {
     if (!dx || !davg || !dmx || !amax || !x || !dpool || N < 1 || C < 1 || H < 1 || W < 1 || !dt_ok(dt)) return -1;
     return launch_cbam_final_pool_bwd(dx, dx_bs, davg, dmx, amax, x, x_bs, dpool, dp_bs, N, C, H, W, ST, dt);
+}
+
+int smaat_cbam_bwd3_ok(const void* x, long x_bs, const void* dout, long dout_bs, const void* dpool, long dp_bs, int N, int C,
+                       int H, int W, int dt) {
+    if (!x || !dout || !dt_ok(dt)) return 0;
+    return cbam_bwd3_ok(x, x_bs, dout, dout_bs, dpool, dp_bs, N, C, H, W, dt);
+}
+int smaat_cbam_bwd_gate_ds_t(const void* dout, long dout_bs, const void* x, long x_bs, const float* s, const float* gate,
+                             const float* conv, const float* mean, const float* invstd, int N, int C, int P, float* dbn,
+                             float* part, float* dspart, int dt, void* stream) {
+    if (!dout || !x || !s || !gate || !conv || !mean || !invstd || !dbn || !part || !dspart || N < 1 || C < 1 || P < 1 ||
+        !dt_ok(dt))
+        return -1;
+    if (!cbam_bwd3_ok(x, x_bs, dout, dout_bs, nullptr, 0, N, C, 1, 4, dt)) return -2;  // (pointer / stride conditions only)
+    return launch_cbam_bwd_gate_ds(dout, dout_bs, x, x_bs, s, gate, conv, mean, invstd, N, C, P, dbn, part, dspart, ST, dt);
+}
+int smaat_cbam_sppool_idx_t(const void* x, long x_bs, const float* s, int N, int C, int P, float* maps, int* amaxc, int dt,
+                            void* stream) {
+    if (!x || !s || !maps || !amaxc || N < 1 || C < 1 || P < 1 || !dt_ok(dt)) return -1;
+    return launch_cbam_sppool_idx(x, x_bs, s, N, C, P, maps, amaxc, ST, dt);
+}
+int smaat_cbam_bwd_ds2_t(const void* x, long x_bs, const float* dmaps, const int* amaxc, int N, int C, int P, float* dspart,
+                         int dt, void* stream) {
+    if (!x || !dmaps || !amaxc || !dspart || N < 1 || C < 1 || P < 1 || !dt_ok(dt)) return -1;
+    if (!cbam_bwd3_ok(x, x_bs, x, x_bs, nullptr, 0, N, C, 1, 4, dt)) return -2;
+    return launch_cbam_bwd_ds2(x, x_bs, dmaps, amaxc, N, C, P, dspart, ST, dt);
+}
+int smaat_cbam_bwd_apply_t(const void* dout, long dout_bs, const void* x, long x_bs, const float* s, const float* gate,
+                           const float* dmaps, const int* amaxc, const float* davg, const float* dmx, const int* amax,
+                           const void* dpool, long dp_bs, int N, int C, int H, int W, void* dx, long dx_bs, int dt,
+                           void* stream) {
+    if (!dout || !x || !s || !gate || !dmaps || !amaxc || !davg || !dmx || !amax || !dx || N < 1 || C < 1 || H < 1 || W < 1 ||
+        !dt_ok(dt))
+        return -1;
+    return launch_cbam_bwd_apply(dout, dout_bs, x, x_bs, s, gate, dmaps, amaxc, davg, dmx, amax, dpool, dp_bs, N, C, H, W, dx,
+                                 dx_bs, ST, dt);
 }
 
 int smaat_precip_metrics_ws_bytes(long n) { return (int)precip_metrics_ws_bytes(n); }

@@ -9,6 +9,7 @@
 //   k_cbam_apply    out = x * s[n][c] * sigmoid(conv*scale+shift)[n][p]          :110,128
 // backward: see the individual kernels.
 #include "common.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
 
@@ -1049,6 +1050,372 @@ __global__ __launch_bounds__(256) void k_cbam_final_pool_bwd(T* __restrict__ dx,
     st4(dp + p0, make_float4(a0[0], a0[1], a0[2], a0[3]));
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 5: the backward of a level's attention in THREE passes over the level's tensors instead of the gate / main / final
+// passes above (2 + 3 + 3.25 tensor streams -> 2 + 1 + 3.25: `dx` is written ONCE, complete):
+//   ds[n][c] = sum_p dxs * x,  dxs = dout * gate + dmaps0 / C + [c first argmax] dmaps1   (k_cbam_bwd_main)
+//            = sum_p (dout * gate) * x              <- k_cbam_bwd_gate_ds_v4: the gate pass reads dout and x anyway
+//            + sum_p (dmaps0 / C + [..] dmaps1) * x <- k_cbam_bwd_ds2_v4: x alone, after the spatial branch's backward
+//   so the shared MLP's backward (davg, dmx) is known BEFORE dx is formed, and k_cbam_bwd_apply_v4 writes
+//   dx = dxs * s + davg / P + [p == amax] dmx + [p first maximum of its 2 x 2 window] dpool
+//   (the terms of k_cbam_bwd_main + k_cbam_final_pool_bwd in their order: f32 dx is bit-identical given the same ds;
+//   bf16 storage rounds once instead of twice) without the read-modify-write pass over it.
+// The pixel-major passes above walk ALL channels in one wave: a dependent chain of C / 2 trips of ~1.5 us each, which is what
+// the deep levels cost (profiles/r5: 36 x 36 x 512 channels: 350 us for 0.28 GB; 72 x 72 x 256: 230 us for 0.55 GB) while the
+// 288 x 288 and 144 x 144 levels stream at 5 TB/s.  Here a workgroup is CS = blockDim.x / 64 waves that share the block's 256
+// pixels and SPLIT THE CHANNELS (contiguous ranges, in wave order).  That needs the "first argmax over channels" of the spatial
+// max-pool as data instead of as a scan-order flag: k_cbam_sppool_idx_v4 (forward) leaves amaxc[n][p], the index
+// k_cbam_bwd_main finds by its scan (the first channel whose x * s equals the maximum).
+// reference: the autograd of models/layers.py:105-111, 122-129, 138-141 + the MaxPool2d of unet_parts_depthwise_separable.py:48
+// ---------------------------------------------------------------------------------------------------------------
+// channels [c_lo, c_hi) of this wave: even-sized contiguous chunks in wave order (possibly empty)
+__device__ __forceinline__ void cbam_chan_range(int C, int& c_lo, int& c_hi) {
+    const int cs = (int)(blockDim.x >> 6), w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int chunk = (((C + cs - 1) / cs) + 1) & ~1;
+    c_lo = w * chunk < C ? w * chunk : C;
+    c_hi = c_lo + chunk < C ? c_lo + chunk : C;
+}
+
+// k_cbam_sppool_v4 + amaxc[n][p] = the first channel that attains the maximum.  CS == 1: maps bit-identical to
+// k_cbam_sppool_v4; CS > 1: the mean adds the waves' partial sums in wave order (the maximum and its index do not depend on it).
+template <typename T>
+__global__ __launch_bounds__(512) void k_cbam_sppool_idx_v4(const T* __restrict__ x, long x_bs, const float* __restrict__ s,
+                                                            int C, int P, float* __restrict__ maps, int* __restrict__ amaxc) {
+    extern __shared__ float4 sp_red[];  // [3][CS][64] (sum, max, index) when CS > 1
+    const int n = blockIdx.y, lane = threadIdx.x & 63;
+    const int cs = (int)(blockDim.x >> 6), w = (int)(threadIdx.x >> 6);
+    const int p = blockIdx.x * 256 + lane * 4;
+    const bool valid = p < P;
+    const int pp = valid ? p : 0;
+    const T* xp = x + (long)n * x_bs + pp;
+    const float* sp = s + (long)n * C;
+    int c_lo, c_hi;
+    cbam_chan_range(C, c_lo, c_hi);
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f), m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    int i0 = c_lo, i1 = c_lo, i2 = c_lo, i3 = c_lo;
+#pragma unroll 4
+    for (int c = c_lo; c < c_hi; ++c) {
+        const float4 v = ld4(xp + (long)c * P);
+        const float sv = sp[c];
+        const float a = v.x * sv, b = v.y * sv, cc = v.z * sv, d = v.w * sv;
+        sum.x += a; sum.y += b; sum.z += cc; sum.w += d;
+        i0 = a > m.x ? c : i0; m.x = a > m.x ? a : m.x;
+        i1 = b > m.y ? c : i1; m.y = b > m.y ? b : m.y;
+        i2 = cc > m.z ? c : i2; m.z = cc > m.z ? cc : m.z;
+        i3 = d > m.w ? c : i3; m.w = d > m.w ? d : m.w;
+    }
+    if (cs > 1) {
+        sp_red[(0 * cs + w) * 64 + lane] = sum;
+        sp_red[(1 * cs + w) * 64 + lane] = m;
+        sp_red[(2 * cs + w) * 64 + lane] = make_float4(__int_as_float(i0), __int_as_float(i1), __int_as_float(i2), __int_as_float(i3));
+        __syncthreads();
+        if (w != 0) return;
+        for (int k = 1; k < cs; ++k) {
+            const float4 s2 = sp_red[(0 * cs + k) * 64 + lane], m2 = sp_red[(1 * cs + k) * 64 + lane];
+            const float4 j2 = sp_red[(2 * cs + k) * 64 + lane];
+            sum.x += s2.x; sum.y += s2.y; sum.z += s2.z; sum.w += s2.w;
+            i0 = m2.x > m.x ? __float_as_int(j2.x) : i0; m.x = m2.x > m.x ? m2.x : m.x;
+            i1 = m2.y > m.y ? __float_as_int(j2.y) : i1; m.y = m2.y > m.y ? m2.y : m.y;
+            i2 = m2.z > m.z ? __float_as_int(j2.z) : i2; m.z = m2.z > m.z ? m2.z : m.z;
+            i3 = m2.w > m.w ? __float_as_int(j2.w) : i3; m.w = m2.w > m.w ? m2.w : m.w;
+        }
+    }
+    if (!valid) return;
+    const float ic = (float)C;
+    *(float4*)(maps + ((long)n * 2 + 0) * P + p) = make_float4(sum.x / ic, sum.y / ic, sum.z / ic, sum.w / ic);
+    *(float4*)(maps + ((long)n * 2 + 1) * P + p) = m;
+    *(int4*)(amaxc + (long)n * P + p) = make_int4(i0, i1, i2, i3);
+}
+
+// k_cbam_bwd_gate_v4 + dspart[blockIdx.x][n][c] = sum over the block's 256 pixels of (dout * gate) * x.
+// CS == 1: dbn and its partials bit-identical to k_cbam_bwd_gate_v4; CS > 1: the waves' channel-range sums are added in wave order.
+template <typename T>
+__global__ __launch_bounds__(512) void k_cbam_bwd_gate_ds_v4(const T* __restrict__ dout, long dout_bs,
+                                                             const T* __restrict__ x, long x_bs,
+                                                             const float* __restrict__ s, const float* __restrict__ gate,
+                                                             const float* __restrict__ conv,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, int C, int P,
+                                                             float* __restrict__ dbn, float* __restrict__ part,
+                                                             int nblocks, float* __restrict__ dspart) {
+    extern __shared__ float4 gd_red[];  // [CS][64] when CS > 1
+    const int n = blockIdx.y, N = gridDim.y, lane = threadIdx.x & 63;
+    const int cs = (int)(blockDim.x >> 6), w = (int)(threadIdx.x >> 6);
+    const int p = blockIdx.x * 256 + lane * 4;
+    const bool valid = p < P;
+    const int pp = valid ? p : 0;
+    const T* xp = x + (long)n * x_bs + pp;
+    const T* gp = dout + (long)n * dout_bs + pp;
+    const float* sp = s + (long)n * C;
+    const float4 m = *(const float4*)(gate + (long)n * P + pp);
+    float* dsrow = dspart + ((long)blockIdx.x * N + n) * C;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(dsrow, 0, C * 4, 0x00020000);
+    const unsigned svo = lane == 63 ? 0u : 0x80000000u;
+    int c_lo, c_hi;
+    cbam_chan_range(C, c_lo, c_hi);
+    typedef typename Elem<T>::raw4 R4;
+    auto ld = [&](int c, R4& xv, R4& gv, float& sv) {
+        const int cc = c < C ? c : C - 1;
+        xv = ldraw4(xp + (long)cc * P);
+        gv = ldraw4(gp + (long)cc * P);
+        sv = sp[cc];
+    };
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto process = [&](const R4 xr, const R4 gr, const float sv, int c) {  // (c == C: a clamped duplicate, nothing kept)
+        const float4 v = cvt4(xr), g = cvt4(gr);
+        const bool keep = c < C;
+        const float a0 = fmaf(g.x * v.x, sv, acc.x), a1 = fmaf(g.y * v.y, sv, acc.y);
+        const float a2 = fmaf(g.z * v.z, sv, acc.z), a3 = fmaf(g.w * v.w, sv, acc.w);
+        acc.x = keep ? a0 : acc.x;
+        acc.y = keep ? a1 : acc.y;
+        acc.z = keep ? a2 : acc.z;
+        acc.w = keep ? a3 : acc.w;
+        // (explicit fma placement: left to the compiler, the contraction of a * b + c * d may differ between the f32 and the
+        // bf16 instantiation, and the two are tested bit for bit against each other)
+        float r = valid ? fmaf(g.x * m.x, v.x, (g.y * m.y) * v.y) + fmaf(g.z * m.z, v.z, (g.w * m.w) * v.w) : 0.f;
+        r = wave_sum_l63(r);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r), srs, svo + (unsigned)c * 4u, 0, 0);
+    };
+    R4 xa, ga, xb, gb;
+    float sa, sb;
+    ld(c_lo, xa, ga, sa);
+    ld(c_lo + 1, xb, gb, sb);
+    for (int c = c_lo; c < c_hi; c += 2) {
+        const R4 x0 = xa, g0 = ga, x1 = xb, g1 = gb;
+        const float s0 = sa, s1 = sb;
+        ld(c + 2, xa, ga, sa);
+        ld(c + 3, xb, gb, sb);
+        process(x0, g0, s0, c);
+        process(x1, g1, s1, c + 1 < c_hi ? c + 1 : C);
+    }
+    if (cs > 1) {
+        gd_red[w * 64 + lane] = acc;
+        __syncthreads();
+        if (w != 0) return;
+        for (int k = 1; k < cs; ++k) {
+            const float4 a2 = gd_red[k * 64 + lane];
+            acc.x += a2.x; acc.y += a2.y; acc.z += a2.z; acc.w += a2.w;
+        }
+    }
+    float t1 = 0.f, t2 = 0.f;
+    if (valid) {
+        const float4 cv = *(const float4*)(conv + (long)n * P + p);
+        const float mu = mean[0], is = invstd[0];
+        float4 d;
+        d.x = acc.x * m.x * (1.f - m.x);
+        d.y = acc.y * m.y * (1.f - m.y);
+        d.z = acc.z * m.z * (1.f - m.z);
+        d.w = acc.w * m.w * (1.f - m.w);
+        *(float4*)(dbn + (long)n * P + p) = d;
+        t1 = (d.x + d.y) + (d.z + d.w);
+        t2 = (d.x * (cv.x - mu) + d.y * (cv.y - mu) + d.z * (cv.z - mu) + d.w * (cv.w - mu)) * is;
+    }
+    t1 = wave_sum_l63(t1);
+    t2 = wave_sum_l63(t2);
+    if (lane == 63) {
+        const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+        part[blk] = t1;
+        part[nblocks + blk] = t2;
+    }
+}
+
+// dspart[blockIdx.x][n][c] = sum over the block's 256 pixels of (dmaps0 / C + [c == amaxc] dmaps1) * x
+template <typename T>
+__global__ __launch_bounds__(512) void k_cbam_bwd_ds2_v4(const T* __restrict__ x, long x_bs, const float* __restrict__ dmaps,
+                                                         const int* __restrict__ amaxc, int C, int P,
+                                                         float* __restrict__ dspart) {
+    const int n = blockIdx.y, N = gridDim.y, lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 256 + lane * 4;
+    const bool valid = p < P;
+    const int pp = valid ? p : 0;
+    const T* xp = x + (long)n * x_bs + pp;
+    const int4 am = *(const int4*)(amaxc + (long)n * P + pp);
+    float4 da = *(const float4*)(dmaps + ((long)n * 2 + 0) * P + pp);
+    const float4 dm = *(const float4*)(dmaps + ((long)n * 2 + 1) * P + pp);
+    da.x /= (float)C; da.y /= (float)C; da.z /= (float)C; da.w /= (float)C;
+    float* dsrow = dspart + ((long)blockIdx.x * N + n) * C;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(dsrow, 0, C * 4, 0x00020000);
+    const unsigned svo = lane == 63 ? 0u : 0x80000000u;
+    int c_lo, c_hi;
+    cbam_chan_range(C, c_lo, c_hi);
+    typedef typename Elem<T>::raw4 R4;
+    auto ld = [&](int c, R4& xv) {
+        const int cc = c < C ? c : C - 1;
+        xv = ldraw4(xp + (long)cc * P);
+    };
+    auto process = [&](const R4 xr, int c) {
+        const float4 xv = cvt4(xr);
+        const float e0 = da.x + (am.x == c ? dm.x : 0.f), e1 = da.y + (am.y == c ? dm.y : 0.f);
+        const float e2 = da.z + (am.z == c ? dm.z : 0.f), e3 = da.w + (am.w == c ? dm.w : 0.f);
+        float r = valid ? fmaf(e0, xv.x, e1 * xv.y) + fmaf(e2, xv.z, e3 * xv.w) : 0.f;
+        r = wave_sum_l63(r);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r), srs, svo + (unsigned)c * 4u, 0, 0);
+    };
+    // four channels in flight (one 16-byte load each), two per trip
+    R4 xa, xb, xc, xd;
+    ld(c_lo, xa);
+    ld(c_lo + 1, xb);
+    ld(c_lo + 2, xc);
+    ld(c_lo + 3, xd);
+    for (int c = c_lo; c < c_hi; c += 2) {
+        const R4 x0 = xa, x1 = xb;
+        xa = xc;
+        xb = xd;
+        ld(c + 4, xc);
+        ld(c + 5, xd);
+        process(x0, c);
+        process(x1, c + 1 < c_hi ? c + 1 : C);  // (an odd range: the duplicate's store is dropped)
+    }
+}
+
+// dx, complete.  POOL: a lane owns a 2 x 4 patch (two pooling windows) of every channel of its wave's range; + the
+// MaxPool2d(2) backward (window maximum in the scan order of k_maxpool2_bwd, on x as stored); H even, W % 4 == 0.
+// !POOL (the last level: nothing pools it): a lane owns 4 consecutive pixels; P % 4 == 0.
+// The per-pixel maps stay in registers over the channel loop, the per-channel scalars (s, davg, dmx, amax) come through the
+// scalar cache.
+template <typename T, bool POOL>
+__global__ __launch_bounds__(512) void k_cbam_bwd_apply_v4(const T* __restrict__ dout, long dout_bs,
+                                                           const T* __restrict__ x, long x_bs,
+                                                           const float* __restrict__ s, const float* __restrict__ gate,
+                                                           const float* __restrict__ dmaps, const int* __restrict__ amaxc,
+                                                           const float* __restrict__ davg, const float* __restrict__ dmx,
+                                                           const int* __restrict__ amax, const T* __restrict__ dpool,
+                                                           long dp_bs, int C, int H, int W, T* __restrict__ dx, long dx_bs) {
+    constexpr int R = POOL ? 2 : 1;
+    const int n = blockIdx.y, lane = threadIdx.x & 63;
+    const int P = H * W, Wo = W >> 1, Po = (H >> 1) * Wo;
+    int p0, ipl = 0;
+    bool valid;
+    if (POOL) {
+        const int ncol4 = W >> 2, per = ncol4 * (H >> 1);
+        const int idx = blockIdx.x * 64 + lane;
+        valid = idx < per;
+        const int idc = valid ? idx : 0;
+        const int i = idc / ncol4, q = idc - i * ncol4;
+        p0 = 2 * i * W + 4 * q;
+        ipl = i * Wo + 2 * q;
+    } else {
+        const int p = blockIdx.x * 256 + lane * 4;
+        valid = p < P;
+        p0 = valid ? p : 0;
+    }
+    constexpr unsigned EB = Elem<T>::bytes;
+    const T* xp = x + (long)n * x_bs + p0;
+    const T* gp = dout + (long)n * dout_bs + p0;
+    const T* pl = POOL ? dpool + (long)n * dp_bs + ipl : nullptr;
+    const float* sp = s + (long)n * C;
+    const float* dap = davg + (long)n * C;
+    const float* dmp = dmx + (long)n * C;
+    const int* amp = amax + (long)n * C;
+    float g_[R][4], da_[R][4], dm_[R][4];
+    int am_[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int pr = p0 + r * W;
+        const float4 g4 = *(const float4*)(gate + (long)n * P + pr);
+        const float4 a4 = *(const float4*)(dmaps + ((long)n * 2 + 0) * P + pr);
+        const float4 m4 = *(const float4*)(dmaps + ((long)n * 2 + 1) * P + pr);
+        const int4 i4 = *(const int4*)(amaxc + (long)n * P + pr);
+        g_[r][0] = g4.x; g_[r][1] = g4.y; g_[r][2] = g4.z; g_[r][3] = g4.w;
+        da_[r][0] = a4.x / (float)C; da_[r][1] = a4.y / (float)C; da_[r][2] = a4.z / (float)C; da_[r][3] = a4.w / (float)C;
+        dm_[r][0] = m4.x; dm_[r][1] = m4.y; dm_[r][2] = m4.z; dm_[r][3] = m4.w;
+        am_[r][0] = i4.x; am_[r][1] = i4.y; am_[r][2] = i4.z; am_[r][3] = i4.w;
+    }
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(dx + (long)n * dx_bs, 0, C * P * (int)EB, 0x00020000);
+    const unsigned dvo = valid ? (unsigned)p0 * EB : 0x80000000u;
+    int c_lo, c_hi;
+    cbam_chan_range(C, c_lo, c_hi);
+    typedef typename Elem<T>::raw4 R4;
+    struct Ch {
+        R4 xr[R], gr[R];
+        float2 gg;
+        float sv, add, dmv;
+        int am;
+    };
+    auto ld = [&](int c, Ch& k) {
+        const int cc = c < C ? c : C - 1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            k.xr[r] = ldraw4(xp + (long)cc * P + r * W);
+            k.gr[r] = ldraw4(gp + (long)cc * P + r * W);
+        }
+        if constexpr (POOL) k.gg = ld2(pl + (long)cc * Po);
+        k.sv = sp[cc];
+        k.add = dap[cc];
+        k.dmv = dmp[cc];
+        k.am = amp[cc];
+    };
+    auto process = [&](const Ch& k, int c) {
+        float xv[R][4], a[R][4];
+        const float add = k.add / (float)P;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float4 x4 = cvt4(k.xr[r]), g4 = cvt4(k.gr[r]);
+            const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+            xv[r][0] = x4.x; xv[r][1] = x4.y; xv[r][2] = x4.z; xv[r][3] = x4.w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float dxs = fmaf(gv[e], g_[r][e], da_[r][e]);
+                dxs += am_[r][e] == c ? dm_[r][e] : 0.f;
+                float t = dxs * k.sv;
+                asm volatile("" : "+v"(t));  // (no contraction with the add: the rounding of k_cbam_bwd_main's stored product)
+                float v = t + add;
+                v += (p0 + r * W + e == k.am) ? k.dmv : 0.f;
+                a[r][e] = v;
+            }
+        }
+        if constexpr (POOL) {
+            const float gg[2] = {k.gg.x, k.gg.y};
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const float v0 = xv[0][2 * w], v1 = xv[0][2 * w + 1], v2 = xv[R - 1][2 * w], v3 = xv[R - 1][2 * w + 1];
+                int sel = 0;
+                float mm = v0;
+                if (v1 > mm) { mm = v1; sel = 1; }
+                if (v2 > mm) { mm = v2; sel = 2; }
+                if (v3 > mm) { mm = v3; sel = 3; }
+                a[0][2 * w] += sel == 0 ? gg[w] : 0.f;
+                a[0][2 * w + 1] += sel == 1 ? gg[w] : 0.f;
+                a[R - 1][2 * w] += sel == 2 ? gg[w] : 0.f;
+                a[R - 1][2 * w + 1] += sel == 3 ? gg[w] : 0.f;
+            }
+        }
+        const unsigned off = dvo + (unsigned)c * (unsigned)P * EB;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if constexpr (EB == 4) {
+                u4 o;
+                o.x = __builtin_bit_cast(unsigned, a[r][0]);
+                o.y = __builtin_bit_cast(unsigned, a[r][1]);
+                o.z = __builtin_bit_cast(unsigned, a[r][2]);
+                o.w = __builtin_bit_cast(unsigned, a[r][3]);
+                __builtin_amdgcn_raw_buffer_store_b128(o, drs, off + (unsigned)(r * W) * 4u, 0, 0);
+            } else {
+                u2 o;
+                o.x = pack_bf16x2(a[r][0], a[r][1]);
+                o.y = pack_bf16x2(a[r][2], a[r][3]);
+                __builtin_amdgcn_raw_buffer_store_b64(o, drs, off + (unsigned)(r * W) * 2u, 0, 0);
+            }
+        }
+    };
+    // two channels per trip, the loads of the NEXT two issued before the first is processed and no load between the stores of a
+    // trip (k_cbam_bwd_main_v4: a load between stores makes hipcc drain the prefetch with vmcnt(0) -- the first form of this loop
+    // did, and ran at 3.4 TB/s); a channel index >= C reads clamped addresses and its stores fall outside the buffer range
+    // (dropped by the hardware)
+    Ch ka, kb;
+    ld(c_lo, ka);
+    ld(c_lo + 1, kb);
+    for (int c = c_lo; c < c_hi; c += 2) {
+        const Ch k0 = ka, k1 = kb;
+        ld(c + 2, ka);
+        ld(c + 3, kb);
+        process(k0, c);
+        process(k1, c + 1 < c_hi ? c + 1 : C);
+    }
+}
+
 // =====================================================================================
 static inline int cdivc(long a, long b) { return (int)((a + b - 1) / b); }
 static int seg_len_c(int P) { return P <= 8192 ? ((P + 1023) / 1024) * 1024 : 8192; }
@@ -1225,5 +1592,85 @@ int launch_cbam_final_pool_bwd(void* dx, long dx_bs, const float* davg, const fl
     SMAAT_DISPATCH_ET(dt, T,
         hipLaunchKernelGGL(k_cbam_final_pool_bwd<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (T*)dx, dx_bs, davg,
                            dmx, amax, (const T*)x, x_bs, (const T*)dpool, dp_bs, C, H, W, total););
+    return (int)hipGetLastError();
+}
+
+// ---- the three-pass backward (see k_cbam_bwd_gate_ds_v4) --------------------------------------------------------------
+// waves per workgroup that split the channels: 1 while the launch fills the chip with single-wave blocks or the channel loop
+// is short; otherwise enough that a wave walks <= 64 channels (32 trips), at most 8
+static int cbam_chan_split(int N, int C, int P) {
+    static int forced = -1;  // SMAAT_CBAM_CS=<1|2|4|8>: experiment switch
+    if (forced < 0) {
+        const char* e = getenv("SMAAT_CBAM_CS");
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
+    const long waves = (long)cdivc(P, 256) * N;
+    if (waves >= 4096 || C <= 64) return 1;
+    int cs = 1;
+    while (cs < 8 && C / cs > 64) cs *= 2;
+    return cs;
+}
+// 1: every pointer / stride the three kernels touch allows the 16-byte forms; with a pooled gradient H even and W % 4 == 0,
+// without P % 4 == 0
+int cbam_bwd3_ok(const void* x, long x_bs, const void* dout, long dout_bs, const void* dpool, long dp_bs, int N, int C, int H,
+                 int W, int dt) {
+    const unsigned am = dt == SMAAT_BF16 ? 7u : 15u;
+    if (N < 1 || C < 1 || H < 1 || W < 1 || (((long)H * W) & 3)) return 0;
+    if (dpool && (H < 2 || (H & 1) || (W & 3))) return 0;
+    if ((x_bs & 3) || (dout_bs & 3) || (((uintptr_t)x) & am) || (((uintptr_t)dout) & am)) return 0;
+    if (dpool && ((dp_bs & 1) || (((uintptr_t)dpool) & (am >> 1)))) return 0;
+    if ((long)C * H * W * 4 >= (1L << 31)) return 0;  // dX goes through a 32-bit buffer offset (bit 31 = dropped)
+    return 1;
+}
+int launch_cbam_sppool_idx(const void* x, long x_bs, const float* s, int N, int C, int P, float* maps, int* amaxc,
+                           hipStream_t st, int dt) {
+    const unsigned am = dt == SMAAT_BF16 ? 7u : 15u;
+    if ((P & 3) || (x_bs & 3) || (((uintptr_t)x) & am) || (((uintptr_t)maps) & 15) || (((uintptr_t)amaxc) & 15)) return -2;
+    const int cs = cbam_chan_split(N, C, P);
+    SMAAT_DISPATCH_ET(dt, T,
+        hipLaunchKernelGGL(k_cbam_sppool_idx_v4<T>, dim3(cdivc(P, 256), N), dim3(64 * cs), cs > 1 ? (size_t)3 * cs * 64 * 16 : 0, st,
+                           (const T*)x, x_bs, s, C, P, maps, amaxc););
+    return (int)hipGetLastError();
+}
+int launch_cbam_bwd_gate_ds(const void* dout, long dout_bs, const void* x, long x_bs, const float* s, const float* gate,
+                            const float* conv, const float* mean, const float* invstd, int N, int C, int P, float* dbn,
+                            float* part, float* dspart, hipStream_t st, int dt) {
+    if ((P & 3) || (((uintptr_t)gate) & 15) || (((uintptr_t)conv) & 15) || (((uintptr_t)dbn) & 15)) return -2;
+    dim3 grid(cdivc(P, 256), N);
+    const int cs = cbam_chan_split(N, C, P);
+    SMAAT_DISPATCH_ET(dt, T,
+        hipLaunchKernelGGL(k_cbam_bwd_gate_ds_v4<T>, grid, dim3(64 * cs), cs > 1 ? (size_t)cs * 64 * 16 : 0, st, (const T*)dout,
+                           dout_bs, (const T*)x, x_bs, s, gate, conv, mean, invstd, C, P, dbn, part, (int)(grid.x * grid.y),
+                           dspart););
+    return (int)hipGetLastError();
+}
+int launch_cbam_bwd_ds2(const void* x, long x_bs, const float* dmaps, const int* amaxc, int N, int C, int P, float* dspart,
+                        hipStream_t st, int dt) {
+    if ((P & 3) || (((uintptr_t)dmaps) & 15) || (((uintptr_t)amaxc) & 15)) return -2;
+    const int cs = cbam_chan_split(N, C, P);
+    SMAAT_DISPATCH_ET(dt, T,
+        hipLaunchKernelGGL(k_cbam_bwd_ds2_v4<T>, dim3(cdivc(P, 256), N), dim3(64 * cs), 0, st, (const T*)x, x_bs, dmaps, amaxc, C, P,
+                           dspart););
+    return (int)hipGetLastError();
+}
+int launch_cbam_bwd_apply(const void* dout, long dout_bs, const void* x, long x_bs, const float* s, const float* gate,
+                          const float* dmaps, const int* amaxc, const float* davg, const float* dmx, const int* amax,
+                          const void* dpool, long dp_bs, int N, int C, int H, int W, void* dx, long dx_bs, hipStream_t st, int dt) {
+    const unsigned am = dt == SMAAT_BF16 ? 7u : 15u;
+    if (!cbam_bwd3_ok(x, x_bs, dout, dout_bs, dpool, dp_bs, N, C, H, W, dt) || (dx_bs & 3) || (((uintptr_t)dx) & am) ||
+        (((uintptr_t)gate) & 15) || (((uintptr_t)dmaps) & 15) || (((uintptr_t)amaxc) & 15))
+        return -2;
+    const int P = H * W;
+    const int cs = cbam_chan_split(N, C, P);
+    SMAAT_DISPATCH_ET(dt, T,
+        if (dpool)
+            hipLaunchKernelGGL((k_cbam_bwd_apply_v4<T, true>), dim3(cdivc((W >> 2) * (H >> 1), 64), N), dim3(64 * cs), 0, st,
+                               (const T*)dout, dout_bs, (const T*)x, x_bs, s, gate, dmaps, amaxc, davg, dmx, amax, (const T*)dpool,
+                               dp_bs, C, H, W, (T*)dx, dx_bs);
+        else
+            hipLaunchKernelGGL((k_cbam_bwd_apply_v4<T, false>), dim3(cdivc(P, 256), N), dim3(64 * cs), 0, st, (const T*)dout,
+                               dout_bs, (const T*)x, x_bs, s, gate, dmaps, amaxc, davg, dmx, amax, (const T*)nullptr, 0L, C, H, W,
+                               (T*)dx, dx_bs););
     return (int)hipGetLastError();
 }

@@ -1703,6 +1703,7 @@ def _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, 
     s_ = _stream(x)
     dev = x
     bf = _is_bf(x)  # mixed precision: x / out are bf16; the per-(n, c) vectors, maps and the gate stay f32
+    amaxc = None
     if use_ch:
         cr = w1.shape[0]
         w1 = w1.contiguous()
@@ -1753,7 +1754,18 @@ def _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, 
         wconv = wconv.contiguous()
         ks = wconv.shape[-1]
         maps = _new(dev, n, 2, h, w)
-        if bf:
+        rc = -2
+        if CBAM_THREE_PASS and use_ch:
+            # + the channel index of the per-pixel maximum, which lets the backward split the channels over waves
+            amaxc = _new(dev, n, h, w, dtype=torch.int32)
+            rc = L.smaat_cbam_sppool_idx_t(_ptr(x), x_bs, _ptr(sc), n, c, p, _ptr(maps), _ptr(amaxc), 1 if bf else 0, s_)
+            if rc == -2:
+                amaxc = None
+            else:
+                _lib.check(rc, "smaat_cbam_sppool_idx_t")
+        if rc == 0:
+            pass
+        elif bf:
             _lib.check(L.smaat_cbam_sppool_t(_ptr(x), x_bs, _ptr(sc), n, c, p, _ptr(maps), 1, s_), "smaat_cbam_sppool_t")
         else:
             _lib.check(L.smaat_cbam_sppool(_ptr(x), x_bs, _ptr(sc), n, c, p, _ptr(maps), s_), "smaat_cbam_sppool")
@@ -1787,8 +1799,30 @@ def _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, 
     else:
         _lib.check(L.smaat_cbam_apply(_ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(out), o_bs, n, c, p, s_),
                    "smaat_cbam_apply")
-    saved = (x, w1, w2, wconv, gamma, avg, mx, amax, ha, hm, sc, maps, conv, st, gate)
+    saved = (x, w1, w2, wconv, gamma, avg, mx, amax, ha, hm, sc, maps, conv, st, gate, amaxc)
     return out, saved, (use_ch, use_sp, use_batch_stats)
+
+
+CBAM_THREE_PASS = os.environ.get("SMAAT_CBAM_THREE_PASS", "1") != "0"  # (0: the gate / main / final sequence everywhere)
+
+
+def _cbam_mlp_backward(L, dev, ds, sc, avg, mx, ha, hm, w1, w2, n, c, s_):
+    """shared-MLP backward of the channel attention -> dw1, db1, dw2, db2, davg[n][c], dmx[n][c]"""
+    cr = w1.shape[0]
+    pgs = c * cr + c + cr * c + cr
+    pg = _new(dev, n, pgs)
+    davg = _new(dev, n, c)
+    dmx = _new(dev, n, c)
+    _lib.check(L.smaat_cbam_bwd_mlp(_ptr(ds), _ptr(sc), _ptr(avg), _ptr(mx), _ptr(ha), _ptr(hm), _ptr(w1),
+                                    _ptr(w2), n, c, cr, _ptr(pg), _ptr(davg), _ptr(dmx), s_),
+               "smaat_cbam_bwd_mlp")
+    pgr = _new(dev, pgs)
+    _lib.check(L.smaat_reduce_rows(_ptr(pg), n, pgs, _ptr(pgr), 1.0, s_), "smaat_reduce_rows")
+    dw2 = pgr[:c * cr].view(c, cr)
+    db2 = pgr[c * cr:c * cr + c]
+    dw1 = pgr[c * cr + c:c * cr + c + cr * c].view(cr, c)
+    db1 = pgr[c * cr + c + cr * c:]
+    return dw1, db1, dw2, db2, davg, dmx
 
 
 def _cbam_backward_impl(saved, flags, dout, pooled=None):
@@ -1797,7 +1831,7 @@ def _cbam_backward_impl(saved, flags, dout, pooled=None):
     MaxPool2d that reads x as well is added to dx (in the same pass as the channel-attention terms when the shape
     allows)."""
     L = _lib.get()
-    x, w1, w2, wconv, gamma, avg, mx, amax, ha, hm, sc, maps, conv, st, gate = saved
+    x, w1, w2, wconv, gamma, avg, mx, amax, ha, hm, sc, maps, conv, st, gate, amaxc = saved
     use_ch, use_sp, train_stats = flags
     x, x_bs = _planes(x)
     bf = _is_bf(x)
@@ -1809,12 +1843,29 @@ def _cbam_backward_impl(saved, flags, dout, pooled=None):
     s_ = _stream(x)
     dev = x
     dwconv = dgamma = dbeta = None
+    # both halves of the attention (+ the MaxPool2d that reads x too at the encoder levels): three passes that write dx once
+    # and split the channels over waves (csrc/cbam.hip, k_cbam_bwd_gate_ds_v4) when the forward left the channel index of
+    # the per-pixel maximum and shapes and alignments allow, else the gate / main / final sequence
+    three = False
+    dspart3 = None
+    if amaxc is not None and use_sp and use_ch:
+        dpl, dp_bs = pooled if pooled is not None else (None, 0)
+        if dpl is not None and dpl.dtype != x.dtype:
+            dpl, dp_bs = _planes(dpl.to(x.dtype))
+            pooled = (dpl, dp_bs)
+        three = L.smaat_cbam_bwd3_ok(_ptr(x), x_bs, _ptr(dout), do_bs, _ptr(dpl) if dpl is not None else None, dp_bs, n, c, h, w,
+                                     1 if bf else 0) == 1
     if use_sp:
         ks = wconv.shape[-1]
         nbp = L.smaat_cbam_pix_blocks(n, p)
         dbn = _new(dev, n, p)
         part = _new(dev, 2, nbp, 1)
-        if bf:
+        if three:
+            dspart3 = _new(dev, 2 * (nbp // n), n, c)  # [gate pass | ds2 pass][blocks per image][n][c]
+            _lib.check(L.smaat_cbam_bwd_gate_ds_t(_ptr(dout), do_bs, _ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(conv), _ptr(st[0]),
+                                                  _ptr(st[1]), n, c, p, _ptr(dbn), _ptr(part), _ptr(dspart3), 1 if bf else 0, s_),
+                       "smaat_cbam_bwd_gate_ds_t")
+        elif bf:
             _lib.check(L.smaat_cbam_bwd_gate_t(_ptr(dout), do_bs, _ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(conv),
                                                _ptr(st[0]), _ptr(st[1]), n, c, p, _ptr(dbn), _ptr(part), 1, s_),
                        "smaat_cbam_bwd_gate_t")
@@ -1845,6 +1896,19 @@ def _cbam_backward_impl(saved, flags, dout, pooled=None):
         dmaps = torch.zeros(n, 2, h, w, dtype=torch.float32, device=x.device)
     nbp = L.smaat_cbam_pix_blocks(n, p)
     dx = _new(dev, n, c, h, w, dtype=x.dtype)
+    if three:
+        per = nbp // n
+        dt = 1 if bf else 0
+        _lib.check(L.smaat_cbam_bwd_ds2_t(_ptr(x), x_bs, _ptr(dmaps), _ptr(amaxc), n, c, p, _ptr(dspart3[per:]), dt, s_),
+                   "smaat_cbam_bwd_ds2_t")
+        ds = _new(dev, n, c)
+        _lib.check(L.smaat_reduce_rows(_ptr(dspart3), 2 * per, n * c, _ptr(ds), 1.0, s_), "smaat_reduce_rows")
+        dw1, db1, dw2, db2, davg, dmx = _cbam_mlp_backward(L, dev, ds, sc, avg, mx, ha, hm, w1, w2, n, c, s_)
+        dpl, dp_bs = pooled if pooled is not None else (None, 0)
+        _lib.check(L.smaat_cbam_bwd_apply_t(_ptr(dout), do_bs, _ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(dmaps), _ptr(amaxc),
+                                            _ptr(davg), _ptr(dmx), _ptr(amax), _ptr(dpl) if dpl is not None else None, dp_bs,
+                                            n, c, h, w, _ptr(dx), c * p, dt, s_), "smaat_cbam_bwd_apply_t")
+        return dx, dw1, db1, dw2, db2, dwconv, dgamma, dbeta
     dspart = _new(dev, nbp, c)
     if bf:
         _lib.check(L.smaat_cbam_bwd_main_t(_ptr(dout), do_bs, _ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(maps),
@@ -1857,24 +1921,11 @@ def _cbam_backward_impl(saved, flags, dout, pooled=None):
     dw1 = db1 = dw2 = db2 = None
     pool_done = False
     if use_ch:
-        cr = w1.shape[0]
         per = nbp // n
         ds = _new(dev, n, c)
         # dspart is [per][n][c]: one deterministic row reduction
         _lib.check(L.smaat_reduce_rows(_ptr(dspart), per, n * c, _ptr(ds), 1.0, s_), "smaat_reduce_rows")
-        pgs = c * cr + c + cr * c + cr
-        pg = _new(dev, n, pgs)
-        davg = _new(dev, n, c)
-        dmx = _new(dev, n, c)
-        _lib.check(L.smaat_cbam_bwd_mlp(_ptr(ds), _ptr(sc), _ptr(avg), _ptr(mx), _ptr(ha), _ptr(hm), _ptr(w1),
-                                        _ptr(w2), n, c, cr, _ptr(pg), _ptr(davg), _ptr(dmx), s_),
-                   "smaat_cbam_bwd_mlp")
-        pgr = _new(dev, pgs)
-        _lib.check(L.smaat_reduce_rows(_ptr(pg), n, pgs, _ptr(pgr), 1.0, s_), "smaat_reduce_rows")
-        dw2 = pgr[:c * cr].view(c, cr)
-        db2 = pgr[c * cr:c * cr + c]
-        dw1 = pgr[c * cr + c:c * cr + c + cr * c].view(cr, c)
-        db1 = pgr[c * cr + c + cr * c:]
+        dw1, db1, dw2, db2, davg, dmx = _cbam_mlp_backward(L, dev, ds, sc, avg, mx, ha, hm, w1, w2, n, c, s_)
         rc = -2
         if pooled is not None:  # + the backward of the MaxPool2d that reads x too, in the same pass over dx
             dpl, dp_bs = pooled

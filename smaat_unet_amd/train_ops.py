@@ -188,14 +188,22 @@ def double_conv_ds(x, half1, half2, kpl):
 # --------------------------------------------------------------------------------------------------------------------
 # CBAM (+ MaxPool2d + concatenation buffer)
 # --------------------------------------------------------------------------------------------------------------------
-# ops._cbam_forward_impl saves (x, w1, w2, wconv, gamma, avg, mx, amax, ha, hm, sc, maps, conv, st, gate): the first five are
-# the operator's own inputs (an operator must not return its inputs), the other ten are returned and saved by the formula
+# ops._cbam_forward_impl saves (x, w1, w2, wconv, gamma, avg, mx, amax, ha, hm, sc, maps, conv, st, gate, amaxc): the first five
+# are the operator's own inputs (an operator must not return its inputs), the other eleven are returned and saved by the formula
+# (amaxc, the channel index map of the three-pass backward, is an empty int32 tensor when that route is off or not applicable)
+_N_CBAM_SAVED = 11
+
+
+def _cbam_has_index_map(h, w):
+    return ops.CBAM_THREE_PASS and (h * w) % 4 == 0
+
+
 def _cbam_fake_saved(x, w1):
     n, c, h, w = x.shape
     f = lambda *s: x.new_empty(s, dtype=torch.float32)  # noqa: E731
     cr = w1.shape[0]
     return [f(n, c), f(n, c), x.new_empty((n, c), dtype=torch.int32), f(n, cr), f(n, cr), f(n, c), f(n, 2, h, w), f(n, 1, h, w),
-            f(4, 1), f(n, 1, h, w)]
+            f(4, 1), f(n, 1, h, w), x.new_empty((n, h, w) if _cbam_has_index_map(h, w) else (0,), dtype=torch.int32)]
 
 
 @custom_op("smaat::cbam_pool_cat", mutates_args=())
@@ -203,7 +211,7 @@ def cbam_pool_cat_op(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, 
                      beta: Optional[Tensor], rm: Optional[Tensor], rv: Optional[Tensor], training: bool, momentum: float,
                      eps: float, c_extra: int, pool: bool) -> List[Tensor]:
     """-> [cat (CBAM(x) in channels [0, C) of a [N, C + c_extra, H, W] buffer), maxpool2(x) or empty, avg, mx, amax, ha, hm, sc,
-    maps, conv, st, gate, rm', rv']"""
+    maps, conv, st, gate, amaxc or empty, rm', rv']"""
     xx, x_bs = ops._planes(x)
     n, c, h, w = xx.shape
     rm, rv = (t.clone() if t is not None else None for t in (rm, rv))
@@ -211,7 +219,11 @@ def cbam_pool_cat_op(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, 
     _, saved, _ = ops._cbam_forward_impl(xx, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, _mo_back(momentum), eps, True,
                                          True, out=cat[:, :c], pool=(got := []) if pool else None)
     pooled = (got[0] if got else ops._maxpool2_fwd_raw(xx, x_bs)) if pool else _e(xx)
-    return [cat, pooled] + list(saved[5:]) + [t if (t is not None and training) else _e(xx) for t in (rm, rv)]
+    sv = list(saved[5:])
+    assert len(sv) == _N_CBAM_SAVED and (sv[-1] is not None) == _cbam_has_index_map(h, w)
+    if sv[-1] is None:
+        sv[-1] = xx.new_empty((0,), dtype=torch.int32)
+    return [cat, pooled] + sv + [t if (t is not None and training) else _e(xx) for t in (rm, rv)]
 
 
 @cbam_pool_cat_op.register_fake
@@ -227,6 +239,9 @@ def cbam_pool_cat_bwd_op(dcat: Tensor, dpooled: Tensor, x: Tensor, w1: Tensor, w
                          gamma: Optional[Tensor], saved: List[Tensor], train_stats: bool) -> List[Tensor]:
     """-> [dx, dw1, db1, dw2, db2, dwconv, dgamma, dbeta]"""
     c = x.shape[1]
+    saved = list(saved)
+    if saved[-1].numel() == 0:
+        saved[-1] = None  # (no channel index map: the gate / main / final sequence)
     sv = (ops._planes(x)[0], w1.contiguous(), w2.contiguous(), wconv.contiguous(), gamma) + tuple(saved)
     pooled = ops._planes(dpooled) if dpooled.numel() else None
     g = list(ops._cbam_backward_impl(sv, (True, True, train_stats), dcat[:, :c], pooled=pooled))
@@ -247,7 +262,7 @@ def _(dcat, dpooled, x, w1, w2, wconv, gamma, saved, train_stats):
 def _cpc_setup(ctx, inputs, output):
     x, w1, _b1, w2, _b2, wconv, gamma = inputs[:7]
     ctx.train_stats = bool(inputs[10] or inputs[8] is None)
-    ctx.save_for_backward(x, w1, w2, wconv, gamma, *output[2:12])
+    ctx.save_for_backward(x, w1, w2, wconv, gamma, *output[2:2 + _N_CBAM_SAVED])
 
 
 def _cpc_backward(ctx, *grads):
@@ -270,7 +285,7 @@ cbam_pool_cat_op.register_autograd(_cpc_backward, setup_context=_cpc_setup)
 def _cbam_call(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, c_extra, pool):
     r = torch.ops.smaat.cbam_pool_cat(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, _mo(momentum), eps, c_extra, pool)
     with torch.no_grad():
-        for buf, new in ((rm, r[12]), (rv, r[13])):
+        for buf, new in ((rm, r[2 + _N_CBAM_SAVED]), (rv, r[3 + _N_CBAM_SAVED])):
             if buf is not None and new.numel():
                 buf.copy_(new)
     return r

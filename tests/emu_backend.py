@@ -841,6 +841,57 @@ class EmuLib:
         self.smaat_cbam_bwd_final(dx, dx_bs, davg, dmx, amax, N, C, H * W, stream)
         return self.smaat_maxpool2_bwd(x, x_bs, dpool, dp_bs, dx, dx_bs, N, C, H, W, 1, stream)
 
+    # ---- the three-pass backward (csrc/cbam.hip, k_cbam_bwd_gate_ds_v4 ...) ----
+    def smaat_cbam_bwd3_ok(self, x, x_bs, dout, dout_bs, dpool, dp_bs, N, C, H, W, dt):
+        if (H * W) % 4 or x_bs % 4 or dout_bs % 4:
+            return 0
+        if dpool and (H < 2 or H % 2 or W % 4 or dp_bs % 2):
+            return 0
+        return 1
+
+    def _cbam_sppool_idx(self, x, x_bs, s, N, C, P, maps, amaxc, stream):
+        self.smaat_cbam_sppool(x, x_bs, s, N, C, P, maps, stream)
+        xs = planes(x, N, C, P, x_bs) * f32(s, N * C).reshape(N, C)[:, :, None]
+        i32(amaxc, N * P).reshape(N, P)[:] = np.argmax(xs, axis=1)  # (the first maximum)
+        return 0
+
+    def _cbam_bwd_gate_ds(self, dout, dout_bs, x, x_bs, s, gate, conv, mean, invstd, N, C, P, dbn, part, dspart, stream):
+        self.smaat_cbam_bwd_gate(dout, dout_bs, x, x_bs, s, gate, conv, mean, invstd, N, C, P, dbn, part, stream)
+        g = f32(gate, N * P).reshape(N, 1, P)
+        per = 3
+        dp = f32(dspart, per * N * C).reshape(per, N, C)
+        dp[:] = 0
+        dp[1] = ((planes(dout, N, C, P, dout_bs) * g).astype(np.float64) * planes(x, N, C, P, x_bs)).sum(axis=2)
+        return 0
+
+    def _cbam_bwd_ds2(self, x, x_bs, dmaps, amaxc, N, C, P, dspart, stream):
+        xv = planes(x, N, C, P, x_bs)
+        dmp = f32(dmaps, N * 2 * P).reshape(N, 2, P)
+        first = i32(amaxc, N * P).reshape(N, 1, P) == np.arange(C).reshape(1, C, 1)
+        e = dmp[:, 0:1] / np.float32(C) + first * dmp[:, 1:2]
+        per = 3
+        dp = f32(dspart, per * N * C).reshape(per, N, C)
+        dp[:] = 0
+        dp[1] = (e.astype(np.float64) * xv).sum(axis=2)
+        return 0
+
+    def _cbam_bwd_apply(self, dout, dout_bs, x, x_bs, s, gate, dmaps, amaxc, davg, dmx, amax, dpool, dp_bs, N, C, H, W, dx, dx_bs,
+                        stream):
+        P = H * W
+        if not self.smaat_cbam_bwd3_ok(x, x_bs, dout, dout_bs, dpool, dp_bs, N, C, H, W, 0):
+            return -2
+        sv = f32(s, N * C).reshape(N, C)
+        g = f32(gate, N * P).reshape(N, 1, P)
+        dmp = f32(dmaps, N * 2 * P).reshape(N, 2, P)
+        dxs = planes(dout, N, C, P, dout_bs) * g + dmp[:, 0:1] / np.float32(C)
+        first = i32(amaxc, N * P).reshape(N, 1, P) == np.arange(C).reshape(1, C, 1)
+        dxs = dxs + first * dmp[:, 1:2]
+        planes(dx, N, C, P, dx_bs)[:] = dxs * sv[:, :, None]
+        self.smaat_cbam_bwd_final(dx, dx_bs, davg, dmx, amax, N, C, P, stream)
+        if dpool:
+            return self.smaat_maxpool2_bwd(x, x_bs, dpool, dp_bs, dx, dx_bs, N, C, H, W, 1, stream)
+        return 0
+
     def smaat_cbam_bwd_final(self, dx, dx_bs, davg, dmx, amax, N, C, P, stream):
         d = planes(dx, N, C, P, dx_bs)
         d += (f32(davg, N * C).reshape(N, C) / np.float32(P))[:, :, None]
@@ -1143,6 +1194,41 @@ def _t_cbam_bwd_main(self, dout, dout_bs, x, x_bs, s, gate, maps, dmaps, N, C, P
     return rc
 
 
+def _t_cbam_bwd_gate_ds(self, dout, dout_bs, x, x_bs, s, gate, conv, mean, invstd, N, C, P, dbn, part, dspart, dt, stream):
+    if P % 4:
+        return -2
+    gi, xi = _TIn(dout, dt, N, C, P, dout_bs), _TIn(x, dt, N, C, P, x_bs)
+    return self._cbam_bwd_gate_ds(gi.ptr, gi.bs, xi.ptr, xi.bs, s, gate, conv, mean, invstd, N, C, P, dbn, part, dspart, stream)
+
+
+def _t_cbam_sppool_idx(self, x, x_bs, s, N, C, P, maps, amaxc, dt, stream):
+    if P % 4 or x_bs % 4:
+        return -2
+    xi = _TIn(x, dt, N, C, P, x_bs)
+    return self._cbam_sppool_idx(xi.ptr, xi.bs, s, N, C, P, maps, amaxc, stream)
+
+
+def _t_cbam_bwd_ds2(self, x, x_bs, dmaps, amaxc, N, C, P, dspart, dt, stream):
+    if P % 4:
+        return -2
+    xi = _TIn(x, dt, N, C, P, x_bs)
+    return self._cbam_bwd_ds2(xi.ptr, xi.bs, dmaps, amaxc, N, C, P, dspart, stream)
+
+
+def _t_cbam_bwd_apply(self, dout, dout_bs, x, x_bs, s, gate, dmaps, amaxc, davg, dmx, amax, dpool, dp_bs, N, C, H, W, dx, dx_bs, dt,
+                      stream):
+    if not self.smaat_cbam_bwd3_ok(x, x_bs, dout, dout_bs, dpool, dp_bs, N, C, H, W, dt):
+        return -2
+    gi, xi = _TIn(dout, dt, N, C, H * W, dout_bs), _TIn(x, dt, N, C, H * W, x_bs)
+    pi = _TIn(dpool, dt, N, C, (H // 2) * (W // 2), dp_bs) if dpool else None
+    o = _TOut(dx, dt, N, C, H * W, dx_bs)  # (one rounding of the complete gradient with bf16 storage)
+    rc = self._cbam_bwd_apply(gi.ptr, gi.bs, xi.ptr, xi.bs, s, gate, dmaps, amaxc, davg, dmx, amax, pi.ptr if pi else None,
+                              pi.bs if pi else 0, N, C, H, W, o.ptr, o.bs, stream)
+    if rc == 0:
+        o.commit()
+    return rc
+
+
 def _t_cbam_bwd_final(self, dx, dx_bs, davg, dmx, amax, N, C, P, dt, stream):
     o = _TOut(dx, dt, N, C, P, dx_bs, rmw=True)
     rc = self.smaat_cbam_bwd_final(o.ptr, o.bs, davg, dmx, amax, N, C, P, stream)
@@ -1270,7 +1356,9 @@ for _name, _fn in (("smaat_bf16_planes", _t_bf16_planes), ("smaat_pointwise_fwd_
                    ("smaat_cbam_chpool_t", _t_cbam_chpool), ("smaat_cbam_chpool_pool_t", _t_cbam_chpool_pool), ("smaat_cbam_sppool_t", _t_cbam_sppool),
                    ("smaat_cbam_apply_t", _t_cbam_apply), ("smaat_cbam_bwd_gate_t", _t_cbam_bwd_gate),
                    ("smaat_cbam_bwd_main_t", _t_cbam_bwd_main), ("smaat_cbam_bwd_final_t", _t_cbam_bwd_final),
-                   ("smaat_cbam_bwd_final_pool_t", _t_cbam_bwd_final_pool)):
+                   ("smaat_cbam_bwd_final_pool_t", _t_cbam_bwd_final_pool), ("smaat_cbam_bwd_gate_ds_t", _t_cbam_bwd_gate_ds),
+                   ("smaat_cbam_bwd_ds2_t", _t_cbam_bwd_ds2), ("smaat_cbam_bwd_apply_t", _t_cbam_bwd_apply),
+                   ("smaat_cbam_sppool_idx_t", _t_cbam_sppool_idx)):
     setattr(EmuLib, _name, _fn)
 
 

@@ -434,6 +434,51 @@ def test_cbam_chpool_pool_is_the_two_kernels(shape, dt):
     assert L.smaat_cbam_chpool_pool_t(P(xb), 72, None, None, None, 0, P(q), 18, 1, 2, 6, 6, P(a1), P(m1), P(i1), dt, S()) == -2
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 16, 24), (2, 33, 18, 20), (1, 256, 72, 72), (1, 5, 2, 4), (2, 512, 6, 8)])
+@pytest.mark.parametrize("pool", [True, False])
+def test_cbam_three_pass_backward_t(shape, pool):
+    """bf16 storage through the three-pass attention backward == the f32 kernels on the same (bf16-representable) values: dbn, the
+    BatchNorm partials and both sets of ds partials bit for bit, dx = the f32 dx rounded once"""
+    L = _lib.get()
+    N, C, H, W = shape
+    p, Ho, Wo = H * W, H // 2, W // 2
+    x32 = r16(torch.relu(rnd(1, N, C, H, W)))
+    dout32 = r16(rnd(4, N, C, H, W))
+    dpool32 = r16(rnd(10, N, C, Ho, Wo))
+    x, dout, dpool = x32.to(torch.bfloat16), dout32.to(torch.bfloat16), dpool32.to(torch.bfloat16)
+    s = torch.rand(N, C, device=DEV) * 0.7 + 0.2
+    gate = torch.rand(N, 1, H, W, device=DEV)
+    conv = rnd(5, N, 1, H, W)
+    mean, invstd = rnd(6, 1, scale=0.1), torch.rand(1, device=DEV) + 0.5
+    dmaps = rnd(7, N, 2, H, W, scale=0.1)
+    davg, dmx = rnd(8, N, C, scale=0.1), rnd(9, N, C, scale=0.1)
+    amax = torch.randint(0, p, (N, C), dtype=torch.int32, device=DEV)
+    nbp = L.smaat_cbam_pix_blocks(N, p)
+    per = nbp // N
+    out = []
+    for dt, xx, gg, pp, td in ((F32, x32, dout32, dpool32, torch.float32), (BF16, x, dout, dpool, torch.bfloat16)):
+        maps = torch.full((N, 2, H, W), float("nan"), device=DEV)
+        amaxc = torch.full((N, H, W), -1, dtype=torch.int32, device=DEV)
+        assert L.smaat_cbam_sppool_idx_t(P(xx), C * p, P(s), N, C, p, P(maps), P(amaxc), dt, S()) == 0
+        dbn, pa = torch.empty(N, p, device=DEV), torch.empty(2, nbp, 1, device=DEV)
+        dsp = torch.full((2 * per, N, C), float("nan"), device=DEV)
+        dx = torch.full((N, C, H, W), float("nan"), dtype=td, device=DEV)
+        assert L.smaat_cbam_bwd3_ok(P(xx), C * p, P(gg), C * p, P(pp) if pool else None, C * Ho * Wo if pool else 0, N, C, H, W, dt) == 1
+        assert L.smaat_cbam_bwd_gate_ds_t(P(gg), C * p, P(xx), C * p, P(s), P(gate), P(conv), P(mean), P(invstd), N, C, p, P(dbn),
+                                          P(pa), P(dsp), dt, S()) == 0
+        assert L.smaat_cbam_bwd_ds2_t(P(xx), C * p, P(dmaps), P(amaxc), N, C, p, dsp.data_ptr() + 4 * per * N * C, dt, S()) == 0
+        assert L.smaat_cbam_bwd_apply_t(P(gg), C * p, P(xx), C * p, P(s), P(gate), P(dmaps), P(amaxc), P(davg), P(dmx), P(amax),
+                                        P(pp) if pool else None, C * Ho * Wo if pool else 0, N, C, H, W, P(dx), C * p, dt, S()) == 0
+        out.append((dbn, pa, dsp, dx, maps, amaxc))
+    torch.cuda.synchronize()
+    (dbn0, pa0, dsp0, dx0, mp0, ix0), (dbn1, pa1, dsp1, dx1, mp1, ix1) = out
+    assert torch.equal(mp0, mp1) and torch.equal(ix0, ix1) and int(ix0.min()) >= 0
+    assert not bool(torch.isnan(dsp0).any()) and not bool(torch.isnan(dsp1).any())
+    assert torch.equal(dbn0, dbn1) and torch.equal(pa0, pa1)
+    assert torch.equal(dsp0, dsp1), (float((dsp0 - dsp1).abs().max()), float(dsp0.abs().max()))
+    same_as_rounded(dx1, dx0, "cbam_bwd_apply_pool_t")
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 16, 24), (2, 32, 18, 18), (1, 8, 9, 11)])
 def test_cbam_kernels_t(shape):
     L = _lib.get()

@@ -1,6 +1,8 @@
 """GPU: every C-ABI entry point of libsmaat_hip.so against its numpy emulation
 (tests/emu_backend.py, built on the oracle) on identical seeded inputs.
 Tolerance: rel-L2 <= 1e-5 (fp32, north_star asks 1e-4) unless stated."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1000,31 +1002,106 @@ def test_cbam_ks3():
     both(case_cbam, 2, 32, 10, 10, ks=3, tol=3e-5)
 
 
-@pytest.mark.parametrize("shape", [(32, 1024, 512, 18, 18), (4, 256, 128, 12, 12), (2, 512, 64, 16, 8)])
-def test_pointwise_fwd_split_k_training_form(shape):
-    """sliced GEMM with the statistics-emitting slice reduction (18 x 18 layers in training) against the un-sliced kernel"""
-    L, dev = _lib.get(), torch.device("cuda:0")
-    N, C, M, H, W = shape
-    p = H * W
-    x = T(rnd(1, N, C, H, W), dev)
-    w, b = T(rnd(2, M, C, scale=0.2), dev), T(rnd(3, M), dev)
-    cp = (C + 15) // 16 * 16
-    pl = torch.empty(3 * M * cp, dtype=torch.int16, device=dev)
-    assert L.smaat_split_planes(P(w), M, C, P(pl), stream(dev)) == 0
-    slots = L.smaat_pw_split_num_slots(N, H, W)
-    o0, o1 = torch.empty(N, M, H, W, device=dev), torch.full((N, M, H, W), float("nan"), device=dev)
-    p0, p1 = torch.empty(3, slots, M, device=dev), torch.full((3, slots, M), float("nan"), device=dev)
-    assert L.smaat_pointwise_fwd_split(P(x), C * p, P(pl), P(b), P(o0), M * p, P(p0), N, C, M, H, W, stream(dev)) == 0
-    S = max(2, L.smaat_pointwise_splitk_slices(N, C, M, H, W, 2048))
-    ws = torch.empty(N * S * M * p, device=dev)
-    assert L.smaat_pointwise_fwd_split_k(P(x), C * p, P(pl), P(b), P(o1), M * p, P(p1), P(ws), S, N, C, M, H, W, 0, stream(dev)) == 0
-    torch.cuda.synchronize()
-    assert rel(o1.cpu().numpy(), o0.cpu().numpy()) < 2e-6
-    n0, m0, v0 = part_stats(p0)
-    n1, m1, v1 = part_stats(p1)
-    assert torch.equal(n0, n1)
-    assert rel(m1.cpu().numpy(), m0.cpu().numpy()) < 1e-5 and rel(v1.cpu().numpy(), v0.cpu().numpy()) < 1e-5
-    if shape[0] == 32:
-        assert L.smaat_pointwise_splitk_slices(N, C, M, H, W, 2048) == 4   # 384 items -> 1536
-        assert L.smaat_pointwise_splitk_slices(N, C, M, H, W, 512) == 1    # the inference budget leaves it alone
-        assert L.smaat_pointwise_splitk_slices(32, 1024, 512, 36, 36, 2048) == 1  # 1408 items: the chip is full
+def case_cbam_three_pass(L, dev, N, C, H, W, pad_c=0, pool=True):
+    """the three-pass backward of a level's attention (gate + ds1 | ds2 | apply [+ pool]) against the gate / main /
+    final[_pool] sequence: with one wave per 256 pixels dbn and its BatchNorm partials bit for bit (channels split over
+    waves: up to the f32 summation order), ds up to the f32 summation order, and -- fed the SAME davg / dmx -- dx bit for
+    bit; the forward kernel's maps against smaat_cbam_sppool and its index map against the scan rule of
+    k_cbam_bwd_main.  x / dout are channel slices of wider buffers when pad_c > 0."""
+    Pn = H * W
+    s = stream(dev)
+    xw = T(np.maximum(rnd(1, N, C + pad_c, H, W), 0), dev)
+    dw = T(rnd(7, N, C + pad_c, H, W), dev)
+    x, dout = xw[:, pad_c:], dw[:, :C]
+    bs = (C + pad_c) * Pn
+    XP, DP = xw.data_ptr() + 4 * pad_c * Pn, dw.data_ptr()
+    sc = T(np.random.default_rng(2).uniform(0.2, 0.9, (N, C)).astype(np.float32), dev)
+    maps0 = torch.empty((N, 2, H, W), device=dev)
+    assert L.smaat_cbam_sppool(XP, bs, P(sc), N, C, Pn, P(maps0), s) == 0
+    maps = torch.full((N, 2, H, W), float("nan"), device=dev)
+    amaxc = torch.full((N, H, W), -1, dtype=torch.int32, device=dev)
+    assert L.smaat_cbam_sppool_idx_t(XP, bs, P(sc), N, C, Pn, P(maps), P(amaxc), 0, s) == 0
+    gate = T(np.random.default_rng(3).uniform(0.1, 0.9, (N, 1, H, W)).astype(np.float32), dev)
+    conv = T(rnd(5, N, 1, H, W), dev)
+    mean, invstd = T(rnd(6, 1, scale=0.1), dev), T(np.array([0.8], np.float32), dev)
+    dmaps = T(rnd(8, N, 2, H, W, scale=0.1), dev)
+    davg, dmx = T(rnd(9, N, C, scale=0.1), dev), T(rnd(10, N, C, scale=0.1), dev)
+    amax = T(np.random.default_rng(11).integers(0, Pn, (N, C)).astype(np.int32), dev)
+    Ho, Wo = H // 2, W // 2
+    dpool = T(rnd(12, N, C, Ho, Wo), dev) if pool else None
+    nbp = L.smaat_cbam_pix_blocks(N, Pn)
+    per = nbp // N
+    # ---- the sequence it replaces
+    dbn0, pa0 = torch.empty((N, Pn), device=dev), torch.empty((2, nbp, 1), device=dev)
+    assert L.smaat_cbam_bwd_gate(DP, bs, XP, bs, P(sc), P(gate), P(conv), P(mean), P(invstd), N, C, Pn, P(dbn0), P(pa0), s) == 0
+    dx0 = torch.full((N, C, H, W), float("nan"), device=dev)
+    dsp0 = torch.empty((nbp, C), device=dev)
+    assert L.smaat_cbam_bwd_main(DP, bs, XP, bs, P(sc), P(gate), P(maps0), P(dmaps), N, C, Pn, P(dx0), C * Pn, P(dsp0), s) == 0
+    if pool:
+        assert L.smaat_cbam_bwd_final_pool(P(dx0), C * Pn, P(davg), P(dmx), P(amax), XP, bs, P(dpool), C * Ho * Wo, N, C, H, W,
+                                           s) == 0
+    else:
+        assert L.smaat_cbam_bwd_final(P(dx0), C * Pn, P(davg), P(dmx), P(amax), N, C, Pn, s) == 0
+    # ---- three passes
+    assert L.smaat_cbam_bwd3_ok(XP, bs, DP, bs, P(dpool), C * Ho * Wo if pool else 0, N, C, H, W, 0) == 1
+    dbn1, pa1 = torch.empty((N, Pn), device=dev), torch.empty((2, nbp, 1), device=dev)
+    dsp = torch.full((2 * per, N, C), float("nan"), device=dev)
+    assert L.smaat_cbam_bwd_gate_ds_t(DP, bs, XP, bs, P(sc), P(gate), P(conv), P(mean), P(invstd), N, C, Pn, P(dbn1), P(pa1),
+                                      P(dsp), 0, s) == 0
+    assert L.smaat_cbam_bwd_ds2_t(XP, bs, P(dmaps), P(amaxc), N, C, Pn, dsp.data_ptr() + 4 * per * N * C, 0, s) == 0
+    dx1 = torch.full((N, C, H, W), float("nan"), device=dev)
+    assert L.smaat_cbam_bwd_apply_t(DP, bs, XP, bs, P(sc), P(gate), P(dmaps), P(amaxc), P(davg), P(dmx), P(amax), P(dpool),
+                                    C * Ho * Wo if pool else 0, N, C, H, W, P(dx1), C * Pn, 0, s) == 0
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    # the index map: the first channel whose x * s equals the maximum
+    xs = x * sc[:, :, None, None]
+    eq = xs == maps0[:, 1:2]
+    first = (eq & (eq.cumsum(1) == 1)).float().argmax(1)
+    assert torch.equal(amaxc.long(), first)
+    assert torch.equal(maps[:, 1], maps0[:, 1])
+    assert float((maps[:, 0] - maps0[:, 0]).abs().max()) <= 1e-6 * float(xs.abs().max())
+    assert torch.equal(dx0, dx1), float((dx0 - dx1).abs().max())
+    mag1 = (dout.abs() * x.abs() * sc[:, :, None, None]).sum(1).reshape(N, Pn)  # magnitudes of the terms of dgate[n][p]
+    assert bool(((dbn0 - dbn1).abs() <= 1e-6 * mag1 + 1e-30).all())
+    if os.environ.get("SMAAT_CBAM_CS", "") == "1":
+        assert torch.equal(dbn0, dbn1) and torch.equal(pa0, pa1) and torch.equal(maps, maps0)
+    ds0 = dsp0.view(per, N, C).double().sum(0)
+    ds1 = dsp.double().sum(0)
+    mag = ((dout.double().abs() * gate.double() + dmaps[:, 0:1].double().abs() / C + dmaps[:, 1:2].double().abs()) *
+           x.double().abs()).sum((2, 3))  # sum of the magnitudes of the terms of ds[n][c]
+    assert bool(((ds0 - ds1).abs() <= 2e-6 * mag + 1e-30).all()), float(((ds0 - ds1).abs() / (mag + 1e-30)).max())
+    return dict(dbn=dbn1, bsum=pa1.double().sum(1), ds=ds1.float(), dx=dx1, maps=maps, amaxc=amaxc.float())
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 10, 12), (2, 64, 4, 4), (3, 5, 8, 12), (2, 256, 72, 72), (1, 64, 288, 288),
+                                   (2, 7, 18, 20), (1, 3, 2, 4), (2, 512, 36, 36), (2, 130, 6, 8)])
+def test_cbam_three_pass_backward(shape):
+    both(case_cbam_three_pass, *shape, tol=3e-5)
+    both(case_cbam_three_pass, *shape, pad_c=3, tol=3e-5)
+    both(case_cbam_three_pass, *shape, pool=False, tol=3e-5)
+
+
+def test_cbam_three_pass_without_pooling_takes_any_plane_of_whole_float4():
+    both(case_cbam_three_pass, 2, 512, 18, 18, pool=False, tol=3e-5)   # the last level of the network
+    both(case_cbam_three_pass, 2, 96, 5, 12, pool=False, tol=3e-5)
+
+
+def test_cbam_three_pass_declines_shapes_it_does_not_take():
+    L = _lib.get()
+    x = torch.zeros(1, 2, 6, 6, device="cuda")
+    assert L.smaat_cbam_bwd3_ok(P(x), 72, P(x), 72, None, 0, 1, 2, 6, 6, 0) == 1      # no pooling: any plane of whole float4
+    assert L.smaat_cbam_bwd3_ok(P(x), 72, P(x), 72, P(x), 18, 1, 2, 6, 6, 0) == 0     # pooling: W % 4
+    x = torch.zeros(1, 2, 5, 8, device="cuda")
+    assert L.smaat_cbam_bwd3_ok(P(x), 80, P(x), 80, P(x), 16, 1, 2, 5, 8, 0) == 0     # pooling: odd H
+    x = torch.zeros(1, 2, 3, 5, device="cuda")
+    assert L.smaat_cbam_bwd3_ok(P(x), 30, P(x), 30, None, 0, 1, 2, 3, 5, 0) == 0      # H * W % 4
+    x = torch.zeros(1, 2, 4, 8, device="cuda")
+    assert L.smaat_cbam_bwd3_ok(P(x), 64, P(x), 64, P(x), 16, 1, 2, 4, 8, 0) == 1
+    assert L.smaat_cbam_bwd3_ok(P(x) + 4, 64, P(x), 64, None, 0, 1, 2, 4, 8, 0) == 0  # misaligned planes
+    dx = torch.zeros(1, 2, 6, 6, device="cuda")
+    f = torch.zeros(64, device="cuda")
+    i = torch.zeros(64, dtype=torch.int32, device="cuda")
+    assert L.smaat_cbam_bwd_apply_t(P(dx), 72, P(dx), 72, P(f), P(f), P(f), P(i), P(f), P(f), P(i), P(dx), 18, 1, 2, 6, 6, P(dx), 72,
+                                    0, 0) == -2
+    assert L.smaat_cbam_sppool_idx_t(P(dx), 30, P(f), 1, 2, 15, P(f), P(i), 0, 0) == -2

@@ -882,3 +882,35 @@ def test_f16_split_wiring_against_the_three_term_split(monkeypatch):
     # ITSELF (1 vs 8 threads) is 2.5e-3 ... 5.5e-3; the parity bounds proper are the golden tests, which run with
     # the split on.  This is a plumbing check: a wrong scale or a stale maximum word is an error of order one.
     assert rel(f1.numpy(), f0.numpy()) < 1e-2
+
+
+def test_attention_backward_three_pass_route(monkeypatch):
+    """round 5: the attention backward runs gate+ds | ds2 | apply (+ the MaxPool2d backward at the encoder levels, where the
+    level output feeds both) and writes dx once, on the channel index map the forward's pooling kernel leaves; same gradients
+    as the gate / main / final[_pool] sequence, which stays the route of shapes the kernels do not take"""
+    from smaat_unet_amd import ops as _ops
+    torch.manual_seed(3)
+    net = S.SmaAt_UNet(n_channels=4, n_classes=2, kernels_per_layer=2, reduction_ratio=4).train()
+    x = torch.randn(2, 4, 32, 32)
+
+    def run():
+        net.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        net(xi).square().sum().backward()
+        # (the biases in front of a train-mode BatchNorm have an analytically zero gradient: cancellation noise, not compared)
+        return [xi.grad.clone()] + [p.grad.clone() for k, p in net.named_parameters()
+                                    if not (".double_conv." in k and k.endswith(("depthwise.bias", "pointwise.bias")))]
+
+    assert _ops.CBAM_THREE_PASS
+    c3 = _recorded_calls(lambda: run())
+    g3 = run()
+    # 32 -> 16 -> 8 -> 4 -> 2: four pooled levels (even, W % 4 == 0 down to 4 x 4) and the last one, which nothing pools
+    assert c3.get("smaat_cbam_bwd_apply_t", 0) == 5 and c3.get("smaat_cbam_bwd_gate_ds_t", 0) == 5, c3
+    assert c3.get("smaat_cbam_bwd_ds2_t", 0) == 5 and c3.get("smaat_cbam_sppool_idx_t", 0) == 5, c3
+    assert "smaat_cbam_bwd_main" not in c3 and "smaat_cbam_bwd_final_pool" not in c3, c3  # (the emulation nests the old entries' twins)
+    monkeypatch.setattr(_ops, "CBAM_THREE_PASS", False)
+    c1 = _recorded_calls(lambda: run())
+    g1 = run()
+    assert "smaat_cbam_bwd_apply_t" not in c1 and "smaat_cbam_sppool_idx_t" not in c1 and c1.get("smaat_cbam_bwd_main", 0) == 5, c1
+    for a, b in zip(g3, g1):
+        assert rel(a.numpy(), b.numpy()) < 2e-6

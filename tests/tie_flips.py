@@ -54,16 +54,18 @@ def differing_decisions(a, b):
     return out
 
 
-def attribute(run, tie=2e-4):
-    """run(f16: bool, store) -> None or raises AssertionError (the bound check of the test, on a fresh model with the
-    two-term fp16 split allowed / forbidden; it must run its forward inside `record_pre_activations(store)`).
+def attribute(run, tie=2e-4, flag="F16_SPLIT"):
+    """run(on: bool, store) -> None or raises AssertionError (the bound check of the test, on a fresh model with the feature
+    named by `flag` -- a boolean switch of smaat_unet_amd.ops whose two settings differ at f32 round-off level: the two-term
+    fp16 split (default), or CBAM_THREE_PASS, whose kernels add the channels of the attention maps in another order -- on /
+    off; it must run its forward inside `record_pre_activations(store)`).
     Returns the list of tie flips when the violation of run(True) is attributable to them; raises otherwise."""
-    prev = ops.F16_SPLIT
+    prev = getattr(ops, flag)
     rec = {}
     err = {}
     try:
         for f16 in (True, False):
-            ops.F16_SPLIT = f16
+            setattr(ops, flag, f16)
             ops.invalidate_weight_images()
             rec[f16] = []
             try:
@@ -72,7 +74,7 @@ def attribute(run, tie=2e-4):
             except AssertionError as e:  # noqa: PERF203
                 err[f16] = e
     finally:
-        ops.F16_SPLIT = prev
+        setattr(ops, flag, prev)
         ops.invalidate_weight_images()
     if err[True] is None:
         return []
