@@ -89,3 +89,31 @@ def test_row_walking_kernels_do_not_drain_their_prefetch_queue():
                 seen += 1
                 assert n == 0, (fn, f"{n} full drains of the vector-memory counter inside a loop")
         assert seen >= 12, (src, seen)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc not available")
+def test_attention_backward_loops_keep_their_prefetch():
+    """Round 5: the channel loops of the three-pass attention backward (cbam.hip) are hand-pipelined -- the loads of the next two
+    channels are issued before the current two are processed.  The first form of k_cbam_bwd_apply_v4 issued a load BETWEEN the
+    stores of a trip, hipcc answered with `s_waitcnt vmcnt(0)` in the middle of the loop and the kernel ran at 3.4 TB/s instead of
+    5.  In the f32 instantiations that carry the step: no drained loop, and no vector load between the first and
+    the last store of the apply kernel's loop body."""
+    import re
+    spec = importlib.util.spec_from_file_location("asm_lint", os.path.join(ROOT, "scripts", "asm_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    asm = lint.compile_asm(os.path.join(ROOT, "smaat_unet_amd", "csrc", "cbam.hip"))
+    seen = 0
+    for fn, nloops, drains, nstore, serial in lint.analyse(asm):
+        if ("k_cbam_bwd_gate_ds_v4If" in fn or "k_cbam_bwd_ds2_v4If" in fn or "k_cbam_bwd_apply_v4IfLb1" in fn):
+            seen += 1
+            assert drains == 0, fn
+    assert seen == 3
+    name = [m for m in re.findall(r"^(_Z\w*k_cbam_bwd_apply_v4IfLb1\w*):", asm, re.M)][0]
+    body = asm[asm.index("\n" + name + ":"):]
+    body = body[:body.index("s_endpgm")]
+    loop = body[body.rindex(".LBB", 0, body.rindex("s_cbranch_scc")):body.rindex("s_cbranch_scc")]  # the last (main) loop
+    ops = [ln.split()[0] for ln in loop.splitlines() if re.match(r"\s*(global_load|buffer_load|buffer_store|global_store)", ln)]
+    stores = [i for i, o in enumerate(ops) if "store" in o]
+    assert len(stores) == 4, ops  # two channels x two rows
+    assert not any("load" in o for o in ops[stores[0]:stores[-1]]), ops
