@@ -3,6 +3,7 @@
 // models/layers.py:120,127 (biased variance for normalisation, unbiased into
 // running_var, momentum/eps from the module), nn.ReLU(inplace=True) :26,35.
 #include "common.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------
 // finalize forward statistics: per-tile partials part[3][T][C] = (mean_t, M2_t, n_t) of (z - shift_bias)
@@ -308,9 +309,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const TG* __restrict__ dy,
                                                       const float* __restrict__ invstd,
                                                       const float* __restrict__ coef, TD* __restrict__ dz,
                                                       long dz_bs, int C, int P, int seg_len,
-                                                      const float* __restrict__ hw, unsigned* __restrict__ amax) {
+                                                      const float* __restrict__ hw, unsigned* __restrict__ amax, int lin_nseg) {
     // amax (nullable): max |dz| over the whole tensor, for the two-term fp16 split GEMMs that read dz (common.h)
-    const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
+    // lin_nseg > 0: one-dimensional grid, workgroup b = segment b % lin_nseg of plane b / lin_nseg -- consecutive workgroups
+    // walk consecutive addresses (scripts/probes/stream_shape_probe.hip: 5.6-5.9 TB/s against 5.1 for the (planes, segments) grid)
+    const int plane = lin_nseg > 0 ? (int)(blockIdx.x / (unsigned)lin_nseg) : (int)blockIdx.x;
+    const int sgi = lin_nseg > 0 ? (int)(blockIdx.x - (unsigned)plane * (unsigned)lin_nseg) : (int)blockIdx.y;
+    const int n = plane / C, c = plane - n * C;
     const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
     const float c1 = coef[c], c2 = coef[C + c], c3 = coef[2 * C + c];
     float am = 0.f;
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const TG* __restrict__ dy,
     const TZ* zp = z + (long)n * z_bs + (long)c * P;
     const TG* gp = dy + (long)n * dy_bs + (HEAD ? 0L : (long)c * P);
     TD* op = dz + (long)n * dz_bs + (long)c * P;
-    const int p0 = blockIdx.y * seg_len;
+    const int p0 = sgi * seg_len;
     int p1 = p0 + seg_len;
     if (p1 > P) p1 = P;
     const bool vec = ((P & 3) == 0) && ((z_bs & 3) == 0) && ((dy_bs & 3) == 0) && ((dz_bs & 3) == 0) &&
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const TG* __restrict__ dy,
             st1(op + p, o);
         }
     }
-    if (amax) amax_publish_block256(amax, am, blockIdx.x * 5u + blockIdx.y, amred);  // (block-uniform branch)
+    if (amax) amax_publish_block256(amax, am, (unsigned)plane * 5u + (unsigned)sgi, amred);  // (block-uniform branch)
 }
 
 // ---------------------------------------------------------------------------------
@@ -527,11 +532,29 @@ int launch_bn_bwd_finalize(const float* part, int slots, int C, double count, co
 int launch_bn_bwd_apply(const void* dy, int dy_dt, long dy_bs, const void* z, int z_dt, long z_bs, const float* scale,
                         const float* shift, const float* mean, const float* invstd, const float* coef, void* dz, int dz_dt,
                         long dz_bs, int N, int C, int P, int relu, hipStream_t st, const float* hw, unsigned* amax) {
-    const int seg = plane_seg_len(P);
+    int seg = plane_seg_len(P);
     dim3 grid(N * C, cdiv(P, seg));
+    int lin = 0;
+    {
+        // Workgroups in ADDRESS ORDER, one float4 per thread, on the big f32 planes: 64 x 288^2 at batch 32 392 -> 340 us (5.2 ->
+        // 6.0 TB/s), 128 x 144^2 188 -> 176 us; 72^2 and below unchanged or slower (profiles/r5/bn_apply_grid_r5l.txt).  What the
+        // memory system sees is a window of a few MB sweeping through three tensors instead of ~16k concurrent 32 KB streams
+        // (scripts/probes/stream_shape_probe.hip).  SMAAT_BN_LIN=<0|1024|2048|...>: experiment switch (0: always the 2-D grid)
+        static int lin_seg = -1;
+        if (lin_seg < 0) {
+            const char* e = getenv("SMAAT_BN_LIN");
+            lin_seg = e ? atoi(e) : 1024;
+        }
+        const bool big_f32 = P >= 16384 && dy_dt == SMAAT_F32 && z_dt == SMAAT_F32 && dz_dt == SMAAT_F32;
+        if (big_f32 && lin_seg >= 1024 && (lin_seg & 1023) == 0 && (long)N * C * cdiv(P, lin_seg) < (1L << 31)) {
+            seg = lin_seg;
+            lin = cdiv(P, seg);
+            grid = dim3((unsigned)((long)N * C * lin), 1);
+        }
+    }
 #define BNA_GO(R, H, TG, TZ, TD)                                                                                        \
     hipLaunchKernelGGL((k_bn_bwd_apply<R, H, TG, TZ, TD>), grid, dim3(256), 0, st, (const TG*)dy, dy_bs, (const TZ*)z, z_bs,  \
-                       scale, shift, mean, invstd, coef, (TD*)dz, dz_bs, C, P, seg, hw, amax)
+                       scale, shift, mean, invstd, coef, (TD*)dz, dz_bs, C, P, seg, hw, amax, lin)
 #define BNA_T(TG, TZ, TD)                                                              \
     do {                                                                               \
         if (hw) {                                                                      \

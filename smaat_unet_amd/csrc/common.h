@@ -41,8 +41,29 @@ template <> struct Elem<bf16_t> {
     static constexpr unsigned vmask = 7;
     static constexpr int bytes = 2;
 };
-__device__ __forceinline__ float4 ldraw4(const float* p) { return *(const float4*)p; }
-__device__ __forceinline__ uint2 ldraw4(const bf16_t* p) { return *(const uint2*)p; }
+// SMAAT_NT (compile-time, experiment builds: scripts/build_nt_libs.sh): bit 0 = the 4-element streaming loads below carry the
+// non-temporal hint (`global_load_dwordx4 ... nt`), bit 1 = the 4-element streaming stores do
+#ifndef SMAAT_NT
+#define SMAAT_NT 0
+#endif
+typedef float smaat_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned smaat_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 ldraw4(const float* p) {
+#if SMAAT_NT & 1
+    const smaat_f32x4 v = __builtin_nontemporal_load((const smaat_f32x4*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *(const float4*)p;
+#endif
+}
+__device__ __forceinline__ uint2 ldraw4(const bf16_t* p) {
+#if SMAAT_NT & 1
+    const smaat_u32x2 v = __builtin_nontemporal_load((const smaat_u32x2*)p);
+    return make_uint2(v.x, v.y);
+#else
+    return *(const uint2*)p;
+#endif
+}
 __device__ __forceinline__ float ldraw1(const float* p) { return *p; }
 __device__ __forceinline__ unsigned ldraw1(const bf16_t* p) { return *p; }
 __device__ __forceinline__ float4 cvt4(const float4 v) { return v; }
@@ -51,8 +72,22 @@ __device__ __forceinline__ float cvt1(const float v) { return v; }
 __device__ __forceinline__ float cvt1(const unsigned v) { return bf16_lo(v); }
 template <typename T> __device__ __forceinline__ float4 ld4(const T* p) { return cvt4(ldraw4(p)); }
 template <typename T> __device__ __forceinline__ float ld1(const T* p) { return cvt1(ldraw1(p)); }
-__device__ __forceinline__ void st4(float* p, const float4 v) { *(float4*)p = v; }
-__device__ __forceinline__ void st4(bf16_t* p, const float4 v) { *(uint2*)p = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)); }
+__device__ __forceinline__ void st4(float* p, const float4 v) {
+#if SMAAT_NT & 2
+    const smaat_f32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, (smaat_f32x4*)p);
+#else
+    *(float4*)p = v;
+#endif
+}
+__device__ __forceinline__ void st4(bf16_t* p, const float4 v) {
+#if SMAAT_NT & 2
+    const smaat_u32x2 t = {pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+    __builtin_nontemporal_store(t, (smaat_u32x2*)p);
+#else
+    *(uint2*)p = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+#endif
+}
 __device__ __forceinline__ void st1(float* p, const float v) { *p = v; }
 __device__ __forceinline__ void st1(bf16_t* p, const float v) { *p = (bf16_t)(pack_bf16x2(v, 0.f) & 0xFFFFu); }
 __device__ __forceinline__ void st2(float* p, const float a, const float b) { *(float2*)p = make_float2(a, b); }
