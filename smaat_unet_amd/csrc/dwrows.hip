@@ -24,6 +24,8 @@
 
 #include "common.h"
 
+#define DW_LIN_MIN_PLANE 5184  // (72 x 72; see launch_dw3x3_fwd_rows)
+
 struct DwrGeom {
     int H, W, P, ncol4, nbands, BH, wpp;
     int seg, ppw;  // plane packing (small planes): a wave holds ppw = 64 / seg planes, one per segment of seg lanes
@@ -321,6 +323,76 @@ __global__ __launch_bounds__(256) void k_dw3x3_fwd_rows(const TX* __restrict__ x
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// forward, NOT walking (round 5): a lane owns ONE output position (row r, column group q) of its input channel, loads the
+// three window rows r - 1, r, r + 1 itself (float4 + the edge element each; the vertical re-use the walker keeps in
+// registers is left to L1 / L2) and stores its KPL output groups; waves in (plane, row, column group) order, so that what
+// the memory system sees is a window sweeping through x and y in address order instead of one 36-row stream per resident
+// wave.  As pure data movement that is 6.06 against 4.86 TB/s on the 64 x 288 x 288 shape (scripts/probes/
+// dw_shape_probe.hip).  Same window construction (dwr_finish) and the same tap order as k_dw3x3_fwd_rows: bit-identical y.
+// W % 4 == 0; a plane takes a whole number of waves (the channel, hence weights and coefficients, stay wave-uniform).
+// ---------------------------------------------------------------------------------------------------------------
+template <int KPL, typename TX, typename TY>
+__global__ __launch_bounds__(256) void k_dw3x3_fwd_lin(const TX* __restrict__ x, long x_bs, const float* __restrict__ w_dw,
+                                                        const float* __restrict__ b_dw, TY* __restrict__ y, long y_bs, int Cin,
+                                                        int nplanes, int H, int W, int wpp, const float* __restrict__ in_scale,
+                                                        const float* __restrict__ in_shift, unsigned* __restrict__ amax) {
+    __shared__ float amred[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const long gw = (long)blockIdx.x * 4 + (tid >> 6);
+    const int plane_ = (int)(gw / wpp);
+    const bool wave_on = plane_ < nplanes;
+    const int plane = __builtin_amdgcn_readfirstlane(wave_on ? plane_ : nplanes - 1);
+    const int wip = (int)(gw - (long)plane_ * wpp);
+    const int ncol4 = W >> 2, per = H * ncol4, P = H * W;
+    const int t_ = wip * 64 + lane;
+    const bool on = wave_on && t_ < per;
+    const int t = t_ < per ? t_ : per - 1;
+    const int r = t / ncol4, q = t - r * ncol4;
+    const int n = plane / Cin, ci = plane - n * Cin;
+    const TX* xp = x + (long)n * x_bs + (long)ci * P + 4 * q;
+    TY* yp = y + (long)n * y_bs + (long)(ci * KPL) * P + (long)r * W + 4 * q;
+    float wt[KPL][9], bs[KPL];
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wt[j][k] = w_dw[(ci * KPL + j) * 9 + k];
+        bs[j] = b_dw ? b_dw[ci * KPL + j] : 0.f;
+    }
+    const bool aff = in_scale != nullptr;
+    const float asc = aff ? in_scale[ci] : 1.f, ash = aff ? in_shift[ci] : 0.f;
+    const DwrLane ln = dwr_lane<false>(lane, q, ncol4);
+    DwrRaw<TX> ra = dwr_issue(xp, r - 1, H, W, ln), rb = dwr_issue(xp, r, H, W, ln), rc = dwr_issue(xp, r + 1, H, W, ln);
+    dwr_pin(ra);
+    dwr_pin(rb);
+    dwr_pin(rc);
+    float R0[6], R1[6], R2[6];
+    dwr_finish<false>(R0, ra, r - 1, H, ln, aff, asc, ash);
+    dwr_finish<false>(R1, rb, r, H, ln, aff, asc, ash);
+    dwr_finish<false>(R2, rc, r + 1, H, ln, aff, asc, ash);
+    float am = 0.f;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float acc = bs[j];  // (tap order of k_dw3x3_fwd_rows)
+#pragma unroll
+            for (int tc = 0; tc < 3; ++tc) acc = fmaf(wt[j][tc], R0[c + tc], acc);
+#pragma unroll
+            for (int tc = 0; tc < 3; ++tc) acc = fmaf(wt[j][3 + tc], R1[c + tc], acc);
+#pragma unroll
+            for (int tc = 0; tc < 3; ++tc) acc = fmaf(wt[j][6 + tc], R2[c + tc], acc);
+            o[c] = acc;
+        }
+        if (on) {
+            st4(yp + (long)j * P, make_float4(o[0], o[1], o[2], o[3]));
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+        }
+    }
+    if (amax) amax_publish_block256(amax, am, blockIdx.x, amred);  // (block-uniform branch; no wave has returned)
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // backward:
 //   dX[ci][q]        = sum_j sum_tap w[j][tap] * dY[ci*KPL + j][q - off(tap)]
 //   part[n][k][tap]  = sum_q xact[ci][q] * dY[k][q - off(tap)]      (tap < 9),   part[n][k][9] = sum_q dY[k][q]
@@ -534,6 +606,36 @@ int launch_dw3x3_fwd_rows(const void* x, int x_dt, long x_bs, const float* w_dw,
     const DwrGeom g = dw_rows_geom(N, Cin, H, W);
     if (g.wpp == 0) return -2;
     const bool pack = g.ppw > 1;
+    {
+        // the non-walking form on the planes where it was measured faster (profiles/r5/dw_fwd_lin_r5o.txt); SMAAT_DW_LIN=0 / 1:
+        // never / wherever it applies (read at every call: A/B and bit-equality tests in one process)
+        const char* e = getenv("SMAAT_DW_LIN");
+        const int mode = e ? atoi(e) : 2;
+        const bool can = (W & 3) == 0 && !pack && (kpl == 1 || kpl == 2) && H >= 2;
+        // (default: f32 storage from 72 x 72 up -- step 29.00 -> 28.66 ms; mixed precision at batch 64 measured 0.8 % SLOWER
+        // with it, 32.04 -> 32.31 ms, and keeps the walker: profiles/r5/bench_ab_dw_fwd_lin_r5p.txt)
+        const bool want = mode == 1 || (mode == 2 && (long)H * W >= DW_LIN_MIN_PLANE && x_dt == SMAAT_F32 && y_dt == SMAAT_F32);
+        if (can && want) {
+            const int wpp = (H * (W >> 2) + 63) / 64;
+            const long nw = (long)nplanes * wpp;
+            const dim3 grid((unsigned)((nw + 3) / 4)), blk(256);
+#define DWL_GO(K, TX, TY)                                                                                                  \
+    hipLaunchKernelGGL((k_dw3x3_fwd_lin<K, TX, TY>), grid, blk, 0, st, (const TX*)x, x_bs, w_dw, b_dw, (TY*)y, y_bs, Cin, nplanes, \
+                       H, W, wpp, in_scale, in_shift, amax)
+#define DWL_K(TX, TY)                       \
+    do {                                    \
+        if (kpl == 1) DWL_GO(1, TX, TY);    \
+        else DWL_GO(2, TX, TY);             \
+    } while (0)
+            if (x_dt == SMAAT_F32 && y_dt == SMAAT_F32) DWL_K(float, float);
+            else if (x_dt == SMAAT_F32 && y_dt == SMAAT_BF16) DWL_K(float, bf16_t);
+            else if (x_dt == SMAAT_BF16 && y_dt == SMAAT_BF16) DWL_K(bf16_t, bf16_t);
+            else return -2;
+#undef DWL_K
+#undef DWL_GO
+            return (int)hipGetLastError();
+        }
+    }
     const long nwaves = pack ? (long)((N + g.ppw - 1) / g.ppw) * Cin : (long)nplanes * g.wpp;
     const dim3 grid((unsigned)((nwaves + 3) / 4)), blk(256);
     const bool part = (W & 3) != 0;

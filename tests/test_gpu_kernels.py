@@ -517,6 +517,55 @@ def test_dw3x3_fwd(shape):
     both(case_dw_fwd, *shape, aff=True)
 
 
+@pytest.mark.parametrize("shape", [(2, 5, 1, 8, 8), (2, 8, 2, 36, 36), (2, 4, 2, 144, 144), (1, 3, 2, 288, 288), (1, 3, 2, 4, 4),
+                                   (2, 4, 2, 72, 72), (1, 5, 2, 10, 12), (1, 2, 2, 50, 64), (1, 2, 1, 21, 48), (1, 2, 2, 3, 4),
+                                   (1, 2, 2, 2, 8), (3, 64, 2, 16, 16), (2, 33, 2, 32, 24), (1, 3, 2, 64, 160)])
+@pytest.mark.parametrize("aff", [False, True])
+def test_dw3x3_fwd_not_walking_is_the_walker_bit_for_bit(shape, aff, monkeypatch):
+    """round 5: k_dw3x3_fwd_lin (a lane owns one output position and loads its three window rows itself; waves in address
+    order) against k_dw3x3_fwd_rows (a lane walks down a band with the window in registers): the same window construction and
+    tap order, so y and the published maximum must agree bit for bit -- f32 and bf16 storage, x a channel slice of a wider
+    buffer, every plane size the launcher would give either kernel (SMAAT_DW_LIN=1 forces the new one wherever it applies)."""
+    L, dev = _lib.get(), torch.device("cuda:0")
+    N, Cin, kpl, H, W = shape
+    K, pad_c = Cin * kpl, 3
+    xfull = T(rnd(1, N, Cin + pad_c, H, W), dev)
+    w_dw, b_dw = T(rnd(2, K, 9, scale=0.3), dev), T(rnd(3, K, scale=0.3), dev)
+    sc = T(np.random.default_rng(6).uniform(0.5, 1.5, Cin).astype(np.float32), dev) if aff else None
+    sh = T(rnd(7, Cin, scale=0.3), dev) if aff else None
+    for xdt, ydt in ((0, 0), (1, 1), (0, 1)):
+        xs = xfull if xdt == 0 else xfull.to(torch.bfloat16)
+        es = 4 if xdt == 0 else 2
+        out = []
+        for mode in ("0", "1"):
+            monkeypatch.setenv("SMAAT_DW_LIN", mode)
+            y = torch.full((N, K, H, W), float("nan"), dtype=torch.float32 if ydt == 0 else torch.bfloat16, device=dev)
+            rc = L.smaat_dw3x3_fwd_t(xs.data_ptr() + es * pad_c * H * W, xdt, (Cin + pad_c) * H * W, P(sc), P(sh), P(w_dw), P(b_dw),
+                                     P(y), ydt, K * H * W, N, Cin, kpl, H, W, stream(dev))
+            am = None
+            if xdt == 0 and ydt == 0 and rc == 0:
+                am = torch.zeros(1024, dtype=torch.int32, device=dev)
+                y2 = torch.full((N, K, H, W), float("nan"), device=dev)
+                rc2 = L.smaat_dw3x3_fwd_amax(xs.data_ptr() + es * pad_c * H * W, (Cin + pad_c) * H * W, P(sc), P(sh), P(w_dw), P(b_dw),
+                                             P(y2), K * H * W, P(am), N, Cin, kpl, H, W, stream(dev))
+                if rc2 == 0:
+                    torch.cuda.synchronize()
+                    assert torch.equal(y, y2)
+                    assert int(am.max()) == int(y2.abs().max().view(torch.int32))
+                else:
+                    assert rc2 == -2
+                    am = None
+            torch.cuda.synchronize()
+            out.append((rc, y, None if am is None else int(am.max())))
+        assert out[0][0] == out[1][0]
+        if out[0][0] == 0:
+            assert torch.equal(out[0][1].view(torch.int16 if ydt else torch.int32), out[1][1].view(torch.int16 if ydt else torch.int32))
+            assert not bool(torch.isnan(out[1][1].float()).any())
+            assert out[0][2] == out[1][2]
+        else:
+            assert out[0][0] == -2
+
+
 def case_dw_bwd_bnred(L, dev, N, Cin, kpl, H, W, gamma_mode="normal"):
     """x = the PRE-BatchNorm tensor z; y = relu(z*sc + sh) is recomputed on load and the kernel also reduces that
     BatchNorm's backward sums with zhat = (z - mean) * invstd (valid for gamma == 0 / tiny gamma)"""
