@@ -639,8 +639,9 @@ def main():
             klass(["smaat_dw3x3_bwd", "smaat_dw3x3_bwd_bnred"], "hbm", PEAK_HBM_GBS, "GB/s", 1.0,
                   "k_dw3x3_bwd_rows (register row-streaming depthwise backward, + the fused BatchNorm reduction)",
                   pmc=("k_dw3x3_bwd",), peak_name=HBM),
-            klass(["smaat_dw3x3_fwd", "smaat_dw3x3_fwd_amax"], "hbm", PEAK_HBM_GBS, "GB/s", 1.0, "k_dw3x3_fwd_rows (register "
-                  "row-streaming depthwise forward; _amax: + the maximum of its output for the fp16 split)", pmc=("k_dw3x3_fwd",),
+            klass(["smaat_dw3x3_fwd", "smaat_dw3x3_fwd_amax"], "hbm", PEAK_HBM_GBS, "GB/s", 1.0, "k_dw3x3_fwd_lin (one output "
+                  "position per lane, waves in address order: f32 planes of 72 x 72 and more) / k_dw3x3_fwd_rows (register row-streaming "
+                  "walker: the smaller planes); _amax: + the maximum of the output for the fp16 split", pmc=("k_dw3x3_fwd",),
                   peak_name=HBM),
             klass(["smaat_bn_bwd_apply", "smaat_bn_bwd_apply_amax", "smaat_bn_bwd_reduce", "smaat_affine_act"], "hbm", PEAK_HBM_GBS,
                   "GB/s", 1.0,
