@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""ISA edits for scripts/probes/r6_asm_variant.sh: argv = in.s out.s tag.  The tag names the edit:
+  same            no change (control: the assemble-and-bundle pipeline reproduces the compiler's own object)
+  vgpr136_<sub>   kernels whose mangled name contains <sub>: .amdhsa_next_free_vgpr / .amdhsa_accum_offset -> 136 (three waves
+                  per SIMD, the allocation of the failing build, code unchanged)
+  drain_<sub>     s_waitcnt vmcnt(0) after every inline-asm load of those kernels (nothing stays in flight)
+  drainset_<sub>  s_waitcnt vmcnt(0) after every THIRD inline-asm load (= after a whole set: x row, edge, dz)
+  nopmov_<sub>    s_nop 1 in front of every v_mov_b64 of those kernels (two wait states between a 32-bit VALU write of one half of
+                  a register pair and the 64-bit move that reads the pair)
+  splitmov_<sub>  every v_mov_b64 vD[a:a+1], vS[b:b+1] replaced by two v_mov_b32 (no 64-bit move left; same wait states as the
+                  original sequence otherwise)
+"""
+import re
+import sys
+
+src, dst, tag = sys.argv[1:4]
+kind, _, sub = tag.partition("_")
+sub = {"scalar": "ILi2ELb1ELb0EffLb0", "packed": "ILi2ELb1ELb1EffLb0"}.get(sub.split("_")[-1], sub)
+lines = open(src).read().split("\n")
+out, cur, in_kernel_meta, nload = [], None, None, 0
+for ln in lines:
+    m = re.match(r"^(_Z\w+):", ln)
+    if m:
+        cur, nload = m.group(1), 0
+    m = re.match(r"\s*\.amdhsa_kernel (\S+)", ln)
+    if m:
+        in_kernel_meta = m.group(1)
+    if ".end_amdhsa_kernel" in ln:
+        in_kernel_meta = None
+    if kind == "vgpr136" and in_kernel_meta and sub in in_kernel_meta:
+        ln = re.sub(r"(\.amdhsa_next_free_vgpr|\.amdhsa_accum_offset) \d+", r"\1 136", ln)
+    mm = re.match(r"(\s*)v_mov_b64_e32 v\[(\d+):(\d+)\], v\[(\d+):(\d+)\]\s*$", ln.split(";")[0].rstrip())
+    if mm and cur and sub in cur and kind == "nopmov":
+        out.append("\ts_nop 1")
+    if mm and cur and sub in cur and kind == "splitmov":
+        d0, s0 = int(mm.group(2)), int(mm.group(4))
+        # (order: a pair may overlap its source shifted by one register)
+        if d0 == s0 + 1:
+            out += [f"\tv_mov_b32_e32 v{d0 + 1}, v{s0 + 1}", f"\tv_mov_b32_e32 v{d0}, v{s0}"]
+        else:
+            out += [f"\tv_mov_b32_e32 v{d0}, v{s0}", f"\tv_mov_b32_e32 v{d0 + 1}, v{s0 + 1}"]
+        continue
+    out.append(ln)
+    if kind in ("drain", "drainset") and cur and sub in cur and ln.strip().startswith(";;#ASMEND") and len(out) >= 2 and "global_load" in out[-2]:
+        nload += 1
+        if kind == "drain" or nload % 3 == 0:
+            out.append("\ts_waitcnt vmcnt(0)")
+open(dst, "w").write("\n".join(out))

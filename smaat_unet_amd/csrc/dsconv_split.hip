@@ -67,7 +67,9 @@ typedef unsigned dss_u32x4 __attribute__((ext_vector_type(4)));
 // free on both LDS sides).  1: a half wave covers one full tile row of one channel, so that the side output y_out is
 // written as whole 128-B (4 x 32 tile) / 64-B (8 x 16 tile) runs; the bf16 image writes then conflict 2-way.
 template <int TWL, int NT, bool AFF, bool YOUT, bool ROWMAP>
-__global__ __launch_bounds__(512, 4) void k_dsconv_split(const DsSplitArgs a) {
+// (bf16-operand builds with the activation on load: at 128 VGPRs hipcc spills PREFETCHED registers -- scratch stores of load
+// destinations still in flight, scripts/isa_hazards.py; they get the 256-register budget: two workgroups per CU instead of four)
+__global__ __launch_bounds__(512, (NT == 1 && AFF) ? 2 : 4) void k_dsconv_split(const DsSplitArgs a) {
     constexpr int DSS_CSTRIDE = DSS_CSTRIDE_OF(TWL, ROWMAP);
     constexpr int KPL = 2, KC = 16, KCI = KC / KPL;
     constexpr int CT = 2, WPX = 4, PXT = 1;
@@ -106,6 +108,8 @@ __global__ __launch_bounds__(512, 4) void k_dsconv_split(const DsSplitArgs a) {
     const int r0 = ty * TH, c0 = tx * TW;
     const int co0 = cot * COT;
     const int nchunks = (a.Kdim + KC - 1) / KC;
+    constexpr int PD = 3;                                   // load groups in flight per producer thread
+    const int nch_pad = (nchunks + PD - 1) / PD * PD;       // barriers of the chunk loop (producers and consumers alike)
     const float* xn = a.x + (long)n * a.x_bs;
     if (tid < COT) {
         const int m = co0 + tid;
@@ -179,7 +183,6 @@ __global__ __launch_bounds__(512, 4) void k_dsconv_split(const DsSplitArgs a) {
         const int dwmul = (dwt < 9) ? 9 : 1, dwadd = (dwt < 9) ? dwt : 0;
         const bool dwvalid = (dwk < KC) && (dwt < 9 || (dwt == 9 && a.b_dw != nullptr));
         // ---- load groups: PD register sets in flight, inline-asm loads, counted waits ----
-        constexpr int PD = 3;
         constexpr int LPC = NSL + 1 + NAT;                       // loads per group
         constexpr int SPC = YOUT ? 8 : 0;                        // side-output stores per iteration (also count in vmcnt)
         constexpr int WAITN = SPC + (PD - 1) * (LPC + SPC);      // younger operations when a group is consumed
@@ -344,21 +347,22 @@ __global__ __launch_bounds__(512, 4) void k_dsconv_split(const DsSplitArgs a) {
             store_b(1, 1, x1, d1);
             __syncthreads();
         }
-        for (int i0 = 0; i0 < nchunks; i0 += PD) {
+        // The chunk loop runs over nchunks rounded up to a multiple of PD with every slot of the unrolled body unconditional:
+        // a surplus iteration waits for its group, stages clamped (valid) data into buffers nobody reads any more and issues its
+        // side-output stores out of range (dropped by the descriptor) -- the operation counts the hand-counted waits rely on
+        // hold on EVERY path of the control-flow graph, which scripts/isa_hazards.py proves on the generated ISA (round 6).
+        for (int i0 = 0; i0 < nch_pad; i0 += PD) {
 #pragma unroll
             for (int u = 0; u < PD; ++u) {
                 const int i = i0 + u;
-                if (i < nchunks) {
-                    if (i + 1 < nchunks) {
-                        const int nb = (i + 1) & 1;
-                        wait_set(u);                       // group i: its loads were issued PD iterations ago
-                        store_a(nb, sa[u]);                // A(i + 1)
-                        store_b(i + 2, i & 1, sx[u], sdw[u]);  // S(i + 2)
-                        issue(i + PD, u);
-                        dwstage(i + 1, nb);
-                    }
-                    __syncthreads();
-                }
+                const int nb = (i + 1) & 1;
+                wait_set(u);                       // group i: its loads were issued PD iterations ago
+                store_a(nb, sa[u]);                // A(i + 1)
+                store_b(i + 2, i & 1, sx[u], sdw[u]);  // S(i + 2)
+                issue(i + PD, u);
+                dwstage(i + 1, nb);
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);  // slots stay apart (interleaved, the unconditional body spilled 6 registers)
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus groups of the tail still target live registers
@@ -394,6 +398,7 @@ __global__ __launch_bounds__(512, 4) void k_dsconv_split(const DsSplitArgs a) {
             }
             __syncthreads();
         }
+        for (int i = nchunks; i < nch_pad; ++i) __syncthreads();  // the producers' surplus iterations
         // ---- epilogue: bias + row stores (a wave's 32 pixels are one or two full tile rows), BatchNorm partials ----
         const int off = pixoff[wpx * 32 + l31];
         float* obase = a.out + (long)n * a.out_bs;

@@ -91,7 +91,10 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
     constexpr int BUFSZ = NT * BPL;
     constexpr int KSH = 4 * CPT;             // contraction steps per consumer wave (half of KMAX / 16)
     constexpr bool A3L = NT == 3 && CPT == 2;  // third weight plane in LDS (see the consumer prologue)
-    constexpr int PD = sizeof(TX) == 2 ? 8 : 4;  // rows in flight per producer thread (bf16: half the bytes per row, see dswgrad.hip)
+    // rows in flight per producer thread: bf16 halves the bytes per row (dswgrad.hip), two channels per thread double them again.
+    // (Eight sets of two channels are 48 VGPRs of destinations: hipcc then SPILLS prefetched registers -- a scratch store of a
+    // register whose load has not landed, reloaded later as if it held the row: caught by scripts/isa_hazards.py, round 6)
+    constexpr int PD = (sizeof(TX) == 2 && CPT == 1) ? 8 : ((NT == 1 && CPT == 2 && sizeof(TX) == 4) ? 3 : 4);  // (bf16-operand f32-x builds with two channels: a fourth set spills)
     constexpr int LPG = 2 * CPT;             // loads per group and producer thread: row piece + edge element per channel
     static_assert((PD - 1) * LPG <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -131,6 +134,7 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
     };
     int total = 0;
     for (int i = 0; i < nitems; ++i) total += item_rows(it_lo + i * it_st) + 2;  // rows + 2 priming iterations per item
+    const int total_pad = (total + PD - 1) / PD * PD;
 
     if (producer) {
         const int ptid = tid - 256;
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
         float yam = 0.f;  // running max |y| of this thread (published once, at the end of the walk, when a.y_amax is given)
         // B image address of this thread: pixel 4g + i, dword (ci + 64 u) ^ 8 (g >> 2)  (swizzle: conflict-free writes)
         const int bsw = (g >> 2) << 3;
-        auto commit = [&](int set, int buf) __attribute__((always_inline)) {
+        auto commit = [&](int set, int buf, bool live) __attribute__((always_inline)) {
             ++c_j;
             if (c_j >= c_len) {
                 c_item += it_st;
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
                 for (int c = 0; c < 4; ++c) win[u][2][1 + c] = rv ? m[c] : 0.f;
                 win[u][2][5] = rvv ? r : 0.f;
             }
-            if (c_j < 2) return;  // priming iteration
+            if (c_j < 2 || !live) return;  // priming iteration / surplus iteration of the padded walk (no chunk, no maximum)
             unsigned char* base = lds + buf * BUFSZ;
 #pragma unroll
             for (int u = 0; u < CPT; ++u) {
@@ -331,22 +335,18 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
 #pragma unroll
             for (int s_ = 0; s_ < PD; ++s_) issue(s_);
             wait_set(0);
-            commit(0, 0);
+            commit(0, 0, true);
             issue(0);
         }
         __syncthreads();
-        for (int t0 = 0; t0 < total; t0 += PD) {
+        // padded walk, every slot unconditional (dswgrad.hip: the shape scripts/isa_hazards.py can prove)
+        for (int t0 = 0; t0 < total_pad; t0 += PD) {
 #pragma unroll
             for (int u = 0; u < PD; ++u) {
-                const int t = t0 + u;
-                if (t < total) {
-                    if (t + 1 < total) {
-                        wait_set((u + 1) % PD);
-                        commit((u + 1) % PD, (t + 1) & 1);
-                        issue((u + 1) % PD);
-                    }
-                    if constexpr ((DSR_DBG & 16) == 0) __syncthreads();
-                }
+                wait_set((u + 1) % PD);
+                commit((u + 1) % PD, (t0 + u + 1) & 1, t0 + u + 1 < total);
+                issue((u + 1) % PD);
+                if constexpr ((DSR_DBG & 16) == 0) __syncthreads();
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -555,6 +555,8 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
         }
         if (pend) finish();
         if (nitems > 0) flush_stats(it_hi - it_st);
+        if constexpr ((DSR_DBG & 16) == 0)
+            for (int t = total; t < total_pad; ++t) __syncthreads();  // the barriers of the producers' surplus iterations
     }
 }
 

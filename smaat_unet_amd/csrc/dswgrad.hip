@@ -114,18 +114,15 @@ __device__ __forceinline__ void dwg_vals(const dwg_u32x2 v, float (&m)[4]) {
 
 // TX / TG: storage types of x and dz (float | bf16).  bf16 dz (mixed precision, NT = 1) is the MFMA operand as it lies in
 // memory: its pieces go to the A image unconverted.
-// W2: TWO workgroups per CU (bf16 storage: 30 KB of LDS each).  The two barrier domains are independent: while the 12 waves of
-// one workgroup meet at their per-chunk barrier the other workgroup's producers keep the VALU busy.  Needs <= 80 VGPRs (six
-// waves per SIMD): four rows of loads in flight per thread instead of eight (the same bytes in flight per CU).
-template <int NT, bool AFF, bool PK, typename TX, typename TG, bool W2 = false>
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(W2 ? 6 : 3, W2 ? 6 : 8))) void k_dsconv_wgrad_split(const DsWgArgs a) {
+template <int NT, bool AFF, bool PK, typename TX, typename TG>
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_dsconv_wgrad_split(const DsWgArgs a) {
     static_assert(sizeof(TG) == 4 || NT == 1, "bf16 gradients are plain bf16 operands");
     constexpr int MT = 64, KT = 128, ROWS = MT + KT;
     constexpr int PLSZ = ROWS * DWG_SROW, BUFSZ = NT * PLSZ;
     // load groups (rows) in flight per producer thread.  bf16 storage halves the bytes per row AND the iteration time
     // (one MFMA per product, no operand split), so four rows ahead are only ~9 MB in flight on the chip: measured latency-
     // bound (2.2 TB/s); eight rows restore the f32 build's bytes in flight
-    constexpr int PD = (sizeof(TX) == 2 && !W2) ? 8 : 4;
+    constexpr int PD = sizeof(TX) == 2 ? 8 : 4;
     constexpr int LPG = 3;       // loads per group: x row = dwordx4 + one edge dword, dz = dwordx4
     static_assert((PD - 1) * LPG <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -169,6 +166,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(W2 ? 6 : 3,
     };
     int total = 0;
     for (int i = 0; i < nitems; ++i) total += item_rows(it_lo + i * it_st) + 2;  // (wave-uniform scalar loop, <= a few dozen items)
+    const int total_pad = (total + PD - 1) / PD * PD;
     int ky = 0, kdz = 0;  // NT == 2: power-of-two scale exponents of y (its maximum was left by the forward) and dz
     if constexpr (NT == 2) {
         ky = f16_kexp(amax_read(a.y_amax));
@@ -296,7 +294,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(W2 ? 6 : 3,
 #pragma unroll
             for (int c = 0; c < 6; ++c) win[r][c] = 0.f;
         int c_j = 0, c_len = 0, c_item = it_lo - it_st;  // consume cursor
-        auto commit = [&](int set, int buf) __attribute__((always_inline)) {
+        auto commit = [&](int set, int buf, bool live) __attribute__((always_inline)) {
             ++c_j;
             if (c_j >= c_len) {
                 c_item += it_st;
@@ -327,7 +325,7 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(W2 ? 6 : 3,
 #pragma unroll
             for (int c = 0; c < 4; ++c) win[2][1 + c] = rv ? m[c] : 0.f;
             win[2][5] = rvv ? r : 0.f;
-            if (c_j < 2) return;  // priming iteration: no chunk
+            if (c_j < 2 || !live) return;  // priming iteration / surplus iteration of the padded walk: no chunk
             unsigned char* base = lds + buf * BUFSZ;
             // y rows k = 2 ci + j of the chunk: tap order of k_dw3x3_fwd_rows (bias, then row-major taps): bit-identical y
             float yy[2][4];
@@ -391,22 +389,23 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(W2 ? 6 : 3,
 #pragma unroll
             for (int s_ = 0; s_ < PD; ++s_) issue(s_);
             wait_set(0);
-            commit(0, 0);  // iteration 0 -> buffer 0
+            commit(0, 0, true);  // iteration 0 -> buffer 0
             issue(0);
         }
         __syncthreads();
-        for (int t0 = 0; t0 < total; t0 += PD) {
+        // The walk runs over total rounded up to a multiple of PD, every slot of the unrolled body unconditional: the surplus
+        // iterations wait for and re-issue rows `advance` keeps re-loading and commit nothing (live = false: the LDS writes are
+        // skipped, the loads are not).  No slot's loads can be skipped, so on EVERY path of the control-flow graph a set is
+        // waited for exactly PD issues after it was issued -- which is what scripts/isa_hazards.py proves on the generated ISA
+        // (a conditional tail makes paths on which a slot's commit follows a skipped issue: infeasible at run time, but a
+        // path-insensitive proof cannot know, and round 5 shipped an instantiation nobody could vouch for).
+        for (int t0 = 0; t0 < total_pad; t0 += PD) {
 #pragma unroll
             for (int u = 0; u < PD; ++u) {
-                const int t = t0 + u;
-                if (t < total) {
-                    if (t + 1 < total) {
-                        wait_set((u + 1) % PD);              // iteration t + 1: issued PD iterations ago
-                        commit((u + 1) % PD, (t + 1) & 1);
-                        issue((u + 1) % PD);
-                    }
-                    if constexpr ((DWG_DBG & 16) == 0) __syncthreads();
-                }
+                wait_set((u + 1) % PD);              // iteration t0 + u + 1: issued PD iterations ago
+                commit((u + 1) % PD, (t0 + u + 1) & 1, t0 + u + 1 < total);
+                issue((u + 1) % PD);
+                if constexpr ((DWG_DBG & 16) == 0) __syncthreads();
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus loads of the tail still target live registers
@@ -419,14 +418,14 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(W2 ? 6 : 3,
         // which flattened iterations carry a chunk: the same walk, scalar
         int c_item = it_lo - it_st, c_j = 0, c_len = 0;
         __syncthreads();
-        for (int t = 0; t < total; ++t) {
+        for (int t = 0; t < total_pad; ++t) {  // (the producers' barrier count: total rounded up to the unroll depth)
             ++c_j;
             if (c_j >= c_len) {
                 c_item += it_st;
                 c_j = 0;
                 c_len = item_rows(c_item) + 2;
             }
-            if (c_j >= 2 && (DWG_DBG & 1) == 0) {
+            if (t < total && c_j >= 2 && (DWG_DBG & 1) == 0) {
                 const unsigned char* base = lds + (t & 1) * BUFSZ;
                 const unsigned char* ap = base + (wm * 32 + l31) * DWG_SROW + half * 16;
                 const unsigned char* bp = base + (MT + (wk * 2) * 32 + l31) * DWG_SROW + half * 16;
@@ -479,17 +478,8 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(W2 ? 6 : 3,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-static int dswg_w2() {  // SMAAT_DWG_W2=1: two workgroups per CU for the bf16-storage instantiations (experiment)
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("SMAAT_DWG_W2");
-        v = (e && e[0] == '1') ? 1 : 0;
-    }
-    return v;
-}
-
 static void dswg_geom(DsWgArgs& a) {
-    const int slots = dswg_w2() ? 512 : 256;
+    const int slots = 256;  // one workgroup per CU
     a.P = a.H * a.W;
     a.strips = a.W / DWG_CW;
     a.nkt = (a.K + 127) / 128;
@@ -528,10 +518,10 @@ int dsconv_wgrad_split_num_splits(int N, int Cin, int M, int H, int W) {
     return a.nsplit;
 }
 
-template <int NT, bool AFF, bool PK, typename TX, typename TG, bool W2 = false>
+template <int NT, bool AFF, bool PK, typename TX, typename TG>
 static int launch_dswg_cfg(const DsWgArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * NT * (64 + 128) * DWG_SROW;
-    constexpr auto kern = k_dsconv_wgrad_split<NT, AFF, PK, TX, TG, W2>;
+    constexpr auto kern = k_dsconv_wgrad_split<NT, AFF, PK, TX, TG>;
     static size_t granted = 0;
     if (lds > granted) {
         HIP_RET(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -565,12 +555,6 @@ int launch_dsconv_wgrad_split(DsWgArgs& a, int kpl, int x_dt, int dz_dt, hipStre
         pk = (e && e[0] == '1') ? 1 : 0;
     }
     if (dz_dt == SMAAT_BF16) {
-        if (x_dt == SMAAT_BF16 && dswg_w2()) {
-            // (the scalar-math AFF build needs 116 VGPRs at any prefetch depth -- a scheduling artefact; the packed one 80)
-            if (aff) return launch_dswg_cfg<1, true, true, bf16_t, bf16_t, true>(a, st);
-            return pk ? launch_dswg_cfg<1, false, true, bf16_t, bf16_t, true>(a, st)
-                      : launch_dswg_cfg<1, false, false, bf16_t, bf16_t, true>(a, st);
-        }
         if (x_dt == SMAAT_BF16) {
             if (pk) return aff ? launch_dswg_cfg<1, true, true, bf16_t, bf16_t>(a, st) : launch_dswg_cfg<1, false, true, bf16_t, bf16_t>(a, st);
             return aff ? launch_dswg_cfg<1, true, false, bf16_t, bf16_t>(a, st) : launch_dswg_cfg<1, false, false, bf16_t, bf16_t>(a, st);
@@ -585,6 +569,9 @@ int launch_dsconv_wgrad_split(DsWgArgs& a, int kpl, int x_dt, int dz_dt, hipStre
         // AFF build of this instantiation comes out of hipcc 7.2 at 132 VGPRs and is WRONG on the GPU: results differ from call to
         // call by 1e-3 (scripts/probes/dswgrad_h_debug.py, profiles/r5/dswgrad_h_aff_scalar_build_nondeterministic.txt) while the
         // ISA shows the same loads, waits and barriers as the correct builds -- not understood, not shipped (never instantiated).
+#ifdef DWG_SCALAR_AFF  // experiment builds only (profiles/r6/): the scalar-math AFF instantiation
+        if (aff) return launch_dswg_cfg<2, true, false, float, float>(a, st);
+#endif
         if (aff) return launch_dswg_cfg<2, true, true, float, float>(a, st);
         return launch_dswg_cfg<2, false, false, float, float>(a, st);
     }

@@ -170,6 +170,8 @@ __global__ __launch_bounds__(256 + NPT) void k_wgrad_split(const Wg2Args a) {
     const int c_begin = split, c_end = a.total_chunks, c_step = a.nsplit;
     int nit = 0;
     if (c_begin < c_end) nit = (c_end - c_begin + c_step - 1) / c_step;
+    constexpr int PD = 4;                             // register sets of loads in flight per producer thread
+    const int nit_pad = (nit + PD - 1) / PD * PD;     // barriers of the walk (producers and consumers alike)
     // NT == 2: per-tensor power-of-two scales of the two operands (wave-uniform scalar loads)
     int kdz = 0, ky = 0;
     if constexpr (NT == 2) {
@@ -208,7 +210,6 @@ __global__ __launch_bounds__(256 + NPT) void k_wgrad_split(const Wg2Args a) {
         // leave ONE chunk in flight per CU: the iteration time was the memory latency, ~1.7 us, against
         // ~0.65 us of MFMA work).  Invariant: between the prefetch of a set and its commit exactly PD - 1
         // other prefetches (NF4 loads each) are issued.
-        constexpr int PD = 4;
         static_assert((PD - 1) * NF4 <= 63, "vmcnt is a 6-bit counter");
         f32x4 pf[PD][NF4];
         bool pin[PD];
@@ -229,10 +230,11 @@ __global__ __launch_bounds__(256 + NPT) void k_wgrad_split(const Wg2Args a) {
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pf[set][j]) : "v"(src));
             }
         };
-        auto commit = [&](int buf, int set) __attribute__((always_inline)) {
+        auto commit = [&](int buf, int set, bool live) __attribute__((always_inline)) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * NF4) : "memory");
 #pragma unroll
             for (int j = 0; j < NF4; ++j) asm volatile("" : "+v"(pf[set][j]));  // uses stay behind the wait
+            if (!live) return;  // surplus iteration of the padded walk: waited for, not written
             unsigned char* base = lds + buf * BUFSZ;
 #pragma unroll
             for (int j = 0; j < NF4; ++j) {
@@ -251,21 +253,20 @@ __global__ __launch_bounds__(256 + NPT) void k_wgrad_split(const Wg2Args a) {
         if (nit > 0) {
 #pragma unroll
             for (int j = 0; j < PD; ++j) prefetch(j);
-            commit(0, 0);
+            commit(0, 0, true);
             prefetch(0);
         }
         __syncthreads();
-        for (int it0 = 0; it0 < nit; it0 += PD) {
+        // The walk runs over nit rounded up to a multiple of PD with every slot of the unrolled body unconditional (the surplus
+        // iterations wait, re-issue the last chunk's loads and write nothing): on every path of the control-flow graph a set is
+        // committed exactly PD prefetches after it was issued, which scripts/isa_hazards.py proves on the generated ISA
+        // (dswgrad.hip, round 6).
+        for (int it0 = 0; it0 < nit_pad; it0 += PD) {
 #pragma unroll
             for (int u = 0; u < PD; ++u) {
-                const int it = it0 + u;
-                if (it < nit) {
-                    if (it + 1 < nit) {
-                        commit((it + 1) & 1, (u + 1) % PD);  // chunk it+1: its loads were issued PD chunks ago
-                        prefetch((u + 1) % PD);
-                    }
-                    __syncthreads();
-                }
+                commit((it0 + u + 1) & 1, (u + 1) % PD, it0 + u + 1 < nit);  // chunk it+1: its loads were issued PD chunks ago
+                prefetch((u + 1) % PD);
+                __syncthreads();
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus prefetches of the tail
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(256 + NPT) void k_wgrad_split(const Wg2Args a) {
             }
             __syncthreads();
         }
+        for (int it = nit; it < nit_pad; ++it) __syncthreads();  // the producers' surplus iterations
         float* ob = a.part + (long)split * a.M * a.K;
         // two exact factors, the exponent split evenly: 2^-(kdz + ky) itself may be out of range, and so may the product of
         // the accumulator with 2^-kdz alone while the final result is not
@@ -839,6 +841,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
     constexpr int NPL = NT == 2 ? 2 : 3;  // planes per chunk of the weight image
     static_assert(NCW == 4 || NCW == 8, "4 or 8 consumer waves");
     static_assert((PT * 2) % NPT == 0, "producer mapping");
+    static_assert(PT % 64 == 0 && NPT % 64 == 0, "the channel half of a producer thread's B task is wave-uniform");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     // LDS budget: two workgroups per CU need <= 80 KB each.  The 128 x 128 configuration is at 73.7 KB of operand
     // buffers + 2 KB of bias slots; the statistics area is [2][WPX][3][COT] floats = 6 KB and nothing else (the wave
@@ -868,6 +871,8 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
     const int nitems = (lim - 1 - idx0) / gstep + 1;
     const int nchunks = (a.Cin + 15) >> 4;
     const int G = nitems * nchunks;  // chunks of this workgroup
+    constexpr int PD = 4;                       // register sets of loads in flight per producer thread
+    const int G_pad = (G + PD - 1) / PD * PD;   // barriers of the walk (producers and consumers alike)
     int kx = 0, ka = 0;  // NT == 2: power-of-two scale exponents of x (from its maximum) and of the weight image
     if constexpr (NT == 2) {
         kx = f16_kexp(amax_read(a.x_amax));
@@ -900,7 +905,6 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
             ah8[u] = (rem / COT) * 8;
             aofs[u] = pl * APL + arow[u] * BROW + (rem / COT) * 16;
         }
-        constexpr int PD = 4;
         const float sx = pow2i(kx);
         float breg[PD][NBT][8];
         u32x4 areg[PD][NAT];
@@ -927,7 +931,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
             for (int u = 0; u < NBT; ++u) {
                 const int p = tl * PT + bpix[u];
                 pf_bp[u] = p < a.P ? p : a.P - 1;
-                pf_bvo[u] = (unsigned)(bhalf[u] * 8 * a.P + pf_bp[u]) * 4u;
+                pf_bvo[u] = (unsigned)pf_bp[u] * 4u;  // (the half's 8 channels are part of the scalar base)
             }
 #pragma unroll
             for (int u = 0; u < NAT; ++u) {
@@ -949,24 +953,20 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
         // per-lane byte offset that only changes with the item -> no vector address arithmetic per load.
         auto prefetch = [&](int set) __attribute__((always_inline)) {
             const int k0 = pf_ch * 16;
-            if (k0 + 16 <= a.Cin) {  // wave-uniform: all 16 channels of the chunk exist
-                const float* sb = pf_x + (long)k0 * a.P;
+            // ONE form for full and partial chunks (round 6): the channel of element e is clamped in scalar arithmetic -- the
+            // half a producer thread serves is wave-uniform (PT is a multiple of 64) -- and the values of the channels past Cin
+            // are zeroed at the commit.  The earlier two-armed form (scalar bases | per-lane clamped addresses) came out of hipcc
+            // as two flag-guarded blocks, i.e. a graph with paths that issue both or neither: the load count per prefetch must
+            // be the same on every path for the counted waits to be provable (scripts/isa_hazards.py).
 #pragma unroll
-                for (int u = 0; u < NBT; ++u)
+            for (int u = 0; u < NBT; ++u) {
+                const int hb = k0 + __builtin_amdgcn_readfirstlane(bhalf[u]) * 8;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float* sbe = sb + (long)e * a.P;
-                        asm volatile("global_load_dword %0, %1, %2" : "=v"(breg[set][u][e]) : "v"(pf_bvo[u]), "s"(sbe));
-                    }
-            } else {  // last, partial chunk: clamp the channel per lane (the values are zeroed at the commit)
-#pragma unroll
-                for (int u = 0; u < NBT; ++u)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int c = k0 + bhalf[u] * 8 + e;
-                        const float* src = pf_x + (long)(c < a.Cin ? c : a.Cin - 1) * a.P + pf_bp[u];
-                        asm volatile("global_load_dword %0, %1, off" : "=v"(breg[set][u][e]) : "v"(src));
-                    }
+                for (int e = 0; e < 8; ++e) {
+                    const int c = hb + e < a.Cin ? hb + e : a.Cin - 1;
+                    const float* sbe = pf_x + (long)c * a.P;
+                    asm volatile("global_load_dword %0, %1, %2" : "=v"(breg[set][u][e]) : "v"(pf_bvo[u]), "s"(sbe));
+                }
             }
             {
                 const unsigned short* sa = pf_pl + (long)k0 * NPL * a.M;
@@ -984,7 +984,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
                 pf_setup();
             }
         };
-        auto commit = [&](int ch, int buf, int set, int slot) __attribute__((always_inline)) {
+        auto commit = [&](int ch, int buf, int set, int slot, bool live) __attribute__((always_inline)) {
             const int k0 = ch * 16;
             // wait for this set's loads; the "+v" ties keep every use of the set's registers behind the wait
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * LPC) : "memory");
@@ -995,6 +995,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
 #pragma unroll
             for (int u = 0; u < NAT; ++u) asm volatile("" : "+v"(areg[set][u]));
             asm volatile("" : "+v"(bias_reg[set]));
+            if (!live) return;  // surplus iteration of the padded walk: waited for, not written
             const bool partial = k0 + 16 > a.Cin;  // wave-uniform
             biasl[slot * COT + ptid % COT] = a.bias ? bias_reg[set] : 0.f;  // every chunk of the item rewrites the same values
             unsigned char* base = lds + buf * BUFSZ;
@@ -1015,26 +1016,22 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
         pf_setup();
 #pragma unroll
         for (int j = 0; j < PD; ++j) prefetch(j);
-        commit(0, 0, 0, 0);
+        commit(0, 0, 0, 0, true);
         prefetch(0);
         int cm_ch = nchunks > 1 ? 1 : 0;  // chunk (within its item) of the NEXT commit
         int cm_slot = nchunks > 1 ? 0 : 1;  // ... and its item & 3
         __syncthreads();
-        for (int g0 = 0; g0 < G; g0 += PD) {
+        // padded walk, every slot unconditional (k_wgrad_split above: the shape scripts/isa_hazards.py can prove)
+        for (int g0 = 0; g0 < G_pad; g0 += PD) {
 #pragma unroll
             for (int u = 0; u < PD; ++u) {
-                const int g = g0 + u;
-                if (g < G) {
-                    if (g + 1 < G) {
-                        commit(cm_ch, (g + 1) & 1, (u + 1) % PD, cm_slot);  // loads issued PD chunks ago
-                        if (++cm_ch == nchunks) {
-                            cm_ch = 0;
-                            cm_slot = (cm_slot + 1) & 3;
-                        }
-                        prefetch((u + 1) % PD);
-                    }
-                    __syncthreads();
+                commit(cm_ch, (g0 + u + 1) & 1, (u + 1) % PD, cm_slot, g0 + u + 1 < G);  // loads issued PD chunks ago
+                if (++cm_ch == nchunks) {
+                    cm_ch = 0;
+                    cm_slot = (cm_slot + 1) & 3;
                 }
+                prefetch((u + 1) % PD);
+                __syncthreads();
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus prefetches of the tail still target live registers
@@ -1144,6 +1141,7 @@ __global__ __launch_bounds__(WCO * WPX * 64 + NPT, (WCO * WPX == 4) ? 4 : 2) voi
                 prev_co0 = co0;
             }
         }
+        for (int gg = G; gg < G_pad; ++gg) __syncthreads();  // the producers' surplus iterations
         if (a.part) {
             __syncthreads();
             flush((nitems - 1) & 1, prev_ptg, prev_co0);

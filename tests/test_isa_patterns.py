@@ -117,3 +117,67 @@ def test_attention_backward_loops_keep_their_prefetch():
     stores = [i for i, o in enumerate(ops) if "store" in o]
     assert len(stores) == 4, ops  # two channels x two rows
     assert not any("load" in o for o in ops[stores[0]:stores[-1]]), ops
+
+
+# ------------------------------------------------------------------------------------------------ round 6: CFG-aware hazard lint
+def _hazards():
+    spec = importlib.util.spec_from_file_location("isa_hazards", os.path.join(ROOT, "scripts", "isa_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc not available")
+@pytest.mark.parametrize("src,min_kernels", [("dswgrad.hip", 14), ("dsrows.hip", 16), ("splitmma.hip", 13), ("dsconv_split.hip", 24)])
+def test_no_instruction_touches_a_prefetched_register_before_its_wait(src, min_kernels):
+    """Round 6: hipcc believes the destination of an inline-asm `global_load` is valid as soon as the
+    statement has executed -- under register pressure it spills it (a scratch store of a register whose load has not landed,
+    reloaded later as if it held the data), copies it or lends it to a temporary.  The round-6 form of the row-walking and split
+    GEMM kernels (walks padded to the unroll depth, every slot unconditional, one load form per prefetch) makes the proof
+    path-insensitive: on EVERY path of the control-flow graph, back-edges included, no instruction may read or write (other
+    than re-load) a vector register between the inline-asm load that targets it and the counted s_waitcnt that covers it, and
+    no vector-memory instruction may take a scalar base a VALU instruction wrote fewer than 5 wait states earlier.
+    EVERY instantiation in the library is checked: a hipcc upgrade (or an edit) that moves one into the state of round 5's
+    k_dsconv_wgrad_split<2, AFF, scalar> fails here, on the CPU, instead of silently on the GPU."""
+    H = _hazards()
+    res = H.analyse_text(H.compile_asm(os.path.join(ROOT, "smaat_unet_amd", "csrc", src)))
+    assert len(res) >= min_kernels, (src, len(res))
+    bad = {fn: [r for r in rep if r[0] in ("INFLIGHT", "SGPRHAZ")] for fn, (rep, _) in res.items()}
+    bad = {fn: r for fn, r in bad.items() if r}
+    assert not bad, {fn: [(k, t.split(";")[0].strip(), why) for k, _, t, why in r[:3]] for fn, r in bad.items()}
+
+
+def test_hazard_lint_finds_the_planted_hazards():
+    """The lint itself, on hand-written listings: a copy of a prefetched register over a loop back-edge, a spill right after the
+    issue, a counted wait one load short on ONE of two paths, a VALU-written scalar base -- and the clean forms of each."""
+    H = _hazards()
+
+    def run(body):
+        rep, _ = H.analyse_function(body.strip().split("\n"))
+        return [r[0] for r in rep if r[0] in ("INFLIGHT", "SGPRHAZ")]
+
+    load = ";;#ASMSTART\nglobal_load_dwordx4 v[4:7], v1, s[2:3]\n;;#ASMEND"
+    wait0 = ";;#ASMSTART\ns_waitcnt vmcnt(0)\n;;#ASMEND"
+    assert run(f"{load}\n{wait0}\nv_add_f32_e32 v8, v4, v5\ns_endpgm") == []
+    assert run(f"{load}\nv_mov_b32_e32 v9, v4\n{wait0}\ns_endpgm") == ["INFLIGHT"]                     # copy before the wait
+    assert run(f"{load}\nscratch_store_dwordx4 off, v[4:7], off\n{wait0}\ns_endpgm") == ["INFLIGHT"]    # spill of a prefetched set
+    assert run(f"{load}\nglobal_load_dwordx4 v[4:7], v1, s[2:3]\n{wait0}\nv_mov_b32_e32 v9, v4\ns_endpgm") == []  # re-load: harmless
+    # software pipeline, two sets, counted wait vmcnt(1): set A is complete when one younger load is outstanding
+    loop_ok = (".LBB0_1:\n;;#ASMSTART\ns_waitcnt vmcnt(1)\n;;#ASMEND\nv_mov_b32_e32 v20, v4\n;;#ASMSTART\nglobal_load_dword v4, v1, s[2:3]\n;;#ASMEND\n"
+               ";;#ASMSTART\ns_waitcnt vmcnt(1)\n;;#ASMEND\nv_mov_b32_e32 v21, v5\n;;#ASMSTART\nglobal_load_dword v5, v1, s[2:3]\n;;#ASMEND\n"
+               "s_cbranch_scc1 .LBB0_1\ns_endpgm")
+    pro = ";;#ASMSTART\nglobal_load_dword v4, v1, s[2:3]\n;;#ASMEND\n;;#ASMSTART\nglobal_load_dword v5, v1, s[2:3]\n;;#ASMEND\n"
+    assert run(pro + loop_ok) == []
+    # the same loop with a phi copy of the set issued LAST placed on the back-edge: only the graph walk sees it
+    assert "INFLIGHT" in run(pro + loop_ok.replace("s_cbranch_scc1 .LBB0_1", "v_mov_b32_e32 v30, v5\ns_cbranch_scc1 .LBB0_1"))
+    # a slot whose issue can be skipped: on the skipping path the next wait is one load short
+    skip = pro + (".LBB0_1:\n;;#ASMSTART\ns_waitcnt vmcnt(1)\n;;#ASMEND\nv_mov_b32_e32 v20, v4\ns_cbranch_scc0 .LBB0_2\n"
+                  ";;#ASMSTART\nglobal_load_dword v4, v1, s[2:3]\n;;#ASMEND\n.LBB0_2:\n;;#ASMSTART\ns_waitcnt vmcnt(1)\n;;#ASMEND\nv_mov_b32_e32 v21, v5\n"
+                  ";;#ASMSTART\nglobal_load_dword v5, v1, s[2:3]\n;;#ASMEND\ns_cbranch_scc1 .LBB0_1\ns_endpgm")
+    assert "INFLIGHT" in run(skip)
+    # VALU writes the scalar base of a vector-memory instruction: 5 wait states
+    assert run("v_readfirstlane_b32 s2, v1\nv_readfirstlane_b32 s3, v2\nglobal_load_dword v4, v1, s[2:3]\ns_waitcnt vmcnt(0)\ns_endpgm") == ["SGPRHAZ"]
+    assert run("v_readfirstlane_b32 s2, v1\nv_readfirstlane_b32 s3, v2\ns_nop 4\nglobal_load_dword v4, v1, s[2:3]\ns_waitcnt vmcnt(0)\ns_endpgm") == []
+    # packed f32 operands: a register that is named but selected by neither lane is not read
+    assert run(f"{load}\nv_pk_fma_f32 v[10:11], v[12:13], v[3:4], v[14:15] op_sel_hi:[1,0,1]\n{wait0}\ns_endpgm") == []
+    assert run(f"{load}\nv_pk_fma_f32 v[10:11], v[12:13], v[3:4], v[14:15]\n{wait0}\ns_endpgm") == ["INFLIGHT"]
