@@ -7,6 +7,9 @@
   drainset_<sub>  s_waitcnt vmcnt(0) after every THIRD inline-asm load (= after a whole set: x row, edge, dz)
   nopmov_<sub>    s_nop 1 in front of every v_mov_b64 of those kernels (two wait states between a 32-bit VALU write of one half of
                   a register pair and the 64-bit move that reads the pair)
+  nopsA_/nopsB_/nopsC_<sub>   s_nop 3 after every VALU instruction of ONE region of each pipeline slot (a slot = counted wait ..
+                  s_barrier): A = the window update (wait .. first v_pk_fma_f32), B = depthwise + operand split + LDS writes
+                  (.. last ds_write), C = advance + issue + the copies in front of the barrier.  Which region is timing-sensitive?
   splitmov_<sub>  every v_mov_b64 vD[a:a+1], vS[b:b+1] replaced by two v_mov_b32 (no 64-bit move left; same wait states as the
                   original sequence otherwise)
 """
@@ -45,4 +48,33 @@ for ln in lines:
         nload += 1
         if kind == "drain" or nload % 3 == 0:
             out.append("\ts_waitcnt vmcnt(0)")
+if kind in ("nopsA", "nopsB", "nopsC"):
+    res, cur, region = [], None, None
+    body = out
+    # per kernel: slot boundaries from the listing itself
+    i = 0
+    while i < len(body):
+        ln = body[i]
+        m = re.match(r"^(_Z\w+):", ln)
+        if m:
+            cur, region = m.group(1), None
+        t = ln.split(";")[0].strip()
+        if cur and sub in cur:
+            if re.match(r"s_waitcnt vmcnt\([1-9]\d*\)", t):
+                # look ahead to the slot's end and its landmarks
+                j = i
+                while j < len(body) and "s_barrier" not in body[j]:
+                    j += 1
+                idx_pk = next((k for k in range(i, j) if "v_pk_fma_f32" in body[k]), j)
+                idx_ds = max([k for k in range(i, j) if re.match(r"\s*ds_write", body[k])] or [i])
+                lo, hi = {"nopsA": (i, idx_pk), "nopsB": (idx_pk, idx_ds + 1), "nopsC": (idx_ds + 1, j)}[kind]
+                for k in range(i, j):
+                    res.append(body[k])
+                    if lo <= k < hi and re.match(r"\s*v_", body[k]):
+                        res.append("\ts_nop 3")
+                i = j
+                continue
+        res.append(ln)
+        i += 1
+    out = res
 open(dst, "w").write("\n".join(out))

@@ -891,7 +891,8 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None, i
     if _is_bf(x):  # the forward of this block fell back to f32 storage (_bf16_storage_ok) on a bf16 input
         x, x_bs = _planes(x.float())
     # amx = {"w": int32 words [max |y|, max |dz|], "y": bool, "dz": bool}: which maxima the producing kernels left
-    a_dz = amx["w"][AMAX_WORDS:] if (amx is not None and amx.get("dz")) else None
+    # ("wdz": the words THIS backward pass filled -- _half_backward hands every pass fresh zero words)
+    a_dz = amx.get("wdz", amx["w"][AMAX_WORDS:]) if (amx is not None and amx.get("dz")) else None
     a_y = amx["w"][:AMAX_WORDS] if (amx is not None and amx.get("y")) else None
     if y is not None:
         dw_pw = _pointwise_wgrad_raw(y, dz, cout, a_y if a_dz is not None else None, a_dz if a_y is not None else None)
@@ -1106,7 +1107,13 @@ def _half_backward(x, w_dw, b_dw, w_pw, gamma, z, st, y_dw, dy, kpl, train_stats
     BatchNorm: x is its input, the activation is applied on load and its backward sums are emitted (`red`)."""
     if amx is not None and (amx.get("w") is None or not amx.get("dz") or _is_bf(z) or _is_bf(dy) or not _f16_on()):
         amx = None  # (no maxima words, or a storage / mode change since the forward)
-    a_dz = amx["w"][AMAX_WORDS:] if amx is not None else None
+    if amx is not None:
+        # max |dz| is accumulated with atomic max into words that "must hold 0 on entry" (include/smaat_hip.h): a SECOND backward
+        # over the same graph (retain_graph, several losses, Jacobian rows) must not start from the first one's maximum -- a much
+        # smaller dz would be scaled by a stale power of two and lose its second term (ADVICE r5).  Fresh zero words per pass
+        # (a slice of the arena: no launch); the forward's words keep max |y|, which does not change between passes.
+        amx = dict(amx, wdz=_amax_words(z, 1))
+    a_dz = amx["wdz"] if amx is not None else None
     if head is not None:  # dy is w_out (x) dlog, formed on the fly; head["dw"] receives the 1x1 conv's weight gradient
         dz, dgamma, dbeta, head["dw"] = _bn_bwd_head_raw(head["dlog"], head["w"], z, st, gamma, train_stats, amax=a_dz)
     else:

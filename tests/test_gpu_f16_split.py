@@ -419,3 +419,29 @@ def test_recompute_wgrad_h_against_fp64_next_to_the_three_term_kernel():
     e_new, e_old = rel(new, ref), rel(old.cpu().numpy(), ref)
     assert e_new < 2e-6 and e_new < 3 * e_old + 2e-7, (e_new, e_old)
     assert np.array_equal(new, case_rows_amax_and_wgrad_h(L, dev, N, Cin, Cout, H, W)["dw"].cpu().numpy())
+
+
+def test_second_backward_over_a_retained_graph_uses_its_own_gradient_maximum():
+    """max |dz| of a block is accumulated with atomic max into words that must hold 0 on entry.  A second backward over
+    the same graph (retain_graph: several losses, Jacobian rows) with a cotangent 1e-8 times the first one's must not be scaled by
+    the first pass's maximum -- its second fp16 term would vanish (2^-27 below the stale scale) and the operand itself would sit
+    in the fp16 denormals.  Gradients are linear in the cotangent (BatchNorm statistics are fixed by the forward): pass 2 must be
+    1e-8 x pass 1 to f32-class accuracy."""
+    import smaat_unet_amd as S
+    from smaat_unet_amd import ops as K
+    torch.manual_seed(3)
+    blk = S.unet_parts_depthwise_separable.DoubleConvDS(64, 64, kernels_per_layer=2).to(DEV).train()
+    x = torch.randn(2, 64, 64, 64, device=DEV, requires_grad=True)
+    assert 2 * 64 * 64 >= K.F16_MIN_SAMPLES  # (the two-term fp16 split is what runs)
+    out = blk(x)
+    g = torch.randn_like(out)
+    params = [p for p in blk.parameters()]
+    first = torch.autograd.grad(out, [x] + params, grad_outputs=g, retain_graph=True)
+    second = torch.autograd.grad(out, [x] + params, grad_outputs=g * 1e-8)
+    for (name, _), a, b in zip([("x", None)] + list(blk.named_parameters()), first, second):
+        if name.endswith("wise.bias"):  # exactly zero in front of a train-mode BatchNorm
+            assert float(b.abs().max()) == 0.0
+            continue
+        na = float(a.double().norm())
+        err = float((b.double() * 1e8 - a.double()).norm()) / max(na, 1e-30)
+        assert err < 2e-5, (name, err)
