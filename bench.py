@@ -178,7 +178,7 @@ class PowerSampler:
         return {"sclk_mhz_mean": round(sum(clk) / len(clk)), "sclk_mhz_min": min(clk), "sclk_mhz_nominal": 2400,
                 "power_w_mean": round(sum(pw) / len(pw)) if pw else None, "power_w_max": round(max(pw)) if pw else None,
                 "samples": len(clk),
-                "note": "sampled with rocm-smi during the timed steps; the GEMM phases run at the 1400 W board limit and "
+                "note": "sampled with rocm-smi while the step runs; the GEMM phases run at the 1400 W board limit and "
                         "~1.8 GHz, the streaming phases at ~1.0 kW and 2.4 GHz (profiles/r3/clock_under_load_r3.txt)"}
 
 
@@ -489,13 +489,28 @@ def main():
         torch.cuda.synchronize()
 
     fence()
-    sampler = PowerSampler().start() if (rank == 0 and not args.no_power) else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
-    power = sampler.stop() if sampler is not None else None
+    # clock / power: sampled over a SEPARATE pass of the same steps after the timed region, long enough for >= 5 rocm-smi samples
+    # whatever --steps was (the driver's 20 steps are 0.6 s: one sample), and without a host thread
+    # spawning subprocesses inside the timed region.  Fewer than 5 samples -> null.
+    power = None
+    if rank == 0 and world == 1 and not args.no_power:
+        sampler = PowerSampler(period=0.15).start()
+        t_end, nps = time.perf_counter() + 4.0, 0
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize()
+            nps += 8
+        power = sampler.stop()
+        if power is not None and power["samples"] < 5:
+            power = None
+        elif power is not None:
+            power["sampled_over"] = f"{nps} further identical steps after the timed region (~4 s)"
     peak_gb = round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)  # activations + workspaces + optimizer state of this rank
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)

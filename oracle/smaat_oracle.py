@@ -427,22 +427,33 @@ def mse_sum_over_batch(pred, target):
 class Tape:
     """Records what the backward needs. One per forward call."""
 
-    def __init__(self):
+    def __init__(self, relu_masks=None):
         self.d = {}
+        # imposed ReLU decisions (tests/tie_flips.py): one boolean array per DoubleConvDS half in execution order; None =
+        # the decisions follow the sign of the BatchNorm output as in the reference (nn.ReLU)
+        self.relu_masks = list(relu_masks) if relu_masks is not None else None
+        self.n_half = 0
 
 
 def _dsconv_bn_relu_fwd(P, pre, bn_pre, x, kpl, tape, key, eps=1e-5):
     y = dw3x3_fwd(x, P[pre + ".depthwise.weight"], P[pre + ".depthwise.bias"], kpl)
     z = pw1x1_fwd(y, P[pre + ".pointwise.weight"], P[pre + ".pointwise.bias"])
     a, mean, invstd, var = bn_train_fwd(z, P[bn_pre + ".weight"], P[bn_pre + ".bias"], eps)
-    out = relu_fwd(a)
-    tape.d[key] = dict(x=x, y=y, z=z, mean=mean, invstd=invstd, var=var, out=out)
+    mask = None
+    if tape.relu_masks is not None:  # the decisions of ANOTHER run imposed on this one: out = a where it kept its value
+        mask = np.asarray(tape.relu_masks[tape.n_half], bool)
+        assert mask.shape == a.shape, (key, mask.shape, a.shape)
+        out = a * mask
+    else:
+        out = relu_fwd(a)
+    tape.n_half += 1
+    tape.d[key] = dict(x=x, y=y, z=z, mean=mean, invstd=invstd, var=var, out=out, mask=mask)
     return out
 
 
 def _dsconv_bn_relu_bwd(P, G, pre, bn_pre, kpl, tape, key, dout):
     t = tape.d[key]
-    da = relu_bwd(t["out"], dout)
+    da = relu_bwd(t["out"], dout) if t["mask"] is None else dout * t["mask"]
     dz, dg, db = bn_train_bwd(t["z"], P[bn_pre + ".weight"], t["mean"], t["invstd"], da)
     G[bn_pre + ".weight"] = dg
     G[bn_pre + ".bias"] = db
@@ -514,9 +525,9 @@ def up_bwd(P, G, pre, kpl, tape, dout):
     return upsample2x_bwd(t["x1_shape"], np.ascontiguousarray(du)), dx2
 
 
-def smaat_unet_fwd(P, x, kpl=2):
-    """models/SmaAt_UNet.py:41-57.  Returns (logits, tape, acts)."""
-    tape = Tape()
+def smaat_unet_fwd(P, x, kpl=2, relu_masks=None):
+    """models/SmaAt_UNet.py:41-57.  Returns (logits, tape, acts).  relu_masks: see Tape."""
+    tape = Tape(relu_masks)
     a = {}
     a["x1"] = double_conv_ds_fwd(P, "inc", x, kpl, tape)
     a["x1Att"] = cbam_fwd(P, "cbam1", a["x1"], tape)
@@ -556,10 +567,32 @@ def smaat_unet_bwd(P, tape, dlogits, kpl=2):
     return G, dx
 
 
-def train_step_loss_and_grads(P, x, target, kpl=2):
-    """forward + MSE(sum)/N + backward: the unit bench.py's cpu_baseline leg times."""
-    logits, tape, acts = smaat_unet_fwd(P, x, kpl)
-    loss, dlogits = mse_sum_over_batch(logits, target)
+def cross_entropy_mean(logits, target):
+    """nn.CrossEntropyLoss() (reference train_SmaAtUNet.py:183): mean over N*H*W of -log softmax(logits)[target]"""
+    z = logits.astype(np.float64)
+    z = z - z.max(axis=1, keepdims=True)
+    lse = np.log(np.exp(z).sum(axis=1, keepdims=True))
+    logp = z - lse
+    n, c, h, w = logits.shape
+    oh = np.zeros_like(logp)
+    np.put_along_axis(oh, target[:, None].astype(np.int64), 1.0, axis=1)
+    cnt = n * h * w
+    loss = -(logp * oh).sum() / cnt
+    return logits.dtype.type(loss), ((np.exp(logp) - oh) / cnt).astype(logits.dtype)
+
+
+def train_step_loss_and_grads(P, x, target, kpl=2, relu_masks=None, loss="mse", cotangent=None):
+    """forward + loss + backward: the unit bench.py's cpu_baseline leg times (loss "mse" = MSE(sum)/N, reference
+    models/regression_lightning.py:57-65; "ce" = nn.CrossEntropyLoss; "dot" = (logits * cotangent).sum()).
+    relu_masks (tests/tie_flips.py): the ReLU decisions of the 18 DoubleConvDS halves imposed from another run -- the fp64
+    anchor "given THOSE decisions", which a run that landed on the other side of a tie is held against."""
+    logits, tape, acts = smaat_unet_fwd(P, x, kpl, relu_masks)
+    if loss == "mse":
+        loss, dlogits = mse_sum_over_batch(logits, target)
+    elif loss == "ce":
+        loss, dlogits = cross_entropy_mean(logits, target)
+    else:
+        loss, dlogits = logits.dtype.type((logits * cotangent).sum()), np.asarray(cotangent, logits.dtype)
     G, dx = smaat_unet_bwd(P, tape, dlogits, kpl)
     return loss, G, dx, acts
 

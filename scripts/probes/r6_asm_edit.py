@@ -48,6 +48,16 @@ for ln in lines:
         nload += 1
         if kind == "drain" or nload % 3 == 0:
             out.append("\ts_waitcnt vmcnt(0)")
+QUART = None
+if re.match(r"nopsA[1-4]$", kind):  # a quarter of region A's VALU instructions (second bisection step)
+    QUART, kind = int(kind[-1]) - 1, "nopsA"
+NOPAT = None
+m_ = re.match(r"nopat(\d+)$", kind)
+if m_:  # 16 wait states in front of the k-th instruction of region A of every slot (third bisection step: the curing
+    NOPAT, kind = int(m_.group(1)), "nopsA"  # positions are the interval between the two instructions of the hazard)
+ONLY = None
+if kind in ("nopsDPP", "nopsEXEC"):  # s_nop 3 before and after every DPP instruction / after every write of EXEC, region A only
+    ONLY, kind = kind, "nopsA"
 if kind in ("nopsA", "nopsB", "nopsC"):
     res, cur, region = [], None, None
     body = out
@@ -68,9 +78,34 @@ if kind in ("nopsA", "nopsB", "nopsC"):
                 idx_pk = next((k for k in range(i, j) if "v_pk_fma_f32" in body[k]), j)
                 idx_ds = max([k for k in range(i, j) if re.match(r"\s*ds_write", body[k])] or [i])
                 lo, hi = {"nopsA": (i, idx_pk), "nopsB": (idx_pk, idx_ds + 1), "nopsC": (idx_ds + 1, j)}[kind]
+                valu = [k for k in range(lo, hi) if re.match(r"\s*v_", body[k])]
+                if QUART is not None:
+                    n4 = (len(valu) + 3) // 4
+                    valu = valu[QUART * n4:(QUART + 1) * n4]
+                valu = set(valu)
+                if NOPAT is not None:
+                    real = [k for k in range(lo, hi) if re.match(r"\s*[vs]_", body[k])]
+                    for k in range(i, j):
+                        if NOPAT < len(real) and k == real[NOPAT]:
+                            res += ["\ts_nop 7", "\ts_nop 7"]
+                        res.append(body[k])
+                    i = j
+                    continue
                 for k in range(i, j):
+                    t2 = body[k].split(";")[0]
+                    if ONLY == "nopsDPP":
+                        if lo <= k < hi and "_dpp" in t2:
+                            res += ["\ts_nop 3", body[k], "\ts_nop 3"]
+                        else:
+                            res.append(body[k])
+                        continue
+                    if ONLY == "nopsEXEC":
+                        res.append(body[k])
+                        if lo <= k < hi and re.match(r"\s*s_\w+\s+(exec|s\[\d+:\d+\], vcc)", t2) and ("exec" in t2):
+                            res.append("\ts_nop 3")
+                        continue
                     res.append(body[k])
-                    if lo <= k < hi and re.match(r"\s*v_", body[k]):
+                    if k in valu:
                         res.append("\ts_nop 3")
                 i = j
                 continue

@@ -162,18 +162,32 @@ def test_unet_vs_reference_golden(golden_dir, name, policy, monkeypatch):
     # attributes it to ReLU decisions at a tie between this run and the run with the gate / main / final attention kernels
     # of the same build (round 5: the three-pass attention kernels add the channels of the pooled maps in chunks; with eight
     # chunks this fixture lands on the other side of one tie -- scripts/probes/cbam_split_rounding.py)
-    from tests.tie_flips import attribute, record_pre_activations
+    from tests.tie_flips import attribute, check_against_masked_oracle, record_pre_activations
+    cap, sink = {}, {}
 
     def run(on, store):
         with record_pre_activations(store):
-            _unet_vs_reference_golden(golden_dir, name)
-    flips = attribute(run, flag="CBAM_THREE_PASS")
+            _unet_vs_reference_golden(golden_dir, name, capture=cap if on else None)
+    flips = attribute(run, flag="CBAM_THREE_PASS", sink=sink)
+    if flips:
+        # round 6: an accepted flip is followed by an ORACLE check -- the fp64 anchor re-derived with the decisions THIS run took,
+        # every gradient tensor held to the ordinary bound against it
+        g = cap["g"]
+        bad, _ = check_against_masked_oracle(cap["P"], g["x"], g["target"], "mse" if cap["meta"]["loss"] == "mse" else "dot",
+                                             sink["rec"], cap["grads"], lambda k: float(g["noise/" + k]) if "noise/" + k in g.files else 0.0,
+                                             NOISE_FACTOR_SMALL, cotangent=g["target"],
+                                             skip=lambda k: ".double_conv." in "." + k and k.endswith(("depthwise.bias", "pointwise.bias")))
+        assert not bad, ("gradients do not match the fp64 oracle under this run's own ReLU decisions", bad[:6])
     if flips and os.path.isdir("gpurun_out"):
         with open(f"gpurun_out/golden_{name}_{policy}_tie_flips.json", "w") as f:
             json.dump([dict(half=i, element=list(e), three_pass=a, sequence=b, rms=r) for i, e, a, b, r in flips], f, indent=1)
 
 
-def _unet_vs_reference_golden(golden_dir, name):
+NOISE_FACTOR_SMALL = 3.0  # small-network fixtures (planes down to 2 x 2 pixels): see tests/test_host_emu.py check_param_grads
+
+
+def _unet_vs_reference_golden(golden_dir, name, capture=None):
+    from tests.tie_flips import BoundViolation
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     meta = json.loads(str(g["meta"]))
     model, _ = _load_model(meta)
@@ -192,9 +206,15 @@ def _unet_vs_reference_golden(golden_dir, name):
     # tensor (floor 5e-3: one ReLU flip at forward round-off level), the rule of the benchmark-size fixtures
     # (tests/test_eval_and_big.py run_big) -- not one flat 2e-2 for every tensor
     from tests.test_host_emu import check_param_grads
-    bad = check_param_grads(g, [(k, p.grad.cpu().numpy()) for k, p in model.named_parameters()])
-    assert not bad, bad[:6]
-    assert check_summary(g, "dx64", x.grad.cpu().numpy()) < max(3.0 * float(g["noise/dx"]), 5e-3)
+    grads = [(k, p.grad.cpu().numpy()) for k, p in model.named_parameters()]
+    if capture is not None:
+        capture.update(g=g, meta=meta, grads=grads, P=oparams.make_smaat_params(meta["n_channels"], meta["n_classes"], meta.get("kpl", 2),
+                                                                                 16, meta["param_seed"]))
+    bad = check_param_grads(g, grads)
+    if bad:
+        raise BoundViolation(bad[:6])
+    if not check_summary(g, "dx64", x.grad.cpu().numpy()) < max(3.0 * float(g["noise/dx"]), 5e-3):
+        raise BoundViolation("dx")
     sd = model.state_dict()
     for k in g.files:
         if k.startswith("after/"):

@@ -12,9 +12,15 @@ is of that kind, by comparing it with a second run of THIS implementation on the
   * the two runs take different ReLU decisions somewhere, and EVERY differing decision sits on a pre-activation that is
     within `tie` (relative to the rms of its tensor) of zero in BOTH runs.
 
-Anything else -- a difference away from a tie, or no difference at all -- is a real failure."""
+Anything else -- a difference away from a tie, or no difference at all -- is a real failure.
+
+Round 6: attribution alone says WHY the run left the bound, not that its gradients are right given the
+decisions it took.  `check_against_masked_oracle()` therefore re-derives the fp64 anchor with the run's OWN recorded ReLU
+decisions imposed (oracle/smaat_oracle.py train_step_loss_and_grads(relu_masks=...)) and holds every gradient tensor to the
+ordinary per-tensor bound against THAT anchor: an accepted tie flip is followed by an oracle check, not by a shrug."""
 import contextlib
 
+import numpy as np
 import torch
 
 from smaat_unet_amd import ops
@@ -54,11 +60,53 @@ def differing_decisions(a, b):
     return out
 
 
-def attribute(run, tie=2e-4, flag="F16_SPLIT"):
+class BoundViolation(AssertionError):
+    """the per-tensor gradient bound of a network fixture is violated (the only failure a tie flip may explain: logits,
+    loss and running statistics are asserted with plain AssertionErrors and are never forgiven -- ADVICE r5)"""
+
+
+def relu_masks(rec):
+    """the ReLU decisions a recorded run took: one boolean numpy array per DoubleConvDS half, in execution order"""
+    return [((z * st[2][None, :, None, None] + st[3][None, :, None, None]) > 0).cpu().numpy() for z, st in rec]
+
+
+def check_against_masked_oracle(P, x, target, loss, rec, named_grads, noise_of, factor, floor=5e-3, kpl=2, cotangent=None,
+                                skip=lambda k: False):
+    """fp64 oracle with the decisions of `rec` imposed; every gradient tensor of named_grads (name, array) must be within
+    max(factor * noise_of(name), floor) of it (rel-L2), the single-number gradients judged together as one vector.
+    Returns (violations, anchor gradients)."""
+    from oracle import smaat_oracle as O
+    P64 = {k: np.asarray(v, np.float64) for k, v in P.items()}
+    tgt = np.asarray(target) if loss == "ce" else np.asarray(target, np.float64)
+    _, G, dx, _ = O.train_step_loss_and_grads(P64, np.asarray(x, np.float64), tgt, kpl, relu_masks=relu_masks(rec), loss=loss,
+                                              cotangent=None if cotangent is None else np.asarray(cotangent, np.float64))
+    bad, so, sr = [], [], []
+    for k, gk in named_grads:
+        if skip(k):
+            continue
+        gk, ref = np.asarray(gk, np.float64), np.asarray(G[k], np.float64)
+        if gk.size == 1:
+            so.append(float(gk.ravel()[0]))
+            sr.append(float(ref.ravel()[0]))
+            continue
+        e = np.linalg.norm(gk - ref) / max(np.linalg.norm(ref), 1e-30)
+        if e > max(factor * noise_of(k), floor):
+            bad.append((k, float(e), float(noise_of(k))))
+    if so:
+        e = np.linalg.norm(np.array(so) - np.array(sr)) / max(np.linalg.norm(sr), 1e-30)
+        if e > max(factor * max(noise_of("<single>"), 0.0), 2e-2):
+            bad.append(("<single-number gradients as one vector>", float(e), 0.0))
+    G["<dx>"] = dx
+    return sorted(bad, key=lambda t: -t[1]), G
+
+
+def attribute(run, tie=2e-4, flag="F16_SPLIT", sink=None):
     """run(on: bool, store) -> None or raises AssertionError (the bound check of the test, on a fresh model with the feature
     named by `flag` -- a boolean switch of smaat_unet_amd.ops whose two settings differ at f32 round-off level: the two-term
     fp16 split (default), or CBAM_THREE_PASS, whose kernels add the channels of the attention maps in another order -- on /
     off; it must run its forward inside `record_pre_activations(store)`).
+    Only a BoundViolation of the default run can be forgiven; any other AssertionError (logits, loss, running statistics)
+    propagates.  sink (dict): receives rec = the recording of the default run (for check_against_masked_oracle).
     Returns the list of tie flips when the violation of run(True) is attributable to them; raises otherwise."""
     prev = getattr(ops, flag)
     rec = {}
@@ -71,11 +119,13 @@ def attribute(run, tie=2e-4, flag="F16_SPLIT"):
             try:
                 run(f16, rec[f16])
                 err[f16] = None
-            except AssertionError as e:  # noqa: PERF203
+            except BoundViolation as e:  # noqa: PERF203
                 err[f16] = e
     finally:
         setattr(ops, flag, prev)
         ops.invalidate_weight_images()
+    if sink is not None:
+        sink["rec"] = rec[True]
     if err[True] is None:
         return []
     if err[False] is not None:
