@@ -340,6 +340,25 @@ int smaat_dsconv_wgrad_split_h(const float* x, long x_bs, const float* in_scale,
                                const float* b_dw, const void* y_amax, const float* dz, long dz_bs, const void* dz_amax, float* ws,
                                float* dw_out, int N, int Cin, int kpl, int Cout, int H, int W, void* stream);
 
+/* ---- fused BACKWARD of a DepthwiseSeparableConv (round 6; reference: autograd of models/layers.py:47-50, the pointwise data
+ *      gradient of :49 feeding the depthwise backward of :48).  The two-kernel form writes dY = W_pw^T dz (the 2x-expanded
+ *      tensor) with smaat_pointwise_fwd_split_h and reads it back in smaat_dw3x3_bwd[_bnred]; here MFMA waves form one row of dY
+ *      per step into LDS and the depthwise backward consumes it in the same kernel.  Results: dx bit-identical to the two-kernel
+ *      form (same MFMA and FMA sequences), dw_dw / db_dw and the BatchNorm sums merged from per-workgroup partials.
+ *      x: the depthwise input [N][Cin][H][W]; with in_scale / in_shift (both or neither) it is the PRE-BatchNorm tensor of the
+ *      previous half, the activation is applied on load, bn_mean / bn_invstd are that BatchNorm's batch statistics and rpart
+ *      [2][rows][Cin] receives its backward sums (sum g, sum g * xhat; g = dx * [act > 0]) as smaat_dw3x3_bwd_bnred leaves them.
+ *      dz [N][Cout][H][W] with its amax buffer; planes_t = smaat_split_planes_h(pointwise.weight [Cout][K], src_t = 1) (the
+ *      fp16 image of the transpose, exponent in its trailer); ws [rows][K][10] workspace, rows =
+ *      smaat_dsconv_bwd_rows_num_rows; dw_out [K][9], db_out [K].  Returns -2 when smaat_dsconv_bwd_rows_ok says no
+ *      (kernels_per_layer 2, Cout == 64, Cin 64 or 128, W >= 32, H >= 8, tensors < 2 GiB): keep the two-kernel form. */
+int smaat_dsconv_bwd_rows_ok(int kpl, int Cin, int Cout, int H, int W);
+int smaat_dsconv_bwd_rows_num_rows(int N, int Cin, int H, int W);
+int smaat_dsconv_bwd_rows_h(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* bn_mean,
+                            const float* bn_invstd, const float* dz, long dz_bs, const void* dz_amax, const void* planes_t,
+                            const float* w_dw, float* dx, long dx_bs, float* ws, float* dw_out, float* db_out, float* rpart, int N,
+                            int Cin, int kpl, int Cout, int H, int W, void* stream);
+
 /* ---- fused DepthwiseSeparableConv forward on the bf16-split matrix pipe (training path of the plane-dominated
  *      layers; same reference call site as smaat_dsconv_fwd, models/layers.py:47-50).  The depthwise output never
  *      goes through HBM: producer waves stage the halo tile, run the 3x3 stage and write bf16 split planes straight

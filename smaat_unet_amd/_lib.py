@@ -33,6 +33,9 @@ SIGNATURES = {
     "smaat_dsconv_wgrad_split_num_splits": [_I, _I, _I, _I, _I],
     "smaat_dsconv_wgrad_split": [_P, _L, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "smaat_dsconv_wgrad_split_t": [_P, _I, _L, _P, _P, _P, _P, _P, _I, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "smaat_dsconv_bwd_rows_ok": [_I, _I, _I, _I, _I],
+    "smaat_dsconv_bwd_rows_num_rows": [_I, _I, _I, _I],
+    "smaat_dsconv_bwd_rows_h": [_P, _L, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "smaat_dw3x3_bwd_ws_rows": [_I, _I, _I, _I],
     "smaat_dw3x3_bwd": [_P, _L, _P, _L, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "smaat_dw3x3_strip_ok": [_I, _I, _I],
@@ -263,6 +266,8 @@ WORK_MODELS = {
     "smaat_dsconv_wgrad_split": _w_dsconv_wgrad,
     "smaat_dsconv_wgrad_split_h": lambda a: (2.0 * a[12] * a[13] * a[14] * a[15] * a[16] * a[17],
                                              4.0 * a[12] * (a[13] + a[15]) * a[16] * a[17]),
+    "smaat_dsconv_bwd_rows_h": lambda a: (2.0 * a[17] * a[18] * a[19] * a[20] * a[21] * a[22],
+                                          4.0 * a[17] * (a[20] + 2 * a[18]) * a[21] * a[22]),  # dz + x read, dx written
     "smaat_dsconv_fwd_rows_amax": lambda a: (2.0 * a[12] * a[13] * a[14] * a[15] * a[16] * a[17],
                                              4.0 * a[12] * (a[13] + a[15]) * a[16] * a[17]),
     "smaat_dsconv_wgrad_split_t": lambda a: (2.0 * a[12] * a[13] * a[14] * a[15] * a[16] * a[17],

@@ -57,6 +57,9 @@ int launch_dw3x3_bwd(const void*, int, long, const void*, int, long, const float
                      int, int, hipStream_t, const float*, const float*, float*, const float*, const float*);
 int dw_bwd_groups(int N, int Cin, int H, int W);
 int launch_dw_reduce_split(const float* part, int rows, int Cdw, float* dw, float* db, hipStream_t st);
+int dsconv_bwd_rows_ok(int kpl, int Cin, int M, int H, int W);          // dsbwd.hip
+int dsconv_bwd_rows_num_rows(int N, int Cin, int H, int W);
+int launch_dsconv_bwd_rows(DsBwArgs& a, int kpl, hipStream_t st);
 int dw3x3_strip_ok(int kpl, int H, int W);
 
 int smaat_cbam_spconv_blocks_impl(int N, int H, int W);
@@ -284,6 +287,29 @@ int smaat_dw3x3_bwd_bnred(const float* x, long x_bs, const float* in_scale, cons
     CHK(launch_dw3x3_bwd(x, SMAAT_F32, x_bs, dy, SMAAT_F32, dy_bs, w_dw, dx, SMAAT_F32, dx_bs, ws, N, Cin, kpl, H, W, st, bn_mean,
                          bn_invstd, rpart, in_scale, in_shift));
     return launch_dw_reduce_split(ws, rows, Cdw, dw_out, db_out, st);
+}
+
+/* fused backward of a DepthwiseSeparableConv (dsbwd.hip): the pointwise data gradient is formed by MFMA on chip and consumed
+ * by the depthwise backward in the same kernel -- dY never exists in memory */
+int smaat_dsconv_bwd_rows_ok(int kpl, int Cin, int Cout, int H, int W) { return dsconv_bwd_rows_ok(kpl, Cin, Cout, H, W); }
+int smaat_dsconv_bwd_rows_num_rows(int N, int Cin, int H, int W) { return dsconv_bwd_rows_num_rows(N, Cin, H, W); }
+int smaat_dsconv_bwd_rows_h(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* bn_mean,
+                            const float* bn_invstd, const float* dz, long dz_bs, const void* dz_amax, const void* planes_t,
+                            const float* w_dw, float* dx, long dx_bs, float* ws, float* dw_out, float* db_out, float* rpart, int N,
+                            int Cin, int kpl, int Cout, int H, int W, void* stream) {
+    if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || !x || !dz || !dz_amax || !planes_t || !w_dw || !dx || !ws || !dw_out || !db_out)
+        return -1;
+    if ((in_scale == nullptr) != (in_shift == nullptr)) return -1;
+    DsBwArgs a{};
+    a.x = x; a.x_bs = x_bs; a.in_scale = in_scale; a.in_shift = in_shift; a.bn_mean = bn_mean; a.bn_invstd = bn_invstd;
+    a.dz = dz; a.dz_bs = dz_bs; a.dz_amax = (const unsigned*)dz_amax; a.planes_t = (const unsigned short*)planes_t;
+    a.a_kexp = (const int*)((const unsigned char*)planes_t + split_planes_h_kexp_offset(Cin * kpl, Cout));
+    a.w_dw = w_dw; a.dx = dx; a.dx_bs = dx_bs; a.part = ws; a.rpart = rpart;
+    a.N = N; a.Cin = Cin; a.K = Cin * kpl; a.M = Cout; a.H = H; a.W = W;
+    hipStream_t st = ST;
+    const int rc = launch_dsconv_bwd_rows(a, kpl, st);
+    if (rc) return rc;
+    return launch_dw_reduce_split(ws, dsconv_bwd_rows_num_rows(N, Cin, H, W), Cin * kpl, dw_out, db_out, st);
 }
 
 int smaat_bn_finalize(float* part, int T, int C, double count, const float* bias_shift, const float* gamma,

@@ -38,3 +38,27 @@ struct DsWgArgs {
     const unsigned* y_amax;   // NT == 2 (two-term fp16 split): amax buffers of the depthwise output (from the forward) and of dz
     const unsigned* dz_amax;
 };
+
+// fused backward of a DepthwiseSeparableConv (dsbwd.hip): dz -> dY (MFMA, on chip) -> dX, depthwise weight / bias gradient
+// partials, and the backward sums of the previous BatchNorm when its activation is applied on load
+struct DsBwArgs {
+    const float* x;   // [N][Cin][H][W]: the depthwise input (the PRE-BatchNorm tensor of the previous half when in_scale != null)
+    long x_bs;
+    const float* in_scale;  // [Cin] or null: previous BatchNorm + ReLU applied on load
+    const float* in_shift;
+    const float* bn_mean;    // with in_scale: the previous BatchNorm's batch statistics (for rpart)
+    const float* bn_invstd;
+    const float* dz;  // [N][M][H][W]
+    long dz_bs;
+    const unsigned* dz_amax;         // amax buffer of dz (common.h)
+    const unsigned short* planes_t;  // fp16 image of w_pw^T: [M/16][2][K][16] (smaat_split_planes_h, src_t = 1)
+    const int* a_kexp;               // its power-of-two exponent (the image's trailer)
+    const float* w_dw;               // [K][9]
+    float* dx;        // [N][Cin][H][W]
+    long dx_bs;
+    float* part;      // [rows][K][10]: depthwise weight (9 taps) + bias gradient partials, rows = dsconv_bwd_rows_num_rows()
+    float* rpart;     // [2][rows][Cin] or null: sum g, sum g * xhat of the previous BatchNorm (g = dX * [act > 0])
+    int N, Cin, K, M, H, W, P;
+    int strips, bands, RB, items, ips, nhalf, wgh;  // set by the launcher
+    unsigned x_bytes, dz_bytes, dx_bytes;           // buffer descriptor ranges (set by the launcher)
+};

@@ -919,6 +919,29 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None, i
             _lib.check(L.smaat_dsconv_wgrad(_ptr(x), x_bs, _ptr(isc), _ptr(ish), _ptr(w_dw), _ptr(b_dw), _ptr(dz), dz_bs,
                                             _ptr(ws), _ptr(dw_pw), n, cin, kpl, cout, h, w, s), "smaat_dsconv_wgrad")
         del ws
+    # round 6: dgrad GEMM + depthwise backward in ONE kernel where it takes the shape (the 288^2 layers: Cout = 64, Cin 64 | 128):
+    # dY = W^T dZ is formed row by row on chip and never written (include/smaat_hip.h "fused BACKWARD"); dx bit-identical
+    if (FUSED_BWD and a_dz is not None and need_dx and _split_dgrad_ok(cout, k) and (in_aff is None or bnred is not None)
+            and L.smaat_dsconv_bwd_rows_ok(kpl, cin, cout, h, w)):
+        planes_t = _split_planes_h_raw(w_pw.reshape(cout, k), transpose=True)
+        rows = L.smaat_dsconv_bwd_rows_num_rows(n, cin, h, w)
+        dx = _new(x, n, cin, h, w)
+        ws2 = _new(x, rows, k, 10)
+        dw_dw = _new(x, k, 1, 3, 3)
+        db_dw = _new(x, k)
+        isc, ish = in_aff if in_aff is not None else (None, None)
+        mean, invstd = bnred if in_aff is not None else (None, None)
+        rpart = _new(x, 2, rows, cin) if in_aff is not None else None
+        rc = L.smaat_dsconv_bwd_rows_h(_ptr(x), x_bs, _ptr(isc), _ptr(ish), _ptr(mean), _ptr(invstd), _ptr(dz), dz_bs, _ptr(a_dz),
+                                       _ptr(planes_t), _ptr(w_dw), _ptr(dx), cin * h * w, _ptr(ws2), _ptr(dw_dw), _ptr(db_dw),
+                                       _ptr(rpart), n, cin, kpl, cout, h, w, s)
+        if rc != -2:
+            _lib.check(rc, "smaat_dsconv_bwd_rows_h")
+            if in_aff is not None:
+                return dx, dw_dw, db_dw, dw_pw, (rpart, rows)
+            if bnred is not None:
+                return dx, dw_dw, db_dw, dw_pw, None
+            return dx, dw_dw, db_dw, dw_pw
     # data gradient of the pointwise conv: dY = W^T dZ  (wt := w_pw in its natural [Cout][K] layout)
     if _split_dgrad_ok(cout, k):
         # A[m' = k][c = co] = w_pw[co][k]: planes of the transposed weight
@@ -1018,6 +1041,11 @@ def _dsconv_bwd_bf16(x, x_bs, w_dw, b_dw, w_pw, dz, kpl, need_dx, y, bnred, in_a
 
 # keep the depthwise output of the forward for the backward (streamed weight gradient).  Set to
 # False to trade speed for memory: the backward then recomputes it inside the wgrad kernel.
+# dgrad GEMM + depthwise backward in one kernel (csrc/dsbwd.hip).  OFF by default: correct (dX bit-identical to the two-kernel form)
+# but measured SLOWER -- inc.1 at batch 32: 1.23 ms against 0.40 + 0.53 ms, up4.0 2.48 against 0.76 + 1.06; the step 29.4 against
+# 28.0 ms (profiles/r6/dsbwd_ablate_r6i.txt: one workgroup of 12 waves per CU and a barrier per row leave every wave's chain of
+# waits exposed; the dword-granular row accesses a 30-column stride forces cost 0.5 ms of the 1.23).  SMAAT_FUSED_BWD=1 selects it.
+FUSED_BWD = os.environ.get("SMAAT_FUSED_BWD", "0") == "1"
 KEEP_DEPTHWISE_OUTPUT = True
 
 

@@ -532,3 +532,106 @@ def test_soak_split_gemms_h(shape):
     def wgrad():
         assert L.smaat_pointwise_wgrad_h(P(x), C * H * W, P(am), P(dz), M * H * W, P(adz), P(ws), P(dw), N, C, M, H, W, stream(dev)) == 0
     _soak(wgrad, [dw], "k_wgrad_split<NT=2>")
+
+
+# ------------------------------------------------------------------------------------------------ round 6: fused backward
+def _bwd_two_kernel_and_fused(L, dev, N, Cin, Cout, H, W, aff, gamma_mode="normal"):
+    """(two-kernel results, fused results) of the DepthwiseSeparableConv backward on identical inputs: dgrad GEMM
+    (smaat_pointwise_fwd_split_h on the transposed image) + smaat_dw3x3_bwd[_bnred]  vs  smaat_dsconv_bwd_rows_h"""
+    K = 2 * Cin
+    z = rnd(1, N, Cin, H, W) * 1.3 + 0.2
+    w_pw = T(rnd(4, Cout, K, scale=0.2), dev)
+    w_dw = T(rnd(3, K, 9, scale=0.3), dev)
+    dz = T(rnd(8, N, Cout, H, W) * np.exp(2 * rnd(9, N, Cout, 1, 1)) * 1e-3, dev)
+    adz = _publish(dz)
+    pl_t = _h_image(L, dev, w_pw, transposed=True)
+    x = T(z, dev)
+    sc = sh = mean = invstd = None
+    if aff:
+        mean_n = z.mean(axis=(0, 2, 3)).astype(np.float32)
+        invstd_n = (1.0 / np.sqrt(z.var(axis=(0, 2, 3)) + 1e-5)).astype(np.float32)
+        gam = np.random.default_rng(8).uniform(0.5, 1.5, Cin).astype(np.float32)
+        if gamma_mode == "zero":
+            gam[::2] = 0.0
+        bet = (np.abs(rnd(9, Cin, scale=0.3)) + 0.05).astype(np.float32)
+        sc_n = (gam * invstd_n).astype(np.float32)
+        sc, sh, mean, invstd = T(sc_n, dev), T((bet - mean_n * sc_n).astype(np.float32), dev), T(mean_n, dev), T(invstd_n, dev)
+    # ---- two kernels
+    dy = torch.full((N, K, H, W), float("nan"), device=dev)
+    assert L.smaat_pointwise_fwd_split_h(P(dz), Cout * H * W, P(adz), P(pl_t), None, P(dy), K * H * W, None, N, Cout, K, H, W, stream(dev)) == 0
+    rows = L.smaat_dw3x3_bwd_ws_rows(N, Cin, H, W)
+    ws = torch.empty((rows, K, 10), device=dev)
+    a = dict(dx=torch.full((N, Cin, H, W), float("nan"), device=dev), dw=torch.full((K, 9), float("nan"), device=dev),
+             db=torch.full((K,), float("nan"), device=dev))
+    if aff:
+        rp = torch.full((2, rows - 1, Cin), float("nan"), device=dev)
+        assert L.smaat_dw3x3_bwd_bnred(P(x), Cin * H * W, P(sc), P(sh), P(dy), K * H * W, P(w_dw), P(a["dx"]), Cin * H * W, P(ws), P(a["dw"]),
+                                       P(a["db"]), P(mean), P(invstd), P(rp), N, Cin, 2, H, W, stream(dev)) == 0
+        a["r1"], a["r2"] = rp[0].double().sum(0), rp[1].double().sum(0)
+    else:
+        assert L.smaat_dw3x3_bwd(P(x), Cin * H * W, P(dy), K * H * W, P(w_dw), P(a["dx"]), Cin * H * W, P(ws), P(a["dw"]), P(a["db"]), N, Cin, 2,
+                                 H, W, stream(dev)) == 0
+    # ---- fused
+    assert L.smaat_dsconv_bwd_rows_ok(2, Cin, Cout, H, W) == 1
+    rows2 = L.smaat_dsconv_bwd_rows_num_rows(N, Cin, H, W)
+    ws2 = torch.full((rows2, K, 10), float("nan"), device=dev)
+    b = dict(dx=torch.full((N, Cin, H, W), float("nan"), device=dev), dw=torch.full((K, 9), float("nan"), device=dev),
+             db=torch.full((K,), float("nan"), device=dev))
+    rp2 = torch.full((2, rows2, Cin), float("nan"), device=dev) if aff else None
+    assert L.smaat_dsconv_bwd_rows_h(P(x), Cin * H * W, P(sc), P(sh), P(mean), P(invstd), P(dz), Cout * H * W, P(adz), P(pl_t), P(w_dw),
+                                     P(b["dx"]), Cin * H * W, P(ws2), P(b["dw"]), P(b["db"]), P(rp2), N, Cin, 2, Cout, H, W, stream(dev)) == 0
+    if aff:
+        b["r1"], b["r2"] = rp2[0].double().sum(0), rp2[1].double().sum(0)
+    torch.cuda.synchronize()
+    return a, b
+
+
+@pytest.mark.parametrize("aff", [False, True])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 40, 64), (1, 128, 64, 24, 96), (2, 64, 64, 37, 70), (1, 64, 64, 9, 32), (3, 128, 64, 75, 45),
+                                   (1, 64, 64, 288, 288)])
+def test_fused_backward_equals_the_two_kernel_form(shape, aff):
+    """smaat_dsconv_bwd_rows_h (dY formed by MFMA on chip, consumed in the same kernel) against the pair it replaces: dX BIT-identical
+    (same MFMA sequence as k_pw_split_p<NT = 2>, same FMA order as k_dw3x3_bwd_rows), the depthwise weight / bias gradients and the
+    previous BatchNorm's backward sums f32-class (their partial sums are cut differently: per workgroup instead of per wave).
+    Shapes: strips that do not divide the width (70, 45: last tile partly outside), bands that do not divide the height, both
+    channel-half counts, the 288 x 288 plane of BASELINE configs[1]."""
+    L, dev = _lib.get(), DEV
+    if aff and shape[4] % 2:
+        pytest.skip("the two-kernel form has no on-load activation for odd widths (smaat_dw3x3_strip_ok)")
+    a, b = _bwd_two_kernel_and_fused(L, dev, *shape, aff)
+    if shape[4] % 4 == 0:
+        assert torch.equal(a["dx"], b["dx"]), float((a["dx"] - b["dx"]).abs().max())
+    else:  # (odd widths: the two-kernel form runs its general kernels, whose sums associate differently)
+        assert rel(b["dx"].cpu().numpy(), a["dx"].cpu().numpy()) < 1e-6
+    assert rel(b["dw"].cpu().numpy(), a["dw"].cpu().numpy()) < 2e-6
+    assert rel(b["db"].cpu().numpy(), a["db"].cpu().numpy()) < 2e-6
+    if aff:
+        assert rel(b["r1"].cpu().numpy(), a["r1"].cpu().numpy()) < 1e-5
+        assert rel(b["r2"].cpu().numpy(), a["r2"].cpu().numpy()) < 1e-5
+
+
+def test_fused_backward_degenerate_gamma_and_refusals():
+    L, dev = _lib.get(), DEV
+    a, b = _bwd_two_kernel_and_fused(L, dev, 2, 64, 64, 32, 64, True, gamma_mode="zero")
+    assert torch.equal(a["dx"], b["dx"])
+    assert rel(b["r2"].cpu().numpy(), a["r2"].cpu().numpy()) < 1e-5 and rel(b["r1"].cpu().numpy(), a["r1"].cpu().numpy()) < 1e-5
+    for bad in ((2, 32, 64, 32, 64), (2, 64, 128, 32, 64), (1, 64, 64, 32, 64), (2, 64, 64, 4, 64), (2, 64, 64, 32, 16)):
+        assert L.smaat_dsconv_bwd_rows_ok(*bad) == 0, bad
+
+
+def test_soak_fused_backward():
+    """1,000 bit-identical calls at the 288 x 288 plane (inline-asm dz loads with counted waits in the MFMA waves)"""
+    L, dev = _lib.get(), DEV
+    N, Cin, Cout, H, W = 4, 64, 64, 288, 288
+    K = 2 * Cin
+    x, dz = T(rnd(1, N, Cin, H, W), dev), T(rnd(8, N, Cout, H, W) * 1e-3, dev)
+    w_pw, w_dw = T(rnd(4, Cout, K, scale=0.2), dev), T(rnd(3, K, 9, scale=0.3), dev)
+    adz, pl_t = _publish(dz), _h_image(L, dev, w_pw, transposed=True)
+    rows = L.smaat_dsconv_bwd_rows_num_rows(N, Cin, H, W)
+    ws, dx = torch.empty((rows, K, 10), device=dev), torch.empty((N, Cin, H, W), device=dev)
+    dw, db = torch.empty((K, 9), device=dev), torch.empty((K,), device=dev)
+
+    def call():
+        assert L.smaat_dsconv_bwd_rows_h(P(x), Cin * H * W, None, None, None, None, P(dz), Cout * H * W, P(adz), P(pl_t), P(w_dw), P(dx),
+                                         Cin * H * W, P(ws), P(dw), P(db), None, N, Cin, 2, Cout, H, W, stream(dev)) == 0
+    _soak(call, [dx, dw, db], "k_dsconv_bwd_rows")

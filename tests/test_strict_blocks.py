@@ -140,7 +140,8 @@ def test_strict_rows_blocks_gpu(ops_strict_rows, tag, f16, monkeypatch):
     fwd = "smaat_dsconv_fwd_rows_amax" if f16 else "smaat_dsconv_fwd_rows"      # (f16: + the maximum of the depthwise output)
     wg = "smaat_dsconv_wgrad_split_h" if f16 else "smaat_dsconv_wgrad_split"    # (f16: the recompute kernel on the fp16 split)
     assert seen.count(fwd) == 2 and seen.count(wg) == 2, sorted(set(seen))
-    assert ("smaat_pointwise_fwd_split_h" in seen) == f16
+    # the data gradient: the fp16-split GEMM, or (ops.FUSED_BWD, round 6) the fused backward that forms dY on chip
+    assert ("smaat_pointwise_fwd_split_h" in seen or "smaat_dsconv_bwd_rows_h" in seen) == f16
 
 
 @pytest.mark.gpu
