@@ -8,7 +8,7 @@ emu_backend.install()
 gd = '/root/repo/tests/golden'
 name = sys.argv[1]
 for mode in ("off", "h3", "h4"):
-    ops.F16_SPLIT = mode != "off"
+    ops.policy.f16_split = mode != "off"
     os.environ["SMAAT_EMU_H4"] = "1" if mode == "h4" else ""
     ops.invalidate_weight_images()
     rep = {}

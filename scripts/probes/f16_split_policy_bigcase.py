@@ -8,7 +8,7 @@ emu_backend.install()
 gd = '/root/repo/tests/golden'
 name = sys.argv[1]
 for ms in (4096, 0):
-    ops.F16_MIN_SAMPLES = ms
+    ops.policy.f16_min_samples = ms
     ops.invalidate_weight_images()
     rep = {}
     try:

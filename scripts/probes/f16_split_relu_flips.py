@@ -16,7 +16,7 @@ rec = {}
 orig = ops._affine_act_raw
 orig_bn = ops._bn_finalize_raw
 def run(f16):
-    ops.F16_SPLIT = f16; ops.invalidate_weight_images()
+    ops.policy.f16_split = f16; ops.invalidate_weight_images()
     model = S.SmaAt_UNet(meta["n_channels"], meta["n_classes"])
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in P.items()}); model.train()
     pre = []

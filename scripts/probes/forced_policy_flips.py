@@ -21,10 +21,10 @@ DEV = torch.device("cuda:0")
 name = sys.argv[1] if len(sys.argv) > 1 else "unet_3x21_n1_32"
 g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
 meta = json.loads(str(g["meta"]))
-ops.F16_SPLIT = False
+ops.policy.f16_split = False
 res = {}
 for policy in ("auto", "all"):
-    ops.WGRAD_RECOMPUTE = policy
+    ops.policy.wgrad_recompute = policy
     ops.invalidate_weight_images()
     model, _ = _load_model(meta)
     x = torch.from_numpy(g["x"]).to(DEV).requires_grad_(True)

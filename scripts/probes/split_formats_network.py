@@ -21,7 +21,7 @@ from oracle import params as oparams  # noqa: E402
 from smaat_unet_amd import ops as _ops  # noqa: E402
 from tests.test_host_emu import check_param_grads, check_summary, rel  # noqa: E402
 
-_ops.SPLIT_POLICY = "all"  # every supported layer through the split-GEMM wiring
+_ops.policy.split_policy = "all"  # every supported layer through the split-GEMM wiring
 GOLD = os.path.join(ROOT, "tests", "golden")
 for name in ("unet_12x1_n2_32", "unet_3x21_n1_32", "unet_12x1_n2_64x48"):
     path = os.path.join(GOLD, name + ".npz")

@@ -31,6 +31,35 @@ F32 = torch.float32
 # --------------------------------------------------------------------------------------
 # plumbing
 # --------------------------------------------------------------------------------------
+
+class Policy:
+    """The kernel-selection switches of this module in ONE place: which entry point of include/smaat_hip.h runs
+    for a layer follows from the shape, the storage type and these fields (DESIGN.md section 4 has the table).  Defaults are the
+    measured policy; every field has the environment variable that sets it at import for A/B runs.  Tests and probes patch
+    fields of `ops.policy` (monkeypatch.setattr(ops.policy, "f16_split", False)) -- no module globals, no re-import."""
+
+    def __init__(self):
+        e = os.environ.get
+        self.f16_split = e("SMAAT_F16_SPLIT", "1") != "0"
+        self.f16_min_samples = int(e("SMAAT_F16_MIN_SAMPLES", "4096"))
+        self.split_policy = e("SMAAT_SPLIT_POLICY", "auto")
+        self.fuse_dw_split = e("SMAAT_FUSE_DW", "auto")
+        self.wgrad_recompute = e("SMAAT_WGRAD_RECOMPUTE", "auto")
+        self.bf16_recompute = e("SMAAT_BF16_RECOMPUTE", "1") != "0"
+        self.fwd_rows = e("SMAAT_FWD_ROWS", "auto")
+        self.cbam_three_pass = e("SMAAT_CBAM_THREE_PASS", "1") != "0"
+        self.plane_cache = e("SMAAT_PLANE_CACHE", "1") != "0"
+        self.keep_depthwise_output = True
+        self.fuse_first_activation = True
+        self.splitk_train_budget = int(e("SMAAT_SPLITK_TRAIN", "2048"))
+        self.fused_bwd = e("SMAAT_FUSED_BWD", "0") == "1"
+
+    def snapshot(self):
+        return dict(vars(self))
+
+
+policy = Policy()
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -197,14 +226,14 @@ def _split_on():
 # f32-MFMA forward for the plane-dominated layers, which is MFMA-bound at the f32 rate).  Inference
 # (running statistics, typically batch 1) keeps the fused f32 kernel for the narrow layers: one launch
 # instead of three matters more there than the matrix rate.
-SPLITK_TRAIN_BUDGET = int(os.environ.get("SMAAT_SPLITK_TRAIN", "2048"))  # workgroup items a sliced training GEMM may use (0 = off)
-FUSE_FIRST_ACTIVATION = True  # DoubleConvDS: apply the first BatchNorm + ReLU on load instead of writing y1
-SPLIT_POLICY = os.environ.get("SMAAT_SPLIT_POLICY", "auto")  # "auto" = the measured policy; "all" = every supported shape
+# policy.splitk_train_budget: workgroup items a sliced training GEMM may use (0 = off)
+# policy.fuse_first_activation: DoubleConvDS: apply the first BatchNorm + ReLU on load instead of writing y1
+# policy.split_policy: "auto" = the measured policy; "all" = every supported shape
 
 
 def _split_all():
     # mode 1 (plain bf16 operands, one MFMA per product) is 6x cheaper on the matrix pipe: use it wherever supported
-    return SPLIT_POLICY == "all" or _lib.get().smaat_split_mode() == 1
+    return policy.split_policy == "all" or _lib.get().smaat_split_mode() == 1
 
 
 def _split_fwd_ok(k, cout, train=True):
@@ -224,7 +253,7 @@ def _split_dgrad_ok(cout, k):
 # depthwise kernel that writes its operand also leaves max |y|), the data gradient and the streamed weight gradient (the
 # BatchNorm-backward apply kernel leaves max |dz|).  Everything else -- fused forwards, inference, ConvTranspose, OutConv,
 # callers that pass no maxima -- runs the exact three-term bf16 split as before.  SMAAT_F16_SPLIT=0 switches it off (A/B).
-F16_SPLIT = os.environ.get("SMAAT_F16_SPLIT", "1") != "0"
+# policy.f16_split (default os.environ.get("SMAAT_F16_SPLIT", "1") != "0")
 # ... and only where the train-mode BatchNorm behind the GEMM averages at least this many samples per channel (N * H * W).
 # The two-term split's per-product error is ~3x an f32 rounding (22-23 significant bits against exact products): invisible at
 # the benchmark sizes (every reference fixture at 288^2 / 256^2 holds at unchanged bounds), but on planes of a few pixels one
@@ -232,13 +261,13 @@ F16_SPLIT = os.environ.get("SMAAT_F16_SPLIT", "1") != "0"
 # 3 is 36 samples: one flip is 3 % of them), and three times the forward noise means three times the flips -- the
 # counter-examples are recorded in profiles/r5/f16_split_small_plane_counterexamples.txt (SMAAT_F16_MIN_SAMPLES=0 reproduces
 # them).  BASELINE configs: 32 x 18 x 18 = 10,368 at the bottleneck of configs[1], 16 x 16 x 16 = 4,096 for configs[4].
-F16_MIN_SAMPLES = int(os.environ.get("SMAAT_F16_MIN_SAMPLES", "4096"))
+# policy.f16_min_samples (default int(os.environ.get("SMAAT_F16_MIN_SAMPLES", "4096")))
 _AMAX_LOCK = threading.Lock()
 _AMAX_ARENA = {}  # (device, stream) -> [int32 tensor of zeros, next free word]
 
 
 def _f16_on():
-    if not F16_SPLIT or not _split_on() or _lib.get().smaat_split_mode() != 3:
+    if not policy.f16_split or not _split_on() or _lib.get().smaat_split_mode() != 3:
         return False
     from . import train_ops
     return not train_ops.active()  # (the traceable operators declare their saved tensors up front)
@@ -288,12 +317,24 @@ def _zero_grad_words(ref, n):
 
 
 def set_matrix_mode(mode):
-    """"f32" = f32-MFMA kernels only; "f32_split" (default) = exact three-term bf16 operand split (f32-class
-    error); "bf16" = bf16 operands / f32 accumulation (mixed precision, BASELINE configs[3]).  Returns the
-    previous mode string."""
-    codes = {"f32": 0, "bf16": 1, "f32_split": 3}
+    """Arithmetic of the f32-STORAGE matrix path (process-wide A/B switch; precision proper is chosen per call tree, see
+    `precision`).  Returns the previous mode string.
+      "f32_split"        (default) f32-class split GEMMs on the 16-bit matrix pipe: the TWO-term fp16 operand split (three MFMAs
+                         per product, operands to 22-23 bits, ~3 x an f32 rounding per product) where the operand maxima are at
+                         hand and the BatchNorm behind the GEMM averages >= policy.f16_min_samples samples (i.e. it switches
+                         with batch x plane size), the exact three-term bf16 split (six MFMAs) everywhere else;
+      "f32_split_exact"  the exact three-term bf16 split everywhere (= "f32_split" with policy.f16_split off);
+      "f32"              f32-MFMA kernels only (the reference's multiplier width; bench.py's `f32_mfma_only` leg);
+      "bf16"             single-term bf16 operands on f32 storage (round-2 mixed mode; bench.py --precision bf16_operands)."""
+    codes = {"f32": 0, "bf16": 1, "f32_split": 3, "f32_split_exact": 3}
     prev = _lib.get().smaat_set_split_mode(codes[mode])
-    return {0: "f32", 1: "bf16", 2: "f32_split2", 3: "f32_split"}[prev]
+    was_exact = not policy.f16_split
+    if mode in ("f32_split", "f32_split_exact"):
+        if policy.f16_split != (mode == "f32_split"):
+            policy.f16_split = mode == "f32_split"
+            invalidate_weight_images()
+    name = {0: "f32", 1: "bf16", 2: "f32_split2", 3: "f32_split"}[prev]
+    return "f32_split_exact" if (name == "f32_split" and was_exact) else name
 
 
 # ---- operand images of the pointwise weights: one refresh launch per optimizer step -------------------------------------------
@@ -306,7 +347,7 @@ def set_matrix_mode(mode):
 # `.data` bump nothing, an image is served at most ONCE per refresh -- its second use (a new pass over the network) refreshes all
 # images again, so such writes are honoured from the next pass on, at one launch per pass.  The returned image is shared: callers
 # only read it.  SMAAT_PLANE_CACHE=0 restores one launch per use.
-PLANE_CACHE = os.environ.get("SMAAT_PLANE_CACHE", "1") != "0"
+# policy.plane_cache (default os.environ.get("SMAAT_PLANE_CACHE", "1") != "0")
 _PLANES = {}
 _PLANES_TABLE = {}  # tuple of entry ids -> device descriptor table
 _PLANES_LOCK = threading.RLock()  # (replicas / a background evaluation thread share the cache)
@@ -359,7 +400,7 @@ def _weight_planes_locked(w2d, transpose, kind):
         return planes
 
     base = w2d._base if w2d._base is not None else w2d
-    if (not PLANE_CACHE or not w2d.is_contiguous() or base.dtype != torch.float32 or base.is_inference()
+    if (not policy.plane_cache or not w2d.is_contiguous() or base.dtype != torch.float32 or base.is_inference()
             or (w2d.is_cuda and torch.cuda.is_current_stream_capturing())):
         return direct()  # (inference tensors have no version counter; a capture must not bake in a cache decision)
     stream = _stream(w2d)
@@ -503,7 +544,7 @@ def _dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None,
     n, k, h, w = y.shape
     # layers that leave the chip under-filled (18 x 18 at batch 32: 384 serial chains of 64 chunks): the contraction is cut
     # into slices that run as virtual images; the slice reduction writes z and its BatchNorm partials
-    s_k = L.smaat_pointwise_splitk_slices(n, k, cout, h, w, SPLITK_TRAIN_BUDGET) if SPLITK_TRAIN_BUDGET > 0 else 1
+    s_k = L.smaat_pointwise_splitk_slices(n, k, cout, h, w, policy.splitk_train_budget) if policy.splitk_train_budget > 0 else 1
     if s_k > 1:
         z = _new(y, n, cout, h, w)
         ws = _new(y, n * s_k * cout * h * w)
@@ -567,19 +608,19 @@ def _dsconv_fwd_bf16(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, 
 #   "auto" = use it where the depthwise output is not kept (forward under no_grad, eval-mode forward) on the
 #            plane-dominated layers (Cout <= 128: one or two 64-channel tiles re-run the cheap depthwise stage);
 #   "train" = also in training (side output written); "all" = every supported shape; "off".
-FUSE_DW_SPLIT = os.environ.get("SMAAT_FUSE_DW", "auto")
+# policy.fuse_dw_split (default os.environ.get("SMAAT_FUSE_DW", "auto"))
 
 
 # Round 4: weight gradient with the depthwise output recomputed by the GEMM's producer waves (csrc/dswgrad.hip).  Where
 # it applies, training runs the fused forward WITHOUT the side output and keeps no depthwise tensor at all: the
 # 2x-expanded tensor is neither written (forward) nor read (weight gradient).  "auto" = the measured policy
 # (profiles/r4), "all" = every shape the kernels take, "off" = the round-3 behaviour.
-WGRAD_RECOMPUTE = os.environ.get("SMAAT_WGRAD_RECOMPUTE", "auto")
-BF16_RECOMPUTE = os.environ.get("SMAAT_BF16_RECOMPUTE", "1") != "0"  # the same policy under bf16 storage (A/B switch)
+# policy.wgrad_recompute (default os.environ.get("SMAAT_WGRAD_RECOMPUTE", "auto"))
+# policy.bf16_recompute: the same policy under bf16 storage (A/B switch)
 
 
 def _recompute_wgrad_ok(n, cin, h, w, kpl, cout):
-    if WGRAD_RECOMPUTE == "off" or FUSE_DW_SPLIT == "off" or not _split_on():
+    if policy.wgrad_recompute == "off" or policy.fuse_dw_split == "off" or not _split_on():
         return False
     from . import train_ops
     if train_ops.active():  # (the traceable operators declare their saved tensors up front: kept depthwise outputs)
@@ -587,7 +628,7 @@ def _recompute_wgrad_ok(n, cin, h, w, kpl, cout):
     L = _lib.get()
     if not L.smaat_dsconv_wgrad_split_ok(kpl, cout, h, w) or L.smaat_dsconv_split_num_slots(n, h, w) <= 0:
         return False
-    if WGRAD_RECOMPUTE == "all":
+    if policy.wgrad_recompute == "all":
         return True
     # a 64-channel K tile per workgroup: layers with fewer input channels (the 12-channel stem) would idle most producer
     # threads; plane-dominated layers only (the deep layers are not HBM-bound in f32)
@@ -604,13 +645,13 @@ def _recompute_operand_ok(x):
 
 
 def _fused_dw_ok(n, h, w, kpl, cout, keep_y, cin=0):
-    if FUSE_DW_SPLIT == "off" or kpl != 2 or not _split_on():
+    if policy.fuse_dw_split == "off" or kpl != 2 or not _split_on():
         return False
     if _lib.get().smaat_dsconv_split_num_slots(n, h, w) <= 0:
         return False
-    if FUSE_DW_SPLIT == "all":
+    if policy.fuse_dw_split == "all":
         return True
-    if not keep_y or FUSE_DW_SPLIT == "train":
+    if not keep_y or policy.fuse_dw_split == "train":
         return cout <= 128
     # training keeps the depthwise tensor for the weight gradient: the kernel then writes it as a side output.
     # Measured per layer on MI355X (profiles/r2/layer_bench_r2v.txt): that wins where one 64-row output tile covers
@@ -645,7 +686,7 @@ def _dsconv_fwd_fused(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None,
 # Row-walking fused forward (csrc/dsrows.hip, round 4): the depthwise window in the producer threads' registers, the
 # pointwise weight's MFMA fragments in the consumer waves' registers; no depthwise side output (the weight gradient
 # recomputes it).  "auto": wherever the kernel takes the shape and nothing has to be kept; "off": the tile kernel.
-FWD_ROWS = os.environ.get("SMAAT_FWD_ROWS", "auto")
+# policy.fwd_rows (default os.environ.get("SMAAT_FWD_ROWS", "auto"))
 
 
 def _dsconv_fwd_rows(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, in_shift=None, out_dtype=None, amx=None):
@@ -653,7 +694,7 @@ def _dsconv_fwd_rows(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, 
     out_dtype = torch.bfloat16: mixed precision (x f32 | bf16, bf16 weight image, z bf16).
     amx (f32 storage; see _half_forward): the kernel also leaves max |y| of the depthwise output it forms -- never stored -- in
     the first amax buffer, for the two-term fp16 recompute weight gradient of the backward"""
-    if FWD_ROWS == "off":
+    if policy.fwd_rows == "off":
         return None
     L = _lib.get()
     x, x_bs = _planes(x)
@@ -903,7 +944,7 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None, i
         isc, ish = in_aff if in_aff is not None else (None, None)
         dw_pw = _new(x, cout, k, 1, 1)
         rc = -2
-        if _split_on() and WGRAD_RECOMPUTE != "off" and L.smaat_dsconv_wgrad_split_ok(kpl, cout, h, w):
+        if _split_on() and policy.wgrad_recompute != "off" and L.smaat_dsconv_wgrad_split_ok(kpl, cout, h, w):
             ws = _new(x, L.smaat_dsconv_wgrad_split_num_splits(n, cin, cout, h, w), cout, k)
             if a_y is not None and a_dz is not None:  # the forward left max |y|, the BatchNorm apply max |dz|: fp16 split
                 rc = L.smaat_dsconv_wgrad_split_h(_ptr(x), x_bs, _ptr(isc), _ptr(ish), _ptr(w_dw), _ptr(b_dw), _ptr(a_y), _ptr(dz),
@@ -921,7 +962,7 @@ def _dsconv_bwd_raw(x, w_dw, b_dw, w_pw, dz, kpl, need_dx, y=None, bnred=None, i
         del ws
     # round 6: dgrad GEMM + depthwise backward in ONE kernel where it takes the shape (the 288^2 layers: Cout = 64, Cin 64 | 128):
     # dY = W^T dZ is formed row by row on chip and never written (include/smaat_hip.h "fused BACKWARD"); dx bit-identical
-    if (FUSED_BWD and a_dz is not None and need_dx and _split_dgrad_ok(cout, k) and (in_aff is None or bnred is not None)
+    if (policy.fused_bwd and a_dz is not None and need_dx and _split_dgrad_ok(cout, k) and (in_aff is None or bnred is not None)
             and L.smaat_dsconv_bwd_rows_ok(kpl, cin, cout, h, w)):
         planes_t = _split_planes_h_raw(w_pw.reshape(cout, k), transpose=True)
         rows = L.smaat_dsconv_bwd_rows_num_rows(n, cin, h, w)
@@ -1045,8 +1086,8 @@ def _dsconv_bwd_bf16(x, x_bs, w_dw, b_dw, w_pw, dz, kpl, need_dx, y, bnred, in_a
 # but measured SLOWER -- inc.1 at batch 32: 1.23 ms against 0.40 + 0.53 ms, up4.0 2.48 against 0.76 + 1.06; the step 29.4 against
 # 28.0 ms (profiles/r6/dsbwd_ablate_r6i.txt: one workgroup of 12 waves per CU and a barrier per row leave every wave's chain of
 # waits exposed; the dword-granular row accesses a 30-column stride forces cost 0.5 ms of the 1.23).  SMAAT_FUSED_BWD=1 selects it.
-FUSED_BWD = os.environ.get("SMAAT_FUSED_BWD", "0") == "1"
-KEEP_DEPTHWISE_OUTPUT = True
+# policy.fused_bwd (default os.environ.get("SMAAT_FUSED_BWD", "0") == "1")
+# policy.keep_depthwise_output (default True)
 
 
 # --------------------------------------------------------------------------------------
@@ -1078,13 +1119,13 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
         bf = False
         if _is_bf(x):
             x = x.float()
-    rec = (keep_y and _recompute_wgrad_ok(n, cin, h, w, kpl, cout) and (not bf or BF16_RECOMPUTE)
+    rec = (keep_y and _recompute_wgrad_ok(n, cin, h, w, kpl, cout) and (not bf or policy.bf16_recompute)
            and _recompute_operand_ok(x))
     if rec:
         keep_y = False  # the weight gradient recomputes the depthwise output from x: nothing to keep (y_dw = None)
     if amx is not None:
         amx.update(w=None, y=False, dz=False)
-        if not bf and use_batch_stats and n * h * w >= F16_MIN_SAMPLES and _f16_on():
+        if not bf and use_batch_stats and n * h * w >= policy.f16_min_samples and _f16_on():
             amx["w"] = _amax_words(x, 2)
             amx["dz"] = True  # (the backward's BatchNorm apply kernel will leave max |dz| in the second buffer)
     if bf:  # mixed precision: bf16 depthwise output, bf16 GEMM, bf16 z (the f32 kernel families are not involved)
@@ -1172,7 +1213,7 @@ class _DSConvBNReLU(torch.autograd.Function):
         # (mixed precision: the bf16 backward streams the kept depthwise output whatever input needs a gradient -- also
         # when only the BatchNorm affine parameters do)
         bfm = _is_bf(x) or mixed_precision_active()
-        keep_y = ((KEEP_DEPTHWISE_OUTPUT or bfm)
+        keep_y = ((policy.keep_depthwise_output or bfm)
                   and any(ctx.needs_input_grad[:7 if bfm else 4]))  # forward runs under no_grad
         amx = {} if keep_y else None
         y, z, st, y_dw, ubs = _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, momentum, eps,
@@ -1213,13 +1254,13 @@ class _DoubleConvDS(torch.autograd.Function):
                       ("double_conv.4.running_mean", rm2), ("double_conv.4.running_var", rv2)):
             _expect(t, (w_pw2.shape[0],), "double_conv.3/4 " + nm)
         w_dw1, w_pw1, w_dw2, w_pw2 = (t.contiguous() for t in (w_dw1, w_pw1, w_dw2, w_pw2))
-        keep_y = (KEEP_DEPTHWISE_OUTPUT or _is_bf(x) or mixed_precision_active()) and any(ctx.needs_input_grad[:17])
+        keep_y = (policy.keep_depthwise_output or _is_bf(x) or mixed_precision_active()) and any(ctx.needs_input_grad[:17])
         # the activation y1 = relu(bn1(z1)) is never written when every consumer can apply it on load:
         # the second half's forward (depthwise stage) and its depthwise backward (strip kernel: W % 4 == 0),
         # and the weight gradient reads the kept depthwise output, not y1
         n, _, h, w = x.shape
         bf = _is_bf(x) or mixed_precision_active()
-        fuse = (FUSE_FIRST_ACTIVATION and keep_y and g1 is not None
+        fuse = (policy.fuse_first_activation and keep_y and g1 is not None
                 and bool(_lib.get().smaat_dw3x3_strip_ok(kpl, h, w))
                 and (not bf or kpl <= 2))  # (bf16 storage: the row-streaming backward, kernels_per_layer <= 2)
         amx1, amx2 = ({}, {}) if keep_y else (None, None)  # operand maxima of the two halves (two-term fp16 split)
@@ -1336,7 +1377,7 @@ def dsconv_folded(x, w_dw, b_dw, fold, kpl, relu_out=True):
     cout = fold["w"].shape[0]
     ro = 1 if relu_out else 0
     z = _new(x, n, cout, h, w)
-    if fold["planes"] is not None and kpl == 2 and FUSE_DW_SPLIT != "off" and L.smaat_dsconv_split_num_slots(n, h, w) > 0:
+    if fold["planes"] is not None and kpl == 2 and policy.fuse_dw_split != "off" and L.smaat_dsconv_split_num_slots(n, h, w) > 0:
         rc = L.smaat_dsconv_fwd_split_act(_ptr(x), x_bs, None, None, _ptr(w_dw), _ptr(b_dw), _ptr(fold["planes"]),
                                           _ptr(fold["b"]), _ptr(z), cout * h * w, n, cin, kpl, cout, h, w, ro, _stream(x))
         if rc == 0:
@@ -1376,7 +1417,7 @@ class _DSConv(torch.autograd.Function):
         _expect_dsconv(x, w_dw, b_dw, w_pw, b_pw, kpl)
         w_dw = w_dw.contiguous()
         w_pw = w_pw.contiguous()
-        keep_y = KEEP_DEPTHWISE_OUTPUT and any(ctx.needs_input_grad[:4])
+        keep_y = policy.keep_depthwise_output and any(ctx.needs_input_grad[:4])
         rs = (_dsconv_fwd_split(x, w_dw, b_dw, w_pw, b_pw, kpl, False)
               if _split_fwd_ok(w_pw.shape[1], w_pw.shape[0], any(ctx.needs_input_grad[:5])) else None)
         if rs is not None:
@@ -1790,7 +1831,7 @@ def _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, 
         ks = wconv.shape[-1]
         maps = _new(dev, n, 2, h, w)
         rc = -2
-        if CBAM_THREE_PASS and use_ch:
+        if policy.cbam_three_pass and use_ch:
             # + the channel index of the per-pixel maximum, which lets the backward split the channels over waves
             amaxc = _new(dev, n, h, w, dtype=torch.int32)
             rc = L.smaat_cbam_sppool_idx_t(_ptr(x), x_bs, _ptr(sc), n, c, p, _ptr(maps), _ptr(amaxc), 1 if bf else 0, s_)
@@ -1838,7 +1879,7 @@ def _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, 
     return out, saved, (use_ch, use_sp, use_batch_stats)
 
 
-CBAM_THREE_PASS = os.environ.get("SMAAT_CBAM_THREE_PASS", "1") != "0"  # (0: the gate / main / final sequence everywhere)
+# policy.cbam_three_pass: (0: the gate / main / final sequence everywhere)
 
 
 def _cbam_mlp_backward(L, dev, ds, sc, avg, mx, ha, hm, w1, w2, n, c, s_):

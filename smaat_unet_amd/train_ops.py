@@ -73,7 +73,7 @@ def _dc_plan(x, w_pw1, g1, kpl, bf16, keep):
     """(fuse the first activation into its consumers?, element dtype of the activations)"""
     n, _, h, w = x.shape
     bf = bf16 or x.dtype == torch.bfloat16
-    fuse = (ops.FUSE_FIRST_ACTIVATION and keep and g1 is not None and bool(_lib.get().smaat_dw3x3_strip_ok(kpl, h, w))
+    fuse = (ops.policy.fuse_first_activation and keep and g1 is not None and bool(_lib.get().smaat_dw3x3_strip_ok(kpl, h, w))
             and (not bf or kpl <= 2))
     return fuse, (torch.bfloat16 if bf else x.dtype)
 
@@ -195,7 +195,7 @@ _N_CBAM_SAVED = 11
 
 
 def _cbam_has_index_map(h, w):
-    return ops.CBAM_THREE_PASS and (h * w) % 4 == 0
+    return ops.policy.cbam_three_pass and (h * w) % 4 == 0
 
 
 def _cbam_fake_saved(x, w1):

@@ -293,7 +293,7 @@ def test_aten_port_pinned_to_big_goldens(golden_dir, name):
 @pytest.mark.parametrize("tag", sorted(EVAL_BLOCKS))
 def test_eval_blocks_gpu(ops_eval, tag, policy, monkeypatch):
     from smaat_unet_amd import ops as _ops
-    monkeypatch.setattr(_ops, "SPLIT_POLICY", policy)
+    monkeypatch.setattr(_ops.policy, "split_policy", policy)
     run_eval_block(ops_eval, tag, torch.device("cuda:0"))
 
 
@@ -302,7 +302,7 @@ def test_eval_blocks_gpu(ops_eval, tag, policy, monkeypatch):
                                                                                  ("unet_12x1_n2_288", "all")])
 def test_big_cases_gpu(golden_dir, name, policy, monkeypatch):
     from smaat_unet_amd import ops as _ops
-    monkeypatch.setattr(_ops, "SPLIT_POLICY", policy)
+    monkeypatch.setattr(_ops.policy, "split_policy", policy)
     report = {}
     try:
         run_big_tie_aware(golden_dir, name, torch.device("cuda:0"), graph=True, report=report)

@@ -432,7 +432,7 @@ def test_second_backward_over_a_retained_graph_uses_its_own_gradient_maximum():
     torch.manual_seed(3)
     blk = S.unet_parts_depthwise_separable.DoubleConvDS(64, 64, kernels_per_layer=2).to(DEV).train()
     x = torch.randn(2, 64, 64, 64, device=DEV, requires_grad=True)
-    assert 2 * 64 * 64 >= K.F16_MIN_SAMPLES  # (the two-term fp16 split is what runs)
+    assert 2 * 64 * 64 >= K.policy.f16_min_samples  # (the two-term fp16 split is what runs)
     out = blk(x)
     g = torch.randn_like(out)
     params = [p for p in blk.parameters()]

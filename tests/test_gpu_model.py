@@ -155,7 +155,7 @@ def _load_model(meta):
                                          ("unet_4x2_k3_n2_32", "auto")])  # kernels_per_layer = 3: reference fixture, general path
 def test_unet_vs_reference_golden(golden_dir, name, policy, monkeypatch):
     from smaat_unet_amd import ops as _ops
-    monkeypatch.setattr(_ops, "SPLIT_POLICY", policy)  # "all": every supported layer on the bf16-split path
+    monkeypatch.setattr(_ops.policy, "split_policy", policy)  # "all": every supported layer on the bf16-split path
     if name != "unet_12x1_n2_64x48":
         return _unet_vs_reference_golden(golden_dir, name)
     # bottleneck planes of 4 x 3 pixels at batch 2: a violation of the per-tensor bound is accepted IF tests/tie_flips.py
@@ -168,7 +168,7 @@ def test_unet_vs_reference_golden(golden_dir, name, policy, monkeypatch):
     def run(on, store):
         with record_pre_activations(store):
             _unet_vs_reference_golden(golden_dir, name, capture=cap if on else None)
-    flips = attribute(run, flag="CBAM_THREE_PASS", sink=sink)
+    flips = attribute(run, flag="cbam_three_pass", sink=sink)
     if flips:
         # round 6: an accepted flip is followed by an ORACLE check -- the fp64 anchor re-derived with the decisions THIS run took,
         # every gradient tensor held to the ordinary bound against it
@@ -818,7 +818,7 @@ def test_traceable_training_operators_on_gpu(mode, monkeypatch):
     exact three-term split -- their saved tensors are declared up front, the operand maxima of the two-term fp16 split are
     not among them -- so the default path is switched to it as well: this test compares wirings at equal arithmetic.)"""
     from smaat_unet_amd import ops as _ops
-    monkeypatch.setattr(_ops, "F16_SPLIT", False)
+    monkeypatch.setattr(_ops.policy, "f16_split", False)
     meta = dict(n_channels=12, n_classes=1, param_seed=3)
     xn, yn = O.synthetic_precip(2, 12, 64, 64, seed=11)
     x, y = torch.from_numpy(xn).to(DEV), torch.from_numpy(yn).to(DEV)
@@ -846,7 +846,7 @@ def test_training_runs_are_bit_reproducible_with_the_f16_split(monkeypatch):
     order-independent (atomicMax on bit patterns).  scripts/probes/soak_determinism.py is the long form (150 steps at
     288 x 288, profiles/r5/soak_determinism_r5.txt)."""
     from smaat_unet_amd import ops as _ops
-    monkeypatch.setattr(_ops, "F16_MIN_SAMPLES", 0)
+    monkeypatch.setattr(_ops.policy, "f16_min_samples", 0)
 
     def run():
         torch.manual_seed(0)

@@ -163,7 +163,7 @@ def check_param_grads(g, named_grads, prefix="grad64/", noise_prefix="noise/", r
                                          ("unet_12x1_n2_32", "all"), ("unet_4x2_k3_n2_32", "auto")])
 def test_unet(golden_dir, name, policy, monkeypatch):
     from smaat_unet_amd import ops as _ops
-    monkeypatch.setattr(_ops, "SPLIT_POLICY", policy)  # "all": every layer through the split wiring
+    monkeypatch.setattr(_ops.policy, "split_policy", policy)  # "all": every layer through the split wiring
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     meta = json.loads(str(g["meta"]))
     kpl = meta.get("kpl", 2)  # (unet_4x2_k3_*: kernels_per_layer = 3, the general depthwise geometry path end to end)
@@ -354,13 +354,13 @@ def test_matrix_path_policy_training_vs_inference(monkeypatch):
     smaat_pointwise_fwd_split, the depthwise output is kept for the streamed weight gradient); inference (eval mode
     under no_grad) folds BatchNorm into the pointwise weights and runs ONE fused launch per half block."""
     from smaat_unet_amd import ops as _ops
-    assert _ops.SPLIT_POLICY == "auto" and _ops.FUSE_DW_SPLIT == "auto" and _ops.F16_MIN_SAMPLES == 4096
+    assert _ops.policy.split_policy == "auto" and _ops.policy.fuse_dw_split == "auto" and _ops.policy.f16_min_samples == 4096
     # by default planes this small (2 x 8 x 8 = 128 samples per BatchNorm channel) stay on the exact three-term split ...
     mod0 = S.DoubleConvDS(8, 16, kernels_per_layer=2).train()
     c = _recorded_calls(lambda: mod0(torch.randn(2, 8, 8, 8).requires_grad_(True)).sum().backward())
     assert not any(k.endswith(("_h", "_amax")) for k in c), c
     # ... the rest of this test looks at the fp16 wiring, with the sample threshold off
-    monkeypatch.setattr(_ops, "F16_MIN_SAMPLES", 0)
+    monkeypatch.setattr(_ops.policy, "f16_min_samples", 0)
     mod = S.DoubleConvDS(8, 16, kernels_per_layer=2)  # K = 16 / 32, Cout = 16: "narrow"
     x = torch.randn(2, 8, 8, 8)
     mod.train()
@@ -698,7 +698,7 @@ def test_recompute_policy_wiring_equals_the_kept_depthwise_output(mode, monkeypa
     (The two-term fp16 split is switched off here: it applies to the kept-output wiring only, and this test compares wirings
     at equal arithmetic; test_f16_split_wiring_against_the_three_term_split compares the two splits.)"""
     from smaat_unet_amd import ops as K
-    monkeypatch.setattr(K, "F16_SPLIT", False)
+    monkeypatch.setattr(K.policy, "f16_split", False)
     torch.manual_seed(7)
     x = torch.from_numpy(O_precip(2, 12, 32, 64))
     y = torch.rand(2, 32, 64) * 0.3
@@ -706,7 +706,7 @@ def test_recompute_policy_wiring_equals_the_kept_depthwise_output(mode, monkeypa
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     res = {}
     for policy in ("off", "all"):
-        monkeypatch.setattr(K, "WGRAD_RECOMPUTE", policy)
+        monkeypatch.setattr(K.policy, "wgrad_recompute", policy)
         m.load_state_dict(sd)
         m.zero_grad(set_to_none=True)
         m.set_precision(mode)
@@ -739,7 +739,7 @@ def test_weight_images_are_refreshed_in_one_launch_per_optimizer_step(mode, monk
     from smaat_unet_amd import _lib as L_, ops as _ops
 
     def run(cache):
-        monkeypatch.setattr(_ops, "PLANE_CACHE", cache)
+        monkeypatch.setattr(_ops.policy, "plane_cache", cache)
         _ops._PLANES.clear()
         _ops._PLANES_TABLE.clear()
         torch.manual_seed(0)
@@ -796,7 +796,7 @@ def test_weight_image_cache_honours_writes_through_data(monkeypatch):
     from smaat_unet_amd import ops as _ops
 
     def run(cache):
-        monkeypatch.setattr(_ops, "PLANE_CACHE", cache)
+        monkeypatch.setattr(_ops.policy, "plane_cache", cache)
         _ops._PLANES.clear()
         _ops._PLANES_TABLE.clear()
         torch.manual_seed(1)
@@ -825,7 +825,7 @@ def test_weight_image_cache_two_modules_and_writes_through_data(monkeypatch):
     from smaat_unet_amd import ops as _ops
 
     def run(cache):
-        monkeypatch.setattr(_ops, "PLANE_CACHE", cache)
+        monkeypatch.setattr(_ops.policy, "plane_cache", cache)
         _ops.invalidate_weight_images()
         torch.manual_seed(3)
         A = S.DoubleConvDS(32, 32, kernels_per_layer=2).train()
@@ -851,7 +851,7 @@ def test_f16_split_wiring_against_the_three_term_split(monkeypatch):
     does) logits and gradients must agree with the three-term wiring to f32 round-off class, and every maximum word that a
     GEMM read must have been written."""
     from smaat_unet_amd import ops as K
-    monkeypatch.setattr(K, "F16_MIN_SAMPLES", 0)  # (every level of this small network, not only those above the threshold)
+    monkeypatch.setattr(K.policy, "f16_min_samples", 0)  # (every level of this small network, not only those above the threshold)
     torch.manual_seed(11)
     x = torch.from_numpy(O_precip(2, 12, 32, 64))
     y = torch.rand(2, 32, 64) * 0.3
@@ -859,7 +859,7 @@ def test_f16_split_wiring_against_the_three_term_split(monkeypatch):
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     res, calls = {}, {}
     for on in (False, True):
-        monkeypatch.setattr(K, "F16_SPLIT", on)
+        monkeypatch.setattr(K.policy, "f16_split", on)
         K.invalidate_weight_images()
         m.load_state_dict(sd)
         m.zero_grad(set_to_none=True)
@@ -901,14 +901,14 @@ def test_attention_backward_three_pass_route(monkeypatch):
         return [xi.grad.clone()] + [p.grad.clone() for k, p in net.named_parameters()
                                     if not (".double_conv." in k and k.endswith(("depthwise.bias", "pointwise.bias")))]
 
-    assert _ops.CBAM_THREE_PASS
+    assert _ops.policy.cbam_three_pass
     c3 = _recorded_calls(lambda: run())
     g3 = run()
     # 32 -> 16 -> 8 -> 4 -> 2: four pooled levels (even, W % 4 == 0 down to 4 x 4) and the last one, which nothing pools
     assert c3.get("smaat_cbam_bwd_apply_t", 0) == 5 and c3.get("smaat_cbam_bwd_gate_ds_t", 0) == 5, c3
     assert c3.get("smaat_cbam_bwd_ds2_t", 0) == 5 and c3.get("smaat_cbam_sppool_idx_t", 0) == 5, c3
     assert "smaat_cbam_bwd_main" not in c3 and "smaat_cbam_bwd_final_pool" not in c3, c3  # (the emulation nests the old entries' twins)
-    monkeypatch.setattr(_ops, "CBAM_THREE_PASS", False)
+    monkeypatch.setattr(_ops.policy, "cbam_three_pass", False)
     c1 = _recorded_calls(lambda: run())
     g1 = run()
     assert "smaat_cbam_bwd_apply_t" not in c1 and "smaat_cbam_sppool_idx_t" not in c1 and c1.get("smaat_cbam_bwd_main", 0) == 5, c1

@@ -97,7 +97,7 @@ def test_strict_blocks_host_logic(ops_strict, tag, _emu):
 @pytest.mark.parametrize("tag", ROWS_TAGS)
 def test_strict_rows_blocks_host_logic(ops_strict_rows, tag, recompute, _emu, monkeypatch):
     from smaat_unet_amd import ops as _ops
-    monkeypatch.setattr(_ops, "WGRAD_RECOMPUTE", recompute)
+    monkeypatch.setattr(_ops.policy, "wgrad_recompute", recompute)
     run_strict(ops_strict_rows, tag, torch.device("cpu"))
 
 
@@ -127,9 +127,9 @@ def test_strict_rows_blocks_gpu(ops_strict_rows, tag, f16, monkeypatch):
     blocks on the two-term fp16 split (the default) or on the three-term bf16 split."""
     import json
     from smaat_unet_amd import _lib, ops as _ops
-    monkeypatch.setattr(_ops, "WGRAD_RECOMPUTE", "all")
-    monkeypatch.setattr(_ops, "F16_SPLIT", f16)
-    monkeypatch.setattr(_ops, "F16_MIN_SAMPLES", 0)  # (these planes are 256 samples: below the default threshold)
+    monkeypatch.setattr(_ops.policy, "wgrad_recompute", "all")
+    monkeypatch.setattr(_ops.policy, "f16_split", f16)
+    monkeypatch.setattr(_ops.policy, "f16_min_samples", 0)  # (these planes are 256 samples: below the default threshold)
     report = {}
     try:
         seen = _calls_of(_lib.get(), lambda: run_strict(ops_strict_rows, tag, torch.device("cuda:0"), report))
@@ -140,7 +140,7 @@ def test_strict_rows_blocks_gpu(ops_strict_rows, tag, f16, monkeypatch):
     fwd = "smaat_dsconv_fwd_rows_amax" if f16 else "smaat_dsconv_fwd_rows"      # (f16: + the maximum of the depthwise output)
     wg = "smaat_dsconv_wgrad_split_h" if f16 else "smaat_dsconv_wgrad_split"    # (f16: the recompute kernel on the fp16 split)
     assert seen.count(fwd) == 2 and seen.count(wg) == 2, sorted(set(seen))
-    # the data gradient: the fp16-split GEMM, or (ops.FUSED_BWD, round 6) the fused backward that forms dY on chip
+    # the data gradient: the fp16-split GEMM, or (ops.policy.fused_bwd, round 6) the fused backward that forms dY on chip
     assert ("smaat_pointwise_fwd_split_h" in seen or "smaat_dsconv_bwd_rows_h" in seen) == f16
 
 
@@ -150,7 +150,7 @@ def test_strict_rows_blocks_gpu(ops_strict_rows, tag, f16, monkeypatch):
 def test_strict_blocks_gpu(ops_strict, tag, policy, monkeypatch):
     import json
     from smaat_unet_amd import ops as _ops
-    monkeypatch.setattr(_ops, "SPLIT_POLICY", policy)
+    monkeypatch.setattr(_ops.policy, "split_policy", policy)
     report = {}
     try:
         run_strict(ops_strict, tag, torch.device("cuda:0"), report)

@@ -100,20 +100,20 @@ def check_against_masked_oracle(P, x, target, loss, rec, named_grads, noise_of, 
     return sorted(bad, key=lambda t: -t[1]), G
 
 
-def attribute(run, tie=2e-4, flag="F16_SPLIT", sink=None):
+def attribute(run, tie=2e-4, flag="f16_split", sink=None):
     """run(on: bool, store) -> None or raises AssertionError (the bound check of the test, on a fresh model with the feature
-    named by `flag` -- a boolean switch of smaat_unet_amd.ops whose two settings differ at f32 round-off level: the two-term
-    fp16 split (default), or CBAM_THREE_PASS, whose kernels add the channels of the attention maps in another order -- on /
+    named by `flag` -- a boolean field of smaat_unet_amd.ops.policy whose two settings differ at f32 round-off level: the two-term
+    fp16 split (default), or cbam_three_pass, whose kernels add the channels of the attention maps in another order -- on /
     off; it must run its forward inside `record_pre_activations(store)`).
     Only a BoundViolation of the default run can be forgiven; any other AssertionError (logits, loss, running statistics)
     propagates.  sink (dict): receives rec = the recording of the default run (for check_against_masked_oracle).
     Returns the list of tie flips when the violation of run(True) is attributable to them; raises otherwise."""
-    prev = getattr(ops, flag)
+    prev = getattr(ops.policy, flag)
     rec = {}
     err = {}
     try:
         for f16 in (True, False):
-            setattr(ops, flag, f16)
+            setattr(ops.policy, flag, f16)
             ops.invalidate_weight_images()
             rec[f16] = []
             try:
@@ -122,7 +122,7 @@ def attribute(run, tie=2e-4, flag="F16_SPLIT", sink=None):
             except BoundViolation as e:  # noqa: PERF203
                 err[f16] = e
     finally:
-        setattr(ops, flag, prev)
+        setattr(ops.policy, flag, prev)
         ops.invalidate_weight_images()
     if sink is not None:
         sink["rec"] = rec[True]
