@@ -301,7 +301,13 @@ def _zero_grad_words(ref, n):
     """n float32 ZEROS on ref's device that nobody else will ever be handed: the exactly-zero gradient of a convolution bias
     in front of a train-mode BatchNorm (18 per training step; SURVEY 8c "zero-gradient trap").  A slice of a zero-filled arena
     instead of a fill launch per bias: autograd adopts the slice as `.grad` (it is referenced by nothing else), in-place
-    arithmetic on it stays inside the slice, and a slice is never reused, so the arena is refilled once per ~200 steps."""
+    arithmetic on it stays inside the slice, and a slice is never reused, so the arena is refilled once per ~200 steps.
+    ALIASING: such a `.grad` is a VIEW into a 4 MB storage it shares with other parameters' zero gradients and with
+    slices not yet handed out -- value-level use (optimizers, clipping, all-reduce, `.clone()`) cannot tell, but storage-level
+    operations can: `torch.save(p.grad)` pickles the whole storage (save `p.grad.clone()`), `set_` / `resize_` / `share_memory_`
+    act on the arena.  `SMAAT_ZERO_ARENA=0` hands out owning tensors instead (18 fill launches per step)."""
+    if os.environ.get("SMAAT_ZERO_ARENA", "1") == "0":
+        return torch.zeros(n, dtype=torch.float32, device=ref.device)
     from . import train_ops
     if train_ops.active() or (ref.is_cuda and torch.cuda.is_current_stream_capturing()):
         return torch.zeros(n, dtype=torch.float32, device=ref.device)  # (outputs of a torch.library operator must not alias)
