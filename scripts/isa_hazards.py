@@ -35,7 +35,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-ASM_LOAD_SOURCES = ("dswgrad.hip", "dsrows.hip", "splitmma.hip", "dsconv_split.hip", "pwgemm.hip", "dwrows.hip", "uprows.hip", "bf16gemm.hip")
+ASM_LOAD_SOURCES = ("dswgrad.hip", "dsrows.hip", "splitmma.hip", "dsconv_split.hip", "dsbwd.hip", "pwgemm.hip", "dwrows.hip", "uprows.hip", "bf16gemm.hip")
 VMCNT_MAX = 63
 SGPR_WAIT_STATES = 5  # VALU writes SGPR -> VMEM reads that SGPR (gfx90a / gfx940 family hazard table)
 

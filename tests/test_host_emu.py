@@ -132,9 +132,13 @@ def check_summary(store, tag, arr):
     return np.linalg.norm(a.ravel()[idx].astype(np.float64) - ref) / max(np.linalg.norm(ref), 1e-30)
 
 
+# "pass if ours <= 2 x the reference's own error"; rounds 2-5 used 3 x on the small-network fixtures
+SMALL_NET_NOISE_FACTOR = float(__import__("os").environ.get("SMAAT_TEST_SMALL_FACTOR", "2.0"))
+
+
 def check_param_grads(g, named_grads, prefix="grad64/", noise_prefix="noise/", ref32_prefix="grad/"):
-    """per gradient tensor against the reference's fp64 anchor: no worse than max(3 x the reference's own fp32 error on
-    that tensor, 5e-3).  The single-number gradients (BatchNorm(1) affine parameters of the spatial attentions: ONE number
+    """per gradient tensor against the reference's fp64 anchor: no worse than max(SMALL_NET_NOISE_FACTOR x the reference's own fp32 error on
+    that tensor, 5e-3) -- 2 x since round 6.  The single-number gradients (BatchNorm(1) affine parameters of the spatial attentions: ONE number
     summed over a whole map with heavy cancellation, whose stored fp32-vs-fp64 figure is a single sample of that round-off)
     are judged together as one vector, as tests/test_eval_and_big.py::run_big does.  Returns the list of violations."""
     bad = []
@@ -149,12 +153,12 @@ def check_param_grads(g, named_grads, prefix="grad64/", noise_prefix="noise/", r
             scal["ref64"].append(float(g[prefix + k + "#full"].ravel()[0]))
             continue
         e, noise = check_summary(g, prefix + k, gk), float(g[noise_prefix + k])
-        if e > max(3.0 * noise, 5e-3):
+        if e > max(SMALL_NET_NOISE_FACTOR * noise, 5e-3):
             bad.append((k, e, noise))
     if scal["ours"]:
         o, r32, r64 = (np.array(scal[q], np.float64) for q in ("ours", "ref32", "ref64"))
         e, noise = np.linalg.norm(o - r64) / np.linalg.norm(r64), np.linalg.norm(r32 - r64) / np.linalg.norm(r64)
-        if e > max(3.0 * noise, 5e-3):
+        if e > max(SMALL_NET_NOISE_FACTOR * noise, 5e-3):
             bad.append(("<single-number gradients as one vector>", e, noise))
     return sorted(bad, key=lambda t: -t[1])
 

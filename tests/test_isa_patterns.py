@@ -128,7 +128,7 @@ def _hazards():
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc not available")
-@pytest.mark.parametrize("src,min_kernels", [("dswgrad.hip", 14), ("dsrows.hip", 16), ("splitmma.hip", 13), ("dsconv_split.hip", 24)])
+@pytest.mark.parametrize("src,min_kernels", [("dswgrad.hip", 14), ("dsrows.hip", 16), ("splitmma.hip", 13), ("dsconv_split.hip", 24), ("dsbwd.hip", 2)])
 def test_no_instruction_touches_a_prefetched_register_before_its_wait(src, min_kernels):
     """Round 6: hipcc believes the destination of an inline-asm `global_load` is valid as soon as the
     statement has executed -- under register pressure it spills it (a scratch store of a register whose load has not landed,
