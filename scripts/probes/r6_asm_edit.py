@@ -51,6 +51,10 @@ for ln in lines:
 QUART = None
 if re.match(r"nopsA[1-4]$", kind):  # a quarter of region A's VALU instructions (second bisection step)
     QUART, kind = int(kind[-1]) - 1, "nopsA"
+NOPV = None
+m_ = re.match(r"nopv(\d+)$", kind)
+if m_:  # as nopat, but counted from the FIRST VALU instruction of region A (nopat12..30 turned out to sit in the ~40 scalar
+    NOPV, kind = int(m_.group(1)), "nopsA"  # instructions of item bookkeeping that precede the window update: uninformative)
 NOPAT = None
 m_ = re.match(r"nopat(\d+)$", kind)
 if m_:  # 16 wait states in front of the k-th instruction of region A of every slot (third bisection step: the curing
@@ -83,6 +87,15 @@ if kind in ("nopsA", "nopsB", "nopsC"):
                     n4 = (len(valu) + 3) // 4
                     valu = valu[QUART * n4:(QUART + 1) * n4]
                 valu = set(valu)
+                if NOPV is not None:
+                    real = [k for k in range(lo, hi) if re.match(r"\s*[vs]_", body[k])]
+                    first_v = next((q for q, k in enumerate(real) if re.match(r"\s*v_", body[k])), 0)
+                    for k in range(i, j):
+                        if first_v + NOPV < len(real) and k == real[first_v + NOPV]:
+                            res += ["\ts_nop 7", "\ts_nop 7"]
+                        res.append(body[k])
+                    i = j
+                    continue
                 if NOPAT is not None:
                     real = [k for k in range(lo, hi) if re.match(r"\s*[vs]_", body[k])]
                     for k in range(i, j):
