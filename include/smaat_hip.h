@@ -339,6 +339,30 @@ int smaat_dsconv_fwd_rows_amax(const float* x, long x_bs, const float* in_scale,
 int smaat_dsconv_wgrad_split_h(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
                                const float* b_dw, const void* y_amax, const float* dz, long dz_bs, const void* dz_amax, float* ws,
                                float* dw_out, int N, int Cin, int kpl, int Cout, int H, int W, void* stream);
+/* Round 6: the fused forward itself on the two-term fp16 split (three MFMAs per product instead of six).  The scale of y has
+ * to be fixed before y exists, so the kernel BOUNDS it:  |y[k]| <= sum_taps |w_dw[k][tap]| * A[k / kpl] + |b_dw[k]|,
+ * A[c] = max |act(x[c])| <= max(0, |in_scale[c]| * X[c] + in_shift[c])  (A = X without in_scale), where X bounds |x|:
+ *   prev_w == NULL: X = max|x| read from the amax buffer(s) of the kernels that wrote x: x_amax, and x_amax2 (nullable) when
+ *                   x is a channel concatenation with two writers (smaat_cbam_apply_amax, smaat_upsample2x_fwd_amax);
+ *   prev_w != NULL: x is the output of the previous pointwise convolution, x = prev_w [Cin][prev_K] . u + prev_b (prev_b
+ *                   nullable), and x_amax holds max|u| of ITS operand (smaat_dw3x3_fwd_amax / the y_amax of this entry point):
+ *                   X[c] = sum_k |prev_w[c][k]| * max|u| + |prev_b[c]|.  x_amax2 must be NULL.
+ * The split is a floating-point one (h = rn16(t), g = rn16(t - h)), so a bound that is 2^L too large costs nothing for values
+ * above 2^(L - 28) of the bound and an absolute 2^-39 of the bound below.  planes = the fp16 image of w_pw
+ * (smaat_split_planes_h, not transposed).  y_amax (nullable) as smaat_dsconv_fwd_rows_amax (the TRUE maximum, for the recompute
+ * weight gradient); z_amax (nullable) receives max |z|.  Shapes as smaat_dsconv_fwd_rows (f32 storage); -2 otherwise.
+ * (reference: models/layers.py:47-50) */
+int smaat_dsconv_fwd_rows_h(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                            const float* b_dw, const void* x_amax, const void* x_amax2, const float* prev_w, const float* prev_b,
+                            int prev_K, const void* planes, const float* b_pw, float* z, long z_bs, float* part, void* y_amax,
+                            void* z_amax, int N, int Cin, int kpl, int Cout, int H, int W, void* stream);
+/* the two writers of a decoder concatenation buffer, leaving max |out| in an amax buffer (zero on entry, as every amax buffer):
+ * smaat_cbam_apply / smaat_upsample2x_fwd otherwise (reference: models/layers.py:110,128; unet_parts_depthwise_separable.py:64).
+ * smaat_upsample2x_fwd_amax: -2 where the row-walking kernel does not take the shape (Wo % 4, alignment). */
+int smaat_cbam_apply_amax(const float* x, long x_bs, const float* s, const float* gate, float* out, long out_bs, void* amax,
+                          int N, int C, int P, void* stream);
+int smaat_upsample2x_fwd_amax(const float* x, long x_bs, float* out, long out_bs, void* amax, int N, int C, int H, int W, int Ho,
+                              int Wo, int pad_t, int pad_l, void* stream);
 
 /* ---- fused BACKWARD of a DepthwiseSeparableConv (round 6; reference: autograd of models/layers.py:47-50, the pointwise data
  *      gradient of :49 feeding the depthwise backward of :48).  The two-kernel form writes dY = W_pw^T dz (the 2x-expanded

@@ -109,6 +109,9 @@ SIGNATURES = {
     "smaat_pointwise_wgrad_h": [_P, _L, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "smaat_dsconv_fwd_rows_amax": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "smaat_dsconv_wgrad_split_h": [_P, _L, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "smaat_dsconv_fwd_rows_h": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "smaat_cbam_apply_amax": [_P, _L, _P, _P, _P, _L, _P, _I, _I, _I, _P],
+    "smaat_upsample2x_fwd_amax": [_P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     # ---- mixed precision (bf16 activation storage) ----
     "smaat_bf16_planes": [_P, _I, _I, _P, _I, _P],
     "smaat_pointwise_fwd_bf16": [_P, _L, _P, _P, _P, _L, _I, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -270,6 +273,8 @@ WORK_MODELS = {
                                           4.0 * a[17] * (a[20] + 2 * a[18]) * a[21] * a[22]),  # dz + x read, dx written
     "smaat_dsconv_fwd_rows_amax": lambda a: (2.0 * a[12] * a[13] * a[14] * a[15] * a[16] * a[17],
                                              4.0 * a[12] * (a[13] + a[15]) * a[16] * a[17]),
+    "smaat_dsconv_fwd_rows_h": lambda a: (2.0 * a[18] * a[19] * a[20] * a[21] * a[22] * a[23],
+                                          4.0 * a[18] * (a[19] + a[21]) * a[22] * a[23]),
     "smaat_dsconv_wgrad_split_t": lambda a: (2.0 * a[12] * a[13] * a[14] * a[15] * a[16] * a[17],
                                              a[12] * (_es(a[1]) * a[13] + _es(a[8]) * a[15]) * a[16] * a[17]),
     "smaat_pointwise_wgrad": _w_pointwise_wgrad,

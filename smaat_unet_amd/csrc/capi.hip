@@ -78,7 +78,8 @@ int launch_cbam_sppool(const void*, long, const float*, int, int, int, float*, h
 int launch_cbam_spconv(const float*, const float*, int, int, int, int, float*, float*, hipStream_t);
 int launch_cbam_gate(const float*, const float*, const float*, long, float*, hipStream_t);
 int launch_cbam_apply(const void*, long, const float*, const float*, void*, long, int, int, int, hipStream_t,
-                      int dt = SMAAT_F32);
+                      int dt = SMAAT_F32, unsigned* amax = nullptr);
+int launch_upsample2x_fwd_rows(const void*, long, void*, long, int, int, int, int, int, int, int, int, hipStream_t, int, unsigned*);
 int launch_cbam_eval_pool(const float*, long, const float*, const float*, const float*, const float*, const float*,
                           const float*, int, int, int, int, float*, float*, hipStream_t);
 int launch_cbam_eval_apply(const float*, long, const float*, const float*, const float*, int, const float*, const float*,
@@ -384,6 +385,13 @@ int smaat_upsample2x_fwd(const float* x, long x_bs, float* out, long out_bs, int
                          int Wo, int pad_t, int pad_l, void* stream) {
     return launch_upsample2x_fwd(x, x_bs, out, out_bs, N, C, H, W, Ho, Wo, pad_t, pad_l, ST);
 }
+/* + max |out| into an amax buffer (round 6: the scale bound of smaat_dsconv_fwd_rows_h over the concatenation buffer); the
+ * row-walking kernel only: -2 where it does not take the shape (the caller then runs smaat_upsample2x_fwd, without a maximum) */
+int smaat_upsample2x_fwd_amax(const float* x, long x_bs, float* out, long out_bs, void* amax, int N, int C, int H, int W, int Ho,
+                              int Wo, int pad_t, int pad_l, void* stream) {
+    if (!amax || !x || !out) return -1;
+    return launch_upsample2x_fwd_rows(x, x_bs, out, out_bs, N, C, H, W, Ho, Wo, pad_t, pad_l, ST, SMAAT_F32, (unsigned*)amax);
+}
 int smaat_upsample2x_bwd(const float* dout, long dout_bs, float* dx, long dx_bs, int N, int C, int H, int W, int Ho,
                          int Wo, int pad_t, int pad_l, void* stream) {
     return launch_upsample2x_bwd(dout, dout_bs, dx, dx_bs, N, C, H, W, Ho, Wo, pad_t, pad_l, ST);
@@ -427,6 +435,11 @@ int smaat_cbam_gate(const float* conv, const float* scale, const float* shift, l
 int smaat_cbam_apply(const float* x, long x_bs, const float* s, const float* gate, float* out, long out_bs, int N,
                      int C, int P, void* stream) {
     return launch_cbam_apply(x, x_bs, s, gate, out, out_bs, N, C, P, ST);
+}
+int smaat_cbam_apply_amax(const float* x, long x_bs, const float* s, const float* gate, float* out, long out_bs, void* amax,
+                          int N, int C, int P, void* stream) {
+    if (!amax) return -1;
+    return launch_cbam_apply(x, x_bs, s, gate, out, out_bs, N, C, P, ST, SMAAT_F32, (unsigned*)amax);
 }
 int smaat_cbam_eval_pool(const float* x, long x_bs, const float* avg, const float* mx, const float* w1, const float* b1,
                          const float* w2, const float* b2, int N, int C, int Cr, int P, float* s_out, float* maps,
@@ -654,6 +667,29 @@ int smaat_dsconv_fwd_rows_amax(const float* x, long x_bs, const float* in_scale,
     if (!y_amax) return -1;
     return dsconv_fwd_rows_impl(x, SMAAT_F32, x_bs, in_scale, in_shift, w_dw, b_dw, planes, b_pw, z, SMAAT_F32, z_bs, part, y_amax, N,
                                 Cin, kpl, Cout, H, W, stream);
+}
+/* two-term fp16 split form (round 6): planes = the fp16 image of w_pw (smaat_split_planes_h, [K/16][2][Cout][16] + trailer).
+ * The kernel bounds |y| before y exists (dsrows.hip) from a bound of |x|, given in one of two forms:
+ *   prev_w == null: x_amax (+ x_amax2, nullable: a second writer of x) = amax buffers holding max |x| of the tensor itself;
+ *   prev_w != null: x is the output of a pointwise convolution x = prev_w [Cin][prev_K] . u + prev_b and x_amax holds max |u|
+ *                   of ITS operand (the depthwise output of the previous half block): |x[c]| <= sum_k |prev_w[c][k]| max|u| + |prev_b[c]|.
+ * z_amax (nullable) receives max |z| */
+int smaat_dsconv_fwd_rows_h(const float* x, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
+                            const float* b_dw, const void* x_amax, const void* x_amax2, const float* prev_w, const float* prev_b,
+                            int prev_K, const void* planes, const float* b_pw, float* z, long z_bs, float* part, void* y_amax,
+                            void* z_amax, int N, int Cin, int kpl, int Cout, int H, int W, void* stream) {
+    if (N < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || !x || !w_dw || !planes || !z || !x_amax) return -1;
+    if ((in_scale == nullptr) != (in_shift == nullptr)) return -1;
+    if (prev_w && (prev_K < 1 || x_amax2)) return -1;
+    DsRowsArgs a{};
+    a.x = x; a.x_bs = x_bs; a.in_scale = in_scale; a.in_shift = in_shift; a.w_dw = w_dw; a.b_dw = b_dw;
+    a.planes = (const unsigned short*)planes; a.bias = b_pw; a.out = z; a.out_bs = z_bs; a.part = part;
+    a.N = N; a.Cin = Cin; a.K = Cin * kpl; a.M = Cout; a.H = H; a.W = W;
+    a.y_amax = (unsigned*)y_amax; a.z_amax = (unsigned*)z_amax;
+    a.x_amax = (const unsigned*)x_amax; a.x_amax2 = (const unsigned*)x_amax2;
+    a.zb_w = prev_w; a.zb_b = prev_w ? prev_b : nullptr; a.zb_K = prev_w ? prev_K : 0;
+    a.a_kexp = (const int*)((const unsigned char*)planes + split_planes_h_kexp_offset(Cout, Cin * kpl));
+    return launch_dsconv_rows(a, kpl, SMAAT_F32, SMAAT_F32, ST);
 }
 static int dsconv_fwd_rows_impl(const void* x, int x_dt, long x_bs, const float* in_scale, const float* in_shift, const float* w_dw,
                                 const float* b_dw, const void* planes, const float* b_pw, void* z, int z_dt, long z_bs, float* part,

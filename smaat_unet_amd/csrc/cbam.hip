@@ -350,7 +350,10 @@ __global__ __launch_bounds__(256) void k_cbam_gate(const float* __restrict__ con
 template <typename T>
 __global__ __launch_bounds__(256) void k_cbam_apply(const T* __restrict__ x, long x_bs,
                                                     const float* __restrict__ s, const float* __restrict__ gate,
-                                                    T* __restrict__ out, long out_bs, int C, int P, int seg_len) {
+                                                    T* __restrict__ out, long out_bs, int C, int P, int seg_len,
+                                                    unsigned* __restrict__ amax) {
+    __shared__ float amred[4];
+    float am = 0.f;
     const int plane = blockIdx.x, n = plane / C, c = plane - n * C;
     const float sv = s[plane];
     const T* xp = x + (long)n * x_bs + (long)c * P;
@@ -368,6 +371,7 @@ __global__ __launch_bounds__(256) void k_cbam_apply(const T* __restrict__ x, lon
             v.y = v.y * sv * g.y;
             v.z = v.z * sv * g.z;
             v.w = v.w * sv * g.w;
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
             st4(op + p, v);
         };
         int p = p0 + threadIdx.x * 4;  // two positions per trip: four loads in flight
@@ -381,8 +385,15 @@ __global__ __launch_bounds__(256) void k_cbam_apply(const T* __restrict__ x, lon
         }
         if (p < p1) one(ld4(xp + p), *(const float4*)(gp + p), p);
     } else {
-        for (int p = p0 + threadIdx.x; p < p1; p += 256) st1(op + p, ld1(xp + p) * sv * gp[p]);
+        for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+            const float v = ld1(xp + p) * sv * gp[p];
+            am = fmaxf(am, fabsf(v));
+            st1(op + p, v);
+        }
     }
+    // nullable amax buffer (common.h): max |out| (f32 storage) -- the scale bound of a row-walking fused forward that reads the
+    // concatenation buffer this kernel fills (dsrows.hip, NT == 2)
+    if (amax) amax_publish_block256(amax, am, blockIdx.x + blockIdx.y * gridDim.x, amred);  // (block-uniform; no thread has returned)
 }
 
 // ===================================== inference (eval mode) ======================================
@@ -1480,11 +1491,12 @@ int launch_cbam_gate(const float* conv, const float* scale, const float* shift, 
     return (int)hipGetLastError();
 }
 int launch_cbam_apply(const void* x, long x_bs, const float* s, const float* gate, void* out, long out_bs, int N,
-                      int C, int P, hipStream_t st, int dt) {
+                      int C, int P, hipStream_t st, int dt, unsigned* amax) {
+    if (amax && dt != SMAAT_F32) return -2;
     const int seg = seg_len_c(P);
     SMAAT_DISPATCH_ET(dt, T,
         hipLaunchKernelGGL(k_cbam_apply<T>, dim3(N * C, cdivc(P, seg)), dim3(256), 0, st, (const T*)x, x_bs, s, gate, (T*)out,
-                           out_bs, C, P, seg););
+                           out_bs, C, P, seg, amax););
     return (int)hipGetLastError();
 }
 int launch_cbam_eval_pool(const float* x, long x_bs, const float* avg, const float* mx, const float* w1, const float* b1,

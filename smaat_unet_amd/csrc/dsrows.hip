@@ -22,7 +22,14 @@
 //   * all global loads inline asm with counted s_waitcnt, ONE barrier per row.
 // HBM traffic: x once (+ 1/4 for the strip's edge columns, L2) and z once -- 4 (Cin + Cout) HW per image, the north-star's
 // fused minimum -- and no depthwise tensor: the weight gradient recomputes it (dswgrad.hip).
-// TX / TZ: storage types of x and z (float | bf16); NT = 3 (exact split, f32-class error) or 1 (bf16 operands).
+// TX / TZ: storage types of x and z (float | bf16); NT = 3 (exact three-term bf16 split, f32-class error), 1 (bf16 operands) or
+// 2 (round 6: two-term fp16 split, three MFMAs per product, as the other split GEMMs of the step).  The fp16 split needs a
+// power-of-two scale that brings y into fp16's range BEFORE y exists; it comes from an a-priori bound
+//     |y[k]| <= sum_taps |w_dw[k][tap]| * A[k / 2] + |b_dw[k]|,   A[c] = max |act(x[c])| <= max(0, |in_scale[c]| max|x| + in_shift[c])
+// with max |x| taken from the amax buffer(s) the kernels that wrote x left (common.h), or -- x the output of the previous
+// pointwise convolution, x = W' u + b' -- bounded per channel by sum_k |W'[c][k]| max|u| + |b'[c]| from the maximum of ITS operand.  The split is a FLOATING-point one
+// (h = rn16(t), g = rn16(t - h)): a bound that is 2^L too large costs nothing until t falls below fp16's normal range,
+// i.e. for values more than 2^(28 - L) below the bound -- their absolute error is then 2^-25 of the scaled unit, 2^-39 of the bound.
 #include "common.h"
 #include <stdlib.h>
 
@@ -49,10 +56,22 @@ __device__ __forceinline__ const void* dsr_uniform_ptr(const void* p) {  // (an 
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (const void*)(((unsigned long long)hi << 32) | lo);
 }
+typedef float dsr_f32x2_t __attribute__((ext_vector_type(2)));
 // one value pair (k = 2 ci, 2 ci + 1 of one pixel) -> NT dwords {hi: k + 1, lo: k}
+typedef _Float16 dsr_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 dsr_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned dsr_pack_f16(float a, float b) {  // one v_cvt_pk_f16_f32 (round to nearest even)
+    const dsr_f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, dsr_f16x2));
+}
 template <int NT>
-__device__ __forceinline__ void dsr_split_pair(float a, float b, unsigned (&out)[NT]) {
-    if (NT == 1) {
+__device__ __forceinline__ void dsr_split_pair(float a, float b, unsigned (&out)[NT], float sc) {
+    if constexpr (NT == 2) {  // two-term fp16 split of the scaled values (splitmma.hip split2_f16)
+        const float ta = a * sc, tb = b * sc;
+        out[0] = dsr_pack_f16(ta, tb);
+        const dsr_f16x2 hv = __builtin_bit_cast(dsr_f16x2, out[0]);
+        out[1] = dsr_pack_f16(ta - (float)hv.x, tb - (float)hv.y);  // (the residual of a rounding to fewer bits is exact in f32)
+    } else if (NT == 1) {
         out[0] = pack_bf16x2(a, b);  // round to nearest even
     } else {
         const float a1 = dsr_bitsf(dsr_fbits(a) & 0xFFFF0000u), b1 = dsr_bitsf(dsr_fbits(b) & 0xFFFF0000u);
@@ -94,7 +113,7 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
     // rows in flight per producer thread: bf16 halves the bytes per row (dswgrad.hip), two channels per thread double them again.
     // (Eight sets of two channels are 48 VGPRs of destinations: hipcc then SPILLS prefetched registers -- a scratch store of a
     // register whose load has not landed, reloaded later as if it held the row: caught by scripts/isa_hazards.py, round 6)
-    constexpr int PD = (sizeof(TX) == 2 && CPT == 1) ? 8 : ((NT == 1 && CPT == 2 && sizeof(TX) == 4) ? 3 : 4);  // (bf16-operand f32-x builds with two channels: a fourth set spills)
+    constexpr int PD = (sizeof(TX) == 2 && CPT == 1) ? 8 : ((NT != 3 && CPT == 2 && sizeof(TX) == 4) ? 3 : 4);  // (bf16- / fp16-operand f32-x builds with two channels: a fourth set spills)
     constexpr int LPG = 2 * CPT;             // loads per group and producer thread: row piece + edge element per channel
     static_assert((PD - 1) * LPG <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -136,8 +155,50 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
     for (int i = 0; i < nitems; ++i) total += item_rows(it_lo + i * it_st) + 2;  // rows + 2 priming iterations per item
     const int total_pad = (total + PD - 1) / PD * PD;
 
+    // NT == 2: scale exponents of the two operands.  ka: the fp16 weight image's (its trailer); ky: from the a-priori bound of
+    // |y| (file comment), formed by every wave for itself -- lane l takes the k-rows l, l + 64, ... -- so that the producers'
+    // scale and the consumers' epilogue factor are the same number.  1.0001: the f32 roundings of the
+    // bound and of the FMAs that form y (y <= bound (1 + 11 eps)); a scaled bound below 2^15 leaves fp16 a factor 2 beyond that.
+    int ky = 0, ka = 0;
+    if constexpr (NT == 2) {
+        unsigned am = amax_read(a.x_amax);
+        if (a.x_amax2) {
+            const unsigned am2 = amax_read(a.x_amax2);
+            am = am2 > am ? am2 : am;
+        }
+        const float xmax = dsr_bitsf(am);
+        // x given as the output of the previous pointwise convolution (a.zb_w): per-channel bounds of |x| through LDS -- the 12
+        // waves share the rows of zb_w (coalesced reads, one wave sum per row); the B image's first buffer is free until the
+        // first commit, hence the second barrier.  Both barriers are executed by every wave (wave-uniform condition).
+        float* zbnd = (float*)lds;
+        if (a.zb_w) {
+            for (int c = wv; c < a.Cin; c += 12) {
+                float sw = 0.f;
+                for (int k = lane; k < a.zb_K; k += 64) sw += fabsf(a.zb_w[(long)c * a.zb_K + k]);
+                sw = wave_sum_all(sw);
+                if (lane == 0) zbnd[c] = fmaf(sw, xmax, a.zb_b ? fabsf(a.zb_b[c]) : 0.f) * 1.0001f;
+            }
+            __syncthreads();
+        }
+        float bnd = 0.f;
+        for (int k = lane; k < a.K; k += 64) {
+            const int c = k >> 1;
+            const float xb = a.zb_w ? zbnd[c] : xmax;
+            const float A = AFF ? fmaxf(fmaf(fabsf(a.in_scale[c]), xb, a.in_shift[c]), 0.f) : xb;
+            float sw = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) sw += fabsf(a.w_dw[k * 9 + t]);
+            bnd = fmaxf(bnd, fmaf(sw, A, a.b_dw ? fabsf(a.b_dw[k]) : 0.f));
+        }
+        if (a.zb_w) __syncthreads();
+        bnd = wave_max_all(bnd) * 1.0001f;
+        ky = __builtin_amdgcn_readfirstlane(f16_kexp(dsr_fbits(bnd)));
+        ka = __builtin_amdgcn_readfirstlane(*a.a_kexp);
+    }
+
     if (producer) {
         const int ptid = tid - 256;
+        const float ysc = pow2i(ky);
         const int ci = ptid >> 3, g = ptid & 7;
         bool cv[CPT];
         int cgc[CPT];
@@ -325,7 +386,7 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     unsigned pl[NT];
-                    dsr_split_pair<NT>(yy[0][c], yy[1][c], pl);
+                    dsr_split_pair<NT>(yy[0][c], yy[1][c], pl, ysc);
 #pragma unroll
                     for (int t = 0; t < NT; ++t) *(unsigned*)(base + t * BPL + (4 * g + c) * ROWB + dw_) = pl[t];
                 }
@@ -403,6 +464,8 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
         }
         f32x16 acc;
         float keep[8];
+        float zam = 0.f;
+        const float e1 = pow2i(-((ka + ky) / 2)), e2 = pow2i(-((ka + ky) - (ka + ky) / 2));
         float s1[8], s2[8], sh[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) s1[i] = s2[i] = sh[i] = 0.f;
@@ -454,6 +517,14 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
             for (int i = 0; i < 8; ++i) v[i] = xp[i * 64];
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] += keep[i];
+            if constexpr (NT == 2) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = v[i] * e1 * e2;  // (2^-(ka + ky) in two normal factors)
+            }
+            if (a.z_amax) {  // (wave-uniform) max |z| as stored: the scale bound of a row-walking forward that reads this z
+#pragma unroll
+                for (int i = 0; i < 8; ++i) zam = fmaxf(zam, mrow[i] < a.M ? fabsf(v[i] + bias[i]) : 0.f);
+            }
             if constexpr ((DSR_DBG & 32) == 0) {
                 if (a.M == 64 && !a.relu) {  // (the training form: no guard, no clamp)
 #pragma unroll
@@ -531,6 +602,12 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][1], bf[1], acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0], bf[1], acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][1], bf[0], acc, 0, 0, 0);
+                    } else if constexpr (NT == 2) {  // two-term fp16 split: h g' + g h' (+ h h' below); the g g' term is dropped
+                        const dsr_f16x8 a0 = __builtin_bit_cast(dsr_f16x8, af[s][0]), a1 = __builtin_bit_cast(dsr_f16x8, af[s][1]);
+                        const dsr_f16x8 b0 = __builtin_bit_cast(dsr_f16x8, bf[0]), b1 = __builtin_bit_cast(dsr_f16x8, bf[1]);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
                     } else if (NT == 3) {  // smallest terms first (the order of the other split GEMMs)
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0], bf[NT - 1], acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][NT - 1], bf[0], acc, 0, 0, 0);
@@ -538,7 +615,7 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0], bf[NT / 2], acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][NT / 2], bf[0], acc, 0, 0, 0);
                     }
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0], bf[0], acc, 0, 0, 0);
+                    if constexpr (NT != 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0], bf[0], acc, 0, 0, 0);
                 }
                 // hand the partner its half, keep ours
                 float* xw = X + (((t & 1) * 4 + wave) * 8) * 64 + lane;
@@ -555,6 +632,7 @@ __global__ __launch_bounds__(768) void k_dsconv_rows_fwd(const DsRowsArgs a) {
         }
         if (pend) finish();
         if (nitems > 0) flush_stats(it_hi - it_st);
+        if (a.z_amax) amax_publish_wave(a.z_amax, zam, (unsigned)(blockIdx.x * 4 + wave));
         if constexpr ((DSR_DBG & 16) == 0)
             for (int t = total; t < total_pad; ++t) __syncthreads();  // the barriers of the producers' surplus iterations
     }
@@ -624,7 +702,7 @@ static int launch_dsr_sel(const DsRowsArgs& a, hipStream_t st) {
 }
 
 // x_dt / z_dt: SMAAT_F32 | SMAAT_BF16.  f32 storage: planes = the three split planes (or plane 0 only in bf16-operand
-// mode), npl = 3; bf16 storage: planes = the bf16 image of smaat_bf16_planes ([K/16][M][16]), npl = 1, one MFMA per product.
+// mode), npl = 3 -- or, with a.x_amax / a.a_kexp, the fp16 image (npl = 2, two-term split); bf16 storage: planes = the bf16 image of smaat_bf16_planes ([K/16][M][16]), npl = 1, one MFMA per product.
 // -2: shape / alignment / type combination not handled.
 int launch_dsconv_rows(DsRowsArgs& a, int kpl, int x_dt, int z_dt, hipStream_t st) {
     if (!dsconv_rows_ok(kpl, a.Cin, a.M, a.H, a.W) || a.K != 2 * a.Cin) return -2;
@@ -651,6 +729,11 @@ int launch_dsconv_rows(DsRowsArgs& a, int kpl, int x_dt, int z_dt, hipStream_t s
         return launch_dsr_sel<1, float, bf16_t>(a, st);
     }
     if (x_dt != SMAAT_F32) return -2;
+    if (a.x_amax || a.a_kexp) {  // two-term fp16 split: an fp16 weight image + the maximum of x
+        if (!a.x_amax || !a.a_kexp) return -1;
+        a.npl = 2;
+        return launch_dsr_sel<2, float, float>(a, st);
+    }
     a.npl = 3;
     if (split_mode() == 1) return launch_dsr_sel<1, float, float>(a, st);
     return launch_dsr_sel<3, float, float>(a, st);

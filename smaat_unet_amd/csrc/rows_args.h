@@ -20,6 +20,18 @@ struct DsRowsArgs {
     int relu;  // 1: the output is max(z + bias, 0) (inference: BatchNorm folded into the weights, ReLU in the epilogue)
     unsigned* y_amax;  // nullable amax buffer (common.h): receives max |y| of the depthwise output the producers form -- the scale
                        // of the two-term fp16 recompute weight gradient that re-forms the same y in the backward
+    // two-term fp16 split (NT == 2; all null otherwise): planes = the fp16 image of smaat_split_planes_h ([K/16][2][M][16]),
+    // a_kexp = its exponent (the image's trailer), x_amax (+ x_amax2: a second writer of x, nullable) = amax buffers holding
+    // max |x| of the tensor x points into (the RAW tensor when in_scale is given)
+    const unsigned* x_amax;
+    const unsigned* x_amax2;
+    // ... or, zb_w != null: x = zb_w [Cin][zb_K] . u + zb_b is the output of the previous pointwise convolution and x_amax holds
+    // max |u| of ITS operand: the kernel bounds |x[c]| <= sum_k |zb_w[c][k]| max|u| + |zb_b[c]| per channel
+    const float* zb_w;
+    const float* zb_b;  // [Cin] or null
+    int zb_K;
+    const int* a_kexp;
+    unsigned* z_amax;  // nullable amax buffer: receives max |out| (any NT)
 };
 
 struct DsWgArgs {

@@ -719,14 +719,14 @@ int launch_maxpool2_bwd(const void* x, long x_bs, const void* dy, long dy_bs, vo
 }
 
 // uprows.hip: row-walking kernels (float4 rows); -2 = shape / alignment not handled there
-int launch_upsample2x_fwd_rows(const void*, long, void*, long, int, int, int, int, int, int, int, int, hipStream_t, int);
+int launch_upsample2x_fwd_rows(const void*, long, void*, long, int, int, int, int, int, int, int, int, hipStream_t, int, unsigned*);
 int launch_upsample2x_bwd_rows(const void*, long, void*, long, int, int, int, int, int, int, int, int, hipStream_t, int);
 
 // dt: SMAAT_F32 | SMAAT_BF16 (bf16 storage: the row-walking kernels only, -2 when they do not take the shape)
 int launch_upsample2x_fwd(const void* xv, long x_bs, void* outv, long out_bs, int N, int C, int H, int W, int Ho,
                           int Wo, int pad_t, int pad_l, hipStream_t st, int dt) {
     {
-        const int rc = launch_upsample2x_fwd_rows(xv, x_bs, outv, out_bs, N, C, H, W, Ho, Wo, pad_t, pad_l, st, dt);
+        const int rc = launch_upsample2x_fwd_rows(xv, x_bs, outv, out_bs, N, C, H, W, Ho, Wo, pad_t, pad_l, st, dt, nullptr);
         if (rc != -2 || dt != SMAAT_F32) return rc;
     }
     const float* x = (const float*)xv;

@@ -43,9 +43,14 @@ struct UprGeom {
 // T: element type of x and out (f32 | bf16 storage)
 template <typename T>
 __global__ __launch_bounds__(256) void k_upsample2x_fwd_rows(const T* __restrict__ x, long x_bs,
-                                                             T* __restrict__ out, long out_bs, const UprGeom g) {
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= g.total) return;
+                                                             T* __restrict__ out, long out_bs, const UprGeom g,
+                                                             unsigned* __restrict__ amax) {
+    __shared__ float amred[4];
+    // (threads beyond the list repeat its last entry -- the same values to the same addresses -- instead of returning: every
+    // lane is alive for the block-wide maximum below, and no store is divergent)
+    const long gid_ = (long)blockIdx.x * 256 + threadIdx.x;
+    const long gid = gid_ < g.total ? gid_ : g.total - 1;
+    float am = 0.f;
     const int per = g.nbands * g.ntr;
     const int plane = (int)(gid / per), rem = (int)(gid - (long)plane * per);
     const int band = rem / g.ntr, q = rem - band * g.ntr;
@@ -97,9 +102,13 @@ __global__ __launch_bounds__(256) void k_upsample2x_fwd_rows(const T* __restrict
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = cv[i] ? bilerp_v(a0, htop[i], a1, hbot[i]) : 0.f;
             o = make_float4(v[0], v[1], v[2], v[3]);
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
         }
         st4(op + (long)r * g.Wo, o);
     }
+    // nullable amax buffer (common.h): max |out| -- the scale bound of a row-walking fused forward that reads the concatenation
+    // buffer this kernel fills (dsrows.hip, NT == 2; f32 storage -- the bf16 store would round the maximum up)
+    if (amax) amax_publish_block256(amax, am, blockIdx.x, amred);  // (block-uniform branch; every thread is alive)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -233,15 +242,16 @@ static UprGeom upr_geom(int N, int C, int H, int W, int Ho, int Wo, int pad_t, i
 // return -2: shape / alignment not handled here (the caller uses the element-per-thread kernels)
 // dt: SMAAT_F32 | SMAAT_BF16 element type of both tensors
 int launch_upsample2x_fwd_rows(const void* x, long x_bs, void* out, long out_bs, int N, int C, int H, int W, int Ho,
-                               int Wo, int pad_t, int pad_l, hipStream_t st, int dt) {
+                               int Wo, int pad_t, int pad_l, hipStream_t st, int dt, unsigned* amax) {
     const unsigned am = dt == SMAAT_BF16 ? 7u : 15u;
+    if (amax && dt != SMAAT_F32) return -2;
     if (!upr_enabled() || (Wo & 3) != 0 || (out_bs & 3) != 0 || ((((uintptr_t)out) & am) != 0) || H < 1 || W < 1)
         return -2;
     const UprGeom g = upr_geom(N, C, H, W, Ho, Wo, pad_t, pad_l, Wo / 4, Ho, 64, 500000L);
     if (g.total > (1L << 31) * 256L) return -2;
     SMAAT_DISPATCH_ET(dt, T,
         hipLaunchKernelGGL(k_upsample2x_fwd_rows<T>, dim3((unsigned)((g.total + 255) / 256)), dim3(256), 0, st, (const T*)x,
-                           x_bs, (T*)out, out_bs, g););
+                           x_bs, (T*)out, out_bs, g, amax););
     return (int)hipGetLastError();
 }
 

@@ -53,6 +53,7 @@ class Policy:
         self.fuse_first_activation = True
         self.splitk_train_budget = int(e("SMAAT_SPLITK_TRAIN", "2048"))
         self.fused_bwd = e("SMAAT_FUSED_BWD", "0") == "1"
+        self.fwd_rows_h = e("SMAAT_FWD_ROWS_H", "1") != "0"
 
     def snapshot(self):
         return dict(vars(self))
@@ -292,6 +293,50 @@ def _amax_words(ref, n):
         w = a[0][a[1]:a[1] + n]
         a[1] += n
     return w
+
+
+# ---- maxima of tensors that live across autograd nodes (round 6) ------------------------------------------------------
+# The row-walking fused forward on the two-term fp16 split (smaat_dsconv_fwd_rows_h) needs a bound of |x| BEFORE it runs.  For
+# a decoder concatenation buffer that bound is the maximum its two writers leave (cbam_pool_cat: channels [0, C), upsample_into:
+# the rest).  It travels beside the tensor OBJECT -- autograd hands the same Python object from node to node in eager mode --
+# in a side table keyed by id(), guarded by a weak reference (the id of a dead object can be reused) and by the tensor's version
+# counter (anything else that writes the tensor through torch invalidates the entry).  No entry, or a stale one: the consumer
+# runs the exact three-term kernel as before.
+_X_AMAX = {}  # id(tensor) -> [weakref, version, [(c_lo, c_hi, amax buffer), ...]]
+
+
+def _note_x_amax(t, c_lo, c_hi, buf, extend=False):
+    ent = _X_AMAX.get(id(t))
+    if extend and ent is not None and ent[0]() is t:
+        ent[1] = t._version
+        ent[2].append((c_lo, c_hi, buf))
+        return
+    key = id(t)
+    _X_AMAX[key] = [weakref.ref(t, lambda _r, k=key: _X_AMAX.pop(k, None)), t._version, [(c_lo, c_hi, buf)]]
+
+
+def _x_amax_entry(t):
+    """the live, current entry of t or None"""
+    ent = _X_AMAX.get(id(t))
+    if ent is None or ent[0]() is not t or ent[1] != t._version:
+        return None
+    return ent
+
+
+def _x_amax_of(t):
+    """-> (amax buffer, second amax buffer | None) covering every channel of t, or None"""
+    ent = _x_amax_entry(t)
+    if ent is None or t.dim() != 4 or len(ent[2]) > 2:
+        return None
+    rs = sorted(ent[2], key=lambda r: r[0])
+    if rs[0][0] != 0 or rs[-1][1] != t.shape[1] or (len(rs) == 2 and rs[0][1] != rs[1][0]):
+        return None
+    return rs[0][2], (rs[1][2] if len(rs) == 2 else None)
+
+
+def _want_x_amax(t):
+    """producers: leave the maximum of what they write when a two-term fused forward could use it"""
+    return policy.fwd_rows_h and policy.fwd_rows != "off" and t.dtype == F32 and _f16_on()
 
 
 _ZERO_ARENA = {}  # (device, stream) -> [float32 tensor of zeros, next free element]
@@ -695,11 +740,15 @@ def _dsconv_fwd_fused(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None,
 # policy.fwd_rows (default os.environ.get("SMAAT_FWD_ROWS", "auto"))
 
 
-def _dsconv_fwd_rows(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, in_shift=None, out_dtype=None, amx=None):
+def _dsconv_fwd_rows(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, in_shift=None, out_dtype=None, amx=None,
+                     xb=None):
     """-> (z, part, slots, None) or None when the row-walking kernel does not take the shape.  x f32 -> z f32 (split planes);
     out_dtype = torch.bfloat16: mixed precision (x f32 | bf16, bf16 weight image, z bf16).
     amx (f32 storage; see _half_forward): the kernel also leaves max |y| of the depthwise output it forms -- never stored -- in
-    the first amax buffer, for the two-term fp16 recompute weight gradient of the backward"""
+    the first amax buffer, for the two-term fp16 recompute weight gradient of the backward.
+    xb (with amx; round 6): a bound of |x| -- {"amax": buffer, "amax2": buffer | None} (maxima of x itself) or {"amax": buffer of
+    max |u|, "prev_w": [Cin][K'] weight, "prev_b": bias | None} (x = prev_w . u + prev_b) -- with which the GEMM itself runs the
+    two-term fp16 split (smaat_dsconv_fwd_rows_h)"""
     if policy.fwd_rows == "off":
         return None
     L = _lib.get()
@@ -711,10 +760,24 @@ def _dsconv_fwd_rows(x, w_dw, b_dw, w_pw, b_pw, kpl, want_stats, in_scale=None, 
     out_dtype = out_dtype or x.dtype
     # (K = 256 with the exact three-term split -- up4.0 -- used to stay on the tile kernel: 96 registers of resident weight
     # fragments per consumer wave spilled.  Its third weight plane now lives in LDS: 0.83 vs 1.09 ms, profiles/r4.)
-    planes = (_bf16_planes_raw(w_pw.reshape(cout, -1)) if out_dtype == BF16 else _split_planes_raw(w_pw.reshape(cout, -1)))
     slots = L.smaat_dsconv_rows_num_slots(n, h, w)
     z = _new(x, n, cout, h, w, dtype=out_dtype)
     part = _new(x, 3, slots, cout) if want_stats else None
+    if (amx is not None and amx.get("w") is not None and x.dtype == F32 and out_dtype == F32 and xb is not None
+            and policy.fwd_rows_h and kpl == 2):
+        pw = xb.get("prev_w")
+        rc = L.smaat_dsconv_fwd_rows_h(_ptr(x), x_bs, _ptr(in_scale), _ptr(in_shift), _ptr(w_dw), _ptr(b_dw), _ptr(xb["amax"]),
+                                       _ptr(xb.get("amax2")), _ptr(pw), _ptr(xb.get("prev_b")) if pw is not None else None,
+                                       pw.shape[1] if pw is not None else 0, _ptr(_split_planes_h_raw(w_pw.reshape(cout, -1))),
+                                       _ptr(b_pw), _ptr(z), cout * h * w, _ptr(part), _ptr(amx["w"][:AMAX_WORDS]), None, n, cin, kpl,
+                                       cout, h, w, _stream(x))
+        if rc == 0:
+            amx["y"] = True
+            return z, part, (slots if want_stats else 0), None
+        if rc != -2:
+            _lib.check(rc, "smaat_dsconv_fwd_rows_h")
+    # (the three-term / bf16 image is asked for only here: an image that was requested once is refreshed after every weight update)
+    planes = (_bf16_planes_raw(w_pw.reshape(cout, -1)) if out_dtype == BF16 else _split_planes_raw(w_pw.reshape(cout, -1)))
     if amx is not None and amx.get("w") is not None and x.dtype == F32 and out_dtype == F32:
         rc = L.smaat_dsconv_fwd_rows_amax(_ptr(x), x_bs, _ptr(in_scale), _ptr(in_shift), _ptr(w_dw), _ptr(b_dw), _ptr(planes),
                                           _ptr(b_pw), _ptr(z), cout * h * w, _ptr(part), _ptr(amx["w"][:AMAX_WORDS]), n, cin, kpl,
@@ -1106,12 +1169,13 @@ def _bf16_storage_ok(h, w, kpl):
 
 
 def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, momentum, eps, kpl, keep_y, in_aff=None,
-                  want_act=True, amx=None):
+                  want_act=True, amx=None, xb=None):
     """DepthwiseSeparableConv -> BatchNorm2d -> ReLU.  Returns y, z, st, y_dw, use_batch_stats.
     in_aff = (scale, shift): x is a PRE-BatchNorm tensor and relu(x*scale + shift) is applied on load.
     want_act=False: do not materialise y (the consumer applies this BatchNorm + ReLU on load).
     amx (dict, filled in place; None = exact three-term split everywhere): the operand maxima of this half for the two-term
-    fp16 split -- {"w": int32 words [max |y_dw|, max |dz|], "y": produced by the forward, "dz": to be produced by the backward}"""
+    fp16 split -- {"w": int32 words [max |y_dw|, max |dz|], "y": produced by the forward, "dz": to be produced by the backward}
+    xb: a bound of |x| for the row-walking fused forward on the two-term split (_dsconv_fwd_rows)"""
     n, cin, h, w = x.shape
     cout = w_pw.shape[0]
     use_batch_stats = training or rm is None
@@ -1143,7 +1207,8 @@ def _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, mome
                 rs = rs[:3] + (None,)
     elif _split_on() and _fused_dw_ok(n, h, w, kpl, cout, keep_y, cin):
         if not keep_y:
-            rs = _dsconv_fwd_rows(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish, amx=amx if rec else None)
+            rs = _dsconv_fwd_rows(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish, amx=amx if rec else None,
+                                  xb=xb if rec else None)
         if rs is None:
             rs = _dsconv_fwd_fused(x, w_dw, b_dw, w_pw, b_pw, kpl, use_batch_stats, isc, ish, want_y=keep_y)
     if rs is None and not bf and _split_fwd_ok(cin * kpl, cout, use_batch_stats):
@@ -1222,8 +1287,9 @@ class _DSConvBNReLU(torch.autograd.Function):
         keep_y = ((policy.keep_depthwise_output or bfm)
                   and any(ctx.needs_input_grad[:7 if bfm else 4]))  # forward runs under no_grad
         amx = {} if keep_y else None
+        xa = _x_amax_of(x) if amx is not None else None
         y, z, st, y_dw, ubs = _half_forward(x, w_dw, b_dw, w_pw, b_pw, gamma, beta, rm, rv, training, momentum, eps,
-                                            kpl, keep_y, amx=amx)
+                                            kpl, keep_y, amx=amx, xb=dict(amax=xa[0], amax2=xa[1]) if xa else None)
         ctx.amx = amx
         ctx.save_for_backward(x, w_dw, b_dw, w_pw, gamma, z, st, y_dw)
         ctx.kpl = kpl
@@ -1270,17 +1336,24 @@ class _DoubleConvDS(torch.autograd.Function):
                 and bool(_lib.get().smaat_dw3x3_strip_ok(kpl, h, w))
                 and (not bf or kpl <= 2))  # (bf16 storage: the row-streaming backward, kernels_per_layer <= 2)
         amx1, amx2 = ({}, {}) if keep_y else (None, None)  # operand maxima of the two halves (two-term fp16 split)
+        xa = _x_amax_of(x) if amx1 is not None else None  # (a concatenation buffer whose writers left their maxima)
         y1, z1, st1, ydw1, ubs1 = _half_forward(x, w_dw1, b_dw1, w_pw1, b_pw1, g1, be1, rm1, rv1, tr1, mo1, eps1, kpl,
-                                                keep_y, want_act=not fuse, amx=amx1)
+                                                keep_y, want_act=not fuse, amx=amx1,
+                                                xb=dict(amax=xa[0], amax2=xa[1]) if xa else None)
         # head: an OutConv with ONE output channel consumes the block (w_out [1][C][1][1]): the block output is not
         # written, the logits come from the pre-BatchNorm tensor with the activation applied on load
         head = w_out is not None
         if head:
             _expect(w_out, (1, w_pw2.shape[0], 1, 1), "outc.conv.weight")
             _expect(b_out, (1,), "outc.conv.bias")
+        # the second half reads z1 = w_pw1 . y1 + b_pw1 with the activation applied on load: where the first half left max |y1|,
+        # |z1| is bounded per channel through the weight (smaat_dsconv_fwd_rows_h, prev_w form)
+        xb2 = None
+        if fuse and amx1 is not None and amx1.get("y") and amx1.get("w") is not None and z1.dtype == F32:
+            xb2 = dict(amax=amx1["w"][:AMAX_WORDS], prev_w=w_pw1.reshape(w_pw1.shape[0], -1), prev_b=b_pw1)
         y2, z2, st2, ydw2, ubs2 = _half_forward(z1 if fuse else y1, w_dw2, b_dw2, w_pw2, b_pw2, g2, be2, rm2, rv2, tr2,
                                                 mo2, eps2, kpl, keep_y, in_aff=(st1[2], st1[3]) if fuse else None,
-                                                want_act=not (head or defer), amx=amx2)
+                                                want_act=not (head or defer), amx=amx2, xb=xb2)
         ctx.amx = (amx1, amx2)
         ctx.save_for_backward(x, w_dw1, b_dw1, w_pw1, g1, be1, z1, st1, ydw1, y1, w_dw2, b_dw2, w_pw2, g2, z2, st2,
                               ydw2, w_out)
@@ -1754,14 +1827,15 @@ def upsample_cat(x1, x2):
 # CBAM (channel attention and/or spatial attention)
 # --------------------------------------------------------------------------------------
 def _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, use_ch, use_sp,
-                       out=None, lazy=None, pool=None):
+                       out=None, lazy=None, pool=None, out_amax=None):
     """out = spatial_att(channel_att(x)); `out` may be a channel slice of a larger buffer (dense
     planes, any batch stride).  Returns (out, saved tensors, flags).
     pool = []: the caller also needs maxpool2(x) (an encoder level): when the shape allows, the channel pooling kernel
     produces it in the same pass and it is appended to the list; otherwise the list stays empty.
     lazy = (scale, shift): x is the PRE-BatchNorm tensor of the block in front (deferred activation, see
     _DoubleConvDS): relu(x * scale + shift) is formed and written by the channel pooling kernel; saved[0] is that
-    activated tensor."""
+    activated tensor.
+    out_amax (f32 storage): an amax buffer that receives max |out| (smaat_cbam_apply_amax)"""
     _check(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv)
     if lazy is not None and not use_ch:  # no pooling kernel to fuse with: materialise up front
         x = _affine_act_raw(x, lazy[0], lazy[1], True)
@@ -1878,6 +1952,9 @@ def _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, 
     if bf:
         _lib.check(L.smaat_cbam_apply_t(_ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(out), o_bs, n, c, p, 1, s_),
                    "smaat_cbam_apply_t")
+    elif out_amax is not None:
+        _lib.check(L.smaat_cbam_apply_amax(_ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(out), o_bs, _ptr(out_amax), n, c, p, s_),
+                   "smaat_cbam_apply_amax")
     else:
         _lib.check(L.smaat_cbam_apply(_ptr(x), x_bs, _ptr(sc), _ptr(gate), _ptr(out), o_bs, n, c, p, s_),
                    "smaat_cbam_apply")
@@ -2136,14 +2213,18 @@ class _CBAMPoolCat(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, c_extra,
-                lazy_scale=None, lazy_shift=None):
+                lazy_scale=None, lazy_shift=None, amax_out=None):
         L = _lib.get()
         x, x_bs = _planes(x)
         n, c, h, w = x.shape
         cat = _new(x, n, c + c_extra, h, w, dtype=x.dtype)
         lazy = (lazy_scale, lazy_shift) if lazy_scale is not None else None
+        # amax_out (a list, filled in place): the maximum of the skip half of the buffer, for the decoder block that reads it
+        oa = _amax_words(x, 1) if (amax_out is not None and _want_x_amax(x)) else None
         _, saved, flags = _cbam_forward_impl(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps,
-                                             True, True, out=cat[:, :c], lazy=lazy, pool=(got := []))
+                                             True, True, out=cat[:, :c], lazy=lazy, pool=(got := []), out_amax=oa)
+        if oa is not None:
+            amax_out.append(oa)
         if got:
             pooled = got[0]
         else:
@@ -2170,15 +2251,17 @@ class _CBAMPoolCat(torch.autograd.Function):
                 xx, x_bs = _planes(x)
                 dpooled, dp_bs = _planes(dpooled)
                 _maxpool2_bwd_raw(xx, x_bs, dpooled, dp_bs, dx, 1)
-        return (dx,) + tuple(g[1:]) + (None,) * 8
+        return (dx,) + tuple(g[1:]) + (None,) * 9
 
 
 def cbam_pool_cat(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, c_extra, lazy=None):
     """lazy = (scale, shift): x is a deferred-activation block output (see double_conv_ds(..., defer=True))"""
-    if lazy is not None:
-        return _CBAMPoolCat.apply(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, c_extra,
-                                  lazy[0], lazy[1])
-    return _CBAMPoolCat.apply(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, c_extra)
+    lz = lazy if lazy is not None else (None, None)
+    cat, pooled = _CBAMPoolCat.apply(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps, c_extra,
+                                     lz[0], lz[1], (got := []))
+    if got:  # max |cat[:, :C]| was left by the apply kernel (_X_AMAX)
+        _note_x_amax(cat, 0, x.shape[1], got[0])
+    return cat, pooled
 
 
 class _UpsampleInto(torch.autograd.Function):
@@ -2186,7 +2269,7 @@ class _UpsampleInto(torch.autograd.Function):
     Upsample + F.pad + the second operand of torch.cat); the first c_off channels already hold the skip."""
 
     @staticmethod
-    def forward(ctx, cat, x1, c_off):
+    def forward(ctx, cat, x1, c_off, amax_out=None):
         _check(cat, x1, acts=2)
         L = _lib.get()
         x1, x1_bs = _planes(x1)
@@ -2201,8 +2284,19 @@ class _UpsampleInto(torch.autograd.Function):
             # a block in front fell back to f32 storage (_bf16_storage_ok) while the skip was stored as bf16, or the other
             # way round: the upsampled map follows the buffer it is written into
             x1, x1_bs = _planes(x1.to(cat.dtype))
-        _upsample_fwd_raw(x1, x1_bs, cat.data_ptr() + cat.element_size() * c_off * ho * wo, ct * ho * wo, n, c1, h, w, ho, wo,
-                          pt, pl, _stream(x1))
+        done = False
+        if amax_out is not None and x1.dtype == F32 and cat.dtype == F32:  # + max |cat[:, c_off:]| where the row kernel runs
+            oa = _amax_words(x1, 1)
+            rc = L.smaat_upsample2x_fwd_amax(_ptr(x1), x1_bs, cat.data_ptr() + 4 * c_off * ho * wo, ct * ho * wo, _ptr(oa), n, c1,
+                                             h, w, ho, wo, pt, pl, _stream(x1))
+            if rc == 0:
+                amax_out.append(oa)
+                done = True
+            elif rc != -2:
+                _lib.check(rc, "smaat_upsample2x_fwd_amax")
+        if not done:
+            _upsample_fwd_raw(x1, x1_bs, cat.data_ptr() + cat.element_size() * c_off * ho * wo, ct * ho * wo, n, c1, h, w, ho, wo,
+                              pt, pl, _stream(x1))
         ctx.geom = (n, c1, h, w, c_off, ho, wo, pt, pl)
         ctx.mark_dirty(cat)
         return cat
@@ -2217,11 +2311,16 @@ class _UpsampleInto(torch.autograd.Function):
             dx1 = _new(dcat, n, c1, h, w, dtype=dcat.dtype)
             _upsample_bwd_raw(dcat.data_ptr() + dcat.element_size() * c_off * ho * wo, (c_off + c1) * ho * wo, dx1, n, c1, h,
                               w, ho, wo, pt, pl, _stream(dcat))
-        return dcat, dx1, None
+        return dcat, dx1, None, None
 
 
 def upsample_into(cat, x1, c_off):
-    return _UpsampleInto.apply(cat, x1, c_off)
+    if _x_amax_entry(cat) is None or not _want_x_amax(cat):
+        return _UpsampleInto.apply(cat, x1, c_off, None)
+    out = _UpsampleInto.apply(cat, x1, c_off, (got := []))
+    if got and out is cat:  # both writers of the buffer have left their maxima (the in-place write moved the version on)
+        _note_x_amax(cat, c_off, cat.shape[1], got[0], extend=True)
+    return out
 
 
 # --------------------------------------------------------------------------------------

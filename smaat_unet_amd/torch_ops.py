@@ -82,7 +82,7 @@ def _(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, eps, c_extra):
 @custom_op("smaat::upsample_into_", mutates_args=("cat",))
 def upsample_into_(cat: Tensor, x1: Tensor, c_off: int) -> None:
     with torch.no_grad():
-        ops._UpsampleInto.apply(cat, x1, c_off)
+        ops._UpsampleInto.apply(cat, x1, c_off, None)
 
 
 @upsample_into_.register_fake

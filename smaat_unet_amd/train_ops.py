@@ -308,7 +308,7 @@ def cbam(x, w1, b1, w2, b2, wconv, gamma, beta, rm, rv, training, momentum, eps)
 @custom_op("smaat::upsample_into", mutates_args=("cat",))
 def upsample_into_op(cat: Tensor, x1: Tensor, c_off: int) -> Tensor:
     with torch.no_grad():
-        ops._UpsampleInto.apply(cat, x1, c_off)
+        ops._UpsampleInto.apply(cat, x1, c_off, None)
     return cat.new_empty((0,))  # (the result is the mutated `cat`)
 
 

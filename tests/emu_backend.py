@@ -1340,8 +1340,80 @@ def _dsconv_wgrad_split_h(self, x, x_bs, in_scale, in_shift, w_dw, b_dw, y_amax,
     return 0
 
 
+def rows_h_y_kexp(xmax_bits, w_dw, b_dw, in_scale, in_shift, prev_w=None, prev_b=None):
+    """the scale exponent smaat_dsconv_fwd_rows_h derives for y before y exists (csrc/dsrows.hip, NT == 2 prologue), operation
+    for operation in float32 where the order matters for the result: f16_kexp only looks at the exponent of the bound, so the
+    sums' rounding (a wave sum on the device, a sequential one here) is covered by comparing exponents of 1.0001-slacked values --
+    the tests use operands whose bound does not sit within 1e-4 of a power of two"""
+    f = np.float32
+    K = w_dw.shape[0]
+    xmax = np.array([xmax_bits], np.uint32).view(np.float32)[0]
+    if prev_w is not None:
+        xb = (np.abs(prev_w).astype(f).sum(axis=1, dtype=f) * xmax + (np.abs(prev_b) if prev_b is not None else f(0))).astype(f) * f(1.0001)
+    else:
+        xb = np.full(K // 2, xmax, f)
+    if in_scale is not None:
+        A = np.maximum(np.abs(in_scale).astype(f) * xb + in_shift, f(0)).astype(f)
+    else:
+        A = xb
+    sw = np.abs(w_dw.reshape(K, 9)).astype(f).sum(axis=1, dtype=f)
+    bnd = (sw * np.repeat(A, 2) + (np.abs(b_dw) if b_dw is not None else f(0))).astype(f)
+    m = f(np.max(bnd)) * f(1.0001)
+    return f16_kexp(int(np.array([m], f).view(np.uint32)[0]))
+
+
+def _dsconv_fwd_rows_h(self, x, x_bs, in_scale, in_shift, w_dw, b_dw, x_amax, x_amax2, prev_w, prev_b, prev_K, pl, b_pw, z, z_bs, part,
+                       y_amax, z_amax, N, Cin, kpl, Cout, H, W, stream):
+    """row-walking fused forward on the two-term fp16 split: y scaled by the power of two of its a-priori bound"""
+    if not self.smaat_dsconv_rows_ok(kpl, Cin, Cout, H, W):
+        return -2
+    P, K = H * W, Cin * kpl
+    T = self.smaat_dsconv_rows_num_slots(N, H, W)
+    xv = np.array(planes(x, N, Cin, P, x_bs)).reshape(N, Cin, H, W)
+    sc = f32(in_scale, Cin) if in_scale else None
+    sh = f32(in_shift, Cin) if in_scale else None
+    if in_scale:
+        xv = np.maximum(xv * sc[None, :, None, None] + sh[None, :, None, None], 0).astype(np.float32)
+    wd = f32(w_dw, K * 9).reshape(K, 9)
+    bd = f32(b_dw, K) if b_dw else None
+    y = O.dw3x3_fwd(xv, wd.reshape(K, 1, 3, 3), bd, kpl).reshape(N, K, P).astype(np.float32)
+    am = _amax_read(x_amax)
+    if x_amax2:
+        am = max(am, _amax_read(x_amax2))
+    ky = rows_h_y_kexp(am, wd, bd, sc, sh, f32(prev_w, Cin * prev_K).reshape(Cin, prev_K) if prev_w else None,
+                       (f32(prev_b, Cin) if prev_b else None) if prev_w else None)
+    a_terms, ka = _h_image(pl, Cout, K)
+    acc = mm_h("mk,nkp->nmp", a_terms, ka, y, ky)
+    out = acc + (f32(b_pw, Cout)[None, :, None] if b_pw else 0)
+    planes(z, N, Cout, P, z_bs)[:] = out
+    self._write_part(part, T, Cout, acc)
+    if y_amax:
+        _amax_publish(y_amax, y)
+    if z_amax:
+        _amax_publish(z_amax, out)
+    return 0
+
+
+def _cbam_apply_amax(self, x, x_bs, s, gate, out, out_bs, amax, N, C, P, stream):
+    rc = self.smaat_cbam_apply(x, x_bs, s, gate, out, out_bs, N, C, P, stream)
+    if rc == 0:
+        _amax_publish(amax, planes(out, N, C, P, out_bs))
+    return rc
+
+
+def _upsample2x_fwd_amax(self, x, x_bs, out, out_bs, amax, N, C, H, W, Ho, Wo, pad_t, pad_l, stream):
+    if Wo % 4:
+        return -2
+    rc = self.smaat_upsample2x_fwd(x, x_bs, out, out_bs, N, C, H, W, Ho, Wo, pad_t, pad_l, stream)
+    if rc == 0:
+        _amax_publish(amax, planes(out, N, C, Ho * Wo, out_bs))
+    return rc
+
+
 for _name, _fn in (("smaat_dsconv_wgrad_split_t", _t_dsconv_wgrad_split), ("smaat_dsconv_rows_ok", _t_dsconv_rows_ok), ("smaat_dsconv_rows_num_slots", _t_dsconv_rows_num_slots),
                    ("smaat_dsconv_fwd_rows", _t_dsconv_fwd_rows), ("smaat_dsconv_fwd_rows_amax", _dsconv_fwd_rows_amax),
+                   ("smaat_dsconv_fwd_rows_h", _dsconv_fwd_rows_h), ("smaat_cbam_apply_amax", _cbam_apply_amax),
+                   ("smaat_upsample2x_fwd_amax", _upsample2x_fwd_amax),
                    ("smaat_dsconv_wgrad_split_h", _dsconv_wgrad_split_h)):
     setattr(EmuLib, _name, _fn)
 

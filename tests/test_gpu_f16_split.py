@@ -635,3 +635,202 @@ def test_soak_fused_backward():
         assert L.smaat_dsconv_bwd_rows_h(P(x), Cin * H * W, None, None, None, None, P(dz), Cout * H * W, P(adz), P(pl_t), P(w_dw), P(dx),
                                          Cin * H * W, P(ws), P(dw), P(db), None, N, Cin, 2, Cout, H, W, stream(dev)) == 0
     _soak(call, [dx, dw, db], "k_dsconv_bwd_rows")
+
+
+# ------------------------------------------------------------ round 6: the fused row-walking forward on the two-term split
+def _rows_h_inputs(dev, N, Cin, Cout, H, W, aff, prev_K=0, xscale=1.0):
+    K = 2 * Cin
+    w_dw, b_dw = T(rnd(2, K, 9, scale=0.3), dev), T(rnd(3, K, scale=0.3), dev)
+    w_pw, b_pw = T(rnd(4, Cout, K, scale=0.2), dev), T(rnd(5, Cout), dev)
+    sc = T(np.random.default_rng(6).uniform(0.5, 1.5, Cin).astype(np.float32), dev) if aff else None
+    sh = T(rnd(7, Cin, scale=0.3), dev) if aff else None
+    if prev_K:  # x = prev_w . u + prev_b: the output of a previous pointwise convolution whose operand's maximum is known
+        u = T(rnd(10, N, prev_K, H, W), dev)
+        pw, pb = T(rnd(11, Cin, prev_K, scale=0.25), dev), T(rnd(12, Cin, scale=0.5), dev)
+        x = (torch.einsum("ck,nkhw->nchw", pw.double(), u.double()) + pb.double().view(1, -1, 1, 1)).float().contiguous()
+        ax = _publish(u)
+    else:
+        x = T(rnd(1, N, Cin, H, W) * xscale, dev)
+        pw = pb = None
+        ax = _publish(x)
+    return x, w_dw, b_dw, w_pw, b_pw, sc, sh, pw, pb, ax
+
+
+def case_rows_h(L, dev, N, Cin, Cout, H, W, aff=False, prev_K=0, two=False):
+    """smaat_dsconv_fwd_rows_h: z, BatchNorm partials, max |y| (true), max |z|"""
+    K = 2 * Cin
+    x, w_dw, b_dw, w_pw, b_pw, sc, sh, pw, pb, ax = _rows_h_inputs(dev, N, Cin, Cout, H, W, aff, prev_K)
+    ax2 = None
+    if two:  # two writers of x: the first half of the channels in one buffer, the rest in the other
+        ax, ax2 = _publish(x[:, :Cin // 2]), _publish(x[:, Cin // 2:])
+    plh = _h_image(L, dev, w_pw)
+    slots = L.smaat_dsconv_rows_num_slots(N, H, W)
+    z = torch.full((N, Cout, H, W), float("nan"), device=dev)
+    part = torch.full((3, slots, Cout), float("nan"), device=dev)
+    ay, az = _amax_word(dev), _amax_word(dev)
+    assert L.smaat_dsconv_fwd_rows_h(P(x), Cin * H * W, P(sc), P(sh), P(w_dw), P(b_dw), P(ax), P(ax2), P(pw), P(pb), prev_K, P(plh),
+                                     P(b_pw), P(z), Cout * H * W, P(part), P(ay), P(az), N, Cin, 2, Cout, H, W, stream(dev)) == 0
+    pn, pmean, pvar = part_stats(part)
+    return dict(z=z, amax_y=torch.tensor([_amax_of(ay)], dtype=torch.int64), amax_z=torch.tensor([_amax_of(az)], dtype=torch.int64),
+                pn=pn, pmean=pmean, pvar=pvar)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 32, 32), (1, 40, 50, 8, 64), (2, 128, 64, 36, 96), (1, 8, 16, 70, 32)])
+@pytest.mark.parametrize("form", ["amax", "two_writers", "prev_w"])
+@pytest.mark.parametrize("aff", [False, True])
+def test_rows_forward_h(shape, form, aff):
+    """against the numpy twin (same three fp16 products, same a-priori scale exponent): f32 round-off class; the maxima exactly"""
+    N, Cin, Cout, H, W = shape
+    L, dev = _lib.get(), DEV
+    r = both(case_rows_h, *shape, aff=aff, prev_K=24 if form == "prev_w" else 0, two=form == "two_writers", tol=1e-5)
+    assert int(r["hip"]["amax_z"][0]) == _bits(float(np.abs(r["hip"]["z"]).max()))
+    # the maximum of y is the TRUE one (not the bound), that of the depthwise output the standalone kernel writes (same tap order)
+    x, w_dw, b_dw, w_pw, b_pw, sc, sh, pw, pb, ax = _rows_h_inputs(dev, N, Cin, Cout, H, W, aff, 24 if form == "prev_w" else 0)
+    y = torch.empty((N, 2 * Cin, H, W), device=dev)
+    assert L.smaat_dw3x3_fwd(P(x), Cin * H * W, P(sc), P(sh), P(w_dw), P(b_dw), P(y), 2 * Cin * H * W, N, Cin, 2, H, W, stream(dev)) == 0
+    torch.cuda.synchronize()
+    assert int(r["hip"]["amax_y"][0]) == _amax_of(_publish(y))
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 64, 64, True, 0), (2, 128, 64, 36, 96, False, 0), (2, 64, 64, 64, 64, True, 24),
+                                  (2, 128, 64, 32, 64, True, 256)])
+def test_rows_forward_h_against_fp64_next_to_the_three_term_kernel(case):
+    """error against an fp64 evaluation no worse than 3 x the exact three-term kernel's + 2e-7 (the bar of the other two-term
+    GEMMs), with the bound coming from max |x| or through the previous GEMM's weight (K' = 24: the stem; 256: a decoder block)"""
+    L, dev = _lib.get(), DEV
+    N, Cin, Cout, H, W, aff, prev_K = case
+    K = 2 * Cin
+    x, w_dw, b_dw, w_pw, b_pw, sc, sh, pw, pb, ax = _rows_h_inputs(dev, N, Cin, Cout, H, W, aff, prev_K)
+    plh = _h_image(L, dev, w_pw)
+    pl3 = torch.empty((3, Cout, (K + 15) // 16 * 16), dtype=torch.int16, device=dev)
+    assert L.smaat_split_planes(P(w_pw), Cout, K, P(pl3), stream(dev)) == 0
+    zh, z3 = torch.empty((N, Cout, H, W), device=dev), torch.empty((N, Cout, H, W), device=dev)
+    ay = _amax_word(dev)
+    assert L.smaat_dsconv_fwd_rows_h(P(x), Cin * H * W, P(sc), P(sh), P(w_dw), P(b_dw), P(ax), None, P(pw), P(pb), prev_K, P(plh),
+                                     P(b_pw), P(zh), Cout * H * W, None, P(ay), None, N, Cin, 2, Cout, H, W, stream(dev)) == 0
+    assert L.smaat_dsconv_fwd_rows(P(x), 0, Cin * H * W, P(sc), P(sh), P(w_dw), P(b_dw), P(pl3), P(b_pw), P(z3), 0, Cout * H * W, None,
+                                   N, Cin, 2, Cout, H, W, stream(dev)) == 0
+    xd = x.double()
+    if aff:
+        xd = torch.relu(xd * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+    yd = torch.nn.functional.conv2d(xd, w_dw.double().view(K, 1, 3, 3), b_dw.double(), padding=1, groups=Cin)
+    zd = torch.nn.functional.conv2d(yd, w_pw.double().view(Cout, K, 1, 1), b_pw.double())
+    eh, e3 = float((zh.double() - zd).norm() / zd.norm()), float((z3.double() - zd).norm() / zd.norm())
+    assert eh <= 3 * e3 + 2e-7, (eh, e3)
+    mh = float((zh.double() - zd).abs().max() / zd.abs().max())
+    assert mh <= 2e-6, mh
+
+
+def test_rows_forward_h_loose_bounds_zero_planes_and_nan():
+    """a bound 2^16 too large costs at most the subnormal tail (still f32 class); all-zero input with biases; all-zero
+    everything (scale exponent 0, exact zeros); a NaN in x comes out as NaNs"""
+    L, dev = _lib.get(), DEV
+    N, Cin, Cout, H, W = 2, 64, 64, 32, 64
+    K = 2 * Cin
+    x, w_dw, b_dw, w_pw, b_pw, sc, sh, pw, pb, ax = _rows_h_inputs(dev, N, Cin, Cout, H, W, False)
+    plh = _h_image(L, dev, w_pw)
+
+    def run(xx, axx, bdw=b_dw, bpw=b_pw):
+        z = torch.full((N, Cout, H, W), float("nan"), device=dev)
+        assert L.smaat_dsconv_fwd_rows_h(P(xx), Cin * H * W, None, None, P(w_dw), P(bdw), P(axx), None, None, None, 0, P(plh), P(bpw),
+                                         P(z), Cout * H * W, None, None, None, N, Cin, 2, Cout, H, W, stream(dev)) == 0
+        torch.cuda.synchronize()
+        return z
+
+    yd = torch.nn.functional.conv2d(x.double(), w_dw.double().view(K, 1, 3, 3), b_dw.double(), padding=1, groups=Cin)
+    zd = torch.nn.functional.conv2d(yd, w_pw.double().view(Cout, K, 1, 1), b_pw.double())
+    tight = float((run(x, ax).double() - zd).norm() / zd.norm())
+    loose = float((run(x, _publish(x * 65536.0)).double() - zd).norm() / zd.norm())
+    assert tight < 3e-7 and loose < 3e-6, (tight, loose)
+    zero = torch.zeros_like(x)
+    z0 = run(zero, _publish(zero))
+    ref0 = torch.nn.functional.conv2d(torch.nn.functional.conv2d(zero.double(), w_dw.double().view(K, 1, 3, 3), b_dw.double(), padding=1,
+                                                                 groups=Cin), w_pw.double().view(Cout, K, 1, 1), b_pw.double())
+    assert float((z0.double() - ref0).norm() / ref0.norm()) < 3e-7
+    assert torch.equal(run(zero, _publish(zero), bdw=None, bpw=None), torch.zeros(N, Cout, H, W, device=dev))
+    xn = x.clone()
+    xn[1, 3, 5, 7] = float("nan")
+    zn = run(xn, _publish(x))
+    assert torch.isnan(zn[1, :, 4:7, 6:9]).all() and not torch.isnan(zn[0]).any()
+
+
+def test_rows_forward_h_refusals():
+    L, dev = _lib.get(), DEV
+    N, Cin, Cout, H, W = 1, 64, 64, 16, 32
+    x, w_dw, b_dw, w_pw, b_pw, sc, sh, pw, pb, ax = _rows_h_inputs(dev, N, Cin, Cout, H, W, False, prev_K=24)
+    plh = _h_image(L, dev, w_pw)
+    z = torch.empty((N, Cout, H, W), device=dev)
+    a = [P(x), Cin * H * W, None, None, P(w_dw), P(b_dw), P(ax), None, P(pw), P(pb), 24, P(plh), P(b_pw), P(z), Cout * H * W, None, None,
+         None, N, Cin, 2, Cout, H, W, stream(dev)]
+    assert L.smaat_dsconv_fwd_rows_h(*a) == 0
+    b = list(a); b[6] = None
+    assert L.smaat_dsconv_fwd_rows_h(*b) == -1                      # no maximum
+    b = list(a); b[7] = P(ax)
+    assert L.smaat_dsconv_fwd_rows_h(*b) == -1                      # the weight form has one maximum
+    b = list(a); b[23] = 40; b[14] = Cout * H * 40
+    assert L.smaat_dsconv_fwd_rows_h(*b) == -2                      # W % 32
+    b = list(a); b[20] = 1
+    assert L.smaat_dsconv_fwd_rows_h(*b) == -2                      # kernels_per_layer
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 288 * 288), (3, 128, 144 * 144), (2, 5, 77), (1, 3, 18 * 18)])
+def test_cbam_apply_amax(shape):
+    """out bit-identical to smaat_cbam_apply; the buffer holds max |out| exactly"""
+    L, dev = _lib.get(), DEV
+    N, C, Pn = shape
+    x = T(rnd(1, N, C, Pn), dev)
+    s = T(np.random.default_rng(2).uniform(0.1, 1.0, (N, C)).astype(np.float32), dev)
+    gate = T(np.random.default_rng(3).uniform(0.1, 1.0, (N, Pn)).astype(np.float32), dev)
+    o0, o1 = torch.full((N, C, Pn), float("nan"), device=dev), torch.full((N, C, Pn), float("nan"), device=dev)
+    am = _amax_word(dev)
+    assert L.smaat_cbam_apply(P(x), C * Pn, P(s), P(gate), P(o0), C * Pn, N, C, Pn, stream(dev)) == 0
+    assert L.smaat_cbam_apply_amax(P(x), C * Pn, P(s), P(gate), P(o1), C * Pn, P(am), N, C, Pn, stream(dev)) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(o0, o1)
+    assert _amax_of(am) == _bits(float(o1.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 144, 144, 288, 288), (2, 16, 9, 9, 20, 20), (1, 8, 18, 18, 36, 36), (1, 4, 5, 7, 10, 14)])
+def test_upsample2x_fwd_amax(shape):
+    """out bit-identical to smaat_upsample2x_fwd (into a channel slice of a larger buffer); max |out| exactly; -2 where the
+    row-walking kernel does not take the shape"""
+    L, dev = _lib.get(), DEV
+    N, C, H, W, Ho, Wo = shape
+    x = T(rnd(1, N, C, H, W), dev)
+    pt, pl_ = (Ho - 2 * H) // 2, (Wo - 2 * W) // 2
+    c0 = 3
+    o0 = torch.full((N, C + c0, Ho, Wo), float("nan"), device=dev)
+    o1 = torch.full((N, C + c0, Ho, Wo), float("nan"), device=dev)
+    am = _amax_word(dev)
+    assert L.smaat_upsample2x_fwd(P(x), C * H * W, o0.data_ptr() + 4 * c0 * Ho * Wo, (C + c0) * Ho * Wo, N, C, H, W, Ho, Wo, pt, pl_,
+                                  stream(dev)) == 0
+    rc = L.smaat_upsample2x_fwd_amax(P(x), C * H * W, o1.data_ptr() + 4 * c0 * Ho * Wo, (C + c0) * Ho * Wo, P(am), N, C, H, W, Ho, Wo,
+                                     pt, pl_, stream(dev))
+    if Wo % 4:
+        assert rc == -2
+        return
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(o0[:, c0:], o1[:, c0:]) and torch.isnan(o1[:, :c0]).all()
+    assert _amax_of(am) == _bits(float(o1[:, c0:].abs().max()))
+
+
+@pytest.mark.parametrize("case", [(4, 64, 64, 288, 288, True, 24), (4, 128, 64, 288, 288, False, 0), (4, 64, 64, 288, 288, True, 256),
+                                  (2, 64, 64, 32, 32, True, 0)])
+def test_soak_rows_forward_h(case):
+    """k_dsconv_rows_fwd<NT=2> (inline-asm loads, counted waits; scripts/isa_hazards.py proves the ISA) on the three layers of the
+    step that run it: 1,000 bit-identical calls"""
+    L, dev = _lib.get(), DEV
+    N, Cin, Cout, H, W, aff, prev_K = case
+    x, w_dw, b_dw, w_pw, b_pw, sc, sh, pw, pb, ax = _rows_h_inputs(dev, N, Cin, Cout, H, W, aff, prev_K)
+    plh = _h_image(L, dev, w_pw)
+    slots = L.smaat_dsconv_rows_num_slots(N, H, W)
+    z = torch.empty((N, Cout, H, W), device=dev)
+    part = torch.empty((3, slots, Cout), device=dev)
+    ay = _amax_word(dev)
+
+    def fwd():
+        ay.zero_()
+        assert L.smaat_dsconv_fwd_rows_h(P(x), Cin * H * W, P(sc), P(sh), P(w_dw), P(b_dw), P(ax), None, P(pw), P(pb), prev_K, P(plh),
+                                         P(b_pw), P(z), Cout * H * W, P(part), P(ay), None, N, Cin, 2, Cout, H, W, stream(dev)) == 0
+    _soak(fwd, [z, part], "k_dsconv_rows_fwd<NT=2>")

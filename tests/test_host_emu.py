@@ -888,6 +888,75 @@ def test_f16_split_wiring_against_the_three_term_split(monkeypatch):
     assert rel(f1.numpy(), f0.numpy()) < 1e-2
 
 
+def test_rows_forward_on_the_two_term_split_wiring(monkeypatch):
+    """Round 6: the row-walking fused forward runs the two-term fp16 split (smaat_dsconv_fwd_rows_h) wherever a bound of |x| is at
+    hand -- second halves through the first half's weight and max |y1| (prev_w form), the first half of a decoder block through
+    the maxima its concatenation buffer's two writers leave (smaat_cbam_apply_amax, smaat_upsample2x_fwd_amax; ops._X_AMAX) -- and
+    the three-term kernel otherwise.  The emulation evaluates the same three fp16 products with the same a-priori scale: logits
+    and gradients agree with the three-term wiring to f32 round-off class; a wrong bound (overflow) or a stale buffer is an
+    error of order one or an inf."""
+    from smaat_unet_amd import ops as K
+    monkeypatch.setattr(K.policy, "f16_min_samples", 0)
+    monkeypatch.setattr(K.policy, "wgrad_recompute", "all")  # (the row-walking pair at this small size)
+    torch.manual_seed(13)
+    x = torch.from_numpy(O_precip(2, 12, 32, 64))
+    y = torch.rand(2, 32, 64) * 0.3
+    m = S.SmaAt_UNet(12, 1).train()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    res, calls = {}, {}
+    for on in (False, True):
+        monkeypatch.setattr(K.policy, "fwd_rows_h", on)
+        K.invalidate_weight_images()
+        m.load_state_dict(sd)
+        m.zero_grad(set_to_none=True)
+
+        def step():
+            out = m(x)
+            (torch.nn.functional.mse_loss(out.squeeze(1), y, reduction="sum") / 2).backward()
+            res[on] = (out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()})
+        calls[on] = _recorded_calls(step)
+    c0, c1 = calls[False], calls[True]
+    n_rows = c0.get("smaat_dsconv_fwd_rows_amax", 0)
+    assert n_rows >= 3 and not any(k in c0 for k in ("smaat_dsconv_fwd_rows_h", "smaat_cbam_apply_amax", "smaat_upsample2x_fwd_amax")), c0
+    # (inc.1 stays on the three-term kernel HERE: with the recompute policy forced on every layer the stem inc.0 runs the fused
+    # tile kernel, which leaves no max |y|; under the default policy it runs smaat_dw3x3_fwd_amax + the GEMM and inc.1 follows)
+    assert c1.get("smaat_dsconv_fwd_rows_h", 0) == n_rows - 1 >= 3 and c1.get("smaat_dsconv_fwd_rows_amax", 0) == 1, c1
+    assert c1.get("smaat_cbam_apply_amax", 0) >= 1 and c1.get("smaat_upsample2x_fwd_amax", 0) >= 1, c1
+    (o0, g0), (o1, g1) = res[False], res[True]
+    assert torch.isfinite(o1).all() and rel(o1.numpy(), o0.numpy()) < 3e-5
+    f0 = torch.cat([g.flatten() for g in g0.values()])
+    f1 = torch.cat([g1[k].flatten() for k in g0])
+    assert rel(f1.numpy(), f0.numpy()) < 1e-2  # (ReLU decisions at round-off level: see test_f16_split_wiring_...)
+    # the side table holds no dead entries once the step's tensors are gone
+    del res, o0, o1, g0, g1
+    import gc
+    gc.collect()
+    assert all(e[0]() is not None for e in K._X_AMAX.values())
+
+
+def test_x_amax_side_table_is_invalidated_by_writes_and_object_reuse():
+    """ops._X_AMAX: an entry is valid for the tensor OBJECT it was noted for, at the version it was noted at, and only when its
+    channel ranges cover the tensor"""
+    from smaat_unet_amd import ops as K
+    t = torch.zeros(2, 6, 4, 4)
+    b1, b2 = torch.zeros(4, dtype=torch.int32), torch.zeros(4, dtype=torch.int32)
+    K._note_x_amax(t, 0, 4, b1)
+    assert K._x_amax_of(t) is None  # channels 4, 5 not covered
+    K._note_x_amax(t, 4, 6, b2, extend=True)
+    got = K._x_amax_of(t)
+    assert got is not None and got[0] is b1 and got[1] is b2
+    t.add_(1.0)  # anything else that writes the tensor
+    assert K._x_amax_of(t) is None and K._x_amax_entry(t) is None
+    u = torch.zeros(2, 6, 4, 4)
+    K._note_x_amax(u, 0, 6, b1)
+    assert K._x_amax_of(u) == (b1, None)
+    key = id(u)
+    del u
+    assert key not in K._X_AMAX  # (the weak reference's callback)
+    v = t.view(2, 6, 16)
+    assert K._x_amax_of(v) is None  # (another object)
+
+
 def test_attention_backward_three_pass_route(monkeypatch):
     """round 5: the attention backward runs gate+ds | ds2 | apply (+ the MaxPool2d backward at the encoder levels, where the
     level output feeds both) and writes dx once, on the channel index map the forward's pooling kernel leaves; same gradients

@@ -59,7 +59,9 @@ def test_row_walking_kernels_do_not_drain_their_prefetch_queue():
     the loop, once per iteration, in all but two instantiations: the queue was emptied every chunk.  The kernels now use those
     values once before the first asm load; no loop of theirs may contain a full drain -- which also means no instantiation may
     spill (scratch reloads wait with vmcnt(0)): the f32 two-channel build of the fused forward did until its third weight
-    plane moved to LDS and its store addresses to scalar row pointers."""
+    plane moved to LDS and its store addresses to scalar row pointers.
+    (Round 6: loops laid out BEFORE the function's first inline-asm load are not counted -- the two-term fused forward bounds
+    |y| in a prologue whose loops read the depthwise weights with ordinary loads; nothing is in flight there to be drained.)"""
     import re
     import subprocess
     import tempfile
@@ -69,20 +71,26 @@ def test_row_walking_kernels_do_not_drain_their_prefetch_queue():
                             "--cuda-device-only", os.path.join(ROOT, "smaat_unet_amd", "csrc", src), "-o", f.name],
                            check=True, capture_output=True)
             asm = open(f.name).read()
-        fn, inloop, drains, seen = None, False, {}, 0
+        fn, inloop, drains, seen, in_asm, asm_load = None, False, {}, 0, False, False
         for ln in asm.splitlines():
             m = re.match(r"^(_Z\w+):", ln)
             if m:
-                fn, inloop = m.group(1), False
+                fn, inloop, in_asm, asm_load = m.group(1), False, False, False
                 drains[fn] = 0
                 continue
+            if "#ASMSTART" in ln:
+                in_asm = True
+            elif "#ASMEND" in ln:
+                in_asm = False
+            elif in_asm and re.search(r"\b(global|buffer)_load_", ln):
+                asm_load = True
             if ln.startswith(".Lfunc_end"):
                 fn = None
             if fn is None:
                 continue
             if re.match(r"^\.LBB\d+_\d+:", ln) or re.match(r"^; %bb\.\d+:", ln):
                 inloop = "in Loop" in ln or "Loop Header" in ln
-            if inloop and "s_waitcnt vmcnt(0)" in ln:
+            if inloop and asm_load and "s_waitcnt vmcnt(0)" in ln:
                 drains[fn] += 1
         for fn, n in drains.items():
             if "k_dsconv_wgrad_split" in fn or "k_dsconv_rows_fwd" in fn:

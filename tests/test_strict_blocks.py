@@ -137,9 +137,14 @@ def test_strict_rows_blocks_gpu(ops_strict_rows, tag, f16, monkeypatch):
         if os.path.isdir("gpurun_out"):
             with open(f"gpurun_out/strict_{tag}_f16{int(f16)}.json", "w") as f:
                 json.dump(report, f, indent=1, default=float)
-    fwd = "smaat_dsconv_fwd_rows_amax" if f16 else "smaat_dsconv_fwd_rows"      # (f16: + the maximum of the depthwise output)
+    # f16: + the maximum of the depthwise output; since round 6 the SECOND half runs the forward GEMM itself on the two-term split
+    # (smaat_dsconv_fwd_rows_h, bound of |z1| through the first half's weight), the first half -- a block input nobody left a
+    # maximum for -- the three-term kernel
+    n_fwd = (seen.count("smaat_dsconv_fwd_rows_amax") + seen.count("smaat_dsconv_fwd_rows_h")) if f16 else seen.count("smaat_dsconv_fwd_rows")
     wg = "smaat_dsconv_wgrad_split_h" if f16 else "smaat_dsconv_wgrad_split"    # (f16: the recompute kernel on the fp16 split)
-    assert seen.count(fwd) == 2 and seen.count(wg) == 2, sorted(set(seen))
+    assert n_fwd == 2 and seen.count(wg) == 2, sorted(set(seen))
+    if f16 and _ops.policy.fwd_rows_h:
+        assert seen.count("smaat_dsconv_fwd_rows_h") == 1, sorted(set(seen))
     # the data gradient: the fp16-split GEMM, or (ops.policy.fused_bwd, round 6) the fused backward that forms dY on chip
     assert ("smaat_pointwise_fwd_split_h" in seen or "smaat_dsconv_bwd_rows_h" in seen) == f16
 
