@@ -237,7 +237,8 @@ def side_roofline(summ, dtype):
     """dominant entry-point class of a profiled pair of steps -> roofline record (bound, achieved, peak, frac, traffic).
     bf16 storage: every class is HBM-bound; f32: the split GEMMs are priced on the 16-bit matrix pipe
     (executed = 3 fp16 or 6 bf16 MFMAs per product), everything else on HBM."""
-    gemm3 = ("smaat_pointwise_fwd_split_h", "smaat_pointwise_fwd_split_k_h", "smaat_pointwise_wgrad_h", "smaat_dsconv_wgrad_split_h")
+    gemm3 = ("smaat_pointwise_fwd_split_h", "smaat_pointwise_fwd_split_k_h", "smaat_pointwise_wgrad_h", "smaat_dsconv_wgrad_split_h",
+             "smaat_dsconv_fwd_rows_h")
     gemm6 = ("smaat_pointwise_fwd_split", "smaat_pointwise_wgrad", "smaat_dsconv_fwd_rows", "smaat_dsconv_fwd_rows_amax",
              "smaat_dsconv_wgrad_split", "smaat_dsconv_fwd_split")
     groups = {}
@@ -636,6 +637,11 @@ def main():
             klass(["smaat_dsconv_wgrad_split_h"], "mfma", PEAK_BF16_MFMA_TFLOPS, "TFLOP/s", 3.0,
                   "k_dsconv_wgrad_split<NT=2>: recompute weight gradient of the 288^2 layers on the two-term fp16 split (the "
                   "forward left the maximum of the depthwise output it formed)", pmc=("k_dsconv_wgrad_split<2,",), peak_name=F16),
+            klass(["smaat_dsconv_fwd_rows_h"], "mfma", PEAK_BF16_MFMA_TFLOPS, "TFLOP/s", 3.0,
+                  "k_dsconv_rows_fwd<NT=2>: fused depthwise 3x3 -> GEMM forward of the 288^2 layers on the two-term fp16 split (row-walking "
+                  "register window, register-resident weight fragments; the scale of the depthwise output from an a-priori bound: "
+                  "max |x| of the tensor's writers, or through the previous pointwise weight); no depthwise tensor in HBM",
+                  pmc=("k_dsconv_rows_fwd<2,",), peak_name=F16),
             klass(["smaat_dsconv_fwd_split", "smaat_dsconv_fwd_rows_amax"] + (["smaat_dsconv_fwd_rows"] if args.precision != "bf16" else []), "mfma",
                   PEAK_BF16_MFMA_TFLOPS, "TFLOP/s", nt,
                   "k_dsconv_rows_fwd: fused depthwise 3x3 -> split GEMM forward of the 288^2 layers (row-walking "

@@ -732,7 +732,7 @@ int launch_dsconv_rows(DsRowsArgs& a, int kpl, int x_dt, int z_dt, hipStream_t s
     if (a.x_amax || a.a_kexp) {  // two-term fp16 split: an fp16 weight image + the maximum of x
         if (!a.x_amax || !a.a_kexp) return -1;
         a.npl = 2;
-        return launch_dsr_sel<2, float, float>(a, st);
+        return launch_dsr_sel<2, float, float>(a, st);  // (hipcc packs the depthwise FMAs of this build into v_pk_fma_f32 by itself)
     }
     a.npl = 3;
     if (split_mode() == 1) return launch_dsr_sel<1, float, float>(a, st);
