@@ -311,7 +311,11 @@ def side_config(kind, dev, steps=24, warmup=6):
         what = ("SmaAt-UNet 3->21ch (PascalVOC head), 256x256 synthetic images, batch=16 fp32, fwd+CrossEntropy+bwd+Adam "
                 "(BASELINE.json configs[4])")
         dtype = "f32"
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, foreach=True)
+    if os.environ.get("SMAAT_ADAM", "one") == "one":  # (as the headline configuration)
+        from smaat_unet_amd.optim import Adam as OneLaunchAdam
+        opt = OneLaunchAdam(model.parameters(), lr=1e-3)
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, foreach=True)
 
     def step():
         loss = lossf(model(x))
@@ -452,10 +456,17 @@ def main():
         model.set_precision("bf16")
     ddp = FlatGradAllReduce(model, world_size=world)  # persistent flat gradient buffer, bucketed async all-reduce
     ddp.broadcast_parameters()
-    # stock torch Adam; "fused" = torch's single-kernel multi-tensor implementation of the same update
-    adam_impl = os.environ.get("SMAAT_ADAM", "foreach")
-    opt = (torch.optim.Adam(model.parameters(), lr=1e-3, fused=True) if adam_impl == "fused"
-           else torch.optim.Adam(model.parameters(), lr=1e-3, foreach=True))
+    # Adam(lr 1e-3), reference models/regression_lightning.py:48.  "one" (default): smaat_unet_amd.optim.Adam -- torch.optim.Adam's
+    # multi-tensor update (same f32 expressions) in ONE launch over the 145 tensors; "foreach" / "fused": stock torch.optim.Adam
+    # (SURVEY 8 a14).  Interleaved on one box (profiles/r6/bench_ab_adam_r6t2.txt): one launch 27.92 / 27.90 ms, foreach 28.18 /
+    # 28.17, fused 28.40 / 28.56.
+    adam_impl = os.environ.get("SMAAT_ADAM", "one")
+    if adam_impl == "one":
+        from smaat_unet_amd.optim import Adam as OneLaunchAdam
+        opt = OneLaunchAdam(model.parameters(), lr=1e-3)
+    else:
+        opt = (torch.optim.Adam(model.parameters(), lr=1e-3, fused=True) if adam_impl == "fused"
+               else torch.optim.Adam(model.parameters(), lr=1e-3, foreach=True))
     if voc:  # ImageNet-normalised-like images, integer class maps
         g = torch.Generator().manual_seed(1234 + rank)
         x = torch.randn(args.batch, 3, args.size, args.size, generator=g).to(dev)
@@ -849,6 +860,10 @@ def main():
                                       "operand split with per-tensor power-of-two scales (3 MFMAs per product) where the operand "
                                       "maxima are at hand and the BatchNorm behind the GEMM averages >= 4096 samples, exact "
                                       "three-term bf16 split (6 MFMAs) elsewhere; f32-class error"),
+                       "optimizer": {"one": "smaat_unet_amd.optim.Adam(lr=1e-3): torch.optim.Adam's multi-tensor update (same "
+                                            "expressions in f32, default betas / eps) in one launch over all parameter tensors",
+                                     "foreach": "torch.optim.Adam(lr=1e-3, foreach=True)",
+                                     "fused": "torch.optim.Adam(lr=1e-3, fused=True)"}.get(adam_impl, adam_impl),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "final_loss": round(final_loss, 5)},
             "roofline": roof,

@@ -599,6 +599,22 @@ int smaat_precip_metrics_update(const float* preds, const float* target, long n,
                                 float threshold, int denormalize, void* ws, double* state_f64, long long* state_i64,
                                 void* stream);
 
+/* ---- Adam in one launch (round 6) -------------------------------------------------------------------------------------------
+ * reference: optim.Adam(self.parameters(), lr) -- models/regression_lightning.py:48, train_SmaAtUNet.py:182 (default betas, eps,
+ * no weight decay, no amsgrad); arithmetic of torch.optim.Adam's multi-tensor path, operation for operation in f32:
+ *   m = m + w1 (g - m);  v = v beta2 + w2 g g;  p = p + step_size * (m / (sqrt(v) / bc2_sqrt + eps))
+ * rows: DEVICE table [n][4] of 64-bit words {p, m, v, numel} (f32 tensors, dense); grads: HOST array of n device pointers (this
+ * step's gradients: autograd hands over fresh tensors each step, so they travel in the kernel arguments); blk2t [total_blocks],
+ * blk0 [n]: device int32 -- the row of block b and the first block of row t, smaat_adam_block_elems() elements per block;
+ * n <= smaat_adam_max_tensors() per call.  Scalars in double, formed by the caller exactly as torch/optim/adam.py forms them
+ * (Python floats): w1 = 1 - beta1, w2 = 1 - beta2, bc2_sqrt = (1 - beta2 ** t) ** 0.5, step_size = (lr / (1 - beta1 ** t)) * -1,
+ * rounded to f32 once.  variant: bits 1 / 2 / 4 = first moment / second moment / update contracted into one fma (which of them
+ * torch's own kernels contract is a property of its build; smaat_unet_amd/optim.py uses the combination its test found). */
+int smaat_adam_max_tensors(void);
+int smaat_adam_block_elems(void);
+int smaat_adam_step(const void* rows, const void* const* grads, const int* blk2t, const int* blk0, int n, int total_blocks, double w1,
+                    double beta2, double w2, double bc2_sqrt, double eps, double step_size, int variant, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,10 @@ int launch_cbam_spconv(const float*, const float*, int, int, int, int, float*, f
 int launch_cbam_gate(const float*, const float*, const float*, long, float*, hipStream_t);
 int launch_cbam_apply(const void*, long, const float*, const float*, void*, long, int, int, int, hipStream_t,
                       int dt = SMAAT_F32, unsigned* amax = nullptr);
+int adam_max_tensors();
+int adam_block_elems();
+int launch_adam_multi(const void*, const void* const*, const int*, const int*, int, int, double, double, double, double, double,
+                      double, int, hipStream_t);
 int launch_upsample2x_fwd_rows(const void*, long, void*, long, int, int, int, int, int, int, int, int, hipStream_t, int, unsigned*);
 int launch_cbam_eval_pool(const float*, long, const float*, const float*, const float*, const float*, const float*,
                           const float*, int, int, int, int, float*, float*, hipStream_t);
@@ -435,6 +439,18 @@ int smaat_cbam_gate(const float* conv, const float* scale, const float* shift, l
 int smaat_cbam_apply(const float* x, long x_bs, const float* s, const float* gate, float* out, long out_bs, int N,
                      int C, int P, void* stream) {
     return launch_cbam_apply(x, x_bs, s, gate, out, out_bs, N, C, P, ST);
+}
+/* Adam (reference models/regression_lightning.py:48): one launch over up to smaat_adam_max_tensors() parameter tensors.
+ * rows: device table [n][4] of 64-bit words {p, m, v, numel}; grads: HOST array of n device pointers (this step's gradients);
+ * blk2t [total_blocks] / blk0 [n]: device int32, block -> row and first block of a row (smaat_adam_block_elems() elements per
+ * block).  Scalars in double, formed by the caller exactly as torch/optim/adam.py forms them: w1 = 1 - beta1, w2 = 1 - beta2,
+ * bc2_sqrt = (1 - beta2 ** t) ** 0.5, step_size = (lr / (1 - beta1 ** t)) * -1.  variant: bit 1 / 2 / 4 = first moment /
+ * second moment / update as one fma (which of these torch's own kernels contract is a property of its build: the test finds it) */
+int smaat_adam_max_tensors(void) { return adam_max_tensors(); }
+int smaat_adam_block_elems(void) { return adam_block_elems(); }
+int smaat_adam_step(const void* rows, const void* const* grads, const int* blk2t, const int* blk0, int n, int total_blocks, double w1,
+                    double beta2, double w2, double bc2_sqrt, double eps, double step_size, int variant, void* stream) {
+    return launch_adam_multi(rows, grads, blk2t, blk0, n, total_blocks, w1, beta2, w2, bc2_sqrt, eps, step_size, variant, ST);
 }
 int smaat_cbam_apply_amax(const float* x, long x_bs, const float* s, const float* gate, float* out, long out_bs, void* amax,
                           int N, int C, int P, void* stream) {

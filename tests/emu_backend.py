@@ -1394,6 +1394,44 @@ def _dsconv_fwd_rows_h(self, x, x_bs, in_scale, in_shift, w_dw, b_dw, x_amax, x_
     return 0
 
 
+ADAM_EPB, ADAM_MAX = 1024, 256
+
+
+def _adam_max_tensors(self):
+    return ADAM_MAX
+
+
+def _adam_block_elems(self):
+    return ADAM_EPB
+
+
+def _adam_step(self, rows, grads, blk2t, blk0, n, total_blocks, w1, beta2, w2, bc2_sqrt, eps, step_size, variant, stream):
+    """smaat_adam_step: torch.optim.Adam's multi-tensor arithmetic, operation for operation in float32 (the fma variants of the
+    device kernel differ from this by at most one rounding per expression: the CPU tests compare with a tolerance)"""
+    if n < 1 or n > ADAM_MAX or total_blocks < 1 or not bc2_sqrt > 0:
+        return -1
+    f = np.float32
+    tab = np.ctypeslib.as_array((ctypes.c_int64 * (4 * n)).from_address(int(rows))).reshape(n, 4)
+    b0 = i32(blk0, n)
+    b2t = i32(blk2t, total_blocks)
+    nb = 0
+    for t in range(n):
+        numel = int(tab[t, 3])
+        k = (numel + ADAM_EPB - 1) // ADAM_EPB
+        assert int(b0[t]) == nb and np.all(b2t[nb:nb + k] == t), "block tables do not describe the rows"
+        nb += k
+        pp, mm, vv = f32(int(tab[t, 0]), numel), f32(int(tab[t, 1]), numel), f32(int(tab[t, 2]), numel)
+        g = f32(int(grads[t]), numel)
+        m = (mm + f(w1) * (g - mm)).astype(f)
+        v = ((vv * f(beta2)).astype(f) + ((f(w2) * g).astype(f) * g).astype(f)).astype(f)
+        d = ((np.sqrt(v).astype(f) / f(bc2_sqrt)).astype(f) + f(eps)).astype(f)
+        pp[:] = (pp + (f(step_size) * (m / d).astype(f)).astype(f)).astype(f)
+        mm[:] = m
+        vv[:] = v
+    assert nb == total_blocks
+    return 0
+
+
 def _cbam_apply_amax(self, x, x_bs, s, gate, out, out_bs, amax, N, C, P, stream):
     rc = self.smaat_cbam_apply(x, x_bs, s, gate, out, out_bs, N, C, P, stream)
     if rc == 0:
@@ -1413,6 +1451,8 @@ def _upsample2x_fwd_amax(self, x, x_bs, out, out_bs, amax, N, C, H, W, Ho, Wo, p
 for _name, _fn in (("smaat_dsconv_wgrad_split_t", _t_dsconv_wgrad_split), ("smaat_dsconv_rows_ok", _t_dsconv_rows_ok), ("smaat_dsconv_rows_num_slots", _t_dsconv_rows_num_slots),
                    ("smaat_dsconv_fwd_rows", _t_dsconv_fwd_rows), ("smaat_dsconv_fwd_rows_amax", _dsconv_fwd_rows_amax),
                    ("smaat_dsconv_fwd_rows_h", _dsconv_fwd_rows_h), ("smaat_cbam_apply_amax", _cbam_apply_amax),
+                   ("smaat_adam_max_tensors", _adam_max_tensors), ("smaat_adam_block_elems", _adam_block_elems),
+                   ("smaat_adam_step", _adam_step),
                    ("smaat_upsample2x_fwd_amax", _upsample2x_fwd_amax),
                    ("smaat_dsconv_wgrad_split_h", _dsconv_wgrad_split_h)):
     setattr(EmuLib, _name, _fn)

@@ -732,15 +732,18 @@ def test_recompute_policy_wiring_equals_the_kept_depthwise_output(mode, monkeypa
     assert (big(s0, 128), big(s0, 256)) == (3, 1) and (big(s1, 128), big(s1, 256)) == (1, 0), (s0, s1)
 
 
+@pytest.mark.parametrize("which", ["sgd", "adam_one_launch"])
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
-def test_weight_images_are_refreshed_in_one_launch_per_optimizer_step(mode, monkeypatch):
+def test_weight_images_are_refreshed_in_one_launch_per_optimizer_step(mode, which, monkeypatch):
     """Round 4: the operand images of all pointwise weights (and of their transposes, for the data gradients) go stale
     together, at the optimizer step; the first use after it refreshes every registered image in ONE launch
     (ops._weight_planes / smaat_weight_planes_multi).  Three training steps with the cache must be what three steps without
     it are (bit for bit on the emulated C ABI), and steps 2 and 3 must each issue exactly one refresh launch that covers all
-    images and no single-matrix launches."""
+    images and no single-matrix launches.  Round 6: the same with smaat_unet_amd.optim.Adam, which updates the parameters
+    through raw pointers and reports the modification with torch.autograd.graph.increment_version."""
     import contextlib
     from smaat_unet_amd import _lib as L_, ops as _ops
+    from smaat_unet_amd.optim import Adam as OneLaunchAdam
 
     def run(cache):
         monkeypatch.setattr(_ops.policy, "plane_cache", cache)
@@ -748,7 +751,7 @@ def test_weight_images_are_refreshed_in_one_launch_per_optimizer_step(mode, monk
         _ops._PLANES_TABLE.clear()
         torch.manual_seed(0)
         model = S.SmaAt_UNet(4, 2, kernels_per_layer=2).train()
-        opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+        opt = torch.optim.SGD(model.parameters(), lr=1e-2) if which == "sgd" else OneLaunchAdam(model.parameters(), lr=1e-2)
         x, t = torch.randn(2, 4, 32, 32), torch.randn(2, 2, 32, 32)
         lib = L_.get()
         calls = []
