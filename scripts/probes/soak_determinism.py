@@ -19,7 +19,11 @@ B, H = int(os.environ.get("SOAK_BATCH", "16")), int(os.environ.get("SOAK_SIZE", 
 def run():
     torch.manual_seed(0)
     m = S.SmaAt_UNet(12, 1).to(dev).train()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3, foreach=True)
+    if os.environ.get("SMAAT_ADAM", "one") == "one":  # (bench.py's default since round 6)
+        from smaat_unet_amd.optim import Adam as OneLaunchAdam
+        opt = OneLaunchAdam(m.parameters(), lr=1e-3)
+    else:
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, foreach=True)
     g = torch.Generator().manual_seed(7)
     losses = []
     for i in range(steps):
