@@ -11,7 +11,8 @@ tensor; `smaat_adam_step` reads p, g, m, v once and writes p, m, v once, in one 
 `smaat_adam_max_tensors()` tensors).  The moments of a group live in two flat buffers (the state entries are views).
 
 No CPU fallback: parameters, gradients and state are f32 CUDA tensors (the CPU test suite runs the host logic against the
-numpy twin of the library, tests/emu_backend.py)."""
+numpy twin of the library, tests/emu_backend.py).  Not capturable into a hipGraph (like torch.optim.Adam without
+`capturable=True`): the step count lives on the host and the gradient pointers of the step are kernel arguments."""
 from __future__ import annotations
 
 import ctypes
@@ -20,8 +21,10 @@ import torch
 
 from . import _lib
 
-# which of the three update expressions torch's own foreach kernels evaluate as one fma (a property of how that build was
-# compiled: `-ffp-contract`); found by tests/test_gpu_kernels.py::test_adam_one_launch_matches_torch_adam bit for bit
+# which of the three update expressions are evaluated as one fma (smaat_adam_step's `variant` bits).  torch's own three
+# implementations of this update (for-loop, foreach, fused) are compiled with contraction on and agree with each other to one
+# rounding, not bit for bit; all-contracted is the variant closest to foreach (scripts/probes/adam_variant_probe.py,
+# profiles/r6/adam_variant_probe_r6s.txt: 52 of 145 tensors bit-equal after 12 steps, max relative distance 7e-8)
 TORCH_CONTRACTION_VARIANT = 7
 
 
@@ -50,6 +53,8 @@ class Adam(torch.optim.Optimizer):
         for p in plist:
             if p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
                 raise TypeError("smaat_unet_amd.optim.Adam: parameters of a group must be contiguous float32 tensors on one device")
+        if not plist[0].is_cuda and not _lib._ALLOW_HOST_POINTERS:
+            raise TypeError("smaat_unet_amd.optim.Adam updates GPU tensors (there is no CPU path); use torch.optim.Adam on the CPU")
         # moments: flat buffers, one slice per parameter (16-byte aligned slices: float4 accesses), adopted from existing state
         offs, total = [], 0
         for p in plist:

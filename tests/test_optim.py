@@ -102,6 +102,14 @@ def test_adam_more_tensors_than_one_launch_takes_and_a_changing_set_of_gradients
         o.step()
 
 
+def test_adam_refuses_cpu_tensors_without_the_emulation():
+    p = [torch.nn.Parameter(torch.zeros(3))]
+    o = Adam(p)
+    p[0].grad = torch.ones(3)
+    with pytest.raises(TypeError, match="no CPU path"):
+        o.step()
+
+
 def test_adam_refuses_what_it_does_not_implement(emu):
     p = [torch.nn.Parameter(torch.zeros(3))]
     for kw in (dict(weight_decay=1e-2), dict(amsgrad=True), dict(maximize=True)):
