@@ -68,6 +68,19 @@ def _worker(rank, world, port, out_dir):
         np.save(os.path.join(out_dir, "buckets.npy"), np.array([(a, b) for a, b, _ in ddp._buckets], np.int64))
     np.save(os.path.join(out_dir, f"flat{rank}.npy"), flat.numpy())
     np.save(os.path.join(out_dir, f"w{rank}.npy"), model.outc.conv.weight.detach().numpy())
+    # the optimizer step of bench.py on the reduced gradients (views of the flat buffer, not 16-byte aligned in general):
+    # smaat_unet_amd.optim.Adam against torch.optim.Adam on a copy; every rank must end with the same parameters
+    from smaat_unet_amd.optim import Adam as OneLaunchAdam
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in model.parameters()]
+    for q, p in zip(ref, model.parameters()):
+        q.grad = p.grad.detach().clone()
+    torch.optim.Adam(ref, lr=1e-3, foreach=True).step()
+    OneLaunchAdam(model.parameters(), lr=1e-3).step()
+    worst = max(float((p.detach() - q.detach()).abs().max() / q.detach().abs().max().clamp(min=1e-30))
+                for p, q in zip(model.parameters(), ref))
+    assert worst < 3e-7, worst
+    np.save(os.path.join(out_dir, f"stepped{rank}.npy"),
+            torch.cat([p.detach().reshape(-1)[:64] for p in model.parameters()]).numpy())
     # a rank-local step (bench.py's profiling pass) must not touch the process group
     ddp.active = False
     ddp.zero_grad()
@@ -88,6 +101,7 @@ def test_flat_allreduce_world2(tmp_path, overlap, monkeypatch):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     f0, f1 = np.load(tmp_path / "flat0.npy"), np.load(tmp_path / "flat1.npy")
     assert np.array_equal(f0, f1)  # every rank holds the same averaged gradient
+    assert np.array_equal(np.load(tmp_path / "stepped0.npy"), np.load(tmp_path / "stepped1.npy"))  # ... and the same parameters after Adam
     P = oparams.make_smaat_params(12, 1, 2, 16, 0)
     assert np.array_equal(np.load(tmp_path / "w1.npy"), P["outc.conv.weight"])  # broadcast worked
     # oracle: mean of the per-shard gradients (fresh BN statistics per shard)

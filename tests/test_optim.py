@@ -102,6 +102,32 @@ def test_adam_more_tensors_than_one_launch_takes_and_a_changing_set_of_gradients
         o.step()
 
 
+def test_training_a_network_with_the_one_launch_adam_tracks_torch_adam(emu):
+    """four training steps of SmaAt_UNet through the (emulated) library: the losses with smaat_unet_amd.optim.Adam follow those with
+    torch.optim.Adam to round-off -- the parameters are written through raw pointers, so this also pins that everything which
+    watches version counters (the weight-image cache of ops.py) sees the update"""
+    from smaat_unet_amd import ops as K
+    from smaat_unet_amd.SmaAt_UNet import SmaAt_UNet
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.rand(2, 12, 32, 32, generator=g), torch.rand(2, 32, 32, generator=g) * 0.3
+
+    def run(make):
+        torch.manual_seed(1)
+        m = SmaAt_UNet(12, 1).train()
+        K.invalidate_weight_images()
+        opt, losses = make(m.parameters()), []
+        for _ in range(4):
+            loss = torch.nn.functional.mse_loss(m(x).squeeze(1), y, reduction="sum") / 2
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        return losses
+    a, b = run(lambda ps: Adam(ps, lr=1e-2)), run(lambda ps: torch.optim.Adam(ps, lr=1e-2, foreach=True))
+    assert a[0] == b[0] and a[1] != a[0]
+    assert all(abs(u - v) <= 2e-5 * abs(v) for u, v in zip(a, b)), (a, b)
+
+
 def test_adam_refuses_cpu_tensors_without_the_emulation():
     p = [torch.nn.Parameter(torch.zeros(3))]
     o = Adam(p)
