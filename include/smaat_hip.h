@@ -615,6 +615,17 @@ int smaat_adam_block_elems(void);
 int smaat_adam_step(const void* rows, const void* const* grads, const int* blk2t, const int* blk0, int n, int total_blocks, double w1,
                     double beta2, double w2, double bc2_sqrt, double eps, double step_size, int variant, void* stream);
 
+/* ---- PROTOTYPE (round 6): pointwise GEMM on pre-split fp16 planes of both operands -- measurement only ---------------------
+ * out[n][m][p] = 2^-ksum * sum_c (Ah Xg + Ag Xh + Ah Xh) + bias[m]: the arithmetic of smaat_pointwise_fwd_split_h (reference
+ * models/layers.py:45,49) with NO operand split inside the kernel: x_planes [N][2][Cin][H*W] fp16 (h, g of x * 2^kx; x_bs / xp_bs =
+ * elements between images / planes), a_planes [2][Cin/16][M][16] fp16 (h, g of w * 2^ka; ap_bs elements between the planes),
+ * ksum = ka + kx.  LDS-DMA + transposed LDS reads, no VALU in the loop (csrc/h2gemm.hip).  cfg 0 / 1 / 2: stage depth x resident
+ * workgroups.  Cin % 32 == 0, M > 64, (H*W) % 8 == 0; -2 otherwise.  Nothing in the training step produces activation planes, so
+ * nothing selects this entry: scripts/probes/h2_gemm_probe.py measures what such a GEMM reaches (NOTEBOOK 4.9). */
+int smaat_pointwise_fwd_h2_proto(const void* x_planes, long x_bs, long xp_bs, const void* a_planes, long ap_bs, const float* bias,
+                                 float* out, long out_bs, float* part, int N, int Cin, int M, int H, int W, int ksum, int cfg,
+                                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

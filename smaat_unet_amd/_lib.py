@@ -110,6 +110,7 @@ SIGNATURES = {
     "smaat_dsconv_fwd_rows_amax": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "smaat_dsconv_wgrad_split_h": [_P, _L, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "smaat_dsconv_fwd_rows_h": [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "smaat_pointwise_fwd_h2_proto": [_P, _L, _L, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "smaat_adam_max_tensors": [],
     "smaat_adam_block_elems": [],
     "smaat_adam_step": [_P, _P, _P, _P, _I, _I, _D, _D, _D, _D, _D, _D, _I, _P],

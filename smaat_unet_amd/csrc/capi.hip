@@ -79,6 +79,7 @@ int launch_cbam_spconv(const float*, const float*, int, int, int, int, float*, f
 int launch_cbam_gate(const float*, const float*, const float*, long, float*, hipStream_t);
 int launch_cbam_apply(const void*, long, const float*, const float*, void*, long, int, int, int, hipStream_t,
                       int dt = SMAAT_F32, unsigned* amax = nullptr);
+int pw_h2_proto(const void*, long, long, const void*, long, const float*, float*, long, float*, int, int, int, int, int, int, hipStream_t);
 int adam_max_tensors();
 int adam_block_elems();
 int launch_adam_multi(const void*, const void* const*, const int*, const int*, int, int, double, double, double, double, double,
@@ -446,6 +447,12 @@ int smaat_cbam_apply(const float* x, long x_bs, const float* s, const float* gat
  * block).  Scalars in double, formed by the caller exactly as torch/optim/adam.py forms them: w1 = 1 - beta1, w2 = 1 - beta2,
  * bc2_sqrt = (1 - beta2 ** t) ** 0.5, step_size = (lr / (1 - beta1 ** t)) * -1.  variant: bit 1 / 2 / 4 = first moment /
  * second moment / update as one fma (which of these torch's own kernels contract is a property of its build: the test finds it) */
+/* PROTOTYPE, not used by the step (h2gemm.hip): the pointwise GEMM on pre-split fp16 planes of BOTH operands */
+int smaat_pointwise_fwd_h2_proto(const void* x_planes, long x_bs, long xp_bs, const void* a_planes, long ap_bs, const float* bias,
+                                 float* out, long out_bs, float* part, int N, int Cin, int M, int H, int W, int ksum, int cfg,
+                                 void* stream) {
+    return pw_h2_proto(x_planes, x_bs, xp_bs, a_planes, ap_bs, bias, out, out_bs, part, N, Cin, M, H * W, ksum, cfg, ST);
+}
 int smaat_adam_max_tensors(void) { return adam_max_tensors(); }
 int smaat_adam_block_elems(void) { return adam_block_elems(); }
 int smaat_adam_step(const void* rows, const void* const* grads, const int* blk2t, const int* blk0, int n, int total_blocks, double w1,

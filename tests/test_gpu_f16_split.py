@@ -834,3 +834,47 @@ def test_soak_rows_forward_h(case):
         assert L.smaat_dsconv_fwd_rows_h(P(x), Cin * H * W, P(sc), P(sh), P(w_dw), P(b_dw), P(ax), None, P(pw), P(pb), prev_K, P(plh),
                                          P(b_pw), P(z), Cout * H * W, P(part), P(ay), None, N, Cin, 2, Cout, H, W, stream(dev)) == 0
     _soak(fwd, [z, part], "k_dsconv_rows_fwd<NT=2>")
+
+
+# ------------------------------------------------------------ round 6: the prototype GEMM on pre-split planes (measurement only)
+@pytest.mark.parametrize("shape", [(2, 64, 128, 16, 32), (1, 512, 256, 12, 24), (3, 32, 200, 8, 16)])
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+def test_pointwise_fwd_h2_prototype_equals_the_shipped_two_term_gemm(shape, cfg):
+    """smaat_pointwise_fwd_h2_proto (csrc/h2gemm.hip; not selected by ops.py): the same three fp16 products as
+    smaat_pointwise_fwd_split_h on operand planes split OUTSIDE the kernel -- f32 round-off class against it and against fp64"""
+    L, dev = _lib.get(), DEV
+    N, C, M, H, W = shape
+    Pn = H * W
+    x, w, b = T(rnd(1, N, C, Pn), dev), T(rnd(2, M, C, scale=0.1), dev), T(rnd(3, M), dev)
+    kx, ka = f16_kexp(_bits(float(x.abs().max()))), f16_kexp(_bits(float(w.abs().max())))
+
+    def planes(t, k):
+        ts = t * (2.0 ** k)
+        h = ts.half()
+        return h, (ts - h.float()).half()
+    xh, xg = planes(x, kx)
+    wh, wg = planes(w, ka)
+    xp = torch.stack([xh, xg], dim=1).contiguous()
+    ap = torch.stack([t.view(M, C // 16, 16).permute(1, 0, 2).contiguous() for t in (wh, wg)], dim=0).contiguous()
+    z = torch.full((N, M, Pn), float("nan"), device=dev)
+    assert L.smaat_pointwise_fwd_h2_proto(P(xp), 2 * C * Pn, C * Pn, P(ap), (C // 16) * M * 16, P(b), P(z), M * Pn, None, N, C, M, H, W,
+                                          ka + kx, cfg, stream(dev)) == 0
+    plh = _h_image(L, dev, w)
+    z0 = torch.empty(N, M, Pn, device=dev)
+    assert L.smaat_pointwise_fwd_split_h(P(x), C * Pn, P(_publish(x)), P(plh), P(b), P(z0), M * Pn, None, N, C, M, H, W, stream(dev)) == 0
+    torch.cuda.synchronize()
+    zd = torch.einsum("mc,ncp->nmp", w.double(), x.double()) + b.double().view(1, -1, 1)
+    assert float((z - z0).abs().max() / z0.abs().max()) < 2e-6
+    assert float((z.double() - zd).norm() / zd.norm()) < 6e-7
+
+
+def test_pointwise_fwd_h2_prototype_refusals():
+    L, dev = _lib.get(), DEV
+    t = torch.zeros(1 << 16, dtype=torch.float16, device=dev)
+    o = torch.zeros(1 << 16, device=dev)
+    call = lambda C, M, H, W, cfg: L.smaat_pointwise_fwd_h2_proto(P(t), 2 * C * H * W, C * H * W, P(t), (C // 16) * M * 16, None, P(o), M * H * W,  # noqa: E731
+                                                                  None, 1, C, M, H, W, 0, cfg, stream(dev))
+    assert call(32, 64, 8, 16, 2) == -2    # M <= 64
+    assert call(24, 128, 8, 16, 2) == -2   # Cin % 32
+    assert call(32, 128, 3, 6, 2) == -2    # P % 8
+    assert call(32, 128, 8, 16, 7) == -1   # configuration
